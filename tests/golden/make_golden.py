@@ -1,0 +1,506 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by RUNNING the reference.
+
+Run in the build container only (it needs /root/reference, which never travels):
+
+    python tests/golden/make_golden.py
+
+It imports the reference's own modules from /root/reference/objnerf (render_rays, embedding,
+model, loss directly; utils, trainer, vmap after stubbing the GUI / mesh packages that are not
+installed with MagicMock -- SURVEY.md section 8(c)), feeds them seeded inputs and stores inputs
+and outputs as small .npz files.  Only data is written: no reference source is copied.
+
+Fixtures:
+  g1_embed   UniDirsEmbed.forward                         (embedding.py:46-55)
+  g2_mlp     OccupancyMap.forward, H=32 and H=128         (model.py:61-103)
+  g3_render  occupancy_activation / _to_termination / render, batch and non-batch
+  g4_loss    step_batch_loss incl. both early-return outcomes (loss.py, render_rays.py:85-117)
+  g5_step    one full vmap training iteration: loss + grads of all stacked tensors
+  g6_adamw   3 iterations with torch.optim.AdamW(lr 1e-3, wd 0.013): params after each step
+  g7_sample  sceneObject.sample_3d_points / get_training_samples with recorded random draws
+  g8_box     ray_box_intersection, rays_dir_cache, origin_dirs_W
+  g9_psnr    analytic ellipsoid scene, 300 iterations: loss curve + PSNR on held-out rays
+  g10_bg     background-shaped (K=1, H=128, S=14) iteration: loss + grads
+"""
+import os
+import sys
+import types
+from unittest.mock import MagicMock
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference/objnerf"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+for name in ["cv2", "imgviz", "open3d", "trimesh", "bidict", "skimage", "skimage.measure",
+             "matplotlib", "matplotlib.pyplot"]:
+    if name not in sys.modules:
+        sys.modules[name] = MagicMock()
+
+import embedding as ref_embedding      # noqa: E402
+import model as ref_model              # noqa: E402
+import render_rays as ref_rr           # noqa: E402
+import loss as ref_loss                # noqa: E402
+import utils as ref_utils              # noqa: E402
+import trainer as ref_trainer          # noqa: E402
+import vmap as ref_vmap                # noqa: E402
+from functorch import vmap             # noqa: E402
+
+from openobj_amd import synthetic      # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if torch.is_tensor(v):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def make_cfg(hidden=32, scale=2.0, clip=512):
+    return types.SimpleNamespace(obj_id=1, training_device="cpu", hidden_feature_size=hidden,
+                                 clip_point_feature_size=clip, obj_scale=scale, n_unidir_funcs=5,
+                                 W=1200, H=680)
+
+
+def make_trainers(K, seed, hidden=32, scale=2.0, perturb_B=True):
+    torch.manual_seed(seed)
+    ts = [ref_trainer.Trainer(make_cfg(hidden, scale)) for _ in range(K)]
+    if perturb_B:
+        g = torch.Generator().manual_seed(seed + 1)
+        for t in ts:
+            with torch.no_grad():
+                t.pe.B_layer.weight.add_(0.02 * torch.randn(21, 3, generator=g))
+    return ts
+
+
+def stack_params(ts):
+    fc = [torch.stack([list(t.fc_occ_map.parameters())[i].detach() for t in ts]) for i in range(18)]
+    B = torch.stack([t.pe.B_layer.weight.detach() for t in ts])
+    return fc, B
+
+
+def to_t(d, keys):
+    return [torch.from_numpy(d[k]) for k in keys]
+
+
+# ------------------------------------------------------------------------------------------- G1
+def g1():
+    torch.manual_seed(11)
+    out = {}
+    for scale in (2.0, 5.0):
+        pe = ref_embedding.UniDirsEmbed(max_deg=5, scale=scale)
+        with torch.no_grad():
+            pe.B_layer.weight.add_(0.05 * torch.randn(21, 3))
+        pts = (torch.rand(2, 5, 7, 3) * 8.0 - 4.0)
+        emb = pe(pts)
+        tag = f"s{int(scale)}"
+        out[f"pts_{tag}"] = pts
+        out[f"B_{tag}"] = pe.B_layer.weight
+        out[f"emb_{tag}"] = emb
+    save("g1_embed", **out)
+
+
+# ------------------------------------------------------------------------------------------- G2
+def g2():
+    out = {}
+    for H in (32, 128):
+        torch.manual_seed(20 + H)
+        m = ref_model.OccupancyMap(87, 42, hidden_size=H, clip_size=512)
+        m.apply(ref_model.init_weights)
+        emb = torch.cat([torch.rand(6, 9, 3) * 2 - 1, torch.sin(torch.randn(6, 9, 126) * 3)], -1)
+        alpha, color, clip = m(emb)
+        for i, p in enumerate(m.parameters()):
+            out[f"h{H}_p{i}"] = p
+        out[f"h{H}_emb"] = emb
+        out[f"h{H}_alpha"] = alpha
+        out[f"h{H}_color"] = color
+        out[f"h{H}_clip"] = clip
+    save("g2_mlp", **out)
+
+
+# ------------------------------------------------------------------------------------------- G3
+def g3():
+    torch.manual_seed(3)
+    K, R, S, C = 2, 6, 10, 512
+    alpha = torch.randn(K, R, S) * 6.0
+    alpha[0, 0, 3] = 40.0            # saturated occupancy -> free prob 1e-10
+    color = torch.rand(K, R, S, 3)
+    clip = torch.randn(K, R, S, C)
+    z = torch.sort(torch.rand(K, R, S) * 5.0, dim=-1).values
+    occ = ref_rr.occupancy_activation(alpha)
+    term_b = ref_rr.occupancy_to_termination(occ, is_batch=True)
+    term_nb = ref_rr.occupancy_to_termination(occ[0], is_batch=False)
+    depth = ref_rr.render(term_b, z)
+    var = ref_rr.render(term_b, (z - depth[..., None]) ** 2)
+    rgb = ref_rr.render(term_b[..., None], color, dim=-2)
+    feat = ref_rr.render(term_b[..., None], clip, dim=-2)
+    opacity = term_b.sum(-1)
+    save("g3_render", alpha=alpha, color=color, clip=clip, z=z, occ=occ, term_b=term_b,
+         term_nb=term_nb, depth=depth, var=var, rgb=rgb, feat=feat, opacity=opacity)
+
+
+# ------------------------------------------------------------------------------------------- G4
+def g4():
+    torch.manual_seed(4)
+    K, R, S, C = 3, 8, 10, 512
+    out = {}
+    alpha = (torch.randn(K, R, S, 1) * 0.4)
+    color = torch.rand(K, R, S, 3)
+    clip = torch.randn(K, R, S, C)
+    z = torch.sort(torch.rand(K, R, S) * 5.0 + 0.2, dim=-1).values
+    gt_depth = torch.rand(K, R) * 5.0
+    gt_rgb = torch.rand(K, R, 3)
+    gt_feat = torch.nn.functional.normalize(torch.randn(K, R, C), dim=-1)
+    dmask = torch.ones(K, R, dtype=torch.bool)
+    cases = {}
+    lab = torch.tensor(np.random.RandomState(0).choice([0, 1, 2], size=(K, R), p=[.35, .55, .10]),
+                       dtype=torch.uint8)
+    lab[:, 0] = 1
+    lab[:, 1] = 0
+    cases["normal"] = lab
+    lab2 = lab.clone()
+    lab2[1][lab2[1] == 1] = 0          # object 1 has no this-object ray -> depth/colour/feat zeroed for all
+    cases["no_label1"] = lab2
+    lab3 = lab.clone()
+    lab3[2] = 2                        # object 2 all unknown -> every term zeroed for all
+    cases["all_unknown"] = lab3
+    for name, labels in cases.items():
+        for feat_on in (False, True):
+            a = alpha.clone().requires_grad_(True)
+            c = color.clone().requires_grad_(True)
+            f = clip.clone().requires_grad_(True)
+            if feat_on:
+                l, _ = ref_loss.step_batch_loss(a, c, gt_depth, gt_rgb, labels, dmask, z,
+                                                gt_partfeat=gt_feat, pred_partfeat=f)
+            else:
+                l, _ = ref_loss.step_batch_loss(a, c, gt_depth, gt_rgb, labels, dmask, z)
+            if l.requires_grad:
+                l.backward()
+            tag = f"{name}_{'feat' if feat_on else 'nofeat'}"
+            out[f"loss_{tag}"] = l.detach()
+            out[f"dalpha_{tag}"] = a.grad if a.grad is not None else torch.zeros_like(a)
+            out[f"dcolor_{tag}"] = c.grad if c.grad is not None else torch.zeros_like(c)
+            if feat_on:
+                out[f"dclip_{tag}"] = f.grad if f.grad is not None else torch.zeros_like(f)
+        out[f"labels_{name}"] = labels
+    # var ~ 0 case: a single dominant sample per ray
+    a0 = torch.full((K, R, S, 1), -30.0)
+    a0[:, :, 4] = 30.0
+    a0.requires_grad_(True)
+    c0 = color.clone().requires_grad_(True)
+    l0, _ = ref_loss.step_batch_loss(a0, c0, gt_depth, gt_rgb, cases["normal"], dmask, z)
+    l0.backward()
+    out["alpha_var0"] = a0.detach()
+    out["loss_var0"] = l0.detach()
+    out["dcolor_var0"] = c0.grad
+    save("g4_loss", alpha=alpha, color=color, clip=clip, z=z, gt_depth=gt_depth, gt_rgb=gt_rgb,
+         gt_feat=gt_feat, **out)
+
+
+# ---------------------------------------------------------------------------------------- G5/G6
+def run_reference_steps(ts, batches, feat_on, n_steps, lr=1e-3, wd=0.013, record_grads=True):
+    """train.py:78,272-276,424-474 on CPU: update_vmap -> vmap(pe)/vmap(fc) -> step_batch_loss
+    -> backward -> AdamW.step -> zero_grad."""
+    optimiser = torch.optim.AdamW([torch.autograd.Variable(torch.tensor(0))], lr=lr, weight_decay=wd)
+    fc_models = [t.fc_occ_map for t in ts]
+    pe_models = [t.pe for t in ts]
+    fc_model, fc_param, fc_buffer = ref_utils.update_vmap(fc_models, optimiser)
+    pe_model, pe_param, pe_buffer = ref_utils.update_vmap(pe_models, optimiser)
+    rec = dict(loss=[], grads=[], params=[], none_grad=[])
+    for it in range(n_steps):
+        b = batches(it)
+        pts, gt_depth, gt_rgb, labels, z = to_t(b, ["pts", "gt_depth", "gt_rgb", "labels", "z"])
+        emb = vmap(pe_model)(pe_param, pe_buffer, pts)
+        alpha, color, clip = vmap(fc_model)(fc_param, fc_buffer, emb)
+        dmask = torch.ones_like(gt_depth, dtype=torch.bool)
+        if feat_on:
+            gt_feat = torch.from_numpy(b["gt_feat"])
+            l, _ = ref_loss.step_batch_loss(alpha, color, gt_depth, gt_rgb, labels, dmask, z,
+                                            gt_partfeat=gt_feat, pred_partfeat=clip)
+        else:
+            l, _ = ref_loss.step_batch_loss(alpha, color, gt_depth, gt_rgb, labels, dmask, z)
+        l.backward()
+        rec["loss"].append(l.item())
+        if record_grads:
+            rec["none_grad"].append([int(p.grad is None) for p in list(fc_param) + list(pe_param)])
+            rec["grads"].append([(p.grad.clone() if p.grad is not None else torch.zeros_like(p))
+                                 for p in list(fc_param) + list(pe_param)])
+        optimiser.step()
+        optimiser.zero_grad(set_to_none=True)
+        if record_grads:
+            rec["params"].append([p.detach().clone() for p in list(fc_param) + list(pe_param)])
+    rec["final_fc"] = [p.detach().clone() for p in fc_param]
+    rec["final_B"] = pe_param[0].detach().clone()
+    rec["optimiser"] = optimiser
+    return rec
+
+
+def g5_g6():
+    for tag, (K, R, n1, n2, feat_on) in {
+        "s10_nofeat": (3, 16, 1, 9, False),
+        "s10_feat": (3, 16, 1, 9, True),
+        "s64_feat": (2, 8, 16, 48, True),
+    }.items():
+        ts = make_trainers(K, seed=50)
+        fc0, B0 = stack_params(ts)
+
+        def batches(it, K=K, R=R, n1=n1, n2=n2):
+            return synthetic.random_batch(K, R, n1, n2, seed=500 + it, feat_dim=512)
+
+        rec = run_reference_steps(ts, batches, feat_on, n_steps=3)
+        out = {f"fc0_{i}": fc0[i] for i in range(18)}
+        out["B0"] = B0
+        out["scale"] = np.full(K, 2.0, np.float32)
+        out["loss"] = np.array(rec["loss"], np.float64)
+        out["none_grad"] = np.array(rec["none_grad"], np.int32)
+        for it in range(3):
+            for i in range(19):
+                if it == 0:
+                    out[f"grad{it}_{i}"] = rec["grads"][it][i]
+                out[f"param{it}_{i}"] = rec["params"][it][i]
+        # Adam moments after the 3 steps (state of the two vmap param groups)
+        opt = rec["optimiser"]
+        ms, vs = [], []
+        for grp in opt.param_groups[1:]:
+            for p in grp["params"]:
+                st = opt.state.get(p, None)
+                ms.append(st["exp_avg"] if st else torch.zeros_like(p))
+                vs.append(st["exp_avg_sq"] if st else torch.zeros_like(p))
+        for i in range(19):
+            out[f"m_{i}"] = ms[i]
+            out[f"v_{i}"] = vs[i]
+        out["meta"] = np.array([K, R, n1, n2, int(feat_on)], np.int32)
+        save(f"g5_step_{tag}", **out)
+
+
+# ------------------------------------------------------------------------------------------- G7
+class _Recorder:
+    """Records every torch.rand / Tensor.normal_ draw made inside the reference sampler."""
+
+    def __init__(self):
+        self.rand, self.normal = [], []
+
+    def __enter__(self):
+        self._rand = torch.rand
+        self._normal = torch.Tensor.normal_
+        rec = self
+
+        def rand(*a, **k):
+            r = rec._rand(*a, **k)
+            rec.rand.append(r.clone())
+            return r
+
+        def normal_(t, *a, **k):
+            r = rec._normal(t, *a, **k)
+            rec.normal.append(r.clone())
+            return r
+
+        torch.rand = rand
+        torch.Tensor.normal_ = normal_
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand = self._rand
+        torch.Tensor.normal_ = self._normal
+
+
+def g7():
+    torch.manual_seed(7)
+    out = {}
+    for tag, (N, M) in {"obj": (1, 9), "bg": (5, 9), "metric": (16, 48)}.items():
+        F_, P = 6, 8
+        state = torch.tensor(np.random.RandomState(1).choice([0, 1, 2], size=(F_, P), p=[.3, .55, .15]),
+                             dtype=torch.uint8)
+        rgbs = torch.cat([torch.randint(0, 256, (F_, P, 3), dtype=torch.uint8), state[..., None]], -1)
+        depth = torch.rand(F_, P) * 5.0 + 0.5
+        depth[0, 0] = 0.0
+        depth[2, 3] = 0.0
+        depth[5, 7] = 0.0
+        origins = torch.randn(F_, 3)
+        dirs = torch.randn(F_, P, 3)
+        self_ns = types.SimpleNamespace(n_bins_cam2surface=N, n_bins=M, surface_eps=0.1, stop_eps=0.05,
+                                        depth_batch=torch.zeros(1), data_device="cpu", min_bound=0.0,
+                                        this_obj=1, obj_center=torch.tensor(0.0))
+        with _Recorder() as rec:
+            r_rgb, r_depth, r_valid, r_lab, r_pts, r_z, _ = ref_vmap.sceneObject.sample_3d_points(
+                self_ns, rgbs, depth, origins, dirs)
+        # scatter the recorded draws into per-ray tables (call order: invalid, valid cam2surf,
+        # [normal for this-object], other-object near-surface -- vmap.py:498-542)
+        n = F_ * P
+        d = depth.view(-1)
+        invalid = d <= 0
+        valid = ~invalid
+        obj = (state.view(-1) == 1) & valid
+        oth = (state.view(-1) != 1) & valid
+        u = torch.zeros(n, N + M)
+        g = torch.zeros(n, M)
+        ri = 0
+        u[invalid] = rec.rand[ri]; ri += 1
+        u[valid, :N] = rec.rand[ri]; ri += 1
+        g[obj] = rec.normal[0]
+        u[oth, N:] = rec.rand[ri]; ri += 1
+        assert ri == len(rec.rand) and len(rec.normal) == 1
+        out.update({f"{tag}_rgbs": rgbs, f"{tag}_depth": depth, f"{tag}_origins": origins,
+                    f"{tag}_dirs": dirs, f"{tag}_u": u, f"{tag}_g": g, f"{tag}_z": r_z,
+                    f"{tag}_pts": r_pts, f"{tag}_valid": r_valid, f"{tag}_labels": r_lab,
+                    f"{tag}_NM": np.array([N, M], np.int32)})
+    # get_training_samples: keyframe/pixel gather (vmap.py:386-436)
+    torch.manual_seed(71)
+    Fk, W, H = 4, 40, 30
+    cfg = types.SimpleNamespace(data_device="cpu", W=W, H=H, fx=30.0, fy=30.0, cx=19.5, cy=14.5)
+    cam = ref_vmap.cameraInfo(cfg)
+    rgbs_batch = torch.randint(0, 256, (Fk, W, H, 4), dtype=torch.uint8)
+    rgbs_batch[..., 3] = torch.randint(0, 3, (Fk, W, H), dtype=torch.uint8)
+    depth_batch = torch.rand(Fk, W, H) * 4 + 0.5
+    depth_batch[torch.rand(Fk, W, H) < 0.1] = 0.0
+    t_wc = torch.eye(4).repeat(Fk, 1, 1)
+    t_wc[:, :3, :3] = torch.from_numpy(synthetic._random_rotations(np.random.RandomState(3), Fk)).float()
+    t_wc[:, :3, 3] = torch.randn(Fk, 3)
+    bbox = torch.tensor([[3., 30., 2., 25.], [0., 39., 0., 29.], [10., 12., 5., 28.], [5., 20., 5., 20.]])
+    n_frames, n_samples = 7, 5
+    self_ns = types.SimpleNamespace(n_keyframes=Fk, data_device="cpu", lastest_kf_queue=[2, 3], bbox=bbox,
+                                    rgbs_batch=rgbs_batch, depth_batch=depth_batch, t_wc_batch=t_wc,
+                                    part_mode=False, n_bins_cam2surface=1, n_bins=9, surface_eps=0.1,
+                                    stop_eps=0.05, min_bound=0.0, this_obj=1, obj_center=torch.tensor(0.0))
+    self_ns.sample_3d_points = lambda *a, **k: ref_vmap.sceneObject.sample_3d_points(self_ns, *a, **k)
+    _randint = torch.randint
+    kf_rec = []
+
+    def randint(*a, **k):
+        r = _randint(*a, **k)
+        kf_rec.append(r.clone())
+        return r
+
+    torch.randint = randint
+    try:
+        with _Recorder() as rec:
+            g_rgb, g_depth, g_valid, g_lab, g_pts, g_z, _ = ref_vmap.sceneObject.get_training_samples(
+                self_ns, n_frames, n_samples, cam.rays_dir_cache, None)
+    finally:
+        torch.randint = _randint
+    kf_ids = torch.cat([kf_rec[0], torch.tensor([2, 3])])
+    u_w, u_h = rec.rand[0], rec.rand[1]
+    n = n_frames * n_samples
+    d = g_depth.reshape(-1)
+    invalid = d <= 0
+    valid = ~invalid
+    obj = (g_lab == 1) & valid
+    oth = (g_lab != 1) & valid
+    u = torch.zeros(n, 10)
+    g = torch.zeros(n, 9)
+    ri = 2
+    if invalid.any():
+        u[invalid] = rec.rand[ri]; ri += 1
+    u[valid, :1] = rec.rand[ri]; ri += 1
+    if obj.any():
+        g[obj] = rec.normal[0]
+    if oth.any():
+        u[oth, 1:] = rec.rand[ri]; ri += 1
+    assert ri == len(rec.rand)
+    out.update(dict(gts_rgbs_batch=rgbs_batch, gts_depth_batch=depth_batch, gts_t_wc=t_wc, gts_bbox=bbox,
+                    gts_rays_dir_cache=cam.rays_dir_cache, gts_kf_ids=kf_ids, gts_u_w=u_w, gts_u_h=u_h,
+                    gts_u=u, gts_g=g, gts_rgb=g_rgb, gts_depth=g_depth, gts_valid=g_valid,
+                    gts_labels=g_lab, gts_pts=g_pts, gts_z=g_z,
+                    gts_cam=np.array([W, H, 30.0, 30.0, 19.5, 14.5], np.float32)))
+    save("g7_sample", **out)
+
+
+# ------------------------------------------------------------------------------------------- G8
+def g8():
+    torch.manual_seed(8)
+    n = 64
+    o = torch.randn(n, 3) * 2
+    d = torch.randn(n, 3)
+    bmin = torch.tensor([-0.5, -0.7, -0.3])
+    bmax = torch.tensor([0.5, 0.7, 0.3])
+    near, far, hit = ref_utils.ray_box_intersection(o, d, bmin, bmax)
+    T = torch.eye(4).repeat(5, 1, 1)
+    T[:, :3, :3] = torch.from_numpy(synthetic._random_rotations(np.random.RandomState(8), 5)).float()
+    T[:, :3, 3] = torch.randn(5, 3)
+    dc = torch.randn(5, 6, 3)
+    ow, dw = ref_utils.origin_dirs_W(T, dc)
+    dc2 = torch.randn(5, 3)
+    ow2, dw2 = ref_utils.origin_dirs_W(T, dc2)
+    grid = ref_rr.make_3D_grid(occ_range=[-1., 1.], dim=5, device="cpu",
+                               transform=T[0], scale=torch.tensor([0.4, 0.6, 0.8]))
+    save("g8_box", o=o, d=d, bmin=bmin, bmax=bmax, near=near, far=far, hit=hit, T=T, dc=dc, ow=ow, dw=dw,
+         dc2=dc2, ow2=ow2, dw2=dw2, grid=grid)
+
+
+# ------------------------------------------------------------------------------------------- G9
+G9 = dict(K=4, R=96, N=4, M=12, steps=300, eval_R=256, eval_S=32, scene_seed=7, weight_seed=90)
+
+
+def g9():
+    scene = synthetic.EllipsoidScene.make(G9["K"], 512, seed=G9["scene_seed"])
+    for feat_on in (False, True):
+        ts = make_trainers(G9["K"], seed=G9["weight_seed"], perturb_B=False)
+        fc0, B0 = stack_params(ts)
+
+        def batches(it):
+            return scene.batch(G9["R"], G9["N"], G9["M"], seed=9000 + it, with_feat=True)
+
+        rec = run_reference_steps(ts, batches, feat_on, n_steps=G9["steps"], record_grads=False)
+        ev = scene.eval_rays(G9["eval_R"], G9["eval_S"])
+        pts, z, gt_rgb = to_t(ev, ["pts", "z", "gt_rgb"])
+        with torch.no_grad():
+            rgbs, depths = [], []
+            for k, t in enumerate(ts):
+                # copy-back (train.py:478-485)
+                for i, p in enumerate(t.fc_occ_map.parameters()):
+                    p.copy_(rec["final_fc"][i][k])
+                t.pe.B_layer.weight.copy_(rec["final_B"][k])
+                a, c, _ = t.fc_occ_map(t.pe(pts[k]))
+                term = ref_rr.occupancy_to_termination(ref_rr.occupancy_activation(a.squeeze(-1)))
+                rgbs.append(ref_rr.render(term[..., None], c, dim=-2))
+                depths.append(ref_rr.render(term, z[k]))
+            rgb = torch.stack(rgbs)
+            depth = torch.stack(depths)
+        mse = torch.mean((rgb - gt_rgb) ** 2).item()
+        psnr = -10 * np.log10(mse)
+        tag = "feat" if feat_on else "nofeat"
+        print(f"g9 {tag}: final loss {rec['loss'][-1]:.4f}  PSNR {psnr:.3f} dB")
+        out = {f"fc0_{i}": fc0[i] for i in range(18)}
+        out["B0"] = B0
+        out.update({f"fcT_{i}": rec["final_fc"][i] for i in range(18)})
+        out["BT"] = rec["final_B"]
+        save(f"g9_psnr_{tag}", loss=np.array(rec["loss"]), psnr=np.array(psnr), eval_rgb=rgb,
+             eval_depth=depth, meta=np.array([G9[k] for k in ["K", "R", "N", "M", "steps", "eval_R",
+                                                              "eval_S", "scene_seed"]], np.int32), **out)
+
+
+# ------------------------------------------------------------------------------------------ G10
+def g10():
+    K, R, N, M, H = 1, 64, 5, 9, 128
+    ts = make_trainers(K, seed=100, hidden=H, scale=5.0)
+    fc0, B0 = stack_params(ts)
+
+    def batches(it):
+        return synthetic.random_batch(K, R, N, M, seed=1000 + it, feat_dim=512)
+
+    for feat_on in (False, True):
+        ts = make_trainers(K, seed=100, hidden=H, scale=5.0)
+        rec = run_reference_steps(ts, batches, feat_on, n_steps=1)
+        out = {f"fc0_{i}": fc0[i] for i in range(18)}
+        out["B0"] = B0
+        out["loss"] = np.array(rec["loss"])
+        for i in range(19):
+            out[f"grad0_{i}"] = rec["grads"][0][i]
+        out["meta"] = np.array([K, R, N, M, int(feat_on), H], np.int32)
+        save(f"g10_bg_{'feat' if feat_on else 'nofeat'}", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g7", "g8", "g9", "g10"]
+    for w in which:
+        {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5": g5_g6, "g7": g7, "g8": g8, "g9": g9,
+         "g10": g10}[w]()
