@@ -1,0 +1,200 @@
+/*
+ * objnerf_hip.h -- C ABI of libobjnerf_hip.so, the MI355X (gfx950) implementation of OpenObj's
+ * vectorised object-NeRF hot path.
+ *
+ * The reference (BIT-DYN/OpenObj, objnerf/) has no FFI / operator layer of its own: its hot path
+ * is a Python call sequence (train.py:394-474).  This header is the boundary a maintainer binds
+ * that call sequence to; each entry point cites the reference interface it replaces.  All
+ * pointers are DEVICE pointers unless named host_*; all tensors are contiguous row-major fp32
+ * unless stated; outputs and workspaces are caller-allocated; nothing here allocates, frees or
+ * synchronises; every launch goes to `stream` (a hipStream_t passed as void*).  Return value:
+ * 0 on success, a negative OBJNERF_E* code otherwise (the reference's assert / exit(-1) paths).
+ *
+ * Symbols (paths relative to the reference's objnerf/):
+ *   K objects, R rays per object, S samples per ray, H hidden width, C feature width (512),
+ *   E1=87 / E2=42 embedding split (trainer.py:20-21).
+ *
+ * Parameter arena.  The reference stacks the K networks into 18+1 tensors with
+ * functorch.combine_state_for_ensemble (utils.py:55-62).  Here the same values live in ONE
+ * object-major fp32 arena [K][P_stride]: object k's 19 tensors back to back in the order of
+ * OccupancyMap.parameters() (model.py:29-56) followed by UniDirsEmbed.B_layer.weight
+ * (embedding.py:39-40).  objnerf_param_layout() returns the offsets; the stacked tensors the
+ * reference API exposes are strided views of the arena.  Gradients and Adam moments use the same
+ * layout.
+ */
+#ifndef OBJNERF_HIP_H
+#define OBJNERF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OBJNERF_ABI_VERSION 1
+
+#define OBJNERF_OK 0
+#define OBJNERF_EINVAL (-22)       /* bad shape / null pointer / unsupported size        */
+#define OBJNERF_ENOTSUP (-95)      /* shape valid for the reference but not built here   */
+#define OBJNERF_ELAUNCH (-5)       /* HIP launch error (hipGetLastError != hipSuccess)   */
+
+#define OBJNERF_N_TENSORS 19       /* 18 OccupancyMap tensors + B_layer.weight           */
+
+/* Index of each tensor inside an object's block of the arena (model.py:29-56 order). */
+enum objnerf_tensor {
+  OBJNERF_T_IN_W = 0, OBJNERF_T_IN_B, OBJNERF_T_M1_W, OBJNERF_T_M1_B, OBJNERF_T_CAT_W,
+  OBJNERF_T_CAT_B, OBJNERF_T_M2_W, OBJNERF_T_M2_B, OBJNERF_T_ALPHA_W, OBJNERF_T_ALPHA_B,
+  OBJNERF_T_CL_W, OBJNERF_T_CL_B, OBJNERF_T_OC_W, OBJNERF_T_OC_B, OBJNERF_T_FL_W, OBJNERF_T_FL_B,
+  OBJNERF_T_OF_W, OBJNERF_T_OF_B, OBJNERF_T_PE_B
+};
+
+/* Network shape: trainer.py:15-21,36-44. */
+typedef struct objnerf_net {
+  int32_t hidden;        /* cfg.hidden_feature_size (32 objects / 128 background)         */
+  int32_t feat_dim;      /* cfg.clip_point_feature_size (512)                             */
+  int32_t n_freqs;       /* cfg.n_unidir_funcs + 1 (6)                                    */
+  int32_t reserved;
+} objnerf_net;
+
+/* offsets[i] = start of tensor i inside an object's block, offsets[19] = parameter count P;
+ * returns P_stride (P rounded up to 64 floats), or a negative error. */
+int64_t objnerf_param_layout(const objnerf_net* net, int64_t offsets[OBJNERF_N_TENSORS + 1]);
+
+int objnerf_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * A1  cameraInfo.get_rays_dirs (vmap.py:701-720): out [W][H][3], un-normalised, transposed image.
+ */
+int objnerf_rays_dirs(int32_t W, int32_t H, float fx, float fy, float cx, float cy, float* out,
+                      void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A2+A3+A4  sceneObject.get_training_samples + sample_3d_points (vmap.py:386-554,
+ * utils.py:324-397) for ONE object: gather pixels from the keyframe buffers and place the
+ * depth-guided z-values.  Randomness is INJECTED (the reference's torch.rand / normal_ draws):
+ *   kf_ids [n_frames] int64, u_w,u_h [n_frames][n_px] in [0,1),
+ *   u [n_frames*n_px][N+M] uniforms, g [n_frames*n_px][M] draws of N(0,(eps/3)^2).
+ * Keyframe buffers: rgbs [F][W][H][4] u8 (rgb+state), depth [F][W][H], t_wc [F][4][4],
+ * bbox [F][4] = [u lo,u hi,v lo,v hi], rays_dir_cache [W][H][3].
+ * Outputs: rgb [n][3] u8, gt_depth [n], valid [n] u8, labels [n] u8, z [n][N+M], pts [n][N+M][3]
+ * (n = n_frames*n_px).  max_depth_ws: device scratch of 1 + 6*n floats ([0] receives the batch depth
+ * maximum of vmap.py:489, the rest holds the world-frame origins / directions between the passes).
+ */
+typedef struct objnerf_sample_args {
+  int32_t F, W, H, n_frames, n_px, n_cam2surf, n_bins, reserved;
+  float surface_eps, stop_eps, min_bound, obj_center;
+  const uint8_t* rgbs; const float* depth; const float* t_wc; const float* bbox;
+  const float* rays_dir_cache;
+  const int64_t* kf_ids; const float* u_w; const float* u_h; const float* u; const float* g;
+  uint8_t* out_rgb; float* out_depth; uint8_t* out_valid; uint8_t* out_labels;
+  float* out_z; float* out_pts; float* max_depth_ws;
+} objnerf_sample_args;
+int objnerf_sample_rays(const objnerf_sample_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A6+A7  UniDirsEmbed.forward + OccupancyMap.forward (embedding.py:46-55, model.py:61-103),
+ * inference: K objects x N points each.
+ *   params [K][P_stride], scale [K] (pe buffer `scale`), pts [K][N][3]
+ *   out_alpha [K][N] (= 10*raw, model.py:88), out_color [K][N][3] (sigmoid applied),
+ *   out_hfeat [K][N][H] = relu(clip_linear(.)) or NULL, out_clip [K][N][C] = out_clip(.) or NULL.
+ * This is what Trainer.eval_points (trainer.py:105-128) and render_2D_syn (vmap.py:644-655) run.
+ */
+int objnerf_eval_points(const objnerf_net* net, int32_t K, int64_t N, const float* params,
+                        int64_t p_stride, const float* scale, const float* pts, float* out_alpha,
+                        float* out_color, float* out_hfeat, float* out_clip, void* stream);
+
+/* A6 alone: emb [K][N][3+21*n_freqs]. */
+int objnerf_embed(const objnerf_net* net, int32_t K, int64_t N, const float* params,
+                  int64_t p_stride, const float* scale, const float* pts, float* out_emb,
+                  void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A8+A9+A10  occupancy_activation -> occupancy_to_termination -> render (render_rays.py:6-63,
+ * loss.py:27-35,82) for n_rays rays of S samples:
+ *   alpha [n][S], color [n][S][3], z [n][S], vals [n][S][V] or NULL (any per-sample vector to
+ *   composite: the H-wide feature hidden, or the reference's C-wide clip tensor).
+ *   out_term [n][S] or NULL, out_depth/out_var/out_opacity [n], out_rgb [n][3], out_vals [n][V].
+ */
+int objnerf_composite(int64_t n_rays, int32_t S, const float* alpha, const float* color,
+                      const float* z, const float* vals, int32_t V, float* out_term,
+                      float* out_depth, float* out_var, float* out_rgb, float* out_opacity,
+                      float* out_vals, void* stream);
+
+/* out_clip head applied after compositing (exact: the head is linear):
+ * out [K][n][C] = of_w[k] . hfeat[k][n] + of_b[k] * weight[k][n]   (weight = opacity, or NULL=1). */
+int objnerf_feature_head(const objnerf_net* net, int32_t K, int64_t n, const float* params,
+                         int64_t p_stride, const float* hfeat, const float* weight, float* out,
+                         void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A11  loss.step_batch_loss (loss.py:5-103) on materialised network outputs:
+ *   alpha [K][R][S], color [K][R][S][3], z [K][R][S], gt_depth [K][R], gt_rgb [K][R][3],
+ *   labels [K][R] u8 (0 other / 1 this / 2 unknown), optional pred_feat [K][R][S][C] + gt_feat
+ *   [K][R][C].  Scalings as loss.py:6.
+ * Outputs: loss_terms [K][4] = per-object (depth, colour, opacity, feature) means, total [1],
+ *   optional d_alpha / d_color / d_pred_feat (gradients of `total`), status [1] int32 != 0 when a
+ *   per-object term exceeds 1e5 (render_rays.py:109-111 "loss explode").
+ * The cross-object early return (render_rays.py:89-94) is applied: if ANY object has no label-1
+ * ray the depth / colour / feature terms are zero for ALL objects, likewise label!=2 for opacity.
+ * counts: int32 workspace of 2*K + 2 entries; receives [K][2] = (n_label1, n_label_not2) and the two
+ * early-return flags.
+ * flags_in: optional [2] int32 "some object elsewhere (other GPU) had an empty mask".
+ */
+typedef struct objnerf_loss_args {
+  int32_t K, R, S, C;
+  float color_scaling, opacity_scaling, feat_scaling, reserved;
+  const float* alpha; const float* color; const float* z; const float* gt_depth;
+  const float* gt_rgb; const uint8_t* labels; const float* pred_feat; const float* gt_feat;
+  const int32_t* flags_in;
+  float* loss_terms; float* total; float* d_alpha; float* d_color; float* d_pred_feat;
+  int32_t* counts; int32_t* status;
+} objnerf_loss_args;
+int objnerf_step_batch_loss(const objnerf_loss_args* a, void* stream);
+
+/* Label statistics alone: counts [K][2], flags_out [2] (1 = some object has an empty mask). */
+int objnerf_label_counts(int32_t K, int32_t R, const uint8_t* labels, int32_t* counts,
+                         int32_t* flags_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A12  one training iteration, fused: train.py:424-472 (vmap(pe) -> vmap(fc) -> step_batch_loss
+ * -> backward) for K stacked objects in ONE pass over the rays.
+ *
+ * Inputs: params/scale as above; either pts [K][R][S][3] (train.py:397 batch_input_pcs) or, when
+ * pts == NULL, origins [K][R][3] + dirs [K][R][3] + z (pts = o + d*z - center, vmap.py:548-551);
+ * z [K][R][S]; gt_depth, gt_rgb, labels as objnerf_step_batch_loss; gt_feat [K][R][C] or NULL
+ * (NULL = cfg.part_mode off: the feature branch gets no gradient, train.py:435-438).
+ * counts [K][2] + flags [2]: from objnerf_label_counts (flags may have been max-reduced across
+ * GPUs first -- the early return spans every object of the batch).
+ * Outputs: grads [K][P_stride] (same layout as params; entries of tensors without gradient are
+ * left untouched), loss_terms [K][4], status [1].
+ * workspace: objnerf_train_workspace_bytes() bytes, 256-byte aligned.
+ */
+typedef struct objnerf_train_args {
+  int32_t K, R, S, reserved;
+  float color_scaling, opacity_scaling, feat_scaling, obj_center;
+  const float* params; int64_t p_stride; const float* scale;
+  const float* pts; const float* origins; const float* dirs; const float* z;
+  const float* gt_depth; const float* gt_rgb; const uint8_t* labels; const float* gt_feat;
+  const int32_t* counts; const int32_t* flags;
+  float* grads; float* loss_terms; int32_t* status;
+  void* workspace; size_t workspace_bytes;
+} objnerf_train_args;
+size_t objnerf_train_workspace_bytes(const objnerf_net* net, int32_t K, int32_t R, int32_t S,
+                                     int32_t with_feat);
+int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A12  torch.optim.AdamW.step as train.py:78 configures it (lr, weight_decay; betas .9/.999,
+ * eps 1e-8), over the arena.  has_grad [P] u8: 0 for tensors that received no gradient this
+ * iteration (they get NO update and NO decay, like a None .grad).  step = 1-based step count.
+ */
+int objnerf_adamw_step(int32_t K, int64_t P, int64_t p_stride, float* params, const float* grads,
+                       float* exp_avg, float* exp_avg_sq, const uint8_t* has_grad, int32_t step,
+                       float lr, float beta1, float beta2, float eps, float weight_decay,
+                       void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OBJNERF_HIP_H */

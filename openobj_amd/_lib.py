@@ -1,0 +1,135 @@
+"""ctypes binding of libobjnerf_hip.so (include/objnerf_hip.h).
+
+The library is built in-tree (openobj_amd/csrc/libobjnerf_hip.so, `make -C openobj_amd/csrc` or
+`__graft_entry__.build()`).  There is NO fallback: if it is missing, or a call returns an error
+code, this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libobjnerf_hip.so")
+
+OBJNERF_N_TENSORS = 19
+ABI_VERSION = 1
+
+
+class ObjnerfError(RuntimeError):
+    pass
+
+
+class Net(C.Structure):
+    _fields_ = [("hidden", C.c_int32), ("feat_dim", C.c_int32), ("n_freqs", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class SampleArgs(C.Structure):
+    _fields_ = [("F", C.c_int32), ("W", C.c_int32), ("H", C.c_int32), ("n_frames", C.c_int32),
+                ("n_px", C.c_int32), ("n_cam2surf", C.c_int32), ("n_bins", C.c_int32),
+                ("reserved", C.c_int32),
+                ("surface_eps", C.c_float), ("stop_eps", C.c_float), ("min_bound", C.c_float),
+                ("obj_center", C.c_float),
+                ("rgbs", C.c_void_p), ("depth", C.c_void_p), ("t_wc", C.c_void_p), ("bbox", C.c_void_p),
+                ("rays_dir_cache", C.c_void_p),
+                ("kf_ids", C.c_void_p), ("u_w", C.c_void_p), ("u_h", C.c_void_p), ("u", C.c_void_p),
+                ("g", C.c_void_p),
+                ("out_rgb", C.c_void_p), ("out_depth", C.c_void_p), ("out_valid", C.c_void_p),
+                ("out_labels", C.c_void_p), ("out_z", C.c_void_p), ("out_pts", C.c_void_p),
+                ("max_depth_ws", C.c_void_p)]
+
+
+class LossArgs(C.Structure):
+    _fields_ = [("K", C.c_int32), ("R", C.c_int32), ("S", C.c_int32), ("C", C.c_int32),
+                ("color_scaling", C.c_float), ("opacity_scaling", C.c_float),
+                ("feat_scaling", C.c_float), ("reserved", C.c_float),
+                ("alpha", C.c_void_p), ("color", C.c_void_p), ("z", C.c_void_p), ("gt_depth", C.c_void_p),
+                ("gt_rgb", C.c_void_p), ("labels", C.c_void_p), ("pred_feat", C.c_void_p),
+                ("gt_feat", C.c_void_p), ("flags_in", C.c_void_p),
+                ("loss_terms", C.c_void_p), ("total", C.c_void_p), ("d_alpha", C.c_void_p),
+                ("d_color", C.c_void_p), ("d_pred_feat", C.c_void_p),
+                ("counts", C.c_void_p), ("status", C.c_void_p)]
+
+
+class TrainArgs(C.Structure):
+    _fields_ = [("K", C.c_int32), ("R", C.c_int32), ("S", C.c_int32), ("reserved", C.c_int32),
+                ("color_scaling", C.c_float), ("opacity_scaling", C.c_float),
+                ("feat_scaling", C.c_float), ("obj_center", C.c_float),
+                ("params", C.c_void_p), ("p_stride", C.c_int64), ("scale", C.c_void_p),
+                ("pts", C.c_void_p), ("origins", C.c_void_p), ("dirs", C.c_void_p), ("z", C.c_void_p),
+                ("gt_depth", C.c_void_p), ("gt_rgb", C.c_void_p), ("labels", C.c_void_p),
+                ("gt_feat", C.c_void_p),
+                ("counts", C.c_void_p), ("flags", C.c_void_p),
+                ("grads", C.c_void_p), ("loss_terms", C.c_void_p), ("status", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
+# name -> (restype, argtypes); every symbol include/objnerf_hip.h declares
+SIGNATURES = {
+    "objnerf_abi_version": (C.c_int, []),
+    "objnerf_param_layout": (C.c_int64, [C.POINTER(Net), C.POINTER(C.c_int64)]),
+    "objnerf_rays_dirs": (C.c_int, [C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float,
+                                    C.c_void_p, C.c_void_p]),
+    "objnerf_sample_rays": (C.c_int, [C.POINTER(SampleArgs), C.c_void_p]),
+    "objnerf_eval_points": (C.c_int, [C.POINTER(Net), C.c_int32, C.c_int64, C.c_void_p, C.c_int64,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p]),
+    "objnerf_embed": (C.c_int, [C.POINTER(Net), C.c_int32, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+                                C.c_void_p, C.c_void_p, C.c_void_p]),
+    "objnerf_composite": (C.c_int, [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p]),
+    "objnerf_feature_head": (C.c_int, [C.POINTER(Net), C.c_int32, C.c_int64, C.c_void_p, C.c_int64,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "objnerf_step_batch_loss": (C.c_int, [C.POINTER(LossArgs), C.c_void_p]),
+    "objnerf_label_counts": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p]),
+    "objnerf_train_workspace_bytes": (C.c_size_t, [C.POINTER(Net), C.c_int32, C.c_int32, C.c_int32,
+                                                   C.c_int32]),
+    "objnerf_train_step": (C.c_int, [C.POINTER(Net), C.POINTER(TrainArgs), C.c_void_p]),
+    "objnerf_adamw_step": (C.c_int, [C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float,
+                                     C.c_float, C.c_float, C.c_void_p]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the library; raises ObjnerfError if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ObjnerfError(
+                f"{LIB_PATH} is missing: build it with `make -C openobj_amd/csrc` "
+                "(or __graft_entry__.build()).  There is no CPU / PyTorch fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)          # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        if l.objnerf_abi_version() != ABI_VERSION:
+            raise ObjnerfError("libobjnerf_hip.so ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+_ERR = {-22: "EINVAL (bad shape / null pointer)", -95: "ENOTSUP (shape not built)",
+        -5: "ELAUNCH (HIP launch failed)"}
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise ObjnerfError(f"{what} failed: {rc} {_ERR.get(rc, '')}")
+
+
+def param_layout(hidden: int, feat_dim: int = 512, n_freqs: int = 6):
+    """-> (offsets[20], p_stride)"""
+    net = Net(hidden, feat_dim, n_freqs, 0)
+    offs = (C.c_int64 * (OBJNERF_N_TENSORS + 1))()
+    ps = lib().objnerf_param_layout(C.byref(net), offs)
+    if ps < 0:
+        raise ObjnerfError("objnerf_param_layout failed")
+    return list(offs), int(ps)

@@ -1,0 +1,533 @@
+// Memory-bound companions of the fused MLP kernels (gfx950): compositing, the materialised-tensor
+// loss, label statistics, AdamW, the un-fused embedding, the post-composite feature head, camera ray
+// directions and the depth-guided ray sampler.  Built with -ffp-contract=off: every product/sum below
+// rounds where the reference's separate ATen ops round; fused multiply-adds are written as fmaf.
+#include "objnerf_device.h"
+#include "../../include/objnerf_hip.h"
+
+namespace {
+
+__device__ __forceinline__ float sgnf(float x) { return x > 0.f ? 1.0f : (x < 0.f ? -1.0f : 0.0f); }
+
+// ------------------------------------------------------------------------------------------------
+// composite: one wave per ray, samples on lanes in chunks of 64 with carries.
+// render_rays.py:6-63 / loss.py:27-35,82.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void composite_kernel(long n_rays, int S, const float* alpha, const float* color,
+                                                        const float* z, const float* vals, int V, float* out_term,
+                                                        float* out_depth, float* out_var, float* out_rgb,
+                                                        float* out_opacity, float* out_vals) {
+  extern __shared__ float sm[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float* wv = sm + (long)w * S;
+  const long ray = (long)blockIdx.x * 4 + w;
+  if (ray >= n_rays) return;
+  float carry = 1.0f, D = 0.f, O = 0.f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
+  for (int s0 = 0; s0 < S; s0 += 64) {
+    const int s = s0 + lane;
+    const bool on = s < S;
+    const float al = on ? alpha[ray * S + s] : 0.f;
+    const float occ = on ? sigmoid_acc(al) : 0.f;
+    const float fr = on ? (1.0f - occ) + 1e-10f : 1.0f;
+    const float pinc = seg_scan_mul(fr, lane, 64) * carry;
+    float T = __shfl_up(pinc, 1, 64);
+    if (lane == 0) T = carry;
+    carry = __shfl(pinc, 63, 64);
+    const float wt = occ * T;
+    if (on) {
+      wv[s] = wt;
+      if (out_term) out_term[ray * S + s] = wt;
+    }
+    const float zz = on ? z[ray * S + s] : 0.f;
+    D += wave_sum64(wt * zz);
+    O += wave_sum64(wt);
+    if (color) {
+      const float* cp = color + (ray * S + s) * 3;
+      C0 += wave_sum64(on ? wt * cp[0] : 0.f);
+      C1 += wave_sum64(on ? wt * cp[1] : 0.f);
+      C2 += wave_sum64(on ? wt * cp[2] : 0.f);
+    }
+  }
+  float Vv = 0.f;
+  for (int s0 = 0; s0 < S; s0 += 64) {
+    const int s = s0 + lane;
+    const bool on = s < S;
+    const float dz = on ? z[ray * S + s] - D : 0.f;
+    Vv += wave_sum64(on ? wv[s] * (dz * dz) : 0.f);
+  }
+  if (lane == 0) {
+    if (out_depth) out_depth[ray] = D;
+    if (out_var) out_var[ray] = Vv;
+    if (out_opacity) out_opacity[ray] = O;
+    if (out_rgb) { out_rgb[ray * 3] = C0; out_rgb[ray * 3 + 1] = C1; out_rgb[ray * 3 + 2] = C2; }
+  }
+  if (vals && out_vals) {
+    for (int v = lane; v < V; v += 64) {
+      float acc = 0.f;
+      for (int s = 0; s < S; ++s) acc += wv[s] * vals[(ray * S + s) * (long)V + v];
+      out_vals[ray * (long)V + v] = acc;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// out[k][n][c] = sum_h of_w[k][c][h] * hfeat[k][n][h] + of_b[k][c] * weight[k][n]
+// (model.py:101 applied after compositing).  One workgroup: 64 points x all C of one object.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void feature_head_kernel(int K, long n, int Hh, int C, const float* params,
+                                                           long p_stride, long off_w, long off_b, const float* hfeat,
+                                                           const float* weight, float* out) {
+  extern __shared__ float sm[];          // hfeat tile [64][Hh+1]
+  const int k = blockIdx.y;
+  const long n0 = (long)blockIdx.x * 64;
+  const float* W = params + (long)k * p_stride + off_w;
+  const float* B = params + (long)k * p_stride + off_b;
+  for (int i = threadIdx.x; i < 64 * Hh; i += 256) {
+    const int p = i / Hh, h = i % Hh;
+    sm[p * (Hh + 1) + h] = (n0 + p < n) ? hfeat[((long)k * n + n0 + p) * Hh + h] : 0.f;
+  }
+  __syncthreads();
+  for (int cc = threadIdx.x; cc < C; cc += 256) {
+    float wrow[128];
+    for (int h = 0; h < Hh; ++h) wrow[h] = W[(long)cc * Hh + h];
+    const float b = B[cc];
+    for (int p = 0; p < 64 && n0 + p < n; ++p) {
+      float acc = 0.f;
+      for (int h = 0; h < Hh; ++h) acc = fmaf(wrow[h], sm[p * (Hh + 1) + h], acc);
+      const float wgt = weight ? weight[(long)k * n + n0 + p] : 1.0f;
+      out[((long)k * n + n0 + p) * C + cc] = acc + b * wgt;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// embedding.py:46-55, one thread per point.
+// ------------------------------------------------------------------------------------------------
+__global__ void embed_kernel(int K, long N, int n_freqs, const float* params, long p_stride, long off_B,
+                             const float* scale, const float* pts, float* out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = blockIdx.y;
+  if (i >= N) return;
+  const float* B = params + (long)k * p_stride + off_B;
+  const float sc = scale[k];
+  const float* p = pts + ((long)k * N + i) * 3;
+  const float t0 = p[0] / sc, t1 = p[1] / sc, t2 = p[2] / sc;
+  const int E = 3 + OBJ_NDIR * n_freqs;
+  float* o = out + ((long)k * N + i) * E;
+  o[0] = t0; o[1] = t1; o[2] = t2;
+  for (int j = 0; j < OBJ_NDIR; ++j) {
+    const float pj = fmaf(t2, B[3 * j + 2], fmaf(t1, B[3 * j + 1], t0 * B[3 * j]));
+    for (int f = 0; f < n_freqs; ++f) {
+      const float arg = (pj * (float)(1 << f)) * OBJ_PI_F;
+      float s, c;
+      sincos_acc(arg, s, c);
+      o[3 + f * OBJ_NDIR + j] = s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// label statistics (loss.py:16-21 masks; render_rays.py:88-89 counts)
+// ------------------------------------------------------------------------------------------------
+__global__ void label_counts_kernel(int K, int R, const uint8_t* labels, int* counts, int* flags) {
+  const int k = blockIdx.x;
+  int c1 = 0, c2 = 0;
+  for (int r = threadIdx.x; r < R; r += blockDim.x) {
+    const int l = labels[(long)k * R + r];
+    c1 += (l == 1);
+    c2 += (l != 2);
+  }
+  __shared__ int s1[4], s2[4];
+  for (int d = 32; d >= 1; d >>= 1) {
+    c1 += __shfl_xor(c1, d, 64);
+    c2 += __shfl_xor(c2, d, 64);
+  }
+  if ((threadIdx.x & 63) == 0) { s1[threadIdx.x >> 6] = c1; s2[threadIdx.x >> 6] = c2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int a = s1[0] + s1[1] + s1[2] + s1[3], b = s2[0] + s2[1] + s2[2] + s2[3];
+    counts[2 * k] = a;
+    counts[2 * k + 1] = b;
+    if (a == 0) atomicOr(&flags[0], 1);
+    if (b == 0) atomicOr(&flags[1], 1);
+  }
+}
+
+__global__ void merge_flags_kernel(int* flags, const int* flags_in) {
+  if (threadIdx.x < 2 && flags_in && flags_in[threadIdx.x]) flags[threadIdx.x] = 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// loss.step_batch_loss on materialised alpha/color (+ optional C-wide predicted features):
+// one wave per ray.  Per-object terms are accumulated with float atomics.
+// ------------------------------------------------------------------------------------------------
+struct LossDev {
+  int K, R, S, C;
+  float cs, os, fs;
+  const float* alpha; const float* color; const float* z; const float* gt_depth; const float* gt_rgb;
+  const uint8_t* labels; const float* pred_feat; const float* gt_feat;
+  const int* counts; const int* flags;
+  float* loss_terms; float* d_alpha; float* d_color; float* d_pred_feat;
+};
+
+__global__ __launch_bounds__(256) void loss_kernel(const LossDev a) {
+  extern __shared__ float sm[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int S = a.S;
+  float* wv = sm + (long)w * 3 * S;      // weights
+  float* tv = wv + S;                    // transmittance
+  float* dwv = tv + S;                   // feature contribution to dL/dw
+  const long rr = (long)blockIdx.x * 4 + w;
+  if (rr >= (long)a.K * a.R) return;
+  const int k = (int)(rr / a.R);
+  const float n1 = (float)a.counts[2 * k], n2 = (float)a.counts[2 * k + 1];
+  const float inv1 = a.flags[0] ? 0.0f : 1.0f / (n1 + 1e-10f);
+  const float inv2 = a.flags[1] ? 0.0f : 1.0f / (n2 + 1e-10f);
+  const int lab = a.labels[rr];
+  const float m1 = (lab == 1) ? 1.f : 0.f, m2 = (lab != 2) ? 1.f : 0.f, tgt = (lab != 0) ? 1.f : 0.f;
+  float carry = 1.0f, D = 0.f, O = 0.f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
+  for (int s0 = 0; s0 < S; s0 += 64) {
+    const int s = s0 + lane;
+    const bool on = s < S;
+    const float occ = on ? sigmoid_acc(a.alpha[rr * S + s]) : 0.f;
+    const float fr = on ? (1.0f - occ) + 1e-10f : 1.0f;
+    const float pinc = seg_scan_mul(fr, lane, 64) * carry;
+    float T = __shfl_up(pinc, 1, 64);
+    if (lane == 0) T = carry;
+    carry = __shfl(pinc, 63, 64);
+    const float wt = occ * T;
+    if (on) { wv[s] = wt; tv[s] = T; dwv[s] = 0.f; }
+    const float* cp = a.color + (rr * S + (on ? s : 0)) * 3;
+    D += wave_sum64(on ? wt * a.z[rr * S + s] : 0.f);
+    O += wave_sum64(wt);
+    C0 += wave_sum64(on ? wt * cp[0] : 0.f);
+    C1 += wave_sum64(on ? wt * cp[1] : 0.f);
+    C2 += wave_sum64(on ? wt * cp[2] : 0.f);
+  }
+  float Vv = 0.f;
+  for (int s0 = 0; s0 < S; s0 += 64) {
+    const int s = s0 + lane;
+    const bool on = s < S;
+    const float dz = on ? a.z[rr * S + s] - D : 0.f;
+    Vv += wave_sum64(on ? wv[s] * (dz * dz) : 0.f);
+  }
+  const float info = 1.0f / (sqrtf(Vv) + 1e-4f);
+  const float rd = D - a.gt_depth[rr];
+  const float r0 = C0 - a.gt_rgb[rr * 3], r1 = C1 - a.gt_rgb[rr * 3 + 1], r2 = C2 - a.gt_rgb[rr * 3 + 2];
+  const float ro = O - tgt;
+  const float gD = m1 * sgnf(rd) * info * inv1;
+  const float gC0 = a.cs * m1 * sgnf(r0) * inv1, gC1 = a.cs * m1 * sgnf(r1) * inv1, gC2 = a.cs * m1 * sgnf(r2) * inv1;
+  const float gO = a.os * m2 * sgnf(ro) * inv2;
+  float lf = 0.f;
+  // feature term (loss.py:82-99): F = sum_s w_s f_s ; 1 - cos(F, g)
+  if (a.pred_feat && a.gt_feat) {
+    const int C = a.C;
+    float dotFg = 0.f, nF2 = 0.f, ng2 = 0.f;
+    for (int cc = lane; cc < C; cc += 64) {
+      float F = 0.f;
+      for (int s = 0; s < S; ++s) F += wv[s] * a.pred_feat[(rr * S + s) * (long)C + cc];
+      const float gv = a.gt_feat[rr * (long)C + cc];
+      dotFg += F * gv; nF2 += F * F; ng2 += gv * gv;
+    }
+    dotFg = wave_sum64(dotFg); nF2 = wave_sum64(nF2); ng2 = wave_sum64(ng2);
+    const float nF = fmaxf(sqrtf(nF2), 1e-8f), ng = fmaxf(sqrtf(ng2), 1e-8f);
+    const float cosv = dotFg / (nF * ng);
+    lf = m1 * (1.0f - cosv) * inv1;
+    const float gs = -a.fs * m1 * inv1;      // d total / d cos
+    for (int cc = lane; cc < C; cc += 64) {
+      float F = 0.f;
+      for (int s = 0; s < S; ++s) F += wv[s] * a.pred_feat[(rr * S + s) * (long)C + cc];
+      const float gv = a.gt_feat[rr * (long)C + cc];
+      const float dF = gs * (gv / (nF * ng) - cosv * F / (nF * nF));
+      for (int s = 0; s < S; ++s) {
+        const long idx = (rr * S + s) * (long)C + cc;
+        if (a.d_pred_feat) a.d_pred_feat[idx] = dF * wv[s];
+        atomicAdd(&dwv[s], dF * a.pred_feat[idx]);
+      }
+    }
+  }
+  if (lane == 0) {
+    atomicAdd(&a.loss_terms[k * 4 + 0], m1 * fabsf(rd) * info * inv1);
+    atomicAdd(&a.loss_terms[k * 4 + 1], m1 * (fabsf(r0) + fabsf(r1) + fabsf(r2)) * inv1);
+    atomicAdd(&a.loss_terms[k * 4 + 2], m2 * fabsf(ro) * inv2);
+    atomicAdd(&a.loss_terms[k * 4 + 3], lf);
+  }
+  if (!a.d_alpha && !a.d_color) return;
+  float sufc = 0.f;
+  const int nch = (S + 63) / 64;
+  for (int ch = nch - 1; ch >= 0; --ch) {
+    const int s = ch * 64 + lane;
+    const bool on = s < S;
+    const float* cp = a.color + (rr * S + (on ? s : 0)) * 3;
+    const float c0 = cp[0], c1 = cp[1], c2 = cp[2];
+    const float wt = on ? wv[s] : 0.f, T = on ? tv[s] : 0.f;
+    const float zz = on ? a.z[rr * S + s] : 0.f;
+    const float dw = on ? gD * zz + gO + gC0 * c0 + gC1 * c1 + gC2 * c2 + dwv[s] : 0.f;
+    const float qv = dw * wt;
+    const float inc = seg_rscan_add(qv, lane, 64);
+    const float suf = inc - qv + sufc;
+    sufc += __shfl(inc, 0, 64);
+    if (on) {
+      const float occ = sigmoid_acc(a.alpha[rr * S + s]);
+      const float fr = (1.0f - occ) + 1e-10f;
+      const float docc = dw * T - suf / fr;
+      if (a.d_alpha) a.d_alpha[rr * S + s] = docc * occ * (1.0f - occ);
+      if (a.d_color) {
+        a.d_color[(rr * S + s) * 3] = gC0 * wt;
+        a.d_color[(rr * S + s) * 3 + 1] = gC1 * wt;
+        a.d_color[(rr * S + s) * 3 + 2] = gC2 * wt;
+      }
+    }
+  }
+}
+
+__global__ void loss_total_kernel(int K, const float* terms, float cs, float os, float fs, float* total, int* status) {
+  // single thread: K is small; sequential sum keeps the result run-to-run deterministic
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float t = 0.f;
+    int bad = 0;
+    for (int k = 0; k < K; ++k) {
+      const float d = terms[4 * k], c = terms[4 * k + 1], o = terms[4 * k + 2], f = terms[4 * k + 3];
+      if (d > 100000.f || c > 100000.f || o > 100000.f || f > 100000.f) bad = 1;
+      t += d + c * cs + o * os + f * fs;
+    }
+    if (total) *total = t;
+    if (status) *status = bad;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// torch.optim.AdamW (single-tensor formulation) over the arena.
+// ------------------------------------------------------------------------------------------------
+__global__ void adamw_kernel(long P, long p_stride, float* params, const float* grads, float* m, float* v,
+                             const uint8_t* has_grad, float decay, float w1, float beta2, float w2, float step_size,
+                             float bc2_sqrt, float eps) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P || (has_grad && !has_grad[i])) return;
+  const long idx = (long)blockIdx.y * p_stride + i;
+  const float g = grads[idx];
+  float p = params[idx] * decay;
+  const float mo = m[idx];
+  const float mn = mo + w1 * (g - mo);
+  const float vn = v[idx] * beta2 + (w2 * g) * g;
+  const float denom = sqrtf(vn) / bc2_sqrt + eps;
+  p = p + (-step_size) * (mn / denom);
+  params[idx] = p;
+  m[idx] = mn;
+  v[idx] = vn;
+}
+
+// ------------------------------------------------------------------------------------------------
+// vmap.py:701-720
+// ------------------------------------------------------------------------------------------------
+__global__ void rays_dirs_kernel(int W, int H, float fx, float fy, float cx, float cy, float* out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)W * H) return;
+  const int iw = (int)(i / H), ih = (int)(i % H);
+  out[i * 3] = ((float)iw - cx) / fx;
+  out[i * 3 + 1] = ((float)ih - cy) / fy;
+  out[i * 3 + 2] = 1.0f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// vmap.py:386-554: pixel gather (pass 1, also the batch depth maximum) and z placement (pass 2).
+// ------------------------------------------------------------------------------------------------
+__global__ void sample_gather_kernel(const objnerf_sample_args a, float* origins_ws, float* dirs_ws) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = a.n_frames * a.n_px;
+  if (i >= n) return;
+  const int f = i / a.n_px;
+  const long kf = a.kf_ids[f];
+  const float* bb = a.bbox + kf * 4;
+  const float fw = a.u_w[i] * (bb[1] - bb[0]) + bb[0];
+  const float fh = a.u_h[i] * (bb[3] - bb[2]) + bb[2];
+  const long iw = (long)fw, ih = (long)fh;                       // .long() truncation (vmap.py:418-419)
+  const long pix = (kf * a.W + iw) * a.H + ih;
+  const uint8_t* px = a.rgbs + pix * 4;
+  a.out_rgb[i * 3] = px[0]; a.out_rgb[i * 3 + 1] = px[1]; a.out_rgb[i * 3 + 2] = px[2];
+  a.out_labels[i] = px[3];
+  const float d = a.depth[pix];
+  a.out_depth[i] = d;
+  atomicMax((int*)a.max_depth_ws, __float_as_int(fmaxf(d, 0.0f)));
+  const float* dc = a.rays_dir_cache + (iw * a.H + ih) * 3;
+  const float* T = a.t_wc + kf * 16;
+  for (int r = 0; r < 3; ++r) {
+    dirs_ws[i * 3 + r] = fmaf(T[r * 4 + 2], dc[2], fmaf(T[r * 4 + 1], dc[1], T[r * 4] * dc[0]));
+    origins_ws[i * 3 + r] = T[r * 4 + 3];
+  }
+}
+
+__device__ __forceinline__ float lin01(int i, int n) {           // torch.linspace(0,1,n+1)[i], fp32
+  const float step = 1.0f / (float)n;
+  return (i < (n + 1) / 2) ? step * (float)i : 1.0f - step * (float)(n - i);
+}
+__device__ __forceinline__ float strat(float lo, float hi, int i, int n, float u) {   // utils.py:342-379
+  const float rng = hi - lo;
+  return (rng * lin01(i, n) + lo) + u * (rng / (float)n);
+}
+
+__global__ void sample_place_kernel(const objnerf_sample_args a, const float* origins_ws, const float* dirs_ws) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = a.n_frames * a.n_px;
+  if (i >= n) return;
+  const int N = a.n_cam2surf, M = a.n_bins, S = N + M;
+  const float d = a.out_depth[i];
+  const float maxd = *a.max_depth_ws;
+  const uint8_t lab = a.out_labels[i];
+  float* z = a.out_z + (long)i * S;
+  const float* u = a.u + (long)i * S;
+  const bool invalid = d <= a.min_bound;
+  a.out_valid[i] = invalid ? 0 : 1;
+  if (invalid) {
+    for (int s = 0; s < S; ++s) z[s] = strat(a.min_bound, maxd, s, S, u[s]);
+  } else {
+    for (int s = 0; s < N; ++s) z[s] = strat(a.min_bound, d - a.surface_eps, s, N, u[s]);
+    if (lab == 1) {
+      // sorted N(0,(eps/3)^2) draws, clipped to +-eps, around the surface (utils.py:382-397)
+      const float* g = a.g + (long)i * M;
+      for (int s = 0; s < M; ++s) {          // rank sort: stable for ties
+        const float v = g[s];
+        int rank = 0;
+        for (int j = 0; j < M; ++j) rank += (g[j] < v) || (g[j] == v && j < s);
+        z[N + rank] = d + fminf(fmaxf(v, -a.surface_eps), a.surface_eps);
+      }
+    } else {
+      for (int s = 0; s < M; ++s) z[N + s] = strat(d - a.surface_eps, d + a.stop_eps, s, M, u[N + s]);
+    }
+  }
+  const float* o = origins_ws + (long)i * 3;
+  const float* dr = dirs_ws + (long)i * 3;
+  for (int s = 0; s < S; ++s) {
+    float* p = a.out_pts + ((long)i * S + s) * 3;
+    p[0] = (o[0] + dr[0] * z[s]) - a.obj_center;
+    p[1] = (o[1] + dr[1] * z[s]) - a.obj_center;
+    p[2] = (o[2] + dr[2] * z[s]) - a.obj_center;
+  }
+}
+
+}  // namespace
+
+#define CHECK_LAUNCH() do { if (hipGetLastError() != hipSuccess) return OBJNERF_ELAUNCH; } while (0)
+
+extern "C" {
+
+int objnerf_composite(int64_t n_rays, int32_t S, const float* alpha, const float* color, const float* z,
+                      const float* vals, int32_t V, float* out_term, float* out_depth, float* out_var, float* out_rgb,
+                      float* out_opacity, float* out_vals, void* stream) {
+  if (n_rays <= 0 || S <= 0 || !alpha || !z) return OBJNERF_EINVAL;
+  if (S > 4096) return OBJNERF_ENOTSUP;
+  hipLaunchKernelGGL(composite_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), (size_t)4 * S * 4,
+                     (hipStream_t)stream, (long)n_rays, S, alpha, color, z, vals, V, out_term, out_depth, out_var,
+                     out_rgb, out_opacity, out_vals);
+  CHECK_LAUNCH();
+  return OBJNERF_OK;
+}
+
+int objnerf_feature_head(const objnerf_net* net, int32_t K, int64_t n, const float* params, int64_t p_stride,
+                         const float* hfeat, const float* weight, float* out, void* stream) {
+  if (!net || !params || !hfeat || !out || K <= 0 || n <= 0) return OBJNERF_EINVAL;
+  if (net->hidden > 128) return OBJNERF_ENOTSUP;
+  int64_t offs[OBJNERF_N_TENSORS + 1];
+  if (objnerf_param_layout(net, offs) < 0) return OBJNERF_EINVAL;
+  dim3 grid((unsigned)((n + 63) / 64), (unsigned)K);
+  hipLaunchKernelGGL(feature_head_kernel, grid, dim3(256), (size_t)64 * (net->hidden + 1) * 4, (hipStream_t)stream, K,
+                     (long)n, net->hidden, net->feat_dim, params, (long)p_stride, (long)offs[OBJNERF_T_OF_W],
+                     (long)offs[OBJNERF_T_OF_B], hfeat, weight, out);
+  CHECK_LAUNCH();
+  return OBJNERF_OK;
+}
+
+int objnerf_embed(const objnerf_net* net, int32_t K, int64_t N, const float* params, int64_t p_stride,
+                  const float* scale, const float* pts, float* out_emb, void* stream) {
+  if (!net || !params || !scale || !pts || !out_emb || K <= 0 || N <= 0) return OBJNERF_EINVAL;
+  int64_t offs[OBJNERF_N_TENSORS + 1];
+  if (objnerf_param_layout(net, offs) < 0) return OBJNERF_EINVAL;
+  dim3 grid((unsigned)((N + 255) / 256), (unsigned)K);
+  hipLaunchKernelGGL(embed_kernel, grid, dim3(256), 0, (hipStream_t)stream, K, (long)N, net->n_freqs, params,
+                     (long)p_stride, (long)offs[OBJNERF_T_PE_B], scale, pts, out_emb);
+  CHECK_LAUNCH();
+  return OBJNERF_OK;
+}
+
+int objnerf_label_counts(int32_t K, int32_t R, const uint8_t* labels, int32_t* counts, int32_t* flags_out,
+                         void* stream) {
+  if (K <= 0 || R <= 0 || !labels || !counts || !flags_out) return OBJNERF_EINVAL;
+  hipMemsetAsync(flags_out, 0, 2 * sizeof(int), (hipStream_t)stream);
+  hipLaunchKernelGGL(label_counts_kernel, dim3(K), dim3(256), 0, (hipStream_t)stream, K, R, labels, counts, flags_out);
+  CHECK_LAUNCH();
+  return OBJNERF_OK;
+}
+
+int objnerf_step_batch_loss(const objnerf_loss_args* a, void* stream) {
+  if (!a || !a->alpha || !a->color || !a->z || !a->gt_depth || !a->gt_rgb || !a->labels || !a->loss_terms ||
+      !a->counts || a->K <= 0 || a->R <= 0 || a->S <= 0)
+    return OBJNERF_EINVAL;
+  if ((a->pred_feat == nullptr) != (a->gt_feat == nullptr)) return OBJNERF_EINVAL;
+  if (a->S > 2048) return OBJNERF_ENOTSUP;
+  hipStream_t st = (hipStream_t)stream;
+  int* flags = a->counts + 2 * a->K;     // counts workspace is [K][2] + [2]
+  hipMemsetAsync(flags, 0, 2 * sizeof(int), st);
+  hipLaunchKernelGGL(label_counts_kernel, dim3(a->K), dim3(256), 0, st, a->K, a->R, a->labels, a->counts, flags);
+  if (a->flags_in) hipLaunchKernelGGL(merge_flags_kernel, dim3(1), dim3(64), 0, st, flags, a->flags_in);
+  hipMemsetAsync(a->loss_terms, 0, (size_t)a->K * 4 * sizeof(float), st);
+  LossDev d;
+  d.K = a->K; d.R = a->R; d.S = a->S; d.C = a->C;
+  d.cs = a->color_scaling; d.os = a->opacity_scaling; d.fs = a->feat_scaling;
+  d.alpha = a->alpha; d.color = a->color; d.z = a->z; d.gt_depth = a->gt_depth; d.gt_rgb = a->gt_rgb;
+  d.labels = a->labels; d.pred_feat = a->pred_feat; d.gt_feat = a->gt_feat; d.counts = a->counts; d.flags = flags;
+  d.loss_terms = a->loss_terms; d.d_alpha = a->d_alpha; d.d_color = a->d_color; d.d_pred_feat = a->d_pred_feat;
+  const long nr = (long)a->K * a->R;
+  hipLaunchKernelGGL(loss_kernel, dim3((unsigned)((nr + 3) / 4)), dim3(256), (size_t)4 * 3 * a->S * 4, st, d);
+  CHECK_LAUNCH();
+  hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(64), 0, st, a->K, a->loss_terms, a->color_scaling,
+                     a->opacity_scaling, a->pred_feat ? a->feat_scaling : 0.0f, a->total, a->status);
+  CHECK_LAUNCH();
+  return OBJNERF_OK;
+}
+
+int objnerf_adamw_step(int32_t K, int64_t P, int64_t p_stride, float* params, const float* grads, float* exp_avg,
+                       float* exp_avg_sq, const uint8_t* has_grad, int32_t step, float lr, float beta1, float beta2,
+                       float eps, float weight_decay, void* stream) {
+  if (K <= 0 || P <= 0 || p_stride < P || !params || !grads || !exp_avg || !exp_avg_sq || step < 1)
+    return OBJNERF_EINVAL;
+  // scalars exactly as torch.optim.adamw._single_tensor_adamw forms them (python doubles -> fp32 op)
+  const double lr_d = (double)lr, b1 = (double)beta1, b2 = (double)beta2, wd = (double)weight_decay;
+  const double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
+  const float decay = (float)(1.0 - lr_d * wd);
+  const float w1 = (float)(1.0 - b1), w2 = (float)(1.0 - b2);
+  const float step_size = (float)(lr_d / bc1), bc2_sqrt = (float)sqrt(bc2);
+  dim3 grid((unsigned)((P + 255) / 256), (unsigned)K);
+  hipLaunchKernelGGL(adamw_kernel, grid, dim3(256), 0, (hipStream_t)stream, (long)P, (long)p_stride, params, grads,
+                     exp_avg, exp_avg_sq, has_grad, decay, w1, beta2, w2, step_size, bc2_sqrt, eps);
+  CHECK_LAUNCH();
+  return OBJNERF_OK;
+}
+
+int objnerf_rays_dirs(int32_t W, int32_t H, float fx, float fy, float cx, float cy, float* out, void* stream) {
+  if (W <= 0 || H <= 0 || !out) return OBJNERF_EINVAL;
+  const long n = (long)W * H;
+  hipLaunchKernelGGL(rays_dirs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, H, fx,
+                     fy, cx, cy, out);
+  CHECK_LAUNCH();
+  return OBJNERF_OK;
+}
+
+int objnerf_sample_rays(const objnerf_sample_args* a, void* stream) {
+  if (!a || !a->rgbs || !a->depth || !a->t_wc || !a->bbox || !a->rays_dir_cache || !a->kf_ids || !a->u_w || !a->u_h ||
+      !a->u || !a->g || !a->out_rgb || !a->out_depth || !a->out_valid || !a->out_labels || !a->out_z || !a->out_pts ||
+      !a->max_depth_ws || a->n_frames <= 0 || a->n_px <= 0 || a->n_cam2surf <= 0 || a->n_bins <= 0)
+    return OBJNERF_EINVAL;
+  const int n = a->n_frames * a->n_px;
+  hipStream_t st = (hipStream_t)stream;
+  // origins / dirs of the sampled rays live in the tail of the pts output until pass 2 consumes them:
+  // pts has n*S*3 floats with S >= 2, pass 2 reads ray i's 6 floats before writing ray i's points.
+  float* ws = a->max_depth_ws + 1;
+  hipMemsetAsync(a->max_depth_ws, 0, sizeof(float), st);
+  hipLaunchKernelGGL(sample_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, st, *a, ws, ws + (size_t)n * 3);
+  CHECK_LAUNCH();
+  hipLaunchKernelGGL(sample_place_kernel, dim3((n + 255) / 256), dim3(256), 0, st, *a, ws, ws + (size_t)n * 3);
+  CHECK_LAUNCH();
+  return OBJNERF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,306 @@
+"""Thin tensor-level wrappers over the C ABI (include/objnerf_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; all arithmetic of the path runs in
+libobjnerf_hip.so.  Every function requires CUDA(HIP) tensors and raises on anything else.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import LossArgs, Net, SampleArgs, TrainArgs, check, lib
+
+EMB1, EMB2, N_DIRS = 87, 42, 21
+TENSOR_NAMES = [
+    "in_layer.0.weight", "in_layer.0.bias", "mid1.0.0.weight", "mid1.0.0.bias",
+    "cat_layer.0.weight", "cat_layer.0.bias", "mid2.0.0.weight", "mid2.0.0.bias",
+    "out_alpha.weight", "out_alpha.bias", "color_linear.0.weight", "color_linear.0.bias",
+    "out_color.weight", "out_color.bias", "clip_linear.0.weight", "clip_linear.0.bias",
+    "out_clip.weight", "out_clip.bias", "B_layer.weight",
+]
+FEAT_TENSORS = (14, 15, 16, 17)
+
+
+def tensor_shapes(hidden: int, feat_dim: int = 512) -> List[Tuple[int, ...]]:
+    H, Cc = hidden, feat_dim
+    return [(H, EMB1), (H,), (H, H), (H,), (H, H + EMB1), (H,), (H, H), (H,), (1, H), (1,),
+            (H, EMB2 + H), (H,), (3, H), (3,), (H, EMB2 + H), (H,), (Cc, H), (Cc,), (N_DIRS, 3)]
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _req(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise _lib.ObjnerfError(f"{name}: expected a GPU tensor (there is no CPU path)")
+    if t.dtype != dtype:
+        raise _lib.ObjnerfError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        t = t.contiguous()
+    return t
+
+
+@dataclass
+class NetShape:
+    hidden: int = 32
+    feat_dim: int = 512
+    n_freqs: int = 6
+
+    def c(self) -> Net:
+        return Net(self.hidden, self.feat_dim, self.n_freqs, 0)
+
+
+class ParamArena:
+    """K networks in one object-major fp32 arena [K, p_stride] (+ same-layout grad / Adam buffers).
+
+    `views(buf)` returns the 19 stacked tensors the reference exposes after
+    functorch.combine_state_for_ensemble (utils.py:55-62) as strided views of the arena.
+    """
+
+    def __init__(self, K: int, net: NetShape, device):
+        self.K, self.net = K, net
+        self.offsets, self.p_stride = _lib.param_layout(net.hidden, net.feat_dim, net.n_freqs)
+        self.P = self.offsets[-1]
+        self.shapes = tensor_shapes(net.hidden, net.feat_dim)
+        self.params = torch.zeros(K, self.p_stride, dtype=torch.float32, device=device)
+        self.scale = torch.full((K,), 2.0, dtype=torch.float32, device=device)
+
+    def views(self, buf: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
+        buf = self.params if buf is None else buf
+        out = []
+        for i, shp in enumerate(self.shapes):
+            n = 1
+            for s in shp:
+                n *= s
+            out.append(buf[:, self.offsets[i]:self.offsets[i] + n].view(self.K, *shp))
+        return out
+
+    def load_stacked(self, tensors: Sequence[torch.Tensor]) -> None:
+        """tensors: 19 stacked [K,...] tensors (18 FC in parameters() order + B)."""
+        for v, t in zip(self.views(), tensors):
+            v.copy_(t.to(v.device))
+
+    def has_grad_mask(self, with_feat: bool) -> torch.Tensor:
+        m = torch.ones(self.P, dtype=torch.uint8, device=self.params.device)
+        if not with_feat:
+            m[self.offsets[14]:self.offsets[18]] = 0
+        return m
+
+
+# ---------------------------------------------------------------------------------------------------
+def eval_points(arena: ParamArena, pts: torch.Tensor, want_hfeat: bool = False, want_clip: bool = False):
+    """pts [K,N,3] -> alpha [K,N], color [K,N,3], hfeat [K,N,H] | None, clip [K,N,C] | None."""
+    pts = _req(pts, torch.float32, "pts")
+    K, N = pts.shape[0], pts.shape[1]
+    dev = pts.device
+    alpha = torch.empty(K, N, device=dev)
+    color = torch.empty(K, N, 3, device=dev)
+    hfeat = torch.empty(K, N, arena.net.hidden, device=dev) if (want_hfeat or want_clip) else None
+    clip = torch.empty(K, N, arena.net.feat_dim, device=dev) if want_clip else None
+    net = arena.net.c()
+    check(lib().objnerf_eval_points(C.byref(net), K, N, _ptr(arena.params), arena.p_stride, _ptr(arena.scale),
+                                    _ptr(pts), _ptr(alpha), _ptr(color), _ptr(hfeat), _ptr(clip), _stream()),
+          "objnerf_eval_points")
+    return alpha, color, hfeat, clip
+
+
+def embed(arena: ParamArena, pts: torch.Tensor) -> torch.Tensor:
+    pts = _req(pts, torch.float32, "pts")
+    K, N = pts.shape[0], pts.shape[1]
+    E = 3 + N_DIRS * arena.net.n_freqs
+    out = torch.empty(K, N, E, device=pts.device)
+    net = arena.net.c()
+    check(lib().objnerf_embed(C.byref(net), K, N, _ptr(arena.params), arena.p_stride, _ptr(arena.scale),
+                              _ptr(pts), _ptr(out), _stream()), "objnerf_embed")
+    return out
+
+
+def composite(alpha: torch.Tensor, color: Optional[torch.Tensor], z: torch.Tensor,
+              vals: Optional[torch.Tensor] = None, want_term: bool = False) -> Dict[str, torch.Tensor]:
+    """alpha [n,S], color [n,S,3], z [n,S], vals [n,S,V] -> term/depth/var/rgb/opacity/vals."""
+    alpha = _req(alpha, torch.float32, "alpha")
+    z = _req(z, torch.float32, "z")
+    n, S = alpha.shape
+    dev = alpha.device
+    if color is not None:
+        color = _req(color, torch.float32, "color")
+    V = 0
+    out_vals = None
+    if vals is not None:
+        vals = _req(vals, torch.float32, "vals")
+        V = vals.shape[-1]
+        out_vals = torch.empty(n, V, device=dev)
+    term = torch.empty(n, S, device=dev) if want_term else None
+    depth = torch.empty(n, device=dev)
+    var = torch.empty(n, device=dev)
+    rgb = torch.empty(n, 3, device=dev) if color is not None else None
+    opacity = torch.empty(n, device=dev)
+    check(lib().objnerf_composite(n, S, _ptr(alpha), _ptr(color), _ptr(z), _ptr(vals), V, _ptr(term), _ptr(depth),
+                                  _ptr(var), _ptr(rgb), _ptr(opacity), _ptr(out_vals), _stream()),
+          "objnerf_composite")
+    return dict(term=term, depth=depth, var=var, rgb=rgb, opacity=opacity, vals=out_vals)
+
+
+def feature_head(arena: ParamArena, hfeat: torch.Tensor, weight: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """hfeat [K,n,H] (+ weight [K,n]) -> [K,n,C] = out_clip(.) applied after compositing."""
+    hfeat = _req(hfeat, torch.float32, "hfeat")
+    K, n = hfeat.shape[0], hfeat.shape[1]
+    if weight is not None:
+        weight = _req(weight, torch.float32, "weight")
+    out = torch.empty(K, n, arena.net.feat_dim, device=hfeat.device)
+    net = arena.net.c()
+    check(lib().objnerf_feature_head(C.byref(net), K, n, _ptr(arena.params), arena.p_stride, _ptr(hfeat),
+                                     _ptr(weight), _ptr(out), _stream()), "objnerf_feature_head")
+    return out
+
+
+def label_counts(labels: torch.Tensor):
+    labels = _req(labels, torch.uint8, "labels")
+    K, R = labels.shape
+    counts = torch.empty(K, 2, dtype=torch.int32, device=labels.device)
+    flags = torch.empty(2, dtype=torch.int32, device=labels.device)
+    check(lib().objnerf_label_counts(K, R, _ptr(labels), _ptr(counts), _ptr(flags), _stream()),
+          "objnerf_label_counts")
+    return counts, flags
+
+
+def step_batch_loss(alpha, color, gt_depth, gt_rgb, labels, z, color_scaling=5.0, opacity_scaling=10.0,
+                    gt_feat=None, pred_feat=None, feat_scaling=5.0, want_grads=True, flags_in=None):
+    """loss.step_batch_loss on materialised tensors.  Returns dict(total, terms [K,4], d_alpha, d_color,
+    d_pred_feat, status)."""
+    alpha = _req(alpha, torch.float32, "alpha")
+    K, R, S = alpha.shape[0], alpha.shape[1], alpha.shape[2]
+    color = _req(color, torch.float32, "color")
+    z = _req(z, torch.float32, "z")
+    gt_depth = _req(gt_depth, torch.float32, "gt_depth")
+    gt_rgb = _req(gt_rgb, torch.float32, "gt_rgb")
+    labels = _req(labels, torch.uint8, "labels")
+    dev = alpha.device
+    Cc = 0
+    if gt_feat is not None:
+        gt_feat = _req(gt_feat, torch.float32, "gt_feat")
+        pred_feat = _req(pred_feat, torch.float32, "pred_feat")
+        Cc = gt_feat.shape[-1]
+    terms = torch.empty(K, 4, device=dev)
+    total = torch.empty(1, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    counts = torch.empty(2 * K + 2, dtype=torch.int32, device=dev)
+    d_alpha = torch.empty(K, R, S, device=dev) if want_grads else None
+    d_color = torch.empty(K, R, S, 3, device=dev) if want_grads else None
+    d_pf = torch.empty_like(pred_feat) if (want_grads and pred_feat is not None) else None
+    a = LossArgs(K, R, S, Cc, color_scaling, opacity_scaling, feat_scaling, 0.0, _ptr(alpha), _ptr(color), _ptr(z),
+                 _ptr(gt_depth), _ptr(gt_rgb), _ptr(labels), _ptr(pred_feat), _ptr(gt_feat), _ptr(flags_in),
+                 _ptr(terms), _ptr(total), _ptr(d_alpha), _ptr(d_color), _ptr(d_pf), _ptr(counts), _ptr(status))
+    check(lib().objnerf_step_batch_loss(C.byref(a), _stream()), "objnerf_step_batch_loss")
+    return dict(total=total, terms=terms, d_alpha=d_alpha, d_color=d_color, d_pred_feat=d_pf, status=status,
+                counts=counts)
+
+
+class TrainWorkspace:
+    """Caller-owned buffers of the fused training step, allocated once per (K,R,S)."""
+
+    def __init__(self, arena: ParamArena, K: int, R: int, S: int, with_feat: bool):
+        dev = arena.params.device
+        net = arena.net.c()
+        nbytes = lib().objnerf_train_workspace_bytes(C.byref(net), K, R, S, int(with_feat))
+        if nbytes == 0:
+            raise _lib.ObjnerfError("objnerf_train_workspace_bytes returned 0")
+        self.nbytes = int(nbytes)
+        self.buf = torch.empty(self.nbytes, dtype=torch.uint8, device=dev)
+        self.grads = torch.zeros_like(arena.params)
+        self.loss_terms = torch.zeros(K, 4, device=dev)
+        self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.counts = torch.zeros(K, 2, dtype=torch.int32, device=dev)
+        self.flags = torch.zeros(2, dtype=torch.int32, device=dev)
+        self.key = (K, R, S, with_feat)
+
+
+def train_step(arena: ParamArena, ws: TrainWorkspace, batch: Dict[str, torch.Tensor], color_scaling=5.0,
+               opacity_scaling=10.0, feat_scaling=5.0, with_feat=False, obj_center=0.0,
+               global_flags: Optional[torch.Tensor] = None) -> None:
+    """One fused iteration (train.py:424-472): fills ws.grads, ws.loss_terms, ws.status.
+
+    batch: pts [K,R,S,3] (or origins+dirs), z, gt_depth, gt_rgb, labels u8 (+ gt_feat when with_feat).
+    global_flags: optional [2] int32 tensor already max-reduced over all ranks (object sharding)."""
+    z = _req(batch["z"], torch.float32, "z")
+    K, R, S = z.shape
+    labels = _req(batch["labels"], torch.uint8, "labels")
+    pts = batch.get("pts")
+    pts = _req(pts, torch.float32, "pts") if pts is not None else None
+    origins = _req(batch["origins"], torch.float32, "origins") if pts is None else None
+    dirs = _req(batch["dirs"], torch.float32, "dirs") if pts is None else None
+    gt_depth = _req(batch["gt_depth"], torch.float32, "gt_depth")
+    gt_rgb = _req(batch["gt_rgb"], torch.float32, "gt_rgb")
+    gt_feat = _req(batch["gt_feat"], torch.float32, "gt_feat") if with_feat else None
+    st = _stream()
+    check(lib().objnerf_label_counts(K, R, _ptr(labels), _ptr(ws.counts), _ptr(ws.flags), st),
+          "objnerf_label_counts")
+    flags = ws.flags
+    if global_flags is not None:
+        flags = global_flags
+    net = arena.net.c()
+    a = TrainArgs(K, R, S, 0, color_scaling, opacity_scaling, feat_scaling, obj_center, _ptr(arena.params),
+                  arena.p_stride, _ptr(arena.scale), _ptr(pts), _ptr(origins), _ptr(dirs), _ptr(z), _ptr(gt_depth),
+                  _ptr(gt_rgb), _ptr(labels), _ptr(gt_feat), _ptr(ws.counts), _ptr(flags), _ptr(ws.grads),
+                  _ptr(ws.loss_terms), _ptr(ws.status), _ptr(ws.buf), ws.nbytes)
+    check(lib().objnerf_train_step(C.byref(net), C.byref(a), st), "objnerf_train_step")
+
+
+def adamw_step(arena: ParamArena, grads: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor,
+               has_grad: Optional[torch.Tensor], step: int, lr: float, weight_decay: float, beta1=0.9, beta2=0.999,
+               eps=1e-8, params: Optional[torch.Tensor] = None) -> None:
+    p = arena.params if params is None else params
+    check(lib().objnerf_adamw_step(arena.K, arena.P, arena.p_stride, _ptr(p), _ptr(grads), _ptr(exp_avg),
+                                   _ptr(exp_avg_sq), _ptr(has_grad), step, lr, beta1, beta2, eps, weight_decay,
+                                   _stream()), "objnerf_adamw_step")
+
+
+def rays_dirs(W: int, H: int, fx: float, fy: float, cx: float, cy: float, device) -> torch.Tensor:
+    out = torch.empty(W, H, 3, device=device)
+    check(lib().objnerf_rays_dirs(W, H, fx, fy, cx, cy, _ptr(out), _stream()), "objnerf_rays_dirs")
+    return out
+
+
+def sample_rays(rgbs_batch, depth_batch, t_wc_batch, bbox, rays_dir_cache, kf_ids, u_w, u_h, u, g,
+                n_cam2surf: int, n_bins: int, surface_eps: float, stop_eps: float, min_bound: float = 0.0,
+                obj_center: float = 0.0):
+    """sceneObject.get_training_samples + sample_3d_points with injected draws (vmap.py:386-554)."""
+    rgbs_batch = _req(rgbs_batch, torch.uint8, "rgbs_batch")
+    depth_batch = _req(depth_batch, torch.float32, "depth_batch")
+    t_wc_batch = _req(t_wc_batch, torch.float32, "t_wc_batch")
+    bbox = _req(bbox, torch.float32, "bbox")
+    rays_dir_cache = _req(rays_dir_cache, torch.float32, "rays_dir_cache")
+    kf_ids = _req(kf_ids, torch.int64, "kf_ids")
+    u_w = _req(u_w, torch.float32, "u_w")
+    u_h = _req(u_h, torch.float32, "u_h")
+    u = _req(u, torch.float32, "u")
+    g = _req(g, torch.float32, "g")
+    F, W, H = rgbs_batch.shape[0], rgbs_batch.shape[1], rgbs_batch.shape[2]
+    n_frames, n_px = u_w.shape
+    n = n_frames * n_px
+    S = n_cam2surf + n_bins
+    dev = rgbs_batch.device
+    out_rgb = torch.empty(n_frames, n_px, 3, dtype=torch.uint8, device=dev)
+    out_depth = torch.empty(n_frames, n_px, device=dev)
+    out_valid = torch.empty(n, dtype=torch.uint8, device=dev)
+    out_labels = torch.empty(n, dtype=torch.uint8, device=dev)
+    out_z = torch.empty(n_frames, n_px, S, device=dev)
+    out_pts = torch.empty(n_frames, n_px, S, 3, device=dev)
+    ws = torch.empty(1 + 6 * n, device=dev)
+    a = SampleArgs(F, W, H, n_frames, n_px, n_cam2surf, n_bins, 0, surface_eps, stop_eps, min_bound, obj_center,
+                   _ptr(rgbs_batch), _ptr(depth_batch), _ptr(t_wc_batch), _ptr(bbox), _ptr(rays_dir_cache),
+                   _ptr(kf_ids), _ptr(u_w), _ptr(u_h), _ptr(u), _ptr(g), _ptr(out_rgb), _ptr(out_depth),
+                   _ptr(out_valid), _ptr(out_labels), _ptr(out_z), _ptr(out_pts), _ptr(ws))
+    check(lib().objnerf_sample_rays(C.byref(a), _stream()), "objnerf_sample_rays")
+    return out_rgb, out_depth, out_valid.bool(), out_labels, out_pts, out_z

@@ -1,0 +1,281 @@
+"""GPU parity: the HIP path (through the C ABI) against the golden fixtures generated from the
+reference and against the CPU oracle on seeded inputs.  Tolerances: 1e-4 absolute on rendered
+outputs / losses (BASELINE.json north_star), tighter where the arithmetic allows; bit-exact for
+integer / index work."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import T
+from oracle import objnerf_oracle as O
+from openobj_amd import ops, synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def maxerr(a, b):
+    return (torch.as_tensor(a).double().cpu() - torch.as_tensor(b).double().cpu()).abs().max().item()
+
+
+def arena_from_fixture(g, dev, prefix="fc0_", bname="B0", scale=2.0, hidden=32):
+    K = g[bname].shape[0]
+    arena = ops.ParamArena(K, ops.NetShape(hidden=hidden), dev)
+    arena.load_stacked([T(g[f"{prefix}{i}"]) for i in range(18)] + [T(g[bname])])
+    arena.scale.fill_(scale)
+    return arena
+
+
+def to_dev(b, dev, keys):
+    return {k: T(b[k]).to(dev) for k in keys if k in b}
+
+
+# ------------------------------------------------------------------------------------------------
+def test_embed_g1(golden, dev):
+    g = golden("g1_embed")
+    for tag, scale in (("s2", 2.0), ("s5", 5.0)):
+        pts = T(g[f"pts_{tag}"])                       # [2,5,7,3] -> K=1, N=70
+        arena = ops.ParamArena(1, ops.NetShape(), dev)
+        arena.views()[18].copy_(T(g[f"B_{tag}"]).to(dev)[None])
+        arena.scale.fill_(scale)
+        emb = ops.embed(arena, pts.reshape(1, -1, 3).to(dev))
+        assert maxerr(emb.reshape(2, 5, 7, 129), g[f"emb_{tag}"]) < 2e-5   # arg ~ 1e2: 1 ulp(arg) ~ 1e-5
+
+
+def test_eval_points_vs_oracle(golden, dev):
+    g = golden("g5_step_s10_feat")
+    arena = arena_from_fixture(g, dev)
+    K = arena.K
+    rs = np.random.RandomState(5)
+    pts = torch.from_numpy(rs.uniform(-3, 3, (K, 333, 3)).astype(np.float32))
+    alpha, color, hfeat, clip = ops.eval_points(arena, pts.to(dev), want_clip=True)
+    fc = [T(g[f"fc0_{i}"]) for i in range(18)]
+    emb = O.embed_stacked(T(g["B0"]), torch.full((K,), 2.0), pts)
+    a, c, f = O.mlp_forward_stacked(fc, emb, True)
+    assert maxerr(alpha, a.squeeze(-1)) < 1e-4
+    assert maxerr(color, c) < 1e-5
+    assert maxerr(clip, f) < 1e-4
+
+
+def test_eval_points_g2_weights(golden, dev):
+    """G2 pins the MLP alone (given embeddings); here the same weights are driven through pts and
+    checked against the oracle, which test_oracle_golden pins to G2."""
+    g = golden("g2_mlp")
+    arena = ops.ParamArena(1, ops.NetShape(), dev)
+    arena.load_stacked([T(g[f"h32_p{i}"])[None] for i in range(18)] + [O.icosa_dirs()[None]])
+    pts = torch.from_numpy(np.random.RandomState(2).uniform(-2, 2, (1, 1000, 3)).astype(np.float32))
+    alpha, color, _, clip = ops.eval_points(arena, pts.to(dev), want_clip=True)
+    p = [T(g[f"h32_p{i}"]) for i in range(18)]
+    a, c, f = O.mlp_forward(p, O.unidirs_embed(pts[0], O.icosa_dirs(), 2.0))
+    assert maxerr(alpha[0], a.squeeze(-1)) < 1e-4
+    assert maxerr(color[0], c) < 1e-5
+    assert maxerr(clip[0], f) < 1e-4
+
+
+def test_composite_g3(golden, dev):
+    g = golden("g3_render")
+    K, R, S = g["alpha"].shape
+    out = ops.composite(T(g["alpha"]).reshape(-1, S).to(dev), T(g["color"]).reshape(-1, S, 3).to(dev),
+                        T(g["z"]).reshape(-1, S).to(dev), T(g["clip"]).reshape(K * R, S, -1).to(dev),
+                        want_term=True)
+    assert maxerr(out["term"].reshape(K, R, S), g["term_b"]) < 1e-6
+    assert maxerr(out["depth"].reshape(K, R), g["depth"]) < 1e-5
+    assert maxerr(out["var"].reshape(K, R), g["var"]) < 1e-5
+    assert maxerr(out["rgb"].reshape(K, R, 3), g["rgb"]) < 1e-6
+    assert maxerr(out["opacity"].reshape(K, R), g["opacity"]) < 1e-6
+    assert maxerr(out["vals"].reshape(K, R, -1), g["feat"]) < 1e-5
+
+
+def test_composite_long_ray(dev):
+    """S = 149 (render_2D_syn's 150 bins, trainer.py:141-178) crosses the 64-lane chunk boundary."""
+    rs = np.random.RandomState(9)
+    n, S = 37, 149
+    alpha = torch.from_numpy(rs.randn(n, S).astype(np.float32) * 4)
+    color = torch.from_numpy(rs.rand(n, S, 3).astype(np.float32))
+    z = torch.from_numpy(np.sort(rs.rand(n, S).astype(np.float32) * 5, axis=1))
+    out = ops.composite(alpha.to(dev), color.to(dev), z.to(dev), want_term=True)
+    term = O.occupancy_to_termination(O.occupancy_activation(alpha))
+    assert maxerr(out["term"], term) < 1e-6
+    assert maxerr(out["depth"], O.render(term, z)) < 1e-5
+    assert maxerr(out["rgb"], O.render(term[..., None], color, dim=-2)) < 1e-5
+
+
+@pytest.mark.parametrize("case", ["normal", "no_label1", "all_unknown"])
+@pytest.mark.parametrize("feat_on", [False, True])
+def test_step_batch_loss_g4(golden, dev, case, feat_on):
+    g = golden("g4_loss")
+    tag = f"{case}_{'feat' if feat_on else 'nofeat'}"
+    kw = dict(gt_feat=T(g["gt_feat"]).to(dev), pred_feat=T(g["clip"]).to(dev)) if feat_on else {}
+    out = ops.step_batch_loss(T(g["alpha"]).squeeze(-1).to(dev), T(g["color"]).to(dev), T(g["gt_depth"]).to(dev),
+                              T(g["gt_rgb"]).to(dev), T(g[f"labels_{case}"]).to(dev), T(g["z"]).to(dev), **kw)
+    assert abs(out["total"].item() - float(g[f"loss_{tag}"])) < 1e-4 * max(1.0, abs(float(g[f"loss_{tag}"])))
+    assert maxerr(out["d_alpha"], g[f"dalpha_{tag}"].squeeze(-1)) < 1e-5
+    assert maxerr(out["d_color"], g[f"dcolor_{tag}"]) < 1e-5
+    if feat_on:
+        assert maxerr(out["d_pred_feat"], g[f"dclip_{tag}"]) < 1e-5
+    assert int(out["status"].item()) == 0
+
+
+def _hip_step(arena, ws, b, dev, with_feat=False):
+    keys = ["pts", "z", "gt_depth", "gt_rgb", "labels"] + (["gt_feat"] if with_feat else [])
+    ops.train_step(arena, ws, to_dev(b, dev, keys), with_feat=with_feat)
+    torch.cuda.synchronize()
+
+
+def test_train_step_g5_grads(golden, dev):
+    """One fused iteration == reference loss and gradients of every stacked tensor (train.py:424-472)."""
+    g = golden("g5_step_s10_nofeat")
+    K, R, n1, n2, feat_on = [int(x) for x in g["meta"]]
+    arena = arena_from_fixture(g, dev)
+    ws = ops.TrainWorkspace(arena, K, R, n1 + n2, False)
+    b = synthetic.random_batch(K, R, n1, n2, seed=500, feat_dim=512)
+    _hip_step(arena, ws, b, dev)
+    terms = ws.loss_terms.cpu()
+    total = (terms[:, 0] + 5 * terms[:, 1] + 10 * terms[:, 2]).sum().item()
+    assert abs(total - g["loss"][0]) < 1e-4 * abs(g["loss"][0])
+    gv = arena.views(ws.grads)
+    for i in range(19):
+        if i in ops.FEAT_TENSORS:
+            continue
+        ref = g[f"grad0_{i}"]
+        scale = max(1e-3, float(np.abs(ref).max()))
+        assert maxerr(gv[i], ref) < 1e-4 * scale, (i, ops.TENSOR_NAMES[i], maxerr(gv[i], ref), scale)
+    assert int(ws.status.item()) == 0
+
+
+def test_train_three_steps_g6_adamw(golden, dev):
+    """3 iterations of fused step + AdamW == reference params and Adam moments (G6)."""
+    g = golden("g5_step_s10_nofeat")
+    K, R, n1, n2, _ = [int(x) for x in g["meta"]]
+    arena = arena_from_fixture(g, dev)
+    ws = ops.TrainWorkspace(arena, K, R, n1 + n2, False)
+    m = torch.zeros_like(arena.params)
+    v = torch.zeros_like(arena.params)
+    mask = arena.has_grad_mask(False)
+    for it in range(3):
+        b = synthetic.random_batch(K, R, n1, n2, seed=500 + it, feat_dim=512)
+        _hip_step(arena, ws, b, dev)
+        ops.adamw_step(arena, ws.grads, m, v, mask, it + 1, 1e-3, 0.013)
+        pv = arena.views()
+        for i in range(19):
+            assert maxerr(pv[i], g[f"param{it}_{i}"]) < 5e-6, (it, i)
+    mv, vv = arena.views(m), arena.views(v)
+    for i in range(19):
+        if i in ops.FEAT_TENSORS:
+            assert float(mv[i].abs().max()) == 0.0          # no grad -> no update, no decay
+            continue
+        assert maxerr(mv[i], g[f"m_{i}"]) < 1e-4 * max(1e-3, float(np.abs(g[f"m_{i}"]).max()))
+        assert maxerr(vv[i], g[f"v_{i}"]) < 1e-4 * max(1e-6, float(np.abs(g[f"v_{i}"]).max()))
+
+
+@pytest.mark.parametrize("shape", [(2, 40, 16, 48), (3, 70, 5, 9), (1, 256, 8, 24), (5, 33, 1, 9)])
+def test_train_step_vs_oracle(golden, dev, shape):
+    """Metric-shaped (S=64), background-shaped (S=14), c1 (S=32) and native (S=10) batches with ragged
+    ray counts, against oracle autograd."""
+    K, R, n1, n2 = shape
+    g = golden("g9_psnr_nofeat")
+    fc = [T(g[f"fc0_{i}"])[:1].repeat(K, *([1] * (T(g[f"fc0_{i}"]).dim() - 1))).clone() for i in range(18)]
+    gen = torch.Generator().manual_seed(K * 100 + R)
+    fc = [p + 0.05 * torch.randn(p.shape, generator=gen) * p.abs().mean() for p in fc]
+    B = O.icosa_dirs()[None].repeat(K, 1, 1) + 0.01 * torch.randn(K, 21, 3, generator=gen)
+    arena = ops.ParamArena(K, ops.NetShape(), dev)
+    arena.load_stacked(fc + [B])
+    ws = ops.TrainWorkspace(arena, K, R, n1 + n2, False)
+    b = synthetic.random_batch(K, R, n1, n2, seed=77 + R)
+    _hip_step(arena, ws, b, dev)
+    fcr = [p.clone().requires_grad_(True) for p in fc]
+    Br = B.clone().requires_grad_(True)
+    loss, terms = O.train_forward_loss(fcr, Br, torch.full((K,), 2.0), T(b["pts"]), T(b["gt_depth"]), T(b["gt_rgb"]),
+                                       T(b["labels"]), T(b["z"]), return_terms=True)
+    grads = torch.autograd.grad(loss, fcr + [Br], allow_unused=True)
+    t = ws.loss_terms.cpu()
+    assert maxerr(t[:, 0], terms["depth"]) < 1e-4 * max(1.0, float(terms["depth"].abs().max()))
+    assert maxerr(t[:, 1], terms["color"]) < 1e-4
+    assert maxerr(t[:, 2], terms["opacity"]) < 1e-4
+    gv = arena.views(ws.grads)
+    for i in range(19):
+        if grads[i] is None:
+            continue
+        scale = max(1e-3, float(grads[i].abs().max()))
+        assert maxerr(gv[i], grads[i]) < 2e-4 * scale, (i, ops.TENSOR_NAMES[i], maxerr(gv[i], grads[i]), scale)
+
+
+def test_train_step_early_return_flags(golden, dev):
+    """An object without a label-1 ray zeroes depth/colour for ALL objects (render_rays.py:89-94)."""
+    g = golden("g5_step_s10_nofeat")
+    K, R, n1, n2, _ = [int(x) for x in g["meta"]]
+    arena = arena_from_fixture(g, dev)
+    ws = ops.TrainWorkspace(arena, K, R, n1 + n2, False)
+    b = synthetic.random_batch(K, R, n1, n2, seed=500)
+    b["labels"][1][b["labels"][1] == 1] = 0
+    _hip_step(arena, ws, b, dev)
+    t = ws.loss_terms.cpu()
+    assert float(t[:, 0].abs().max()) == 0.0 and float(t[:, 1].abs().max()) == 0.0
+    assert float(t[:, 2].abs().min()) > 0.0
+    fc = [T(g[f"fc0_{i}"]).clone().requires_grad_(True) for i in range(18)]
+    Bq = T(g["B0"]).clone().requires_grad_(True)
+    loss, _ = O.train_forward_loss(fc, Bq, torch.full((K,), 2.0), T(b["pts"]), T(b["gt_depth"]), T(b["gt_rgb"]),
+                                   T(b["labels"]), T(b["z"]))
+    assert abs((10 * t[:, 2]).sum().item() - loss.item()) < 1e-4 * abs(loss.item())
+
+
+def test_train_step_origins_dirs_equals_pts(golden, dev):
+    g = golden("g5_step_s10_nofeat")
+    K, R, n1, n2, _ = [int(x) for x in g["meta"]]
+    arena = arena_from_fixture(g, dev)
+    ws = ops.TrainWorkspace(arena, K, R, n1 + n2, False)
+    b = synthetic.random_batch(K, R, n1, n2, seed=500)
+    _hip_step(arena, ws, b, dev)
+    g1 = ws.grads.clone()
+    b2 = dict(b)
+    del b2["pts"]
+    ops.train_step(arena, ws, to_dev(b2, dev, ["origins", "dirs", "z", "gt_depth", "gt_rgb", "labels"]))
+    torch.cuda.synchronize()
+    assert torch.equal(g1, ws.grads)
+
+
+@pytest.mark.parametrize("tag", ["obj", "bg", "metric"])
+def test_sampler_g7(golden, dev, tag):
+    """sample_3d_points through the gather kernel with identity gather (F frames of P pixels)."""
+    g = golden("g7_sample")
+    N, M = [int(x) for x in g[f"{tag}_NM"]]
+    rgbs = T(g[f"{tag}_rgbs"])           # [F,P,4]
+    F_, P = rgbs.shape[:2]
+    # lay the F*P rays out as a [F][W=P][H=1] keyframe buffer sampled with u_w = (p+0.5)/P, identity pose
+    depth = T(g[f"{tag}_depth"])
+    t_wc = torch.eye(4).repeat(F_, 1, 1)
+    t_wc[:, :3, 3] = T(g[f"{tag}_origins"])
+    dirs = T(g[f"{tag}_dirs"])           # per-ray world dirs: feed through a per-frame dir cache is impossible,
+    # so this case checks z only (pts are checked in test_get_training_samples_g7)
+    bbox = torch.tensor([[0.0, float(P), 0.0, 1.0]]).repeat(F_, 1)
+    u_w = ((torch.arange(P) + 0.5) / P)[None].repeat(F_, 1)
+    u_h = torch.zeros(F_, P)
+    cache = torch.ones(P, 1, 3)
+    out = ops.sample_rays(rgbs.reshape(F_, P, 1, 4).to(dev), depth.reshape(F_, P, 1).to(dev), t_wc.to(dev),
+                          bbox.to(dev), cache.to(dev), torch.arange(F_).to(dev), u_w.to(dev), u_h.to(dev),
+                          T(g[f"{tag}_u"]).to(dev), T(g[f"{tag}_g"]).to(dev), N, M, 0.1, 0.05)
+    rgb, d, valid, labels, pts, z = out
+    assert torch.equal(labels.cpu(), T(g[f"{tag}_labels"]))
+    assert torch.equal(valid.cpu(), T(g[f"{tag}_valid"]))
+    assert torch.equal(z.cpu(), T(g[f"{tag}_z"]))          # bit-exact z placement
+
+
+def test_get_training_samples_g7(golden, dev):
+    g = golden("g7_sample")
+    out = ops.sample_rays(T(g["gts_rgbs_batch"]).to(dev), T(g["gts_depth_batch"]).to(dev), T(g["gts_t_wc"]).to(dev),
+                          T(g["gts_bbox"]).to(dev), T(g["gts_rays_dir_cache"]).to(dev), T(g["gts_kf_ids"]).to(dev),
+                          T(g["gts_u_w"]).to(dev), T(g["gts_u_h"]).to(dev), T(g["gts_u"]).to(dev),
+                          T(g["gts_g"]).to(dev), 1, 9, 0.1, 0.05)
+    rgb, d, valid, labels, pts, z = out
+    assert torch.equal(rgb.cpu(), T(g["gts_rgb"]))
+    assert torch.equal(d.cpu(), T(g["gts_depth"]))
+    assert torch.equal(labels.cpu(), T(g["gts_labels"]))
+    assert torch.equal(valid.cpu(), T(g["gts_valid"]))
+    assert torch.equal(z.cpu(), T(g["gts_z"]))
+    assert maxerr(pts, g["gts_pts"]) < 2e-6
+
+
+def test_rays_dirs_g7(golden, dev):
+    g = golden("g7_sample")
+    W, H, fx, fy, cx, cy = [float(x) for x in g["gts_cam"]]
+    out = ops.rays_dirs(int(W), int(H), fx, fy, cx, cy, dev)
+    assert torch.equal(out.cpu(), T(g["gts_rays_dir_cache"]))
