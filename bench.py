@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Throughput bench of the hot path: training rays/s of the vectorised object-NeRF iteration.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one complete training iteration of train.py:394-474 for the K_obj stacked object
+networks of THIS rank (label statistics -> fused forward/loss/backward kernel -> gradient finalize ->
+AdamW), inputs already resident in HBM.  Workload (BASELINE.json configs[1]): 50 objects per GPU,
+hidden 32, 64 samples per ray (n_bins_cam2surface 16 + n_bins 48), RGB + depth + opacity loss,
+synthetic Replica-shaped rays (openobj_amd.synthetic.random_batch), reference-initialised weights.
+Objects shard across ranks with no data-path collective (the per-step early-return flags are a
+2-int all-reduce); scaling is weak: every rank trains its own 50 objects.
+
+Prints ONE JSON line (rank 0).  `roofline` is the fused kernel against the dense fp32 MFMA peak,
+`cpu_baseline` is the oracle (the reference's op sequence in PyTorch on the host cores) on a bounded
+sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from openobj_amd import init as obj_init  # noqa: E402
+from openobj_amd import ops, synthetic    # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+
+
+def flop_per_ray(S: int, H: int = 32, feat: bool = False) -> float:
+    """Algorithmic training FLOP per ray, SURVEY.md section 8(d): 3 * 2 * (S * M_s [+ 512 H])."""
+    ms = 63 + (5 * H * H + 262 * H if feat else 4 * H * H + 220 * H)
+    return 3.0 * 2.0 * (S * ms + (512 * H if feat else 0))
+
+
+def cpu_baseline(K, R, n1, n2, seed, steps=2):
+    """Oracle = the reference's op sequence (vmap(pe) -> vmap(fc) -> step_batch_loss -> backward -> AdamW),
+    fp32, on the host cores.  Bounded sample: same K, S, H; fewer rays per object."""
+    from oracle import objnerf_oracle as O
+    stacked = obj_init.init_stacked(K, 32, 512, seed=0)
+    fc = [p.clone().requires_grad_(True) for p in stacked[:18]]
+    B = stacked[18].clone().requires_grad_(True)
+    params = fc + [B]
+    m = [torch.zeros_like(p) for p in params]
+    v = [torch.zeros_like(p) for p in params]
+    b = synthetic.random_batch(K, R, n1, n2, seed=seed)
+    tb = {k: torch.from_numpy(b[k]) for k in ["pts", "gt_depth", "gt_rgb", "labels", "z"]}
+    scale = torch.full((K,), 2.0)
+    times = []
+    for it in range(steps + 1):
+        t0 = time.perf_counter()
+        loss, _ = O.train_forward_loss(fc, B, scale, tb["pts"], tb["gt_depth"], tb["gt_rgb"], tb["labels"], tb["z"])
+        grads = torch.autograd.grad(loss, params, allow_unused=True)
+        with torch.no_grad():
+            for p, g, mm, vv in zip(params, grads, m, v):
+                if g is not None:
+                    O.adamw_step(p, g, mm, vv, it + 1, 1e-3, 0.013)
+        times.append(time.perf_counter() - t0)
+    t = float(np.median(times[1:]))
+    return dict(value=K * R / t, unit="rays/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"K={K} objects x R={R} rays x S={n1 + n2} samples, hidden 32, {steps} timed steps, "
+                       f"{t * 1e3:.0f} ms/step (oracle/objnerf_oracle.py, torch {torch.__version__} CPU fp32)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--objects", type=int, default=50, help="object networks per GPU")
+    ap.add_argument("--rays", type=int, default=4096, help="rays per object per step")
+    ap.add_argument("--n-cam2surf", type=int, default=16)
+    ap.add_argument("--n-bins", type=int, default=48)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rays", type=int, default=192)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    K, R, n1, n2 = args.objects, args.rays, args.n_cam2surf, args.n_bins
+    S = n1 + n2
+    arena = ops.ParamArena(K, ops.NetShape(), dev)
+    arena.load_stacked(obj_init.init_stacked(K, 32, 512, seed=1000 + rank))
+    ws = ops.TrainWorkspace(arena, K, R, S, False)
+    m = torch.zeros_like(arena.params)
+    v = torch.zeros_like(arena.params)
+    mask = arena.has_grad_mask(False)
+    keys = ["pts", "z", "gt_depth", "gt_rgb", "labels"]
+    batches = []
+    for i in range(2):      # two resident batches, alternated, so no step re-reads its own outputs
+        b = synthetic.random_batch(K, R, n1, n2, seed=4242 + 17 * rank + i)
+        batches.append({k: torch.from_numpy(b[k]).to(dev) for k in keys})
+    gflags = torch.zeros(2, dtype=torch.int32, device=dev)
+
+    step_no = [0]
+
+    def step(i):
+        from openobj_amd import _lib
+        import ctypes as C
+        b = batches[i & 1]
+        if world > 1:
+            # the early return of render_rays.py:89-94 spans every object of the batch -> global flags
+            _lib.check(_lib.lib().objnerf_label_counts(K, R, b["labels"].data_ptr(), ws.counts.data_ptr(),
+                                                      gflags.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                       "label_counts")
+            dist.all_reduce(gflags, op=dist.ReduceOp.MAX)
+            ops.train_step(arena, ws, b, global_flags=gflags)
+        else:
+            ops.train_step(arena, ws, b)
+        step_no[0] += 1
+        ops.adamw_step(arena, ws.grads, m, v, mask, step_no[0], 1e-3, 0.013)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # dominant kernel alone: HIP events on the launch stream around objnerf_train_step
+    # (fused kernel + finalize; the finalize is <1 % of it)
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    nk = max(5, min(args.steps, 20))
+    ev0.record()
+    for i in range(nk):
+        ops.train_step(arena, ws, batches[i & 1])
+    ev1.record()
+    torch.cuda.synchronize()
+    kern_ms = ev0.elapsed_time(ev1) / nk
+    status = int(ws.status.item())
+
+    if rank == 0:
+        rays_per_step = K * R * world
+        value = rays_per_step * args.steps / dt
+        fpr = flop_per_ray(S)
+        achieved = K * R * fpr / (kern_ms * 1e-3) / 1e12
+        out = {
+            "metric": "training rays/sec/GPU @64 samples/ray, 50 obj; PSNR delta vs ref",
+            "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"Replica room_0-shaped, {K} object MLPs/GPU (hidden 32), {R} rays/object/step, "
+                                   f"{S} samples/ray ({n1}+{n2}), RGB+depth+opacity loss, fused fwd+loss+bwd+AdamW",
+                       "objects_per_gpu": K, "rays_per_object": R, "samples_per_ray": S, "hidden": 32,
+                       "feature_head": False, "parallelism": f"objects sharded x{world}",
+                       "loss_status": status},
+            "rays_per_sec_per_gpu": value / world,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "train_fused_kernel<false>", "kernel_ms": kern_ms,
+                         "flop_per_ray": fpr},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(K, args.cpu_rays, n1, n2, seed=4242)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -10,6 +10,11 @@ import ctypes as C
 import os
 from typing import Optional
 
+# torch must be imported BEFORE libobjnerf_hip.so is dlopen'ed: the torch wheel bundles its own
+# libamdhip64.so.7 and both must share ONE HIP runtime in the process (streams, device pointers).
+# Loading ours first would bind /opt/rocm's runtime and kernel launches on torch's streams fail.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libobjnerf_hip.so")
 

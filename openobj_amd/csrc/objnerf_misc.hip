@@ -408,12 +408,16 @@ __global__ void sample_place_kernel(const objnerf_sample_args a, const float* or
 }  // namespace
 
 #define CHECK_LAUNCH() do { if (hipGetLastError() != hipSuccess) return OBJNERF_ELAUNCH; } while (0)
+// a stale non-sticky error of another HIP user of this thread (e.g. hipErrorNotReady from event polling)
+// must not be mistaken for a launch failure
+#define CLEAR_STALE() (void)hipGetLastError()
 
 extern "C" {
 
 int objnerf_composite(int64_t n_rays, int32_t S, const float* alpha, const float* color, const float* z,
                       const float* vals, int32_t V, float* out_term, float* out_depth, float* out_var, float* out_rgb,
                       float* out_opacity, float* out_vals, void* stream) {
+  CLEAR_STALE();
   if (n_rays <= 0 || S <= 0 || !alpha || !z) return OBJNERF_EINVAL;
   if (S > 4096) return OBJNERF_ENOTSUP;
   hipLaunchKernelGGL(composite_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), (size_t)4 * S * 4,
@@ -425,6 +429,7 @@ int objnerf_composite(int64_t n_rays, int32_t S, const float* alpha, const float
 
 int objnerf_feature_head(const objnerf_net* net, int32_t K, int64_t n, const float* params, int64_t p_stride,
                          const float* hfeat, const float* weight, float* out, void* stream) {
+  CLEAR_STALE();
   if (!net || !params || !hfeat || !out || K <= 0 || n <= 0) return OBJNERF_EINVAL;
   if (net->hidden > 128) return OBJNERF_ENOTSUP;
   int64_t offs[OBJNERF_N_TENSORS + 1];
@@ -439,6 +444,7 @@ int objnerf_feature_head(const objnerf_net* net, int32_t K, int64_t n, const flo
 
 int objnerf_embed(const objnerf_net* net, int32_t K, int64_t N, const float* params, int64_t p_stride,
                   const float* scale, const float* pts, float* out_emb, void* stream) {
+  CLEAR_STALE();
   if (!net || !params || !scale || !pts || !out_emb || K <= 0 || N <= 0) return OBJNERF_EINVAL;
   int64_t offs[OBJNERF_N_TENSORS + 1];
   if (objnerf_param_layout(net, offs) < 0) return OBJNERF_EINVAL;
@@ -451,6 +457,7 @@ int objnerf_embed(const objnerf_net* net, int32_t K, int64_t N, const float* par
 
 int objnerf_label_counts(int32_t K, int32_t R, const uint8_t* labels, int32_t* counts, int32_t* flags_out,
                          void* stream) {
+  CLEAR_STALE();
   if (K <= 0 || R <= 0 || !labels || !counts || !flags_out) return OBJNERF_EINVAL;
   hipMemsetAsync(flags_out, 0, 2 * sizeof(int), (hipStream_t)stream);
   hipLaunchKernelGGL(label_counts_kernel, dim3(K), dim3(256), 0, (hipStream_t)stream, K, R, labels, counts, flags_out);
@@ -459,6 +466,7 @@ int objnerf_label_counts(int32_t K, int32_t R, const uint8_t* labels, int32_t* c
 }
 
 int objnerf_step_batch_loss(const objnerf_loss_args* a, void* stream) {
+  CLEAR_STALE();
   if (!a || !a->alpha || !a->color || !a->z || !a->gt_depth || !a->gt_rgb || !a->labels || !a->loss_terms ||
       !a->counts || a->K <= 0 || a->R <= 0 || a->S <= 0)
     return OBJNERF_EINVAL;
@@ -488,6 +496,7 @@ int objnerf_step_batch_loss(const objnerf_loss_args* a, void* stream) {
 int objnerf_adamw_step(int32_t K, int64_t P, int64_t p_stride, float* params, const float* grads, float* exp_avg,
                        float* exp_avg_sq, const uint8_t* has_grad, int32_t step, float lr, float beta1, float beta2,
                        float eps, float weight_decay, void* stream) {
+  CLEAR_STALE();
   if (K <= 0 || P <= 0 || p_stride < P || !params || !grads || !exp_avg || !exp_avg_sq || step < 1)
     return OBJNERF_EINVAL;
   // scalars exactly as torch.optim.adamw._single_tensor_adamw forms them (python doubles -> fp32 op)
@@ -504,6 +513,7 @@ int objnerf_adamw_step(int32_t K, int64_t P, int64_t p_stride, float* params, co
 }
 
 int objnerf_rays_dirs(int32_t W, int32_t H, float fx, float fy, float cx, float cy, float* out, void* stream) {
+  CLEAR_STALE();
   if (W <= 0 || H <= 0 || !out) return OBJNERF_EINVAL;
   const long n = (long)W * H;
   hipLaunchKernelGGL(rays_dirs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, H, fx,
@@ -513,6 +523,7 @@ int objnerf_rays_dirs(int32_t W, int32_t H, float fx, float fy, float cx, float 
 }
 
 int objnerf_sample_rays(const objnerf_sample_args* a, void* stream) {
+  CLEAR_STALE();
   if (!a || !a->rgbs || !a->depth || !a->t_wc || !a->bbox || !a->rays_dir_cache || !a->kf_ids || !a->u_w || !a->u_h ||
       !a->u || !a->g || !a->out_rgb || !a->out_depth || !a->out_valid || !a->out_labels || !a->out_z || !a->out_pts ||
       !a->max_depth_ws || a->n_frames <= 0 || a->n_px <= 0 || a->n_cam2surf <= 0 || a->n_bins <= 0)

@@ -493,6 +493,7 @@ size_t objnerf_train_workspace_bytes(const objnerf_net* net, int32_t K, int32_t 
 }
 
 int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void* stream) {
+  (void)hipGetLastError();   // drop stale non-sticky errors of other HIP users
   if (!net || !a || !a->params || !a->scale || !a->z || !a->gt_depth || !a->gt_rgb || !a->labels || !a->counts ||
       !a->flags || !a->grads || !a->loss_terms || !a->status || !a->workspace)
     return OBJNERF_EINVAL;
@@ -554,6 +555,7 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
 int objnerf_eval_points(const objnerf_net* net, int32_t K, int64_t N, const float* params, int64_t p_stride,
                         const float* scale, const float* pts, float* out_alpha, float* out_color, float* out_hfeat,
                         float* out_clip, void* stream) {
+  (void)hipGetLastError();   // drop stale non-sticky errors of other HIP users
   if (!net || !params || !scale || !pts || !out_alpha || !out_color || K <= 0 || N <= 0) return OBJNERF_EINVAL;
   if (net->hidden != 32 || net->n_freqs != 6) return OBJNERF_ENOTSUP;
   if (out_clip && !out_hfeat) return OBJNERF_EINVAL;   // the head runs on the H-wide hidden

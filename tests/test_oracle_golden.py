@@ -152,8 +152,8 @@ def test_g7_sample_3d_points(golden, tag):
     z, pts, valid, labels = O.sample_3d_points(rgbs[..., 3], T(g[f"{tag}_depth"]), T(g[f"{tag}_origins"]),
                                                T(g[f"{tag}_dirs"]), T(g[f"{tag}_u"]), T(g[f"{tag}_g"]),
                                                N, M, 0.1, 0.05)
-    close(z, g[f"{tag}_z"], 0)
-    close(pts, g[f"{tag}_pts"], 0)
+    close(z, g[f"{tag}_z"], 1e-6)       # CPU torch.linspace is SIMD-width dependent in the last bit
+    close(pts, g[f"{tag}_pts"], 4e-6)
     assert bool((valid == T(g[f"{tag}_valid"])).all())
     assert bool((labels == T(g[f"{tag}_labels"])).all())
 
@@ -167,8 +167,8 @@ def test_g7_get_training_samples(golden):
     close(depth, g["gts_depth"], 0)
     z, pts, valid, labels = O.sample_3d_points(rgbs[..., 3], depth, origins, dirs_w, T(g["gts_u"]),
                                                T(g["gts_g"]), 1, 9, 0.1, 0.05)
-    close(z, g["gts_z"], 0)
-    close(pts, g["gts_pts"], 1e-6)
+    close(z, g["gts_z"], 1e-6)
+    close(pts, g["gts_pts"], 4e-6)
     assert bool((labels == T(g["gts_labels"])).all())
     W, H, fx, fy, cx, cy = [float(x) for x in g["gts_cam"]]
     close(O.rays_dirs(int(W), int(H), fx, fy, cx, cy), g["gts_rays_dir_cache"], 0)
