@@ -104,6 +104,12 @@ int objnerf_eval_points(const objnerf_net* net, int32_t K, int64_t N, const floa
                         int64_t p_stride, const float* scale, const float* pts, float* out_alpha,
                         float* out_color, float* out_hfeat, float* out_clip, void* stream);
 
+/* A7 alone: OccupancyMap.forward on a caller-supplied embedding emb [K][N][129] (model.py:61-103, the
+ * call vmap(fc_model)(fc_param, fc_buffer, batch_embedding) of train.py:425).  Outputs as above. */
+int objnerf_mlp_forward(const objnerf_net* net, int32_t K, int64_t N, const float* params,
+                        int64_t p_stride, const float* emb, float* out_alpha, float* out_color,
+                        float* out_hfeat, float* out_clip, void* stream);
+
 /* A6 alone: emb [K][N][3+21*n_freqs]. */
 int objnerf_embed(const objnerf_net* net, int32_t K, int64_t N, const float* params,
                   int64_t p_stride, const float* scale, const float* pts, float* out_emb,

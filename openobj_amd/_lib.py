@@ -81,6 +81,9 @@ SIGNATURES = {
     "objnerf_eval_points": (C.c_int, [C.POINTER(Net), C.c_int32, C.c_int64, C.c_void_p, C.c_int64,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p]),
+    "objnerf_mlp_forward": (C.c_int, [C.POINTER(Net), C.c_int32, C.c_int64, C.c_void_p, C.c_int64,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p]),
     "objnerf_embed": (C.c_int, [C.POINTER(Net), C.c_int32, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                 C.c_void_p, C.c_void_p, C.c_void_p]),
     "objnerf_composite": (C.c_int, [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

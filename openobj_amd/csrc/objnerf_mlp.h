@@ -1,34 +1,43 @@
-// Per-object MLP (hidden = 32) on gfx950: LDS weight image, register-resident forward chain and
-// its backward (dgrad in registers, wgrad through an LDS transpose) on v_mfma_f32_32x32x2_f32.
+// Per-object MLP (hidden = 32) on gfx950: LDS weight image, register-resident forward chain and its
+// backward on v_mfma_f32_16x16x4_f32 (exact fp32; C/D: col = lane & 15, row = 4*(lane >> 4) + reg).
 //
-// Reference math: OccupancyMap.forward (model.py:61-103) on UniDirsEmbed.forward
-// (embedding.py:46-55).  Biases of in/cat/color/feature layers ride along as an extra weight
-// column against a constant-1 embedding row; mid1/mid2 biases initialise the accumulator.
+// "D16 layout": a 32(feature) x 16(sample) fp32 block lives in one wave64 as 8 registers per lane:
+// lane l = (c = l & 15 sample column, g = l >> 4), T32.t[tt][r] <-> feature 16*tt + 4*g + r.  A layer's
+// output block is directly the B operand of the next layer's MFMAs (k-step (tt, r) consumes register
+// (tt, r); the A operand supplies the weight column of the same feature), so activations never leave
+// registers between layers, and a wave needs only 8 registers per activation -- two waves per SIMD fit.
+//
+// Reference math: OccupancyMap.forward (model.py:61-103) on UniDirsEmbed.forward (embedding.py:46-55).
+// Biases of in/cat/color/feature layers ride along as an extra weight column against a constant-1
+// embedding row; mid1/mid2 biases initialise the accumulator.
 #pragma once
 #include "objnerf_device.h"
 
 namespace obj32 {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 constexpr int H = 32;
-// LDS weight image (float offsets); row strides are odd so the 32 output rows hit 32 banks.
-constexpr int ST_IN = 89;    // [32][89]  cols 0..86 W_in, 87 bias, 88 zero
-constexpr int ST_M = 33;     // [32][33]
-constexpr int ST_CAT = 121;  // [32][121] cols 0..31 (h2) | 32..118 (x1) | 119 bias | 120 zero
-constexpr int ST_CL = 81;    // [32][81]  cols 0..31 (h4) | 32..73 (x2) | 74 bias | 75..80 zero
+// LDS weight image (float offsets).  Row strides are = 3 (mod 8): forward (row = lane) and transposed
+// (column = lane) A-operand reads are then at most 2-way conflicted on 4 of 16 lanes.
+constexpr int ST_IN = 99;    // [32][99]   cols 0..86 W_in | 87 bias | 88..98 zero          (x1: 96 rows)
+constexpr int ST_M = 35;     // [32][35]
+constexpr int ST_CAT = 131;  // [32][131]  cols 0..31 (h2) | 32..118 (x1) | 119 bias | zero
+constexpr int ST_CL = 83;    // [32][83]   cols 0..31 (h4) | 32..73 (x2) | 74 bias | zero    (x2: 48 rows)
 constexpr int OFF_IN = 0;
-constexpr int OFF_M1 = OFF_IN + H * ST_IN;       // 2848
-constexpr int OFF_CAT = OFF_M1 + H * ST_M;       // 3904
-constexpr int OFF_M2 = OFF_CAT + H * ST_CAT;     // 7776
-constexpr int OFF_CL = OFF_M2 + H * ST_M;        // 8832
-constexpr int OFF_BM1 = OFF_CL + H * ST_CL;      // 11424
+constexpr int OFF_M1 = OFF_IN + H * ST_IN;       // 3168
+constexpr int OFF_CAT = OFF_M1 + H * ST_M;       // 4288
+constexpr int OFF_M2 = OFF_CAT + H * ST_CAT;     // 8480
+constexpr int OFF_CL = OFF_M2 + H * ST_M;        // 9600
+constexpr int OFF_BM1 = OFF_CL + H * ST_CL;      // 12256
 constexpr int OFF_BM2 = OFF_BM1 + H;
 constexpr int OFF_WA = OFF_BM2 + H;
 constexpr int OFF_WOC = OFF_WA + H;              // [3][32]
 constexpr int OFF_HB = OFF_WOC + 3 * H;          // ba, boc[3]
-constexpr int OFF_PEB = OFF_HB + 4;              // B [21][3]
-constexpr int OFF_FL = 11712;                    // feature layer image [32][81] (only if used)
-static_assert(OFF_PEB + 63 <= OFF_FL, "lds image overlap");
-constexpr int W_FLOATS_NOFEAT = OFF_FL + 32;     // + slack for the over-reads of the T blocks
+constexpr int OFF_PEB = OFF_HB + 4;              // B doubled: rows 0..32 = B[row % 21]  ([33][3])
+constexpr int OFF_FL = 12608;                    // feature layer image [32][83] (only if used)
+static_assert(OFF_PEB + 99 <= OFF_FL, "lds image overlap");
+constexpr int W_FLOATS_NOFEAT = OFF_FL + 32;
 constexpr int W_FLOATS_FEAT = OFF_FL + H * ST_CL + 32;
 
 // arena offsets of the 19 tensors of one object (objnerf_param_layout order)
@@ -91,147 +100,316 @@ __device__ __forceinline__ void stage_weights(float* lds, const float* __restric
   for (int i = tid; i < 3 * H; i += nthr) lds[OFF_WOC + i] = P[L.oc_w + i];
   if (tid == 0) lds[OFF_HB] = P[L.a_b];
   if (tid < 3) lds[OFF_HB + 1 + tid] = P[L.oc_b + tid];
-  for (int i = tid; i < OBJ_NDIR * 3; i += nthr) lds[OFF_PEB + i] = P[L.pe_b + i];
+  for (int i = tid; i < 33 * 3; i += nthr) lds[OFF_PEB + i] = P[L.pe_b + ((i / 3) % OBJ_NDIR) * 3 + (i % 3)];
   __syncthreads();
 }
 
-// acc += W[:, col0 + (feature rows of x)] * x       (x: a 32-feature block in D layout)
-// wl = &W[c * stride + 4*kh]  (c = lane & 31 is the OUTPUT row of the A operand here)
-template <int NSTEPS>
-__device__ __forceinline__ void mma_fwd(f32x16& acc, const float* wl, const int col0, const f32x16& x) {
-#pragma unroll
-  for (int r = 0; r < NSTEPS; ++r)
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[col0 + row0(r)], x[r], acc, 0, 0, 0);
-}
-// acc += W[:, col0 : col0+32]^T * d     (d: 32 output-feature rows in D layout)
-// wt = &W[(4*kh) * STRIDE + c]   (c = lane & 31 is the INPUT feature of the A operand here)
-template <int STRIDE>
-__device__ __forceinline__ void mma_bwd(f32x16& acc, const float* wt, const int col0, const f32x16& d) {
-#pragma unroll
-  for (int r = 0; r < 16; ++r)
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wt[row0(r) * STRIDE + col0], d[r], acc, 0, 0, 0);
-}
+struct T32 {
+  f32x4 t[2];
+};
 
-__device__ __forceinline__ f32x16 relu16(const f32x16& a) {
-  f32x16 o;
+__device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+__device__ __forceinline__ T32 zero32() { return T32{{zero4(), zero4()}}; }
+__device__ __forceinline__ T32 relu32(const T32& a) {
+  T32 o;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) o[r] = fmaxf(a[r], 0.0f);
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o.t[tt][r] = fmaxf(a.t[tt][r], 0.0f);
   return o;
 }
-__device__ __forceinline__ f32x16 relu_mask16(const f32x16& g, const f32x16& act) {
-  f32x16 o;
+__device__ __forceinline__ T32 relu_mask32(const T32& gr, const T32& act) {
+  T32 o;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) o[r] = act[r] > 0.0f ? g[r] : 0.0f;
-  return o;
-}
-__device__ __forceinline__ f32x16 zero16() {
-  f32x16 o;
+  for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-  for (int r = 0; r < 16; ++r) o[r] = 0.0f;
+    for (int r = 0; r < 4; ++r) o.t[tt][r] = act.t[tt][r] > 0.0f ? gr.t[tt][r] : 0.0f;
   return o;
 }
 
-// Embedding of this lane's sample in B-operand / D layout: x1 = 3 blocks (88 rows), x2 = 2 blocks.
+#define OBJ_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// acc(32 out rows) += W[:, col0 + 4g + r] * xt     (xt: one 16-feature tile, feature = 4g + r)
+// wl = &W[c * ST + 4 * g]   (c = lane & 15 is the OUTPUT row inside each 16-row out tile)
+template <int ST>
+__device__ __forceinline__ void mma_fwd16(T32& acc, const float* wl, const int col0, const f32x4& xt) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    acc.t[0] = OBJ_MFMA(wl[col0 + r], xt[r], acc.t[0]);
+    acc.t[1] = OBJ_MFMA(wl[16 * ST + col0 + r], xt[r], acc.t[1]);
+  }
+}
+template <int ST>
+__device__ __forceinline__ void mma_fwd32(T32& acc, const float* wl, const int col0, const T32& x) {
+  mma_fwd16<ST>(acc, wl, col0, x.t[0]);
+  mma_fwd16<ST>(acc, wl, col0 + 16, x.t[1]);
+}
+// acc(16 in rows: col .. col+15) += W[:, col : col+16]^T * d      (d: 32 out rows, D16 layout)
+// wt = &W[(4 * g) * ST + c]   (c = lane & 15 is the INPUT feature of the A operand here)
+template <int ST>
+__device__ __forceinline__ void mma_bwd16(f32x4& acc, const float* wt, const int col, const T32& d) {
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc = OBJ_MFMA(wt[(16 * tt + r) * ST + col], d.t[tt][r], acc);
+}
+template <int ST>
+__device__ __forceinline__ void mma_bwd32(T32& acc, const float* wt, const int col0, const T32& d) {
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      acc.t[0] = OBJ_MFMA(wt[(16 * tt + r) * ST + col0], d.t[tt][r], acc.t[0]);
+      acc.t[1] = OBJ_MFMA(wt[(16 * tt + r) * ST + col0 + 16], d.t[tt][r], acc.t[1]);
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Positional encoding in D16 layout.  Embedding entry e >= 3 is sin(pi * 2^f * proj[j]) with
+// e - 3 = 21 f + j (embedding.py:49-52).  Lane group g owns entries e = e0 + 4 g for compile-time e0,
+// i.e. direction (j0 + 4 g) mod 21: every lane keeps the ROTATED, octave-corrected projections
+//     ps[i] = proj[(i + 4g) mod 21] * (i + 4g >= 21 ? 2 : 1)
+// so that entry e0 + 4g is sin(pi * 2^f0 * ps[j0]) with compile-time (j0, f0) and no per-entry select
+// (scaling by powers of two commutes with the reference's fp32 roundings of proj*2^f and of (.)*pi).
+// ----------------------------------------------------------------------------------------------
+struct Pe {
+  float t[3];
+  float ps[OBJ_NDIR];
+};
+
+__device__ __forceinline__ void pe_project(const float* lds, const int g, const float px, const float py,
+                                           const float pz, const float scale, Pe& pe) {
+  pe.t[0] = px / scale;        // embedding.py:47
+  pe.t[1] = py / scale;
+  pe.t[2] = pz / scale;
+  const float* bl = lds + OFF_PEB + 12 * g;
+#pragma unroll
+  for (int i = 0; i < OBJ_NDIR; ++i) {
+    const float p = fmaf(pe.t[2], bl[3 * i + 2], fmaf(pe.t[1], bl[3 * i + 1], pe.t[0] * bl[3 * i]));   // :48
+    // i + 4g >= 21  <=>  the entry belongs to the next octave; never for i <= 8
+    pe.ps[i] = (i > 8 && 4 * g + i >= OBJ_NDIR) ? 2.0f * p : p;
+  }
+}
+
+// band value (or its derivative w.r.t. ps[j0]) for rotated index q0 = 21 f0 + j0, q0 in [-3, 125]
+template <bool WANT_COS>
+__device__ __forceinline__ float pe_band(const Pe& pe, const int q0) {
+  const int qq = q0 + OBJ_NDIR;                 // >= 18
+  const int j0 = qq % OBJ_NDIR, f0 = qq / OBJ_NDIR - 1;
+  const float sc = f0 < 0 ? 0.5f : (float)(1 << (f0 < 0 ? 0 : f0));
+  const float arg = (pe.ps[j0] * sc) * OBJ_PI_F;
+  float sv, cv;
+  sincos_acc(arg, sv, cv);
+  return WANT_COS ? (cv * OBJ_PI_F) * sc : sv;
+}
+
+// x1 tile T (0..5): entries e = 16 T + 4 g + r  (87 = constant 1, >= 88 zero)
+__device__ __forceinline__ f32x4 pe_x1_tile(const Pe& pe, const int T, const int g) {
+  f32x4 o;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float v = pe_band<false>(pe, 16 * T + r - 3);
+    if (T == 0 && r < 3) v = (g == 0) ? pe.t[r] : v;
+    if (T == 5) {
+      if (r == 3) v = (g == 1) ? 1.0f : v;
+      v = (g >= 2) ? 0.0f : v;
+    }
+    o[r] = v;
+  }
+  return o;
+}
+// x2 tile T (0..2): entries e2 = 16 T + 4 g + r  <->  embedding entry 87 + e2  (42 = constant 1, > 42 zero)
+__device__ __forceinline__ f32x4 pe_x2_tile(const Pe& pe, const int T, const int g) {
+  f32x4 o;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float v = pe_band<false>(pe, 84 + 16 * T + r);
+    if (T == 2) {
+      if (r == 2) v = (g == 2) ? 1.0f : v;
+      if (r == 3) v = (g == 2) ? 0.0f : v;
+      v = (g == 3) ? 0.0f : v;
+    }
+    o[r] = v;
+  }
+  return o;
+}
+// d ps[j] += d_x[e] * d sin / d ps  for one tile (entries that are not sin bands contribute nothing)
+__device__ __forceinline__ void pe_x1_tile_bwd(const Pe& pe, const int T, const int g, const f32x4& dx,
+                                               float (&dps)[OBJ_NDIR]) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int qq = 16 * T + r - 3 + OBJ_NDIR;
+    float v = dx[r] * pe_band<true>(pe, 16 * T + r - 3);
+    if (T == 0 && r < 3) v = (g == 0) ? 0.0f : v;
+    if (T == 5) {
+      if (r == 3) v = (g == 1) ? 0.0f : v;
+      v = (g >= 2) ? 0.0f : v;
+    }
+    dps[qq % OBJ_NDIR] += v;
+  }
+}
+__device__ __forceinline__ void pe_x2_tile_bwd(const Pe& pe, const int T, const int g, const f32x4& dx,
+                                               float (&dps)[OBJ_NDIR]) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int qq = 84 + 16 * T + r + OBJ_NDIR;
+    float v = dx[r] * pe_band<true>(pe, 84 + 16 * T + r);
+    if (T == 2) {
+      if (r >= 2) v = (g == 2) ? 0.0f : v;
+      v = (g == 3) ? 0.0f : v;
+    }
+    dps[qq % OBJ_NDIR] += v;
+  }
+}
+
+// Backward of one tile that ALSO re-creates the tile's forward values (one sincos gives both), so the
+// embedding does not have to stay live between the forward and the backward pass.
+__device__ __forceinline__ f32x4 pe_x1_tile_fb(const Pe& pe, const int T, const int g, const f32x4& dx,
+                                               float (&dps)[OBJ_NDIR]) {
+  f32x4 o;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int q0 = 16 * T + r - 3, qq = q0 + OBJ_NDIR;
+    const int j0 = qq % OBJ_NDIR, f0 = qq / OBJ_NDIR - 1;
+    const float sc = f0 < 0 ? 0.5f : (float)(1 << (f0 < 0 ? 0 : f0));
+    float sv, cv;
+    sincos_acc((pe.ps[j0] * sc) * OBJ_PI_F, sv, cv);
+    float v = dx[r] * ((cv * OBJ_PI_F) * sc);
+    if (T == 0 && r < 3) { v = (g == 0) ? 0.0f : v; sv = (g == 0) ? pe.t[r] : sv; }
+    if (T == 5) {
+      if (r == 3) { v = (g == 1) ? 0.0f : v; sv = (g == 1) ? 1.0f : sv; }
+      v = (g >= 2) ? 0.0f : v;
+      sv = (g >= 2) ? 0.0f : sv;
+    }
+    dps[j0] += v;
+    o[r] = sv;
+  }
+  return o;
+}
+__device__ __forceinline__ f32x4 pe_x2_tile_fb(const Pe& pe, const int T, const int g, const f32x4& dx,
+                                               float (&dps)[OBJ_NDIR]) {
+  f32x4 o;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int q0 = 84 + 16 * T + r, qq = q0 + OBJ_NDIR;
+    const int j0 = qq % OBJ_NDIR, f0 = qq / OBJ_NDIR - 1;
+    const float sc = (float)(1 << f0);
+    float sv, cv;
+    sincos_acc((pe.ps[j0] * sc) * OBJ_PI_F, sv, cv);
+    float v = dx[r] * ((cv * OBJ_PI_F) * sc);
+    if (T == 2) {
+      if (r == 2) { v = (g == 2) ? 0.0f : v; sv = (g == 2) ? 1.0f : sv; }
+      if (r == 3) { v = (g == 2) ? 0.0f : v; sv = (g == 2) ? 0.0f : sv; }
+      v = (g == 3) ? 0.0f : v;
+      sv = (g == 3) ? 0.0f : sv;
+    }
+    dps[j0] += v;
+    o[r] = sv;
+  }
+  return o;
+}
+
 struct Emb {
-  f32x16 x1[3];
-  f32x16 x2[2];
+  f32x4 x1[6];
+  f32x4 x2[3];
 };
-
-__device__ __forceinline__ void project(const float* lds, const float px, const float py, const float pz,
-                                        const float scale, float (&t)[3], float (&proj)[OBJ_NDIR]) {
-  t[0] = px / scale;
-  t[1] = py / scale;
-  t[2] = pz / scale;
+__device__ __forceinline__ void embed(Emb& e, const Pe& pe, const int g) {
 #pragma unroll
-  for (int j = 0; j < OBJ_NDIR; ++j) {
-    const float b0 = lds[OFF_PEB + 3 * j], b1 = lds[OFF_PEB + 3 * j + 1], b2 = lds[OFF_PEB + 3 * j + 2];
-    proj[j] = fmaf(t[2], b2, fmaf(t[1], b1, t[0] * b0));
-  }
+  for (int T = 0; T < 6; ++T) e.x1[T] = pe_x1_tile(pe, T, g);
+#pragma unroll
+  for (int T = 0; T < 3; ++T) e.x2[T] = pe_x2_tile(pe, T, g);
+}
+// embedding supplied by the caller (OccupancyMap.forward on an explicit embedding tensor)
+__device__ __forceinline__ void embed_load(Emb& e, const float* __restrict__ emb, const int g) {
+#pragma unroll
+  for (int T = 0; T < 6; ++T)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 16 * T + 4 * g + r;
+      e.x1[T][r] = i < OBJ_E1 ? emb[i] : (i == OBJ_E1 ? 1.0f : 0.0f);
+    }
+#pragma unroll
+  for (int T = 0; T < 3; ++T)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 16 * T + 4 * g + r;
+      e.x2[T][r] = i < OBJ_E2 ? emb[OBJ_E1 + i] : (i == OBJ_E2 ? 1.0f : 0.0f);
+    }
 }
 
-__device__ __forceinline__ void embed(Emb& e, const int kh, const float (&t)[3], const float (&proj)[OBJ_NDIR]) {
-#pragma unroll
-  for (int b = 0; b < 3; ++b) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int e0 = 32 * b + row0(r);
-      e.x1[b][r] = (e0 + 4 <= OBJ_E1) ? pe_lane_value<false>(pe_sel_x1(e0), pe_sel_x1(e0 + 4), kh, t, proj) : 0.0f;
-    }
-  }
-#pragma unroll
-  for (int b = 0; b < 2; ++b) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int e0 = 32 * b + row0(r);
-      e.x2[b][r] = (e0 <= OBJ_E2) ? pe_lane_value<false>(pe_sel_x2(e0), pe_sel_x2(e0 + 4), kh, t, proj) : 0.0f;
-    }
-  }
-}
-
-// Forward activations of one 32-sample tile (all in D layout).
+// Forward activations of one 16-sample block.
 struct Acts {
-  f32x16 h1, h2, h3, h4, hc, hf;
+  T32 h1, h2, h3, h4, hc, hf;
 };
-
 struct Heads {
   float alpha;      // 10 * raw (model.py:88)
   float col[3];     // sigmoid applied (model.py:96)
 };
 
+__device__ __forceinline__ float xgroup_sum(float v) {   // sum over the 4 lane groups of a sample
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
 template <bool FEAT>
-__device__ __forceinline__ void mlp_forward(const float* lds, const int c, const int kh, const Emb& e,
-                                            Acts& a, Heads& hd) {
-  const float* wl_in = lds + OFF_IN + c * ST_IN + 4 * kh;
-  const float* wl_m1 = lds + OFF_M1 + c * ST_M + 4 * kh;
-  const float* wl_cat = lds + OFF_CAT + c * ST_CAT + 4 * kh;
-  const float* wl_m2 = lds + OFF_M2 + c * ST_M + 4 * kh;
-  const float* wl_cl = lds + OFF_CL + c * ST_CL + 4 * kh;
-  f32x16 acc = zero16();
-  mma_fwd<16>(acc, wl_in, 0, e.x1[0]);
-  mma_fwd<16>(acc, wl_in, 32, e.x1[1]);
-  mma_fwd<12>(acc, wl_in, 64, e.x1[2]);
-  a.h1 = relu16(acc);
+__device__ __forceinline__ void mlp_forward(const float* lds, const int c, const int g, const Emb& e, Acts& a,
+                                            Heads& hd) {
+  const float* wl_in = lds + OFF_IN + c * ST_IN + 4 * g;
+  const float* wl_m1 = lds + OFF_M1 + c * ST_M + 4 * g;
+  const float* wl_cat = lds + OFF_CAT + c * ST_CAT + 4 * g;
+  const float* wl_m2 = lds + OFF_M2 + c * ST_M + 4 * g;
+  const float* wl_cl = lds + OFF_CL + c * ST_CL + 4 * g;
+  T32 acc = zero32();
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = lds[OFF_BM1 + row0(r) + 4 * kh];
-  mma_fwd<16>(acc, wl_m1, 0, a.h1);
-  a.h2 = relu16(acc);
-  acc = zero16();
-  mma_fwd<16>(acc, wl_cat, 0, a.h2);
-  mma_fwd<16>(acc, wl_cat, 32, e.x1[0]);
-  mma_fwd<16>(acc, wl_cat, 64, e.x1[1]);
-  mma_fwd<12>(acc, wl_cat, 96, e.x1[2]);
-  a.h3 = relu16(acc);
+  for (int T = 0; T < 6; ++T) mma_fwd16<ST_IN>(acc, wl_in, 16 * T, e.x1[T]);
+  a.h1 = relu32(acc);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = lds[OFF_BM2 + row0(r) + 4 * kh];
-  mma_fwd<16>(acc, wl_m2, 0, a.h3);
-  a.h4 = relu16(acc);
-  acc = zero16();
-  mma_fwd<16>(acc, wl_cl, 0, a.h4);
-  mma_fwd<16>(acc, wl_cl, 32, e.x2[0]);
-  mma_fwd<7>(acc, wl_cl, 64, e.x2[1]);
-  a.hc = relu16(acc);
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc.t[tt][r] = lds[OFF_BM1 + 16 * tt + 4 * g + r];
+  mma_fwd32<ST_M>(acc, wl_m1, 0, a.h1);
+  a.h2 = relu32(acc);
+  acc = zero32();
+  mma_fwd32<ST_CAT>(acc, wl_cat, 0, a.h2);
+#pragma unroll
+  for (int T = 0; T < 6; ++T) mma_fwd16<ST_CAT>(acc, wl_cat, 32 + 16 * T, e.x1[T]);
+  a.h3 = relu32(acc);
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc.t[tt][r] = lds[OFF_BM2 + 16 * tt + 4 * g + r];
+  mma_fwd32<ST_M>(acc, wl_m2, 0, a.h3);
+  a.h4 = relu32(acc);
+  acc = zero32();
+  mma_fwd32<ST_CL>(acc, wl_cl, 0, a.h4);
+#pragma unroll
+  for (int T = 0; T < 3; ++T) mma_fwd16<ST_CL>(acc, wl_cl, 32 + 16 * T, e.x2[T]);
+  a.hc = relu32(acc);
   if (FEAT) {
-    const float* wl_fl = lds + OFF_FL + c * ST_CL + 4 * kh;
-    acc = zero16();
-    mma_fwd<16>(acc, wl_fl, 0, a.h4);
-    mma_fwd<16>(acc, wl_fl, 32, e.x2[0]);
-    mma_fwd<7>(acc, wl_fl, 64, e.x2[1]);
-    a.hf = relu16(acc);
+    const float* wl_fl = lds + OFF_FL + c * ST_CL + 4 * g;
+    acc = zero32();
+    mma_fwd32<ST_CL>(acc, wl_fl, 0, a.h4);
+#pragma unroll
+    for (int T = 0; T < 3; ++T) mma_fwd16<ST_CL>(acc, wl_fl, 32 + 16 * T, e.x2[T]);
+    a.hf = relu32(acc);
   }
-  // heads: each half holds 16 of the 32 hidden rows of its sample
+  // heads: each lane group holds 8 of the 32 hidden rows of its sample
   float pa = 0.f, pc0 = 0.f, pc1 = 0.f, pc2 = 0.f;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = row0(r) + 4 * kh;
-    pa = fmaf(lds[OFF_WA + row], a.h4[r], pa);
-    pc0 = fmaf(lds[OFF_WOC + row], a.hc[r], pc0);
-    pc1 = fmaf(lds[OFF_WOC + H + row], a.hc[r], pc1);
-    pc2 = fmaf(lds[OFF_WOC + 2 * H + row], a.hc[r], pc2);
-  }
-  hd.alpha = (xhalf_sum(pa) + lds[OFF_HB]) * 10.0f;
-  hd.col[0] = sigmoid_acc(xhalf_sum(pc0) + lds[OFF_HB + 1]);
-  hd.col[1] = sigmoid_acc(xhalf_sum(pc1) + lds[OFF_HB + 2]);
-  hd.col[2] = sigmoid_acc(xhalf_sum(pc2) + lds[OFF_HB + 3]);
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * tt + 4 * g + r;
+      pa = fmaf(lds[OFF_WA + row], a.h4.t[tt][r], pa);
+      pc0 = fmaf(lds[OFF_WOC + row], a.hc.t[tt][r], pc0);
+      pc1 = fmaf(lds[OFF_WOC + H + row], a.hc.t[tt][r], pc1);
+      pc2 = fmaf(lds[OFF_WOC + 2 * H + row], a.hc.t[tt][r], pc2);
+    }
+  hd.alpha = (xgroup_sum(pa) + lds[OFF_HB]) * 10.0f;
+  hd.col[0] = sigmoid_acc(xgroup_sum(pc0) + lds[OFF_HB + 1]);
+  hd.col[1] = sigmoid_acc(xgroup_sum(pc1) + lds[OFF_HB + 2]);
+  hd.col[2] = sigmoid_acc(xgroup_sum(pc2) + lds[OFF_HB + 3]);
 }
 
 }  // namespace obj32

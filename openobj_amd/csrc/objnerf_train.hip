@@ -2,15 +2,17 @@
 //
 // Replaces, for cfg.training_strategy == "hip", the reference's per-iteration op sequence
 //   vmap(pe_model) -> vmap(fc_model) -> loss.step_batch_loss -> backward          (train.py:424-472)
-// with ONE kernel: each 256-thread workgroup owns one object's weights in LDS and sweeps that
-// object's rays in tiles of 128 samples (whole rays).  Per tile:
-//   1. every wave embeds 32 samples and runs the MLP forward chain on MFMA, activations in registers;
+// with ONE kernel.  A 512-thread workgroup (8 waves, two per SIMD so one wave's VALU work overlaps the
+// other's MFMAs) owns one object's weights in LDS and sweeps that object's rays in tiles of 128 samples
+// (whole rays).  Per tile:
+//   1. every wave embeds 16 samples and runs the MLP forward chain on MFMA, activations in registers;
 //   2. sigma / rgb go to LDS, a wave per ray-group composites (segmented wave scans), evaluates the
-//      masked losses of loss.py and writes d(loss)/d(sigma,rgb) back to LDS;
-//   3. every wave back-propagates its 32 samples in registers (dgrad), transposes (d_out, input)
-//      pairs through LDS and the four waves share the weight-gradient MFMAs (one 32x32 tile each per
-//      layer group), accumulating in registers across the whole sweep.
-// Each workgroup then writes one partial-gradient slab; objnerf_finalize sums the slabs (no atomics).
+//      masked losses of loss.py and writes d(loss)/d(sigma,rgb) back in place;
+//   3. every wave back-propagates its 16 samples in registers (dgrad), transposes (d_out, input) pairs
+//      through LDS and the eight waves share the weight-gradient MFMAs (two 16x16 tiles each per layer
+//      group), accumulating in registers across the whole sweep.
+// Each workgroup then writes one partial-gradient slab; finalize_kernel sums the slabs (no atomics on
+// global memory, bit-reproducible run to run).
 #include "objnerf_mlp.h"
 #include "../../include/objnerf_hip.h"
 
@@ -19,10 +21,12 @@ using namespace obj32;
 namespace {
 
 constexpr int TS = 128;            // samples per workgroup tile
-constexpr int STG_LD = TS + 1;     // staging row stride (floats), odd -> conflict-free columns
+constexpr int NWAVE = 8;
+constexpr int NTHR = 64 * NWAVE;
+constexpr int STG_LD = 130;        // staging row stride (floats): = 2 (mod 32) -> wgrad operand reads hit 32 banks
 constexpr int STG_ROWS = 192;
-constexpr int SM_FLOATS = 8 * TS;  // s_alpha, s_col[3], s_da, s_dc[3]
-constexpr int NRED = 6 * 32 + 4 + 63 + 4;
+constexpr int SM_FLOATS = 4 * TS;  // s_alpha | s_col[3]; overwritten in place by d raw-alpha | d raw-colour
+constexpr int NRED = 6 * 32 + 4 + 4;
 
 struct TrainDev {
   int K, R, S, G, TR, NT;
@@ -39,53 +43,65 @@ struct TrainDev {
 
 struct EvalDev {
   int K, G; long N;
-  const float* params; long p_stride; const float* scale; const float* pts;
+  const float* params; long p_stride; const float* scale; const float* pts; const float* emb;
   float* alpha; float* color; float* hfeat;
   Layout L;
 };
 
-__device__ __forceinline__ void store_tile_T(float* stg_lane, const int rowbase, const f32x16& v, const int n = 16) {
+// stg[(rowbase + 16 tt + 4 g + r)][16 w + c] = v  for a 32-feature block / a 16-feature tile
+__device__ __forceinline__ void store_T32(float* stg_lane, const int rowbase, const T32& v) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r)
-    if (r < n) stg_lane[(rowbase + row0(r)) * STG_LD] = v[r];
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) stg_lane[(rowbase + 16 * tt + r) * STG_LD] = v.t[tt][r];
+}
+__device__ __forceinline__ void store_T16(float* stg_lane, const int rowbase, const f32x4& v) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) stg_lane[(rowbase + r) * STG_LD] = v[r];
 }
 
-// D[out][in] += sum_s dT[out][s] * aT[in][s] over the 128 staged samples
-__device__ __forceinline__ void wgrad_tile(f32x16& acc, const float* dT, const float* aT) {
-#pragma unroll 16
-  for (int t = 0; t < TS / 2; ++t)
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(dT[2 * t], aT[2 * t], acc, 0, 0, 0);
+// D[out 0..31][in 16 cols] += sum_s dT[out][s] * aT[in][s] over the 128 staged samples
+__device__ __forceinline__ void wgrad_pair(f32x4& acc0, f32x4& acc1, const float* dT, const float* aT) {
+#pragma unroll 8
+  for (int st = 0; st < TS / 4; ++st) {
+    const float b = aT[4 * st];
+    acc0 = OBJ_MFMA(dT[4 * st], b, acc0);
+    acc1 = OBJ_MFMA(dT[16 * STG_LD + 4 * st], b, acc1);
+  }
 }
 
-__device__ __forceinline__ void write_tile(float* slab, const f32x16& acc, const int c, const int kh, const int ct,
-                                           const int w_off, const int ncols, const int b_off) {
-  const int col = 32 * ct + c;
+__device__ __forceinline__ void write_pair(float* slab, const f32x4& a0, const f32x4& a1, const int c, const int g,
+                                           const int ct, const int w_off, const int ncols, const int b_off) {
+  const int col = 16 * ct + c;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int out = row0(r) + 4 * kh;
-    if (col < ncols) slab[w_off + out * ncols + col] = acc[r];
-    else if (col == ncols && b_off >= 0) slab[b_off + out] = acc[r];
+  for (int r = 0; r < 4; ++r) {
+    const int o0 = 4 * g + r, o1 = 16 + 4 * g + r;
+    if (col < ncols) {
+      slab[w_off + o0 * ncols + col] = a0[r];
+      slab[w_off + o1 * ncols + col] = a1[r];
+    } else if (col == ncols && b_off >= 0) {
+      slab[b_off + o0] = a0[r];
+      slab[b_off + o1] = a1[r];
+    }
   }
 }
 
 // ------------------------------------------------------------------------------------------------
 template <bool FEAT>
-__global__ __launch_bounds__(256, 1) void train_fused_kernel(const TrainDev a) {
+__global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int c = lane & 31, kh = lane >> 5;
-  const int k = blockIdx.x / a.G, g = blockIdx.x % a.G;
+  const int c = lane & 15, g = lane >> 4;
+  const int k = blockIdx.x / a.G, gi = blockIdx.x % a.G;
   constexpr int WF = FEAT ? W_FLOATS_FEAT : W_FLOATS_NOFEAT;
   float* s_alpha = lds + WF;
   float* s_col = s_alpha + TS;
-  float* s_da = s_col + 3 * TS;
-  float* s_dc = s_da + TS;
   float* stg = lds + WF + SM_FLOATS;
 
-  stage_weights(lds, a.params + (long)k * a.p_stride, a.L, FEAT, tid, 256);
-  for (int i = tid; i < STG_ROWS * STG_LD; i += 256) stg[i] = 0.0f;
+  stage_weights(lds, a.params + (long)k * a.p_stride, a.L, FEAT, tid, NTHR);
+  for (int i = tid; i < STG_ROWS * STG_LD; i += NTHR) stg[i] = 0.0f;
   __syncthreads();
 
   const float scale = a.scale[k];
@@ -95,27 +111,30 @@ __global__ __launch_bounds__(256, 1) void train_fused_kernel(const TrainDev a) {
   const float inv2 = a.flags[1] ? 0.0f : 1.0f / (n2 + 1e-10f);
 
   // persistent gradient accumulators
-  f32x16 accA = zero16(), accB = zero16(), accC = zero16();
-  // row-wise sums over samples: one register each, slot r (lane 16+r of a half) = feature row0(r)+4kh
-  float g_bm1 = 0.f, g_bm2 = 0.f, g_wa = 0.f, g_woc0 = 0.f, g_woc1 = 0.f, g_woc2 = 0.f;
+  f32x4 accA0 = zero4(), accA1 = zero4(), accB0 = zero4(), accB1 = zero4(), accC0 = zero4(), accC1 = zero4();
+  // row-wise sums over samples: slot s of a register = lane s of each lane group; feature of slot s (< 8) is
+  // 16 (s >> 2) + 4 g + (s & 3); lanes 8..15 carry a second quantity
+  float gS0 = 0.f;   // [0..7] d W_alpha   | [8..15] d W_oc[0]
+  float gS1 = 0.f;   // [0..7] d W_oc[1]   | [8..15] d W_oc[2]
+  float gS2 = 0.f;   // [0..7] d b_mid1    | [8..15] d b_mid2
   float g_ba = 0.f, g_boc0 = 0.f, g_boc1 = 0.f, g_boc2 = 0.f;
-  float g_B0 = 0.f, g_B1 = 0.f, g_B2 = 0.f;   // slot i of g_Bn = entry 16n+i of this half's 33 (dir, xyz) sums
+  float g_dB = 0.f;  // thread (p = tid >> 3, q = tid & 7): partial of d B[p / 3][p % 3] over samples 16q..16q+15
   float l_d = 0.f, l_c = 0.f, l_o = 0.f;
 
-  float* stg_lane = stg + (4 * kh) * STG_LD + 32 * w + c;
-  const float* lane_rd = stg + c * STG_LD + kh;   // + row0*STG_LD + 2t
+  float* stg_lane = stg + (4 * g) * STG_LD + 16 * w + c;
+  const float* lane_rd = stg + c * STG_LD + g;
 
-  const float* wt_in = lds + OFF_IN + (4 * kh) * ST_IN + c;
-  const float* wt_m1 = lds + OFF_M1 + (4 * kh) * ST_M + c;
-  const float* wt_cat = lds + OFF_CAT + (4 * kh) * ST_CAT + c;
-  const float* wt_m2 = lds + OFF_M2 + (4 * kh) * ST_M + c;
-  const float* wt_cl = lds + OFF_CL + (4 * kh) * ST_CL + c;
+  const float* wt_in = lds + OFF_IN + (4 * g) * ST_IN + c;
+  const float* wt_m1 = lds + OFF_M1 + (4 * g) * ST_M + c;
+  const float* wt_cat = lds + OFF_CAT + (4 * g) * ST_CAT + c;
+  const float* wt_m2 = lds + OFF_M2 + (4 * g) * ST_M + c;
+  const float* wt_cl = lds + OFF_CL + (4 * g) * ST_CL + c;
 
-  for (int tile = g; tile < a.NT; tile += a.G) {
+  for (int tile = gi; tile < a.NT; tile += a.G) {
     asm volatile("" ::: "memory");   // keep the LDS weight reads inside the loop (no LICM into registers)
     const int ray0 = tile * TR;
     // ---------------------------------------------------------------- 1. forward
-    const int slot = 32 * w + c;
+    const int slot = 16 * w + c;
     const int q = slot / S, si = slot - q * S;
     const int ray = ray0 + q;
     const bool valid = (q < TR) && (ray < R);
@@ -129,19 +148,21 @@ __global__ __launch_bounds__(256, 1) void train_fused_kernel(const TrainDev a) {
         const float zz = a.z[rr * S + si];
         const float* o = a.origins + rr * 3;
         const float* d = a.dirs + rr * 3;
-        px = __fadd_rn(o[0], __fmul_rn(d[0], zz)) - a.obj_center;   // vmap.py:548-551
-        py = __fadd_rn(o[1], __fmul_rn(d[1], zz)) - a.obj_center;
-        pz = __fadd_rn(o[2], __fmul_rn(d[2], zz)) - a.obj_center;
+        px = (o[0] + d[0] * zz) - a.obj_center;   // vmap.py:548-551 (two roundings: -ffp-contract=off)
+        py = (o[1] + d[1] * zz) - a.obj_center;
+        pz = (o[2] + d[2] * zz) - a.obj_center;
       }
     }
-    float t[3], proj[OBJ_NDIR];
-    project(lds, px, py, pz, scale, t, proj);
-    Emb e;
-    embed(e, kh, t, proj);
+    Pe pe;
+    pe_project(lds, g, px, py, pz, scale, pe);
     Acts act;
     Heads hd;
-    mlp_forward<FEAT>(lds, c, kh, e, act, hd);
-    if (kh == 0) {
+    {
+      Emb e;                          // forward-only: the backward re-creates the embedding tile by tile
+      embed(e, pe, g);
+      mlp_forward<FEAT>(lds, c, g, e, act, hd);
+    }
+    if (g == 0) {
       s_alpha[slot] = hd.alpha;
       s_col[slot] = hd.col[0];
       s_col[TS + slot] = hd.col[1];
@@ -152,7 +173,7 @@ __global__ __launch_bounds__(256, 1) void train_fused_kernel(const TrainDev a) {
     {
       const int rpp = 64 / S;                       // rays per wave pass
       const int npass = (TR + rpp - 1) / rpp;
-      for (int ps = w; ps < npass; ps += 4) {
+      for (int ps = w; ps < npass; ps += NWAVE) {
         const int ql = lane / S, pos = lane - ql * S;
         const int qq = ps * rpp + ql;
         const int rayq = ray0 + qq;
@@ -203,182 +224,189 @@ __global__ __launch_bounds__(256, 1) void train_fused_kernel(const TrainDev a) {
         const float qv = dw * wgt;
         const float suf = seg_rscan_add(qv, pos, S) - qv;            // sum_{j>i} dL/dw_j * w_j
         const float docc = dw * T - suf / fr;
-        if (on) {
-          s_da[sl] = 10.0f * (docc * occ * (1.0f - occ));            // d / d raw alpha (model.py:88)
-          s_dc[sl] = gC0 * wgt * c0 * (1.0f - c0);                   // d / d raw colour (pre-sigmoid)
-          s_dc[TS + sl] = gC1 * wgt * c1 * (1.0f - c1);
-          s_dc[2 * TS + sl] = gC2 * wgt * c2 * (1.0f - c2);
+        if (on) {                                                    // in place: this lane owns slot sl
+          s_alpha[sl] = 10.0f * (docc * occ * (1.0f - occ));         // d / d raw alpha (model.py:88)
+          s_col[sl] = gC0 * wgt * c0 * (1.0f - c0);                  // d / d raw colour (pre-sigmoid)
+          s_col[TS + sl] = gC1 * wgt * c1 * (1.0f - c1);
+          s_col[2 * TS + sl] = gC2 * wgt * c2 * (1.0f - c2);
         }
       }
     }
     __syncthreads();
     // ---------------------------------------------------------------- 3. backward
-    const float da = valid ? s_da[slot] : 0.0f;
-    const float dc0 = valid ? s_dc[slot] : 0.0f;
-    const float dc1 = valid ? s_dc[TS + slot] : 0.0f;
-    const float dc2 = valid ? s_dc[2 * TS + slot] : 0.0f;
-    if (kh == 0) { g_ba += da; g_boc0 += dc0; g_boc1 += dc1; g_boc2 += dc2; }
-    // The sincos of the embedding is RE-computed below: hide proj from CSE, otherwise the compiler keeps
-    // every forward cos value live across the whole backward pass.
+    const float da = valid ? s_alpha[slot] : 0.0f;
+    const float dc0 = valid ? s_col[slot] : 0.0f;
+    const float dc1 = valid ? s_col[TS + slot] : 0.0f;
+    const float dc2 = valid ? s_col[2 * TS + slot] : 0.0f;
+    if (g == 0) { g_ba += da; g_boc0 += dc0; g_boc1 += dc1; g_boc2 += dc2; }
+    // The sincos of the embedding is RE-computed below: hide ps from CSE, otherwise the compiler keeps every
+    // forward cos value live across the whole backward pass.
 #pragma unroll
-    for (int j = 0; j < OBJ_NDIR; ++j) asm volatile("" : "+v"(proj[j]));
-    float dproj[OBJ_NDIR];
+    for (int j = 0; j < OBJ_NDIR; ++j) asm volatile("" : "+v"(pe.ps[j]));
+    float dps[OBJ_NDIR];
 #pragma unroll
-    for (int j = 0; j < OBJ_NDIR; ++j) dproj[j] = 0.f;
+    for (int j = 0; j < OBJ_NDIR; ++j) dps[j] = 0.f;
 
     // ---- phase A: heads, colour layer, mid2
-    f32x16 d_hc, d_h4;
+    T32 d_hc, d_h4;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = row0(r) + 4 * kh;
-      const float hv = act.hc[r];
-      slot_accum(g_woc0, dc0 * hv, r, c);
-      slot_accum(g_woc1, dc1 * hv, r, c);
-      slot_accum(g_woc2, dc2 * hv, r, c);
-      const float dv = fmaf(lds[OFF_WOC + 2 * H + row], dc2, fmaf(lds[OFF_WOC + H + row], dc1, lds[OFF_WOC + row] * dc0));
-      d_hc[r] = hv > 0.0f ? dv : 0.0f;
-      slot_accum(g_wa, da * act.h4[r], r, c);
-      d_h4[r] = lds[OFF_WA + row] * da;
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * tt + 4 * g + r;
+        const int s = 4 * tt + r;
+        const float hv = act.hc.t[tt][r];
+        slot_accum16(gS0, da * act.h4.t[tt][r], s, c);
+        slot_accum16(gS0, dc0 * hv, 8 + s, c);
+        slot_accum16(gS1, dc1 * hv, s, c);
+        slot_accum16(gS1, dc2 * hv, 8 + s, c);
+        const float dv = fmaf(lds[OFF_WOC + 2 * H + row], dc2, fmaf(lds[OFF_WOC + H + row], dc1, lds[OFF_WOC + row] * dc0));
+        d_hc.t[tt][r] = hv > 0.0f ? dv : 0.0f;
+        d_h4.t[tt][r] = lds[OFF_WA + row] * da;
+      }
+    // group A staging: [h4 | x2] rows 0..79, h3 rows 96..127, d_hc rows 128.., d_h4pre rows 160..
+    store_T32(stg_lane, 0, act.h4);
+    store_T32(stg_lane, 96, act.h3);
+    store_T32(stg_lane, 128, d_hc);
+    mma_bwd32<ST_CL>(d_h4, wt_cl, 0, d_hc);
+    d_h4 = relu_mask32(d_h4, act.h4);
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) slot_accum16(gS2, d_h4.t[tt][r], 8 + 4 * tt + r, c);
+    store_T32(stg_lane, 160, d_h4);
+    // PE backward, x2 part, one 16-row tile at a time
+#pragma unroll
+    for (int T = 0; T < 3; ++T) {
+      f32x4 d_x = zero4();
+      mma_bwd16<ST_CL>(d_x, wt_cl, 32 + 16 * T, d_hc);
+      store_T16(stg_lane, 32 + 16 * T, pe_x2_tile_fb(pe, T, g, d_x, dps));
     }
-    // group A staging: [h4 | x2] rows 0..75, h3 rows 96..127, d_hc rows 128.., d_h4pre rows 160..
-    store_tile_T(stg_lane, 0, act.h4);
-    store_tile_T(stg_lane, 32, e.x2[0]);
-    store_tile_T(stg_lane, 64, e.x2[1], 7);
-    store_tile_T(stg_lane, 96, act.h3);
-    store_tile_T(stg_lane, 128, d_hc);
-    mma_bwd<ST_CL>(d_h4, wt_cl, 0, d_hc);
-    d_h4 = relu_mask16(d_h4, act.h4);
+    T32 d_h3 = zero32();
+    mma_bwd32<ST_M>(d_h3, wt_m2, 0, d_h4);
+    d_h3 = relu_mask32(d_h3, act.h3);
+    __syncthreads();
+    if (w < 7) {
+      const int dTr = (w < 5) ? 128 : 160;
+      const int aTr = (w < 5) ? 16 * w : 96 + 16 * (w - 5);
+      wgrad_pair(accA0, accA1, lane_rd + dTr * STG_LD, lane_rd + aTr * STG_LD);
+    }
+    __syncthreads();
+    // ---- phase B: cat layer.  [h2 | x1] rows 0..127, d_h3pre rows 128..
+    store_T32(stg_lane, 0, act.h2);
+    store_T32(stg_lane, 128, d_h3);
+    T32 d_h2 = zero32();
+    mma_bwd32<ST_CAT>(d_h2, wt_cat, 0, d_h3);
+    d_h2 = relu_mask32(d_h2, act.h2);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) slot_accum(g_bm2, d_h4[r], r, c);
-    store_tile_T(stg_lane, 160, d_h4);
-    // PE backward, x2 part, one 32-row block at a time
+    for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      f32x16 d_x = zero16();
-      mma_bwd<ST_CL>(d_x, wt_cl, 32 + 32 * b, d_hc);
+      for (int r = 0; r < 4; ++r) slot_accum16(gS2, d_h2.t[tt][r], 4 * tt + r, c);
+    T32 d_h1 = zero32();
+    mma_bwd32<ST_M>(d_h1, wt_m1, 0, d_h2);
+    d_h1 = relu_mask32(d_h1, act.h1);
+    // PE backward, x1 part: d x1 tile = cat^T d_h3 + in^T d_h1, consumed tile by tile
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int e0 = 32 * b + row0(r);
-        if (e0 < OBJ_E2) {
-          const PeSel s0 = pe_sel_x2(e0), s1 = pe_sel_x2(e0 + 4);
-          const float v = d_x[r] * pe_lane_value<true>(s0, s1, kh, t, proj);
-          if (s0.kind == 1) dproj[s0.idx] += kh ? 0.0f : v;
-          if (s1.kind == 1) dproj[s1.idx] += kh ? v : 0.0f;
-        }
+    for (int T = 0; T < 6; ++T) {
+      f32x4 d_x = zero4();
+      mma_bwd16<ST_CAT>(d_x, wt_cat, 32 + 16 * T, d_h3);
+      mma_bwd16<ST_IN>(d_x, wt_in, 16 * T, d_h1);
+      store_T16(stg_lane, 32 + 16 * T, pe_x1_tile_fb(pe, T, g, d_x, dps));
+    }
+    // d proj[(i + 4g) mod 21][sample] = d ps[i] * (1 or 2)  ->  rows 160..180 of the staging area (free in
+    // phase B).  The four lane groups of a sample sit in ONE wave and LDS executes a wave's accesses in order:
+    // group 0 stores (its rows are i, i.e. all 21), groups 1..3 then add.
+    {
+      float* trow = stg + 160 * STG_LD + 16 * w + c;
+#pragma unroll
+      for (int i = 0; i < OBJ_NDIR; ++i) {
+        const int wrap = (i > 8 && 4 * g + i >= OBJ_NDIR);
+        const int row = 4 * g + i - (wrap ? OBJ_NDIR : 0);
+        const float v = wrap ? 2.0f * dps[i] : dps[i];
+        if (g == 0) trow[row * STG_LD] = v;
+      }
+      // compiler barrier: per thread the stores and the adds are mutually exclusive, so the compiler may
+      // legally interleave them; the cross-LANE order (all stores, then the adds) is what matters here.
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < OBJ_NDIR; ++i) {
+        const int wrap = (i > 8 && 4 * g + i >= OBJ_NDIR);
+        const int row = 4 * g + i - (wrap ? OBJ_NDIR : 0);
+        const float v = wrap ? 2.0f * dps[i] : dps[i];
+        if (g != 0) atomicAdd(&trow[row * STG_LD], v);
       }
     }
-    f32x16 d_h3 = zero16();
-    mma_bwd<ST_M>(d_h3, wt_m2, 0, d_h4);
-    d_h3 = relu_mask16(d_h3, act.h3);
     __syncthreads();
     {
-      const int dTr = (w < 3) ? 128 : 160;
-      const int aTr = (w < 3) ? 32 * w : 96;
-      wgrad_tile(accA, lane_rd + dTr * STG_LD, lane_rd + aTr * STG_LD);
-    }
-    __syncthreads();
-    // ---- phase B: cat layer.  [h2 | x1] rows 0..119, d_h3pre rows 128..
-    store_tile_T(stg_lane, 0, act.h2);
-    store_tile_T(stg_lane, 32, e.x1[0]);
-    store_tile_T(stg_lane, 64, e.x1[1]);
-    store_tile_T(stg_lane, 96, e.x1[2], 12);
-    store_tile_T(stg_lane, 128, d_h3);
-    f32x16 d_h2 = zero16();
-    mma_bwd<ST_CAT>(d_h2, wt_cat, 0, d_h3);
-    d_h2 = relu_mask16(d_h2, act.h2);
+      // d B[j][x] += sum_s dproj[j][s] * t[x][s]  (embedding.py:48): thread (p, q) takes 16 samples of pair p
+      const int p = tid >> 3, qq = tid & 7;
+      if (p < 3 * OBJ_NDIR) {
+        const float* tp = stg + (160 + p / 3) * STG_LD + 16 * qq;
+        const float* xp = stg + (32 + p % 3) * STG_LD + 16 * qq;
+        float acc = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) slot_accum(g_bm1, d_h2[r], r, c);
-    f32x16 d_h1 = zero16();
-    mma_bwd<ST_M>(d_h1, wt_m1, 0, d_h2);
-    d_h1 = relu_mask16(d_h1, act.h1);
-    // PE backward, x1 part: d x1 block = cat^T d_h3 + in^T d_h1, consumed block by block
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-      f32x16 d_x = zero16();
-      mma_bwd<ST_CAT>(d_x, wt_cat, 32 + 32 * b, d_h3);
-      mma_bwd<ST_IN>(d_x, wt_in, 32 * b, d_h1);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int e0 = 32 * b + row0(r);
-        if (e0 < OBJ_E1) {
-          const PeSel s0 = pe_sel_x1(e0), s1 = pe_sel_x1(e0 + 4);
-          if (s0.kind == 1 || s1.kind == 1) {
-            const float v = d_x[r] * pe_lane_value<true>(s0, s1, kh, t, proj);
-            if (s0.kind == 1) dproj[s0.idx] += kh ? 0.0f : v;
-            if (s1.kind == 1) dproj[s1.idx] += kh ? v : 0.0f;
-          }
-        }
+        for (int s = 0; s < 16; ++s) acc = fmaf(tp[s], xp[s], acc);
+        g_dB += acc;
       }
-    }
-    // d B[j][:] += dproj[j] * t   (embedding.py:48); lanes kh=0 keep j = 0..10, kh=1 keep j = 11..20
-#pragma unroll
-    for (int j = 0; j < 11; ++j) {
-      const float lo = xhalf_sum(dproj[j]);
-      const float hi = (j + 11 < OBJ_NDIR) ? xhalf_sum(dproj[j + 11]) : 0.0f;
-      const float dv = kh ? hi : lo;
-#pragma unroll
-      for (int x = 0; x < 3; ++x) {
-        const int i = 3 * j + x;
-        slot_accum(i < 16 ? g_B0 : (i < 32 ? g_B1 : g_B2), dv * t[x], i & 15, c);
-      }
+      wgrad_pair(accB0, accB1, lane_rd + 128 * STG_LD, lane_rd + (16 * w) * STG_LD);
     }
     __syncthreads();
-    wgrad_tile(accB, lane_rd + 128 * STG_LD, lane_rd + (32 * w) * STG_LD);
-    __syncthreads();
-    // ---- phase C: in layer (x1 stays at rows 32..119) + mid1.  h1 rows 0.., d_h1pre 128.., d_h2pre 160..
-    store_tile_T(stg_lane, 0, act.h1);
-    store_tile_T(stg_lane, 128, d_h1);
-    store_tile_T(stg_lane, 160, d_h2);
+    // ---- phase C: in layer (x1 stays at rows 32..127) + mid1.  h1 rows 0.., d_h1pre 128.., d_h2pre 160..
+    store_T32(stg_lane, 0, act.h1);
+    store_T32(stg_lane, 128, d_h1);
+    store_T32(stg_lane, 160, d_h2);
     __syncthreads();
     {
-      const int dTr = (w < 3) ? 128 : 160;
-      const int aTr = (w < 3) ? 32 + 32 * w : 0;
-      wgrad_tile(accC, lane_rd + dTr * STG_LD, lane_rd + aTr * STG_LD);
+      const int dTr = (w < 6) ? 128 : 160;
+      const int aTr = (w < 6) ? 32 + 16 * w : 16 * (w - 6);
+      wgrad_pair(accC0, accC1, lane_rd + dTr * STG_LD, lane_rd + aTr * STG_LD);
     }
     __syncthreads();
   }
 
   // ------------------------------------------------------------------ write this workgroup's slab
-  float* slab = a.slab + ((long)k * a.G + g) * a.slab_stride;
+  float* slab = a.slab + ((long)k * a.G + gi) * a.slab_stride;
   const Layout& L = a.L;
-  if (w < 3) write_tile(slab, accA, c, kh, w, L.cl_w, H + OBJ_E2, L.cl_b);
-  else write_tile(slab, accA, c, kh, 0, L.m2_w, H, -1);
-  write_tile(slab, accB, c, kh, w, L.cat_w, H + OBJ_E1, L.cat_b);
-  if (w < 3) write_tile(slab, accC, c, kh, w, L.in_w, OBJ_E1, L.in_b);
-  else write_tile(slab, accC, c, kh, 0, L.m1_w, H, -1);
-
-  // slot registers -> LDS (per wave), then sum the 4 waves
-  float* red = stg;   // [4][NRED]
+  if (w < 5) write_pair(slab, accA0, accA1, c, g, w, L.cl_w, H + OBJ_E2, L.cl_b);
+  else if (w < 7) write_pair(slab, accA0, accA1, c, g, w - 5, L.m2_w, H, -1);
+  write_pair(slab, accB0, accB1, c, g, w, L.cat_w, H + OBJ_E1, L.cat_b);
+  if (w < 6) write_pair(slab, accC0, accC1, c, g, w, L.in_w, OBJ_E1, L.in_b);
+  else write_pair(slab, accC0, accC1, c, g, w - 6, L.m1_w, H, -1);
+  {
+    // d B: the 8 threads of pair p sit in one wave
+    float v = g_dB;
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    const int p = tid >> 3;
+    if ((tid & 7) == 0 && p < 3 * OBJ_NDIR) slab[L.pe_b + p] = v;
+  }
+  // slot registers -> LDS (per wave), then sum the 8 waves
+  float* red = stg;   // [NWAVE][NRED]
   {
     float* mine = red + w * NRED;
-    if (c >= 16) {
-      const int row = row0(c - 16) + 4 * kh;
-      mine[row] = g_bm1; mine[32 + row] = g_bm2; mine[64 + row] = g_wa;
-      mine[96 + row] = g_woc0; mine[128 + row] = g_woc1; mine[160 + row] = g_woc2;
-#pragma unroll
-      for (int n = 0; n < 3; ++n) {
-        const int i = 16 * n + (c - 16);          // entry of this half's 33 sums: i = 3*j' + x
-        const int j = i / 3 + 11 * kh;
-        const float v = n == 0 ? g_B0 : (n == 1 ? g_B1 : g_B2);
-        if (i < 33 && j < OBJ_NDIR) mine[196 + 3 * j + (i % 3)] = v;
-      }
-    }
+    const int s = c & 7;
+    const int row = 16 * (s >> 2) + 4 * g + (s & 3);
+    if (c < 8) { mine[64 + row] = gS0; mine[128 + row] = gS1; mine[row] = gS2; }          // wa, woc1, bm1
+    else { mine[96 + row] = gS0; mine[160 + row] = gS1; mine[32 + row] = gS2; }           // woc0, woc2, bm2
     const float s0 = wave_sum64(g_ba), s1 = wave_sum64(g_boc0), s2 = wave_sum64(g_boc1), s3 = wave_sum64(g_boc2);
     if (lane == 0) { mine[192] = s0; mine[193] = s1; mine[194] = s2; mine[195] = s3; }
     const float e0 = wave_sum64(l_d), e1 = wave_sum64(l_c), e2 = wave_sum64(l_o);
-    if (lane == 0) { mine[259] = e0; mine[260] = e1; mine[261] = e2; mine[262] = 0.0f; }
+    if (lane == 0) { mine[196] = e0; mine[197] = e1; mine[198] = e2; mine[199] = 0.0f; }
   }
   __syncthreads();
-  for (int i = tid; i < NRED; i += 256) {
-    const float v = red[i] + red[NRED + i] + red[2 * NRED + i] + red[3 * NRED + i];
+  for (int i = tid; i < NRED; i += NTHR) {
+    float v = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < NWAVE; ++ww) v += red[ww * NRED + i];
     if (i < 32) slab[L.m1_b + i] = v;
     else if (i < 64) slab[L.m2_b + i - 32] = v;
     else if (i < 96) slab[L.a_w + i - 64] = v;
     else if (i < 192) slab[L.oc_w + i - 96] = v;
     else if (i == 192) slab[L.a_b] = v;
     else if (i < 196) slab[L.oc_b + i - 193] = v;
-    else if (i < 259) slab[L.pe_b + i - 196] = v;
-    else a.loss_part[((long)k * a.G + g) * 4 + (i - 259)] = v;
+    else a.loss_part[((long)k * a.G + gi) * 4 + (i - 196)] = v;
   }
 }
 
@@ -402,35 +430,36 @@ __global__ void finalize_kernel(const float* slab, const float* loss_part, int K
 }
 
 // ------------------------------------------------------------------------------------------------
-template <bool FEAT>
+// Inference: 4 independent waves per workgroup, 16 points per wave per step.
+template <bool FEAT, bool FROM_EMB>
 __global__ __launch_bounds__(256) void eval_kernel(const EvalDev a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int c = lane & 31, kh = lane >> 5;
-  const int k = blockIdx.x / a.G, g = blockIdx.x % a.G;
+  const int c = lane & 15, g = lane >> 4;
+  const int k = blockIdx.x / a.G, gi = blockIdx.x % a.G;
   stage_weights(lds, a.params + (long)k * a.p_stride, a.L, FEAT, tid, 256);
-  const float scale = a.scale[k];
-  const long ntiles = (a.N + TS - 1) / TS;
-  for (long tile = g; tile < ntiles; tile += a.G) {
+  const float scale = FROM_EMB ? 1.0f : a.scale[k];
+  const long ntiles = (a.N + 63) / 64;
+  for (long tile = gi; tile < ntiles; tile += a.G) {
     asm volatile("" ::: "memory");   // keep the LDS weight reads inside the loop (no LICM into registers)
-    const long n = tile * TS + 32 * w + c;
+    const long n = tile * 64 + 16 * w + c;
     const bool valid = n < a.N;
-    float px = 0.f, py = 0.f, pz = 0.f;
-    if (valid) {
-      const float* p = a.pts + ((long)k * a.N + n) * 3;
-      px = p[0]; py = p[1]; pz = p[2];
-    }
-    float t[3], proj[OBJ_NDIR];
-    project(lds, px, py, pz, scale, t, proj);
+    const long o = (long)k * a.N + (valid ? n : 0);
     Emb e;
-    embed(e, kh, t, proj);
+    if (FROM_EMB) {
+      embed_load(e, a.emb + o * OBJ_EMB, g);
+    } else {
+      const float* p = a.pts + o * 3;
+      Pe pe;
+      pe_project(lds, g, p[0], p[1], p[2], scale, pe);
+      embed(e, pe, g);
+    }
     Acts act;
     Heads hd;
-    mlp_forward<FEAT>(lds, c, kh, e, act, hd);
+    mlp_forward<FEAT>(lds, c, g, e, act, hd);
     if (valid) {
-      const long o = (long)k * a.N + n;
-      if (kh == 0) {
+      if (g == 0) {
         a.alpha[o] = hd.alpha;
         a.color[o * 3] = hd.col[0];
         a.color[o * 3 + 1] = hd.col[1];
@@ -438,7 +467,10 @@ __global__ __launch_bounds__(256) void eval_kernel(const EvalDev a) {
       }
       if (FEAT) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) a.hfeat[o * H + row0(r) + 4 * kh] = act.hf[r];
+        for (int tt = 0; tt < 2; ++tt) {
+          float4 v = make_float4(act.hf.t[tt][0], act.hf.t[tt][1], act.hf.t[tt][2], act.hf.t[tt][3]);
+          *reinterpret_cast<float4*>(a.hfeat + o * H + 16 * tt + 4 * g) = v;
+        }
       }
     }
   }
@@ -456,6 +488,34 @@ int num_cu() {
 }
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+int eval_launch(const objnerf_net* net, int32_t K, int64_t N, const float* params, int64_t p_stride,
+                const float* scale, const float* pts, const float* emb, float* out_alpha, float* out_color,
+                float* out_hfeat, float* out_clip, void* stream) {
+  EvalDev d;
+  d.K = K; d.N = N; d.params = params; d.p_stride = p_stride; d.scale = scale; d.pts = pts; d.emb = emb;
+  d.alpha = out_alpha; d.color = out_color; d.hfeat = out_hfeat;
+  d.L = make_layout(net->feat_dim);
+  const long ntiles = (N + 63) / 64;
+  long G = (2L * num_cu()) / K;
+  if (G < 1) G = 1;
+  if (G > ntiles) G = ntiles;
+  d.G = (int)G;
+  hipStream_t st = (hipStream_t)stream;
+  const bool feat = out_hfeat != nullptr;
+  const size_t lds_bytes = (size_t)(feat ? W_FLOATS_FEAT : W_FLOATS_NOFEAT) * 4;
+  const dim3 grid(K * d.G), blk(256);
+  if (emb) {
+    if (feat) hipLaunchKernelGGL((eval_kernel<true, true>), grid, blk, lds_bytes, st, d);
+    else hipLaunchKernelGGL((eval_kernel<false, true>), grid, blk, lds_bytes, st, d);
+  } else {
+    if (feat) hipLaunchKernelGGL((eval_kernel<true, false>), grid, blk, lds_bytes, st, d);
+    else hipLaunchKernelGGL((eval_kernel<false, false>), grid, blk, lds_bytes, st, d);
+  }
+  if (hipGetLastError() != hipSuccess) return OBJNERF_ELAUNCH;
+  if (out_clip) return objnerf_feature_head(net, K, N, params, p_stride, out_hfeat, nullptr, out_clip, stream);
+  return OBJNERF_OK;
+}
 
 }  // namespace
 
@@ -487,13 +547,13 @@ size_t objnerf_train_workspace_bytes(const objnerf_net* net, int32_t K, int32_t 
   if (!net || K <= 0 || R <= 0 || S <= 0) return 0;
   int64_t offs[OBJNERF_N_TENSORS + 1];
   const int64_t ps = objnerf_param_layout(net, offs);
-  const int Gmax = num_cu();   // upper bound on G
+  const int Gmax = num_cu();   // upper bound on the workgroups per object
   (void)with_feat;
   return align256((size_t)K * Gmax * ps * 4) + align256((size_t)K * Gmax * 4 * 4) + align256((size_t)ps) + 256;
 }
 
 int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void* stream) {
-  (void)hipGetLastError();   // drop stale non-sticky errors of other HIP users
+  (void)hipGetLastError();   // drop stale non-sticky errors of other HIP users of this thread
   if (!net || !a || !a->params || !a->scale || !a->z || !a->gt_depth || !a->gt_rgb || !a->labels || !a->counts ||
       !a->flags || !a->grads || !a->loss_terms || !a->status || !a->workspace)
     return OBJNERF_EINVAL;
@@ -501,12 +561,12 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
   if (a->K <= 0 || a->R <= 0 || a->S <= 0) return OBJNERF_EINVAL;
   if (net->hidden != 32 || net->n_freqs != 6) return OBJNERF_ENOTSUP;
   if (a->S > 64) return OBJNERF_ENOTSUP;
-  if (a->gt_feat) return OBJNERF_ENOTSUP;   // feature-distillation branch: see objnerf_feat.hip
+  if (a->gt_feat) return OBJNERF_ENOTSUP;   // feature-distillation branch not built yet
   if (a->workspace_bytes < objnerf_train_workspace_bytes(net, a->K, a->R, a->S, a->gt_feat != nullptr))
     return OBJNERF_EINVAL;
   int64_t offs[OBJNERF_N_TENSORS + 1];
   const int64_t ps = objnerf_param_layout(net, offs);
-  if (a->p_stride < ps) return OBJNERF_EINVAL;
+  if (a->p_stride < offs[OBJNERF_N_TENSORS]) return OBJNERF_EINVAL;
 
   TrainDev d;
   d.K = a->K; d.R = a->R; d.S = a->S;
@@ -523,6 +583,7 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
   char* ws = (char*)a->workspace;
   const int Gmax = num_cu();
   d.slab = (float*)ws;
+  d.slab_stride = ps;
   ws += align256((size_t)a->K * Gmax * ps * 4);
   d.loss_part = (float*)ws;
   ws += align256((size_t)a->K * Gmax * 4 * 4);
@@ -530,24 +591,23 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
 
   hipStream_t st = (hipStream_t)stream;
   // has_grad mask: everything except the feature branch (train.py:435-438 -> .grad stays None)
-  hipMemsetAsync(has_grad, 1, (size_t)ps, st);
-  hipMemsetAsync(has_grad + d.L.fl_w, 0, (size_t)(d.L.pe_b - d.L.fl_w), st);
-  hipMemsetAsync(a->status, 0, sizeof(int), st);
+  (void)hipMemsetAsync(has_grad, 1, (size_t)ps, st);
+  (void)hipMemsetAsync(has_grad + d.L.fl_w, 0, (size_t)(d.L.pe_b - d.L.fl_w), st);
+  (void)hipMemsetAsync(a->status, 0, sizeof(int), st);
 
   const size_t lds_bytes = (size_t)(W_FLOATS_NOFEAT + SM_FLOATS + STG_ROWS * STG_LD) * 4;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)train_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)lds_bytes);
+    (void)hipFuncSetAttribute((const void*)train_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds_bytes);
     attr_set = true;
   }
-  d.slab_stride = ps;
-  hipLaunchKernelGGL(train_fused_kernel<false>, dim3(a->K * d.G), dim3(256), lds_bytes, st, d);
+  hipLaunchKernelGGL(train_fused_kernel<false>, dim3(a->K * d.G), dim3(NTHR), lds_bytes, st, d);
   if (hipGetLastError() != hipSuccess) return OBJNERF_ELAUNCH;
   const long P = offs[OBJNERF_N_TENSORS];
   dim3 fg((unsigned)((P + 255) / 256), (unsigned)a->K);
-  hipLaunchKernelGGL(finalize_kernel, fg, dim3(256), 0, st, d.slab, d.loss_part, a->K, d.G, P, (long)ps, (long)a->p_stride,
-                     has_grad, a->grads, a->loss_terms, a->status);
+  hipLaunchKernelGGL(finalize_kernel, fg, dim3(256), 0, st, d.slab, d.loss_part, a->K, d.G, P, (long)ps,
+                     (long)a->p_stride, has_grad, a->grads, a->loss_terms, a->status);
   if (hipGetLastError() != hipSuccess) return OBJNERF_ELAUNCH;
   return OBJNERF_OK;
 }
@@ -555,27 +615,23 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
 int objnerf_eval_points(const objnerf_net* net, int32_t K, int64_t N, const float* params, int64_t p_stride,
                         const float* scale, const float* pts, float* out_alpha, float* out_color, float* out_hfeat,
                         float* out_clip, void* stream) {
-  (void)hipGetLastError();   // drop stale non-sticky errors of other HIP users
+  (void)hipGetLastError();
   if (!net || !params || !scale || !pts || !out_alpha || !out_color || K <= 0 || N <= 0) return OBJNERF_EINVAL;
   if (net->hidden != 32 || net->n_freqs != 6) return OBJNERF_ENOTSUP;
   if (out_clip && !out_hfeat) return OBJNERF_EINVAL;   // the head runs on the H-wide hidden
-  EvalDev d;
-  d.K = K; d.N = N; d.params = params; d.p_stride = p_stride; d.scale = scale; d.pts = pts;
-  d.alpha = out_alpha; d.color = out_color; d.hfeat = out_hfeat;
-  d.L = make_layout(net->feat_dim);
-  const long ntiles = (N + TS - 1) / TS;
-  long G = (2L * num_cu()) / K;
-  if (G < 1) G = 1;
-  if (G > ntiles) G = ntiles;
-  d.G = (int)G;
-  hipStream_t st = (hipStream_t)stream;
-  const bool feat = out_hfeat != nullptr;
-  const size_t lds_bytes = (size_t)(feat ? W_FLOATS_FEAT : W_FLOATS_NOFEAT) * 4;
-  if (feat) hipLaunchKernelGGL(eval_kernel<true>, dim3(K * d.G), dim3(256), lds_bytes, st, d);
-  else hipLaunchKernelGGL(eval_kernel<false>, dim3(K * d.G), dim3(256), lds_bytes, st, d);
-  if (hipGetLastError() != hipSuccess) return OBJNERF_ELAUNCH;
-  if (out_clip) return objnerf_feature_head(net, K, N, params, p_stride, out_hfeat, nullptr, out_clip, stream);
-  return OBJNERF_OK;
+  return eval_launch(net, K, N, params, p_stride, scale, pts, nullptr, out_alpha, out_color, out_hfeat, out_clip,
+                     stream);
+}
+
+int objnerf_mlp_forward(const objnerf_net* net, int32_t K, int64_t N, const float* params, int64_t p_stride,
+                        const float* emb, float* out_alpha, float* out_color, float* out_hfeat, float* out_clip,
+                        void* stream) {
+  (void)hipGetLastError();
+  if (!net || !params || !emb || !out_alpha || !out_color || K <= 0 || N <= 0) return OBJNERF_EINVAL;
+  if (net->hidden != 32 || net->n_freqs != 6) return OBJNERF_ENOTSUP;
+  if (out_clip && !out_hfeat) return OBJNERF_EINVAL;
+  return eval_launch(net, K, N, params, p_stride, nullptr, nullptr, emb, out_alpha, out_color, out_hfeat, out_clip,
+                     stream);
 }
 
 }  // extern "C"

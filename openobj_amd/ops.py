@@ -115,6 +115,21 @@ def eval_points(arena: ParamArena, pts: torch.Tensor, want_hfeat: bool = False, 
     return alpha, color, hfeat, clip
 
 
+def mlp_forward(arena: ParamArena, emb: torch.Tensor, want_hfeat: bool = False, want_clip: bool = False):
+    """emb [K,N,129] -> alpha [K,N], color [K,N,3], hfeat | None, clip | None (OccupancyMap.forward)."""
+    emb = _req(emb, torch.float32, "emb")
+    K, N = emb.shape[0], emb.shape[1]
+    dev = emb.device
+    alpha = torch.empty(K, N, device=dev)
+    color = torch.empty(K, N, 3, device=dev)
+    hfeat = torch.empty(K, N, arena.net.hidden, device=dev) if (want_hfeat or want_clip) else None
+    clip = torch.empty(K, N, arena.net.feat_dim, device=dev) if want_clip else None
+    net = arena.net.c()
+    check(lib().objnerf_mlp_forward(C.byref(net), K, N, _ptr(arena.params), arena.p_stride, _ptr(emb), _ptr(alpha),
+                                    _ptr(color), _ptr(hfeat), _ptr(clip), _stream()), "objnerf_mlp_forward")
+    return alpha, color, hfeat, clip
+
+
 def embed(arena: ParamArena, pts: torch.Tensor) -> torch.Tensor:
     pts = _req(pts, torch.float32, "pts")
     K, N = pts.shape[0], pts.shape[1]
