@@ -107,15 +107,15 @@ __device__ __forceinline__ void stage_weights(float* lds, const float* __restric
 struct T32 {
   f32x4 t[2];
 };
-
 __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+
 __device__ __forceinline__ T32 zero32() { return T32{{zero4(), zero4()}}; }
 __device__ __forceinline__ T32 relu32(const T32& a) {
   T32 o;
 #pragma unroll
   for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) o.t[tt][r] = fmaxf(a.t[tt][r], 0.0f);
+    for (int r = 0; r < 4; ++r) o.t[tt][r] = fmaxf(a.t[tt][r], 0.0f);   // (no inline asm: MFMA->VALU hazards are the compiler's)
   return o;
 }
 __device__ __forceinline__ T32 relu_mask32(const T32& gr, const T32& act) {
@@ -133,10 +133,16 @@ __device__ __forceinline__ T32 relu_mask32(const T32& gr, const T32& act) {
 // wl = &W[c * ST + 4 * g]   (c = lane & 15 is the OUTPUT row inside each 16-row out tile)
 template <int ST>
 __device__ __forceinline__ void mma_fwd16(T32& acc, const float* wl, const int col0, const f32x4& xt) {
+  float a0[4], a1[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    acc.t[0] = OBJ_MFMA(wl[col0 + r], xt[r], acc.t[0]);
-    acc.t[1] = OBJ_MFMA(wl[16 * ST + col0 + r], xt[r], acc.t[1]);
+    a0[r] = wl[col0 + r];
+    a1[r] = wl[16 * ST + col0 + r];
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    acc.t[0] = OBJ_MFMA(a0[r], xt[r], acc.t[0]);
+    acc.t[1] = OBJ_MFMA(a1[r], xt[r], acc.t[1]);
   }
 }
 template <int ST>
@@ -148,20 +154,34 @@ __device__ __forceinline__ void mma_fwd32(T32& acc, const float* wl, const int c
 // wt = &W[(4 * g) * ST + c]   (c = lane & 15 is the INPUT feature of the A operand here)
 template <int ST>
 __device__ __forceinline__ void mma_bwd16(f32x4& acc, const float* wt, const int col, const T32& d) {
+  float a[8];
 #pragma unroll
-  for (int tt = 0; tt < 2; ++tt)
+  for (int i = 0; i < 8; ++i) a[i] = wt[(16 * (i >> 2) + (i & 3)) * ST + col];
+  // two accumulation chains (even / odd k-steps) keep the dependent-MFMA latency off the critical path
+  f32x4 acc2 = zero4();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc = OBJ_MFMA(wt[(16 * tt + r) * ST + col], d.t[tt][r], acc);
+  for (int i = 0; i < 8; i += 2) {
+    acc = OBJ_MFMA(a[i], d.t[i >> 2][i & 3], acc);
+    acc2 = OBJ_MFMA(a[i + 1], d.t[(i + 1) >> 2][(i + 1) & 3], acc2);
+  }
+  acc += acc2;
 }
 template <int ST>
 __device__ __forceinline__ void mma_bwd32(T32& acc, const float* wt, const int col0, const T32& d) {
 #pragma unroll
-  for (int tt = 0; tt < 2; ++tt)
+  for (int tt = 0; tt < 2; ++tt) {
+    float a0[4], a1[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      acc.t[0] = OBJ_MFMA(wt[(16 * tt + r) * ST + col0], d.t[tt][r], acc.t[0]);
-      acc.t[1] = OBJ_MFMA(wt[(16 * tt + r) * ST + col0 + 16], d.t[tt][r], acc.t[1]);
+      a0[r] = wt[(16 * tt + r) * ST + col0];
+      a1[r] = wt[(16 * tt + r) * ST + col0 + 16];
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      acc.t[0] = OBJ_MFMA(a0[r], d.t[tt][r], acc.t[0]);
+      acc.t[1] = OBJ_MFMA(a1[r], d.t[tt][r], acc.t[1]);
+    }
+  }
 }
 
 // ----------------------------------------------------------------------------------------------
