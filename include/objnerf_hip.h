@@ -122,10 +122,14 @@ int objnerf_embed(const objnerf_net* net, int32_t K, int64_t N, const float* par
  *   composite: the H-wide feature hidden, or the reference's C-wide clip tensor).
  *   out_term [n][S] or NULL, out_depth/out_var/out_opacity [n], out_rgb [n][3], out_vals [n][V].
  */
-int objnerf_composite(int64_t n_rays, int32_t S, const float* alpha, const float* color,
+#define OBJNERF_COMPOSITE_INPUT_IS_OCCUPANCY 1   /* `alpha` already holds sigmoid(alpha) (render_rays.py:32) */
+int objnerf_composite(int64_t n_rays, int32_t S, int32_t flags, const float* alpha, const float* color,
                       const float* z, const float* vals, int32_t V, float* out_term,
                       float* out_depth, float* out_var, float* out_rgb, float* out_opacity,
                       float* out_vals, void* stream);
+
+/* A8 alone: occupancy_activation(alpha) = sigmoid(alpha), n elements (render_rays.py:6-14). */
+int objnerf_occupancy(int64_t n, const float* alpha, float* out, void* stream);
 
 /* out_clip head applied after compositing (exact: the head is linear):
  * out [K][n][C] = of_w[k] . hfeat[k][n] + of_b[k] * weight[k][n]   (weight = opacity, or NULL=1). */

@@ -86,7 +86,8 @@ SIGNATURES = {
                                       C.c_void_p]),
     "objnerf_embed": (C.c_int, [C.POINTER(Net), C.c_int32, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                 C.c_void_p, C.c_void_p, C.c_void_p]),
-    "objnerf_composite": (C.c_int, [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+    "objnerf_occupancy": (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "objnerf_composite": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p]),
     "objnerf_feature_head": (C.c_int, [C.POINTER(Net), C.c_int32, C.c_int64, C.c_void_p, C.c_int64,

@@ -13,8 +13,9 @@ __device__ __forceinline__ float sgnf(float x) { return x > 0.f ? 1.0f : (x < 0.
 // composite: one wave per ray, samples on lanes in chunks of 64 with carries.
 // render_rays.py:6-63 / loss.py:27-35,82.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void composite_kernel(long n_rays, int S, const float* alpha, const float* color,
-                                                        const float* z, const float* vals, int V, float* out_term,
+__global__ __launch_bounds__(256) void composite_kernel(long n_rays, int S, int in_is_occ, const float* alpha,
+                                                        const float* color, const float* z, const float* vals,
+                                                        int V, float* out_term,
                                                         float* out_depth, float* out_var, float* out_rgb,
                                                         float* out_opacity, float* out_vals) {
   extern __shared__ float sm[];
@@ -27,7 +28,7 @@ __global__ __launch_bounds__(256) void composite_kernel(long n_rays, int S, cons
     const int s = s0 + lane;
     const bool on = s < S;
     const float al = on ? alpha[ray * S + s] : 0.f;
-    const float occ = on ? sigmoid_acc(al) : 0.f;
+    const float occ = on ? (in_is_occ ? al : sigmoid_acc(al)) : 0.f;
     const float fr = on ? (1.0f - occ) + 1e-10f : 1.0f;
     const float pinc = seg_scan_mul(fr, lane, 64) * carry;
     float T = __shfl_up(pinc, 1, 64);
@@ -38,7 +39,7 @@ __global__ __launch_bounds__(256) void composite_kernel(long n_rays, int S, cons
       wv[s] = wt;
       if (out_term) out_term[ray * S + s] = wt;
     }
-    const float zz = on ? z[ray * S + s] : 0.f;
+    const float zz = (on && z) ? z[ray * S + s] : 0.f;
     D += wave_sum64(wt * zz);
     O += wave_sum64(wt);
     if (color) {
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(256) void composite_kernel(long n_rays, int S, cons
   for (int s0 = 0; s0 < S; s0 += 64) {
     const int s = s0 + lane;
     const bool on = s < S;
-    const float dz = on ? z[ray * S + s] - D : 0.f;
+    const float dz = (on && z) ? z[ray * S + s] - D : 0.f;
     Vv += wave_sum64(on ? wv[s] * (dz * dz) : 0.f);
   }
   if (lane == 0) {
@@ -124,6 +125,12 @@ __global__ void embed_kernel(int K, long N, int n_freqs, const float* params, lo
       o[3 + f * OBJ_NDIR + j] = s;
     }
   }
+}
+
+// render_rays.py:6-14 (distances=None branch): occ = sigmoid(alpha)
+__global__ void occupancy_kernel(long n, const float* alpha, float* out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = sigmoid_acc(alpha[i]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -414,15 +421,25 @@ __global__ void sample_place_kernel(const objnerf_sample_args a, const float* or
 
 extern "C" {
 
-int objnerf_composite(int64_t n_rays, int32_t S, const float* alpha, const float* color, const float* z,
-                      const float* vals, int32_t V, float* out_term, float* out_depth, float* out_var, float* out_rgb,
-                      float* out_opacity, float* out_vals, void* stream) {
+int objnerf_composite(int64_t n_rays, int32_t S, int32_t flags, const float* alpha, const float* color,
+                      const float* z, const float* vals, int32_t V, float* out_term, float* out_depth, float* out_var,
+                      float* out_rgb, float* out_opacity, float* out_vals, void* stream) {
   CLEAR_STALE();
-  if (n_rays <= 0 || S <= 0 || !alpha || !z) return OBJNERF_EINVAL;
+  if (n_rays <= 0 || S <= 0 || !alpha) return OBJNERF_EINVAL;
+  if (!z && (out_depth || out_var)) return OBJNERF_EINVAL;
   if (S > 4096) return OBJNERF_ENOTSUP;
   hipLaunchKernelGGL(composite_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), (size_t)4 * S * 4,
-                     (hipStream_t)stream, (long)n_rays, S, alpha, color, z, vals, V, out_term, out_depth, out_var,
-                     out_rgb, out_opacity, out_vals);
+                     (hipStream_t)stream, (long)n_rays, S, (int)(flags & OBJNERF_COMPOSITE_INPUT_IS_OCCUPANCY), alpha,
+                     color, z, vals, V, out_term, out_depth, out_var, out_rgb, out_opacity, out_vals);
+  CHECK_LAUNCH();
+  return OBJNERF_OK;
+}
+
+int objnerf_occupancy(int64_t n, const float* alpha, float* out, void* stream) {
+  CLEAR_STALE();
+  if (n <= 0 || !alpha || !out) return OBJNERF_EINVAL;
+  hipLaunchKernelGGL(occupancy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (long)n,
+                     alpha, out);
   CHECK_LAUNCH();
   return OBJNERF_OK;
 }

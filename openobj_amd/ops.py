@@ -141,11 +141,20 @@ def embed(arena: ParamArena, pts: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def composite(alpha: torch.Tensor, color: Optional[torch.Tensor], z: torch.Tensor,
-              vals: Optional[torch.Tensor] = None, want_term: bool = False) -> Dict[str, torch.Tensor]:
+def occupancy(alpha: torch.Tensor) -> torch.Tensor:
+    alpha = _req(alpha, torch.float32, "alpha")
+    out = torch.empty_like(alpha)
+    check(lib().objnerf_occupancy(alpha.numel(), _ptr(alpha), _ptr(out), _stream()), "objnerf_occupancy")
+    return out
+
+
+def composite(alpha: torch.Tensor, color: Optional[torch.Tensor], z: Optional[torch.Tensor],
+              vals: Optional[torch.Tensor] = None, want_term: bool = False,
+              input_is_occupancy: bool = False) -> Dict[str, torch.Tensor]:
     """alpha [n,S], color [n,S,3], z [n,S], vals [n,S,V] -> term/depth/var/rgb/opacity/vals."""
     alpha = _req(alpha, torch.float32, "alpha")
-    z = _req(z, torch.float32, "z")
+    if z is not None:
+        z = _req(z, torch.float32, "z")
     n, S = alpha.shape
     dev = alpha.device
     if color is not None:
@@ -157,11 +166,11 @@ def composite(alpha: torch.Tensor, color: Optional[torch.Tensor], z: torch.Tenso
         V = vals.shape[-1]
         out_vals = torch.empty(n, V, device=dev)
     term = torch.empty(n, S, device=dev) if want_term else None
-    depth = torch.empty(n, device=dev)
-    var = torch.empty(n, device=dev)
+    depth = torch.empty(n, device=dev) if z is not None else None
+    var = torch.empty(n, device=dev) if z is not None else None
     rgb = torch.empty(n, 3, device=dev) if color is not None else None
     opacity = torch.empty(n, device=dev)
-    check(lib().objnerf_composite(n, S, _ptr(alpha), _ptr(color), _ptr(z), _ptr(vals), V, _ptr(term), _ptr(depth),
+    check(lib().objnerf_composite(n, S, int(input_is_occupancy), _ptr(alpha), _ptr(color), _ptr(z), _ptr(vals), V, _ptr(term), _ptr(depth),
                                   _ptr(var), _ptr(rgb), _ptr(opacity), _ptr(out_vals), _stream()),
           "objnerf_composite")
     return dict(term=term, depth=depth, var=var, rgb=rgb, opacity=opacity, vals=out_vals)

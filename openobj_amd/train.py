@@ -1,0 +1,64 @@
+"""The training loop of the reference's train.py:272-276,394-485 for training_strategy == "hip":
+stack the object networks into the arena, run n_iter_per_frame fused iterations over slices of the
+per-frame sample pool, copy the stacked parameters back.  Object creation, dataset reading, labelling
+and visualisation (the rest of train.py) stay with the caller."""
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops, optim
+from .render_rays import LossExplode
+
+
+class HipTrainLoop:
+    def __init__(self, cfg, trainers: List, with_feat: bool = False):
+        """trainers: the per-object Trainer instances in obj_dict order (train.py:255-256)."""
+        self.cfg, self.trainers, self.with_feat = cfg, list(trainers), with_feat
+        self.arena = None
+        self.opt = None
+        self.ws = None
+        self.rebuild()
+
+    def rebuild(self):
+        """utils.update_vmap for both model lists (train.py:272-276): gather the K per-object arena
+        blocks; Adam moments restart because the reference adds a fresh param group."""
+        K = len(self.trainers)
+        t0 = self.trainers[0]
+        self.arena = ops.ParamArena(K, t0.arena.net, t0.arena.params.device)
+        with torch.no_grad():
+            for k, t in enumerate(self.trainers):
+                self.arena.params[k].copy_(t.arena.params[0])
+                self.arena.scale[k] = float(t.obj_scale)
+        self.opt = optim.ArenaAdamW(self.arena, lr=self.cfg.learning_rate, weight_decay=self.cfg.weight_decay)
+        self.mask = self.arena.has_grad_mask(self.with_feat)
+        self.ws = None
+
+    def step(self, batch: Dict[str, torch.Tensor], global_flags: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """One iteration (train.py:424-474).  Returns the per-object loss terms [K,4] (device tensor)."""
+        K, R, S = batch["z"].shape
+        if self.ws is None or self.ws.key != (K, R, S, self.with_feat):
+            self.ws = ops.TrainWorkspace(self.arena, K, R, S, self.with_feat)
+        ops.train_step(self.arena, self.ws, batch, with_feat=self.with_feat, global_flags=global_flags)
+        self.opt.step(self.ws.grads, self.mask)
+        return self.ws.loss_terms
+
+    def train_frame(self, pool: Dict[str, torch.Tensor], n_iter: Optional[int] = None,
+                    n_per_optim: Optional[int] = None, check_status: bool = True) -> List[torch.Tensor]:
+        """pool: the stacked per-frame sample tensors of train.py:368-388 ([K, n_iter*n_per_optim, ...]);
+        iteration i trains on rays [i*n_per_optim, (i+1)*n_per_optim) (train.py:396-404)."""
+        n_iter = n_iter or self.cfg.n_iter_per_frame
+        npo = n_per_optim or self.cfg.n_per_optim
+        out = []
+        for it in range(n_iter):
+            sl = slice(it * npo, (it + 1) * npo)
+            batch = {k: v[:, sl].contiguous() for k, v in pool.items()}
+            out.append(self.step(batch).clone())
+        if check_status and int(self.ws.status.item()) != 0:
+            raise LossExplode("loss explode")
+        return out
+
+    def copy_back(self):
+        """train.py:478-485: stacked parameters -> each object's modules (their arena block)."""
+        with torch.no_grad():
+            for k, t in enumerate(self.trainers):
+                t.arena.params[0].copy_(self.arena.params[k])

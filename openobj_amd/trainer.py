@@ -1,0 +1,57 @@
+"""Trainer -- owns one OccupancyMap + UniDirsEmbed per object (trainer.py:11-128); both modules'
+parameters are views of ONE per-object arena block, so update_vmap can gather K of them with a copy."""
+import numpy as np
+import torch
+
+from . import embedding, model, ops
+
+
+class Trainer:
+    def __init__(self, cfg):
+        self.obj_id = cfg.obj_id
+        self.device = cfg.training_device
+        self.hidden_feature_size = cfg.hidden_feature_size        # 32 objects / 128 background
+        self.clip_point_feature_size = cfg.clip_point_feature_size
+        self.obj_scale = cfg.obj_scale
+        self.n_unidir_funcs = cfg.n_unidir_funcs
+        self.emb_size1 = 21 * (3 + 1) + 3                         # trainer.py:20
+        self.emb_size2 = 21 * (5 + 1) + 3 - self.emb_size1        # trainer.py:21
+        self.load_network()
+        self.bound_extent = 0.995 if self.obj_id == 0 else 0.9    # trainer.py:25-28
+        self.W_vis, self.H_vis = cfg.W, cfg.H
+        self.T_WC_gt = None
+        self.dirs_C_gt = None
+        self.input_pcs = None
+
+    def load_network(self):                                       # trainer.py:36-44
+        self.arena = ops.ParamArena(1, ops.NetShape(self.hidden_feature_size, self.clip_point_feature_size,
+                                                    self.n_unidir_funcs + 1), self.device)
+        self.fc_occ_map = model.OccupancyMap(self.emb_size1, self.emb_size2, hidden_size=self.hidden_feature_size,
+                                             clip_size=self.clip_point_feature_size, device=self.device,
+                                             _arena=self.arena)
+        self.fc_occ_map.apply(model.init_weights)
+        self.pe = embedding.UniDirsEmbed(max_deg=self.n_unidir_funcs, scale=self.obj_scale, device=self.device,
+                                         _arena=self.arena)
+
+    def eval_points(self, points, chunk_size=300000):
+        """points [N,3] -> (occupancy [N], color [N,3], clip [N,C]) or None (trainer.py:105-128).
+        One fused launch per chunk: PE + MLP + feature head; occupancy = sigmoid(alpha)."""
+        self.arena.scale.fill_(float(self.obj_scale))
+        n_chunks = int(np.ceil(points.shape[0] / chunk_size))
+        occ, color, clip = [], [], []
+        with torch.no_grad():
+            for k in range(n_chunks):
+                pts = points[k * chunk_size:(k + 1) * chunk_size].reshape(1, -1, 3).to(self.device).contiguous()
+                a, c, _, f = ops.eval_points(self.arena, pts, want_clip=True)
+                occ.append(ops.occupancy(a[0]))
+                color.append(c[0])
+                clip.append(f[0])
+        occ, color, clip = torch.cat(occ), torch.cat(color), torch.cat(clip)
+        if occ.max() == 0:
+            print("no occ")
+            return None
+        return (occ, color, clip)
+
+    def meshing(self, *a, **k):
+        raise NotImplementedError("marching cubes / open3d meshing (trainer.py:46-103, vis.py) is outside the "
+                                  "accelerated path; evaluate the grid with eval_points(render_rays.make_3D_grid(...))")

@@ -1,0 +1,220 @@
+"""vmap -- scene-object state of the reference's vmap.py that feeds the hot path: cameraInfo
+(:689-720), sceneObject's keyframe buffers + append_keyframe (:29-257), the pixel / ray sampler
+get_training_samples + sample_3d_points (:386-554) on objnerf_sample_rays, and the checkpoint dict
+(:556-602).  3-D bounding-box estimation, point-cloud denoising and novel-view rendering
+(get_bound, render_2D_syn) are not on the accelerated training path.
+"""
+import copy
+import os
+import random
+
+import numpy as np
+import torch
+
+from . import ops, trainer
+
+
+class cameraInfo:
+    def __init__(self, cfg) -> None:
+        self.device = cfg.data_device
+        self.width, self.height = cfg.W, cfg.H
+        self.fx, self.fy, self.cx, self.cy = cfg.fx, cfg.fy, cfg.cx, cfg.cy
+        self.rays_dir_cache = self.get_rays_dirs()
+
+    def get_rays_dirs(self, depth_type="z"):
+        """(W,H,3) un-normalised camera rays, image stored transposed (vmap.py:701-720)."""
+        if depth_type != "z":
+            raise Exception("Get camera rays directions with euclidean depth not yet implemented")
+        return ops.rays_dirs(self.width, self.height, float(self.fx), float(self.fy), float(self.cx),
+                             float(self.cy), self.device)
+
+
+class sceneObject:
+    """Keyframe ring buffers of one object + its Trainer (networks)."""
+
+    def __init__(self, cfg, obj_id, rgb, depth, mask, bbox_2d, t_wc, live_frame_id, clip_feat=None,
+                 caption_feat=None) -> None:
+        self.do_bg = cfg.do_bg
+        self.obj_id = obj_id
+        self.data_device = cfg.data_device
+        self.training_device = cfg.training_device
+        self.part_mode = cfg.part_mode
+        self.stride = cfg.stride
+        assert rgb.shape[:2] == depth.shape
+        assert rgb.shape[:2] == mask.shape
+        assert bbox_2d.shape == (4,)
+        assert t_wc.shape == (4, 4,)
+        if self.do_bg and self.obj_id == 0:      # separate background network (vmap.py:43-52)
+            self.obj_scale = cfg.bg_scale
+            self.hidden_feature_size = cfg.hidden_feature_size_bg
+            self.n_bins_cam2surface = cfg.n_bins_cam2surface_bg
+            self.keyframe_step = cfg.keyframe_step_bg
+        else:
+            self.obj_scale = cfg.obj_scale
+            self.hidden_feature_size = cfg.hidden_feature_size
+            self.n_bins_cam2surface = cfg.n_bins_cam2surface
+            self.keyframe_step = cfg.keyframe_step
+        self.frames_width, self.frames_height = rgb.shape[0], rgb.shape[1]
+        self.min_bound, self.max_bound = cfg.min_depth, cfg.max_depth
+        self.n_bins = cfg.n_bins
+        self.n_unidir_funcs = cfg.n_unidir_funcs
+        self.surface_eps, self.stop_eps = cfg.surface_eps, cfg.stop_eps
+        self.n_keyframes = 1
+        self.kf_pointer = None
+        self.keyframe_buffer_size = cfg.keyframe_buffer_size
+        self.kf_id_dict = {live_frame_id: 0}        # frame id -> slot (insertion ordered, like the bidict)
+        self.kf_buffer_full = False
+        self.frame_cnt = 0
+        self.lastest_kf_queue = []
+        self.feat_cnt = 1
+        self.clip_feat, self.caption_feat = clip_feat, caption_feat
+        dev = self.data_device
+        self.bbox = torch.empty(self.keyframe_buffer_size, 4, device=dev)
+        self.bbox[0] = bbox_2d
+        self.rgb_idx, self.state_idx = slice(0, 3), slice(3, 4)
+        self.rgbs_batch = torch.empty(self.keyframe_buffer_size, self.frames_width, self.frames_height, 4,
+                                      dtype=torch.uint8, device=dev)
+        if self.part_mode:
+            self.part_down = cfg.part_down
+            self.use_frame = np.zeros(self.keyframe_buffer_size)
+            self.use_frame[0] = live_frame_id
+        self.other_obj, self.this_obj, self.unknown_obj = 0, 1, 2
+        self.semantic_id = None
+        self.rgbs_batch[0, :, :, self.rgb_idx] = rgb
+        self.rgbs_batch[0, :, :, self.state_idx] = mask[..., None]
+        self.depth_batch = torch.empty(self.keyframe_buffer_size, self.frames_width, self.frames_height,
+                                       dtype=torch.float32, device=dev)
+        self.depth_batch[0] = depth
+        self.t_wc_batch = torch.empty(self.keyframe_buffer_size, 4, 4, dtype=torch.float32, device=dev)
+        self.t_wc_batch[0] = t_wc
+        trainer_cfg = copy.deepcopy(cfg)
+        trainer_cfg.obj_id = self.obj_id
+        trainer_cfg.hidden_feature_size = self.hidden_feature_size
+        trainer_cfg.obj_scale = self.obj_scale
+        self.trainer = trainer.Trainer(trainer_cfg)
+        self.bbox_final = False
+        self.bbox3dour = None
+        self.obj_center = torch.tensor(0.0)
+
+    # ------------------------------------------------------------------ keyframes (vmap.py:166-257)
+    def _write_slot(self, slot, rgb, depth, mask, bbox_2d, t_wc, frame_id):
+        self.rgbs_batch[slot, :, :, self.rgb_idx] = rgb
+        self.rgbs_batch[slot, :, :, self.state_idx] = mask[..., None]
+        self.depth_batch[slot, ...] = depth
+        self.t_wc_batch[slot, ...] = t_wc
+        self.bbox[slot, ...] = bbox_2d
+        if self.part_mode:
+            self.use_frame[slot] = frame_id
+
+    def _rebind(self, slot, frame_id):
+        for k, v in list(self.kf_id_dict.items()):
+            if v == slot:
+                del self.kf_id_dict[k]
+        self.kf_id_dict[frame_id] = slot
+
+    def append_keyframe(self, rgb, depth, mask, bbox_2d, t_wc, frame_id=1, clip_feat=None, caption_feat=None):
+        assert rgb.shape[:2] == depth.shape and rgb.shape[:2] == mask.shape
+        assert bbox_2d.shape == (4,) and t_wc.shape == (4, 4,)
+        assert self.n_keyframes <= self.keyframe_buffer_size - 1
+        assert rgb.dtype == torch.uint8 and mask.dtype == torch.uint8 and depth.dtype == torch.float32
+        is_kf = (self.frame_cnt % self.keyframe_step == 0) or self.n_keyframes == 1
+        if self.n_keyframes == self.keyframe_buffer_size - 1:      # buffer full: overwrite the free slot
+            self.kf_buffer_full = True
+            if self.kf_pointer is None:
+                self.kf_pointer = self.n_keyframes
+            self._write_slot(self.kf_pointer, rgb, depth, mask, bbox_2d, t_wc, frame_id)
+            self._rebind(self.kf_pointer, frame_id)
+            if is_kf:
+                self.lastest_kf_queue.append(self.kf_pointer)
+                _, self.kf_pointer = self.prune_keyframe()
+        elif not is_kf:                                            # replace the live (last) slot
+            self._write_slot(self.n_keyframes - 1, rgb, depth, mask, bbox_2d, t_wc, frame_id)
+            self._rebind(self.n_keyframes - 1, frame_id)
+        else:                                                      # add a new keyframe
+            self.kf_id_dict[frame_id] = self.n_keyframes
+            self._write_slot(self.n_keyframes, rgb, depth, mask, bbox_2d, t_wc, frame_id)
+            self.lastest_kf_queue.append(self.n_keyframes)
+            self.n_keyframes += 1
+        self.frame_cnt += 1
+        if clip_feat is not None:
+            self.clip_feat = np.vstack((self.clip_feat, clip_feat))
+            self.caption_feat = np.vstack((self.caption_feat, caption_feat))
+            self.feat_cnt += 1
+        if len(self.lastest_kf_queue) > 2:
+            self.lastest_kf_queue = self.lastest_kf_queue[-2:]
+
+    def prune_keyframe(self):
+        key, value = random.choice(list(self.kf_id_dict.items())[:-2])   # never the latest two
+        return key, value
+
+    # ------------------------------------------------------------------ sampling (vmap.py:386-554)
+    def draw_keyframe_ids(self, n_frames):
+        dev = self.data_device
+        if self.n_keyframes > 2:      # the latest two keyframes are always included, LAST (vmap.py:390-401)
+            ids = torch.randint(low=0, high=self.n_keyframes, size=(n_frames - 2,), dtype=torch.long, device=dev)
+            return torch.cat([ids, torch.tensor(self.lastest_kf_queue[-2:], device=dev)])
+        return torch.randint(low=0, high=self.n_keyframes, size=(n_frames,), dtype=torch.long, device=dev)
+
+    def get_training_samples(self, n_frames, n_samples, cached_rays_dir, global_partfeat=None, draws=None):
+        """Returns the reference's 7-tuple (rgb u8, depth, valid_depth_mask[flat], obj_labels[flat] u8,
+        input_pcs, sampled_z, sampled_partfeat).  `draws` = dict(kf_ids, u_w, u_h, u, g) injects the
+        random numbers; otherwise they are drawn on the device (torch generator)."""
+        dev = self.data_device
+        N, M = self.n_bins_cam2surface, self.n_bins
+        n = n_frames * n_samples
+        if draws is None:
+            draws = dict(kf_ids=self.draw_keyframe_ids(n_frames),
+                         u_w=torch.rand(n_frames, n_samples, device=dev),
+                         u_h=torch.rand(n_frames, n_samples, device=dev),
+                         u=torch.rand(n, N + M, device=dev),
+                         g=torch.empty(n, M, device=dev).normal_(mean=0., std=self.surface_eps / 3.))
+        rgb, depth, valid, labels, pts, z = ops.sample_rays(
+            self.rgbs_batch, self.depth_batch, self.t_wc_batch, self.bbox, cached_rays_dir, draws["kf_ids"],
+            draws["u_w"], draws["u_h"], draws["u"], draws["g"], N, M, self.surface_eps, self.stop_eps,
+            float(self.min_bound), float(self.obj_center))
+        partfeat = None
+        if self.part_mode and global_partfeat is not None:          # vmap.py:437-452
+            kf = draws["kf_ids"][:, None]
+            bb = self.bbox[kf]
+            idx_w = draws["u_w"] * (bb[..., 1] - bb[..., 0]) + bb[..., 0]
+            idx_h = draws["u_h"] * (bb[..., 3] - bb[..., 2]) + bb[..., 2]
+            use_frame = torch.tensor(self.use_frame).to(dev)
+            fid = (use_frame[kf] / self.stride).long()
+            partfeat = global_partfeat[fid, torch.floor(idx_w / self.part_down).long(),
+                                       torch.floor(idx_h / self.part_down).long()]
+        return rgb, depth, valid, labels, pts, z, partfeat
+
+    # ------------------------------------------------------------------ checkpoints (vmap.py:556-602)
+    def save_checkpoints(self, path, epoch):
+        torch.save({
+            "epoch": epoch,
+            "FC_state_dict": self.trainer.fc_occ_map.state_dict(),
+            "PE_state_dict": self.trainer.pe.state_dict(),
+            "obj_id": self.obj_id,
+            "bbox": self.bbox3dour,
+            "obj_scale": self.trainer.obj_scale,
+            "clip_feat": self.clip_feat,
+            "caption_feat": self.caption_feat,
+            "semantic_id": self.semantic_id,
+        }, path + "/obj_" + str(self.obj_id) + ".pth")
+
+    def load_checkpoints(self, ckpt_file):
+        if not os.path.exists(ckpt_file):
+            print("ckpt not exist ", ckpt_file)
+            return
+        checkpoint = torch.load(ckpt_file, weights_only=False)
+        with torch.no_grad():
+            for k, v in checkpoint["FC_state_dict"].items():     # copy INTO the arena views
+                self.trainer.fc_occ_map.state_dict()[k].copy_(v)
+            self.trainer.pe.B_layer.weight.copy_(checkpoint["PE_state_dict"]["B_layer.weight"])
+        self.obj_id = checkpoint["obj_id"]
+        self.bbox3dour = checkpoint["bbox"]
+        self.trainer.obj_scale = checkpoint["obj_scale"]
+        if "clip_feat" not in checkpoint.keys():
+            print("no clip_feat for this obj:", self.obj_id)
+            return False
+        self.clip_feat = checkpoint["clip_feat"]
+        self.caption_feat = checkpoint["caption_feat"]
+        self.semantic_id = checkpoint["semantic_id"]
+        self.bbox_final = True
+        return True

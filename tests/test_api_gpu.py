@@ -1,0 +1,200 @@
+"""GPU: the host-side mirror used the way the reference's train.py / gen_map_vis.py use it."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import T
+from oracle import objnerf_oracle as O
+from openobj_amd import cfg as ocfg
+from openobj_amd import loss as oloss
+from openobj_amd import ops, render_rays, synthetic, trainer, utils
+from openobj_amd import train as otrain
+from openobj_amd import vmap as ovmap
+
+pytestmark = pytest.mark.gpu
+
+
+def maxerr(a, b):
+    return (torch.as_tensor(a).double().cpu() - torch.as_tensor(b).double().cpu()).abs().max().item()
+
+
+def make_cfg(dev, **kw):
+    c = ocfg.Config(ocfg.replica_room0_config(train_device=str(dev), **kw))
+    c.obj_id = 1
+    return c
+
+
+def make_trainers(K, dev, seed, **kw):
+    torch.manual_seed(seed)
+    return [trainer.Trainer(make_cfg(dev, **kw)) for _ in range(K)]
+
+
+def oracle_params(ts):
+    fc = [torch.stack([list(t.fc_occ_map.parameters())[i].detach().cpu() for t in ts]) for i in range(18)]
+    B = torch.stack([t.pe.B_layer.weight.detach().cpu() for t in ts])
+    return fc, B
+
+
+def test_modules_forward_like_reference(dev):
+    """pe(pts) then fc_occ_map(emb), as render_2D_syn / eval_points do (vmap.py:644-655)."""
+    t = make_trainers(1, dev, 3)[0]
+    pts = torch.from_numpy(np.random.RandomState(0).uniform(-2, 2, (7, 11, 3)).astype(np.float32))
+    emb = t.pe(pts.to(dev))
+    alpha, color, clip = t.fc_occ_map(emb)
+    fc, B = oracle_params([t])
+    e = O.unidirs_embed(pts, B[0], 2.0)
+    a, c, f = O.mlp_forward([p[0] for p in fc], e)
+    assert emb.shape == (7, 11, 129) and alpha.shape == (7, 11, 1) and clip.shape == (7, 11, 512)
+    assert maxerr(emb, e) < 2e-5
+    assert maxerr(alpha, a) < 1e-4 and maxerr(color, c) < 1e-5 and maxerr(clip, f) < 1e-4
+    assert t.fc_occ_map(emb, do_clip=False)[2] is None
+
+
+def test_eval_points_like_trainer(dev):
+    t = make_trainers(1, dev, 4)[0]
+    pts = torch.from_numpy(np.random.RandomState(1).uniform(-1, 1, (1000, 3)).astype(np.float32))
+    occ, color, clip = t.eval_points(pts.to(dev), chunk_size=300)
+    fc, B = oracle_params([t])
+    a, c, f = O.mlp_forward([p[0] for p in fc], O.unidirs_embed(pts, B[0], 2.0))
+    assert maxerr(occ, torch.sigmoid(a.squeeze(-1))) < 1e-5
+    assert maxerr(color, c) < 1e-5 and maxerr(clip, f) < 1e-4
+
+
+def test_vmap_call_sequence(dev):
+    """train.py:272-276,424-425: update_vmap, then vmap(pe_model) / vmap(fc_model)."""
+    ts = make_trainers(3, dev, 5)
+    fc_model, fc_param, fc_buffer = utils.update_vmap([t.fc_occ_map for t in ts])
+    pe_model, pe_param, pe_buffer = utils.update_vmap([t.pe for t in ts], arena=fc_model.arena)
+    pcs = torch.from_numpy(np.random.RandomState(2).uniform(-2, 2, (3, 20, 10, 3)).astype(np.float32))
+    emb = utils.vmap(pe_model)(pe_param, pe_buffer, pcs.to(dev))
+    alpha, color, clip = utils.vmap(fc_model)(fc_param, fc_buffer, emb)
+    fc, B = oracle_params(ts)
+    e = O.embed_stacked(B, torch.full((3,), 2.0), pcs)
+    a, c, f = O.mlp_forward_stacked(fc, e, True)
+    assert alpha.shape == (3, 20, 10, 1) and clip.shape == (3, 20, 10, 512)
+    assert maxerr(emb, e) < 2e-5 and maxerr(alpha, a) < 1e-4 and maxerr(color, c) < 1e-5 and maxerr(clip, f) < 1e-4
+
+
+def test_render_rays_helpers_g3(golden, dev):
+    g = golden("g3_render")
+    occ = render_rays.occupancy_activation(T(g["alpha"]).to(dev))
+    assert maxerr(occ, g["occ"]) < 1e-6
+    assert maxerr(render_rays.occupancy_to_termination(occ, is_batch=True), g["term_b"]) < 1e-6
+    assert maxerr(render_rays.occupancy_to_termination(occ[0]), g["term_nb"]) < 1e-6
+    term = T(g["term_b"]).to(dev)
+    assert maxerr(render_rays.render(term, T(g["z"]).to(dev)), g["depth"]) < 1e-5
+
+
+@pytest.mark.parametrize("feat_on", [False, True])
+def test_step_batch_loss_autograd_g4(golden, dev, feat_on):
+    """loss.step_batch_loss with the reference's signature, differentiated with autograd."""
+    g = golden("g4_loss")
+    tag = "normal_" + ("feat" if feat_on else "nofeat")
+    a = T(g["alpha"]).to(dev).requires_grad_(True)
+    c = T(g["color"]).to(dev).requires_grad_(True)
+    f = T(g["clip"]).to(dev).requires_grad_(True)
+    labels = T(g["labels_normal"]).to(dev)
+    kw = dict(gt_partfeat=T(g["gt_feat"]).to(dev), pred_partfeat=f) if feat_on else {}
+    l, none = oloss.step_batch_loss(a, c, T(g["gt_depth"]).to(dev), T(g["gt_rgb"]).to(dev), labels,
+                                    torch.ones_like(labels, dtype=torch.bool), T(g["z"]).to(dev), **kw)
+    assert none is None
+    (2.0 * l).backward()
+    assert abs(l.item() - float(g[f"loss_{tag}"])) < 1e-4 * abs(float(g[f"loss_{tag}"]))
+    assert maxerr(a.grad, 2 * g[f"dalpha_{tag}"]) < 2e-5 and maxerr(c.grad, 2 * g[f"dcolor_{tag}"]) < 2e-5
+    if feat_on:
+        assert maxerr(f.grad, 2 * g[f"dclip_{tag}"]) < 2e-5
+
+
+def test_scene_object_sampling_g7(golden, dev):
+    """sceneObject built from keyframe buffers; get_training_samples with the reference's recorded draws."""
+    g = golden("g7_sample")
+    W, H = g["gts_rgbs_batch"].shape[1:3]
+    c = make_cfg(dev, **{"model.keyframe_buffer_size": 4, "trainer.part_mode": 0})
+    c.W, c.H = int(W), int(H)
+    c.fx = c.fy = 30.0
+    c.cx, c.cy = 19.5, 14.5
+    cam = ovmap.cameraInfo(c)
+    assert torch.equal(cam.rays_dir_cache.cpu(), T(g["gts_rays_dir_cache"]))
+    rb = T(g["gts_rgbs_batch"])
+    obj = ovmap.sceneObject(c, 1, rb[0, :, :, :3].to(dev), T(g["gts_depth_batch"])[0].to(dev), rb[0, :, :, 3].to(dev),
+                            T(g["gts_bbox"])[0].to(dev), T(g["gts_t_wc"])[0].to(dev), 0)
+    obj.rgbs_batch.copy_(rb.to(dev))
+    obj.depth_batch.copy_(T(g["gts_depth_batch"]).to(dev))
+    obj.t_wc_batch.copy_(T(g["gts_t_wc"]).to(dev))
+    obj.bbox.copy_(T(g["gts_bbox"]).to(dev))
+    obj.n_keyframes = 4
+    draws = dict(kf_ids=T(g["gts_kf_ids"]).to(dev), u_w=T(g["gts_u_w"]).to(dev), u_h=T(g["gts_u_h"]).to(dev),
+                 u=T(g["gts_u"]).to(dev), g=T(g["gts_g"]).to(dev))
+    rgb, depth, valid, labels, pts, z, pf = obj.get_training_samples(7, 5, cam.rays_dir_cache, None, draws=draws)
+    assert pf is None
+    assert torch.equal(rgb.cpu(), T(g["gts_rgb"])) and torch.equal(labels.cpu(), T(g["gts_labels"]))
+    assert torch.equal(valid.cpu(), T(g["gts_valid"]))
+    assert maxerr(z, g["gts_z"]) < 1e-6 and maxerr(pts, g["gts_pts"]) < 4e-6
+    # un-injected draws: bounds of the depth-guided placement (vmap.py:483-542)
+    rgb, depth, valid, labels, pts, z, _ = obj.get_training_samples(50, 8, cam.rays_dir_cache)
+    z, depth, labels, valid = z.reshape(-1, 10).cpu(), depth.reshape(-1).cpu(), labels.cpu(), valid.cpu()
+    v1 = valid & (labels == 1)
+    assert bool(((z[v1, 1:] - depth[v1, None]).abs() <= 0.1 + 1e-6).all())
+    vo = valid & (labels != 1)
+    assert bool((z[vo, 1:] >= depth[vo, None] - 0.1 - 1e-6).all() and (z[vo, 1:] <= depth[vo, None] + 0.05 + 1e-6).all())
+    assert bool((z[valid, 0] <= depth[valid] - 0.1 + 1e-6).all() and (z >= -1e-6).all())
+
+
+def test_keyframe_ring_and_checkpoint_roundtrip(dev, tmp_path):
+    c = make_cfg(dev, **{"model.keyframe_buffer_size": 4, "model.keyframe_step": 10, "trainer.part_mode": 0})
+    c.W, c.H = 16, 12
+    rs = np.random.RandomState(0)
+    def frame():
+        return (torch.from_numpy(rs.randint(0, 255, (16, 12, 3)).astype(np.uint8)).to(dev),
+                torch.from_numpy(rs.rand(16, 12).astype(np.float32)).to(dev),
+                torch.from_numpy(rs.randint(0, 3, (16, 12)).astype(np.uint8)).to(dev),
+                torch.tensor([0., 15., 0., 11.], device=dev), torch.eye(4, device=dev))
+    obj = ovmap.sceneObject(c, 7, *frame(), 0)
+    for fid in range(1, 9):
+        obj.append_keyframe(*frame(), frame_id=fid)
+        assert obj.n_keyframes <= c.keyframe_buffer_size - 1
+        assert len(obj.lastest_kf_queue) <= 2
+    assert obj.kf_buffer_full
+    obj.save_checkpoints(str(tmp_path), 3)
+    ck = torch.load(str(tmp_path / "obj_7.pth"), weights_only=False)
+    assert sorted(ck.keys()) == sorted(["epoch", "FC_state_dict", "PE_state_dict", "obj_id", "bbox", "obj_scale",
+                                        "clip_feat", "caption_feat", "semantic_id"])     # vmap.py:563-575
+    assert list(ck["PE_state_dict"].keys()) == ["scale", "B_layer.weight"]
+    before = [p.detach().clone() for p in obj.trainer.fc_occ_map.parameters()]
+    with torch.no_grad():
+        for p in obj.trainer.fc_occ_map.parameters():
+            p.zero_()
+    obj.load_checkpoints(str(tmp_path / "obj_7.pth"))
+    for p, b in zip(obj.trainer.fc_occ_map.parameters(), before):
+        assert torch.equal(p, b)
+    assert float(obj.trainer.arena.params.abs().sum()) > 0      # the values landed in the arena block
+
+
+def test_train_loop_psnr_g9(golden, dev):
+    """The integration fixture: 300 iterations on the analytic ellipsoid scene from the reference's
+    initial weights.  Loss curve follows the reference's, PSNR on held-out rays within 0.1 dB."""
+    g = golden("g9_psnr_nofeat")
+    K, R, N, M, steps, eval_R, eval_S, scene_seed = [int(x) for x in g["meta"]]
+    scene = synthetic.EllipsoidScene.make(K, 512, seed=scene_seed)
+    ts = make_trainers(K, dev, 90)
+    for k, t in enumerate(ts):          # the fixture's initial weights == Trainer(seed 90) (checked, then forced)
+        for i, p in enumerate(t.fc_occ_map.parameters()):
+            assert torch.equal(p.detach().cpu(), T(g[f"fc0_{i}"])[k])
+    loop = otrain.HipTrainLoop(make_cfg(dev), ts, with_feat=False)
+    losses = []
+    for it in range(steps):
+        b = scene.batch(R, N, M, seed=9000 + it)
+        batch = {k: T(b[k]).to(dev) for k in ["pts", "z", "gt_depth", "gt_rgb", "labels"]}
+        t = loop.step(batch)
+        losses.append(float((t[:, 0] + 5 * t[:, 1] + 10 * t[:, 2]).sum()))
+    np.testing.assert_allclose(losses[:10], g["loss"][:10], rtol=2e-4)
+    assert abs(losses[-1] - g["loss"][-1]) < 0.05 * abs(g["loss"][-1])
+    loop.copy_back()
+    ev = scene.eval_rays(eval_R, eval_S)
+    rgbs = []
+    for k, t in enumerate(ts):
+        a, c, _, _ = ops.eval_points(t.arena, T(ev["pts"][k]).reshape(1, -1, 3).to(dev))
+        out = ops.composite(a.reshape(eval_R, eval_S), c.reshape(eval_R, eval_S, 3), T(ev["z"][k]).to(dev))
+        rgbs.append(out["rgb"].cpu())
+    psnr = O.psnr(torch.stack(rgbs), T(ev["gt_rgb"]))
+    assert abs(psnr - float(g["psnr"])) < 0.1, (psnr, float(g["psnr"]))

@@ -1,0 +1,106 @@
+"""CPU: host-side mirror of the reference interface (no kernels run here)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import T
+from openobj_amd import cfg as ocfg
+from openobj_amd import dist as odist
+from openobj_amd import ops, trainer, utils
+
+
+def make_cfg(**kw):
+    c = ocfg.Config(ocfg.replica_room0_config(train_device="cpu", **kw))
+    c.obj_id = 1
+    return c
+
+
+def test_config_matches_room0_json():
+    """Attribute names and derived values of cfg.py:16-114 on the shipped room_0 hyper-parameters."""
+    c = make_cfg()
+    assert (c.n_per_optim, c.win_size, c.n_samples_per_frame) == (120, 5, 24)
+    assert (c.n_per_optim_bg, c.win_size_bg, c.n_samples_per_frame_bg) == (1200, 10, 120)
+    assert (c.n_bins, c.n_bins_cam2surface, c.n_bins_cam2surface_bg) == (9, 1, 5)
+    assert (c.hidden_feature_size, c.hidden_feature_size_bg, c.clip_point_feature_size) == (32, 128, 512)
+    assert (c.W, c.H, c.fx, c.cx, c.cy) == (1200, 680, 600.0, 599.5, 339.5)
+    assert (c.learning_rate, c.weight_decay) == (0.001, 0.013)
+    assert c.keyframe_step == 2.5 and c.keyframe_step_bg == 5.0 and c.part_mode and c.part_down == 5
+    assert (c.surface_eps, c.stop_eps, c.obj_scale, c.bg_scale) == (0.1, 0.05, 2.0, 5.0)
+
+
+def test_config_from_json_file(tmp_path):
+    p = tmp_path / "c.json"
+    p.write_text(json.dumps(ocfg.replica_room0_config(train_device="cpu", strategy="vmap")))
+    assert ocfg.Config(str(p)).training_strategy == "vmap"
+
+
+def test_trainer_init_reproduces_reference(golden):
+    """Same seed -> same initial parameters as the reference's Trainer (trainer.py:36-44, model.py:4-6):
+    the G5 fixture holds the reference's stack for torch.manual_seed(50)."""
+    g = golden("g5_step_s10_nofeat")
+    torch.manual_seed(50)
+    ts = [trainer.Trainer(make_cfg()) for _ in range(3)]
+    for k, t in enumerate(ts):
+        for i, p in enumerate(t.fc_occ_map.parameters()):
+            assert torch.equal(p.detach(), T(g[f"fc0_{i}"])[k]), (k, i)
+    keys = list(ts[0].fc_occ_map.state_dict().keys())
+    assert keys == [n for n in ops.TENSOR_NAMES[:18]]
+    assert list(ts[0].pe.state_dict().keys()) == ["scale", "B_layer.weight"]
+
+
+def test_update_vmap_stacks_like_combine_state_for_ensemble(golden):
+    g = golden("g5_step_s10_nofeat")
+    torch.manual_seed(50)
+    ts = [trainer.Trainer(make_cfg()) for _ in range(3)]
+    fmodel, params, buffers = utils.update_vmap([t.fc_occ_map for t in ts])
+    pe_model, pe_params, pe_buffers = utils.update_vmap([t.pe for t in ts], arena=fmodel.arena)
+    assert len(params) == 18 and len(pe_params) == 1
+    for i, p in enumerate(params):
+        assert tuple(p.shape) == tuple(g[f"fc0_{i}"].shape)
+        assert torch.equal(p, T(g[f"fc0_{i}"]))
+    assert tuple(pe_params[0].shape) == (3, 21, 3)
+    assert tuple(pe_buffers[0].shape) == (3, 6) and tuple(pe_buffers[1].shape) == (3,)
+
+
+def test_shard_objects_partition():
+    for K in (1, 7, 50, 120, 512):
+        for world in (1, 2, 4, 8):
+            blocks = [odist.shard_objects(K, world, r) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == K
+            assert all(blocks[i][1] == blocks[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in blocks]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # rank 1 owns an object with an empty label-1 mask: the flag must become global
+    flags = torch.tensor([1 if rank == 1 else 0, 0], dtype=torch.int32)
+    odist.global_flags(flags)
+    terms = torch.full((2, 4), float(rank + 1))
+    tot = odist.total_loss(terms)
+    q.put((rank, flags.tolist(), float(tot)))
+    dist.destroy_process_group()
+
+
+def test_two_rank_flags_and_loss_gloo():
+    """world_size-2 gloo run of the object-sharding host logic (the N>1 path of bench.py)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    expect = 2 * (1 + 5 + 10 + 5) * 1.0 + 2 * (1 + 5 + 10 + 5) * 2.0
+    for rank, flags, tot in res:
+        assert flags == [1, 0]
+        assert abs(tot - expect) < 1e-4
