@@ -14,7 +14,12 @@ from . import ops
 
 def init_weights(m, init_fn=torch.nn.init.xavier_normal_):
     if type(m) == torch.nn.Linear:        # model.py:4-6
-        init_fn(m.weight)
+        # The reference initialises on the CPU (then .to(device)); draw from the CPU generator as well so
+        # that a seed yields the same weights, then write into the (possibly device-resident) arena view.
+        tmp = torch.empty(m.weight.shape, dtype=m.weight.dtype)
+        init_fn(tmp)
+        with torch.no_grad():
+            m.weight.copy_(tmp)
 
 
 def fc_block(in_f, out_f):

@@ -152,7 +152,7 @@ class sceneObject:
         dev = self.data_device
         if self.n_keyframes > 2:      # the latest two keyframes are always included, LAST (vmap.py:390-401)
             ids = torch.randint(low=0, high=self.n_keyframes, size=(n_frames - 2,), dtype=torch.long, device=dev)
-            return torch.cat([ids, torch.tensor(self.lastest_kf_queue[-2:], device=dev)])
+            return torch.cat([ids, torch.tensor(self.lastest_kf_queue[-2:], dtype=torch.long, device=dev)])
         return torch.randint(low=0, high=self.n_keyframes, size=(n_frames,), dtype=torch.long, device=dev)
 
     def get_training_samples(self, n_frames, n_samples, cached_rays_dir, global_partfeat=None, draws=None):

@@ -440,42 +440,59 @@ def g8():
 G9 = dict(K=4, R=96, N=4, M=12, steps=300, eval_R=256, eval_S=32, scene_seed=7, weight_seed=90)
 
 
+def _g9_eval(ts, fc_list, B, ev):
+    pts, z, gt_rgb = to_t(ev, ["pts", "z", "gt_rgb"])
+    with torch.no_grad():
+        rgbs, depths = [], []
+        for k, t in enumerate(ts):
+            # copy-back (train.py:478-485), then the reference's own modules render the held-out rays
+            for i, p in enumerate(t.fc_occ_map.parameters()):
+                p.copy_(fc_list[i][k])
+            t.pe.B_layer.weight.copy_(B[k])
+            a, c, _ = t.fc_occ_map(t.pe(pts[k]))
+            term = ref_rr.occupancy_to_termination(ref_rr.occupancy_activation(a.squeeze(-1)))
+            rgbs.append(ref_rr.render(term[..., None], c, dim=-2))
+            depths.append(ref_rr.render(term, z[k]))
+        rgb, depth = torch.stack(rgbs), torch.stack(depths)
+    mse = torch.mean((rgb - gt_rgb) ** 2).item()
+    return -10 * np.log10(mse), rgb, depth
+
+
 def g9():
+    """PSNR scene.  Training is chaotic (Adam on ReLU nets): a 1e-7 relative perturbation of the initial
+    weights moves the reference's own 300-iteration PSNR by ~0.5 dB, so besides the single run the
+    fixture holds (a) the PSNR after 50 iterations, where trajectories have not yet diverged, and (b) an
+    ensemble of 300-iteration PSNRs over 6 weight seeds."""
     scene = synthetic.EllipsoidScene.make(G9["K"], 512, seed=G9["scene_seed"])
+    ev = scene.eval_rays(G9["eval_R"], G9["eval_S"])
+
+    def batches(it):
+        return scene.batch(G9["R"], G9["N"], G9["M"], seed=9000 + it, with_feat=True)
+
     for feat_on in (False, True):
         ts = make_trainers(G9["K"], seed=G9["weight_seed"], perturb_B=False)
         fc0, B0 = stack_params(ts)
-
-        def batches(it):
-            return scene.batch(G9["R"], G9["N"], G9["M"], seed=9000 + it, with_feat=True)
-
+        rec50 = run_reference_steps(ts, batches, feat_on, n_steps=50, record_grads=False)
+        psnr50, _, _ = _g9_eval(ts, rec50["final_fc"], rec50["final_B"], ev)
+        ts = make_trainers(G9["K"], seed=G9["weight_seed"], perturb_B=False)
         rec = run_reference_steps(ts, batches, feat_on, n_steps=G9["steps"], record_grads=False)
-        ev = scene.eval_rays(G9["eval_R"], G9["eval_S"])
-        pts, z, gt_rgb = to_t(ev, ["pts", "z", "gt_rgb"])
-        with torch.no_grad():
-            rgbs, depths = [], []
-            for k, t in enumerate(ts):
-                # copy-back (train.py:478-485)
-                for i, p in enumerate(t.fc_occ_map.parameters()):
-                    p.copy_(rec["final_fc"][i][k])
-                t.pe.B_layer.weight.copy_(rec["final_B"][k])
-                a, c, _ = t.fc_occ_map(t.pe(pts[k]))
-                term = ref_rr.occupancy_to_termination(ref_rr.occupancy_activation(a.squeeze(-1)))
-                rgbs.append(ref_rr.render(term[..., None], c, dim=-2))
-                depths.append(ref_rr.render(term, z[k]))
-            rgb = torch.stack(rgbs)
-            depth = torch.stack(depths)
-        mse = torch.mean((rgb - gt_rgb) ** 2).item()
-        psnr = -10 * np.log10(mse)
+        psnr, rgb, depth = _g9_eval(ts, rec["final_fc"], rec["final_B"], ev)
         tag = "feat" if feat_on else "nofeat"
-        print(f"g9 {tag}: final loss {rec['loss'][-1]:.4f}  PSNR {psnr:.3f} dB")
+        ens = []
+        if not feat_on:
+            for seed in range(G9["weight_seed"], G9["weight_seed"] + 6):
+                tse = make_trainers(G9["K"], seed=seed, perturb_B=False)
+                rece = run_reference_steps(tse, batches, False, n_steps=G9["steps"], record_grads=False)
+                ens.append(_g9_eval(tse, rece["final_fc"], rece["final_B"], ev)[0])
+        print(f"g9 {tag}: final loss {rec['loss'][-1]:.4f}  PSNR {psnr:.3f} dB  (50 it: {psnr50:.3f})  ensemble {ens}")
         out = {f"fc0_{i}": fc0[i] for i in range(18)}
         out["B0"] = B0
         out.update({f"fcT_{i}": rec["final_fc"][i] for i in range(18)})
         out["BT"] = rec["final_B"]
-        save(f"g9_psnr_{tag}", loss=np.array(rec["loss"]), psnr=np.array(psnr), eval_rgb=rgb,
-             eval_depth=depth, meta=np.array([G9[k] for k in ["K", "R", "N", "M", "steps", "eval_R",
-                                                              "eval_S", "scene_seed"]], np.int32), **out)
+        save(f"g9_psnr_{tag}", loss=np.array(rec["loss"]), psnr=np.array(psnr), psnr50=np.array(psnr50),
+             psnr_ensemble=np.array(ens), eval_rgb=rgb, eval_depth=depth,
+             meta=np.array([G9[k] for k in ["K", "R", "N", "M", "steps", "eval_R", "eval_S", "scene_seed"]],
+                           np.int32), **out)
 
 
 # ------------------------------------------------------------------------------------------ G10
