@@ -38,8 +38,21 @@ struct TrainDev {
   float* slab;        // [K][G][slab_stride]
   long slab_stride;
   float* loss_part;   // [K][G][4]
+  // feature-distillation branch (gt_feat != NULL)
+  const float* rayin;   // [K][R][RAYIN]  u = W_of^T g (32), beta = b_of . g, |g|     (feat_pre_kernel)
+  const float* gram;    // [K][GRAM]      G = W_of^T W_of (32x32), wb = W_of^T b_of (32), b_of . b_of
+  float* rayfeat;       // [K][R][RAYFEAT] composited hidden fh (32), a, c, opacity   (-> feat_post kernels)
   Layout L;
 };
+constexpr int RAYIN = 34, GRAM = 1088, RAYFEAT = 36;
+// LDS aliases inside the staging area, valid from the forward pass until phase B of the backward pass
+constexpr int HF_LD = 33;                       // hfbuf [128][33] at stg + 0
+constexpr int OFF_GBUF = TS * HF_LD;            // G [32][33], wb [32], bb          (4224 ..)
+constexpr int OFF_FHB = OFF_GBUF + 32 * 33 + 64;   // fh exchange buffer [2][32]
+constexpr int OFF_SW = 80 * STG_LD;             // rows 80..95 are untouched by the phase-A staging
+constexpr int OFF_GFH = OFF_SW + TS;            // gfh [16][32]
+constexpr int OFF_GOF = OFF_GFH + 16 * 32;      // gO_feat [16], O [16]
+static_assert(OFF_FHB + 64 <= 80 * STG_LD && OFF_GOF + 32 <= 96 * STG_LD, "feat lds aliases");
 
 struct EvalDev {
   int K, G; long N;
@@ -119,7 +132,9 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
   float gS2 = 0.f;   // [0..7] d b_mid1    | [8..15] d b_mid2
   float g_ba = 0.f, g_boc0 = 0.f, g_boc1 = 0.f, g_boc2 = 0.f;
   float g_dB = 0.f;  // thread (p = tid >> 3, q = tid & 7): partial of d B[p / 3][p % 3] over samples 16q..16q+15
-  float l_d = 0.f, l_c = 0.f, l_o = 0.f;
+  float l_d = 0.f, l_c = 0.f, l_o = 0.f, l_f = 0.f;
+  f32x4 accF0 = zero4(), accF1 = zero4();
+  const float* wt_fl = lds + OFF_FL + (4 * g) * ST_CL + c;
 
   float* stg_lane = stg + (4 * g) * STG_LD + 16 * w + c;
   const float* lane_rd = stg + c * STG_LD + g;
@@ -167,6 +182,17 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
       s_col[slot] = hd.col[0];
       s_col[TS + slot] = hd.col[1];
       s_col[2 * TS + slot] = hd.col[2];
+    }
+    if (FEAT) {
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) stg[slot * HF_LD + 16 * tt + 4 * g + r] = act.hf.t[tt][r];
+      for (int i = tid; i < 32 * 32 + 33; i += NTHR) {       // this object's Gram matrix (+ wb, bb) for the tile
+        const float v = a.gram[(long)k * GRAM + i];
+        if (i < 1024) stg[OFF_GBUF + (i >> 5) * 33 + (i & 31)] = v;
+        else stg[OFF_GBUF + 32 * 33 + (i - 1024)] = v;
+      }
     }
     __syncthreads();
     // ---------------------------------------------------------------- 2. composite + loss (loss.py:27-101)
@@ -220,7 +246,71 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
           l_c += m1 * (fabsf(r0) + fabsf(r1) + fabsf(r2)) * inv1;
           l_o += m2 * fabsf(ro) * inv2;
         }
-        const float dw = gD * zz + gO + gC0 * c0 + gC1 * c1 + gC2 * c2;
+        float dw = gD * zz + gO + gC0 * c0 + gC1 * c1 + gC2 * c2;
+        if (FEAT) {
+          // ---- feature-distillation term (loss.py:82-99) with the linear 512-d head hoisted past the
+          // compositing: F = W_of fh + b_of O,  fh = sum_s w_s hf_s.  cos(F, g) only needs
+          //   F.g = fh.u + O beta,   |F|^2 = fh^T G fh + 2 O wb.fh + O^2 bb     (u, beta, G, wb, bb precomputed)
+          float* s_w = stg + OFF_SW;
+          float* s_gfh = stg + OFF_GFH;
+          float* s_gof = stg + OFF_GOF;
+          float* s_fhb = stg + OFF_FHB;
+          const float* Gb = stg + OFF_GBUF;
+          if (on) s_w[sl] = wgt;
+          if (on && pos == 0) s_gof[16 + qq] = O;
+          __builtin_amdgcn_wave_barrier();
+          asm volatile("" ::: "memory");
+          const int half = lane >> 5, hh = lane & 31;
+          for (int qb = 0; qb < rpp; qb += 2) {
+            const int ql2 = qb + half;
+            const int qq2 = ps * rpp + ql2;
+            const int ray2 = ray0 + qq2;
+            const bool on2 = (ql2 < rpp) && (qq2 < TR) && (ray2 < R);
+            const long rr2 = (long)k * R + (on2 ? ray2 : 0);
+            float fh = 0.f;
+            if (on2)
+              for (int s2 = 0; s2 < S; ++s2) fh = fmaf(s_w[qq2 * S + s2], stg[(qq2 * S + s2) * HF_LD + hh], fh);
+            s_fhb[half * 32 + hh] = fh;
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("" ::: "memory");
+            float Gfh = 0.f;
+#pragma unroll 8
+            for (int h2 = 0; h2 < 32; ++h2) Gfh = fmaf(Gb[hh * 33 + h2], s_fhb[half * 32 + h2], Gfh);
+            const float wbh = Gb[32 * 33 + hh], bb = Gb[32 * 33 + 32];
+            const float uh = on2 ? a.rayin[rr2 * RAYIN + hh] : 0.f;
+            const float beta = on2 ? a.rayin[rr2 * RAYIN + 32] : 0.f;
+            const float ngv = on2 ? a.rayin[rr2 * RAYIN + 33] : 1.f;
+            const float O2 = on2 ? s_gof[16 + qq2] : 0.f;
+            const float fu = wave_sum32(fh * uh), fGf = wave_sum32(fh * Gfh), fwb = wave_sum32(fh * wbh);
+            const float dotFg = fu + O2 * beta;
+            const float nF2 = fmaxf(fGf + 2.0f * O2 * fwb + O2 * O2 * bb, 0.0f);
+            const float nF = fmaxf(sqrtf(nF2), 1e-8f), ngc = fmaxf(ngv, 1e-8f);
+            const float cosv = dotFg / (nF * ngc);
+            const int lab2 = on2 ? (int)a.labels[rr2] : 2;
+            const float mm1 = (lab2 == 1) ? 1.0f : 0.0f;
+            const float gam = -a.feat_scaling * mm1 * inv1;         // d total / d cos
+            const float ar = gam / (nF * ngc), cr = -gam * cosv / (nF * nF);
+            if (on2) {
+              if (hh == 0) {
+                l_f += mm1 * (1.0f - cosv) * inv1;
+                s_gof[qq2] = ar * beta + cr * (fwb + O2 * bb);       // d total / d opacity (feature part)
+                a.rayfeat[rr2 * RAYFEAT + 32] = ar;
+                a.rayfeat[rr2 * RAYFEAT + 33] = cr;
+                a.rayfeat[rr2 * RAYFEAT + 34] = O2;
+              }
+              s_gfh[qq2 * 32 + hh] = ar * uh + cr * (Gfh + O2 * wbh);   // d total / d fh
+              a.rayfeat[rr2 * RAYFEAT + hh] = fh;
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("" ::: "memory");
+          }
+          if (on) {
+            float dwf = s_gof[qq];
+#pragma unroll 8
+            for (int h2 = 0; h2 < 32; ++h2) dwf = fmaf(s_gfh[qq * 32 + h2], stg[sl * HF_LD + h2], dwf);
+            dw += dwf;
+          }
+        }
         const float qv = dw * wgt;
         const float suf = seg_rscan_add(qv, pos, S) - qv;            // sum_{j>i} dL/dw_j * w_j
         const float docc = dw * T - suf / fr;
@@ -247,7 +337,19 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
 #pragma unroll
     for (int j = 0; j < OBJ_NDIR; ++j) dps[j] = 0.f;
 
-    // ---- phase A: heads, colour layer, mid2
+    // ---- phase A: heads, colour layer, (feature layer,) mid2
+    T32 d_hf = zero32();
+    if (FEAT) {
+      const float wv = valid ? stg[OFF_SW + slot] : 0.0f;
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float gv = valid ? stg[OFF_GFH + q * 32 + 16 * tt + 4 * g + r] : 0.0f;
+          d_hf.t[tt][r] = act.hf.t[tt][r] > 0.0f ? wv * gv : 0.0f;
+        }
+      // (rows 80..95, where s_w / gfh live, are not touched by the phase-A staging below)
+    }
     T32 d_hc, d_h4;
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
@@ -269,6 +371,7 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
     store_T32(stg_lane, 96, act.h3);
     store_T32(stg_lane, 128, d_hc);
     mma_bwd32<ST_CL>(d_h4, wt_cl, 0, d_hc);
+    if (FEAT) mma_bwd32<ST_CL>(d_h4, wt_fl, 0, d_hf);
     d_h4 = relu_mask32(d_h4, act.h4);
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
@@ -280,6 +383,7 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
     for (int T = 0; T < 3; ++T) {
       f32x4 d_x = zero4();
       mma_bwd16<ST_CL>(d_x, wt_cl, 32 + 16 * T, d_hc);
+      if (FEAT) mma_bwd16<ST_CL>(d_x, wt_fl, 32 + 16 * T, d_hf);
       store_T16(stg_lane, 32 + 16 * T, pe_x2_tile_fb(pe, T, g, d_x, dps));
     }
     T32 d_h3 = zero32();
@@ -292,6 +396,12 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
       wgrad_pair(accA0, accA1, lane_rd + dTr * STG_LD, lane_rd + aTr * STG_LD);
     }
     __syncthreads();
+    if (FEAT) {             // feature layer weight gradient: same inputs [h4 | x2], d_hf in place of d_hc
+      store_T32(stg_lane, 128, d_hf);
+      __syncthreads();
+      if (w < 5) wgrad_pair(accF0, accF1, lane_rd + 128 * STG_LD, lane_rd + (16 * w) * STG_LD);
+      __syncthreads();
+    }
     // ---- phase B: cat layer.  [h2 | x1] rows 0..127, d_h3pre rows 128..
     store_T32(stg_lane, 0, act.h2);
     store_T32(stg_lane, 128, d_h3);
@@ -373,6 +483,7 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
   write_pair(slab, accB0, accB1, c, g, w, L.cat_w, H + OBJ_E1, L.cat_b);
   if (w < 6) write_pair(slab, accC0, accC1, c, g, w, L.in_w, OBJ_E1, L.in_b);
   else write_pair(slab, accC0, accC1, c, g, w - 6, L.m1_w, H, -1);
+  if (FEAT && w < 5) write_pair(slab, accF0, accF1, c, g, w, L.fl_w, H + OBJ_E2, L.fl_b);
   {
     // d B: the 8 threads of pair p sit in one wave
     float v = g_dB;
@@ -393,7 +504,8 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
     const float s0 = wave_sum64(g_ba), s1 = wave_sum64(g_boc0), s2 = wave_sum64(g_boc1), s3 = wave_sum64(g_boc2);
     if (lane == 0) { mine[192] = s0; mine[193] = s1; mine[194] = s2; mine[195] = s3; }
     const float e0 = wave_sum64(l_d), e1 = wave_sum64(l_c), e2 = wave_sum64(l_o);
-    if (lane == 0) { mine[196] = e0; mine[197] = e1; mine[198] = e2; mine[199] = 0.0f; }
+    const float e3 = wave_sum64(l_f);
+    if (lane == 0) { mine[196] = e0; mine[197] = e1; mine[198] = e2; mine[199] = e3; }
   }
   __syncthreads();
   for (int i = tid; i < NRED; i += NTHR) {
@@ -476,6 +588,140 @@ __global__ __launch_bounds__(256) void eval_kernel(const EvalDev a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Feature head hoisting, per-step helper kernels (HBM-bound on gt_feat, read twice per step).
+// gram:  G = W_of^T W_of, wb = W_of^T b_of, bb = b_of . b_of                       per object
+__global__ __launch_bounds__(1024) void feat_gram_kernel(const float* params, long p_stride, int off_w, int off_b, int C,
+                                                         float* gram) {
+  const int k = blockIdx.x;
+  const float* W = params + (long)k * p_stride + off_w;
+  const float* B = params + (long)k * p_stride + off_b;
+  const int h = threadIdx.x >> 5, h2 = threadIdx.x & 31;
+  float acc = 0.f, accb = 0.f, accbb = 0.f;
+  for (int cc = 0; cc < C; ++cc) {
+    const float wv = W[cc * 32 + h], bv = B[cc];
+    acc = fmaf(wv, W[cc * 32 + h2], acc);
+    if (h2 == 0) accb = fmaf(wv, bv, accb);
+    if (threadIdx.x == 0) accbb = fmaf(bv, bv, accbb);
+  }
+  gram[(long)k * GRAM + h * 32 + h2] = acc;
+  if (h2 == 0) gram[(long)k * GRAM + 1024 + h] = accb;
+  if (threadIdx.x == 0) gram[(long)k * GRAM + 1056] = accbb;
+}
+// pre: u[r] = W_of^T g[r], beta[r] = b_of . g[r], |g[r]|       thread = (ray of 8, h)
+__global__ __launch_bounds__(256) void feat_pre_kernel(const float* params, long p_stride, int off_w, int off_b, int C,
+                                                       int R, const float* gt_feat, float* rayin) {
+  const int k = blockIdx.y;
+  const int rl = threadIdx.x >> 5, h = threadIdx.x & 31;
+  const float* W = params + (long)k * p_stride + off_w;
+  const float* B = params + (long)k * p_stride + off_b;
+  for (int r0 = blockIdx.x * 8; r0 < R; r0 += gridDim.x * 8) {
+    const int r = r0 + rl;
+    if (r >= R) continue;
+    const float* gp = gt_feat + ((long)k * R + r) * C;
+    float u = 0.f;
+#pragma unroll 8
+    for (int cc = 0; cc < C; ++cc) u = fmaf(W[cc * 32 + h], gp[cc], u);
+    float bs = 0.f, gs = 0.f;
+    for (int cc = h; cc < C; cc += 32) {
+      const float gv = gp[cc];
+      bs = fmaf(B[cc], gv, bs);
+      gs = fmaf(gv, gv, gs);
+    }
+    bs = wave_sum32(bs);
+    gs = wave_sum32(gs);
+    float* o = rayin + ((long)k * R + r) * RAYIN;
+    o[h] = u;
+    if (h == 0) { o[32] = bs; o[33] = sqrtf(gs); }
+  }
+}
+// post, stage 1: partial[k][ch][c][h] = sum_{r in chunk} g[r][c] * a_r fh_r[h],  partial_b[c] = sum g[r][c] a_r O_r
+constexpr int POST_CHUNKS = 8;
+__global__ __launch_bounds__(256) void feat_post_kernel(int C, int R, const float* gt_feat, const float* rayfeat,
+                                                        float* partial) {
+  __shared__ float P[32][36];
+  const int k = blockIdx.y, ch = blockIdx.x;
+  const int per = (R + POST_CHUNKS - 1) / POST_CHUNKS;
+  const int rb = ch * per, re = min(R, rb + per);
+  float acc[2][32], accb[2] = {0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int h = 0; h < 32; ++h) acc[j][h] = 0.f;
+  for (int r0 = rb; r0 < re; r0 += 32) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 32 * 36; i += 256) {
+      const int rr = r0 + i / 36;
+      P[i / 36][i % 36] = rr < re ? rayfeat[((long)k * R + rr) * RAYFEAT + (i % 36)] : 0.f;
+    }
+    __syncthreads();
+    const int n = min(32, re - r0);
+    for (int j = 0; j < n; ++j) {
+      const float* gp = gt_feat + ((long)k * R + r0 + j) * C;
+      const float ar = P[j][32], ao = ar * P[j][34];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int cc = threadIdx.x + 256 * q;
+        if (cc < C) {
+          const float gv = gp[cc] * ar;
+#pragma unroll
+          for (int h = 0; h < 32; ++h) acc[q][h] = fmaf(gv, P[j][h], acc[q][h]);
+          accb[q] = fmaf(gp[cc], ao, accb[q]);
+        }
+      }
+    }
+  }
+  float* out = partial + ((long)k * POST_CHUNKS + ch) * ((long)C * 33);
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int cc = threadIdx.x + 256 * q;
+    if (cc < C) {
+#pragma unroll
+      for (int h = 0; h < 32; ++h) out[(long)cc * 32 + h] = acc[q][h];
+      out[(long)C * 32 + cc] = accb[q];
+    }
+  }
+}
+// post, stage 2: moments M2 = sum_r c_r fh fh^T, m1 = sum_r c_r O_r fh, s2 = sum_r c_r O_r^2, then
+//   dW_of = sum_ch partial + W_of M2 + b_of m1^T ;  db_of = sum_ch partial_b + W_of m1 + b_of s2
+__global__ __launch_bounds__(1024) void feat_finish_kernel(const float* params, long p_stride, int off_w, int off_b,
+                                                           int C, int R, const float* rayfeat, const float* partial,
+                                                           float* grads) {
+  __shared__ float M2[32][33], m1v[32], s2s;
+  const int k = blockIdx.x;
+  const int h = threadIdx.x >> 5, h2 = threadIdx.x & 31;
+  float acc = 0.f, accm = 0.f, accs = 0.f;
+  for (int r = 0; r < R; ++r) {
+    const float* rf = rayfeat + ((long)k * R + r) * RAYFEAT;
+    const float cr = rf[33], fa = rf[h], fb = rf[h2], Or = rf[34];
+    acc = fmaf(cr * fa, fb, acc);
+    if (h2 == 0) accm = fmaf(cr * Or, fa, accm);
+    if (threadIdx.x == 0) accs = fmaf(cr * Or, Or, accs);
+  }
+  M2[h][h2] = acc;
+  if (h2 == 0) m1v[h] = accm;
+  if (threadIdx.x == 0) s2s = accs;
+  __syncthreads();
+  const float* W = params + (long)k * p_stride + off_w;
+  const float* B = params + (long)k * p_stride + off_b;
+  float* gW = grads + (long)k * p_stride + off_w;
+  float* gB = grads + (long)k * p_stride + off_b;
+  for (int i = threadIdx.x; i < C * 32; i += 1024) {
+    const int cc = i >> 5, hh = i & 31;
+    float v = 0.f;
+    for (int chn = 0; chn < POST_CHUNKS; ++chn) v += partial[((long)k * POST_CHUNKS + chn) * ((long)C * 33) + i];
+    for (int j = 0; j < 32; ++j) v = fmaf(W[cc * 32 + j], M2[j][hh], v);
+    gW[i] = fmaf(B[cc], m1v[hh], v);
+  }
+  for (int cc = threadIdx.x; cc < C; cc += 1024) {
+    float v = 0.f;
+    for (int chn = 0; chn < POST_CHUNKS; ++chn)
+      v += partial[((long)k * POST_CHUNKS + chn) * ((long)C * 33) + (long)C * 32 + cc];
+    for (int j = 0; j < 32; ++j) v = fmaf(W[cc * 32 + j], m1v[j], v);
+    gB[cc] = fmaf(B[cc], s2s, v);
+  }
+}
+
 int g_num_cu = 0;
 int num_cu() {
   if (g_num_cu == 0) {
@@ -548,8 +794,11 @@ size_t objnerf_train_workspace_bytes(const objnerf_net* net, int32_t K, int32_t 
   int64_t offs[OBJNERF_N_TENSORS + 1];
   const int64_t ps = objnerf_param_layout(net, offs);
   const int Gmax = num_cu();   // upper bound on the workgroups per object
-  (void)with_feat;
-  return align256((size_t)K * Gmax * ps * 4) + align256((size_t)K * Gmax * 4 * 4) + align256((size_t)ps) + 256;
+  size_t n = align256((size_t)K * Gmax * ps * 4) + align256((size_t)K * Gmax * 4 * 4) + align256((size_t)ps) + 256;
+  if (with_feat)
+    n += align256((size_t)K * R * RAYIN * 4) + align256((size_t)K * GRAM * 4) + align256((size_t)K * R * RAYFEAT * 4) +
+         align256((size_t)K * POST_CHUNKS * (size_t)net->feat_dim * 33 * 4);
+  return n;
 }
 
 int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void* stream) {
@@ -561,7 +810,8 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
   if (a->K <= 0 || a->R <= 0 || a->S <= 0) return OBJNERF_EINVAL;
   if (net->hidden != 32 || net->n_freqs != 6) return OBJNERF_ENOTSUP;
   if (a->S > 64) return OBJNERF_ENOTSUP;
-  if (a->gt_feat) return OBJNERF_ENOTSUP;   // feature-distillation branch not built yet
+  const bool feat = a->gt_feat != nullptr;
+  if (feat && (TS / a->S) > 16) return OBJNERF_ENOTSUP;
   if (a->workspace_bytes < objnerf_train_workspace_bytes(net, a->K, a->R, a->S, a->gt_feat != nullptr))
     return OBJNERF_EINVAL;
   int64_t offs[OBJNERF_N_TENSORS + 1];
@@ -588,21 +838,51 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
   d.loss_part = (float*)ws;
   ws += align256((size_t)a->K * Gmax * 4 * 4);
   uint8_t* has_grad = (uint8_t*)ws;
+  ws += align256((size_t)ps) + 256;
+  float* rayin = nullptr; float* gram = nullptr; float* rayfeat = nullptr; float* partial = nullptr;
+  const int C = net->feat_dim;
+  if (feat) {
+    rayin = (float*)ws;   ws += align256((size_t)a->K * a->R * RAYIN * 4);
+    gram = (float*)ws;    ws += align256((size_t)a->K * GRAM * 4);
+    rayfeat = (float*)ws; ws += align256((size_t)a->K * a->R * RAYFEAT * 4);
+    partial = (float*)ws;
+  }
+  d.rayin = rayin; d.gram = gram; d.rayfeat = rayfeat;
 
   hipStream_t st = (hipStream_t)stream;
-  // has_grad mask: everything except the feature branch (train.py:435-438 -> .grad stays None)
+  // slab-reduced entries: everything except what this launch does not differentiate.  Without gt_feat the
+  // whole feature branch has no gradient (train.py:435-438 -> .grad stays None); with it, the 512-d head's
+  // gradient is produced by feat_finish_kernel instead of the slabs.
   (void)hipMemsetAsync(has_grad, 1, (size_t)ps, st);
-  (void)hipMemsetAsync(has_grad + d.L.fl_w, 0, (size_t)(d.L.pe_b - d.L.fl_w), st);
+  if (feat) (void)hipMemsetAsync(has_grad + d.L.of_w, 0, (size_t)(d.L.pe_b - d.L.of_w), st);
+  else (void)hipMemsetAsync(has_grad + d.L.fl_w, 0, (size_t)(d.L.pe_b - d.L.fl_w), st);
   (void)hipMemsetAsync(a->status, 0, sizeof(int), st);
 
-  const size_t lds_bytes = (size_t)(W_FLOATS_NOFEAT + SM_FLOATS + STG_ROWS * STG_LD) * 4;
+  const size_t lds_bytes = (size_t)((feat ? W_FLOATS_FEAT : W_FLOATS_NOFEAT) + SM_FLOATS + STG_ROWS * STG_LD) * 4;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)train_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds_bytes);
+                              (int)((W_FLOATS_NOFEAT + SM_FLOATS + STG_ROWS * STG_LD) * 4));
+    (void)hipFuncSetAttribute((const void*)train_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)((W_FLOATS_FEAT + SM_FLOATS + STG_ROWS * STG_LD) * 4));
     attr_set = true;
   }
-  hipLaunchKernelGGL(train_fused_kernel<false>, dim3(a->K * d.G), dim3(NTHR), lds_bytes, st, d);
+  if (feat) {
+    hipLaunchKernelGGL(feat_gram_kernel, dim3(a->K), dim3(1024), 0, st, a->params, (long)a->p_stride, d.L.of_w,
+                       d.L.of_b, C, gram);
+    int gx = (a->R + 7) / 8;
+    if (gx > 256) gx = 256;
+    hipLaunchKernelGGL(feat_pre_kernel, dim3(gx, a->K), dim3(256), 0, st, a->params, (long)a->p_stride, d.L.of_w,
+                       d.L.of_b, C, a->R, a->gt_feat, rayin);
+    hipLaunchKernelGGL(train_fused_kernel<true>, dim3(a->K * d.G), dim3(NTHR), lds_bytes, st, d);
+    if (hipGetLastError() != hipSuccess) return OBJNERF_ELAUNCH;
+    hipLaunchKernelGGL(feat_post_kernel, dim3(POST_CHUNKS, a->K), dim3(256), 0, st, C, a->R, a->gt_feat, rayfeat,
+                       partial);
+    hipLaunchKernelGGL(feat_finish_kernel, dim3(a->K), dim3(1024), 0, st, a->params, (long)a->p_stride, d.L.of_w,
+                       d.L.of_b, C, a->R, rayfeat, partial, a->grads);
+  } else {
+    hipLaunchKernelGGL(train_fused_kernel<false>, dim3(a->K * d.G), dim3(NTHR), lds_bytes, st, d);
+  }
   if (hipGetLastError() != hipSuccess) return OBJNERF_ELAUNCH;
   const long P = offs[OBJNERF_N_TENSORS];
   dim3 fg((unsigned)((P + 255) / 256), (unsigned)a->K);

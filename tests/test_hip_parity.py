@@ -121,20 +121,22 @@ def _hip_step(arena, ws, b, dev, with_feat=False):
     torch.cuda.synchronize()
 
 
-def test_train_step_g5_grads(golden, dev):
-    """One fused iteration == reference loss and gradients of every stacked tensor (train.py:424-472)."""
-    g = golden("g5_step_s10_nofeat")
+@pytest.mark.parametrize("tag", ["s10_nofeat", "s10_feat", "s64_feat"])
+def test_train_step_g5_grads(golden, dev, tag):
+    """One fused iteration == reference loss and gradients of every stacked tensor (train.py:424-472),
+    without and with the 512-d feature-distillation loss (cfg.part_mode)."""
+    g = golden(f"g5_step_{tag}")
     K, R, n1, n2, feat_on = [int(x) for x in g["meta"]]
     arena = arena_from_fixture(g, dev)
-    ws = ops.TrainWorkspace(arena, K, R, n1 + n2, False)
+    ws = ops.TrainWorkspace(arena, K, R, n1 + n2, bool(feat_on))
     b = synthetic.random_batch(K, R, n1, n2, seed=500, feat_dim=512)
-    _hip_step(arena, ws, b, dev)
+    _hip_step(arena, ws, b, dev, with_feat=bool(feat_on))
     terms = ws.loss_terms.cpu()
-    total = (terms[:, 0] + 5 * terms[:, 1] + 10 * terms[:, 2]).sum().item()
+    total = (terms[:, 0] + 5 * terms[:, 1] + 10 * terms[:, 2] + 5 * terms[:, 3]).sum().item()
     assert abs(total - g["loss"][0]) < 1e-4 * abs(g["loss"][0])
     gv = arena.views(ws.grads)
     for i in range(19):
-        if i in ops.FEAT_TENSORS:
+        if i in ops.FEAT_TENSORS and not feat_on:
             continue
         ref = g[f"grad0_{i}"]
         scale = max(1e-3, float(np.abs(ref).max()))
@@ -191,10 +193,11 @@ def test_train_three_steps_g6(golden, dev):
         assert float(mv[i].abs().max()) == 0.0          # no grad -> no update, no decay
 
 
+@pytest.mark.parametrize("feat_on", [False, True])
 @pytest.mark.parametrize("shape", [(2, 40, 16, 48), (3, 70, 5, 9), (1, 256, 8, 24), (5, 33, 1, 9)])
-def test_train_step_vs_oracle(golden, dev, shape):
+def test_train_step_vs_oracle(golden, dev, shape, feat_on):
     """Metric-shaped (S=64), background-shaped (S=14), c1 (S=32) and native (S=10) batches with ragged
-    ray counts, against oracle autograd."""
+    ray counts, against oracle autograd; with and without the feature-distillation branch."""
     K, R, n1, n2 = shape
     g = golden("g9_psnr_nofeat")
     fc = [T(g[f"fc0_{i}"])[:1].repeat(K, *([1] * (T(g[f"fc0_{i}"]).dim() - 1))).clone() for i in range(18)]
@@ -203,18 +206,21 @@ def test_train_step_vs_oracle(golden, dev, shape):
     B = O.icosa_dirs()[None].repeat(K, 1, 1) + 0.01 * torch.randn(K, 21, 3, generator=gen)
     arena = ops.ParamArena(K, ops.NetShape(), dev)
     arena.load_stacked(fc + [B])
-    ws = ops.TrainWorkspace(arena, K, R, n1 + n2, False)
-    b = synthetic.random_batch(K, R, n1, n2, seed=77 + R)
-    _hip_step(arena, ws, b, dev)
+    ws = ops.TrainWorkspace(arena, K, R, n1 + n2, feat_on)
+    b = synthetic.random_batch(K, R, n1, n2, seed=77 + R, feat_dim=512)
+    _hip_step(arena, ws, b, dev, with_feat=feat_on)
     fcr = [p.clone().requires_grad_(True) for p in fc]
     Br = B.clone().requires_grad_(True)
     loss, terms = O.train_forward_loss(fcr, Br, torch.full((K,), 2.0), T(b["pts"]), T(b["gt_depth"]), T(b["gt_rgb"]),
-                                       T(b["labels"]), T(b["z"]), return_terms=True)
+                                       T(b["labels"]), T(b["z"]), gt_feat=T(b["gt_feat"]) if feat_on else None,
+                                       return_terms=True)
     grads = torch.autograd.grad(loss, fcr + [Br], allow_unused=True)
     t = ws.loss_terms.cpu()
     assert maxerr(t[:, 0], terms["depth"]) < 1e-4 * max(1.0, float(terms["depth"].abs().max()))
     assert maxerr(t[:, 1], terms["color"]) < 1e-4
     assert maxerr(t[:, 2], terms["opacity"]) < 1e-4
+    if feat_on:
+        assert maxerr(t[:, 3], terms["feat"]) < 1e-4
     gv = arena.views(ws.grads)
     for i in range(19):
         if grads[i] is None:
