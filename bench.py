@@ -39,7 +39,7 @@ def flop_per_ray(S: int, H: int = 32, feat: bool = False) -> float:
     return 3.0 * 2.0 * (S * ms + (512 * H if feat else 0))
 
 
-def cpu_baseline(K, R, n1, n2, seed, steps=2):
+def cpu_baseline(K, R, n1, n2, seed, steps=2, feat=False):
     """Oracle = the reference's op sequence (vmap(pe) -> vmap(fc) -> step_batch_loss -> backward -> AdamW),
     fp32, on the host cores.  Bounded sample: same K, S, H; fewer rays per object."""
     from oracle import objnerf_oracle as O
@@ -49,13 +49,14 @@ def cpu_baseline(K, R, n1, n2, seed, steps=2):
     params = fc + [B]
     m = [torch.zeros_like(p) for p in params]
     v = [torch.zeros_like(p) for p in params]
-    b = synthetic.random_batch(K, R, n1, n2, seed=seed)
-    tb = {k: torch.from_numpy(b[k]) for k in ["pts", "gt_depth", "gt_rgb", "labels", "z"]}
+    b = synthetic.random_batch(K, R, n1, n2, seed=seed, feat_dim=512 if feat else 0)
+    tb = {k: torch.from_numpy(b[k]) for k in ["pts", "gt_depth", "gt_rgb", "labels", "z"] + (["gt_feat"] if feat else [])}
     scale = torch.full((K,), 2.0)
     times = []
     for it in range(steps + 1):
         t0 = time.perf_counter()
-        loss, _ = O.train_forward_loss(fc, B, scale, tb["pts"], tb["gt_depth"], tb["gt_rgb"], tb["labels"], tb["z"])
+        loss, _ = O.train_forward_loss(fc, B, scale, tb["pts"], tb["gt_depth"], tb["gt_rgb"], tb["labels"], tb["z"],
+                                       gt_feat=tb["gt_feat"] if feat else None)
         grads = torch.autograd.grad(loss, params, allow_unused=True)
         with torch.no_grad():
             for p, g, mm, vv in zip(params, grads, m, v):
@@ -77,6 +78,8 @@ def main():
     ap.add_argument("--rays", type=int, default=4096, help="rays per object per step")
     ap.add_argument("--n-cam2surf", type=int, default=16)
     ap.add_argument("--n-bins", type=int, default=48)
+    ap.add_argument("--feat", action="store_true",
+                    help="BASELINE configs[2]: add the 512-d feature-distillation loss (cfg.part_mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=192)
     args = ap.parse_args()
@@ -97,14 +100,15 @@ def main():
     S = n1 + n2
     arena = ops.ParamArena(K, ops.NetShape(), dev)
     arena.load_stacked(obj_init.init_stacked(K, 32, 512, seed=1000 + rank))
-    ws = ops.TrainWorkspace(arena, K, R, S, False)
+    feat = bool(args.feat)
+    ws = ops.TrainWorkspace(arena, K, R, S, feat)
     m = torch.zeros_like(arena.params)
     v = torch.zeros_like(arena.params)
-    mask = arena.has_grad_mask(False)
-    keys = ["pts", "z", "gt_depth", "gt_rgb", "labels"]
+    mask = arena.has_grad_mask(feat)
+    keys = ["pts", "z", "gt_depth", "gt_rgb", "labels"] + (["gt_feat"] if feat else [])
     batches = []
     for i in range(2):      # two resident batches, alternated, so no step re-reads its own outputs
-        b = synthetic.random_batch(K, R, n1, n2, seed=4242 + 17 * rank + i)
+        b = synthetic.random_batch(K, R, n1, n2, seed=4242 + 17 * rank + i, feat_dim=512 if feat else 0)
         batches.append({k: torch.from_numpy(b[k]).to(dev) for k in keys})
     gflags = torch.zeros(2, dtype=torch.int32, device=dev)
 
@@ -120,9 +124,9 @@ def main():
                                                       gflags.data_ptr(), torch.cuda.current_stream().cuda_stream),
                        "label_counts")
             dist.all_reduce(gflags, op=dist.ReduceOp.MAX)
-            ops.train_step(arena, ws, b, global_flags=gflags)
+            ops.train_step(arena, ws, b, global_flags=gflags, with_feat=feat)
         else:
-            ops.train_step(arena, ws, b)
+            ops.train_step(arena, ws, b, with_feat=feat)
         step_no[0] += 1
         ops.adamw_step(arena, ws.grads, m, v, mask, step_no[0], 1e-3, 0.013)
 
@@ -152,7 +156,7 @@ def main():
     nk = max(5, min(args.steps, 20))
     ev0.record()
     for i in range(nk):
-        ops.train_step(arena, ws, batches[i & 1])
+        ops.train_step(arena, ws, batches[i & 1], with_feat=feat)
     ev1.record()
     torch.cuda.synchronize()
     kern_ms = ev0.elapsed_time(ev1) / nk
@@ -161,7 +165,7 @@ def main():
     if rank == 0:
         rays_per_step = K * R * world
         value = rays_per_step * args.steps / dt
-        fpr = flop_per_ray(S)
+        fpr = flop_per_ray(S, feat=feat)
         achieved = K * R * fpr / (kern_ms * 1e-3) / 1e12
         out = {
             "metric": "training rays/sec/GPU @64 samples/ray, 50 obj; PSNR delta vs ref",
@@ -169,18 +173,19 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"Replica room_0-shaped, {K} object MLPs/GPU (hidden 32), {R} rays/object/step, "
-                                   f"{S} samples/ray ({n1}+{n2}), RGB+depth+opacity loss, fused fwd+loss+bwd+AdamW",
+                                   f"{S} samples/ray ({n1}+{n2}), RGB+depth+opacity"
+                                   f"{'+512-d feature' if feat else ''} loss, fused fwd+loss+bwd+AdamW",
                        "objects_per_gpu": K, "rays_per_object": R, "samples_per_ray": S, "hidden": 32,
-                       "feature_head": False, "parallelism": f"objects sharded x{world}",
+                       "feature_head": feat, "parallelism": f"objects sharded x{world}",
                        "loss_status": status},
             "rays_per_sec_per_gpu": value / world,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                         "kernel": "train_fused_kernel<false>", "kernel_ms": kern_ms,
+                         "kernel": f"train_fused_kernel<{'true' if feat else 'false'}>", "kernel_ms": kern_ms,
                          "flop_per_ray": fpr},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(K, args.cpu_rays, n1, n2, seed=4242)
+            out["cpu_baseline"] = cpu_baseline(K, args.cpu_rays, n1, n2, seed=4242, feat=feat)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -48,11 +48,11 @@ constexpr int RAYIN = 34, GRAM = 1088, RAYFEAT = 36;
 // LDS aliases inside the staging area, valid from the forward pass until phase B of the backward pass
 constexpr int HF_LD = 33;                       // hfbuf [128][33] at stg + 0
 constexpr int OFF_GBUF = TS * HF_LD;            // G [32][33], wb [32], bb          (4224 ..)
-constexpr int OFF_FHB = OFF_GBUF + 32 * 33 + 64;   // fh exchange buffer [2][32]
+constexpr int OFF_FHB = OFF_GBUF + 32 * 33 + 64;   // fh exchange buffer [NWAVE][2][32] (one per wave)
 constexpr int OFF_SW = 80 * STG_LD;             // rows 80..95 are untouched by the phase-A staging
 constexpr int OFF_GFH = OFF_SW + TS;            // gfh [16][32]
 constexpr int OFF_GOF = OFF_GFH + 16 * 32;      // gO_feat [16], O [16]
-static_assert(OFF_FHB + 64 <= 80 * STG_LD && OFF_GOF + 32 <= 96 * STG_LD, "feat lds aliases");
+static_assert(OFF_FHB + 64 * NWAVE <= 80 * STG_LD && OFF_GOF + 32 <= 96 * STG_LD, "feat lds aliases");
 
 struct EvalDev {
   int K, G; long N;
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
           float* s_w = stg + OFF_SW;
           float* s_gfh = stg + OFF_GFH;
           float* s_gof = stg + OFF_GOF;
-          float* s_fhb = stg + OFF_FHB;
+          float* s_fhb = stg + OFF_FHB + 64 * w;
           const float* Gb = stg + OFF_GBUF;
           if (on) s_w[sl] = wgt;
           if (on && pos == 0) s_gof[16 + qq] = O;
