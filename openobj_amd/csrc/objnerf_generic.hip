@@ -1,0 +1,371 @@
+// Layer-wise training iteration for ANY hidden width (multiple of 32): the shared background network
+// (hidden 128, train.py:447-463) and the hidden-256 stress configuration.  The hidden-32 object networks
+// use the fused kernel in objnerf_train.hip; wider networks do not fit one CU's LDS / registers, so this
+// path materialises activations in the caller's workspace and runs the contraction as batched fp32 MFMA
+// GEMMs (v_mfma_f32_16x16x4_f32, 64x64x16 tiles), with the reference's op order:
+//   embedding.py:46-55 -> model.py:61-103 -> loss.py:5-103 (objnerf_step_batch_loss) -> reverse.
+#include "objnerf_device.h"
+#include "../../include/objnerf_hip.h"
+
+namespace objgen {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------
+// C[m][n] (+)= sum_k A(m,k) B(k,n), generic strides, batched over blockIdx.z.  Epilogue (in order):
+// + bias[n], * scale, relu, mask (C = mask(m,n) > 0 ? C : 0).
+struct Gemm {
+  int M, N, Kd;
+  const float* A; long sam, sak, bsa;
+  const float* B; long sbk, sbn, bsb;
+  float* C; long scm, scn, bsc;
+  const float* bias; long bsbias;
+  const float* mask; long smm, smn, bsm;
+  int accumulate, relu;
+};
+
+constexpr int BM = 64, BN = 64, BK = 16;
+
+__global__ __launch_bounds__(256) void gemm_kernel(const Gemm g) {
+  __shared__ float As[BK][BM + 4];
+  __shared__ float Bs[BK][BN + 4];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int c = lane & 15, gg = lane >> 4;
+  const int wm = w >> 1, wn = w & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const long z = blockIdx.z;
+  const float* A = g.A + z * g.bsa;
+  const float* B = g.B + z * g.bsb;
+  float* C = g.C + z * g.bsc;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < g.Kd; k0 += BK) {
+    // global -> LDS: 64 x 16 elements each, 4 per thread
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + 256 * i;
+      // A tile: choose the faster-varying index by stride so loads coalesce for both layouts
+      int am, ak;
+      if (g.sak == 1) { ak = e & 15; am = e >> 4; } else { am = e & 63; ak = e >> 6; }
+      const int gm = m0 + am, gk = k0 + ak;
+      As[ak][am] = (gm < g.M && gk < g.Kd) ? A[gm * g.sam + gk * g.sak] : 0.f;
+      int bn, bk;
+      if (g.sbk == 1) { bk = e & 15; bn = e >> 4; } else { bn = e & 63; bk = e >> 6; }
+      const int gn = n0 + bn, gk2 = k0 + bk;
+      Bs[bk][bn] = (gn < g.N && gk2 < g.Kd) ? B[gk2 * g.sbk + gn * g.sbn] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < BK / 4; ++ks) {
+      float a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = As[4 * ks + gg][32 * wm + 16 * i + c];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = Bs[4 * ks + gg][32 * wn + 16 * j + c];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // epilogue: D layout: col n = lane & 15, row m = 4 * (lane >> 4) + r
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + 32 * wm + 16 * i + 4 * gg + r, n = n0 + 32 * wn + 16 * j + c;
+        if (m < g.M && n < g.N) {
+          float* cp = C + m * g.scm + n * g.scn;
+          float v = acc[i][j][r];
+          if (g.accumulate) v += *cp;
+          if (g.bias) v += g.bias[z * g.bsbias + n];
+          if (g.relu) v = fmaxf(v, 0.f);
+          if (g.mask) v = g.mask[z * g.bsm + m * g.smm + n * g.smn] > 0.f ? v : 0.f;
+          *cp = v;
+        }
+      }
+}
+
+static void gemm(hipStream_t st, int batch, int M, int N, int Kd, const float* A, long sam, long sak, long bsa,
+                 const float* B, long sbk, long sbn, long bsb, float* C, long scm, long scn, long bsc,
+                 bool accumulate = false, const float* bias = nullptr, long bsbias = 0, bool relu = false,
+                 const float* mask = nullptr, long smm = 0, long smn = 0, long bsm = 0) {
+  Gemm g;
+  g.M = M; g.N = N; g.Kd = Kd;
+  g.A = A; g.sam = sam; g.sak = sak; g.bsa = bsa;
+  g.B = B; g.sbk = sbk; g.sbn = sbn; g.bsb = bsb;
+  g.C = C; g.scm = scm; g.scn = scn; g.bsc = bsc;
+  g.bias = bias; g.bsbias = bsbias; g.mask = mask; g.smm = smm; g.smn = smn; g.bsm = bsm;
+  g.accumulate = accumulate; g.relu = relu;
+  dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, batch);
+  hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), 0, st, g);
+}
+
+// column sums: out[z][n] = sum_m X[z][m][n]   (bias gradients)
+__global__ void colsum_kernel(int M, int N, const float* X, long ldx, long bsx, float* out, long bso) {
+  const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int part = threadIdx.x >> 6;      // 4 row partitions
+  const long z = blockIdx.y;
+  __shared__ float red[4][64];
+  float s = 0.f;
+  if (n < N)
+    for (int m = part; m < M; m += 4) s += X[z * bsx + (long)m * ldx + n];
+  red[part][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (part == 0 && n < N) out[z * bso + n] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// heads forward: alpha = 10 (h4 . wa + ba), color = sigmoid(hc Woc^T + boc)        (model.py:81-96)
+__global__ void heads_fwd_kernel(int Hh, long n, const float* h4, const float* hc, const float* params, long p_stride,
+                                 int off_wa, int off_ba, int off_woc, int off_boc, float* alpha, float* color) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long z = blockIdx.y;
+  if (i >= n) return;
+  const float* P = params + z * p_stride;
+  const float* a = h4 + (z * n + i) * Hh;
+  const float* cc = hc + (z * n + i) * Hh;
+  float sa = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  for (int h = 0; h < Hh; ++h) {
+    sa = fmaf(P[off_wa + h], a[h], sa);
+    s0 = fmaf(P[off_woc + h], cc[h], s0);
+    s1 = fmaf(P[off_woc + Hh + h], cc[h], s1);
+    s2 = fmaf(P[off_woc + 2 * Hh + h], cc[h], s2);
+  }
+  alpha[z * n + i] = (sa + P[off_ba]) * 10.0f;
+  color[(z * n + i) * 3] = sigmoid_acc(s0 + P[off_boc]);
+  color[(z * n + i) * 3 + 1] = sigmoid_acc(s1 + P[off_boc + 1]);
+  color[(z * n + i) * 3 + 2] = sigmoid_acc(s2 + P[off_boc + 2]);
+}
+
+// heads backward: dhead[n][4] = (10 d_alpha, d_color * color (1 - color)); d_hc = relu'(hc) Woc^T d_craw;
+// d_h4 = wa * d_araw  (the colour-layer contribution is accumulated by a GEMM afterwards)
+__global__ void heads_bwd_kernel(int Hh, long n, const float* hc, const float* color, const float* d_alpha,
+                                 const float* d_color, const float* params, long p_stride, int off_wa, int off_woc,
+                                 float* dhead, float* d_hc, float* d_h4) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long z = blockIdx.y;
+  if (i >= n) return;
+  const float* P = params + z * p_stride;
+  const long o = z * n + i;
+  const float da = 10.0f * d_alpha[o];
+  float dc[3];
+  for (int x = 0; x < 3; ++x) {
+    const float cv = color[o * 3 + x];
+    dc[x] = d_color[o * 3 + x] * cv * (1.0f - cv);
+  }
+  dhead[o * 4] = da; dhead[o * 4 + 1] = dc[0]; dhead[o * 4 + 2] = dc[1]; dhead[o * 4 + 3] = dc[2];
+  for (int h = 0; h < Hh; ++h) {
+    const float v = fmaf(P[off_woc + 2 * Hh + h], dc[2], fmaf(P[off_woc + Hh + h], dc[1], P[off_woc + h] * dc[0]));
+    d_hc[o * Hh + h] = hc[o * Hh + h] > 0.f ? v : 0.f;
+    d_h4[o * Hh + h] = P[off_wa + h] * da;
+  }
+}
+
+__global__ void relu_mask_kernel(long n, float* d, const float* act) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) d[i] = act[i] > 0.f ? d[i] : 0.f;
+}
+
+// PE backward: d B[j][x] = sum_n t[n][x] sum_f d_emb[n][3 + 21 f + j] cos(arg) pi 2^f     (embedding.py:48-52)
+__global__ __launch_bounds__(256) void pe_bwd_kernel(long n, int n_freqs, const float* params, long p_stride, int off_B,
+                                                     const float* scale, const float* pts, const float* d_emb,
+                                                     float* dB /* [K][63], pre-zeroed */) {
+  __shared__ float red[63];
+  const long z = blockIdx.y;
+  if (threadIdx.x < 63) red[threadIdx.x] = 0.f;
+  __syncthreads();
+  const float* B = params + z * p_stride + off_B;
+  const float sc = scale[z];
+  const int E = 3 + OBJ_NDIR * n_freqs;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float* p = pts + (z * n + i) * 3;
+    const float t0 = p[0] / sc, t1 = p[1] / sc, t2 = p[2] / sc;
+    const float* de = d_emb + (z * n + i) * E;
+    for (int j = 0; j < OBJ_NDIR; ++j) {
+      const float pj = fmaf(t2, B[3 * j + 2], fmaf(t1, B[3 * j + 1], t0 * B[3 * j]));
+      float dp = 0.f;
+      for (int f = 0; f < n_freqs; ++f) {
+        const float sf = (float)(1 << f);
+        float s, cv;
+        sincos_acc((pj * sf) * OBJ_PI_F, s, cv);
+        dp += de[3 + f * OBJ_NDIR + j] * ((cv * OBJ_PI_F) * sf);
+      }
+      atomicAdd(&red[3 * j], dp * t0);
+      atomicAdd(&red[3 * j + 1], dp * t1);
+      atomicAdd(&red[3 * j + 2], dp * t2);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 63) atomicAdd(&dB[z * 63 + threadIdx.x], red[threadIdx.x]);
+}
+
+__global__ void copy_cols_kernel(long rows, int cols, const float* src, long lds_, float* dst, long ldd) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < rows * cols) dst[(i / cols) * ldd + (i % cols)] = src[(i / cols) * lds_ + (i % cols)];
+}
+
+inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Offs {
+  int64_t o[OBJNERF_N_TENSORS + 1];
+  int64_t ps;
+};
+
+// workspace carve (floats)
+struct WS {
+  float *emb, *h1, *h2, *h3, *h4, *hc, *hf, *clip, *alpha, *color, *d_alpha, *d_color, *d_clip, *dhead;
+  float *dA, *dB_, *d_emb, *dBpe;
+  int* counts;
+  size_t bytes;
+};
+
+static WS carve(char* base, int H, int C, long n, int K, bool feat) {
+  WS w;
+  char* p = base;
+  auto take = [&](size_t floats) { float* r = (float*)p; p += al(floats * 4); return r; };
+  w.emb = take((size_t)K * n * OBJ_EMB);
+  w.h1 = take((size_t)K * n * H); w.h2 = take((size_t)K * n * H); w.h3 = take((size_t)K * n * H);
+  w.h4 = take((size_t)K * n * H); w.hc = take((size_t)K * n * H);
+  w.hf = feat ? take((size_t)K * n * H) : nullptr;
+  w.clip = feat ? take((size_t)K * n * C) : nullptr;
+  w.d_clip = feat ? take((size_t)K * n * C) : nullptr;
+  w.alpha = take((size_t)K * n); w.color = take((size_t)K * n * 3);
+  w.d_alpha = take((size_t)K * n); w.d_color = take((size_t)K * n * 3);
+  w.dhead = take((size_t)K * n * 4);
+  w.dA = take((size_t)K * n * H); w.dB_ = take((size_t)K * n * H);
+  w.d_emb = take((size_t)K * n * OBJ_EMB);
+  w.dBpe = take((size_t)K * 64);
+  w.counts = (int*)take((size_t)2 * K + 2);
+  w.bytes = (size_t)(p - base);
+  return w;
+}
+
+size_t train_workspace_bytes(const objnerf_net* net, int K, int R, int S, int feat) {
+  WS w = carve(nullptr, net->hidden, net->feat_dim, (long)R * S, K, feat != 0);
+  return w.bytes + 256;
+}
+
+int train_step(const objnerf_net* net, const objnerf_train_args* a, void* stream) {
+  const int H = net->hidden, C = net->feat_dim, K = a->K;
+  if (H % 32 != 0 || net->n_freqs != 6) return OBJNERF_ENOTSUP;
+  if (!a->pts) return OBJNERF_ENOTSUP;            // origins/dirs form: fused hidden-32 path only
+  const bool feat = a->gt_feat != nullptr;
+  const long n = (long)a->R * a->S;
+  int64_t off[OBJNERF_N_TENSORS + 1];
+  objnerf_param_layout(net, off);
+  const long ps = a->p_stride;
+  hipStream_t st = (hipStream_t)stream;
+  WS w = carve((char*)a->workspace, H, C, n, K, feat);
+  if (a->workspace_bytes < w.bytes) return OBJNERF_EINVAL;
+  const float* P = a->params;
+  float* G = a->grads;
+  const int E1 = OBJ_E1, E2 = OBJ_E2, EM = OBJ_EMB;
+  const long nH = n * H;
+
+  // ---- forward
+  int rc = objnerf_embed(net, K, n, P, ps, a->scale, a->pts, w.emb, stream);
+  if (rc) return rc;
+  // h1 = relu(x1 W_in^T + b)
+  gemm(st, K, n, H, E1, w.emb, EM, 1, n * EM, P + off[0], 1, E1, ps, w.h1, H, 1, nH, false, P + off[1], ps, true);
+  gemm(st, K, n, H, H, w.h1, H, 1, nH, P + off[2], 1, H, ps, w.h2, H, 1, nH, false, P + off[3], ps, true);
+  // h3 = relu([h2 | x1] W_cat^T + b)
+  gemm(st, K, n, H, H, w.h2, H, 1, nH, P + off[4], 1, H + E1, ps, w.h3, H, 1, nH);
+  gemm(st, K, n, H, E1, w.emb, EM, 1, n * EM, P + off[4] + H, 1, H + E1, ps, w.h3, H, 1, nH, true, P + off[5], ps, true);
+  gemm(st, K, n, H, H, w.h3, H, 1, nH, P + off[6], 1, H, ps, w.h4, H, 1, nH, false, P + off[7], ps, true);
+  // hc = relu([h4 | x2] W_cl^T + b)
+  gemm(st, K, n, H, H, w.h4, H, 1, nH, P + off[10], 1, H + E2, ps, w.hc, H, 1, nH);
+  gemm(st, K, n, H, E2, w.emb + E1, EM, 1, n * EM, P + off[10] + H, 1, H + E2, ps, w.hc, H, 1, nH, true, P + off[11], ps,
+       true);
+  dim3 eg((unsigned)((n + 255) / 256), (unsigned)K);
+  hipLaunchKernelGGL(heads_fwd_kernel, eg, dim3(256), 0, st, H, n, w.h4, w.hc, P, ps, (int)off[8], (int)off[9],
+                     (int)off[12], (int)off[13], w.alpha, w.color);
+  if (feat) {
+    gemm(st, K, n, H, H, w.h4, H, 1, nH, P + off[14], 1, H + E2, ps, w.hf, H, 1, nH);
+    gemm(st, K, n, H, E2, w.emb + E1, EM, 1, n * EM, P + off[14] + H, 1, H + E2, ps, w.hf, H, 1, nH, true, P + off[15],
+         ps, true);
+    gemm(st, K, n, C, H, w.hf, H, 1, nH, P + off[16], 1, H, ps, w.clip, C, 1, n * C, false, P + off[17], ps, false);
+  }
+  // ---- loss + d(alpha, color, clip)      (loss.py:5-103)
+  objnerf_loss_args la;
+  la.K = K; la.R = a->R; la.S = a->S; la.C = C;
+  la.color_scaling = a->color_scaling; la.opacity_scaling = a->opacity_scaling; la.feat_scaling = a->feat_scaling;
+  la.reserved = 0;
+  la.alpha = w.alpha; la.color = w.color; la.z = a->z; la.gt_depth = a->gt_depth; la.gt_rgb = a->gt_rgb;
+  la.labels = a->labels; la.pred_feat = feat ? w.clip : nullptr; la.gt_feat = a->gt_feat; la.flags_in = a->flags;
+  la.loss_terms = a->loss_terms; la.total = nullptr; la.d_alpha = w.d_alpha; la.d_color = w.d_color;
+  la.d_pred_feat = feat ? w.d_clip : nullptr; la.counts = w.counts; la.status = a->status;
+  rc = objnerf_step_batch_loss(&la, stream);
+  if (rc) return rc;
+  // ---- backward
+  float* d_hc = w.dA;      // [n][H]
+  float* d_h4 = w.dB_;
+  hipLaunchKernelGGL(heads_bwd_kernel, eg, dim3(256), 0, st, H, n, w.hc, w.color, w.d_alpha, w.d_color, P, ps,
+                     (int)off[8], (int)off[12], w.dhead, d_hc, d_h4);
+  // head weight grads: d wa = dhead[:,0]^T h4, d Woc = dhead[:,1:4]^T hc; biases = column sums of dhead
+  gemm(st, K, 1, H, n, w.dhead, 1, 4, n * 4, w.h4, H, 1, nH, G + off[8], H, 1, ps);
+  gemm(st, K, 3, H, n, w.dhead + 1, 1, 4, n * 4, w.hc, H, 1, nH, G + off[12], H, 1, ps);
+  hipLaunchKernelGGL(colsum_kernel, dim3(1, K), dim3(256), 0, st, (int)n, 1, w.dhead, 4L, n * 4, G + off[9], ps);
+  hipLaunchKernelGGL(colsum_kernel, dim3(1, K), dim3(256), 0, st, (int)n, 3, w.dhead + 1, 4L, n * 4, G + off[13], ps);
+  (void)hipMemsetAsync(w.d_emb, 0, (size_t)K * n * EM * 4, st);
+  if (feat) {
+    // d_hf = relu'(hf) (d_clip W_of); d W_of = d_clip^T hf; d b_of = colsum(d_clip)
+    float* d_hf = w.clip;   // reuse: clip [n][C] is dead after the loss; d_hf lives there with batch pitch n*C
+    gemm(st, K, n, H, C, w.d_clip, C, 1, n * C, P + off[16], H, 1, ps, d_hf, H, 1, n * C, false, nullptr, 0, false, w.hf,
+         H, 1, nH);
+    gemm(st, K, C, H, n, w.d_clip, 1, C, n * C, w.hf, H, 1, nH, G + off[16], H, 1, ps);
+    hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64, K), dim3(256), 0, st, (int)n, C, w.d_clip, (long)C, n * C,
+                       G + off[17], ps);
+    // feature layer: grads + contributions to d_h4 / d_x2
+    gemm(st, K, H, H, n, d_hf, 1, H, n * C, w.h4, H, 1, nH, G + off[14], H + E2, 1, ps);
+    gemm(st, K, H, E2, n, d_hf, 1, H, n * C, w.emb + E1, EM, 1, n * EM, G + off[14] + H, H + E2, 1, ps);
+    hipLaunchKernelGGL(colsum_kernel, dim3((H + 63) / 64, K), dim3(256), 0, st, (int)n, H, d_hf, (long)H, n * C,
+                       G + off[15], ps);
+    gemm(st, K, n, H, H, d_hf, H, 1, n * C, P + off[14], H + E2, 1, ps, d_h4, H, 1, nH, true);
+    gemm(st, K, n, E2, H, d_hf, H, 1, n * C, P + off[14] + H, H + E2, 1, ps, w.d_emb + E1, EM, 1, n * EM, true);
+  }
+  // colour layer
+  gemm(st, K, H, H, n, d_hc, 1, H, nH, w.h4, H, 1, nH, G + off[10], H + E2, 1, ps);
+  gemm(st, K, H, E2, n, d_hc, 1, H, nH, w.emb + E1, EM, 1, n * EM, G + off[10] + H, H + E2, 1, ps);
+  hipLaunchKernelGGL(colsum_kernel, dim3((H + 63) / 64, K), dim3(256), 0, st, (int)n, H, d_hc, (long)H, nH, G + off[11], ps);
+  gemm(st, K, n, H, H, d_hc, H, 1, nH, P + off[10], H + E2, 1, ps, d_h4, H, 1, nH, true, nullptr, 0, false, w.h4, H, 1, nH);
+  gemm(st, K, n, E2, H, d_hc, H, 1, nH, P + off[10] + H, H + E2, 1, ps, w.d_emb + E1, EM, 1, n * EM, true);
+  // mid2:  d_h4 (masked above) -> grads, d_h3
+  float* d_h3 = w.dA;     // d_hc is dead
+  gemm(st, K, H, H, n, d_h4, 1, H, nH, w.h3, H, 1, nH, G + off[6], H, 1, ps);
+  hipLaunchKernelGGL(colsum_kernel, dim3((H + 63) / 64, K), dim3(256), 0, st, (int)n, H, d_h4, (long)H, nH, G + off[7], ps);
+  gemm(st, K, n, H, H, d_h4, H, 1, nH, P + off[6], H, 1, ps, d_h3, H, 1, nH, false, nullptr, 0, false, w.h3, H, 1, nH);
+  // cat layer
+  float* d_h2 = w.dB_;    // d_h4 is dead
+  gemm(st, K, H, H, n, d_h3, 1, H, nH, w.h2, H, 1, nH, G + off[4], H + E1, 1, ps);
+  gemm(st, K, H, E1, n, d_h3, 1, H, nH, w.emb, EM, 1, n * EM, G + off[4] + H, H + E1, 1, ps);
+  hipLaunchKernelGGL(colsum_kernel, dim3((H + 63) / 64, K), dim3(256), 0, st, (int)n, H, d_h3, (long)H, nH, G + off[5], ps);
+  gemm(st, K, n, H, H, d_h3, H, 1, nH, P + off[4], H + E1, 1, ps, d_h2, H, 1, nH, false, nullptr, 0, false, w.h2, H, 1, nH);
+  gemm(st, K, n, E1, H, d_h3, H, 1, nH, P + off[4] + H, H + E1, 1, ps, w.d_emb, EM, 1, n * EM, true);
+  // mid1
+  float* d_h1 = w.dA;     // d_h3 is dead
+  gemm(st, K, H, H, n, d_h2, 1, H, nH, w.h1, H, 1, nH, G + off[2], H, 1, ps);
+  hipLaunchKernelGGL(colsum_kernel, dim3((H + 63) / 64, K), dim3(256), 0, st, (int)n, H, d_h2, (long)H, nH, G + off[3], ps);
+  gemm(st, K, n, H, H, d_h2, H, 1, nH, P + off[2], H, 1, ps, d_h1, H, 1, nH, false, nullptr, 0, false, w.h1, H, 1, nH);
+  // in layer
+  gemm(st, K, H, E1, n, d_h1, 1, H, nH, w.emb, EM, 1, n * EM, G + off[0], E1, 1, ps);
+  hipLaunchKernelGGL(colsum_kernel, dim3((H + 63) / 64, K), dim3(256), 0, st, (int)n, H, d_h1, (long)H, nH, G + off[1], ps);
+  gemm(st, K, n, E1, H, d_h1, H, 1, nH, P + off[0], E1, 1, ps, w.d_emb, EM, 1, n * EM, true);
+  // embedding directions
+  (void)hipMemsetAsync(w.dBpe, 0, (size_t)K * 64 * 4, st);
+  int pg = (int)((n + 255) / 256);
+  if (pg > 128) pg = 128;
+  hipLaunchKernelGGL(pe_bwd_kernel, dim3(pg, K), dim3(256), 0, st, n, net->n_freqs, P, ps, (int)off[18], a->scale, a->pts,
+                     w.d_emb, w.dBpe);
+  hipLaunchKernelGGL(copy_cols_kernel, dim3((unsigned)((K * 63 + 255) / 256)), dim3(256), 0, st, (long)K, 63, w.dBpe, 63L,
+                     G + off[18], ps);
+  if (hipGetLastError() != hipSuccess) return OBJNERF_ELAUNCH;
+  return OBJNERF_OK;
+}
+
+}  // namespace objgen

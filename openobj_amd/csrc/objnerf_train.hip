@@ -14,6 +14,7 @@
 // Each workgroup then writes one partial-gradient slab; finalize_kernel sums the slabs (no atomics on
 // global memory, bit-reproducible run to run).
 #include "objnerf_mlp.h"
+#include "objnerf_generic.h"
 #include "../../include/objnerf_hip.h"
 
 using namespace obj32;
@@ -791,6 +792,7 @@ static int train_grid(int K, int NT) {
 
 size_t objnerf_train_workspace_bytes(const objnerf_net* net, int32_t K, int32_t R, int32_t S, int32_t with_feat) {
   if (!net || K <= 0 || R <= 0 || S <= 0) return 0;
+  if (net->hidden != 32) return objgen::train_workspace_bytes(net, K, R, S, with_feat);
   int64_t offs[OBJNERF_N_TENSORS + 1];
   const int64_t ps = objnerf_param_layout(net, offs);
   const int Gmax = num_cu();   // upper bound on the workgroups per object
@@ -808,8 +810,14 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
     return OBJNERF_EINVAL;
   if (!a->pts && (!a->origins || !a->dirs)) return OBJNERF_EINVAL;
   if (a->K <= 0 || a->R <= 0 || a->S <= 0) return OBJNERF_EINVAL;
-  if (net->hidden != 32 || net->n_freqs != 6) return OBJNERF_ENOTSUP;
-  if (a->S > 64) return OBJNERF_ENOTSUP;
+  if (net->n_freqs != 6) return OBJNERF_ENOTSUP;
+  if (net->hidden != 32 || a->S > 64) {
+    // wider networks (background: hidden 128) and long rays: layer-wise path, activations in the workspace
+    if (a->workspace_bytes < objgen::train_workspace_bytes(net, a->K, a->R, a->S, a->gt_feat != nullptr))
+      return OBJNERF_EINVAL;
+    (void)hipMemsetAsync(a->status, 0, sizeof(int), (hipStream_t)stream);
+    return objgen::train_step(net, a, stream);
+  }
   const bool feat = a->gt_feat != nullptr;
   if (feat && (TS / a->S) > 16) return OBJNERF_ENOTSUP;
   if (a->workspace_bytes < objnerf_train_workspace_bytes(net, a->K, a->R, a->S, a->gt_feat != nullptr))

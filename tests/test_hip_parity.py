@@ -315,3 +315,51 @@ def test_rays_dirs_g7(golden, dev):
     W, H, fx, fy, cx, cy = [float(x) for x in g["gts_cam"]]
     out = ops.rays_dirs(int(W), int(H), fx, fy, cx, cy, dev)
     assert torch.equal(out.cpu(), T(g["gts_rays_dir_cache"]))
+
+
+@pytest.mark.parametrize("tag", ["nofeat", "feat"])
+def test_background_step_g10(golden, dev, tag):
+    """The shared background network (hidden 128, 14 samples/ray, bg_scale 5; train.py:447-463): one
+    iteration through the layer-wise path == the reference's loss and gradients."""
+    g = golden(f"g10_bg_{tag}")
+    K, R, N, M, feat_on, H = [int(x) for x in g["meta"]]
+    arena = arena_from_fixture(g, dev, scale=5.0, hidden=H)
+    ws = ops.TrainWorkspace(arena, K, R, N + M, bool(feat_on))
+    b = synthetic.random_batch(K, R, N, M, seed=1000, feat_dim=512)
+    _hip_step(arena, ws, b, dev, with_feat=bool(feat_on))
+    t = ws.loss_terms.cpu()
+    total = (t[:, 0] + 5 * t[:, 1] + 10 * t[:, 2] + (5 * t[:, 3] if feat_on else 0)).sum().item()
+    assert abs(total - g["loss"][0]) < 1e-4 * abs(g["loss"][0]), (total, g["loss"][0])
+    gv = arena.views(ws.grads)
+    for i in range(19):
+        if i in ops.FEAT_TENSORS and not feat_on:
+            continue
+        ref = g[f"grad0_{i}"]
+        scale = max(1e-3, float(np.abs(ref).max()))
+        assert maxerr(gv[i], ref) < 2e-4 * scale, (i, ops.TENSOR_NAMES[i], maxerr(gv[i], ref), scale)
+
+
+def test_long_ray_step_vs_oracle(golden, dev):
+    """S = 128 (BASELINE configs[4] sample count) takes the layer-wise path even at hidden 32."""
+    K, R, n1, n2 = 2, 12, 32, 96
+    g = golden("g9_psnr_nofeat")
+    fc = [T(g[f"fc0_{i}"])[:K].clone() for i in range(18)]
+    B = O.icosa_dirs()[None].repeat(K, 1, 1)
+    arena = ops.ParamArena(K, ops.NetShape(), dev)
+    arena.load_stacked(fc + [B])
+    ws = ops.TrainWorkspace(arena, K, R, n1 + n2, False)
+    b = synthetic.random_batch(K, R, n1, n2, seed=31)
+    _hip_step(arena, ws, b, dev)
+    fcr = [p.clone().requires_grad_(True) for p in fc]
+    Br = B.clone().requires_grad_(True)
+    loss, terms = O.train_forward_loss(fcr, Br, torch.full((K,), 2.0), T(b["pts"]), T(b["gt_depth"]), T(b["gt_rgb"]),
+                                       T(b["labels"]), T(b["z"]), return_terms=True)
+    grads = torch.autograd.grad(loss, fcr + [Br], allow_unused=True)
+    t = ws.loss_terms.cpu()
+    assert abs((t[:, 0] + 5 * t[:, 1] + 10 * t[:, 2]).sum().item() - loss.item()) < 1e-4 * abs(loss.item())
+    gv = arena.views(ws.grads)
+    for i in range(19):
+        if grads[i] is None:
+            continue
+        scale = max(1e-3, float(grads[i].abs().max()))
+        assert maxerr(gv[i], grads[i]) < 2e-4 * scale, (i, maxerr(gv[i], grads[i]), scale)
