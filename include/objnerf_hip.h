@@ -157,6 +157,8 @@ typedef struct objnerf_loss_args {
   const float* alpha; const float* color; const float* z; const float* gt_depth;
   const float* gt_rgb; const uint8_t* labels; const float* pred_feat; const float* gt_feat;
   const int32_t* flags_in;
+  const int32_t* counts_in;   /* optional [K][2]: use these (e.g. all-reduced over GPUs that split one object's rays)
+                                 instead of counting this call's labels */
   float* loss_terms; float* total; float* d_alpha; float* d_color; float* d_pred_feat;
   int32_t* counts; int32_t* status;
 } objnerf_loss_args;

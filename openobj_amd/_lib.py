@@ -52,7 +52,7 @@ class LossArgs(C.Structure):
                 ("feat_scaling", C.c_float), ("reserved", C.c_float),
                 ("alpha", C.c_void_p), ("color", C.c_void_p), ("z", C.c_void_p), ("gt_depth", C.c_void_p),
                 ("gt_rgb", C.c_void_p), ("labels", C.c_void_p), ("pred_feat", C.c_void_p),
-                ("gt_feat", C.c_void_p), ("flags_in", C.c_void_p),
+                ("gt_feat", C.c_void_p), ("flags_in", C.c_void_p), ("counts_in", C.c_void_p),
                 ("loss_terms", C.c_void_p), ("total", C.c_void_p), ("d_alpha", C.c_void_p),
                 ("d_color", C.c_void_p), ("d_pred_feat", C.c_void_p),
                 ("counts", C.c_void_p), ("status", C.c_void_p)]

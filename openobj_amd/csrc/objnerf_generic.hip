@@ -298,6 +298,7 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a, void* stream
   la.reserved = 0;
   la.alpha = w.alpha; la.color = w.color; la.z = a->z; la.gt_depth = a->gt_depth; la.gt_rgb = a->gt_rgb;
   la.labels = a->labels; la.pred_feat = feat ? w.clip : nullptr; la.gt_feat = a->gt_feat; la.flags_in = a->flags;
+  la.counts_in = a->counts;
   la.loss_terms = a->loss_terms; la.total = nullptr; la.d_alpha = w.d_alpha; la.d_color = w.d_color;
   la.d_pred_feat = feat ? w.d_clip : nullptr; la.counts = w.counts; la.status = a->status;
   rc = objnerf_step_batch_loss(&la, stream);

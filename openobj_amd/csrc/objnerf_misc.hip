@@ -160,6 +160,13 @@ __global__ void label_counts_kernel(int K, int R, const uint8_t* labels, int* co
   }
 }
 
+__global__ void flags_from_counts_kernel(int K, const int* counts, int* flags) {
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    if (counts[2 * k] == 0) atomicOr(&flags[0], 1);
+    if (counts[2 * k + 1] == 0) atomicOr(&flags[1], 1);
+  }
+}
+
 __global__ void merge_flags_kernel(int* flags, const int* flags_in) {
   if (threadIdx.x < 2 && flags_in && flags_in[threadIdx.x]) flags[threadIdx.x] = 1;
 }
@@ -492,7 +499,12 @@ int objnerf_step_batch_loss(const objnerf_loss_args* a, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   int* flags = a->counts + 2 * a->K;     // counts workspace is [K][2] + [2]
   hipMemsetAsync(flags, 0, 2 * sizeof(int), st);
-  hipLaunchKernelGGL(label_counts_kernel, dim3(a->K), dim3(256), 0, st, a->K, a->R, a->labels, a->counts, flags);
+  if (a->counts_in) {
+    hipMemcpyAsync(a->counts, a->counts_in, (size_t)2 * a->K * sizeof(int), hipMemcpyDeviceToDevice, st);
+    hipLaunchKernelGGL(flags_from_counts_kernel, dim3(1), dim3(64), 0, st, a->K, a->counts, flags);
+  } else {
+    hipLaunchKernelGGL(label_counts_kernel, dim3(a->K), dim3(256), 0, st, a->K, a->R, a->labels, a->counts, flags);
+  }
   if (a->flags_in) hipLaunchKernelGGL(merge_flags_kernel, dim3(1), dim3(64), 0, st, flags, a->flags_in);
   hipMemsetAsync(a->loss_terms, 0, (size_t)a->K * 4 * sizeof(float), st);
   LossDev d;

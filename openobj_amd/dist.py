@@ -34,3 +34,16 @@ def total_loss(local_terms: torch.Tensor, color_scaling=5.0, opacity_scaling=10.
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
+
+
+def allreduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place SUM all-reduce (RCCL when the tensor is on a GPU); no-op for a single process."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def shard_rays(R: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous slice of the R rays of ONE replicated network (the background) owned by `rank`."""
+    return shard_objects(R, world, rank)

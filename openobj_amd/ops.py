@@ -200,7 +200,7 @@ def label_counts(labels: torch.Tensor):
 
 
 def step_batch_loss(alpha, color, gt_depth, gt_rgb, labels, z, color_scaling=5.0, opacity_scaling=10.0,
-                    gt_feat=None, pred_feat=None, feat_scaling=5.0, want_grads=True, flags_in=None):
+                    gt_feat=None, pred_feat=None, feat_scaling=5.0, want_grads=True, flags_in=None, counts_in=None):
     """loss.step_batch_loss on materialised tensors.  Returns dict(total, terms [K,4], d_alpha, d_color,
     d_pred_feat, status)."""
     alpha = _req(alpha, torch.float32, "alpha")
@@ -224,7 +224,7 @@ def step_batch_loss(alpha, color, gt_depth, gt_rgb, labels, z, color_scaling=5.0
     d_color = torch.empty(K, R, S, 3, device=dev) if want_grads else None
     d_pf = torch.empty_like(pred_feat) if (want_grads and pred_feat is not None) else None
     a = LossArgs(K, R, S, Cc, color_scaling, opacity_scaling, feat_scaling, 0.0, _ptr(alpha), _ptr(color), _ptr(z),
-                 _ptr(gt_depth), _ptr(gt_rgb), _ptr(labels), _ptr(pred_feat), _ptr(gt_feat), _ptr(flags_in),
+                 _ptr(gt_depth), _ptr(gt_rgb), _ptr(labels), _ptr(pred_feat), _ptr(gt_feat), _ptr(flags_in), _ptr(counts_in),
                  _ptr(terms), _ptr(total), _ptr(d_alpha), _ptr(d_color), _ptr(d_pf), _ptr(counts), _ptr(status))
     check(lib().objnerf_step_batch_loss(C.byref(a), _stream()), "objnerf_step_batch_loss")
     return dict(total=total, terms=terms, d_alpha=d_alpha, d_color=d_color, d_pred_feat=d_pf, status=status,
@@ -252,7 +252,7 @@ class TrainWorkspace:
 
 def train_step(arena: ParamArena, ws: TrainWorkspace, batch: Dict[str, torch.Tensor], color_scaling=5.0,
                opacity_scaling=10.0, feat_scaling=5.0, with_feat=False, obj_center=0.0,
-               global_flags: Optional[torch.Tensor] = None) -> None:
+               global_flags: Optional[torch.Tensor] = None, global_counts: Optional[torch.Tensor] = None) -> None:
     """One fused iteration (train.py:424-472): fills ws.grads, ws.loss_terms, ws.status.
 
     batch: pts [K,R,S,3] (or origins+dirs), z, gt_depth, gt_rgb, labels u8 (+ gt_feat when with_feat).
@@ -273,10 +273,13 @@ def train_step(arena: ParamArena, ws: TrainWorkspace, batch: Dict[str, torch.Ten
     flags = ws.flags
     if global_flags is not None:
         flags = global_flags
+    counts = ws.counts
+    if global_counts is not None:       # one object's rays split over ranks (background): global mask counts
+        counts = _req(global_counts, torch.int32, "global_counts")
     net = arena.net.c()
     a = TrainArgs(K, R, S, 0, color_scaling, opacity_scaling, feat_scaling, obj_center, _ptr(arena.params),
                   arena.p_stride, _ptr(arena.scale), _ptr(pts), _ptr(origins), _ptr(dirs), _ptr(z), _ptr(gt_depth),
-                  _ptr(gt_rgb), _ptr(labels), _ptr(gt_feat), _ptr(ws.counts), _ptr(flags), _ptr(ws.grads),
+                  _ptr(gt_rgb), _ptr(labels), _ptr(gt_feat), _ptr(counts), _ptr(flags), _ptr(ws.grads),
                   _ptr(ws.loss_terms), _ptr(ws.status), _ptr(ws.buf), ws.nbytes)
     check(lib().objnerf_train_step(C.byref(net), C.byref(a), st), "objnerf_train_step")
 

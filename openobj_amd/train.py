@@ -6,8 +6,41 @@ from typing import Dict, List, Optional
 
 import torch
 
+from . import dist as odist
 from . import ops, optim
 from .render_rays import LossExplode
+
+
+class BackgroundLoop:
+    """The separate background network (obj_id 0, hidden_feature_size_bg = 128, train.py:447-463).
+
+    It is NOT in the vmap stack.  Under object sharding it is replicated on every rank: each rank trains
+    on its slice of the iteration's n_per_optim_bg rays, the per-ray loss is normalised by the GLOBAL
+    mask counts (an 2-int SUM all-reduce), the gradient (182 339 floats at hidden 128) is SUM
+    all-reduced over RCCL and every rank applies the same AdamW update."""
+
+    def __init__(self, cfg, bg_trainer, with_feat: bool = False, group=None):
+        self.cfg, self.trainer, self.with_feat, self.group = cfg, bg_trainer, with_feat, group
+        self.arena = bg_trainer.arena           # K = 1: trained in place, no copy-back needed
+        self.arena.scale.fill_(float(bg_trainer.obj_scale))
+        self.opt = optim.ArenaAdamW(self.arena, lr=cfg.learning_rate, weight_decay=cfg.weight_decay)
+        self.mask = self.arena.has_grad_mask(with_feat)
+        self.ws = None
+
+    def step(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """batch: THIS rank's slice of the background rays, tensors shaped [1, R_local, ...]."""
+        K, R, S = batch["z"].shape
+        if self.ws is None or self.ws.key != (K, R, S, self.with_feat):
+            self.ws = ops.TrainWorkspace(self.arena, K, R, S, self.with_feat)
+        counts, flags = ops.label_counts(batch["labels"])
+        odist.allreduce_sum_(counts, self.group)                  # global n(label==1), n(label!=2)
+        flags = ((counts.reshape(-1, 2) == 0).any(dim=0)).to(torch.int32)
+        ops.train_step(self.arena, self.ws, batch, with_feat=self.with_feat, global_flags=flags,
+                       global_counts=counts)
+        odist.allreduce_sum_(self.ws.grads, self.group)           # the one data-path collective
+        odist.allreduce_sum_(self.ws.loss_terms, self.group)
+        self.opt.step(self.ws.grads, self.mask)
+        return self.ws.loss_terms
 
 
 class HipTrainLoop:

@@ -216,3 +216,33 @@ def test_train_loop_psnr_g9(golden, dev):
     print("PSNR ensemble hip", np.round(ens, 3), "reference", np.round(ref, 3))
     assert abs(np.mean(ens) - np.mean(ref)) < 0.35, (np.mean(ens), np.mean(ref))
     assert min(ens) > np.min(ref) - 1.0
+
+
+def test_background_loop_matches_single_shot(dev):
+    """BackgroundLoop on one rank == one objnerf_train_step + AdamW on the hidden-128 network; and splitting
+    the rays in two halves with summed counts / gradients (what two ranks do) gives the same gradient."""
+    c = make_cfg(dev)
+    c.hidden_feature_size, c.obj_scale, c.obj_id = 128, 5.0, 0
+    torch.manual_seed(11)
+    bg = trainer.Trainer(c)
+    b = synthetic.random_batch(1, 64, 5, 9, seed=5)
+    keys = ["pts", "z", "gt_depth", "gt_rgb", "labels"]
+    full = {k: T(b[k]).to(dev) for k in keys}
+    ws = ops.TrainWorkspace(bg.arena, 1, 64, 14, False)
+    ops.train_step(bg.arena, ws, full)
+    g_full = ws.grads.clone()
+    counts, _ = ops.label_counts(full["labels"])
+    halves = []
+    for lo, hi in ((0, 32), (32, 64)):
+        part = {k: v[:, lo:hi].contiguous() for k, v in full.items()}
+        w2 = ops.TrainWorkspace(bg.arena, 1, 32, 14, False)
+        ops.train_step(bg.arena, w2, part, global_counts=counts,
+                       global_flags=torch.zeros(2, dtype=torch.int32, device=dev))
+        halves.append(w2.grads.clone())
+    gsum = halves[0] + halves[1]
+    scale = float(g_full.abs().max())
+    assert maxerr(gsum, g_full) < 2e-5 * scale
+    loop = otrain.BackgroundLoop(c, bg)
+    before = bg.arena.params.clone()
+    t = loop.step(full)
+    assert t.shape == (1, 4) and float((bg.arena.params - before).abs().max()) > 0
