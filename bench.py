@@ -3,13 +3,15 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One "step" = one complete training iteration of train.py:394-474 for the K_obj stacked object
-networks of THIS rank (label statistics -> fused forward/loss/backward kernel -> gradient finalize ->
-AdamW), inputs already resident in HBM.  Workload (BASELINE.json configs[1]): 50 objects per GPU,
+One "step" = one complete training iteration of train.py:394-474: the K_obj stacked object networks of
+THIS rank (label statistics -> fused forward/loss/backward kernel -> gradient finalize -> AdamW) plus
+the shared background network (hidden 128, its 1200 rays split over the ranks, gradient all-reduce),
+inputs already resident in HBM.  Workload (BASELINE.json configs[1]): 50 objects per GPU,
 hidden 32, 64 samples per ray (n_bins_cam2surface 16 + n_bins 48), RGB + depth + opacity loss,
 synthetic Replica-shaped rays (openobj_amd.synthetic.random_batch), reference-initialised weights.
 Objects shard across ranks with no data-path collective (the per-step early-return flags are a
-2-int all-reduce); scaling is weak: every rank trains its own 50 objects.
+2-int all-reduce); the replicated background network's gradient (182 339 floats) is the one RCCL
+all-reduce.  Scaling is weak: every rank trains its own 50 objects.  `value` counts object rays only.
 
 Prints ONE JSON line (rank 0).  `roofline` is the fused kernel against the dense fp32 MFMA peak,
 `cpu_baseline` is the oracle (the reference's op sequence in PyTorch on the host cores) on a bounded
@@ -80,6 +82,10 @@ def main():
     ap.add_argument("--n-bins", type=int, default=48)
     ap.add_argument("--feat", action="store_true",
                     help="BASELINE configs[2]: add the 512-d feature-distillation loss (cfg.part_mode)")
+    ap.add_argument("--no-bg", dest="bg", action="store_false",
+                    help="skip the shared background network.  Default (do_bg = 1, room_0.json:21): every step also "
+                         "trains it (hidden 128, n_per_optim_bg = 1200 rays split over the ranks, 64 samples/ray, "
+                         "gradient all-reduce over RCCL), as train.py:447-463 does; `value` counts object rays only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=192)
     args = ap.parse_args()
@@ -111,6 +117,18 @@ def main():
         b = synthetic.random_batch(K, R, n1, n2, seed=4242 + 17 * rank + i, feat_dim=512 if feat else 0)
         batches.append({k: torch.from_numpy(b[k]).to(dev) for k in keys})
     gflags = torch.zeros(2, dtype=torch.int32, device=dev)
+    bg_loop = None
+    if args.bg:
+        from openobj_amd import cfg as ocfg, dist as odist, trainer as otrainer, train as otrain
+        c = ocfg.Config(ocfg.replica_room0_config(train_device=str(dev)))
+        c.obj_id, c.hidden_feature_size, c.obj_scale = 0, c.hidden_feature_size_bg, c.bg_scale
+        torch.manual_seed(7)                               # identical replica on every rank
+        bg_loop = otrain.BackgroundLoop(c, otrainer.Trainer(c), with_feat=feat)
+        lo, hi = odist.shard_rays(c.n_per_optim_bg, world, rank)
+        bg_batches = []
+        for i in range(2):
+            b = synthetic.random_batch(1, c.n_per_optim_bg, n1, n2, seed=777 + i, feat_dim=512 if feat else 0)
+            bg_batches.append({k: torch.from_numpy(b[k][:, lo:hi]).contiguous().to(dev) for k in keys})
 
     step_no = [0]
 
@@ -129,6 +147,8 @@ def main():
             ops.train_step(arena, ws, b, with_feat=feat)
         step_no[0] += 1
         ops.adamw_step(arena, ws.grads, m, v, mask, step_no[0], 1e-3, 0.013)
+        if bg_loop is not None:
+            bg_loop.step(bg_batches[i & 1])
 
     for i in range(args.warmup):
         step(i)
@@ -176,7 +196,7 @@ def main():
                                    f"{S} samples/ray ({n1}+{n2}), RGB+depth+opacity"
                                    f"{'+512-d feature' if feat else ''} loss, fused fwd+loss+bwd+AdamW",
                        "objects_per_gpu": K, "rays_per_object": R, "samples_per_ray": S, "hidden": 32,
-                       "feature_head": feat, "parallelism": f"objects sharded x{world}",
+                       "feature_head": feat, "background_mlp": bool(args.bg), "parallelism": f"objects sharded x{world}",
                        "loss_status": status},
             "rays_per_sec_per_gpu": value / world,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",

@@ -22,6 +22,7 @@ struct Gemm {
   const float* bias; long bsbias;
   const float* mask; long smm, smn, bsm;
   int accumulate, relu;
+  int splitk;      // > 1: blockIdx.z = batch * splitk + slice; each slice atomically adds its partial into C
 };
 
 constexpr int BM = 64, BN = 64, BK = 16;
@@ -33,16 +34,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Gemm g) {
   const int c = lane & 15, gg = lane >> 4;
   const int wm = w >> 1, wn = w & 1;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const long z = blockIdx.z;
+  const int sk = g.splitk > 1 ? g.splitk : 1;
+  const long z = blockIdx.z / sk;
+  const int slice = blockIdx.z % sk;
   const float* A = g.A + z * g.bsa;
   const float* B = g.B + z * g.bsb;
   float* C = g.C + z * g.bsc;
+  const int kper = ((g.Kd + sk - 1) / sk + BK - 1) / BK * BK;
+  const int kbeg = slice * kper, kend = min(g.Kd, kbeg + kper);
   f32x4 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int k0 = 0; k0 < g.Kd; k0 += BK) {
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
     // global -> LDS: 64 x 16 elements each, 4 per thread
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -51,11 +56,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Gemm g) {
       int am, ak;
       if (g.sak == 1) { ak = e & 15; am = e >> 4; } else { am = e & 63; ak = e >> 6; }
       const int gm = m0 + am, gk = k0 + ak;
-      As[ak][am] = (gm < g.M && gk < g.Kd) ? A[gm * g.sam + gk * g.sak] : 0.f;
+      As[ak][am] = (gm < g.M && gk < kend) ? A[gm * g.sam + gk * g.sak] : 0.f;
       int bn, bk;
       if (g.sbk == 1) { bk = e & 15; bn = e >> 4; } else { bn = e & 63; bk = e >> 6; }
       const int gn = n0 + bn, gk2 = k0 + bk;
-      Bs[bk][bn] = (gn < g.N && gk2 < g.Kd) ? B[gk2 * g.sbk + gn * g.sbn] : 0.f;
+      Bs[bk][bn] = (gn < g.N && gk2 < kend) ? B[gk2 * g.sbk + gn * g.sbn] : 0.f;
     }
     __syncthreads();
 #pragma unroll
@@ -83,6 +88,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Gemm g) {
         if (m < g.M && n < g.N) {
           float* cp = C + m * g.scm + n * g.scn;
           float v = acc[i][j][r];
+          if (sk > 1) { atomicAdd(cp, v); continue; }
           if (g.accumulate) v += *cp;
           if (g.bias) v += g.bias[z * g.bsbias + n];
           if (g.relu) v = fmaxf(v, 0.f);
@@ -95,30 +101,47 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Gemm g) {
 static void gemm(hipStream_t st, int batch, int M, int N, int Kd, const float* A, long sam, long sak, long bsa,
                  const float* B, long sbk, long sbn, long bsb, float* C, long scm, long scn, long bsc,
                  bool accumulate = false, const float* bias = nullptr, long bsbias = 0, bool relu = false,
-                 const float* mask = nullptr, long smm = 0, long smn = 0, long bsm = 0) {
+                 const float* mask = nullptr, long smm = 0, long smn = 0, long bsm = 0, int splitk = 1) {
   Gemm g;
   g.M = M; g.N = N; g.Kd = Kd;
   g.A = A; g.sam = sam; g.sak = sak; g.bsa = bsa;
   g.B = B; g.sbk = sbk; g.sbn = sbn; g.bsb = bsb;
   g.C = C; g.scm = scm; g.scn = scn; g.bsc = bsc;
   g.bias = bias; g.bsbias = bsbias; g.mask = mask; g.smm = smm; g.smn = smn; g.bsm = bsm;
-  g.accumulate = accumulate; g.relu = relu;
-  dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, batch);
+  g.accumulate = accumulate; g.relu = relu; g.splitk = splitk;
+  dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, batch * (splitk > 1 ? splitk : 1));
   hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), 0, st, g);
+}
+
+// weight gradient: C[M][N] += sum over the n samples; few output tiles, long contraction -> split-K + atomics
+static void wgrad(hipStream_t st, int batch, int M, int N, long n, const float* A, long sam, long sak, long bsa,
+                  const float* B, long sbk, long sbn, long bsb, float* C, long scm, long bsc) {
+  int sk = (int)((n + 2047) / 2048);
+  if (sk < 1) sk = 1;
+  if (sk > 64) sk = 64;
+  gemm(st, batch, M, N, (int)n, A, sam, sak, bsa, B, sbk, sbn, bsb, C, scm, 1, bsc, false, nullptr, 0, false, nullptr, 0,
+       0, 0, sk > 1 ? sk : 2);
 }
 
 // column sums: out[z][n] = sum_m X[z][m][n]   (bias gradients)
 __global__ void colsum_kernel(int M, int N, const float* X, long ldx, long bsx, float* out, long bso) {
   const int n = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int part = threadIdx.x >> 6;      // 4 row partitions
+  const int part = threadIdx.x >> 6;      // 4 row partitions per block, gridDim.z row slices (out is pre-zeroed)
   const long z = blockIdx.y;
   __shared__ float red[4][64];
   float s = 0.f;
   if (n < N)
-    for (int m = part; m < M; m += 4) s += X[z * bsx + (long)m * ldx + n];
+    for (int m = blockIdx.z * 4 + part; m < M; m += 4 * gridDim.z) s += X[z * bsx + (long)m * ldx + n];
   red[part][threadIdx.x & 63] = s;
   __syncthreads();
-  if (part == 0 && n < N) out[z * bso + n] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  if (part == 0 && n < N)
+    atomicAdd(&out[z * bso + n], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+static void colsum(hipStream_t st, int K, long n, int N, const float* X, long ldx, long bsx, float* out, long bso) {
+  int zs = (int)((n + 1023) / 1024);
+  if (zs < 1) zs = 1;
+  if (zs > 64) zs = 64;
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, K, zs), dim3(256), 0, st, (int)n, N, X, ldx, bsx, out, bso);
 }
 
 // heads forward: alpha = 10 (h4 . wa + ba), color = sigmoid(hc Woc^T + boc)        (model.py:81-96)
@@ -173,36 +196,41 @@ __global__ void relu_mask_kernel(long n, float* d, const float* act) {
 }
 
 // PE backward: d B[j][x] = sum_n t[n][x] sum_f d_emb[n][3 + 21 f + j] cos(arg) pi 2^f     (embedding.py:48-52)
-__global__ __launch_bounds__(256) void pe_bwd_kernel(long n, int n_freqs, const float* params, long p_stride, int off_B,
+// private register accumulators per thread, wave reduction, one atomic per wave and entry.
+__global__ __launch_bounds__(256) void pe_bwd_kernel(long n, const float* params, long p_stride, int off_B,
                                                      const float* scale, const float* pts, const float* d_emb,
                                                      float* dB /* [K][63], pre-zeroed */) {
-  __shared__ float red[63];
   const long z = blockIdx.y;
-  if (threadIdx.x < 63) red[threadIdx.x] = 0.f;
-  __syncthreads();
   const float* B = params + z * p_stride + off_B;
   const float sc = scale[z];
-  const int E = 3 + OBJ_NDIR * n_freqs;
+  float acc[63];
+#pragma unroll
+  for (int i = 0; i < 63; ++i) acc[i] = 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const float* p = pts + (z * n + i) * 3;
     const float t0 = p[0] / sc, t1 = p[1] / sc, t2 = p[2] / sc;
-    const float* de = d_emb + (z * n + i) * E;
+    const float* de = d_emb + (z * n + i) * OBJ_EMB;
+#pragma unroll
     for (int j = 0; j < OBJ_NDIR; ++j) {
       const float pj = fmaf(t2, B[3 * j + 2], fmaf(t1, B[3 * j + 1], t0 * B[3 * j]));
       float dp = 0.f;
-      for (int f = 0; f < n_freqs; ++f) {
+#pragma unroll
+      for (int f = 0; f < 6; ++f) {
         const float sf = (float)(1 << f);
-        float s, cv;
-        sincos_acc((pj * sf) * OBJ_PI_F, s, cv);
+        float sv, cv;
+        sincos_acc((pj * sf) * OBJ_PI_F, sv, cv);
         dp += de[3 + f * OBJ_NDIR + j] * ((cv * OBJ_PI_F) * sf);
       }
-      atomicAdd(&red[3 * j], dp * t0);
-      atomicAdd(&red[3 * j + 1], dp * t1);
-      atomicAdd(&red[3 * j + 2], dp * t2);
+      acc[3 * j] = fmaf(dp, t0, acc[3 * j]);
+      acc[3 * j + 1] = fmaf(dp, t1, acc[3 * j + 1]);
+      acc[3 * j + 2] = fmaf(dp, t2, acc[3 * j + 2]);
     }
   }
-  __syncthreads();
-  if (threadIdx.x < 63) atomicAdd(&dB[z * 63 + threadIdx.x], red[threadIdx.x]);
+#pragma unroll
+  for (int i = 0; i < 63; ++i) {
+    const float v = wave_sum64(acc[i]);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&dB[z * 63 + i], v);
+  }
 }
 
 __global__ void copy_cols_kernel(long rows, int cols, const float* src, long lds_, float* dst, long ldd) {
@@ -303,66 +331,71 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a, void* stream
   la.d_pred_feat = feat ? w.d_clip : nullptr; la.counts = w.counts; la.status = a->status;
   rc = objnerf_step_batch_loss(&la, stream);
   if (rc) return rc;
-  // ---- backward
+  // ---- backward.  Weight / bias gradients are accumulated with split-K atomics: zero them first
+  // (feature-branch entries only when they receive a gradient, so "no gradient" stays "untouched").
+  for (int k = 0; k < K; ++k) {
+    (void)hipMemsetAsync(G + (long)k * ps, 0, (size_t)off[14] * 4, st);
+    if (feat) (void)hipMemsetAsync(G + (long)k * ps + off[14], 0, (size_t)(off[18] - off[14]) * 4, st);
+  }
   float* d_hc = w.dA;      // [n][H]
   float* d_h4 = w.dB_;
   hipLaunchKernelGGL(heads_bwd_kernel, eg, dim3(256), 0, st, H, n, w.hc, w.color, w.d_alpha, w.d_color, P, ps,
                      (int)off[8], (int)off[12], w.dhead, d_hc, d_h4);
   // head weight grads: d wa = dhead[:,0]^T h4, d Woc = dhead[:,1:4]^T hc; biases = column sums of dhead
-  gemm(st, K, 1, H, n, w.dhead, 1, 4, n * 4, w.h4, H, 1, nH, G + off[8], H, 1, ps);
-  gemm(st, K, 3, H, n, w.dhead + 1, 1, 4, n * 4, w.hc, H, 1, nH, G + off[12], H, 1, ps);
-  hipLaunchKernelGGL(colsum_kernel, dim3(1, K), dim3(256), 0, st, (int)n, 1, w.dhead, 4L, n * 4, G + off[9], ps);
-  hipLaunchKernelGGL(colsum_kernel, dim3(1, K), dim3(256), 0, st, (int)n, 3, w.dhead + 1, 4L, n * 4, G + off[13], ps);
+  wgrad(st, K, 1, H, n, w.dhead, 1, 4, n * 4, w.h4, H, 1, nH, G + off[8], H, ps);
+  wgrad(st, K, 3, H, n, w.dhead + 1, 1, 4, n * 4, w.hc, H, 1, nH, G + off[12], H, ps);
+  colsum(st, K, n, 1, w.dhead, 4L, n * 4, G + off[9], ps);
+  colsum(st, K, n, 3, w.dhead + 1, 4L, n * 4, G + off[13], ps);
   (void)hipMemsetAsync(w.d_emb, 0, (size_t)K * n * EM * 4, st);
   if (feat) {
     // d_hf = relu'(hf) (d_clip W_of); d W_of = d_clip^T hf; d b_of = colsum(d_clip)
     float* d_hf = w.clip;   // reuse: clip [n][C] is dead after the loss; d_hf lives there with batch pitch n*C
     gemm(st, K, n, H, C, w.d_clip, C, 1, n * C, P + off[16], H, 1, ps, d_hf, H, 1, n * C, false, nullptr, 0, false, w.hf,
          H, 1, nH);
-    gemm(st, K, C, H, n, w.d_clip, 1, C, n * C, w.hf, H, 1, nH, G + off[16], H, 1, ps);
-    hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64, K), dim3(256), 0, st, (int)n, C, w.d_clip, (long)C, n * C,
+    wgrad(st, K, C, H, n, w.d_clip, 1, C, n * C, w.hf, H, 1, nH, G + off[16], H, ps);
+    colsum(st, K, n, C, w.d_clip, (long)C, n * C,
                        G + off[17], ps);
     // feature layer: grads + contributions to d_h4 / d_x2
-    gemm(st, K, H, H, n, d_hf, 1, H, n * C, w.h4, H, 1, nH, G + off[14], H + E2, 1, ps);
-    gemm(st, K, H, E2, n, d_hf, 1, H, n * C, w.emb + E1, EM, 1, n * EM, G + off[14] + H, H + E2, 1, ps);
-    hipLaunchKernelGGL(colsum_kernel, dim3((H + 63) / 64, K), dim3(256), 0, st, (int)n, H, d_hf, (long)H, n * C,
+    wgrad(st, K, H, H, n, d_hf, 1, H, n * C, w.h4, H, 1, nH, G + off[14], H + E2, ps);
+    wgrad(st, K, H, E2, n, d_hf, 1, H, n * C, w.emb + E1, EM, 1, n * EM, G + off[14] + H, H + E2, ps);
+    colsum(st, K, n, H, d_hf, (long)H, n * C,
                        G + off[15], ps);
     gemm(st, K, n, H, H, d_hf, H, 1, n * C, P + off[14], H + E2, 1, ps, d_h4, H, 1, nH, true);
     gemm(st, K, n, E2, H, d_hf, H, 1, n * C, P + off[14] + H, H + E2, 1, ps, w.d_emb + E1, EM, 1, n * EM, true);
   }
   // colour layer
-  gemm(st, K, H, H, n, d_hc, 1, H, nH, w.h4, H, 1, nH, G + off[10], H + E2, 1, ps);
-  gemm(st, K, H, E2, n, d_hc, 1, H, nH, w.emb + E1, EM, 1, n * EM, G + off[10] + H, H + E2, 1, ps);
-  hipLaunchKernelGGL(colsum_kernel, dim3((H + 63) / 64, K), dim3(256), 0, st, (int)n, H, d_hc, (long)H, nH, G + off[11], ps);
+  wgrad(st, K, H, H, n, d_hc, 1, H, nH, w.h4, H, 1, nH, G + off[10], H + E2, ps);
+  wgrad(st, K, H, E2, n, d_hc, 1, H, nH, w.emb + E1, EM, 1, n * EM, G + off[10] + H, H + E2, ps);
+  colsum(st, K, n, H, d_hc, (long)H, nH, G + off[11], ps);
   gemm(st, K, n, H, H, d_hc, H, 1, nH, P + off[10], H + E2, 1, ps, d_h4, H, 1, nH, true, nullptr, 0, false, w.h4, H, 1, nH);
   gemm(st, K, n, E2, H, d_hc, H, 1, nH, P + off[10] + H, H + E2, 1, ps, w.d_emb + E1, EM, 1, n * EM, true);
   // mid2:  d_h4 (masked above) -> grads, d_h3
   float* d_h3 = w.dA;     // d_hc is dead
-  gemm(st, K, H, H, n, d_h4, 1, H, nH, w.h3, H, 1, nH, G + off[6], H, 1, ps);
-  hipLaunchKernelGGL(colsum_kernel, dim3((H + 63) / 64, K), dim3(256), 0, st, (int)n, H, d_h4, (long)H, nH, G + off[7], ps);
+  wgrad(st, K, H, H, n, d_h4, 1, H, nH, w.h3, H, 1, nH, G + off[6], H, ps);
+  colsum(st, K, n, H, d_h4, (long)H, nH, G + off[7], ps);
   gemm(st, K, n, H, H, d_h4, H, 1, nH, P + off[6], H, 1, ps, d_h3, H, 1, nH, false, nullptr, 0, false, w.h3, H, 1, nH);
   // cat layer
   float* d_h2 = w.dB_;    // d_h4 is dead
-  gemm(st, K, H, H, n, d_h3, 1, H, nH, w.h2, H, 1, nH, G + off[4], H + E1, 1, ps);
-  gemm(st, K, H, E1, n, d_h3, 1, H, nH, w.emb, EM, 1, n * EM, G + off[4] + H, H + E1, 1, ps);
-  hipLaunchKernelGGL(colsum_kernel, dim3((H + 63) / 64, K), dim3(256), 0, st, (int)n, H, d_h3, (long)H, nH, G + off[5], ps);
+  wgrad(st, K, H, H, n, d_h3, 1, H, nH, w.h2, H, 1, nH, G + off[4], H + E1, ps);
+  wgrad(st, K, H, E1, n, d_h3, 1, H, nH, w.emb, EM, 1, n * EM, G + off[4] + H, H + E1, ps);
+  colsum(st, K, n, H, d_h3, (long)H, nH, G + off[5], ps);
   gemm(st, K, n, H, H, d_h3, H, 1, nH, P + off[4], H + E1, 1, ps, d_h2, H, 1, nH, false, nullptr, 0, false, w.h2, H, 1, nH);
   gemm(st, K, n, E1, H, d_h3, H, 1, nH, P + off[4] + H, H + E1, 1, ps, w.d_emb, EM, 1, n * EM, true);
   // mid1
   float* d_h1 = w.dA;     // d_h3 is dead
-  gemm(st, K, H, H, n, d_h2, 1, H, nH, w.h1, H, 1, nH, G + off[2], H, 1, ps);
-  hipLaunchKernelGGL(colsum_kernel, dim3((H + 63) / 64, K), dim3(256), 0, st, (int)n, H, d_h2, (long)H, nH, G + off[3], ps);
+  wgrad(st, K, H, H, n, d_h2, 1, H, nH, w.h1, H, 1, nH, G + off[2], H, ps);
+  colsum(st, K, n, H, d_h2, (long)H, nH, G + off[3], ps);
   gemm(st, K, n, H, H, d_h2, H, 1, nH, P + off[2], H, 1, ps, d_h1, H, 1, nH, false, nullptr, 0, false, w.h1, H, 1, nH);
   // in layer
-  gemm(st, K, H, E1, n, d_h1, 1, H, nH, w.emb, EM, 1, n * EM, G + off[0], E1, 1, ps);
-  hipLaunchKernelGGL(colsum_kernel, dim3((H + 63) / 64, K), dim3(256), 0, st, (int)n, H, d_h1, (long)H, nH, G + off[1], ps);
+  wgrad(st, K, H, E1, n, d_h1, 1, H, nH, w.emb, EM, 1, n * EM, G + off[0], E1, ps);
+  colsum(st, K, n, H, d_h1, (long)H, nH, G + off[1], ps);
   gemm(st, K, n, E1, H, d_h1, H, 1, nH, P + off[0], E1, 1, ps, w.d_emb, EM, 1, n * EM, true);
   // embedding directions
   (void)hipMemsetAsync(w.dBpe, 0, (size_t)K * 64 * 4, st);
   int pg = (int)((n + 255) / 256);
   if (pg > 128) pg = 128;
-  hipLaunchKernelGGL(pe_bwd_kernel, dim3(pg, K), dim3(256), 0, st, n, net->n_freqs, P, ps, (int)off[18], a->scale, a->pts,
-                     w.d_emb, w.dBpe);
+  hipLaunchKernelGGL(pe_bwd_kernel, dim3(pg, K), dim3(256), 0, st, n, P, ps, (int)off[18], a->scale, a->pts, w.d_emb,
+                     w.dBpe);
   hipLaunchKernelGGL(copy_cols_kernel, dim3((unsigned)((K * 63 + 255) / 256)), dim3(256), 0, st, (long)K, 63, w.dBpe, 63L,
                      G + off[18], ps);
   if (hipGetLastError() != hipSuccess) return OBJNERF_ELAUNCH;
