@@ -13,30 +13,49 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define OBJ_EMB 129
 
 // ----------------------------------------------------------------------------------------------
-// sin / cos accurate to ~1 ulp for |x| < 1e4 (3-term Cody-Waite reduction + degree-7/8 minimax).
-// The reference evaluates torch.sin on fp32(fp32(proj*2^f) * fp32(pi)) (embedding.py:52); the
-// argument reaches a few hundred, so the hardware v_sin_f32 is not accurate enough for the fp32
-// parity path.
+// sin / cos accurate to ~1.3 ulp (1.2e-7 / 1.5e-7 absolute) for |x| < 1e4: 3-term Cody-Waite reduction
+// by pi to r in [-pi/2, pi/2], minimax polynomials, sign = (-1)^n.
+// The reference evaluates torch.sin on fp32(fp32(proj*2^f) * fp32(pi)) (embedding.py:52); the argument
+// reaches a few hundred, so the hardware v_sin_f32 is not accurate enough for the fp32 parity path.
 // ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ float pi_reduce(float x, unsigned& sign) {
+  const float n = rintf(x * 0.31830987f);
+  float r = fmaf(n, -3.1415927f, x);
+  r = fmaf(n, 8.742278e-08f, r);
+  r = fmaf(n, 3.5527137e-15f, r);
+  sign = ((unsigned)(int)n) << 31;
+  return r;
+}
+__device__ __forceinline__ float sin_poly(float r, float r2) {
+  float p = fmaf(r2, 2.5977522e-06f, -0.00019805509f);
+  p = fmaf(p, r2, 0.008333f);
+  p = fmaf(p, r2, -0.16666657f);
+  return fmaf(r * r2, p, r);
+}
+__device__ __forceinline__ float cos_poly(float r2) {
+  float q = fmaf(r2, -2.6058984e-07f, 2.4760864e-05f);
+  q = fmaf(q, r2, -0.0013888384f);
+  q = fmaf(q, r2, 0.041666638f);
+  q = fmaf(q, r2, -0.5f);
+  return fmaf(r2, q, 1.0f);
+}
+__device__ __forceinline__ float sin_acc(float x) {
+#ifdef ABL_CHEAP_PE
+  return x * 0.001f;
+#endif
+  unsigned sg;
+  const float r = pi_reduce(x, sg);
+  return __uint_as_float(__float_as_uint(sin_poly(r, r * r)) ^ sg);
+}
 __device__ __forceinline__ void sincos_acc(float x, float& s, float& c) {
-  const float n = rintf(x * 0.636619747f);
-  float r = fmaf(n, -1.5707964f, x);
-  r = fmaf(n, 4.371139e-08f, r);
-  r = fmaf(n, 1.7763568e-15f, r);
+#ifdef ABL_CHEAP_PE
+  s = x * 0.001f; c = 1.0f - x * 0.002f; return;
+#endif
+  unsigned sg;
+  const float r = pi_reduce(x, sg);
   const float r2 = r * r;
-  float p = fmaf(r2, 2.715026e-06f, -0.00019838927f);
-  p = fmaf(p, r2, 0.008333328f);
-  p = fmaf(p, r2, -0.16666667f);
-  const float sr = fmaf(r * r2, p, r);
-  float q = fmaf(r2, -2.720123e-07f, 2.4799407e-05f);
-  q = fmaf(q, r2, -0.0013888883f);
-  q = fmaf(q, r2, 0.041666668f);
-  const float cr = fmaf(r2 * r2, q, fmaf(-0.5f, r2, 1.0f));
-  const int qi = (int)n;
-  const float sv = (qi & 1) ? cr : sr;
-  const float cv = (qi & 1) ? sr : cr;
-  s = (qi & 2) ? -sv : sv;
-  c = ((qi + 1) & 2) ? -cv : cv;
+  s = __uint_as_float(__float_as_uint(sin_poly(r, r2)) ^ sg);
+  c = __uint_as_float(__float_as_uint(cos_poly(r2)) ^ sg);
 }
 
 __device__ __forceinline__ float sigmoid_acc(float x) { return 1.0f / (1.0f + expf(-x)); }

@@ -120,9 +120,7 @@ __global__ void embed_kernel(int K, long N, int n_freqs, const float* params, lo
     const float pj = fmaf(t2, B[3 * j + 2], fmaf(t1, B[3 * j + 1], t0 * B[3 * j]));
     for (int f = 0; f < n_freqs; ++f) {
       const float arg = (pj * (float)(1 << f)) * OBJ_PI_F;
-      float s, c;
-      sincos_acc(arg, s, c);
-      o[3 + f * OBJ_NDIR + j] = s;
+      o[3 + f * OBJ_NDIR + j] = sin_acc(arg);
     }
   }
 }

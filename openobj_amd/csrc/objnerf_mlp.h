@@ -218,9 +218,10 @@ __device__ __forceinline__ float pe_band(const Pe& pe, const int q0) {
   const int j0 = qq % OBJ_NDIR, f0 = qq / OBJ_NDIR - 1;
   const float sc = f0 < 0 ? 0.5f : (float)(1 << (f0 < 0 ? 0 : f0));
   const float arg = (pe.ps[j0] * sc) * OBJ_PI_F;
+  if (!WANT_COS) return sin_acc(arg);
   float sv, cv;
   sincos_acc(arg, sv, cv);
-  return WANT_COS ? (cv * OBJ_PI_F) * sc : sv;
+  return (cv * OBJ_PI_F) * sc;
 }
 
 // x1 tile T (0..5): entries e = 16 T + 4 g + r  (87 = constant 1, >= 88 zero)

@@ -74,13 +74,26 @@ __device__ __forceinline__ void store_T16(float* stg_lane, const int rowbase, co
   for (int r = 0; r < 4; ++r) stg_lane[(rowbase + r) * STG_LD] = v[r];
 }
 
-// D[out 0..31][in 16 cols] += sum_s dT[out][s] * aT[in][s] over the 128 staged samples
+// D[out 0..31][in 16 cols] += sum_s dT[out][s] * aT[in][s] over the 128 staged samples.
+// The contraction index is free to permute: MFMA k-slot (step st, lane group g) takes sample 32 g + st, so a
+// lane walks CONSECUTIVE samples and fetches two steps per ds_read_b64 (8-byte aligned with the 130-float
+// row stride; 2c + 32g + st covers all 64 banks -> conflict-free).  dT / aT point at &stg[(row0 + c) * LD + 32 g].
 __device__ __forceinline__ void wgrad_pair(f32x4& acc0, f32x4& acc1, const float* dT, const float* aT) {
+#ifdef ABL_NO_WGRAD
+  return;
+#endif
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  dT = (const float*)__builtin_assume_aligned(dT, 8);     // row pitch 520 B, 32 g and st even: 8-byte aligned
+  aT = (const float*)__builtin_assume_aligned(aT, 8);
 #pragma unroll 8
-  for (int st = 0; st < TS / 4; ++st) {
-    const float b = aT[4 * st];
-    acc0 = OBJ_MFMA(dT[4 * st], b, acc0);
-    acc1 = OBJ_MFMA(dT[16 * STG_LD + 4 * st], b, acc1);
+  for (int st = 0; st < 32; st += 2) {
+    const f32x2 b = *reinterpret_cast<const f32x2*>(aT + st);
+    const f32x2 a0 = *reinterpret_cast<const f32x2*>(dT + st);
+    const f32x2 a1 = *reinterpret_cast<const f32x2*>(dT + 16 * STG_LD + st);
+    acc0 = OBJ_MFMA(a0[0], b[0], acc0);
+    acc1 = OBJ_MFMA(a1[0], b[0], acc1);
+    acc0 = OBJ_MFMA(a0[1], b[1], acc0);
+    acc1 = OBJ_MFMA(a1[1], b[1], acc1);
   }
 }
 
@@ -138,7 +151,7 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
   const float* wt_fl = lds + OFF_FL + (4 * g) * ST_CL + c;
 
   float* stg_lane = stg + (4 * g) * STG_LD + 16 * w + c;
-  const float* lane_rd = stg + c * STG_LD + g;
+  const float* lane_rd = stg + c * STG_LD + 32 * g;
 
   const float* wt_in = lds + OFF_IN + (4 * g) * ST_IN + c;
   const float* wt_m1 = lds + OFF_M1 + (4 * g) * ST_M + c;
@@ -199,7 +212,11 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
     // ---------------------------------------------------------------- 2. composite + loss (loss.py:27-101)
     {
       const int rpp = 64 / S;                       // rays per wave pass
+#ifdef ABL_NO_COMPOSITE
+      const int npass = 0;
+#else
       const int npass = (TR + rpp - 1) / rpp;
+#endif
       for (int ps = w; ps < npass; ps += NWAVE) {
         const int ql = lane / S, pos = lane - ql * S;
         const int qq = ps * rpp + ql;

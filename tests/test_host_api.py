@@ -85,7 +85,13 @@ def _worker(rank, world, port, q):
     odist.global_flags(flags)
     terms = torch.full((2, 4), float(rank + 1))
     tot = odist.total_loss(terms)
-    q.put((rank, flags.tolist(), float(tot)))
+    # background network: rays split over ranks, mask counts and gradients SUM-reduced (train.BackgroundLoop)
+    lo, hi = odist.shard_rays(1200, world, rank)
+    counts = torch.tensor([[hi - lo, 7 * (rank + 1)]], dtype=torch.int32)
+    odist.allreduce_sum_(counts)
+    grads = torch.full((1, 8), float(rank + 1))
+    odist.allreduce_sum_(grads)
+    q.put((rank, flags.tolist(), float(tot), counts.tolist(), grads[0, 0].item()))
     dist.destroy_process_group()
 
 
@@ -101,6 +107,7 @@ def test_two_rank_flags_and_loss_gloo():
     for p in procs:
         p.join(60)
     expect = 2 * (1 + 5 + 10 + 5) * 1.0 + 2 * (1 + 5 + 10 + 5) * 2.0
-    for rank, flags, tot in res:
+    for rank, flags, tot, counts, g0 in res:
         assert flags == [1, 0]
         assert abs(tot - expect) < 1e-4
+        assert counts == [[1200, 21]] and g0 == 3.0
