@@ -25,9 +25,13 @@ struct Gemm {
   int splitk;      // > 1: blockIdx.z = batch * splitk + slice; each slice atomically adds its partial into C
 };
 
-constexpr int BM = 64, BN = 64, BK = 16;
+constexpr int BK = 16;
 
+// Workgroup tile (32*TM*2) x (32*TN*2): 4 waves as 2 x 2, each wave TM x TN MFMA tiles of 16 x 16.
+// <1,1> = 64 x 64 (small problems), <2,2> = 128 x 128 (the n x H x H layer GEMMs: 2 MFMAs per LDS read).
+template <int TM, int TN>
 __global__ __launch_bounds__(256) void gemm_kernel(const Gemm g) {
+  constexpr int BM = 32 * TM, BN = 32 * TN;      // (per wave 16*TM x 16*TN, workgroup 2 x 2 waves)
   __shared__ float As[BK][BM + 4];
   __shared__ float Bs[BK][BN + 4];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -42,49 +46,74 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Gemm g) {
   float* C = g.C + z * g.bsc;
   const int kper = ((g.Kd + sk - 1) / sk + BK - 1) / BK * BK;
   const int kbeg = slice * kper, kend = min(g.Kd, kbeg + kper);
-  f32x4 acc[2][2];
+  f32x4 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    // global -> LDS: 64 x 16 elements each, 4 per thread
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int NA = BM * BK / 256, NB = BN * BK / 256;
+  float ra[NA], rb[NB];
+  auto load_tiles = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NA; ++i) {
       const int e = tid + 256 * i;
-      // A tile: choose the faster-varying index by stride so loads coalesce for both layouts
       int am, ak;
-      if (g.sak == 1) { ak = e & 15; am = e >> 4; } else { am = e & 63; ak = e >> 6; }
+      if (g.sak == 1) { ak = e & 15; am = e >> 4; } else { am = e % BM; ak = e / BM; }
       const int gm = m0 + am, gk = k0 + ak;
-      As[ak][am] = (gm < g.M && gk < kend) ? A[gm * g.sam + gk * g.sak] : 0.f;
-      int bn, bk;
-      if (g.sbk == 1) { bk = e & 15; bn = e >> 4; } else { bn = e & 63; bk = e >> 6; }
-      const int gn = n0 + bn, gk2 = k0 + bk;
-      Bs[bk][bn] = (gn < g.N && gk2 < kend) ? B[gk2 * g.sbk + gn * g.sbn] : 0.f;
+      ra[i] = (gm < g.M && gk < kend) ? A[gm * g.sam + gk * g.sak] : 0.f;
     }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int e = tid + 256 * i;
+      int bn, bk;
+      if (g.sbk == 1) { bk = e & 15; bn = e >> 4; } else { bn = e % BN; bk = e / BN; }
+      const int gn = n0 + bn, gk2 = k0 + bk;
+      rb[i] = (gn < g.N && gk2 < kend) ? B[gk2 * g.sbk + gn * g.sbn] : 0.f;
+    }
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int e = tid + 256 * i;
+      int am, ak;
+      if (g.sak == 1) { ak = e & 15; am = e >> 4; } else { am = e % BM; ak = e / BM; }
+      As[ak][am] = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int e = tid + 256 * i;
+      int bn, bk;
+      if (g.sbk == 1) { bk = e & 15; bn = e >> 4; } else { bn = e % BN; bk = e / BN; }
+      Bs[bk][bn] = rb[i];
+    }
+  };
+  if (kbeg < kend) load_tiles(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    store_tiles();
     __syncthreads();
+    if (k0 + BK < kend) load_tiles(k0 + BK);       // next tile's global loads fly under the MFMAs
 #pragma unroll
     for (int ks = 0; ks < BK / 4; ++ks) {
-      float a[2], b[2];
+      float a[TM], b[TN];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = As[4 * ks + gg][32 * wm + 16 * i + c];
+      for (int i = 0; i < TM; ++i) a[i] = As[4 * ks + gg][16 * TM * wm + 16 * i + c];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = Bs[4 * ks + gg][32 * wn + 16 * j + c];
+      for (int j = 0; j < TN; ++j) b[j] = Bs[4 * ks + gg][16 * TN * wn + 16 * j + c];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
   }
   // epilogue: D layout: col n = lane & 15, row m = 4 * (lane >> 4) + r
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int m = m0 + 32 * wm + 16 * i + 4 * gg + r, n = n0 + 32 * wn + 16 * j + c;
+        const int m = m0 + 16 * TM * wm + 16 * i + 4 * gg + r, n = n0 + 16 * TN * wn + 16 * j + c;
         if (m < g.M && n < g.N) {
           float* cp = C + m * g.scm + n * g.scn;
           float v = acc[i][j][r];
@@ -109,16 +138,22 @@ static void gemm(hipStream_t st, int batch, int M, int N, int Kd, const float* A
   g.C = C; g.scm = scm; g.scn = scn; g.bsc = bsc;
   g.bias = bias; g.bsbias = bsbias; g.mask = mask; g.smm = smm; g.smn = smn; g.bsm = bsm;
   g.accumulate = accumulate; g.relu = relu; g.splitk = splitk;
-  dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, batch * (splitk > 1 ? splitk : 1));
-  hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), 0, st, g);
+  const int nz = batch * (splitk > 1 ? splitk : 1);
+  if (M >= 256 && N >= 96) {          // tall layer GEMMs: 128 x 128 tiles
+    dim3 grid((N + 127) / 128, (M + 127) / 128, nz);
+    hipLaunchKernelGGL((gemm_kernel<4, 4>), grid, dim3(256), 0, st, g);
+  } else {
+    dim3 grid((N + 63) / 64, (M + 63) / 64, nz);
+    hipLaunchKernelGGL((gemm_kernel<2, 2>), grid, dim3(256), 0, st, g);
+  }
 }
 
 // weight gradient: C[M][N] += sum over the n samples; few output tiles, long contraction -> split-K + atomics
 static void wgrad(hipStream_t st, int batch, int M, int N, long n, const float* A, long sam, long sak, long bsa,
                   const float* B, long sbk, long sbn, long bsb, float* C, long scm, long bsc) {
-  int sk = (int)((n + 2047) / 2048);
+  int sk = (int)((n + 511) / 512);
   if (sk < 1) sk = 1;
-  if (sk > 64) sk = 64;
+  if (sk > 256) sk = 256;
   gemm(st, batch, M, N, (int)n, A, sam, sak, bsa, B, sbk, sbn, bsb, C, scm, 1, bsc, false, nullptr, 0, false, nullptr, 0,
        0, 0, sk > 1 ? sk : 2);
 }

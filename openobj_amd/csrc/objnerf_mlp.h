@@ -367,10 +367,15 @@ struct Heads {
   float col[3];     // sigmoid applied (model.py:96)
 };
 
-__device__ __forceinline__ float xgroup_sum(float v) {   // sum over the 4 lane groups of a sample
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 32, 64);
-  return v;
+__device__ __forceinline__ float xgroup_sum(float v) {   // sum over the 4 lane groups of a sample, on the VALU
+  // v_permlane16_swap: odd 16-lane rows of the first operand <-> even rows of the second: with both = v the
+  // two results are (r0,r0,r2,r2) and (r1,r1,r3,r3); v_permlane32_swap likewise for the 32-lane halves.
+  const unsigned u = __float_as_uint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const float s16 = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const unsigned u2 = __float_as_uint(s16);
+  const auto b = __builtin_amdgcn_permlane32_swap(u2, u2, false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
 template <bool FEAT>

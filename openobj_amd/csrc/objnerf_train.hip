@@ -113,6 +113,12 @@ __device__ __forceinline__ void write_pair(float* slab, const f32x4& a0, const f
   }
 }
 
+#ifdef ABL_NO_BARRIER
+#define TILE_SYNC() do {} while (0)
+#else
+#define TILE_SYNC() __syncthreads()
+#endif
+
 // ------------------------------------------------------------------------------------------------
 template <bool FEAT>
 __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
@@ -208,7 +214,7 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
         else stg[OFF_GBUF + 32 * 33 + (i - 1024)] = v;
       }
     }
-    __syncthreads();
+    TILE_SYNC();
     // ---------------------------------------------------------------- 2. composite + loss (loss.py:27-101)
     {
       const int rpp = 64 / S;                       // rays per wave pass
@@ -340,7 +346,7 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
         }
       }
     }
-    __syncthreads();
+    TILE_SYNC();
     // ---------------------------------------------------------------- 3. backward
     const float da = valid ? s_alpha[slot] : 0.0f;
     const float dc0 = valid ? s_col[slot] : 0.0f;
@@ -407,18 +413,18 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
     T32 d_h3 = zero32();
     mma_bwd32<ST_M>(d_h3, wt_m2, 0, d_h4);
     d_h3 = relu_mask32(d_h3, act.h3);
-    __syncthreads();
+    TILE_SYNC();
     if (w < 7) {
       const int dTr = (w < 5) ? 128 : 160;
       const int aTr = (w < 5) ? 16 * w : 96 + 16 * (w - 5);
       wgrad_pair(accA0, accA1, lane_rd + dTr * STG_LD, lane_rd + aTr * STG_LD);
     }
-    __syncthreads();
+    TILE_SYNC();
     if (FEAT) {             // feature layer weight gradient: same inputs [h4 | x2], d_hf in place of d_hc
       store_T32(stg_lane, 128, d_hf);
-      __syncthreads();
+      TILE_SYNC();
       if (w < 5) wgrad_pair(accF0, accF1, lane_rd + 128 * STG_LD, lane_rd + (16 * w) * STG_LD);
-      __syncthreads();
+      TILE_SYNC();
     }
     // ---- phase B: cat layer.  [h2 | x1] rows 0..127, d_h3pre rows 128..
     store_T32(stg_lane, 0, act.h2);
@@ -465,7 +471,7 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
         if (g != 0) atomicAdd(&trow[row * STG_LD], v);
       }
     }
-    __syncthreads();
+    TILE_SYNC();
     {
       // d B[j][x] += sum_s dproj[j][s] * t[x][s]  (embedding.py:48): thread (p, q) takes 16 samples of pair p
       const int p = tid >> 3, qq = tid & 7;
@@ -479,18 +485,18 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
       }
       wgrad_pair(accB0, accB1, lane_rd + 128 * STG_LD, lane_rd + (16 * w) * STG_LD);
     }
-    __syncthreads();
+    TILE_SYNC();
     // ---- phase C: in layer (x1 stays at rows 32..127) + mid1.  h1 rows 0.., d_h1pre 128.., d_h2pre 160..
     store_T32(stg_lane, 0, act.h1);
     store_T32(stg_lane, 128, d_h1);
     store_T32(stg_lane, 160, d_h2);
-    __syncthreads();
+    TILE_SYNC();
     {
       const int dTr = (w < 6) ? 128 : 160;
       const int aTr = (w < 6) ? 32 + 16 * w : 16 * (w - 6);
       wgrad_pair(accC0, accC1, lane_rd + dTr * STG_LD, lane_rd + aTr * STG_LD);
     }
-    __syncthreads();
+    TILE_SYNC();
   }
 
   // ------------------------------------------------------------------ write this workgroup's slab
