@@ -33,6 +33,7 @@ from openobj_amd import init as obj_init  # noqa: E402
 from openobj_amd import ops, synthetic    # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA
 
 
 def flop_per_ray(S: int, H: int = 32, feat: bool = False) -> float:
@@ -86,6 +87,9 @@ def main():
                     help="skip the shared background network.  Default (do_bg = 1, room_0.json:21): every step also "
                          "trains it (hidden 128, n_per_optim_bg = 1200 rays split over the ranks, 64 samples/ray, "
                          "gradient all-reduce over RCCL), as train.py:447-463 does; `value` counts object rays only")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="f32 = the reference's arithmetic (default, the headline line).  bf16 = opt-in mode: MFMA "
+                         "operands rounded to bf16, fp32 accumulation / master weights / compositing / AdamW")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=192)
     args = ap.parse_args()
@@ -107,6 +111,7 @@ def main():
     arena = ops.ParamArena(K, ops.NetShape(), dev)
     arena.load_stacked(obj_init.init_stacked(K, 32, 512, seed=1000 + rank))
     feat = bool(args.feat)
+    bf16 = args.dtype == "bf16"
     ws = ops.TrainWorkspace(arena, K, R, S, feat)
     m = torch.zeros_like(arena.params)
     v = torch.zeros_like(arena.params)
@@ -142,9 +147,9 @@ def main():
                                                       gflags.data_ptr(), torch.cuda.current_stream().cuda_stream),
                        "label_counts")
             dist.all_reduce(gflags, op=dist.ReduceOp.MAX)
-            ops.train_step(arena, ws, b, global_flags=gflags, with_feat=feat)
+            ops.train_step(arena, ws, b, global_flags=gflags, with_feat=feat, bf16=bf16)
         else:
-            ops.train_step(arena, ws, b, with_feat=feat)
+            ops.train_step(arena, ws, b, with_feat=feat, bf16=bf16)
         step_no[0] += 1
         ops.adamw_step(arena, ws.grads, m, v, mask, step_no[0], 1e-3, 0.013)
         if bg_loop is not None:
@@ -176,7 +181,7 @@ def main():
     nk = max(5, min(args.steps, 20))
     ev0.record()
     for i in range(nk):
-        ops.train_step(arena, ws, batches[i & 1], with_feat=feat)
+        ops.train_step(arena, ws, batches[i & 1], with_feat=feat, bf16=bf16)
     ev1.record()
     torch.cuda.synchronize()
     kern_ms = ev0.elapsed_time(ev1) / nk
@@ -187,11 +192,13 @@ def main():
         value = rays_per_step * args.steps / dt
         fpr = flop_per_ray(S, feat=feat)
         achieved = K * R * fpr / (kern_ms * 1e-3) / 1e12
+        peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
+        kname = "train_fused_bf16_kernel" if bf16 else f"train_fused_kernel<{'true' if feat else 'false'}>"
         out = {
             "metric": "training rays/sec/GPU @64 samples/ray, 50 obj; PSNR delta vs ref",
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"Replica room_0-shaped, {K} object MLPs/GPU (hidden 32), {R} rays/object/step, "
                                    f"{S} samples/ray ({n1}+{n2}), RGB+depth+opacity"
                                    f"{'+512-d feature' if feat else ''} loss, fused fwd+loss+bwd+AdamW",
@@ -199,9 +206,9 @@ def main():
                        "feature_head": feat, "background_mlp": bool(args.bg), "parallelism": f"objects sharded x{world}",
                        "loss_status": status},
             "rays_per_sec_per_gpu": value / world,
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                         "kernel": f"train_fused_kernel<{'true' if feat else 'false'}>", "kernel_ms": kern_ms,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": None,
+                         "kernel": kname, "kernel_ms": kern_ms,
                          "flop_per_ray": fpr},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -182,8 +182,12 @@ int objnerf_label_counts(int32_t K, int32_t R, const uint8_t* labels, int32_t* c
  * left untouched), loss_terms [K][4], status [1].
  * workspace: objnerf_train_workspace_bytes() bytes, 256-byte aligned.
  */
+#define OBJNERF_TRAIN_BF16 1   /* mode bit: MFMA operands rounded to bf16 (fp32 accumulate, fp32 master weights,
+                                * fp32 embedding/compositing/losses).  NOT the reference's arithmetic (fp32,
+                                * train.py:74) -- an opt-in throughput mode gated by PSNR; hidden 32, S <= 64,
+                                * no feature loss, else OBJNERF_ENOTSUP. */
 typedef struct objnerf_train_args {
-  int32_t K, R, S, reserved;
+  int32_t K, R, S, mode;
   float color_scaling, opacity_scaling, feat_scaling, obj_center;
   const float* params; int64_t p_stride; const float* scale;
   const float* pts; const float* origins; const float* dirs; const float* z;

@@ -58,8 +58,11 @@ class LossArgs(C.Structure):
                 ("counts", C.c_void_p), ("status", C.c_void_p)]
 
 
+TRAIN_BF16 = 1       # objnerf_train_args.mode bit (OBJNERF_TRAIN_BF16)
+
+
 class TrainArgs(C.Structure):
-    _fields_ = [("K", C.c_int32), ("R", C.c_int32), ("S", C.c_int32), ("reserved", C.c_int32),
+    _fields_ = [("K", C.c_int32), ("R", C.c_int32), ("S", C.c_int32), ("mode", C.c_int32),
                 ("color_scaling", C.c_float), ("opacity_scaling", C.c_float),
                 ("feat_scaling", C.c_float), ("obj_center", C.c_float),
                 ("params", C.c_void_p), ("p_stride", C.c_int64), ("scale", C.c_void_p),

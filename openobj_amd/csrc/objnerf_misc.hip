@@ -481,7 +481,7 @@ int objnerf_label_counts(int32_t K, int32_t R, const uint8_t* labels, int32_t* c
                          void* stream) {
   CLEAR_STALE();
   if (K <= 0 || R <= 0 || !labels || !counts || !flags_out) return OBJNERF_EINVAL;
-  hipMemsetAsync(flags_out, 0, 2 * sizeof(int), (hipStream_t)stream);
+  (void)hipMemsetAsync(flags_out, 0, 2 * sizeof(int), (hipStream_t)stream);
   hipLaunchKernelGGL(label_counts_kernel, dim3(K), dim3(256), 0, (hipStream_t)stream, K, R, labels, counts, flags_out);
   CHECK_LAUNCH();
   return OBJNERF_OK;
@@ -496,15 +496,15 @@ int objnerf_step_batch_loss(const objnerf_loss_args* a, void* stream) {
   if (a->S > 2048) return OBJNERF_ENOTSUP;
   hipStream_t st = (hipStream_t)stream;
   int* flags = a->counts + 2 * a->K;     // counts workspace is [K][2] + [2]
-  hipMemsetAsync(flags, 0, 2 * sizeof(int), st);
+  (void)hipMemsetAsync(flags, 0, 2 * sizeof(int), st);
   if (a->counts_in) {
-    hipMemcpyAsync(a->counts, a->counts_in, (size_t)2 * a->K * sizeof(int), hipMemcpyDeviceToDevice, st);
+    (void)hipMemcpyAsync(a->counts, a->counts_in, (size_t)2 * a->K * sizeof(int), hipMemcpyDeviceToDevice, st);
     hipLaunchKernelGGL(flags_from_counts_kernel, dim3(1), dim3(64), 0, st, a->K, a->counts, flags);
   } else {
     hipLaunchKernelGGL(label_counts_kernel, dim3(a->K), dim3(256), 0, st, a->K, a->R, a->labels, a->counts, flags);
   }
   if (a->flags_in) hipLaunchKernelGGL(merge_flags_kernel, dim3(1), dim3(64), 0, st, flags, a->flags_in);
-  hipMemsetAsync(a->loss_terms, 0, (size_t)a->K * 4 * sizeof(float), st);
+  (void)hipMemsetAsync(a->loss_terms, 0, (size_t)a->K * 4 * sizeof(float), st);
   LossDev d;
   d.K = a->K; d.R = a->R; d.S = a->S; d.C = a->C;
   d.cs = a->color_scaling; d.os = a->opacity_scaling; d.fs = a->feat_scaling;
@@ -560,7 +560,7 @@ int objnerf_sample_rays(const objnerf_sample_args* a, void* stream) {
   // origins / dirs of the sampled rays live in the tail of the pts output until pass 2 consumes them:
   // pts has n*S*3 floats with S >= 2, pass 2 reads ray i's 6 floats before writing ray i's points.
   float* ws = a->max_depth_ws + 1;
-  hipMemsetAsync(a->max_depth_ws, 0, sizeof(float), st);
+  (void)hipMemsetAsync(a->max_depth_ws, 0, sizeof(float), st);
   hipLaunchKernelGGL(sample_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, st, *a, ws, ws + (size_t)n * 3);
   CHECK_LAUNCH();
   hipLaunchKernelGGL(sample_place_kernel, dim3((n + 255) / 256), dim3(256), 0, st, *a, ws, ws + (size_t)n * 3);

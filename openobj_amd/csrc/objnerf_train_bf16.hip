@@ -1,0 +1,562 @@
+// bf16-operand variant of the fused training iteration (OBJNERF_TRAIN_BF16): same tile structure as
+// objnerf_train.hip (8 waves x 16 samples, whole rays, register-resident activations, LDS transposes for
+// the weight gradients) but every contraction runs on v_mfma_f32_16x16x32_bf16 with fp32 accumulation.
+//
+// One MFMA consumes a whole 32-feature block: lane (c, g) supplies k-slots 8g..8g+7 = features
+// phi(g,e) = (e < 4 ? 4g + e : 16 + 4g + e - 4), i.e. exactly the 8 fp32 registers the lane holds of a
+// D16-layout activation block, packed to bf16.  Weight images in LDS are stored with that column
+// permutation (forward: [out][block][g][e]; transposed: [in][g][e]) so each A operand is ONE ds_read_b128;
+// row pitches are 32 B x odd (mod 256 B), which the 16-lane ds_read_b128 groups read conflict-free.
+// Master weights, embedding, activations, compositing, losses, gradient accumulators stay fp32; only MFMA
+// operands (weights, activations, staged transposes) are rounded to bf16 (round-to-nearest-even).
+// The reference is fp32-only (train.py:74 AMP = False): this path is gated by PSNR, not by 1e-4.
+#include "objnerf_train_common.h"
+#include "../../include/objnerf_hip.h"
+
+namespace objtrain {
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+// LDS byte layout
+constexpr int RS_IN = 224, RS_M = 96, RS_CAT = 288, RS_CL = 224;   // forward images, 32 rows each
+constexpr int RST = 96;                                            // transposed images: 64 B of outs per input row
+constexpr int B_IN = 0;
+constexpr int B_M1 = B_IN + 32 * RS_IN;
+constexpr int B_CAT = B_M1 + 32 * RS_M;
+constexpr int B_M2 = B_CAT + 32 * RS_CAT;
+constexpr int B_CL = B_M2 + 32 * RS_M;
+constexpr int T_IN = B_CL + 32 * RS_CL;       // 96 rows
+constexpr int T_M1 = T_IN + 96 * RST;         // 32 rows
+constexpr int T_CAT = T_M1 + 32 * RST;        // 128 rows: h2 (32) | x1 (96)
+constexpr int T_M2 = T_CAT + 128 * RST;       // 32 rows
+constexpr int T_CL = T_M2 + 32 * RST;         // 80 rows:  h4 (32) | x2 (48)
+constexpr int B_SMALL = T_CL + 80 * RST;      // fp32: bm1[32] bm2[32] wa[32] woc[96] hb[4] peb[99]
+constexpr int S_BM1 = 0, S_BM2 = 32, S_WA = 64, S_WOC = 96, S_HB = 192, S_PEB = 196;
+constexpr int B_SM = B_SMALL + 1280;          // s_alpha | s_col[3]  (fp32, 2 KB)
+constexpr int TB_LD = 130;
+constexpr int B_TBUF = B_SM + 2048;           // fp32 [24][130]: d proj rows 0..20, t rows 21..23
+constexpr int STG_PITCH = 288;                // bf16 staging row: 128 samples + pad
+constexpr int B_STG = B_TBUF + 24 * TB_LD * 4;
+constexpr int LDS_BYTES = B_STG + STG_ROWS * STG_PITCH;
+static_assert(B_SMALL % 16 == 0 && B_STG % 16 == 0 && LDS_BYTES <= 163840, "bf16 lds layout");
+
+__device__ __forceinline__ int phi(int g, int e) { return e < 4 ? 4 * g + e : 16 + 4 * g + e - 4; }
+
+// value of layer weight (out i, input feature f), bias riding on the constant-1 embedding row
+__device__ __forceinline__ float w_in(const float* P, const Layout& L, int i, int f) {
+  return f < OBJ_E1 ? P[L.in_w + i * OBJ_E1 + f] : (f == OBJ_E1 ? P[L.in_b + i] : 0.f);
+}
+__device__ __forceinline__ float w_cat(const float* P, const Layout& L, int i, int f) {
+  if (f < H) return P[L.cat_w + i * (H + OBJ_E1) + f];
+  const int f2 = f - H;
+  return f2 < OBJ_E1 ? P[L.cat_w + i * (H + OBJ_E1) + H + f2] : (f2 == OBJ_E1 ? P[L.cat_b + i] : 0.f);
+}
+__device__ __forceinline__ float w_cl(const float* P, const Layout& L, int i, int f) {
+  if (f < H) return P[L.cl_w + i * (H + OBJ_E2) + f];
+  const int f2 = f - H;
+  return f2 < OBJ_E2 ? P[L.cl_w + i * (H + OBJ_E2) + H + f2] : (f2 == OBJ_E2 ? P[L.cl_b + i] : 0.f);
+}
+
+__device__ __forceinline__ void stage_weights_bf16(char* lds, const float* __restrict__ P, const Layout& L, int tid) {
+  __bf16* img = reinterpret_cast<__bf16*>(lds);
+  // forward images: element (i, b, g, e) <- W[i][32 b + phi(g, e)]
+  for (int x = tid; x < 32 * 3 * 32; x += NTHR) {
+    const int i = x / 96, rem = x % 96, b = rem >> 5, ge = rem & 31;
+    const int f = 32 * b + phi(ge >> 3, ge & 7);
+    img[(B_IN + i * RS_IN) / 2 + rem] = (__bf16)w_in(P, L, i, f);
+    img[(B_CL + i * RS_CL) / 2 + rem] = (__bf16)w_cl(P, L, i, f);
+  }
+  for (int x = tid; x < 32 * 4 * 32; x += NTHR) {
+    const int i = x >> 7, rem = x & 127, b = rem >> 5, ge = rem & 31;
+    img[(B_CAT + i * RS_CAT) / 2 + rem] = (__bf16)w_cat(P, L, i, 32 * b + phi(ge >> 3, ge & 7));
+  }
+  for (int x = tid; x < 32 * 32; x += NTHR) {
+    const int i = x >> 5, ge = x & 31;
+    const int f = phi(ge >> 3, ge & 7);
+    img[(B_M1 + i * RS_M) / 2 + ge] = (__bf16)P[L.m1_w + i * H + f];
+    img[(B_M2 + i * RS_M) / 2 + ge] = (__bf16)P[L.m2_w + i * H + f];
+  }
+  // transposed images: element (f, g, e) <- W[phi(g, e)][f]
+  for (int x = tid; x < 128 * 32; x += NTHR) {
+    const int f = x >> 5, ge = x & 31, o = phi(ge >> 3, ge & 7);
+    img[(T_CAT + f * RST) / 2 + ge] = (__bf16)w_cat(P, L, o, f);
+    if (f < 96) img[(T_IN + f * RST) / 2 + ge] = (__bf16)w_in(P, L, o, f);
+    if (f < 80) img[(T_CL + f * RST) / 2 + ge] = (__bf16)w_cl(P, L, o, f);
+    if (f < 32) {
+      img[(T_M1 + f * RST) / 2 + ge] = (__bf16)P[L.m1_w + o * H + f];
+      img[(T_M2 + f * RST) / 2 + ge] = (__bf16)P[L.m2_w + o * H + f];
+    }
+  }
+  float* sm = reinterpret_cast<float*>(lds + B_SMALL);
+  for (int i = tid; i < H; i += NTHR) {
+    sm[S_BM1 + i] = P[L.m1_b + i];
+    sm[S_BM2 + i] = P[L.m2_b + i];
+    sm[S_WA + i] = P[L.a_w + i];
+  }
+  for (int i = tid; i < 3 * H; i += NTHR) sm[S_WOC + i] = P[L.oc_w + i];
+  if (tid == 0) sm[S_HB] = P[L.a_b];
+  if (tid < 3) sm[S_HB + 1 + tid] = P[L.oc_b + tid];
+  for (int i = tid; i < 33 * 3; i += NTHR) sm[S_PEB + i] = P[L.pe_b + ((i / 3) % OBJ_NDIR) * 3 + (i % 3)];
+}
+
+__device__ __forceinline__ bf16x8 pack8(const f32x4& lo, const f32x4& hi) {
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    o[e] = (__bf16)lo[e];
+    o[4 + e] = (__bf16)hi[e];
+  }
+  return o;
+}
+__device__ __forceinline__ bf16x8 pack32(const T32& x) { return pack8(x.t[0], x.t[1]); }
+
+// acc (32 outs) += W[:, block] * x        img_lane = lds + B_X + c * RS + 16 g
+template <int RS>
+__device__ __forceinline__ void fwd_blk(T32& acc, const char* img_lane, const int blk, const bf16x8 xb) {
+  const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(img_lane + 64 * blk);
+  const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(img_lane + 16 * RS + 64 * blk);
+  acc.t[0] = MFMA_BF16(a0, xb, acc.t[0]);
+  acc.t[1] = MFMA_BF16(a1, xb, acc.t[1]);
+}
+// acc (input rows 16 ti .. +15 of the transposed image) += W^T d      timg_lane = lds + T_X + c * RST + 16 g
+__device__ __forceinline__ void bwd_tile(f32x4& acc, const char* timg_lane, const int row0, const bf16x8 db) {
+  const bf16x8 a = *reinterpret_cast<const bf16x8*>(timg_lane + row0 * RST);
+  acc = MFMA_BF16(a, db, acc);
+}
+
+__device__ __forceinline__ void pe_project_b(const float* sm, const int g, const float px, const float py,
+                                             const float pz, const float scale, Pe& pe) {
+  pe.t[0] = px / scale;
+  pe.t[1] = py / scale;
+  pe.t[2] = pz / scale;
+  const float* bl = sm + S_PEB + 12 * g;
+#pragma unroll
+  for (int i = 0; i < OBJ_NDIR; ++i) {
+    const float p = fmaf(pe.t[2], bl[3 * i + 2], fmaf(pe.t[1], bl[3 * i + 1], pe.t[0] * bl[3 * i]));
+    pe.ps[i] = (i > 8 && 4 * g + i >= OBJ_NDIR) ? 2.0f * p : p;
+  }
+}
+
+__device__ __forceinline__ void store32_b(char* stg_lane, const int rowbase, const T32& v) {
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      *reinterpret_cast<__bf16*>(stg_lane + (rowbase + 16 * tt + r) * STG_PITCH) = (__bf16)v.t[tt][r];
+}
+__device__ __forceinline__ void store16_b(char* stg_lane, const int rowbase, const f32x4& v) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) *reinterpret_cast<__bf16*>(stg_lane + (rowbase + r) * STG_PITCH) = (__bf16)v[r];
+}
+
+// D[out 0..31][in 16 cols] += sum over the 128 staged samples; k-slot (step, g, e) = sample 32 step + 8 g + e
+__device__ __forceinline__ void wgrad_pair_b(f32x4& acc0, f32x4& acc1, const char* dT, const char* aT) {
+#pragma unroll
+  for (int st = 0; st < 4; ++st) {
+    const bf16x8 b = *reinterpret_cast<const bf16x8*>(aT + 64 * st);
+    const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(dT + 64 * st);
+    const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(dT + 16 * STG_PITCH + 64 * st);
+    acc0 = MFMA_BF16(a0, b, acc0);
+    acc1 = MFMA_BF16(a1, b, acc1);
+  }
+}
+
+__device__ __forceinline__ void write_pair_b(float* slab, const f32x4& a0, const f32x4& a1, const int c, const int g,
+                                             const int ct, const int w_off, const int ncols, const int b_off) {
+  const int col = 16 * ct + c;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int o0 = 4 * g + r, o1 = 16 + 4 * g + r;
+    if (col < ncols) {
+      slab[w_off + o0 * ncols + col] = a0[r];
+      slab[w_off + o1 * ncols + col] = a1[r];
+    } else if (col == ncols && b_off >= 0) {
+      slab[b_off + o0] = a0[r];
+      slab[b_off + o1] = a1[r];
+    }
+  }
+}
+
+__global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a) {
+  extern __shared__ __attribute__((aligned(16))) char ldsb[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  const int k = blockIdx.x / a.G, gi = blockIdx.x % a.G;
+  const float* sm = reinterpret_cast<const float*>(ldsb + B_SMALL);
+  float* s_alpha = reinterpret_cast<float*>(ldsb + B_SM);
+  float* s_col = s_alpha + TS;
+  float* tbuf = reinterpret_cast<float*>(ldsb + B_TBUF);
+  char* stg = ldsb + B_STG;
+
+  for (int i = tid; i < LDS_BYTES / 4; i += NTHR) reinterpret_cast<float*>(ldsb)[i] = 0.0f;
+  __syncthreads();
+  stage_weights_bf16(ldsb, a.params + (long)k * a.p_stride, a.L, tid);
+  __syncthreads();
+
+  const float scale = a.scale[k];
+  const int S = a.S, R = a.R, TR = a.TR;
+  const float n1 = (float)a.counts[2 * k], n2 = (float)a.counts[2 * k + 1];
+  const float inv1 = a.flags[0] ? 0.0f : 1.0f / (n1 + 1e-10f);
+  const float inv2 = a.flags[1] ? 0.0f : 1.0f / (n2 + 1e-10f);
+
+  f32x4 accA0 = zero4(), accA1 = zero4(), accB0 = zero4(), accB1 = zero4(), accC0 = zero4(), accC1 = zero4();
+  float gS0 = 0.f, gS1 = 0.f, gS2 = 0.f;
+  float g_ba = 0.f, g_boc0 = 0.f, g_boc1 = 0.f, g_boc2 = 0.f;
+  float g_dB = 0.f;
+  float l_d = 0.f, l_c = 0.f, l_o = 0.f;
+
+  char* stg_lane = stg + (4 * g) * STG_PITCH + (16 * w + c) * 2;
+  const char* lane_rd = stg + c * STG_PITCH + 16 * g;
+  const char* f_in = ldsb + B_IN + c * RS_IN + 16 * g;
+  const char* f_m1 = ldsb + B_M1 + c * RS_M + 16 * g;
+  const char* f_cat = ldsb + B_CAT + c * RS_CAT + 16 * g;
+  const char* f_m2 = ldsb + B_M2 + c * RS_M + 16 * g;
+  const char* f_cl = ldsb + B_CL + c * RS_CL + 16 * g;
+  const char* t_in = ldsb + T_IN + c * RST + 16 * g;
+  const char* t_m1 = ldsb + T_M1 + c * RST + 16 * g;
+  const char* t_cat = ldsb + T_CAT + c * RST + 16 * g;
+  const char* t_m2 = ldsb + T_M2 + c * RST + 16 * g;
+  const char* t_cl = ldsb + T_CL + c * RST + 16 * g;
+
+  for (int tile = gi; tile < a.NT; tile += a.G) {
+    asm volatile("" ::: "memory");
+    const int ray0 = tile * TR;
+    // ---------------------------------------------------------------- 1. forward
+    const int slot = 16 * w + c;
+    const int q = slot / S, si = slot - q * S;
+    const int ray = ray0 + q;
+    const bool valid = (q < TR) && (ray < R);
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if (valid) {
+      const long rr = (long)k * R + ray;
+      if (a.pts) {
+        const float* p = a.pts + (rr * S + si) * 3;
+        px = p[0]; py = p[1]; pz = p[2];
+      } else {
+        const float zz = a.z[rr * S + si];
+        const float* o = a.origins + rr * 3;
+        const float* d = a.dirs + rr * 3;
+        px = (o[0] + d[0] * zz) - a.obj_center;
+        py = (o[1] + d[1] * zz) - a.obj_center;
+        pz = (o[2] + d[2] * zz) - a.obj_center;
+      }
+    }
+    Pe pe;
+    pe_project_b(sm, g, px, py, pz, scale, pe);
+    T32 h1, h2, h3, h4, hc;
+    float alpha_v, col_v[3];
+    {
+      bf16x8 xb1[3], xb2[2];
+#pragma unroll
+      for (int b = 0; b < 3; ++b) xb1[b] = pack8(pe_x1_tile(pe, 2 * b, g), pe_x1_tile(pe, 2 * b + 1, g));
+      xb2[0] = pack8(pe_x2_tile(pe, 0, g), pe_x2_tile(pe, 1, g));
+      xb2[1] = pack8(pe_x2_tile(pe, 2, g), zero4());
+      T32 acc = zero32();
+#pragma unroll
+      for (int b = 0; b < 3; ++b) fwd_blk<RS_IN>(acc, f_in, b, xb1[b]);
+      h1 = relu32(acc);
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc.t[tt][r] = sm[S_BM1 + 16 * tt + 4 * g + r];
+      fwd_blk<RS_M>(acc, f_m1, 0, pack32(h1));
+      h2 = relu32(acc);
+      acc = zero32();
+      fwd_blk<RS_CAT>(acc, f_cat, 0, pack32(h2));
+#pragma unroll
+      for (int b = 0; b < 3; ++b) fwd_blk<RS_CAT>(acc, f_cat, 1 + b, xb1[b]);
+      h3 = relu32(acc);
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc.t[tt][r] = sm[S_BM2 + 16 * tt + 4 * g + r];
+      fwd_blk<RS_M>(acc, f_m2, 0, pack32(h3));
+      h4 = relu32(acc);
+      acc = zero32();
+      fwd_blk<RS_CL>(acc, f_cl, 0, pack32(h4));
+      fwd_blk<RS_CL>(acc, f_cl, 1, xb2[0]);
+      fwd_blk<RS_CL>(acc, f_cl, 2, xb2[1]);
+      hc = relu32(acc);
+      float pa = 0.f, pc0 = 0.f, pc1 = 0.f, pc2 = 0.f;
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * tt + 4 * g + r;
+          pa = fmaf(sm[S_WA + row], h4.t[tt][r], pa);
+          pc0 = fmaf(sm[S_WOC + row], hc.t[tt][r], pc0);
+          pc1 = fmaf(sm[S_WOC + H + row], hc.t[tt][r], pc1);
+          pc2 = fmaf(sm[S_WOC + 2 * H + row], hc.t[tt][r], pc2);
+        }
+      alpha_v = (xgroup_sum(pa) + sm[S_HB]) * 10.0f;
+      col_v[0] = sigmoid_acc(xgroup_sum(pc0) + sm[S_HB + 1]);
+      col_v[1] = sigmoid_acc(xgroup_sum(pc1) + sm[S_HB + 2]);
+      col_v[2] = sigmoid_acc(xgroup_sum(pc2) + sm[S_HB + 3]);
+    }
+    if (g == 0) {
+      s_alpha[slot] = alpha_v;
+      s_col[slot] = col_v[0];
+      s_col[TS + slot] = col_v[1];
+      s_col[2 * TS + slot] = col_v[2];
+    }
+    __syncthreads();
+    // ---------------------------------------------------------------- 2. composite + loss (fp32, as objnerf_train.hip)
+    {
+      const int rpp = 64 / S;
+      const int npass = (TR + rpp - 1) / rpp;
+      for (int ps = w; ps < npass; ps += NWAVE) {
+        const int ql = lane / S, pos = lane - ql * S;
+        const int qq = ps * rpp + ql;
+        const int rayq = ray0 + qq;
+        const bool on = (ql < rpp) && (qq < TR) && (rayq < R);
+        const int sl = qq * S + pos;
+        float al = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, zz = 0.f;
+        float gtd = 0.f, gr = 0.f, gg = 0.f, gb = 0.f;
+        int lab = 2;
+        if (on) {
+          const long rr = (long)k * R + rayq;
+          al = s_alpha[sl]; c0 = s_col[sl]; c1 = s_col[TS + sl]; c2 = s_col[2 * TS + sl];
+          zz = a.z[rr * S + pos];
+          gtd = a.gt_depth[rr];
+          gr = a.gt_rgb[rr * 3]; gg = a.gt_rgb[rr * 3 + 1]; gb = a.gt_rgb[rr * 3 + 2];
+          lab = a.labels[rr];
+        }
+        const float occ = on ? sigmoid_acc(al) : 0.0f;
+        const float fr = on ? (1.0f - occ) + 1e-10f : 1.0f;
+        const float Pinc = seg_scan_mul(fr, pos, S);
+        float T = __shfl_up(Pinc, 1, 64);
+        if (pos == 0) T = 1.0f;
+        const float wgt = occ * T;
+        const int last = lane - pos + S - 1;
+        const float D = __shfl(seg_scan_add(wgt * zz, pos, S), last, 64);
+        const float O = __shfl(seg_scan_add(wgt, pos, S), last, 64);
+        const float C0 = __shfl(seg_scan_add(wgt * c0, pos, S), last, 64);
+        const float C1 = __shfl(seg_scan_add(wgt * c1, pos, S), last, 64);
+        const float C2 = __shfl(seg_scan_add(wgt * c2, pos, S), last, 64);
+        const float dz = zz - D;
+        const float V = __shfl(seg_scan_add(wgt * (dz * dz), pos, S), last, 64);
+        const float m1 = (lab == 1) ? 1.0f : 0.0f;
+        const float m2 = (lab != 2) ? 1.0f : 0.0f;
+        const float tgt = (lab != 0) ? 1.0f : 0.0f;
+        const float info = 1.0f / (sqrtf(V) + 1e-4f);
+        const float rd = D - gtd, r0 = C0 - gr, r1 = C1 - gg, r2 = C2 - gb, ro = O - tgt;
+        auto sgn = [](float x) { return x > 0.f ? 1.0f : (x < 0.f ? -1.0f : 0.0f); };
+        const float gD = m1 * sgn(rd) * info * inv1;
+        const float gC0 = a.color_scaling * m1 * sgn(r0) * inv1;
+        const float gC1 = a.color_scaling * m1 * sgn(r1) * inv1;
+        const float gC2 = a.color_scaling * m1 * sgn(r2) * inv1;
+        const float gO = a.opacity_scaling * m2 * sgn(ro) * inv2;
+        if (on && pos == 0) {
+          l_d += m1 * fabsf(rd) * info * inv1;
+          l_c += m1 * (fabsf(r0) + fabsf(r1) + fabsf(r2)) * inv1;
+          l_o += m2 * fabsf(ro) * inv2;
+        }
+        const float dw = gD * zz + gO + gC0 * c0 + gC1 * c1 + gC2 * c2;
+        const float qv = dw * wgt;
+        const float suf = seg_rscan_add(qv, pos, S) - qv;
+        const float docc = dw * T - suf / fr;
+        if (on) {
+          s_alpha[sl] = 10.0f * (docc * occ * (1.0f - occ));
+          s_col[sl] = gC0 * wgt * c0 * (1.0f - c0);
+          s_col[TS + sl] = gC1 * wgt * c1 * (1.0f - c1);
+          s_col[2 * TS + sl] = gC2 * wgt * c2 * (1.0f - c2);
+        }
+      }
+    }
+    __syncthreads();
+    // ---------------------------------------------------------------- 3. backward
+    const float da = valid ? s_alpha[slot] : 0.0f;
+    const float dc0 = valid ? s_col[slot] : 0.0f;
+    const float dc1 = valid ? s_col[TS + slot] : 0.0f;
+    const float dc2 = valid ? s_col[2 * TS + slot] : 0.0f;
+    if (g == 0) { g_ba += da; g_boc0 += dc0; g_boc1 += dc1; g_boc2 += dc2; }
+#pragma unroll
+    for (int j = 0; j < OBJ_NDIR; ++j) asm volatile("" : "+v"(pe.ps[j]));
+    float dps[OBJ_NDIR];
+#pragma unroll
+    for (int j = 0; j < OBJ_NDIR; ++j) dps[j] = 0.f;
+
+    // ---- phase A
+    T32 d_hc, d_h4;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * tt + 4 * g + r;
+        const int s = 4 * tt + r;
+        const float hv = hc.t[tt][r];
+        slot_accum16(gS0, da * h4.t[tt][r], s, c);
+        slot_accum16(gS0, dc0 * hv, 8 + s, c);
+        slot_accum16(gS1, dc1 * hv, s, c);
+        slot_accum16(gS1, dc2 * hv, 8 + s, c);
+        const float dv = fmaf(sm[S_WOC + 2 * H + row], dc2, fmaf(sm[S_WOC + H + row], dc1, sm[S_WOC + row] * dc0));
+        d_hc.t[tt][r] = hv > 0.0f ? dv : 0.0f;
+        d_h4.t[tt][r] = sm[S_WA + row] * da;
+      }
+    store32_b(stg_lane, 0, h4);
+    store32_b(stg_lane, 96, h3);
+    store32_b(stg_lane, 128, d_hc);
+    const bf16x8 d_hc_b = pack32(d_hc);
+    bwd_tile(d_h4.t[0], t_cl, 0, d_hc_b);
+    bwd_tile(d_h4.t[1], t_cl, 16, d_hc_b);
+    d_h4 = relu_mask32(d_h4, h4);
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) slot_accum16(gS2, d_h4.t[tt][r], 8 + 4 * tt + r, c);
+    store32_b(stg_lane, 160, d_h4);
+#pragma unroll
+    for (int T = 0; T < 3; ++T) {
+      f32x4 d_x = zero4();
+      bwd_tile(d_x, t_cl, 32 + 16 * T, d_hc_b);
+      store16_b(stg_lane, 32 + 16 * T, pe_x2_tile_fb(pe, T, g, d_x, dps));
+    }
+    const bf16x8 d_h4_b = pack32(d_h4);
+    T32 d_h3 = zero32();
+    bwd_tile(d_h3.t[0], t_m2, 0, d_h4_b);
+    bwd_tile(d_h3.t[1], t_m2, 16, d_h4_b);
+    d_h3 = relu_mask32(d_h3, h3);
+    __syncthreads();
+    if (w < 7) {
+      const int dTr = (w < 5) ? 128 : 160;
+      const int aTr = (w < 5) ? 16 * w : 96 + 16 * (w - 5);
+      wgrad_pair_b(accA0, accA1, lane_rd + dTr * STG_PITCH, lane_rd + aTr * STG_PITCH);
+    }
+    __syncthreads();
+    // ---- phase B
+    store32_b(stg_lane, 0, h2);
+    store32_b(stg_lane, 128, d_h3);
+    const bf16x8 d_h3_b = pack32(d_h3);
+    T32 d_h2 = zero32();
+    bwd_tile(d_h2.t[0], t_cat, 0, d_h3_b);
+    bwd_tile(d_h2.t[1], t_cat, 16, d_h3_b);
+    d_h2 = relu_mask32(d_h2, h2);
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) slot_accum16(gS2, d_h2.t[tt][r], 4 * tt + r, c);
+    const bf16x8 d_h2_b = pack32(d_h2);
+    T32 d_h1 = zero32();
+    bwd_tile(d_h1.t[0], t_m1, 0, d_h2_b);
+    bwd_tile(d_h1.t[1], t_m1, 16, d_h2_b);
+    d_h1 = relu_mask32(d_h1, h1);
+    const bf16x8 d_h1_b = pack32(d_h1);
+#pragma unroll
+    for (int T = 0; T < 6; ++T) {
+      f32x4 d_x = zero4();
+      bwd_tile(d_x, t_cat, 32 + 16 * T, d_h3_b);
+      bwd_tile(d_x, t_in, 16 * T, d_h1_b);
+      store16_b(stg_lane, 32 + 16 * T, pe_x1_tile_fb(pe, T, g, d_x, dps));
+    }
+    {
+      float* trow = tbuf + 16 * w + c;
+#pragma unroll
+      for (int i = 0; i < OBJ_NDIR; ++i) {
+        const int wrap = (i > 8 && 4 * g + i >= OBJ_NDIR);
+        const int row = 4 * g + i - (wrap ? OBJ_NDIR : 0);
+        const float v = wrap ? 2.0f * dps[i] : dps[i];
+        if (g == 0) trow[row * TB_LD] = v;
+      }
+      if (g == 0) {
+        trow[21 * TB_LD] = pe.t[0];
+        trow[22 * TB_LD] = pe.t[1];
+        trow[23 * TB_LD] = pe.t[2];
+      }
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < OBJ_NDIR; ++i) {
+        const int wrap = (i > 8 && 4 * g + i >= OBJ_NDIR);
+        const int row = 4 * g + i - (wrap ? OBJ_NDIR : 0);
+        const float v = wrap ? 2.0f * dps[i] : dps[i];
+        if (g != 0) atomicAdd(&trow[row * TB_LD], v);
+      }
+    }
+    __syncthreads();
+    {
+      const int p = tid >> 3, qq = tid & 7;
+      if (p < 3 * OBJ_NDIR) {
+        const float* tp = tbuf + (p / 3) * TB_LD + 16 * qq;
+        const float* xp = tbuf + (21 + p % 3) * TB_LD + 16 * qq;
+        float acc = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc = fmaf(tp[s], xp[s], acc);
+        g_dB += acc;
+      }
+      wgrad_pair_b(accB0, accB1, lane_rd + 128 * STG_PITCH, lane_rd + (16 * w) * STG_PITCH);
+    }
+    __syncthreads();
+    // ---- phase C
+    store32_b(stg_lane, 0, h1);
+    store32_b(stg_lane, 128, d_h1);
+    store32_b(stg_lane, 160, d_h2);
+    __syncthreads();
+    {
+      const int dTr = (w < 6) ? 128 : 160;
+      const int aTr = (w < 6) ? 32 + 16 * w : 16 * (w - 6);
+      wgrad_pair_b(accC0, accC1, lane_rd + dTr * STG_PITCH, lane_rd + aTr * STG_PITCH);
+    }
+    __syncthreads();
+  }
+
+  float* slab = a.slab + ((long)k * a.G + gi) * a.slab_stride;
+  const Layout& L = a.L;
+  if (w < 5) write_pair_b(slab, accA0, accA1, c, g, w, L.cl_w, H + OBJ_E2, L.cl_b);
+  else if (w < 7) write_pair_b(slab, accA0, accA1, c, g, w - 5, L.m2_w, H, -1);
+  write_pair_b(slab, accB0, accB1, c, g, w, L.cat_w, H + OBJ_E1, L.cat_b);
+  if (w < 6) write_pair_b(slab, accC0, accC1, c, g, w, L.in_w, OBJ_E1, L.in_b);
+  else write_pair_b(slab, accC0, accC1, c, g, w - 6, L.m1_w, H, -1);
+  {
+    float v = g_dB;
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    const int p = tid >> 3;
+    if ((tid & 7) == 0 && p < 3 * OBJ_NDIR) slab[L.pe_b + p] = v;
+  }
+  float* red = reinterpret_cast<float*>(stg);   // [NWAVE][NRED]
+  {
+    float* mine = red + w * NRED;
+    const int s = c & 7;
+    const int row = 16 * (s >> 2) + 4 * g + (s & 3);
+    if (c < 8) { mine[64 + row] = gS0; mine[128 + row] = gS1; mine[row] = gS2; }
+    else { mine[96 + row] = gS0; mine[160 + row] = gS1; mine[32 + row] = gS2; }
+    const float s0 = wave_sum64(g_ba), s1 = wave_sum64(g_boc0), s2 = wave_sum64(g_boc1), s3 = wave_sum64(g_boc2);
+    if (lane == 0) { mine[192] = s0; mine[193] = s1; mine[194] = s2; mine[195] = s3; }
+    const float e0 = wave_sum64(l_d), e1 = wave_sum64(l_c), e2 = wave_sum64(l_o);
+    if (lane == 0) { mine[196] = e0; mine[197] = e1; mine[198] = e2; mine[199] = 0.0f; }
+  }
+  __syncthreads();
+  for (int i = tid; i < NRED; i += NTHR) {
+    float v = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < NWAVE; ++ww) v += red[ww * NRED + i];
+    if (i < 32) slab[L.m1_b + i] = v;
+    else if (i < 64) slab[L.m2_b + i - 32] = v;
+    else if (i < 96) slab[L.a_w + i - 64] = v;
+    else if (i < 192) slab[L.oc_w + i - 96] = v;
+    else if (i == 192) slab[L.a_b] = v;
+    else if (i < 196) slab[L.oc_b + i - 193] = v;
+    else a.loss_part[((long)k * a.G + gi) * 4 + (i - 196)] = v;
+  }
+}
+
+}  // namespace
+
+size_t bf16_lds_bytes() { return LDS_BYTES; }
+
+void launch_train_bf16(const TrainDev& d, void* stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)train_fused_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              LDS_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(train_fused_bf16_kernel, dim3(d.K * d.G), dim3(NTHR), LDS_BYTES, (hipStream_t)stream, d);
+}
+
+}  // namespace objtrain

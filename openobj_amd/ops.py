@@ -252,8 +252,12 @@ class TrainWorkspace:
 
 def train_step(arena: ParamArena, ws: TrainWorkspace, batch: Dict[str, torch.Tensor], color_scaling=5.0,
                opacity_scaling=10.0, feat_scaling=5.0, with_feat=False, obj_center=0.0,
-               global_flags: Optional[torch.Tensor] = None, global_counts: Optional[torch.Tensor] = None) -> None:
+               global_flags: Optional[torch.Tensor] = None, global_counts: Optional[torch.Tensor] = None,
+               bf16: bool = False) -> None:
     """One fused iteration (train.py:424-472): fills ws.grads, ws.loss_terms, ws.status.
+
+    bf16: opt-in OBJNERF_TRAIN_BF16 mode (bf16 MFMA operands, fp32 accumulate / master weights); the default
+    is the reference's fp32 arithmetic.
 
     batch: pts [K,R,S,3] (or origins+dirs), z, gt_depth, gt_rgb, labels u8 (+ gt_feat when with_feat).
     global_flags: optional [2] int32 tensor already max-reduced over all ranks (object sharding)."""
@@ -277,7 +281,7 @@ def train_step(arena: ParamArena, ws: TrainWorkspace, batch: Dict[str, torch.Ten
     if global_counts is not None:       # one object's rays split over ranks (background): global mask counts
         counts = _req(global_counts, torch.int32, "global_counts")
     net = arena.net.c()
-    a = TrainArgs(K, R, S, 0, color_scaling, opacity_scaling, feat_scaling, obj_center, _ptr(arena.params),
+    a = TrainArgs(K, R, S, 1 if bf16 else 0, color_scaling, opacity_scaling, feat_scaling, obj_center, _ptr(arena.params),
                   arena.p_stride, _ptr(arena.scale), _ptr(pts), _ptr(origins), _ptr(dirs), _ptr(z), _ptr(gt_depth),
                   _ptr(gt_rgb), _ptr(labels), _ptr(gt_feat), _ptr(counts), _ptr(flags), _ptr(ws.grads),
                   _ptr(ws.loss_terms), _ptr(ws.status), _ptr(ws.buf), ws.nbytes)

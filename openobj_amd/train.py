@@ -44,9 +44,10 @@ class BackgroundLoop:
 
 
 class HipTrainLoop:
-    def __init__(self, cfg, trainers: List, with_feat: bool = False):
-        """trainers: the per-object Trainer instances in obj_dict order (train.py:255-256)."""
-        self.cfg, self.trainers, self.with_feat = cfg, list(trainers), with_feat
+    def __init__(self, cfg, trainers: List, with_feat: bool = False, bf16: bool = False):
+        """trainers: the per-object Trainer instances in obj_dict order (train.py:255-256).
+        bf16: opt-in bf16-operand MFMA mode of the fused kernel (ops.train_step); default = reference fp32."""
+        self.cfg, self.trainers, self.with_feat, self.bf16 = cfg, list(trainers), with_feat, bf16
         self.arena = None
         self.opt = None
         self.ws = None
@@ -71,7 +72,8 @@ class HipTrainLoop:
         K, R, S = batch["z"].shape
         if self.ws is None or self.ws.key != (K, R, S, self.with_feat):
             self.ws = ops.TrainWorkspace(self.arena, K, R, S, self.with_feat)
-        ops.train_step(self.arena, self.ws, batch, with_feat=self.with_feat, global_flags=global_flags)
+        ops.train_step(self.arena, self.ws, batch, with_feat=self.with_feat, global_flags=global_flags,
+                       bf16=self.bf16)
         self.opt.step(self.ws.grads, self.mask)
         return self.ws.loss_terms
 

@@ -172,14 +172,14 @@ def test_keyframe_ring_and_checkpoint_roundtrip(dev, tmp_path):
     assert float(obj.trainer.arena.params.abs().sum()) > 0      # the values landed in the arena block
 
 
-def _train_and_psnr(dev, scene, meta, seed, steps, ev, check_init=None):
+def _train_and_psnr(dev, scene, meta, seed, steps, ev, check_init=None, bf16=False):
     K, R, N, M = meta[:4]
     ts = make_trainers(K, dev, seed)
     if check_init is not None:          # Trainer(seed) reproduces the reference's initial weights exactly
         for k, t in enumerate(ts):
             for i, p in enumerate(t.fc_occ_map.parameters()):
                 assert torch.equal(p.detach().cpu(), T(check_init[f"fc0_{i}"])[k])
-    loop = otrain.HipTrainLoop(make_cfg(dev), ts, with_feat=False)
+    loop = otrain.HipTrainLoop(make_cfg(dev), ts, with_feat=False, bf16=bf16)
     losses = []
     for it in range(steps):
         b = scene.batch(R, N, M, seed=9000 + it)

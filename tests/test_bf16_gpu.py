@@ -1,0 +1,78 @@
+"""GPU: the opt-in bf16-operand mode of the fused training kernel (OBJNERF_TRAIN_BF16).
+
+The reference computes in fp32 (train.py:74, AMP off), so this mode is NOT held to the 1e-4 parity bar; it is
+held to (a) gradients / losses that agree with the fp32 kernel to bf16 rounding noise and (b) the same
+reconstruction quality (PSNR) as the reference on the integration fixture."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import T
+from openobj_amd import ops, synthetic
+from test_api_gpu import _train_and_psnr
+
+pytestmark = pytest.mark.gpu
+
+
+def _arena(golden, K, dev):
+    g = golden("g9_psnr_nofeat")
+    fc = [T(g[f"fc0_{i}"])[:1].repeat(K, *([1] * (T(g[f"fc0_{i}"]).dim() - 1))).clone() for i in range(18)]
+    gen = torch.Generator().manual_seed(K)
+    fc = [p + 0.05 * torch.randn(p.shape, generator=gen) * p.abs().mean() for p in fc]
+    from oracle import objnerf_oracle as O
+    B = O.icosa_dirs()[None].repeat(K, 1, 1) + 0.01 * torch.randn(K, 21, 3, generator=gen)
+    arena = ops.ParamArena(K, ops.NetShape(), dev)
+    arena.load_stacked(fc + [B])
+    return arena
+
+
+@pytest.mark.parametrize("shape", [(3, 300, 16, 48), (2, 211, 5, 9), (2, 128, 8, 24)])
+def test_bf16_step_close_to_fp32(golden, dev, shape):
+    K, R, n1, n2 = shape
+    arena = _arena(golden, K, dev)
+    b = synthetic.random_batch(K, R, n1, n2, seed=31 + R)
+    batch = {k: T(b[k]).to(dev) for k in ["pts", "z", "gt_depth", "gt_rgb", "labels"]}
+    ws32 = ops.TrainWorkspace(arena, K, R, n1 + n2, False)
+    ws16 = ops.TrainWorkspace(arena, K, R, n1 + n2, False)
+    ops.train_step(arena, ws32, batch)
+    ops.train_step(arena, ws16, batch, bf16=True)
+    torch.cuda.synchronize()
+    assert int(ws16.status.item()) == 0
+    t32, t16 = ws32.loss_terms.cpu(), ws16.loss_terms.cpu()
+    np.testing.assert_allclose(t16[:, :3], t32[:, :3], rtol=2e-2, atol=2e-3)
+    g32, g16 = arena.views(ws32.grads), arena.views(ws16.grads)
+    for i in list(range(14)) + [18]:
+        a, r = g16[i].double().cpu(), g32[i].double().cpu()
+        rel = float((a - r).norm() / (r.norm() + 1e-12))
+        print(ops.TENSOR_NAMES[i], "rel err", round(rel, 4))
+        assert rel < 0.15, (i, ops.TENSOR_NAMES[i], rel)
+    for i in ops.FEAT_TENSORS:
+        assert float(g16[i].abs().max()) == 0.0
+
+
+def test_bf16_rejects_unsupported(golden, dev):
+    arena = _arena(golden, 1, dev)
+    b = synthetic.random_batch(1, 64, 5, 9, seed=3, feat_dim=512)
+    batch = {k: T(b[k]).to(dev) for k in ["pts", "z", "gt_depth", "gt_rgb", "labels", "gt_feat"]}
+    ws = ops.TrainWorkspace(arena, 1, 64, 14, True)
+    with pytest.raises(Exception):
+        ops.train_step(arena, ws, batch, with_feat=True, bf16=True)
+
+
+def test_bf16_psnr_matches_fp32_ensemble(golden, dev):
+    """Same fixture as test_train_loop_psnr_g9 (300 iterations from reference-initialised weights).  Training is
+    chaotic (sigma ~0.6 dB over weight seeds in fp32), so the two modes are compared as distributions over the
+    same 12 seeds.  Measured over 32 seeds (tools/psnr_ensemble.py): fp32 mean 34.14 / median 34.24 dB,
+    bf16 mean 34.07 / median 34.30 dB; the reference's own 6-seed ensemble has mean 33.91 dB."""
+    g = golden("g9_psnr_nofeat")
+    K, R, N, M, steps, eval_R, eval_S, scene_seed = [int(x) for x in g["meta"]]
+    scene = synthetic.EllipsoidScene.make(K, 512, seed=scene_seed)
+    ev = scene.eval_rays(eval_R, eval_S)
+    ens = {}
+    for mode in (False, True):
+        ens[mode] = np.array([_train_and_psnr(dev, scene, (K, R, N, M), 90 + i, steps, ev, bf16=mode)[0]
+                              for i in range(12)])
+    print("PSNR fp32", np.round(ens[False], 2), "bf16", np.round(ens[True], 2), "reference", np.round(g["psnr_ensemble"], 2))
+    assert abs(np.median(ens[True]) - np.median(ens[False])) < 0.4
+    assert abs(ens[True].mean() - ens[False].mean()) < 0.5
+    assert np.median(ens[True]) > np.median(g["psnr_ensemble"]) - 0.4
