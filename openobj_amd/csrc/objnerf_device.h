@@ -90,6 +90,7 @@ __device__ __forceinline__ float dpp_rowsum16(float v) {
 __device__ __forceinline__ void slot_accum16(float& acc, const float v, const int slot, const int c) {
   const float s = dpp_rowsum16(v);
   acc += (c == slot) ? s : 0.0f;
+  asm volatile("" : "+v"(acc));   // consume the row sum NOW (deferred adds keep dozens of partial sums live)
 }
 
 // Segmented (segment = `seg` consecutive lanes starting at multiples of seg) inclusive scans.

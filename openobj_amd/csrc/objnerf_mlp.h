@@ -303,6 +303,7 @@ __device__ __forceinline__ f32x4 pe_x1_tile_fb(const Pe& pe, const int T, const 
       sv = (g >= 2) ? 0.0f : sv;
     }
     dps[j0] += v;
+    asm volatile("" : "+v"(dps[j0]));   // consume v NOW: a deferred add keeps dx and cos live
     o[r] = sv;
   }
   return o;
@@ -325,6 +326,7 @@ __device__ __forceinline__ f32x4 pe_x2_tile_fb(const Pe& pe, const int T, const 
       sv = (g == 3) ? 0.0f : sv;
     }
     dps[j0] += v;
+    asm volatile("" : "+v"(dps[j0]));   // consume v NOW: a deferred add keeps dx and cos live
     o[r] = sv;
   }
   return o;

@@ -80,6 +80,28 @@ __device__ __forceinline__ void write_pair(float* slab, const f32x4& a0, const f
   }
 }
 
+// Diagnostic build (-DPHASE_TIMING): per-wave s_memtime deltas of each phase of workgroup 0, read back with
+// objnerf_debug_phase() (tools/phase_timing.py).  Not part of the product library.
+#ifdef PHASE_TIMING
+__device__ unsigned long long g_phase[8][24];
+#define PT_INIT() unsigned long long pt_acc[18]; for (int i_ = 0; i_ < 18; ++i_) pt_acc[i_] = 0; \
+  unsigned long long pt_t0 = __builtin_amdgcn_s_memtime()
+#define PT(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pt_acc[i] += t_ - pt_t0; pt_t0 = t_; } while (0)
+#define PT_FLUSH() do { if (blockIdx.x == 0 && lane == 0) for (int i_ = 0; i_ < 18; ++i_) g_phase[w][i_] = pt_acc[i_]; } while (0)
+#else
+#define PT_INIT() do {} while (0)
+#define PT(i) do {} while (0)
+#define PT_FLUSH() do {} while (0)
+#endif
+
+// keeps the instruction scheduler from pulling the sincos of later embedding tiles ahead of the current one
+// (which overlaps nicely but needs ~50 more live registers and spills the persistent accumulators)
+#ifdef NO_SCHED_FENCE
+#define SCHED_FENCE() do {} while (0)
+#else
+#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
 #ifdef ABL_NO_BARRIER
 #define TILE_SYNC() do {} while (0)
 #else
@@ -87,6 +109,15 @@ __device__ __forceinline__ void write_pair(float* slab, const f32x4& a0, const f
 #endif
 
 // ------------------------------------------------------------------------------------------------
+#ifndef X1N
+#define X1N 6
+#endif
+#ifndef X2N
+#define X2N 3
+#endif
+#ifdef ABL_NO_SLOT
+#define slot_accum16(a, b, c_, d) do { a += (b); } while (0)
+#endif
 template <bool FEAT>
 __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -121,19 +152,29 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
   float g_dB = 0.f;  // thread (p = tid >> 3, q = tid & 7): partial of d B[p / 3][p % 3] over samples 16q..16q+15
   float l_d = 0.f, l_c = 0.f, l_o = 0.f, l_f = 0.f;
   f32x4 accF0 = zero4(), accF1 = zero4();
-  const float* wt_fl = lds + OFF_FL + (4 * g) * ST_CL + c;
 
-  float* stg_lane = stg + (4 * g) * STG_LD + 16 * w + c;
-  const float* lane_rd = stg + c * STG_LD + 32 * g;
 
-  const float* wt_in = lds + OFF_IN + (4 * g) * ST_IN + c;
-  const float* wt_m1 = lds + OFF_M1 + (4 * g) * ST_M + c;
-  const float* wt_cat = lds + OFF_CAT + (4 * g) * ST_CAT + c;
-  const float* wt_m2 = lds + OFF_M2 + (4 * g) * ST_M + c;
-  const float* wt_cl = lds + OFF_CL + (4 * g) * ST_CL + c;
 
+  // Loop-invariant per-lane LDS addresses must NOT be hoisted out of the tile loop: there are dozens of them
+  // and they end up spilled to scratch, each reload a serialised ~500-cycle stall.  Inside the loop the lane
+  // coordinates (c, g) and every per-lane LDS pointer are macros over an opaque copy of the lane id that is
+  // re-defined at each phase boundary, so addresses are recomputed (a few VALU ops) next to their use.
+  int lane_l = lane;
+#define RELAUNDER() asm volatile("" : "+v"(lane_l))
+#define c (lane_l & 15)
+#define g (lane_l >> 4)
+#define wt_fl (lds + OFF_FL + (4 * g) * ST_CL + c)
+#define stg_lane (stg + (4 * g) * STG_LD + 16 * w + c)
+#define lane_rd (stg + c * STG_LD + 32 * g)
+#define wt_in (lds + OFF_IN + (4 * g) * ST_IN + c)
+#define wt_m1 (lds + OFF_M1 + (4 * g) * ST_M + c)
+#define wt_cat (lds + OFF_CAT + (4 * g) * ST_CAT + c)
+#define wt_m2 (lds + OFF_M2 + (4 * g) * ST_M + c)
+#define wt_cl (lds + OFF_CL + (4 * g) * ST_CL + c)
+  PT_INIT();
   for (int tile = gi; tile < a.NT; tile += a.G) {
     asm volatile("" ::: "memory");   // keep the LDS weight reads inside the loop (no LICM into registers)
+    RELAUNDER();
     const int ray0 = tile * TR;
     // ---------------------------------------------------------------- 1. forward
     const int slot = 16 * w + c;
@@ -157,13 +198,16 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
     }
     Pe pe;
     pe_project(lds, g, px, py, pz, scale, pe);
+    PT(0);
     Acts act;
     Heads hd;
     {
       Emb e;                          // forward-only: the backward re-creates the embedding tile by tile
       embed(e, pe, g);
+      PT(1);
       mlp_forward<FEAT>(lds, c, g, e, act, hd);
     }
+    PT(2);
     if (g == 0) {
       s_alpha[slot] = hd.alpha;
       s_col[slot] = hd.col[0];
@@ -182,6 +226,8 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
       }
     }
     TILE_SYNC();
+    RELAUNDER();
+    PT(3);
     // ---------------------------------------------------------------- 2. composite + loss (loss.py:27-101)
     {
       const int rpp = 64 / S;                       // rays per wave pass
@@ -313,7 +359,10 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
         }
       }
     }
+    PT(4);
     TILE_SYNC();
+    RELAUNDER();
+    PT(5);
     // ---------------------------------------------------------------- 3. backward
     const float da = valid ? s_alpha[slot] : 0.0f;
     const float dc0 = valid ? s_col[slot] : 0.0f;
@@ -371,7 +420,7 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
     store_T32(stg_lane, 160, d_h4);
     // PE backward, x2 part, one 16-row tile at a time
 #pragma unroll
-    for (int T = 0; T < 3; ++T) {
+    for (int T = 0; T < X2N; ++T) {
       f32x4 d_x = zero4();
       mma_bwd16<ST_CL>(d_x, wt_cl, 32 + 16 * T, d_hc);
       if (FEAT) mma_bwd16<ST_CL>(d_x, wt_fl, 32 + 16 * T, d_hf);
@@ -380,18 +429,26 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
     T32 d_h3 = zero32();
     mma_bwd32<ST_M>(d_h3, wt_m2, 0, d_h4);
     d_h3 = relu_mask32(d_h3, act.h3);
+    PT(6);
     TILE_SYNC();
+    RELAUNDER();
+    PT(7);
     if (w < 7) {
       const int dTr = (w < 5) ? 128 : 160;
       const int aTr = (w < 5) ? 16 * w : 96 + 16 * (w - 5);
       wgrad_pair(accA0, accA1, lane_rd + dTr * STG_LD, lane_rd + aTr * STG_LD);
     }
+    PT(8);
     TILE_SYNC();
+    RELAUNDER();
+    PT(9);
     if (FEAT) {             // feature layer weight gradient: same inputs [h4 | x2], d_hf in place of d_hc
       store_T32(stg_lane, 128, d_hf);
       TILE_SYNC();
+    RELAUNDER();
       if (w < 5) wgrad_pair(accF0, accF1, lane_rd + 128 * STG_LD, lane_rd + (16 * w) * STG_LD);
       TILE_SYNC();
+    RELAUNDER();
     }
     // ---- phase B: cat layer.  [h2 | x1] rows 0..127, d_h3pre rows 128..
     store_T32(stg_lane, 0, act.h2);
@@ -408,37 +465,41 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
     d_h1 = relu_mask32(d_h1, act.h1);
     // PE backward, x1 part: d x1 tile = cat^T d_h3 + in^T d_h1, consumed tile by tile
 #pragma unroll
-    for (int T = 0; T < 6; ++T) {
+    for (int T = 0; T < X1N; ++T) {
       f32x4 d_x = zero4();
       mma_bwd16<ST_CAT>(d_x, wt_cat, 32 + 16 * T, d_h3);
       mma_bwd16<ST_IN>(d_x, wt_in, 16 * T, d_h1);
       store_T16(stg_lane, 32 + 16 * T, pe_x1_tile_fb(pe, T, g, d_x, dps));
     }
-    // d proj[(i + 4g) mod 21][sample] = d ps[i] * (1 or 2)  ->  rows 160..180 of the staging area (free in
-    // phase B).  The four lane groups of a sample sit in ONE wave and LDS executes a wave's accesses in order:
-    // group 0 stores (its rows are i, i.e. all 21), groups 1..3 then add.
+    PT(10);
+    // d ps[i] of lane group g belongs to direction j = (i + 4g) mod 21, doubled when it wrapped into the next
+    // octave.  The four groups of a sample are summed ON THE MATRIX CORE: one 16x16x4 MFMA per register i with
+    // B = d ps[i] (k = lane group, n = sample) and a 0/1/2 selection matrix A[row][k] = [row == j(i, k)] * factor
+    // scatters the four values into rows j of a 32-row d-projection tile (exact: products by 0, 1, 2).  No LDS
+    // atomics (ds_add_f32 retires ~1 lane/clk for the whole CU: 8 waves x 21 of them cost ~10 % of the kernel).
     {
-      float* trow = stg + 160 * STG_LD + 16 * w + c;
+      T32 dpj = zero32();
 #pragma unroll
       for (int i = 0; i < OBJ_NDIR; ++i) {
-        const int wrap = (i > 8 && 4 * g + i >= OBJ_NDIR);
-        const int row = 4 * g + i - (wrap ? OBJ_NDIR : 0);
-        const float v = wrap ? 2.0f * dps[i] : dps[i];
-        if (g == 0) trow[row * STG_LD] = v;
-      }
-      // compiler barrier: per thread the stores and the adds are mutually exclusive, so the compiler may
-      // legally interleave them; the cross-LANE order (all stores, then the adds) is what matters here.
-      __builtin_amdgcn_wave_barrier();
-      asm volatile("" ::: "memory");
+        bool need[2] = {false, false};
 #pragma unroll
-      for (int i = 0; i < OBJ_NDIR; ++i) {
-        const int wrap = (i > 8 && 4 * g + i >= OBJ_NDIR);
-        const int row = 4 * g + i - (wrap ? OBJ_NDIR : 0);
-        const float v = wrap ? 2.0f * dps[i] : dps[i];
-        if (g != 0) atomicAdd(&trow[row * STG_LD], v);
+        for (int gg = 0; gg < 4; ++gg) {
+          const int mm = 4 * gg + i;
+          need[((i > 8 && mm >= OBJ_NDIR) ? mm - OBJ_NDIR : mm) >> 4] = true;
+        }
+        const int m = 4 * g + i;
+        const bool wrap = (i > 8) && (m >= OBJ_NDIR);
+        const int j = wrap ? m - OBJ_NDIR : m;
+        const float f = wrap ? 2.0f : 1.0f;
+        if (need[0]) dpj.t[0] = OBJ_MFMA((j == c) ? f : 0.0f, dps[i], dpj.t[0]);
+        if (need[1]) dpj.t[1] = OBJ_MFMA((j - 16 == c) ? f : 0.0f, dps[i], dpj.t[1]);
       }
+      store_T32(stg_lane, 160, dpj);      // rows 160..180 (181..191: zeros), free in phase B
     }
+    PT(11);
     TILE_SYNC();
+    RELAUNDER();
+    PT(12);
     {
       // d B[j][x] += sum_s dproj[j][s] * t[x][s]  (embedding.py:48): thread (p, q) takes 16 samples of pair p
       const int p = tid >> 3, qq = tid & 7;
@@ -452,19 +513,38 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
       }
       wgrad_pair(accB0, accB1, lane_rd + 128 * STG_LD, lane_rd + (16 * w) * STG_LD);
     }
+    PT(13);
     TILE_SYNC();
+    RELAUNDER();
     // ---- phase C: in layer (x1 stays at rows 32..127) + mid1.  h1 rows 0.., d_h1pre 128.., d_h2pre 160..
     store_T32(stg_lane, 0, act.h1);
     store_T32(stg_lane, 128, d_h1);
     store_T32(stg_lane, 160, d_h2);
+    PT(14);
     TILE_SYNC();
+    RELAUNDER();
+    PT(15);
     {
       const int dTr = (w < 6) ? 128 : 160;
       const int aTr = (w < 6) ? 32 + 16 * w : 16 * (w - 6);
       wgrad_pair(accC0, accC1, lane_rd + dTr * STG_LD, lane_rd + aTr * STG_LD);
     }
+    PT(16);
     TILE_SYNC();
+    RELAUNDER();
+    PT(17);
   }
+  PT_FLUSH();
+#undef c
+#undef g
+#undef wt_fl
+#undef stg_lane
+#undef lane_rd
+#undef wt_in
+#undef wt_m1
+#undef wt_cat
+#undef wt_m2
+#undef wt_cl
 
   // ------------------------------------------------------------------ write this workgroup's slab
   float* slab = a.slab + ((long)k * a.G + gi) * a.slab_stride;
@@ -894,6 +974,14 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
   if (hipGetLastError() != hipSuccess) return OBJNERF_ELAUNCH;
   return OBJNERF_OK;
 }
+
+#ifdef PHASE_TIMING
+extern "C" int objnerf_debug_phase(unsigned long long* out_host) {
+  if (hipDeviceSynchronize() != hipSuccess) return OBJNERF_ELAUNCH;
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 8 * 24) == hipSuccess
+             ? OBJNERF_OK : OBJNERF_ELAUNCH;
+}
+#endif
 
 int objnerf_eval_points(const objnerf_net* net, int32_t K, int64_t N, const float* params, int64_t p_stride,
                         const float* scale, const float* pts, float* out_alpha, float* out_color, float* out_hfeat,

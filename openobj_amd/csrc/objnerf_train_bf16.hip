@@ -36,10 +36,12 @@ constexpr int B_SMALL = T_CL + 80 * RST;      // fp32: bm1[32] bm2[32] wa[32] wo
 constexpr int S_BM1 = 0, S_BM2 = 32, S_WA = 64, S_WOC = 96, S_HB = 192, S_PEB = 196;
 constexpr int B_SM = B_SMALL + 1280;          // s_alpha | s_col[3]  (fp32, 2 KB)
 constexpr int TB_LD = 130;
-constexpr int B_TBUF = B_SM + 2048;           // fp32 [24][130]: d proj rows 0..20, t rows 21..23
+constexpr int TB_ROWS = 35;
+constexpr int B_TBUF = B_SM + 2048;           // fp32 [35][130]: d proj rows 0..20 (..31 zero), t rows 32..34
 constexpr int STG_PITCH = 288;                // bf16 staging row: 128 samples + pad
-constexpr int B_STG = B_TBUF + 24 * TB_LD * 4;
-constexpr int LDS_BYTES = B_STG + STG_ROWS * STG_PITCH;
+constexpr int B_STG = (B_TBUF + TB_ROWS * TB_LD * 4 + 15) / 16 * 16;
+constexpr int STG_ROWS_B = 192;
+constexpr int LDS_BYTES = B_STG + STG_ROWS_B * STG_PITCH;
 static_assert(B_SMALL % 16 == 0 && B_STG % 16 == 0 && LDS_BYTES <= 163840, "bf16 lds layout");
 
 __device__ __forceinline__ int phi(int g, int e) { return e < 4 ? 4 * g + e : 16 + 4 * g + e - 4; }
@@ -453,27 +455,32 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
       store16_b(stg_lane, 32 + 16 * T, pe_x1_tile_fb(pe, T, g, d_x, dps));
     }
     {
-      float* trow = tbuf + 16 * w + c;
+      // cross-group sum of d ps on the matrix core (see objnerf_train.hip), then rows j of the fp32 table
+      T32 dpj = zero32();
 #pragma unroll
       for (int i = 0; i < OBJ_NDIR; ++i) {
-        const int wrap = (i > 8 && 4 * g + i >= OBJ_NDIR);
-        const int row = 4 * g + i - (wrap ? OBJ_NDIR : 0);
-        const float v = wrap ? 2.0f * dps[i] : dps[i];
-        if (g == 0) trow[row * TB_LD] = v;
+        bool need[2] = {false, false};
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) {
+          const int mm = 4 * gg + i;
+          need[((i > 8 && mm >= OBJ_NDIR) ? mm - OBJ_NDIR : mm) >> 4] = true;
+        }
+        const int m = 4 * g + i;
+        const bool wrap = (i > 8) && (m >= OBJ_NDIR);
+        const int j = wrap ? m - OBJ_NDIR : m;
+        const float f = wrap ? 2.0f : 1.0f;
+        if (need[0]) dpj.t[0] = OBJ_MFMA((j == c) ? f : 0.0f, dps[i], dpj.t[0]);
+        if (need[1]) dpj.t[1] = OBJ_MFMA((j - 16 == c) ? f : 0.0f, dps[i], dpj.t[1]);
       }
+      float* trow = tbuf + (4 * g) * TB_LD + 16 * w + c;
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) trow[(16 * tt + r) * TB_LD] = dpj.t[tt][r];
       if (g == 0) {
-        trow[21 * TB_LD] = pe.t[0];
-        trow[22 * TB_LD] = pe.t[1];
-        trow[23 * TB_LD] = pe.t[2];
-      }
-      __builtin_amdgcn_wave_barrier();
-      asm volatile("" ::: "memory");
-#pragma unroll
-      for (int i = 0; i < OBJ_NDIR; ++i) {
-        const int wrap = (i > 8 && 4 * g + i >= OBJ_NDIR);
-        const int row = 4 * g + i - (wrap ? OBJ_NDIR : 0);
-        const float v = wrap ? 2.0f * dps[i] : dps[i];
-        if (g != 0) atomicAdd(&trow[row * TB_LD], v);
+        trow[32 * TB_LD] = pe.t[0];
+        trow[33 * TB_LD] = pe.t[1];
+        trow[34 * TB_LD] = pe.t[2];
       }
     }
     __syncthreads();
@@ -481,7 +488,7 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
       const int p = tid >> 3, qq = tid & 7;
       if (p < 3 * OBJ_NDIR) {
         const float* tp = tbuf + (p / 3) * TB_LD + 16 * qq;
-        const float* xp = tbuf + (21 + p % 3) * TB_LD + 16 * qq;
+        const float* xp = tbuf + (32 + p % 3) * TB_LD + 16 * qq;
         float acc = 0.f;
 #pragma unroll
         for (int s = 0; s < 16; ++s) acc = fmaf(tp[s], xp[s], acc);
