@@ -23,6 +23,7 @@ struct Gemm {
   const float* mask; long smm, smn, bsm;
   int accumulate, relu;
   int splitk;      // > 1: blockIdx.z = batch * splitk + slice; each slice atomically adds its partial into C
+  float* rowsum; long bsrs;   // optional: rowsum[m] += sum_k A(m,k)  (bias gradient riding on the weight-gradient GEMM)
 };
 
 constexpr int BK = 16;
@@ -87,11 +88,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Gemm g) {
       Bs[bk][bn] = rb[i];
     }
   };
+  float rs = 0.f;
+  const bool do_rs = g.rowsum != nullptr && blockIdx.x == 0 && tid < BM;
   if (kbeg < kend) load_tiles(kbeg);
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
     store_tiles();
     __syncthreads();
     if (k0 + BK < kend) load_tiles(k0 + BK);       // next tile's global loads fly under the MFMAs
+    if (do_rs) {
+#pragma unroll
+      for (int kk = 0; kk < BK; ++kk) rs += As[kk][tid];
+    }
 #pragma unroll
     for (int ks = 0; ks < BK / 4; ++ks) {
       float a[TM], b[TN];
@@ -106,6 +113,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Gemm g) {
     }
     __syncthreads();
   }
+  if (do_rs && m0 + tid < g.M) atomicAdd(g.rowsum + z * g.bsrs + m0 + tid, rs);
   // epilogue: D layout: col n = lane & 15, row m = 4 * (lane >> 4) + r
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -130,7 +138,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Gemm g) {
 static void gemm(hipStream_t st, int batch, int M, int N, int Kd, const float* A, long sam, long sak, long bsa,
                  const float* B, long sbk, long sbn, long bsb, float* C, long scm, long scn, long bsc,
                  bool accumulate = false, const float* bias = nullptr, long bsbias = 0, bool relu = false,
-                 const float* mask = nullptr, long smm = 0, long smn = 0, long bsm = 0, int splitk = 1) {
+                 const float* mask = nullptr, long smm = 0, long smn = 0, long bsm = 0, int splitk = 1,
+                 float* rowsum = nullptr, long bsrs = 0) {
   Gemm g;
   g.M = M; g.N = N; g.Kd = Kd;
   g.A = A; g.sam = sam; g.sak = sak; g.bsa = bsa;
@@ -138,6 +147,7 @@ static void gemm(hipStream_t st, int batch, int M, int N, int Kd, const float* A
   g.C = C; g.scm = scm; g.scn = scn; g.bsc = bsc;
   g.bias = bias; g.bsbias = bsbias; g.mask = mask; g.smm = smm; g.smn = smn; g.bsm = bsm;
   g.accumulate = accumulate; g.relu = relu; g.splitk = splitk;
+  g.rowsum = rowsum; g.bsrs = bsrs;
   const int nz = batch * (splitk > 1 ? splitk : 1);
   if (M >= 256 && N >= 96) {          // tall layer GEMMs: 128 x 128 tiles
     dim3 grid((N + 127) / 128, (M + 127) / 128, nz);
@@ -148,68 +158,69 @@ static void gemm(hipStream_t st, int batch, int M, int N, int Kd, const float* A
   }
 }
 
-// weight gradient: C[M][N] += sum over the n samples; few output tiles, long contraction -> split-K + atomics
+// weight gradient: C[M][N] += sum over the n samples; few output tiles, long contraction -> split-K + atomics.
+// bias_grad (optional, pre-zeroed like C): [M] column sums of the output-gradient operand, same pass.
 static void wgrad(hipStream_t st, int batch, int M, int N, long n, const float* A, long sam, long sak, long bsa,
-                  const float* B, long sbk, long sbn, long bsb, float* C, long scm, long bsc) {
+                  const float* B, long sbk, long sbn, long bsb, float* C, long scm, long bsc,
+                  float* bias_grad = nullptr) {
   int sk = (int)((n + 511) / 512);
   if (sk < 1) sk = 1;
   if (sk > 256) sk = 256;
   gemm(st, batch, M, N, (int)n, A, sam, sak, bsa, B, sbk, sbn, bsb, C, scm, 1, bsc, false, nullptr, 0, false, nullptr, 0,
-       0, 0, sk > 1 ? sk : 2);
-}
-
-// column sums: out[z][n] = sum_m X[z][m][n]   (bias gradients)
-__global__ void colsum_kernel(int M, int N, const float* X, long ldx, long bsx, float* out, long bso) {
-  const int n = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int part = threadIdx.x >> 6;      // 4 row partitions per block, gridDim.z row slices (out is pre-zeroed)
-  const long z = blockIdx.y;
-  __shared__ float red[4][64];
-  float s = 0.f;
-  if (n < N)
-    for (int m = blockIdx.z * 4 + part; m < M; m += 4 * gridDim.z) s += X[z * bsx + (long)m * ldx + n];
-  red[part][threadIdx.x & 63] = s;
-  __syncthreads();
-  if (part == 0 && n < N)
-    atomicAdd(&out[z * bso + n], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
-}
-static void colsum(hipStream_t st, int K, long n, int N, const float* X, long ldx, long bsx, float* out, long bso) {
-  int zs = (int)((n + 1023) / 1024);
-  if (zs < 1) zs = 1;
-  if (zs > 64) zs = 64;
-  hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, K, zs), dim3(256), 0, st, (int)n, N, X, ldx, bsx, out, bso);
+       0, 0, sk > 1 ? sk : 2, bias_grad, bsc);
 }
 
 // heads forward: alpha = 10 (h4 . wa + ba), color = sigmoid(hc Woc^T + boc)        (model.py:81-96)
-__global__ void heads_fwd_kernel(int Hh, long n, const float* h4, const float* hc, const float* params, long p_stride,
-                                 int off_wa, int off_ba, int off_woc, int off_boc, float* alpha, float* color) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+// 16 lanes per sample row (float4 each, coalesced), the four dot products meet by DPP row sums.
+__global__ __launch_bounds__(256) void heads_fwd_kernel(int Hh, long n, const float* h4, const float* hc,
+                                                        const float* params, long p_stride, int off_wa, int off_ba,
+                                                        int off_woc, int off_boc, float* alpha, float* color) {
+  extern __shared__ float sw[];            // wa | woc[3]  (4 Hh floats)
   const long z = blockIdx.y;
-  if (i >= n) return;
   const float* P = params + z * p_stride;
-  const float* a = h4 + (z * n + i) * Hh;
-  const float* cc = hc + (z * n + i) * Hh;
+  for (int i = threadIdx.x; i < Hh; i += 256) sw[i] = P[off_wa + i];
+  for (int i = threadIdx.x; i < 3 * Hh; i += 256) sw[Hh + i] = P[off_woc + i];
+  __syncthreads();
+  const int l16 = threadIdx.x & 15;
+  const long i = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
   float sa = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
-  for (int h = 0; h < Hh; ++h) {
-    sa = fmaf(P[off_wa + h], a[h], sa);
-    s0 = fmaf(P[off_woc + h], cc[h], s0);
-    s1 = fmaf(P[off_woc + Hh + h], cc[h], s1);
-    s2 = fmaf(P[off_woc + 2 * Hh + h], cc[h], s2);
+  if (i < n) {
+    const float* a = h4 + (z * n + i) * Hh;
+    const float* cc = hc + (z * n + i) * Hh;
+    for (int h = 4 * l16; h < Hh; h += 64) {
+      const float4 av = *reinterpret_cast<const float4*>(a + h);
+      const float4 cv = *reinterpret_cast<const float4*>(cc + h);
+      const float* w0 = sw + h;
+      sa = fmaf(w0[3], av.w, fmaf(w0[2], av.z, fmaf(w0[1], av.y, fmaf(w0[0], av.x, sa))));
+      s0 = fmaf(w0[Hh + 3], cv.w, fmaf(w0[Hh + 2], cv.z, fmaf(w0[Hh + 1], cv.y, fmaf(w0[Hh], cv.x, s0))));
+      s1 = fmaf(w0[2 * Hh + 3], cv.w, fmaf(w0[2 * Hh + 2], cv.z, fmaf(w0[2 * Hh + 1], cv.y, fmaf(w0[2 * Hh], cv.x, s1))));
+      s2 = fmaf(w0[3 * Hh + 3], cv.w, fmaf(w0[3 * Hh + 2], cv.z, fmaf(w0[3 * Hh + 1], cv.y, fmaf(w0[3 * Hh], cv.x, s2))));
+    }
   }
-  alpha[z * n + i] = (sa + P[off_ba]) * 10.0f;
-  color[(z * n + i) * 3] = sigmoid_acc(s0 + P[off_boc]);
-  color[(z * n + i) * 3 + 1] = sigmoid_acc(s1 + P[off_boc + 1]);
-  color[(z * n + i) * 3 + 2] = sigmoid_acc(s2 + P[off_boc + 2]);
+  sa = dpp_rowsum16(sa); s0 = dpp_rowsum16(s0); s1 = dpp_rowsum16(s1); s2 = dpp_rowsum16(s2);
+  if (i < n && l16 == 0) {
+    alpha[z * n + i] = (sa + P[off_ba]) * 10.0f;
+    color[(z * n + i) * 3] = sigmoid_acc(s0 + P[off_boc]);
+    color[(z * n + i) * 3 + 1] = sigmoid_acc(s1 + P[off_boc + 1]);
+    color[(z * n + i) * 3 + 2] = sigmoid_acc(s2 + P[off_boc + 2]);
+  }
 }
 
 // heads backward: dhead[n][4] = (10 d_alpha, d_color * color (1 - color)); d_hc = relu'(hc) Woc^T d_craw;
 // d_h4 = wa * d_araw  (the colour-layer contribution is accumulated by a GEMM afterwards)
-__global__ void heads_bwd_kernel(int Hh, long n, const float* hc, const float* color, const float* d_alpha,
-                                 const float* d_color, const float* params, long p_stride, int off_wa, int off_woc,
-                                 float* dhead, float* d_hc, float* d_h4) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void heads_bwd_kernel(int Hh, long n, const float* hc, const float* color,
+                                                        const float* d_alpha, const float* d_color, const float* params,
+                                                        long p_stride, int off_wa, int off_woc, float* dhead, float* d_hc,
+                                                        float* d_h4) {
+  extern __shared__ float sw[];            // wa | woc[3]
   const long z = blockIdx.y;
-  if (i >= n) return;
   const float* P = params + z * p_stride;
+  for (int i = threadIdx.x; i < Hh; i += 256) sw[i] = P[off_wa + i];
+  for (int i = threadIdx.x; i < 3 * Hh; i += 256) sw[Hh + i] = P[off_woc + i];
+  __syncthreads();
+  const int l16 = threadIdx.x & 15;
+  const long i = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (i >= n) return;
   const long o = z * n + i;
   const float da = 10.0f * d_alpha[o];
   float dc[3];
@@ -217,11 +228,19 @@ __global__ void heads_bwd_kernel(int Hh, long n, const float* hc, const float* c
     const float cv = color[o * 3 + x];
     dc[x] = d_color[o * 3 + x] * cv * (1.0f - cv);
   }
-  dhead[o * 4] = da; dhead[o * 4 + 1] = dc[0]; dhead[o * 4 + 2] = dc[1]; dhead[o * 4 + 3] = dc[2];
-  for (int h = 0; h < Hh; ++h) {
-    const float v = fmaf(P[off_woc + 2 * Hh + h], dc[2], fmaf(P[off_woc + Hh + h], dc[1], P[off_woc + h] * dc[0]));
-    d_hc[o * Hh + h] = hc[o * Hh + h] > 0.f ? v : 0.f;
-    d_h4[o * Hh + h] = P[off_wa + h] * da;
+  if (l16 == 0) *reinterpret_cast<float4*>(dhead + o * 4) = make_float4(da, dc[0], dc[1], dc[2]);
+  for (int h = 4 * l16; h < Hh; h += 64) {
+    const float4 hv = *reinterpret_cast<const float4*>(hc + o * Hh + h);
+    const float* w0 = sw + h;
+    float4 v, u;
+    v.x = fmaf(w0[3 * Hh], dc[2], fmaf(w0[2 * Hh], dc[1], w0[Hh] * dc[0]));
+    v.y = fmaf(w0[3 * Hh + 1], dc[2], fmaf(w0[2 * Hh + 1], dc[1], w0[Hh + 1] * dc[0]));
+    v.z = fmaf(w0[3 * Hh + 2], dc[2], fmaf(w0[2 * Hh + 2], dc[1], w0[Hh + 2] * dc[0]));
+    v.w = fmaf(w0[3 * Hh + 3], dc[2], fmaf(w0[2 * Hh + 3], dc[1], w0[Hh + 3] * dc[0]));
+    v.x = hv.x > 0.f ? v.x : 0.f; v.y = hv.y > 0.f ? v.y : 0.f; v.z = hv.z > 0.f ? v.z : 0.f; v.w = hv.w > 0.f ? v.w : 0.f;
+    u.x = w0[0] * da; u.y = w0[1] * da; u.z = w0[2] * da; u.w = w0[3] * da;
+    *reinterpret_cast<float4*>(d_hc + o * Hh + h) = v;
+    *reinterpret_cast<float4*>(d_h4 + o * Hh + h) = u;
   }
 }
 
@@ -231,40 +250,45 @@ __global__ void relu_mask_kernel(long n, float* d, const float* act) {
 }
 
 // PE backward: d B[j][x] = sum_n t[n][x] sum_f d_emb[n][3 + 21 f + j] cos(arg) pi 2^f     (embedding.py:48-52)
-// private register accumulators per thread, wave reduction, one atomic per wave and entry.
+// lane = (sample slot 0..2, direction j): 63 lanes per wave, the six d_emb reads of a lane group are contiguous
+// over j; three accumulators per thread, LDS reduction per block, one atomic per block and entry.
 __global__ __launch_bounds__(256) void pe_bwd_kernel(long n, const float* params, long p_stride, int off_B,
                                                      const float* scale, const float* pts, const float* d_emb,
                                                      float* dB /* [K][63], pre-zeroed */) {
+  __shared__ float red[4][63][3];
   const long z = blockIdx.y;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int j = lane % OBJ_NDIR, s3 = lane / OBJ_NDIR;      // lane 63: s3 == 3 -> idle
   const float* B = params + z * p_stride + off_B;
+  const float b0 = B[3 * j], b1 = B[3 * j + 1], b2 = B[3 * j + 2];
   const float sc = scale[z];
-  float acc[63];
-#pragma unroll
-  for (int i = 0; i < 63; ++i) acc[i] = 0.f;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  const long stride = (long)gridDim.x * 12;
+  for (long i = ((long)blockIdx.x * 4 + wv) * 3 + s3; i < n && s3 < 3; i += stride) {
     const float* p = pts + (z * n + i) * 3;
     const float t0 = p[0] / sc, t1 = p[1] / sc, t2 = p[2] / sc;
-    const float* de = d_emb + (z * n + i) * OBJ_EMB;
+    const float* de = d_emb + (z * n + i) * OBJ_EMB + 3 + j;
+    const float pj = fmaf(t2, b2, fmaf(t1, b1, t0 * b0));
+    float dp = 0.f;
 #pragma unroll
-    for (int j = 0; j < OBJ_NDIR; ++j) {
-      const float pj = fmaf(t2, B[3 * j + 2], fmaf(t1, B[3 * j + 1], t0 * B[3 * j]));
-      float dp = 0.f;
-#pragma unroll
-      for (int f = 0; f < 6; ++f) {
-        const float sf = (float)(1 << f);
-        float sv, cv;
-        sincos_acc((pj * sf) * OBJ_PI_F, sv, cv);
-        dp += de[3 + f * OBJ_NDIR + j] * ((cv * OBJ_PI_F) * sf);
-      }
-      acc[3 * j] = fmaf(dp, t0, acc[3 * j]);
-      acc[3 * j + 1] = fmaf(dp, t1, acc[3 * j + 1]);
-      acc[3 * j + 2] = fmaf(dp, t2, acc[3 * j + 2]);
+    for (int f = 0; f < 6; ++f) {
+      const float sf = (float)(1 << f);
+      float sv, cv;
+      sincos_acc((pj * sf) * OBJ_PI_F, sv, cv);
+      dp += de[f * OBJ_NDIR] * ((cv * OBJ_PI_F) * sf);
     }
+    a0 = fmaf(dp, t0, a0);
+    a1 = fmaf(dp, t1, a1);
+    a2 = fmaf(dp, t2, a2);
   }
-#pragma unroll
-  for (int i = 0; i < 63; ++i) {
-    const float v = wave_sum64(acc[i]);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&dB[z * 63 + i], v);
+  if (lane < 63) { red[wv][lane][0] = a0; red[wv][lane][1] = a1; red[wv][lane][2] = a2; }
+  __syncthreads();
+  if (threadIdx.x < 63) {
+    const int jj = threadIdx.x / 3, x = threadIdx.x % 3;
+    float v = 0.f;
+    for (int ww = 0; ww < 4; ++ww)
+      for (int ss = 0; ss < 3; ++ss) v += red[ww][ss * OBJ_NDIR + jj][x];
+    atomicAdd(&dB[z * 63 + threadIdx.x], v);
   }
 }
 
@@ -345,8 +369,9 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a, void* stream
   gemm(st, K, n, H, H, w.h4, H, 1, nH, P + off[10], 1, H + E2, ps, w.hc, H, 1, nH);
   gemm(st, K, n, H, E2, w.emb + E1, EM, 1, n * EM, P + off[10] + H, 1, H + E2, ps, w.hc, H, 1, nH, true, P + off[11], ps,
        true);
-  dim3 eg((unsigned)((n + 255) / 256), (unsigned)K);
-  hipLaunchKernelGGL(heads_fwd_kernel, eg, dim3(256), 0, st, H, n, w.h4, w.hc, P, ps, (int)off[8], (int)off[9],
+  dim3 eg((unsigned)((n + 15) / 16), (unsigned)K);      // 16 lanes per sample row
+  const size_t head_lds = (size_t)4 * H * sizeof(float);
+  hipLaunchKernelGGL(heads_fwd_kernel, eg, dim3(256), head_lds, st, H, n, w.h4, w.hc, P, ps, (int)off[8], (int)off[9],
                      (int)off[12], (int)off[13], w.alpha, w.color);
   if (feat) {
     gemm(st, K, n, H, H, w.h4, H, 1, nH, P + off[14], 1, H + E2, ps, w.hf, H, 1, nH);
@@ -374,61 +399,53 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a, void* stream
   }
   float* d_hc = w.dA;      // [n][H]
   float* d_h4 = w.dB_;
-  hipLaunchKernelGGL(heads_bwd_kernel, eg, dim3(256), 0, st, H, n, w.hc, w.color, w.d_alpha, w.d_color, P, ps,
+  hipLaunchKernelGGL(heads_bwd_kernel, eg, dim3(256), head_lds, st, H, n, w.hc, w.color, w.d_alpha, w.d_color, P, ps,
                      (int)off[8], (int)off[12], w.dhead, d_hc, d_h4);
   // head weight grads: d wa = dhead[:,0]^T h4, d Woc = dhead[:,1:4]^T hc; biases = column sums of dhead
-  wgrad(st, K, 1, H, n, w.dhead, 1, 4, n * 4, w.h4, H, 1, nH, G + off[8], H, ps);
-  wgrad(st, K, 3, H, n, w.dhead + 1, 1, 4, n * 4, w.hc, H, 1, nH, G + off[12], H, ps);
-  colsum(st, K, n, 1, w.dhead, 4L, n * 4, G + off[9], ps);
-  colsum(st, K, n, 3, w.dhead + 1, 4L, n * 4, G + off[13], ps);
-  (void)hipMemsetAsync(w.d_emb, 0, (size_t)K * n * EM * 4, st);
+  // (every bias gradient rides on its layer's weight-gradient GEMM: row sums of the d-output operand tile)
+  wgrad(st, K, 1, H, n, w.dhead, 1, 4, n * 4, w.h4, H, 1, nH, G + off[8], H, ps, G + off[9]);
+  wgrad(st, K, 3, H, n, w.dhead + 1, 1, 4, n * 4, w.hc, H, 1, nH, G + off[12], H, ps, G + off[13]);
+  // d_emb needs no zero fill: the first dgrad into each column block overwrites (x2: feature layer if
+  // present, else colour layer; x1: cat layer), later ones accumulate; columns 0..2 (d t) are never read.
   if (feat) {
     // d_hf = relu'(hf) (d_clip W_of); d W_of = d_clip^T hf; d b_of = colsum(d_clip)
     float* d_hf = w.clip;   // reuse: clip [n][C] is dead after the loss; d_hf lives there with batch pitch n*C
     gemm(st, K, n, H, C, w.d_clip, C, 1, n * C, P + off[16], H, 1, ps, d_hf, H, 1, n * C, false, nullptr, 0, false, w.hf,
          H, 1, nH);
-    wgrad(st, K, C, H, n, w.d_clip, 1, C, n * C, w.hf, H, 1, nH, G + off[16], H, ps);
-    colsum(st, K, n, C, w.d_clip, (long)C, n * C,
-                       G + off[17], ps);
+    wgrad(st, K, C, H, n, w.d_clip, 1, C, n * C, w.hf, H, 1, nH, G + off[16], H, ps, G + off[17]);
     // feature layer: grads + contributions to d_h4 / d_x2
-    wgrad(st, K, H, H, n, d_hf, 1, H, n * C, w.h4, H, 1, nH, G + off[14], H + E2, ps);
+    wgrad(st, K, H, H, n, d_hf, 1, H, n * C, w.h4, H, 1, nH, G + off[14], H + E2, ps, G + off[15]);
     wgrad(st, K, H, E2, n, d_hf, 1, H, n * C, w.emb + E1, EM, 1, n * EM, G + off[14] + H, H + E2, ps);
-    colsum(st, K, n, H, d_hf, (long)H, n * C,
-                       G + off[15], ps);
     gemm(st, K, n, H, H, d_hf, H, 1, n * C, P + off[14], H + E2, 1, ps, d_h4, H, 1, nH, true);
-    gemm(st, K, n, E2, H, d_hf, H, 1, n * C, P + off[14] + H, H + E2, 1, ps, w.d_emb + E1, EM, 1, n * EM, true);
+    gemm(st, K, n, E2, H, d_hf, H, 1, n * C, P + off[14] + H, H + E2, 1, ps, w.d_emb + E1, EM, 1, n * EM, false);
   }
   // colour layer
-  wgrad(st, K, H, H, n, d_hc, 1, H, nH, w.h4, H, 1, nH, G + off[10], H + E2, ps);
+  wgrad(st, K, H, H, n, d_hc, 1, H, nH, w.h4, H, 1, nH, G + off[10], H + E2, ps, G + off[11]);
   wgrad(st, K, H, E2, n, d_hc, 1, H, nH, w.emb + E1, EM, 1, n * EM, G + off[10] + H, H + E2, ps);
-  colsum(st, K, n, H, d_hc, (long)H, nH, G + off[11], ps);
   gemm(st, K, n, H, H, d_hc, H, 1, nH, P + off[10], H + E2, 1, ps, d_h4, H, 1, nH, true, nullptr, 0, false, w.h4, H, 1, nH);
-  gemm(st, K, n, E2, H, d_hc, H, 1, nH, P + off[10] + H, H + E2, 1, ps, w.d_emb + E1, EM, 1, n * EM, true);
+  gemm(st, K, n, E2, H, d_hc, H, 1, nH, P + off[10] + H, H + E2, 1, ps, w.d_emb + E1, EM, 1, n * EM, feat);
   // mid2:  d_h4 (masked above) -> grads, d_h3
   float* d_h3 = w.dA;     // d_hc is dead
-  wgrad(st, K, H, H, n, d_h4, 1, H, nH, w.h3, H, 1, nH, G + off[6], H, ps);
-  colsum(st, K, n, H, d_h4, (long)H, nH, G + off[7], ps);
+  wgrad(st, K, H, H, n, d_h4, 1, H, nH, w.h3, H, 1, nH, G + off[6], H, ps, G + off[7]);
   gemm(st, K, n, H, H, d_h4, H, 1, nH, P + off[6], H, 1, ps, d_h3, H, 1, nH, false, nullptr, 0, false, w.h3, H, 1, nH);
   // cat layer
   float* d_h2 = w.dB_;    // d_h4 is dead
-  wgrad(st, K, H, H, n, d_h3, 1, H, nH, w.h2, H, 1, nH, G + off[4], H + E1, ps);
+  wgrad(st, K, H, H, n, d_h3, 1, H, nH, w.h2, H, 1, nH, G + off[4], H + E1, ps, G + off[5]);
   wgrad(st, K, H, E1, n, d_h3, 1, H, nH, w.emb, EM, 1, n * EM, G + off[4] + H, H + E1, ps);
-  colsum(st, K, n, H, d_h3, (long)H, nH, G + off[5], ps);
   gemm(st, K, n, H, H, d_h3, H, 1, nH, P + off[4], H + E1, 1, ps, d_h2, H, 1, nH, false, nullptr, 0, false, w.h2, H, 1, nH);
-  gemm(st, K, n, E1, H, d_h3, H, 1, nH, P + off[4] + H, H + E1, 1, ps, w.d_emb, EM, 1, n * EM, true);
+  gemm(st, K, n, E1, H, d_h3, H, 1, nH, P + off[4] + H, H + E1, 1, ps, w.d_emb, EM, 1, n * EM, false);
   // mid1
   float* d_h1 = w.dA;     // d_h3 is dead
-  wgrad(st, K, H, H, n, d_h2, 1, H, nH, w.h1, H, 1, nH, G + off[2], H, ps);
-  colsum(st, K, n, H, d_h2, (long)H, nH, G + off[3], ps);
+  wgrad(st, K, H, H, n, d_h2, 1, H, nH, w.h1, H, 1, nH, G + off[2], H, ps, G + off[3]);
   gemm(st, K, n, H, H, d_h2, H, 1, nH, P + off[2], H, 1, ps, d_h1, H, 1, nH, false, nullptr, 0, false, w.h1, H, 1, nH);
   // in layer
-  wgrad(st, K, H, E1, n, d_h1, 1, H, nH, w.emb, EM, 1, n * EM, G + off[0], E1, ps);
-  colsum(st, K, n, H, d_h1, (long)H, nH, G + off[1], ps);
+  wgrad(st, K, H, E1, n, d_h1, 1, H, nH, w.emb, EM, 1, n * EM, G + off[0], E1, ps, G + off[1]);
   gemm(st, K, n, E1, H, d_h1, H, 1, nH, P + off[0], E1, 1, ps, w.d_emb, EM, 1, n * EM, true);
   // embedding directions
   (void)hipMemsetAsync(w.dBpe, 0, (size_t)K * 64 * 4, st);
-  int pg = (int)((n + 255) / 256);
-  if (pg > 128) pg = 128;
+  int pg = (int)((n + 47) / 48);           // 12 samples per block and pass: at least 4 passes per block
+  if (pg > 1024) pg = 1024;
+  if (pg < 1) pg = 1;
   hipLaunchKernelGGL(pe_bwd_kernel, dim3(pg, K), dim3(256), 0, st, n, P, ps, (int)off[18], a->scale, a->pts, w.d_emb,
                      w.dBpe);
   hipLaunchKernelGGL(copy_cols_kernel, dim3((unsigned)((K * 63 + 255) / 256)), dim3(256), 0, st, (long)K, 63, w.dBpe, 63L,

@@ -102,27 +102,29 @@ __global__ __launch_bounds__(256) void feature_head_kernel(int K, long n, int Hh
 }
 
 // ------------------------------------------------------------------------------------------------
-// embedding.py:46-55, one thread per point.
+// embedding.py:46-55, one thread per output entry (coalesced stores; the row pitch is 129 floats).
 // ------------------------------------------------------------------------------------------------
 __global__ void embed_kernel(int K, long N, int n_freqs, const float* params, long p_stride, long off_B,
                              const float* scale, const float* pts, float* out) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int E = 3 + OBJ_NDIR * n_freqs;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int k = blockIdx.y;
-  if (i >= N) return;
+  if (idx >= N * E) return;
+  const long i = idx / E;
+  const int e = (int)(idx - i * E);
   const float* B = params + (long)k * p_stride + off_B;
   const float sc = scale[k];
   const float* p = pts + ((long)k * N + i) * 3;
-  const float t0 = p[0] / sc, t1 = p[1] / sc, t2 = p[2] / sc;
-  const int E = 3 + OBJ_NDIR * n_freqs;
-  float* o = out + ((long)k * N + i) * E;
-  o[0] = t0; o[1] = t1; o[2] = t2;
-  for (int j = 0; j < OBJ_NDIR; ++j) {
+  float v;
+  if (e < 3) {
+    v = p[e] / sc;
+  } else {
+    const float t0 = p[0] / sc, t1 = p[1] / sc, t2 = p[2] / sc;
+    const int f = (e - 3) / OBJ_NDIR, j = (e - 3) - f * OBJ_NDIR;
     const float pj = fmaf(t2, B[3 * j + 2], fmaf(t1, B[3 * j + 1], t0 * B[3 * j]));
-    for (int f = 0; f < n_freqs; ++f) {
-      const float arg = (pj * (float)(1 << f)) * OBJ_PI_F;
-      o[3 + f * OBJ_NDIR + j] = sin_acc(arg);
-    }
+    v = sin_acc((pj * (float)(1 << f)) * OBJ_PI_F);
   }
+  out[(long)k * N * E + idx] = v;
 }
 
 // render_rays.py:6-14 (distances=None branch): occ = sigmoid(alpha)
@@ -470,7 +472,8 @@ int objnerf_embed(const objnerf_net* net, int32_t K, int64_t N, const float* par
   if (!net || !params || !scale || !pts || !out_emb || K <= 0 || N <= 0) return OBJNERF_EINVAL;
   int64_t offs[OBJNERF_N_TENSORS + 1];
   if (objnerf_param_layout(net, offs) < 0) return OBJNERF_EINVAL;
-  dim3 grid((unsigned)((N + 255) / 256), (unsigned)K);
+  const long total = (long)N * (3 + OBJ_NDIR * net->n_freqs);
+  dim3 grid((unsigned)((total + 255) / 256), (unsigned)K);
   hipLaunchKernelGGL(embed_kernel, grid, dim3(256), 0, (hipStream_t)stream, K, (long)N, net->n_freqs, params,
                      (long)p_stride, (long)offs[OBJNERF_T_PE_B], scale, pts, out_emb);
   CHECK_LAUNCH();
