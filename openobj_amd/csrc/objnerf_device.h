@@ -93,28 +93,83 @@ __device__ __forceinline__ void slot_accum16(float& acc, const float v, const in
   asm volatile("" : "+v"(acc));   // consume the row sum NOW (deferred adds keep dozens of partial sums live)
 }
 
-// Segmented (segment = `seg` consecutive lanes starting at multiples of seg) inclusive scans.
-__device__ __forceinline__ float seg_scan_mul(float v, int pos, int seg) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const float o = __shfl_up(v, d, 64);
-    if (d < seg && pos >= d) v *= o;
-  }
-  return v;
+// Segmented scans over the 64 lanes of a wave; a segment = `seg` consecutive lanes starting at a multiple of seg
+// (one ray of seg samples).  Two interchangeable policies:
+//   SegRows    seg in {16, 32, 64}: row_shr / row_shl DPP steps inside each 16-lane row, rows linked by three
+//              v_readlane broadcasts and per-lane selects fixed at kernel start -- no LDS permutes, no branches.
+//   SegGeneric any seg (the reference's native 10 / 14 samples per ray): ds_bpermute shuffles.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(const float old, const float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
+                                                              CTRL, 0xF, 0xF, false));
 }
-__device__ __forceinline__ float seg_scan_add(float v, int pos, int seg) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const float o = __shfl_up(v, d, 64);
-    if (d < seg && pos >= d) v += o;
-  }
-  return v;
+__device__ __forceinline__ float lane_bcast(const float v, const int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
-__device__ __forceinline__ float seg_rscan_add(float v, int pos, int seg) {   // suffix inclusive
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const float o = __shfl_down(v, d, 64);
-    if (d < seg && pos + d < seg) v += o;
+__device__ __forceinline__ bool seg_is_rows(const int seg) { return seg == 64 || seg == 32 || seg == 16; }
+
+struct SegRows {
+  bool u0, u1, u2;        // forward: this lane's row continues a segment that includes row 0 / 1 / 2's end
+  bool r1, r2, r3;        // reverse: ... that includes the start of row 1 / 2 / 3
+  bool m0, m1, m2, m3;    // row i belongs to this lane's segment
+  __device__ __forceinline__ static SegRows make(const int seg, const int lane) {
+    const int row = lane >> 4, sid = (16 * row) / seg;
+    SegRows s;
+    s.m0 = sid == 0; s.m1 = (16 / seg) == sid; s.m2 = (32 / seg) == sid; s.m3 = (48 / seg) == sid;
+    s.u0 = s.m0 && row > 0; s.u1 = s.m1 && row > 1; s.u2 = s.m2 && row > 2;
+    s.r1 = s.m1 && row < 1; s.r2 = s.m2 && row < 2; s.r3 = s.m3 && row < 3;
+    return s;
   }
-  return v;
-}
+  __device__ __forceinline__ float scan_mul(float v, int) const {
+    v *= dpp_mov<0x111>(1.0f, v); v *= dpp_mov<0x112>(1.0f, v); v *= dpp_mov<0x114>(1.0f, v); v *= dpp_mov<0x118>(1.0f, v);
+    const float t0 = lane_bcast(v, 15), t1 = lane_bcast(v, 31), t2 = lane_bcast(v, 47);
+    return v * (((u0 ? t0 : 1.0f) * (u1 ? t1 : 1.0f)) * (u2 ? t2 : 1.0f));
+  }
+  __device__ __forceinline__ float scan_add(float v, int) const {
+    v += dpp_mov<0x111>(0.0f, v); v += dpp_mov<0x112>(0.0f, v); v += dpp_mov<0x114>(0.0f, v); v += dpp_mov<0x118>(0.0f, v);
+    const float t0 = lane_bcast(v, 15), t1 = lane_bcast(v, 31), t2 = lane_bcast(v, 47);
+    return v + (((u0 ? t0 : 0.0f) + (u1 ? t1 : 0.0f)) + (u2 ? t2 : 0.0f));
+  }
+  __device__ __forceinline__ float total_add(const float v, int) const {     // segment sum on every lane
+    const float rs = dpp_rowsum16(v);
+    const float q0 = lane_bcast(rs, 0), q1 = lane_bcast(rs, 16), q2 = lane_bcast(rs, 32), q3 = lane_bcast(rs, 48);
+    return ((m0 ? q0 : 0.0f) + (m1 ? q1 : 0.0f)) + ((m2 ? q2 : 0.0f) + (m3 ? q3 : 0.0f));
+  }
+  __device__ __forceinline__ float rscan_add(float v, int) const {            // suffix inclusive
+    v += dpp_mov<0x101>(0.0f, v); v += dpp_mov<0x102>(0.0f, v); v += dpp_mov<0x104>(0.0f, v); v += dpp_mov<0x108>(0.0f, v);
+    const float t1 = lane_bcast(v, 16), t2 = lane_bcast(v, 32), t3 = lane_bcast(v, 48);
+    return v + ((r1 ? t1 : 0.0f) + ((r2 ? t2 : 0.0f) + (r3 ? t3 : 0.0f)));
+  }
+};
+
+struct SegGeneric {
+  int seg;
+  __device__ __forceinline__ float scan_mul(float v, const int pos) const {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const float o = __shfl_up(v, d, 64);
+      if (d < seg && pos >= d) v *= o;
+    }
+    return v;
+  }
+  __device__ __forceinline__ float scan_add(float v, const int pos) const {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const float o = __shfl_up(v, d, 64);
+      if (d < seg && pos >= d) v += o;
+    }
+    return v;
+  }
+  __device__ __forceinline__ float total_add(const float v, const int pos) const {
+    const int last = (int)(threadIdx.x & 63) - pos + seg - 1;
+    return __shfl(scan_add(v, pos), last, 64);
+  }
+  __device__ __forceinline__ float rscan_add(float v, const int pos) const {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const float o = __shfl_down(v, d, 64);
+      if (d < seg && pos + d < seg) v += o;
+    }
+    return v;
+  }
+};

@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void composite_kernel(long n_rays, int S, int 
     const float al = on ? alpha[ray * S + s] : 0.f;
     const float occ = on ? (in_is_occ ? al : sigmoid_acc(al)) : 0.f;
     const float fr = on ? (1.0f - occ) + 1e-10f : 1.0f;
-    const float pinc = seg_scan_mul(fr, lane, 64) * carry;
+    const float pinc = SegRows::make(64, lane).scan_mul(fr, lane) * carry;
     float T = __shfl_up(pinc, 1, 64);
     if (lane == 0) T = carry;
     carry = __shfl(pinc, 63, 64);
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void loss_kernel(const LossDev a) {
     const bool on = s < S;
     const float occ = on ? sigmoid_acc(a.alpha[rr * S + s]) : 0.f;
     const float fr = on ? (1.0f - occ) + 1e-10f : 1.0f;
-    const float pinc = seg_scan_mul(fr, lane, 64) * carry;
+    const float pinc = SegRows::make(64, lane).scan_mul(fr, lane) * carry;
     float T = __shfl_up(pinc, 1, 64);
     if (lane == 0) T = carry;
     carry = __shfl(pinc, 63, 64);
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void loss_kernel(const LossDev a) {
     const float zz = on ? a.z[rr * S + s] : 0.f;
     const float dw = on ? gD * zz + gO + gC0 * c0 + gC1 * c1 + gC2 * c2 + dwv[s] : 0.f;
     const float qv = dw * wt;
-    const float inc = seg_rscan_add(qv, lane, 64);
+    const float inc = SegRows::make(64, lane).rscan_add(qv, lane);
     const float suf = inc - qv + sufc;
     sufc += __shfl(inc, 0, 64);
     if (on) {

@@ -171,6 +171,31 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
 #define wt_cat (lds + OFF_CAT + (4 * g) * ST_CAT + c)
 #define wt_m2 (lds + OFF_M2 + (4 * g) * ST_M + c)
 #define wt_cl (lds + OFF_CL + (4 * g) * ST_CL + c)
+  // sample position of (tile, slot); issued one tile ahead (phase C) so that the HBM latency is off the tile's
+  // critical path
+  auto fetch_point = [&](const int tile_, const int slot_, float& x, float& y, float& z_) {
+    const int q_ = slot_ / a.S, si_ = slot_ - q_ * a.S;
+    const int ray_ = tile_ * a.TR + q_;
+    x = 0.f; y = 0.f; z_ = 0.f;
+    if (tile_ < a.NT && q_ < a.TR && ray_ < a.R) {
+      const long rr = (long)k * a.R + ray_;
+      if (a.pts) {
+        const float* p = a.pts + (rr * a.S + si_) * 3;
+        x = p[0]; y = p[1]; z_ = p[2];
+      } else {
+        const float zz = a.z[rr * a.S + si_];
+        const float* o = a.origins + rr * 3;
+        const float* d = a.dirs + rr * 3;
+        x = (o[0] + d[0] * zz) - a.obj_center;   // vmap.py:548-551 (two roundings: -ffp-contract=off)
+        y = (o[1] + d[1] * zz) - a.obj_center;
+        z_ = (o[2] + d[2] * zz) - a.obj_center;
+      }
+    }
+  };
+  const bool rows_mode = seg_is_rows(a.S);
+  const SegRows seg_rows = SegRows::make(rows_mode ? a.S : 64, lane);
+  float nx, ny, nz;
+  fetch_point(gi, 16 * w + lane_l % 16, nx, ny, nz);
   PT_INIT();
   for (int tile = gi; tile < a.NT; tile += a.G) {
     asm volatile("" ::: "memory");   // keep the LDS weight reads inside the loop (no LICM into registers)
@@ -178,24 +203,10 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
     const int ray0 = tile * TR;
     // ---------------------------------------------------------------- 1. forward
     const int slot = 16 * w + c;
-    const int q = slot / S, si = slot - q * S;
+    const int q = slot / S;
     const int ray = ray0 + q;
     const bool valid = (q < TR) && (ray < R);
-    float px = 0.f, py = 0.f, pz = 0.f;
-    if (valid) {
-      const long rr = (long)k * R + ray;
-      if (a.pts) {
-        const float* p = a.pts + (rr * S + si) * 3;
-        px = p[0]; py = p[1]; pz = p[2];
-      } else {
-        const float zz = a.z[rr * S + si];
-        const float* o = a.origins + rr * 3;
-        const float* d = a.dirs + rr * 3;
-        px = (o[0] + d[0] * zz) - a.obj_center;   // vmap.py:548-551 (two roundings: -ffp-contract=off)
-        py = (o[1] + d[1] * zz) - a.obj_center;
-        pz = (o[2] + d[2] * zz) - a.obj_center;
-      }
-    }
+    const float px = nx, py = ny, pz = nz;       // fetched during the previous tile's phase C
     Pe pe;
     pe_project(lds, g, px, py, pz, scale, pe);
     PT(0);
@@ -225,11 +236,29 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
         else stg[OFF_GBUF + 32 * 33 + (i - 1024)] = v;
       }
     }
+    // ray inputs of this wave's compositing pass, requested BEFORE the barrier so their latency hides behind it
+    auto ray_inputs = [&](const int ps_, float& zz_, float& gtd_, float& gr_, float& gg_, float& gb_, int& lab_) {
+      const int rpp_ = 64 / S;
+      const int ql_ = lane / S, pos_ = lane - ql_ * S;
+      const int qq_ = ps_ * rpp_ + ql_;
+      const int rayq_ = ray0 + qq_;
+      zz_ = 0.f; gtd_ = 0.f; gr_ = 0.f; gg_ = 0.f; gb_ = 0.f; lab_ = 2;
+      if ((ql_ < rpp_) && (qq_ < TR) && (rayq_ < R)) {
+        const long rr = (long)k * R + rayq_;
+        zz_ = a.z[rr * S + pos_];
+        gtd_ = a.gt_depth[rr];
+        gr_ = a.gt_rgb[rr * 3]; gg_ = a.gt_rgb[rr * 3 + 1]; gb_ = a.gt_rgb[rr * 3 + 2];
+        lab_ = a.labels[rr];
+      }
+    };
+    float pf_zz = 0.f, pf_gtd = 0.f, pf_gr = 0.f, pf_gg = 0.f, pf_gb = 0.f;
+    int pf_lab = 2;
+    if (w * (64 / S) < TR) ray_inputs(w, pf_zz, pf_gtd, pf_gr, pf_gg, pf_gb, pf_lab);
     TILE_SYNC();
     RELAUNDER();
     PT(3);
     // ---------------------------------------------------------------- 2. composite + loss (loss.py:27-101)
-    {
+    auto composite_passes = [&](const auto& sg) {
       const int rpp = 64 / S;                       // rays per wave pass
 #ifdef ABL_NO_COMPOSITE
       const int npass = 0;
@@ -242,31 +271,24 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
         const int rayq = ray0 + qq;
         const bool on = (ql < rpp) && (qq < TR) && (rayq < R);
         const int sl = qq * S + pos;
-        float al = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, zz = 0.f;
-        float gtd = 0.f, gr = 0.f, gg = 0.f, gb = 0.f;
-        int lab = 2;
-        if (on) {
-          const long rr = (long)k * R + rayq;
-          al = s_alpha[sl]; c0 = s_col[sl]; c1 = s_col[TS + sl]; c2 = s_col[2 * TS + sl];
-          zz = a.z[rr * S + pos];
-          gtd = a.gt_depth[rr];
-          gr = a.gt_rgb[rr * 3]; gg = a.gt_rgb[rr * 3 + 1]; gb = a.gt_rgb[rr * 3 + 2];
-          lab = a.labels[rr];
-        }
+        float al = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, zz = pf_zz;
+        float gtd = pf_gtd, gr = pf_gr, gg = pf_gg, gb = pf_gb;
+        int lab = pf_lab;
+        if (ps != w) ray_inputs(ps, zz, gtd, gr, gg, gb, lab);      // (only when a tile has more than 8 passes)
+        if (on) { al = s_alpha[sl]; c0 = s_col[sl]; c1 = s_col[TS + sl]; c2 = s_col[2 * TS + sl]; }
         const float occ = on ? sigmoid_acc(al) : 0.0f;               // render_rays.py:13
         const float fr = on ? (1.0f - occ) + 1e-10f : 1.0f;          // render_rays.py:38
-        const float Pinc = seg_scan_mul(fr, pos, S);
+        const float Pinc = sg.scan_mul(fr, pos);
         float T = __shfl_up(Pinc, 1, 64);
         if (pos == 0) T = 1.0f;
         const float wgt = occ * T;                                   // render_rays.py:43
-        const int last = lane - pos + S - 1;
-        const float D = __shfl(seg_scan_add(wgt * zz, pos, S), last, 64);       // loss.py:31
-        const float O = __shfl(seg_scan_add(wgt, pos, S), last, 64);            // loss.py:35
-        const float C0 = __shfl(seg_scan_add(wgt * c0, pos, S), last, 64);      // loss.py:34
-        const float C1 = __shfl(seg_scan_add(wgt * c1, pos, S), last, 64);
-        const float C2 = __shfl(seg_scan_add(wgt * c2, pos, S), last, 64);
+        const float D = sg.total_add(wgt * zz, pos);       // loss.py:31
+        const float O = sg.total_add(wgt, pos);            // loss.py:35
+        const float C0 = sg.total_add(wgt * c0, pos);      // loss.py:34
+        const float C1 = sg.total_add(wgt * c1, pos);
+        const float C2 = sg.total_add(wgt * c2, pos);
         const float dz = zz - D;
-        const float V = __shfl(seg_scan_add(wgt * (dz * dz), pos, S), last, 64);  // loss.py:32-33
+        const float V = sg.total_add(wgt * (dz * dz), pos);  // loss.py:32-33
         const float m1 = (lab == 1) ? 1.0f : 0.0f;                   // mask_sem & mask_obj
         const float m2 = (lab != 2) ? 1.0f : 0.0f;                   // mask_sem
         const float tgt = (lab != 0) ? 1.0f : 0.0f;                  // mask_obj.float()
@@ -349,7 +371,7 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
           }
         }
         const float qv = dw * wgt;
-        const float suf = seg_rscan_add(qv, pos, S) - qv;            // sum_{j>i} dL/dw_j * w_j
+        const float suf = sg.rscan_add(qv, pos) - qv;            // sum_{j>i} dL/dw_j * w_j
         const float docc = dw * T - suf / fr;
         if (on) {                                                    // in place: this lane owns slot sl
           s_alpha[sl] = 10.0f * (docc * occ * (1.0f - occ));         // d / d raw alpha (model.py:88)
@@ -358,7 +380,8 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
           s_col[2 * TS + sl] = gC2 * wgt * c2 * (1.0f - c2);
         }
       }
-    }
+    };
+    if (rows_mode) composite_passes(seg_rows); else composite_passes(SegGeneric{S});
     PT(4);
     TILE_SYNC();
     RELAUNDER();
@@ -517,6 +540,7 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
     TILE_SYNC();
     RELAUNDER();
     // ---- phase C: in layer (x1 stays at rows 32..127) + mid1.  h1 rows 0.., d_h1pre 128.., d_h2pre 160..
+    fetch_point(tile + a.G, slot, nx, ny, nz);
     store_T32(stg_lane, 0, act.h1);
     store_T32(stg_lane, 128, d_h1);
     store_T32(stg_lane, 160, d_h2);

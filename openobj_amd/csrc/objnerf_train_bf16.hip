@@ -224,6 +224,8 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
   const char* t_m2 = ldsb + T_M2 + c * RST + 16 * g;
   const char* t_cl = ldsb + T_CL + c * RST + 16 * g;
 
+  const bool rows_mode = seg_is_rows(a.S);
+  const SegRows seg_rows = SegRows::make(rows_mode ? a.S : 64, lane);
   for (int tile = gi; tile < a.NT; tile += a.G) {
     asm volatile("" ::: "memory");
     const int ray0 = tile * TR;
@@ -305,9 +307,27 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
       s_col[TS + slot] = col_v[1];
       s_col[2 * TS + slot] = col_v[2];
     }
+    // ray inputs of this wave's compositing pass, requested BEFORE the barrier so their latency hides behind it
+    auto ray_inputs = [&](const int ps_, float& zz_, float& gtd_, float& gr_, float& gg_, float& gb_, int& lab_) {
+      const int rpp_ = 64 / S;
+      const int ql_ = lane / S, pos_ = lane - ql_ * S;
+      const int qq_ = ps_ * rpp_ + ql_;
+      const int rayq_ = ray0 + qq_;
+      zz_ = 0.f; gtd_ = 0.f; gr_ = 0.f; gg_ = 0.f; gb_ = 0.f; lab_ = 2;
+      if ((ql_ < rpp_) && (qq_ < TR) && (rayq_ < R)) {
+        const long rr = (long)k * R + rayq_;
+        zz_ = a.z[rr * S + pos_];
+        gtd_ = a.gt_depth[rr];
+        gr_ = a.gt_rgb[rr * 3]; gg_ = a.gt_rgb[rr * 3 + 1]; gb_ = a.gt_rgb[rr * 3 + 2];
+        lab_ = a.labels[rr];
+      }
+    };
+    float pf_zz = 0.f, pf_gtd = 0.f, pf_gr = 0.f, pf_gg = 0.f, pf_gb = 0.f;
+    int pf_lab = 2;
+    if (w * (64 / S) < TR) ray_inputs(w, pf_zz, pf_gtd, pf_gr, pf_gg, pf_gb, pf_lab);
     __syncthreads();
     // ---------------------------------------------------------------- 2. composite + loss (fp32, as objnerf_train.hip)
-    {
+    auto composite_passes = [&](const auto& sg) {
       const int rpp = 64 / S;
       const int npass = (TR + rpp - 1) / rpp;
       for (int ps = w; ps < npass; ps += NWAVE) {
@@ -316,31 +336,24 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
         const int rayq = ray0 + qq;
         const bool on = (ql < rpp) && (qq < TR) && (rayq < R);
         const int sl = qq * S + pos;
-        float al = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, zz = 0.f;
-        float gtd = 0.f, gr = 0.f, gg = 0.f, gb = 0.f;
-        int lab = 2;
-        if (on) {
-          const long rr = (long)k * R + rayq;
-          al = s_alpha[sl]; c0 = s_col[sl]; c1 = s_col[TS + sl]; c2 = s_col[2 * TS + sl];
-          zz = a.z[rr * S + pos];
-          gtd = a.gt_depth[rr];
-          gr = a.gt_rgb[rr * 3]; gg = a.gt_rgb[rr * 3 + 1]; gb = a.gt_rgb[rr * 3 + 2];
-          lab = a.labels[rr];
-        }
+        float al = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, zz = pf_zz;
+        float gtd = pf_gtd, gr = pf_gr, gg = pf_gg, gb = pf_gb;
+        int lab = pf_lab;
+        if (ps != w) ray_inputs(ps, zz, gtd, gr, gg, gb, lab);      // (only when a tile has more than 8 passes)
+        if (on) { al = s_alpha[sl]; c0 = s_col[sl]; c1 = s_col[TS + sl]; c2 = s_col[2 * TS + sl]; }
         const float occ = on ? sigmoid_acc(al) : 0.0f;
         const float fr = on ? (1.0f - occ) + 1e-10f : 1.0f;
-        const float Pinc = seg_scan_mul(fr, pos, S);
+        const float Pinc = sg.scan_mul(fr, pos);
         float T = __shfl_up(Pinc, 1, 64);
         if (pos == 0) T = 1.0f;
         const float wgt = occ * T;
-        const int last = lane - pos + S - 1;
-        const float D = __shfl(seg_scan_add(wgt * zz, pos, S), last, 64);
-        const float O = __shfl(seg_scan_add(wgt, pos, S), last, 64);
-        const float C0 = __shfl(seg_scan_add(wgt * c0, pos, S), last, 64);
-        const float C1 = __shfl(seg_scan_add(wgt * c1, pos, S), last, 64);
-        const float C2 = __shfl(seg_scan_add(wgt * c2, pos, S), last, 64);
+        const float D = sg.total_add(wgt * zz, pos);
+        const float O = sg.total_add(wgt, pos);
+        const float C0 = sg.total_add(wgt * c0, pos);
+        const float C1 = sg.total_add(wgt * c1, pos);
+        const float C2 = sg.total_add(wgt * c2, pos);
         const float dz = zz - D;
-        const float V = __shfl(seg_scan_add(wgt * (dz * dz), pos, S), last, 64);
+        const float V = sg.total_add(wgt * (dz * dz), pos);
         const float m1 = (lab == 1) ? 1.0f : 0.0f;
         const float m2 = (lab != 2) ? 1.0f : 0.0f;
         const float tgt = (lab != 0) ? 1.0f : 0.0f;
@@ -359,7 +372,7 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
         }
         const float dw = gD * zz + gO + gC0 * c0 + gC1 * c1 + gC2 * c2;
         const float qv = dw * wgt;
-        const float suf = seg_rscan_add(qv, pos, S) - qv;
+        const float suf = sg.rscan_add(qv, pos) - qv;
         const float docc = dw * T - suf / fr;
         if (on) {
           s_alpha[sl] = 10.0f * (docc * occ * (1.0f - occ));
@@ -368,7 +381,8 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
           s_col[2 * TS + sl] = gC2 * wgt * c2 * (1.0f - c2);
         }
       }
-    }
+    };
+    if (rows_mode) composite_passes(seg_rows); else composite_passes(SegGeneric{S});
     __syncthreads();
     // ---------------------------------------------------------------- 3. backward
     const float da = valid ? s_alpha[slot] : 0.0f;
