@@ -1,0 +1,22 @@
+#!/bin/bash
+# Run ON THE GPU BOX (gpurun): refresh the rocprofv3 evidence for profiles/ (kernel stats + PMC passes).
+# Counters are collected in their own passes with --kernel-trace only (never with sys/hip trace domains).
+set -x
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/prof
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_default -o s -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_default.json 2> $OUT/bench_default.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_feat -o s -- python3 $R/bench.py --feat --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_feat.json 2> $OUT/bench_feat.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- python3 $R/bench.py --no-bg --no-bf16-line --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- python3 $R/bench.py --no-bg --no-bf16-line --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_write.err
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INST_CYCLES_VMEM SQ_INSTS_VALU --output-format csv -d $OUT/pmc_sq -o p -- python3 $R/bench.py --no-bg --no-bf16-line --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_sq.err
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmc_sq2 -o p -- python3 $R/bench.py --no-bg --no-bf16-line --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_sq2.err
+python3 $R/bench.py --no-bg --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_nobg.json 2>/dev/null
+python3 $R/bench.py > $OUT/bench_full.json 2>/dev/null
+for d in pmc_fetch pmc_write pmc_sq pmc_sq2; do
+  f=$(ls $OUT/$d/*counter_collection.csv 2>/dev/null | head -1)
+  [ -n "$f" ] && python3 $R/tools/pmc_summary.py $f train_fused > $OUT/$d.txt
+done
+rm -f $OUT/*/*kernel_trace.csv $OUT/pmc_*/*counter_collection.csv   # large; the summaries above are what is kept
+ls -la $OUT $OUT/*
