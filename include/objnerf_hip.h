@@ -93,6 +93,23 @@ typedef struct objnerf_sample_args {
 int objnerf_sample_rays(const objnerf_sample_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * f-1  Trainer.sample_points_bbox (trainer.py:130-198), the sampler of render_2D_syn (vmap.py:604-685).
+ * objnerf_box_rays: P camera rays dirs_C [P][3] (un-normalised, rays_dir_cache[pixels]) of ONE view against an
+ *   oriented box: T_WC, T_OC = inverse(T_WO) @ T_WC (both [4][4] row-major, computed by the caller as
+ *   trainer.py:152-157 does), half = extent / 2.  Outputs: dirs_W [P][3] (origin_dirs_W, utils.py:324-336),
+ *   near [P] (clipped at 0), far [P] (+0.2, :166-167), hit [P] u8 (ray_box_intersection, utils.py:309-319).
+ * objnerf_box_points: for the n hit rays (compacted by the caller): z_vals [n][n_bins-1] = mid-points of
+ *   stratified_bins(near, far, n_bins) with the injected draw u [n][n_bins] (utils.py:342-379, trainer.py:171-175)
+ *   and pts [n][n_bins-1][3] = origin + dirs_W * z (:176).
+ */
+int objnerf_box_rays(int64_t P, const float* T_WC, const float* T_OC, const float* half_extent,
+                     const float* dirs_C, float* out_dirs_W, float* out_near, float* out_far,
+                     uint8_t* out_hit, void* stream);
+int objnerf_box_points(int64_t n, int32_t n_bins, const float* origin /* [3] */, const float* dirs_W,
+                       const float* near, const float* far, const float* u, float* out_z, float* out_pts,
+                       void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * A6+A7  UniDirsEmbed.forward + OccupancyMap.forward (embedding.py:46-55, model.py:61-103),
  * inference: K objects x N points each.
  *   params [K][P_stride], scale [K] (pe buffer `scale`), pts [K][N][3]
@@ -103,6 +120,16 @@ int objnerf_sample_rays(const objnerf_sample_args* a, void* stream);
 int objnerf_eval_points(const objnerf_net* net, int32_t K, int64_t N, const float* params,
                         int64_t p_stride, const float* scale, const float* pts, float* out_alpha,
                         float* out_color, float* out_hfeat, float* out_clip, void* stream);
+
+/* The same for ANY hidden width that is a multiple of 32 (the background network of trainer.py:15-17 is 128
+ * wide and is rendered by the same render_2D_syn, vmap.py:644-655): hidden 32 runs the fused kernel above and
+ * needs no workspace; wider networks run layer by layer with activations in the caller's workspace of
+ * objnerf_eval_workspace_bytes(net, K, N) bytes (256-byte aligned). */
+size_t objnerf_eval_workspace_bytes(const objnerf_net* net, int32_t K, int64_t N);
+int objnerf_eval_points_ws(const objnerf_net* net, int32_t K, int64_t N, const float* params,
+                           int64_t p_stride, const float* scale, const float* pts, float* out_alpha,
+                           float* out_color, float* out_hfeat, float* out_clip, void* workspace,
+                           size_t workspace_bytes, void* stream);
 
 /* A7 alone: OccupancyMap.forward on a caller-supplied embedding emb [K][N][129] (model.py:61-103, the
  * call vmap(fc_model)(fc_param, fc_buffer, batch_embedding) of train.py:425).  Outputs as above. */

@@ -81,9 +81,17 @@ SIGNATURES = {
     "objnerf_rays_dirs": (C.c_int, [C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float,
                                     C.c_void_p, C.c_void_p]),
     "objnerf_sample_rays": (C.c_int, [C.POINTER(SampleArgs), C.c_void_p]),
+    "objnerf_box_rays": (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p]),
+    "objnerf_box_points": (C.c_int, [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "objnerf_eval_points": (C.c_int, [C.POINTER(Net), C.c_int32, C.c_int64, C.c_void_p, C.c_int64,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p]),
+    "objnerf_eval_workspace_bytes": (C.c_size_t, [C.POINTER(Net), C.c_int32, C.c_int64]),
+    "objnerf_eval_points_ws": (C.c_int, [C.POINTER(Net), C.c_int32, C.c_int64, C.c_void_p, C.c_int64,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "objnerf_mlp_forward": (C.c_int, [C.POINTER(Net), C.c_int32, C.c_int64, C.c_void_p, C.c_int64,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p]),

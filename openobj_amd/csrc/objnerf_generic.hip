@@ -454,4 +454,54 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a, void* stream
   return OBJNERF_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Inference (embedding.py:46-55 + model.py:61-103) for any hidden width: the forward half of train_step with
+// ping-pong activation buffers.  workspace: emb [K][N][129] | A | B | C  ([K][N][H] each).
+size_t eval_workspace_bytes(const objnerf_net* net, int K, long N) {
+  return al((size_t)K * N * OBJ_EMB * 4) + 3 * al((size_t)K * N * net->hidden * 4) + 256;
+}
+
+int eval_points(const objnerf_net* net, int K, long N, const float* params, long p_stride, const float* scale,
+                const float* pts, float* out_alpha, float* out_color, float* out_hfeat, float* out_clip,
+                void* workspace, size_t workspace_bytes, void* stream) {
+  const int H = net->hidden, C = net->feat_dim;
+  if (H % 32 != 0 || net->n_freqs != 6) return OBJNERF_ENOTSUP;
+  if (!workspace || workspace_bytes < eval_workspace_bytes(net, K, N) - 256) return OBJNERF_EINVAL;
+  int64_t off[OBJNERF_N_TENSORS + 1];
+  objnerf_param_layout(net, off);
+  hipStream_t st = (hipStream_t)stream;
+  char* p = (char*)workspace;
+  float* emb = (float*)p; p += al((size_t)K * N * OBJ_EMB * 4);
+  float* bA = (float*)p;  p += al((size_t)K * N * H * 4);
+  float* bB = (float*)p;  p += al((size_t)K * N * H * 4);
+  float* bC = (float*)p;
+  const float* P = params;
+  const long ps = p_stride, n = N, nH = N * H;
+  const int E1 = OBJ_E1, E2 = OBJ_E2, EM = OBJ_EMB;
+  int rc = objnerf_embed(net, K, N, params, p_stride, scale, pts, emb, stream);
+  if (rc) return rc;
+  float *h1 = bA, *h2 = bB, *h3 = bA, *h4 = bB, *hc = bA;
+  gemm(st, K, n, H, E1, emb, EM, 1, n * EM, P + off[0], 1, E1, ps, h1, H, 1, nH, false, P + off[1], ps, true);
+  gemm(st, K, n, H, H, h1, H, 1, nH, P + off[2], 1, H, ps, h2, H, 1, nH, false, P + off[3], ps, true);
+  gemm(st, K, n, H, H, h2, H, 1, nH, P + off[4], 1, H + E1, ps, h3, H, 1, nH);
+  gemm(st, K, n, H, E1, emb, EM, 1, n * EM, P + off[4] + H, 1, H + E1, ps, h3, H, 1, nH, true, P + off[5], ps, true);
+  gemm(st, K, n, H, H, h3, H, 1, nH, P + off[6], 1, H, ps, h4, H, 1, nH, false, P + off[7], ps, true);
+  gemm(st, K, n, H, H, h4, H, 1, nH, P + off[10], 1, H + E2, ps, hc, H, 1, nH);
+  gemm(st, K, n, H, E2, emb + E1, EM, 1, n * EM, P + off[10] + H, 1, H + E2, ps, hc, H, 1, nH, true, P + off[11], ps,
+       true);
+  dim3 eg((unsigned)((n + 15) / 16), (unsigned)K);
+  hipLaunchKernelGGL(heads_fwd_kernel, eg, dim3(256), (size_t)4 * H * sizeof(float), st, H, n, h4, hc, P, ps,
+                     (int)off[8], (int)off[9], (int)off[12], (int)off[13], out_alpha, out_color);
+  if (out_hfeat || out_clip) {
+    float* hf = out_hfeat ? out_hfeat : bC;
+    gemm(st, K, n, H, H, h4, H, 1, nH, P + off[14], 1, H + E2, ps, hf, H, 1, nH);
+    gemm(st, K, n, H, E2, emb + E1, EM, 1, n * EM, P + off[14] + H, 1, H + E2, ps, hf, H, 1, nH, true, P + off[15], ps,
+         true);
+    if (out_clip)
+      gemm(st, K, n, C, H, hf, H, 1, nH, P + off[16], 1, H, ps, out_clip, C, 1, n * C, false, P + off[17], ps, false);
+  }
+  if (hipGetLastError() != hipSuccess) return OBJNERF_ELAUNCH;
+  return OBJNERF_OK;
+}
+
 }  // namespace objgen

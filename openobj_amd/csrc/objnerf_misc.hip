@@ -380,6 +380,46 @@ __device__ __forceinline__ float strat(float lo, float hi, int i, int n, float u
   return (rng * lin01(i, n) + lo) + u * (rng / (float)n);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Trainer.sample_points_bbox (trainer.py:130-198)
+// ------------------------------------------------------------------------------------------------
+__global__ void box_rays_kernel(long P, const float* T_WC, const float* T_OC, const float* half, const float* dirs_C,
+                                float* dirs_W, float* near_o, float* far_o, uint8_t* hit_o) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  const float d0 = dirs_C[i * 3], d1 = dirs_C[i * 3 + 1], d2 = dirs_C[i * 3 + 2];
+  float nr = -INFINITY, fr = INFINITY;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    // utils.py:324-336: R @ d, products accumulated left to right
+    dirs_W[i * 3 + r] = (T_WC[r * 4] * d0 + T_WC[r * 4 + 1] * d1) + T_WC[r * 4 + 2] * d2;
+    const float dr = (T_OC[r * 4] * d0 + T_OC[r * 4 + 1] * d1) + T_OC[r * 4 + 2] * d2;
+    const float o = T_OC[r * 4 + 3];
+    const float ta = (-half[r] - o) / dr, tb = (half[r] - o) / dr;       // utils.py:311-312
+    nr = fmaxf(nr, fminf(ta, tb));
+    fr = fminf(fr, fmaxf(ta, tb));
+  }
+  hit_o[i] = (nr <= fr) && (fr > 0.f);                                    // :317
+  near_o[i] = fmaxf(nr, 0.f);                                             // trainer.py:166
+  far_o[i] = fr + 0.2f;                                                   // :167
+}
+
+__global__ void box_points_kernel(long n, int n_bins, const float* origin, const float* dirs_W, const float* near_i,
+                                  const float* far_i, const float* u, float* out_z, float* out_pts) {
+  const int S = n_bins - 1;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * S) return;
+  const long r = idx / S;
+  const int s = (int)(idx - r * S);
+  const float lo = near_i[r], hi = far_i[r];
+  const float z0 = strat(lo, hi, s, n_bins, u[r * n_bins + s]);
+  const float z1 = strat(lo, hi, s + 1, n_bins, u[r * n_bins + s + 1]);
+  const float z = 0.5f * (z1 + z0);                                       // trainer.py:175
+  out_z[idx] = z;
+#pragma unroll
+  for (int x = 0; x < 3; ++x) out_pts[idx * 3 + x] = origin[x] + dirs_W[r * 3 + x] * z;   // :176
+}
+
 __global__ void sample_place_kernel(const objnerf_sample_args a, const float* origins_ws, const float* dirs_ws) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = a.n_frames * a.n_px;
@@ -548,6 +588,28 @@ int objnerf_rays_dirs(int32_t W, int32_t H, float fx, float fy, float cx, float 
   const long n = (long)W * H;
   hipLaunchKernelGGL(rays_dirs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, H, fx,
                      fy, cx, cy, out);
+  CHECK_LAUNCH();
+  return OBJNERF_OK;
+}
+
+int objnerf_box_rays(int64_t P, const float* T_WC, const float* T_OC, const float* half_extent, const float* dirs_C,
+                     float* out_dirs_W, float* out_near, float* out_far, uint8_t* out_hit, void* stream) {
+  CLEAR_STALE();
+  if (P <= 0 || !T_WC || !T_OC || !half_extent || !dirs_C || !out_dirs_W || !out_near || !out_far || !out_hit)
+    return OBJNERF_EINVAL;
+  hipLaunchKernelGGL(box_rays_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (long)P, T_WC,
+                     T_OC, half_extent, dirs_C, out_dirs_W, out_near, out_far, out_hit);
+  CHECK_LAUNCH();
+  return OBJNERF_OK;
+}
+
+int objnerf_box_points(int64_t n, int32_t n_bins, const float* origin, const float* dirs_W, const float* near,
+                       const float* far, const float* u, float* out_z, float* out_pts, void* stream) {
+  CLEAR_STALE();
+  if (n <= 0 || n_bins < 2 || !origin || !dirs_W || !near || !far || !u || !out_z || !out_pts) return OBJNERF_EINVAL;
+  const long total = (long)n * (n_bins - 1);
+  hipLaunchKernelGGL(box_points_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (long)n,
+                     n_bins, origin, dirs_W, near, far, u, out_z, out_pts);
   CHECK_LAUNCH();
   return OBJNERF_OK;
 }

@@ -1018,6 +1018,22 @@ int objnerf_eval_points(const objnerf_net* net, int32_t K, int64_t N, const floa
                      stream);
 }
 
+size_t objnerf_eval_workspace_bytes(const objnerf_net* net, int32_t K, int64_t N) {
+  if (!net || K <= 0 || N <= 0 || net->hidden == 32) return 0;
+  return objgen::eval_workspace_bytes(net, K, (long)N);
+}
+
+int objnerf_eval_points_ws(const objnerf_net* net, int32_t K, int64_t N, const float* params, int64_t p_stride,
+                           const float* scale, const float* pts, float* out_alpha, float* out_color, float* out_hfeat,
+                           float* out_clip, void* workspace, size_t workspace_bytes, void* stream) {
+  (void)hipGetLastError();
+  if (!net || !params || !scale || !pts || !out_alpha || !out_color || K <= 0 || N <= 0) return OBJNERF_EINVAL;
+  if (net->hidden == 32)
+    return objnerf_eval_points(net, K, N, params, p_stride, scale, pts, out_alpha, out_color, out_hfeat, out_clip, stream);
+  return objgen::eval_points(net, K, (long)N, params, (long)p_stride, scale, pts, out_alpha, out_color, out_hfeat,
+                             out_clip, workspace, workspace_bytes, stream);
+}
+
 int objnerf_mlp_forward(const objnerf_net* net, int32_t K, int64_t N, const float* params, int64_t p_stride,
                         const float* emb, float* out_alpha, float* out_color, float* out_hfeat, float* out_clip,
                         void* stream) {

@@ -109,10 +109,48 @@ def eval_points(arena: ParamArena, pts: torch.Tensor, want_hfeat: bool = False, 
     hfeat = torch.empty(K, N, arena.net.hidden, device=dev) if (want_hfeat or want_clip) else None
     clip = torch.empty(K, N, arena.net.feat_dim, device=dev) if want_clip else None
     net = arena.net.c()
-    check(lib().objnerf_eval_points(C.byref(net), K, N, _ptr(arena.params), arena.p_stride, _ptr(arena.scale),
-                                    _ptr(pts), _ptr(alpha), _ptr(color), _ptr(hfeat), _ptr(clip), _stream()),
-          "objnerf_eval_points")
+    nbytes = int(lib().objnerf_eval_workspace_bytes(C.byref(net), K, N))      # 0 for hidden 32 (fused kernel)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev) if nbytes else None
+    check(lib().objnerf_eval_points_ws(C.byref(net), K, N, _ptr(arena.params), arena.p_stride, _ptr(arena.scale),
+                                       _ptr(pts), _ptr(alpha), _ptr(color), _ptr(hfeat), _ptr(clip), _ptr(ws), nbytes,
+                                       _stream()),
+          "objnerf_eval_points_ws")
     return alpha, color, hfeat, clip
+
+
+def box_rays(T_WC: torch.Tensor, T_OC: torch.Tensor, half_extent: torch.Tensor, dirs_C: torch.Tensor):
+    """Camera rays of one view against an oriented box (trainer.py:136-167): dirs_C [P,3] ->
+    dirs_W [P,3], near [P] (>= 0), far [P] (+0.2), hit [P] bool."""
+    dirs_C = _req(dirs_C, torch.float32, "dirs_C")
+    dev = dirs_C.device
+    P = dirs_C.shape[0]
+    T_WC = T_WC.to(dev, torch.float32).contiguous()
+    T_OC = T_OC.to(dev, torch.float32).contiguous()
+    half_extent = half_extent.to(dev, torch.float32).contiguous()
+    dirs_W = torch.empty(P, 3, device=dev)
+    near = torch.empty(P, device=dev)
+    far = torch.empty(P, device=dev)
+    hit = torch.empty(P, dtype=torch.uint8, device=dev)
+    check(lib().objnerf_box_rays(P, _ptr(T_WC), _ptr(T_OC), _ptr(half_extent), _ptr(dirs_C), _ptr(dirs_W), _ptr(near),
+                                 _ptr(far), _ptr(hit), _stream()), "objnerf_box_rays")
+    return dirs_W, near, far, hit.bool()
+
+
+def box_points(origin: torch.Tensor, dirs_W: torch.Tensor, near: torch.Tensor, far: torch.Tensor, u: torch.Tensor):
+    """Mid-points of the stratified bins of [near, far] (trainer.py:171-176): u [n, n_bins] ->
+    z_vals [n, n_bins-1], pts [n, n_bins-1, 3]."""
+    dirs_W = _req(dirs_W, torch.float32, "dirs_W")
+    near = _req(near, torch.float32, "near")
+    far = _req(far, torch.float32, "far")
+    u = _req(u, torch.float32, "u")
+    dev = dirs_W.device
+    n, n_bins = u.shape
+    origin = origin.to(dev, torch.float32).contiguous()
+    z = torch.empty(n, n_bins - 1, device=dev)
+    pts = torch.empty(n, n_bins - 1, 3, device=dev)
+    check(lib().objnerf_box_points(n, n_bins, _ptr(origin), _ptr(dirs_W), _ptr(near), _ptr(far), _ptr(u), _ptr(z),
+                                   _ptr(pts), _stream()), "objnerf_box_points")
+    return z, pts
 
 
 def mlp_forward(arena: ParamArena, emb: torch.Tensor, want_hfeat: bool = False, want_clip: bool = False):

@@ -52,6 +52,35 @@ class Trainer:
             return None
         return (occ, color, clip)
 
+    def sample_points_bbox(self, bbox, do_eval=True, draws=None):
+        """Points inside a known oriented 3-D box along the rays self.T_WC_gt / self.dirs_C_gt
+        (trainer.py:130-198).  bbox: anything with .center [3], .R [3,3], .extent [3] (the reference passes an
+        open3d OrientedBoundingBox).  draws: optional [n_hit, n_bins] tensor replacing the torch.rand of
+        stratified_bins (utils.py:371) -- tests inject the reference's draw.  Sets self.dirs_W, self.origins,
+        self.z_vals, self.input_pcs (device tensors) and returns (hit_mask, near[hit], far[hit]) or
+        (None, None, None) when at most one ray hits (:164-165)."""
+        n_bins = 60 if self.obj_id == 0 else 20                  # :141-144
+        if do_eval:
+            n_bins = 150
+        dev = self.device
+        T_WC = torch.as_tensor(self.T_WC_gt[0], dtype=torch.float32).cpu()     # one view: every row is the same pose
+        T_WO = torch.eye(4)
+        T_WO[:3, :3] = torch.as_tensor(np.asarray(bbox.R))                      # :152-154
+        T_WO[:3, 3] = torch.as_tensor(np.asarray(bbox.center))
+        T_OC = torch.inverse(T_WO) @ T_WC                                       # :156-157
+        half = torch.as_tensor(np.asarray(bbox.extent, np.float64) / 2.0).float()       # :161
+        dirs_C = torch.as_tensor(self.dirs_C_gt, dtype=torch.float32).to(dev).reshape(-1, 3)
+        dirs_W, near, far, hit = ops.box_rays(T_WC, T_OC, half, dirs_C)
+        n_rays = int(hit.sum())
+        if n_rays <= 1:
+            return None, None, None
+        self.dirs_W = dirs_W[hit]
+        self.origins = T_WC[:3, 3].to(dev).expand(n_rays, 3)
+        near_h, far_h = near[hit].contiguous(), far[hit].contiguous()
+        u = torch.rand(n_rays, n_bins, device=dev) if draws is None else torch.as_tensor(draws).to(dev)
+        self.z_vals, self.input_pcs = ops.box_points(T_WC[:3, 3], self.dirs_W.contiguous(), near_h, far_h, u)
+        return hit, near_h, far_h
+
     def meshing(self, *a, **k):
         raise NotImplementedError("marching cubes / open3d meshing (trainer.py:46-103, vis.py) is outside the "
                                   "accelerated path; evaluate the grid with eval_points(render_rays.make_3D_grid(...))")

@@ -185,6 +185,58 @@ class sceneObject:
         return rgb, depth, valid, labels, pts, z, partfeat
 
     # ------------------------------------------------------------------ checkpoints (vmap.py:556-602)
+    def get_bound(self, intrinsic_open3d=None, final=True):
+        """The object's oriented 3-D box (vmap.py:259-384 builds it from the keyframe point cloud with open3d,
+        outside the accelerated path): returns (None, self.bbox3dour), which the caller must have set."""
+        if self.bbox3dour is None:
+            raise RuntimeError("sceneObject.bbox3dour is not set: assign an oriented box (.center, .R, .extent)")
+        return None, self.bbox3dour
+
+    def render_2D_syn(self, T_WC, intrinsic_open3d, cached_rays_dir, T_WO=None, chunk_size=1000, do_fine=True,
+                      obj_mask=None, render_part=False, draws=None):
+        """Render this object from camera pose T_WC [4,4] inside its oriented box (vmap.py:604-685).
+        Returns (obj_mask [W,H] bool ndarray, depth [n], colour [n,3] uint8, feature [n,C] | None) for the
+        n pixels that hit the box, terminate inside it (near <= depth <= far) and reach opacity 0.9 -- or
+        (None, None, None).  The whole view is ONE launch chain on the device: box sampler -> fused PE + MLP ->
+        compositing (depth, rgb, opacity and the H-wide feature hidden) -> the linear 512-d head applied to the
+        composited hidden (exact, the head is linear); chunk_size is accepted for signature parity only."""
+        tr = self.trainer
+        W, H = tr.W_vis, tr.H_vis
+        _, bbox = self.get_bound(intrinsic_open3d, final=True)
+        dev = self.training_device
+        if obj_mask is None:
+            obj_mask = np.ones([W, H], dtype=bool)
+        mask_t = torch.as_tensor(obj_mask).to(dev)
+        idx = mask_t.nonzero(as_tuple=True)
+        tr.T_WC_gt = torch.as_tensor(T_WC, dtype=torch.float32).unsqueeze(0)
+        tr.dirs_C_gt = cached_rays_dir.to(dev)[idx[0], idx[1]]
+        obj_hit, obj_near, obj_far = tr.sample_points_bbox(bbox, do_eval=True, draws=draws)
+        if obj_hit is None:
+            return None, None, None
+        n_pts, S = tr.z_vals.shape
+        if n_pts <= 1:
+            print("too few hits")
+            return None, None, None
+        tr.arena.scale.fill_(float(tr.obj_scale))
+        with torch.no_grad():
+            alpha, color, hfeat, _ = ops.eval_points(tr.arena, tr.input_pcs.reshape(1, -1, 3), want_hfeat=render_part)
+            out = ops.composite(alpha.reshape(n_pts, S), color.reshape(n_pts, S, 3), tr.z_vals,
+                                vals=hfeat.reshape(n_pts, S, -1) if render_part else None)
+            depth, opacity = out["depth"], out["opacity"]
+            bad = (depth < obj_near) | (depth > obj_far) | (opacity < 0.9)          # :665,672
+            keep = ~bad
+            render_color = (out["rgb"] * 255).to(torch.uint8)                       # :671 (truncation)
+            feat = None
+            if render_part:
+                feat = ops.feature_head(tr.arena, out["vals"].reshape(1, n_pts, -1), opacity.reshape(1, n_pts))[0]
+                feat = feat[keep].cpu().numpy()
+            sel = torch.zeros(idx[0].shape[0], dtype=torch.bool, device=dev)
+            hit_idx = obj_hit.nonzero(as_tuple=True)[0]
+            sel[hit_idx[keep]] = True                                               # :627-629 and :681-683
+            mask_out = torch.zeros_like(mask_t)
+            mask_out[idx[0][sel], idx[1][sel]] = True
+        return (mask_out.cpu().numpy(), depth[keep].cpu().numpy(), render_color[keep].cpu().numpy(), feat,)
+
     def save_checkpoints(self, path, epoch):
         torch.save({
             "epoch": epoch,

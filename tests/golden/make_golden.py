@@ -21,6 +21,8 @@ Fixtures:
   g8_box     ray_box_intersection, rays_dir_cache, origin_dirs_W
   g9_psnr    analytic ellipsoid scene, 300 iterations: loss curve + PSNR on held-out rays
   g10_bg     background-shaped (K=1, H=128, S=14) iteration: loss + grads
+  g11_render Trainer.sample_points_bbox + sceneObject.render_2D_syn (novel-view depth / rgb / 512-d feature
+             maps of one object inside its oriented box), hidden 32 and 128
 """
 import os
 import sys
@@ -436,6 +438,66 @@ def g8():
          dc2=dc2, ow2=ow2, dw2=dw2, grid=grid)
 
 
+
+# ------------------------------------------------------------------------------------------- G11
+class _Box:
+    """Data holder standing in for open3d.geometry.OrientedBoundingBox (open3d is not installed; the reference
+    only reads .center / .R / .extent of it in Trainer.sample_points_bbox, trainer.py:148-160)."""
+
+    def __init__(self, center, R, extent):
+        self.center, self.R, self.extent = np.asarray(center, np.float64), np.asarray(R, np.float64), \
+            np.asarray(extent, np.float64)
+
+
+ALPHA_BIAS = {32: -2.0, 128: -0.1}      # chosen so that a third of the rays fail the opacity / depth tests
+
+
+def g11():
+    out = {}
+    W, H = 20, 14                                   # W_vis x H_vis image (stored transposed like the reference)
+    fx = fy = 18.0
+    cx, cy = 9.5, 6.5
+    uu, vv = np.meshgrid(np.arange(W), np.arange(H), indexing="ij")
+    rays_dir = torch.from_numpy(np.stack([(uu - cx) / fx, (vv - cy) / fy, np.ones_like(uu, float)], -1)).float()
+    rs = np.random.RandomState(11)
+    Rbox = synthetic._random_rotations(rs, 1)[0].astype(np.float64)
+    box = _Box(center=[0.1, -0.05, 2.0], R=Rbox, extent=[1.1, 0.8, 0.9])
+    T_WC = np.eye(4, dtype=np.float32)
+    T_WC[:3, :3] = synthetic._random_rotations(np.random.RandomState(12), 1)[0] * 0 + np.eye(3)
+    T_WC[:3, 3] = [0.05, 0.02, -0.1]
+    ref_trainer.o3d.geometry.OrientedBoundingBox = _Box
+    for Hd in (32, 128):
+        torch.manual_seed(110 + Hd)
+        cfg = make_cfg(hidden=Hd, scale=2.0)
+        t = ref_trainer.Trainer(cfg)
+        with torch.no_grad():                       # push the field towards an occupied blob so rays terminate
+            t.fc_occ_map.out_alpha.bias.add_(ALPHA_BIAS[Hd])
+            t.pe.B_layer.weight.add_(0.02 * torch.randn(21, 3))
+        t.W_vis, t.H_vis = W, H
+        obj_mask = np.ones([W, H], dtype=bool)
+        obj_mask[:2, :] = False                     # a caller-supplied pixel mask
+        self_ns = types.SimpleNamespace(trainer=t, training_device="cpu",
+                                        get_bound=lambda *a, **k: (None, box))
+        with _Recorder() as rec:
+            res = ref_vmap.sceneObject.render_2D_syn(self_ns, T_WC.copy(), None, rays_dir, chunk_size=97,
+                                                     obj_mask=obj_mask.copy(), render_part=True)
+        assert res[0] is not None and len(rec.rand) == 1
+        mask_out, depth, color, feat = res
+        tag = f"h{Hd}"
+        for i, p_ in enumerate(t.fc_occ_map.parameters()):
+            out[f"{tag}_p{i}"] = p_
+        out[f"{tag}_B"] = t.pe.B_layer.weight
+        out[f"{tag}_u"] = rec.rand[0]               # the stratified_bins draw, [n_hit, 150]
+        out[f"{tag}_z_vals"] = t.z_vals
+        out[f"{tag}_pts"] = t.input_pcs
+        out[f"{tag}_mask_out"] = mask_out
+        out[f"{tag}_depth"] = depth
+        out[f"{tag}_color"] = color
+        out[f"{tag}_feat"] = feat
+        print(tag, "hit rays", t.z_vals.shape, "kept", depth.shape)
+    save("g11_render", rays_dir=rays_dir, T_WC=T_WC, box_center=box.center, box_R=box.R, box_extent=box.extent,
+         mask_in=obj_mask, cam=np.array([W, H, fx, fy, cx, cy], np.float32), scale=np.float32(2.0), **out)
+
 # ------------------------------------------------------------------------------------------- G9
 G9 = dict(K=4, R=96, N=4, M=12, steps=300, eval_R=256, eval_S=32, scene_seed=7, weight_seed=90)
 
@@ -517,7 +579,7 @@ def g10():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g7", "g8", "g9", "g10", "g11"]
     for w in which:
-        {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5": g5_g6, "g7": g7, "g8": g8, "g9": g9,
+        {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5": g5_g6, "g7": g7, "g8": g8, "g9": g9, "g11": g11,
          "g10": g10}[w]()

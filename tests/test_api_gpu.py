@@ -246,3 +246,42 @@ def test_background_loop_matches_single_shot(dev):
     before = bg.arena.params.clone()
     t = loop.step(full)
     assert t.shape == (1, 4) and float((bg.arena.params - before).abs().max()) > 0
+
+
+@pytest.mark.parametrize("H", [32, 128])
+def test_render_2d_syn_g11(golden, dev, H):
+    """Novel-view rendering of one object inside its oriented box (Trainer.sample_points_bbox +
+    sceneObject.render_2D_syn, trainer.py:130-198 / vmap.py:604-685): box sampler, fused PE + MLP (hidden 32) or
+    the layer-wise path (hidden 128, the background network), compositing, hoisted 512-d head, reject masks."""
+    import types
+    g = golden("g11_render")
+    tag = f"h{H}"
+    W, Hh = int(g["cam"][0]), int(g["cam"][1])
+    c = make_cfg(dev)
+    c.W, c.H = W, Hh
+    c.hidden_feature_size = H
+    c.obj_scale = float(g["scale"])
+    t = trainer.Trainer(c)
+    with torch.no_grad():
+        for i, p in enumerate(t.fc_occ_map.parameters()):
+            p.copy_(T(g[f"{tag}_p{i}"]))
+        t.pe.B_layer.weight.copy_(T(g[f"{tag}_B"]))
+    box = types.SimpleNamespace(center=g["box_center"], R=g["box_R"], extent=g["box_extent"])
+    ns = types.SimpleNamespace(trainer=t, training_device=dev, get_bound=lambda *a, **k: (None, box))
+    res = ovmap.sceneObject.render_2D_syn(ns, g["T_WC"], None, T(g["rays_dir"]), obj_mask=g["mask_in"].copy(),
+                                          render_part=True, draws=T(g[f"{tag}_u"]))
+    assert res[0] is not None
+    mask, depth, color, feat = res
+    assert maxerr(t.z_vals, g[f"{tag}_z_vals"]) < 2e-6
+    assert maxerr(t.input_pcs, g[f"{tag}_pts"]) < 4e-6
+    # the accept / reject decision of a ray is a threshold on opacity and depth: identical unless a ray sits on it
+    fc = [T(g[f"{tag}_p{i}"]) for i in range(18)]
+    r = O.render_2d_syn(fc, T(g[f"{tag}_B"]), float(g["scale"]), T(g["T_WC"]), T(g["rays_dir"]), g["box_center"],
+                        g["box_R"], g["box_extent"], T(g["mask_in"]), T(g[f"{tag}_u"]))
+    margin = torch.minimum((r["opacity"] - 0.9).abs(),
+                           torch.minimum((r["depth_all"] - r["near"]).abs(), (r["depth_all"] - r["far"]).abs()))
+    assert float(margin.min()) > 1e-4, "fixture has a ray on a threshold"
+    assert np.array_equal(mask, g[f"{tag}_mask_out"])
+    assert maxerr(depth, g[f"{tag}_depth"]) < 1e-4 * max(1.0, float(np.abs(g[f"{tag}_depth"]).max()))
+    assert np.abs(color.astype(int) - g[f"{tag}_color"].astype(int)).max() <= 1      # uint8 truncation of rgb*255
+    assert maxerr(feat, g[f"{tag}_feat"]) < 1e-4 * max(1.0, float(np.abs(g[f"{tag}_feat"]).max()))

@@ -111,3 +111,23 @@ def test_two_rank_flags_and_loss_gloo():
         assert flags == [1, 0]
         assert abs(tot - expect) < 1e-4
         assert counts == [[1200, 21]] and g0 == 3.0
+
+
+def test_view_buffers_zbuffer_merge():
+    """train.py:581-598: nearer object wins a pixel; a background object paints colour but leaves the depth
+    buffer alone, so a later foreground object still takes the pixel."""
+    from openobj_amd.render_view import ViewBuffers
+    buf = ViewBuffers(3, 2)
+    m_bg = np.ones((3, 2), dtype=bool)
+    ok = buf.merge(m_bg, np.full(6, 5.0, np.float32), np.full((6, 3), 10, np.uint8), class_id=7, is_background=True)
+    assert ok.all() and (buf.depth == 100).all() and (buf.rgb == 10).all() and (buf.maskid == 7).all()
+    m1 = np.zeros((3, 2), dtype=bool)
+    m1[0, 0] = m1[1, 1] = True
+    buf.merge(m1, np.array([2.0, 3.0], np.float32), np.full((2, 3), 50, np.uint8), class_id=1, is_background=False)
+    assert buf.depth[0, 0] == 2.0 and buf.depth[1, 1] == 3.0 and buf.maskid[0, 0] == 1 and buf.rgb[1, 1, 0] == 50
+    m2 = np.zeros((3, 2), dtype=bool)
+    m2[0, 0] = m2[2, 1] = True
+    buf.merge(m2, np.array([2.5, 4.0], np.float32), np.full((2, 3), 90, np.uint8), class_id=2, is_background=False)
+    assert buf.maskid[0, 0] == 1 and buf.rgb[0, 0, 0] == 50          # farther: loses
+    assert buf.maskid[2, 1] == 2 and buf.depth[2, 1] == 4.0          # free pixel: wins
+    assert buf.maskid[1, 0] == 7                                     # untouched background pixel

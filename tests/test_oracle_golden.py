@@ -224,3 +224,20 @@ def test_g9_psnr_scene(golden, tag):
     fc, B = rec["params"][-1][:18], rec["params"][-1][18]
     p, out = render_eval_psnr(fc, B, torch.full((K,), 2.0), ev)
     assert abs(p - float(g["psnr"])) < 0.1, (p, float(g["psnr"]))
+
+
+@pytest.mark.parametrize("H", [32, 128])
+def test_g11_render_2d_syn(golden, H):
+    """Trainer.sample_points_bbox + sceneObject.render_2D_syn (trainer.py:130-198, vmap.py:604-685)."""
+    g = golden("g11_render")
+    tag = f"h{H}"
+    fc = [T(g[f"{tag}_p{i}"]) for i in range(18)]
+    r = O.render_2d_syn(fc, T(g[f"{tag}_B"]), float(g["scale"]), T(g["T_WC"]), T(g["rays_dir"]), g["box_center"],
+                        g["box_R"], g["box_extent"], T(g["mask_in"]), T(g[f"{tag}_u"]))
+    assert r is not None
+    np.testing.assert_allclose(r["z_vals"], g[f"{tag}_z_vals"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(r["pts"], g[f"{tag}_pts"], rtol=0, atol=2e-6)
+    assert np.array_equal(r["mask"].numpy(), g[f"{tag}_mask_out"])
+    np.testing.assert_allclose(r["depth"], g[f"{tag}_depth"], rtol=1e-5, atol=1e-6)
+    assert np.abs(r["color"].numpy().astype(int) - g[f"{tag}_color"].astype(int)).max() <= 1
+    np.testing.assert_allclose(r["feat"].detach(), g[f"{tag}_feat"], rtol=1e-4, atol=1e-5)
