@@ -8,6 +8,7 @@ import torch
 
 from conftest import T
 from oracle import objnerf_oracle as O
+from openobj_amd import init as obj_init
 from openobj_amd import ops, synthetic
 
 pytestmark = pytest.mark.gpu
@@ -363,3 +364,95 @@ def test_long_ray_step_vs_oracle(golden, dev):
             continue
         scale = max(1e-3, float(grads[i].abs().max()))
         assert maxerr(gv[i], grads[i]) < 2e-4 * scale, (i, maxerr(gv[i], grads[i]), scale)
+
+
+@pytest.mark.parametrize("H", [128, 256])
+def test_eval_points_wide_vs_oracle(golden, dev, H):
+    """Inference of the wider networks (background 128; BASELINE configs[4] 256) through objnerf_eval_points_ws;
+    hidden 128 uses the G2 weights that pin the oracle."""
+    g = golden("g2_mlp")
+    if H == 128:
+        p = [T(g[f"h128_p{i}"]) for i in range(18)]
+    else:
+        p = [q[0] for q in obj_init.init_stacked(1, H, 512, seed=5)[:18]]
+    K = 2
+    arena = ops.ParamArena(K, ops.NetShape(H, 512, 6), dev)
+    B = O.icosa_dirs()[None].repeat(K, 1, 1) + 0.01 * torch.randn(K, 21, 3, generator=torch.Generator().manual_seed(1))
+    arena.load_stacked([q[None].repeat(K, *([1] * q.dim())) for q in p] + [B])
+    arena.scale.fill_(5.0)
+    pts = torch.from_numpy(np.random.RandomState(3).uniform(-4, 4, (K, 333, 3)).astype(np.float32))
+    alpha, color, hf, clip = ops.eval_points(arena, pts.to(dev), want_clip=True)
+    for k in range(K):
+        a, c, f = O.mlp_forward(p, O.unidirs_embed(pts[k], B[k], 5.0))
+        assert maxerr(alpha[k], a.squeeze(-1)) < 1e-4 * max(1.0, float(a.abs().max()))
+        assert maxerr(color[k], c) < 1e-5
+        assert maxerr(clip[k], f) < 1e-4 * max(1.0, float(f.abs().max()))
+
+
+def test_stress_shape_step_vs_oracle(dev):
+    """BASELINE configs[4] shape in miniature: hidden 256, 128 samples per ray (32 + 96), with the feature loss."""
+    K, R, n1, n2, H = 2, 10, 32, 96, 256
+    st = obj_init.init_stacked(K, H, 512, seed=9)
+    fc, B = [q.clone() for q in st[:18]], st[18].clone()
+    arena = ops.ParamArena(K, ops.NetShape(H, 512, 6), dev)
+    arena.load_stacked(fc + [B])
+    ws = ops.TrainWorkspace(arena, K, R, n1 + n2, True)
+    b = synthetic.random_batch(K, R, n1, n2, seed=77, feat_dim=512)
+    _hip_step(arena, ws, b, dev, with_feat=True)
+    fcr = [q.clone().requires_grad_(True) for q in fc]
+    Br = B.clone().requires_grad_(True)
+    loss, terms = O.train_forward_loss(fcr, Br, torch.full((K,), 2.0), T(b["pts"]), T(b["gt_depth"]), T(b["gt_rgb"]),
+                                       T(b["labels"]), T(b["z"]), gt_feat=T(b["gt_feat"]), return_terms=True)
+    grads = torch.autograd.grad(loss, fcr + [Br], allow_unused=True)
+    t = ws.loss_terms.cpu()
+    total = (t[:, 0] + 5 * t[:, 1] + 10 * t[:, 2] + 5 * t[:, 3]).sum().item()
+    assert abs(total - loss.item()) < 1e-4 * abs(loss.item())
+    gv = arena.views(ws.grads)
+    for i in range(19):
+        scale = max(1e-3, float(grads[i].abs().max()))
+        assert maxerr(gv[i], grads[i]) < 3e-4 * scale, (i, ops.TENSOR_NAMES[i], maxerr(gv[i], grads[i]), scale)
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1, 9), (3, 2, 16, 48), (1, 129, 8, 24)])
+def test_train_step_tiny_and_ragged(golden, dev, shape):
+    """One ray per object / fewer rays than a tile / a ray count that leaves a ragged last tile."""
+    K, R, n1, n2 = shape
+    g = golden("g9_psnr_nofeat")
+    fc = [T(g[f"fc0_{i}"])[:1].repeat(K, *([1] * (T(g[f"fc0_{i}"]).dim() - 1))).clone() for i in range(18)]
+    B = O.icosa_dirs()[None].repeat(K, 1, 1)
+    arena = ops.ParamArena(K, ops.NetShape(), dev)
+    arena.load_stacked(fc + [B])
+    ws = ops.TrainWorkspace(arena, K, R, n1 + n2, False)
+    b = synthetic.random_batch(K, R, n1, n2, seed=5 + R)
+    b["labels"][:, 0] = 1                        # keep the early return out of this test
+    _hip_step(arena, ws, b, dev)
+    fcr = [p.clone().requires_grad_(True) for p in fc]
+    Br = B.clone().requires_grad_(True)
+    loss, _ = O.train_forward_loss(fcr, Br, torch.full((K,), 2.0), T(b["pts"]), T(b["gt_depth"]), T(b["gt_rgb"]),
+                                   T(b["labels"]), T(b["z"]), return_terms=True)
+    grads = torch.autograd.grad(loss, fcr + [Br], allow_unused=True)
+    t = ws.loss_terms.cpu()
+    assert abs((t[:, 0] + 5 * t[:, 1] + 10 * t[:, 2]).sum().item() - loss.item()) < 1e-4 * max(1.0, abs(loss.item()))
+    gv = arena.views(ws.grads)
+    for i in range(19):
+        if grads[i] is None:
+            continue
+        scale = max(1e-3, float(grads[i].abs().max()))
+        assert maxerr(gv[i], grads[i]) < 2e-4 * scale, (i, maxerr(gv[i], grads[i]), scale)
+
+
+def test_train_step_rejects_bad_arguments(golden, dev):
+    """Error behaviour of the boundary: null / mis-sized arguments are refused with OBJNERF_EINVAL, nothing runs."""
+    import ctypes as C
+    from openobj_amd import _lib
+    arena = ops.ParamArena(1, ops.NetShape(), dev)
+    net = arena.net.c()
+    a = _lib.TrainArgs()                          # all zero / null
+    assert _lib.lib().objnerf_train_step(C.byref(net), C.byref(a), None) == -22
+    assert _lib.lib().objnerf_train_step(None, None, None) == -22
+    ws = ops.TrainWorkspace(arena, 1, 8, 10, False)
+    b = synthetic.random_batch(1, 8, 1, 9, seed=1)
+    batch = {k: T(b[k]).to(dev) for k in ["pts", "z", "gt_depth", "gt_rgb", "labels"]}
+    ws.nbytes = 16                                # lie about the workspace size
+    with pytest.raises(_lib.ObjnerfError):
+        ops.train_step(arena, ws, batch)
