@@ -4,6 +4,13 @@
 namespace objgen {
 size_t train_workspace_bytes(const objnerf_net* net, int K, int R, int S, int feat);
 int train_step(const objnerf_net* net, const objnerf_train_args* a, void* stream);
+// the batched fp32 MFMA GEMM of this path, for the feature-head kernels of objnerf_train.hip:
+//   C[z][m][n] (+)= sum_k A(z; m,k) B(z; k,n), element strides (sam, sak), (sbk, sbn), (scm, scn), batch strides bs*
+void gemm_f32(void* stream, int batch, int M, int N, int Kd, const float* A, long sam, long sak, long bsa, const float* B,
+              long sbk, long sbn, long bsb, float* C, long scm, long scn, long bsc, bool accumulate);
+//   long contraction over n, few output tiles: split-K with float atomics into a PRE-ZEROED C (scn = 1)
+void wgrad_f32(void* stream, int batch, int M, int N, long n, const float* A, long sam, long sak, long bsa, const float* B,
+               long sbk, long sbn, long bsb, float* C, long scm, long bsc);
 size_t eval_workspace_bytes(const objnerf_net* net, int K, long N);
 int eval_points(const objnerf_net* net, int K, long N, const float* params, long p_stride, const float* scale,
                 const float* pts, float* out_alpha, float* out_color, float* out_hfeat, float* out_clip,

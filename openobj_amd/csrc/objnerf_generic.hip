@@ -504,4 +504,13 @@ int eval_points(const objnerf_net* net, int K, long N, const float* params, long
   return OBJNERF_OK;
 }
 
+void gemm_f32(void* stream, int batch, int M, int N, int Kd, const float* A, long sam, long sak, long bsa, const float* B,
+              long sbk, long sbn, long bsb, float* C, long scm, long scn, long bsc, bool accumulate) {
+  gemm((hipStream_t)stream, batch, M, N, Kd, A, sam, sak, bsa, B, sbk, sbn, bsb, C, scm, scn, bsc, accumulate);
+}
+void wgrad_f32(void* stream, int batch, int M, int N, long n, const float* A, long sam, long sak, long bsa, const float* B,
+               long sbk, long sbn, long bsb, float* C, long scm, long bsc) {
+  wgrad((hipStream_t)stream, batch, M, N, n, A, sam, sak, bsa, B, sbk, sbn, bsb, C, scm, bsc);
+}
+
 }  // namespace objgen

@@ -353,9 +353,9 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
               if (hh == 0) {
                 l_f += mm1 * (1.0f - cosv) * inv1;
                 s_gof[qq2] = ar * beta + cr * (fwb + O2 * bb);       // d total / d opacity (feature part)
-                a.rayfeat[rr2 * RAYFEAT + 32] = ar;
-                a.rayfeat[rr2 * RAYFEAT + 33] = cr;
-                a.rayfeat[rr2 * RAYFEAT + 34] = O2;
+                a.rayfeat[rr2 * RAYFEAT + 32] = O2;      // layout (fh[32], O, a, c): [fh | O] is a GEMM operand
+                a.rayfeat[rr2 * RAYFEAT + 33] = ar;
+                a.rayfeat[rr2 * RAYFEAT + 34] = cr;
               }
               s_gfh[qq2 * 32 + hh] = ar * uh + cr * (Gfh + O2 * wbh);   // d total / d fh
               a.rayfeat[rr2 * RAYFEAT + hh] = fh;
@@ -703,117 +703,66 @@ __global__ __launch_bounds__(1024) void feat_gram_kernel(const float* params, lo
   if (h2 == 0) gram[(long)k * GRAM + 1024 + h] = accb;
   if (threadIdx.x == 0) gram[(long)k * GRAM + 1056] = accbb;
 }
-// pre: u[r] = W_of^T g[r], beta[r] = b_of . g[r], |g[r]|       thread = (ray of 8, h)
-__global__ __launch_bounds__(256) void feat_pre_kernel(const float* params, long p_stride, int off_w, int off_b, int C,
-                                                       int R, const float* gt_feat, float* rayin) {
+// pre: u[r] = W_of^T g[r] is a batched GEMM (objgen::gemm_f32); this kernel adds beta[r] = b_of . g[r] and |g[r]|:
+// one 16-lane group per ray, float4 loads.
+__global__ __launch_bounds__(256) void feat_rowstats_kernel(const float* params, long p_stride, int off_b, int C, int R,
+                                                            const float* gt_feat, float* rayin) {
   const int k = blockIdx.y;
-  const int rl = threadIdx.x >> 5, h = threadIdx.x & 31;
-  const float* W = params + (long)k * p_stride + off_w;
+  const int l16 = threadIdx.x & 15;
+  const long r = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
   const float* B = params + (long)k * p_stride + off_b;
-  for (int r0 = blockIdx.x * 8; r0 < R; r0 += gridDim.x * 8) {
-    const int r = r0 + rl;
-    if (r >= R) continue;
+  float bs = 0.f, gs = 0.f;
+  if (r < R) {
     const float* gp = gt_feat + ((long)k * R + r) * C;
-    float u = 0.f;
-#pragma unroll 8
-    for (int cc = 0; cc < C; ++cc) u = fmaf(W[cc * 32 + h], gp[cc], u);
-    float bs = 0.f, gs = 0.f;
-    for (int cc = h; cc < C; cc += 32) {
-      const float gv = gp[cc];
-      bs = fmaf(B[cc], gv, bs);
-      gs = fmaf(gv, gv, gs);
+    for (int cc = 4 * l16; cc < C; cc += 64) {
+      const float4 gv = *reinterpret_cast<const float4*>(gp + cc);
+      bs = fmaf(B[cc + 3], gv.w, fmaf(B[cc + 2], gv.z, fmaf(B[cc + 1], gv.y, fmaf(B[cc], gv.x, bs))));
+      gs = fmaf(gv.w, gv.w, fmaf(gv.z, gv.z, fmaf(gv.y, gv.y, fmaf(gv.x, gv.x, gs))));
     }
-    bs = wave_sum32(bs);
-    gs = wave_sum32(gs);
+  }
+  bs = dpp_rowsum16(bs);
+  gs = dpp_rowsum16(gs);
+  if (r < R && l16 == 0) {
     float* o = rayin + ((long)k * R + r) * RAYIN;
-    o[h] = u;
-    if (h == 0) { o[32] = bs; o[33] = sqrtf(gs); }
+    o[32] = bs;
+    o[33] = sqrtf(gs);
   }
 }
-// post, stage 1: partial[k][ch][c][h] = sum_{r in chunk} g[r][c] * a_r fh_r[h],  partial_b[c] = sum g[r][c] a_r O_r
-constexpr int POST_CHUNKS = 8;
-__global__ __launch_bounds__(256) void feat_post_kernel(int C, int R, const float* gt_feat, const float* rayfeat,
-                                                        float* partial) {
-  __shared__ float P[32][36];
-  const int k = blockIdx.y, ch = blockIdx.x;
-  const int per = (R + POST_CHUNKS - 1) / POST_CHUNKS;
-  const int rb = ch * per, re = min(R, rb + per);
-  float acc[2][32], accb[2] = {0.f, 0.f};
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int h = 0; h < 32; ++h) acc[j][h] = 0.f;
-  for (int r0 = rb; r0 < re; r0 += 32) {
-    __syncthreads();
-    for (int i = threadIdx.x; i < 32 * 36; i += 256) {
-      const int rr = r0 + i / 36;
-      P[i / 36][i % 36] = rr < re ? rayfeat[((long)k * R + rr) * RAYFEAT + (i % 36)] : 0.f;
-    }
-    __syncthreads();
-    const int n = min(32, re - r0);
-    for (int j = 0; j < n; ++j) {
-      const float* gp = gt_feat + ((long)k * R + r0 + j) * C;
-      const float ar = P[j][32], ao = ar * P[j][34];
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int cc = threadIdx.x + 256 * q;
-        if (cc < C) {
-          const float gv = gp[cc] * ar;
-#pragma unroll
-          for (int h = 0; h < 32; ++h) acc[q][h] = fmaf(gv, P[j][h], acc[q][h]);
-          accb[q] = fmaf(gp[cc], ao, accb[q]);
-        }
-      }
-    }
-  }
-  float* out = partial + ((long)k * POST_CHUNKS + ch) * ((long)C * 33);
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int cc = threadIdx.x + 256 * q;
-    if (cc < C) {
-#pragma unroll
-      for (int h = 0; h < 32; ++h) out[(long)cc * 32 + h] = acc[q][h];
-      out[(long)C * 32 + cc] = accb[q];
-    }
-  }
+// post: the fused kernel left (fh[32], O, a, c) per ray.  d W_of = sum_r (a_r g_r + c_r F_r) fh_r^T with
+// F_r = W_of fh_r + b_of O_r, so  d W_of = gt_feat^T [a fh] + W_of M2 + b_of m1^T  and
+// d b_of = gt_feat^T [a O] + W_of m1 + b_of s2  with the moments  [M2 m1; . s2] = [c fh | c O]^T [fh | O].
+// This kernel writes the two row-scaled copies X1 = [a fh | a O], X2 = [c fh | c O]; two GEMMs do the sums.
+constexpr int XCOLS = 33;
+__global__ void feat_scale_kernel(long n, const float* rayfeat, float* X1, float* X2) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * XCOLS) return;
+  const long r = i / XCOLS;
+  const int j = (int)(i - r * XCOLS);
+  const float* rf = rayfeat + r * RAYFEAT;
+  const float v = rf[j];                  // fh[0..31], O
+  X1[i] = rf[33] * v;
+  X2[i] = rf[34] * v;
 }
-// post, stage 2: moments M2 = sum_r c_r fh fh^T, m1 = sum_r c_r O_r fh, s2 = sum_r c_r O_r^2, then
-//   dW_of = sum_ch partial + W_of M2 + b_of m1^T ;  db_of = sum_ch partial_b + W_of m1 + b_of s2
-__global__ __launch_bounds__(1024) void feat_finish_kernel(const float* params, long p_stride, int off_w, int off_b,
-                                                           int C, int R, const float* rayfeat, const float* partial,
-                                                           float* grads) {
-  __shared__ float M2[32][33], m1v[32], s2s;
-  const int k = blockIdx.x;
-  const int h = threadIdx.x >> 5, h2 = threadIdx.x & 31;
-  float acc = 0.f, accm = 0.f, accs = 0.f;
-  for (int r = 0; r < R; ++r) {
-    const float* rf = rayfeat + ((long)k * R + r) * RAYFEAT;
-    const float cr = rf[33], fa = rf[h], fb = rf[h2], Or = rf[34];
-    acc = fmaf(cr * fa, fb, acc);
-    if (h2 == 0) accm = fmaf(cr * Or, fa, accm);
-    if (threadIdx.x == 0) accs = fmaf(cr * Or, Or, accs);
-  }
-  M2[h][h2] = acc;
-  if (h2 == 0) m1v[h] = accm;
-  if (threadIdx.x == 0) s2s = accs;
+// d W_of[c][h] = T[c][h] + sum_j W_of[c][j] M2[j][h] + b_of[c] m1[h];  d b_of[c] = T[c][32] + W_of[c] . m1 + b_of[c] s2
+__global__ __launch_bounds__(256) void feat_finish_kernel(const float* params, long p_stride, int off_w, int off_b, int C,
+                                                          const float* Tm /* [K][C][33] */,
+                                                          const float* mom /* [K][33][33] */, float* grads) {
+  __shared__ float M[XCOLS][XCOLS];
+  const int k = blockIdx.y;
+  for (int i = threadIdx.x; i < XCOLS * XCOLS; i += 256) M[i / XCOLS][i % XCOLS] = mom[(long)k * XCOLS * XCOLS + i];
   __syncthreads();
-  const float* W = params + (long)k * p_stride + off_w;
-  const float* B = params + (long)k * p_stride + off_b;
-  float* gW = grads + (long)k * p_stride + off_w;
-  float* gB = grads + (long)k * p_stride + off_b;
-  for (int i = threadIdx.x; i < C * 32; i += 1024) {
-    const int cc = i >> 5, hh = i & 31;
-    float v = 0.f;
-    for (int chn = 0; chn < POST_CHUNKS; ++chn) v += partial[((long)k * POST_CHUNKS + chn) * ((long)C * 33) + i];
-    for (int j = 0; j < 32; ++j) v = fmaf(W[cc * 32 + j], M2[j][hh], v);
-    gW[i] = fmaf(B[cc], m1v[hh], v);
-  }
-  for (int cc = threadIdx.x; cc < C; cc += 1024) {
-    float v = 0.f;
-    for (int chn = 0; chn < POST_CHUNKS; ++chn)
-      v += partial[((long)k * POST_CHUNKS + chn) * ((long)C * 33) + (long)C * 32 + cc];
-    for (int j = 0; j < 32; ++j) v = fmaf(W[cc * 32 + j], m1v[j], v);
-    gB[cc] = fmaf(B[cc], s2s, v);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= C * XCOLS) return;
+  const int cc = i / XCOLS, hh = i - cc * XCOLS;
+  const float* W = params + (long)k * p_stride + off_w + cc * 32;
+  const float bc = params[(long)k * p_stride + off_b + cc];
+  float v = Tm[(long)k * C * XCOLS + i];
+  if (hh < 32) {
+    for (int j = 0; j < 32; ++j) v = fmaf(W[j], M[j][hh], v);              // M2[j][h]  (c fh_j . fh_h)
+    grads[(long)k * p_stride + off_w + cc * 32 + hh] = fmaf(bc, M[32][hh], v);   // m1[h] = (c O) . fh_h
+  } else {
+    for (int j = 0; j < 32; ++j) v = fmaf(W[j], M[32][j], v);
+    grads[(long)k * p_stride + off_b + cc] = fmaf(bc, M[32][32], v);      // s2 = (c O) . O
   }
 }
 
@@ -893,7 +842,8 @@ size_t objnerf_train_workspace_bytes(const objnerf_net* net, int32_t K, int32_t 
   size_t n = align256((size_t)K * Gmax * ps * 4) + align256((size_t)K * Gmax * 4 * 4) + align256((size_t)ps) + 256;
   if (with_feat)
     n += align256((size_t)K * R * RAYIN * 4) + align256((size_t)K * GRAM * 4) + align256((size_t)K * R * RAYFEAT * 4) +
-         align256((size_t)K * POST_CHUNKS * (size_t)net->feat_dim * 33 * 4);
+         2 * align256((size_t)K * R * XCOLS * 4) +
+         align256(((size_t)K * net->feat_dim * XCOLS + (size_t)K * XCOLS * XCOLS) * 4);
   return n;
 }
 
@@ -944,13 +894,17 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
   ws += align256((size_t)a->K * Gmax * 4 * 4);
   uint8_t* has_grad = (uint8_t*)ws;
   ws += align256((size_t)ps) + 256;
-  float* rayin = nullptr; float* gram = nullptr; float* rayfeat = nullptr; float* partial = nullptr;
+  float* rayin = nullptr; float* gram = nullptr; float* rayfeat = nullptr;
+  float *X1 = nullptr, *X2 = nullptr, *Tm = nullptr, *mom = nullptr;
   const int C = net->feat_dim;
   if (feat) {
     rayin = (float*)ws;   ws += align256((size_t)a->K * a->R * RAYIN * 4);
     gram = (float*)ws;    ws += align256((size_t)a->K * GRAM * 4);
     rayfeat = (float*)ws; ws += align256((size_t)a->K * a->R * RAYFEAT * 4);
-    partial = (float*)ws;
+    X1 = (float*)ws;      ws += align256((size_t)a->K * a->R * XCOLS * 4);
+    X2 = (float*)ws;      ws += align256((size_t)a->K * a->R * XCOLS * 4);
+    Tm = (float*)ws;
+    mom = Tm + (size_t)a->K * C * XCOLS;
   }
   d.rayin = rayin; d.gram = gram; d.rayfeat = rayfeat;
 
@@ -975,16 +929,23 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
   if (feat) {
     hipLaunchKernelGGL(feat_gram_kernel, dim3(a->K), dim3(1024), 0, st, a->params, (long)a->p_stride, d.L.of_w,
                        d.L.of_b, C, gram);
-    int gx = (a->R + 7) / 8;
-    if (gx > 256) gx = 256;
-    hipLaunchKernelGGL(feat_pre_kernel, dim3(gx, a->K), dim3(256), 0, st, a->params, (long)a->p_stride, d.L.of_w,
-                       d.L.of_b, C, a->R, a->gt_feat, rayin);
+    // u = gt_feat W_of  ([R x C] [C x 32] per object) on the batched MFMA GEMM; beta, |g| beside it
+    objgen::gemm_f32(stream, a->K, a->R, 32, C, a->gt_feat, C, 1, (long)a->R * C, a->params + d.L.of_w, 32, 1,
+                     (long)a->p_stride, rayin, RAYIN, 1, (long)a->R * RAYIN, false);
+    hipLaunchKernelGGL(feat_rowstats_kernel, dim3((a->R + 15) / 16, a->K), dim3(256), 0, st, a->params,
+                       (long)a->p_stride, d.L.of_b, C, a->R, a->gt_feat, rayin);
     hipLaunchKernelGGL(train_fused_kernel<true>, dim3(a->K * d.G), dim3(NTHR), lds_bytes, st, d);
     if (hipGetLastError() != hipSuccess) return OBJNERF_ELAUNCH;
-    hipLaunchKernelGGL(feat_post_kernel, dim3(POST_CHUNKS, a->K), dim3(256), 0, st, C, a->R, a->gt_feat, rayfeat,
-                       partial);
-    hipLaunchKernelGGL(feat_finish_kernel, dim3(a->K), dim3(1024), 0, st, a->params, (long)a->p_stride, d.L.of_w,
-                       d.L.of_b, C, a->R, rayfeat, partial, a->grads);
+    // 512-d head gradient from the per-ray (fh, O, a, c): two split-K GEMMs over the rays + a small finish
+    const long nr = (long)a->K * a->R;
+    hipLaunchKernelGGL(feat_scale_kernel, dim3((unsigned)((nr * XCOLS + 255) / 256)), dim3(256), 0, st, nr, rayfeat, X1, X2);
+    (void)hipMemsetAsync(Tm, 0, ((size_t)a->K * C * XCOLS + (size_t)a->K * XCOLS * XCOLS) * 4, st);
+    objgen::wgrad_f32(stream, a->K, C, XCOLS, a->R, a->gt_feat, 1, C, (long)a->R * C, X1, XCOLS, 1, (long)a->R * XCOLS, Tm,
+                      XCOLS, (long)C * XCOLS);
+    objgen::wgrad_f32(stream, a->K, XCOLS, XCOLS, a->R, X2, 1, XCOLS, (long)a->R * XCOLS, rayfeat, RAYFEAT, 1,
+                      (long)a->R * RAYFEAT, mom, XCOLS, (long)XCOLS * XCOLS);
+    hipLaunchKernelGGL(feat_finish_kernel, dim3((C * XCOLS + 255) / 256, a->K), dim3(256), 0, st, a->params,
+                       (long)a->p_stride, d.L.of_w, d.L.of_b, C, Tm, mom, a->grads);
   } else if (bf16) {
     launch_train_bf16(d, stream);
   } else {
