@@ -254,6 +254,24 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
     float pf_zz = 0.f, pf_gtd = 0.f, pf_gr = 0.f, pf_gg = 0.f, pf_gb = 0.f;
     int pf_lab = 2;
     if (w * (64 / S) < TR) ray_inputs(w, pf_zz, pf_gtd, pf_gr, pf_gg, pf_gb, pf_lab);
+    // feature term: (u[hh], beta, |g|, label) of ray pair (qb, half) -- same idea, first pair of the pass
+    auto feat_inputs = [&](const int ps_, const int qb_, float& uh_, float& beta_, float& ngv_, int& lab_) {
+      const int rpp_ = 64 / S;
+      const int ql2_ = qb_ + (lane >> 5);
+      const int qq2_ = ps_ * rpp_ + ql2_;
+      const int ray2_ = ray0 + qq2_;
+      uh_ = 0.f; beta_ = 0.f; ngv_ = 1.f; lab_ = 2;
+      if ((ql2_ < rpp_) && (qq2_ < TR) && (ray2_ < R)) {
+        const long rr2_ = (long)k * R + ray2_;
+        uh_ = a.rayin[rr2_ * RAYIN + (lane & 31)];
+        beta_ = a.rayin[rr2_ * RAYIN + 32];
+        ngv_ = a.rayin[rr2_ * RAYIN + 33];
+        lab_ = (int)a.labels[rr2_];
+      }
+    };
+    float pf_uh = 0.f, pf_beta = 0.f, pf_ngv = 1.f;
+    int pf_lab2 = 2;
+    if (FEAT && w * (64 / S) < TR) feat_inputs(w, 0, pf_uh, pf_beta, pf_ngv, pf_lab2);
     TILE_SYNC();
     RELAUNDER();
     PT(3);
@@ -327,8 +345,16 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
             const bool on2 = (ql2 < rpp) && (qq2 < TR) && (ray2 < R);
             const long rr2 = (long)k * R + (on2 ? ray2 : 0);
             float fh = 0.f;
-            if (on2)
+            if (rpp == 1) {
+              // one ray per pass (S = 33..64): both 32-lane halves work on it, half the samples each
+              const bool on1 = (qb < rpp) && (ps * rpp + qb < TR) && (ray0 + ps * rpp + qb < R);
+              const int q1 = ps * rpp + qb;
+              if (on1)
+                for (int s2 = half; s2 < S; s2 += 2) fh = fmaf(s_w[q1 * S + s2], stg[(q1 * S + s2) * HF_LD + hh], fh);
+              fh += __shfl_xor(fh, 32, 64);
+            } else if (on2) {
               for (int s2 = 0; s2 < S; ++s2) fh = fmaf(s_w[qq2 * S + s2], stg[(qq2 * S + s2) * HF_LD + hh], fh);
+            }
             s_fhb[half * 32 + hh] = fh;
             __builtin_amdgcn_wave_barrier();
             asm volatile("" ::: "memory");
@@ -336,16 +362,15 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
 #pragma unroll 8
             for (int h2 = 0; h2 < 32; ++h2) Gfh = fmaf(Gb[hh * 33 + h2], s_fhb[half * 32 + h2], Gfh);
             const float wbh = Gb[32 * 33 + hh], bb = Gb[32 * 33 + 32];
-            const float uh = on2 ? a.rayin[rr2 * RAYIN + hh] : 0.f;
-            const float beta = on2 ? a.rayin[rr2 * RAYIN + 32] : 0.f;
-            const float ngv = on2 ? a.rayin[rr2 * RAYIN + 33] : 1.f;
+            float uh = pf_uh, beta = pf_beta, ngv = pf_ngv;
+            int lab2 = pf_lab2;
+            if (ps != w || qb != 0) feat_inputs(ps, qb, uh, beta, ngv, lab2);
             const float O2 = on2 ? s_gof[16 + qq2] : 0.f;
             const float fu = wave_sum32(fh * uh), fGf = wave_sum32(fh * Gfh), fwb = wave_sum32(fh * wbh);
             const float dotFg = fu + O2 * beta;
             const float nF2 = fmaxf(fGf + 2.0f * O2 * fwb + O2 * O2 * bb, 0.0f);
             const float nF = fmaxf(sqrtf(nF2), 1e-8f), ngc = fmaxf(ngv, 1e-8f);
             const float cosv = dotFg / (nF * ngc);
-            const int lab2 = on2 ? (int)a.labels[rr2] : 2;
             const float mm1 = (lab2 == 1) ? 1.0f : 0.0f;
             const float gam = -a.feat_scaling * mm1 * inv1;         // d total / d cos
             const float ar = gam / (nF * ngc), cr = -gam * cosv / (nF * nF);

@@ -15,11 +15,12 @@ dev = torch.device("cuda:0")
 K, R, n1, n2 = 50, 4096, 16, 48
 arena = ops.ParamArena(K, ops.NetShape(), dev)
 arena.load_stacked(obj_init.init_stacked(K, 32, 512, seed=1000))
-ws = ops.TrainWorkspace(arena, K, R, n1 + n2, False)
-b = synthetic.random_batch(K, R, n1, n2, seed=4242)
-batch = {k: torch.from_numpy(b[k]).to(dev) for k in ["pts", "z", "gt_depth", "gt_rgb", "labels"]}
+FEAT = "--feat" in sys.argv
+ws = ops.TrainWorkspace(arena, K, R, n1 + n2, FEAT)
+b = synthetic.random_batch(K, R, n1, n2, seed=4242, feat_dim=512 if FEAT else 0)
+batch = {k: torch.from_numpy(b[k]).to(dev) for k in ["pts", "z", "gt_depth", "gt_rgb", "labels"] + (["gt_feat"] if FEAT else [])}
 for _ in range(3):
-    ops.train_step(arena, ws, batch)
+    ops.train_step(arena, ws, batch, with_feat=FEAT)
 torch.cuda.synchronize()
 out = (C.c_ulonglong * (8 * 24))()
 f = _lib.lib().objnerf_debug_phase
