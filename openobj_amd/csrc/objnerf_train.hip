@@ -579,7 +579,9 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
       wgrad_pair(accC0, accC1, lane_rd + dTr * STG_LD, lane_rd + aTr * STG_LD);
     }
     PT(16);
-    TILE_SYNC();
+    // The staging area is next written in phase A of the following tile, two barriers from here; only the feature
+    // build writes it earlier (its hidden-feature buffer after the forward pass) and needs this barrier.
+    if (FEAT) TILE_SYNC();
     RELAUNDER();
     PT(17);
   }
@@ -614,6 +616,7 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
     if ((tid & 7) == 0 && p < 3 * OBJ_NDIR) slab[L.pe_b + p] = v;
   }
   // slot registers -> LDS (per wave), then sum the 8 waves
+  __syncthreads();    // the last tile's weight-gradient reads of the staging area are done
   float* red = stg;   // [NWAVE][NRED]
   {
     float* mine = red + w * NRED;
