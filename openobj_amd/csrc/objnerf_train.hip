@@ -149,7 +149,7 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
   float gS1 = 0.f;   // [0..7] d W_oc[1]   | [8..15] d W_oc[2]
   float gS2 = 0.f;   // [0..7] d b_mid1    | [8..15] d b_mid2
   float g_ba = 0.f, g_boc0 = 0.f, g_boc1 = 0.f, g_boc2 = 0.f;
-  float g_dB = 0.f;  // thread (p = tid >> 3, q = tid & 7): partial of d B[p / 3][p % 3] over samples 16q..16q+15
+  f32x4 accT0 = zero4(), accT1 = zero4();   // d B: rows j = 4g + r (accT1: 16 + 4g + r), column x = c < 3
   float l_d = 0.f, l_c = 0.f, l_o = 0.f, l_f = 0.f;
   f32x4 accF0 = zero4(), accF1 = zero4();
 
@@ -543,24 +543,24 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
         if (need[1]) dpj.t[1] = OBJ_MFMA((j - 16 == c) ? f : 0.0f, dps[i], dpj.t[1]);
       }
       store_T32(stg_lane, 160, dpj);      // rows 160..180 (181..191: zeros), free in phase B
+      // d B[j][x] += sum over THIS wave's 16 samples of dproj[j][s] t[x][s] (embedding.py:48): the wave re-reads
+      // its own columns as MFMA operands (A = table rows, B = the t rows 32..34 of the x1 staging)
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("" ::: "memory");
+      const float* ta = stg + (160 + c) * STG_LD + 16 * w + g;
+      const float* tb = stg + (32 + (c < 3 ? c : 2)) * STG_LD + 16 * w + g;
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        const float bv = (c < 3) ? tb[4 * st] : 0.0f;
+        accT0 = OBJ_MFMA(ta[4 * st], bv, accT0);
+        accT1 = OBJ_MFMA(ta[16 * STG_LD + 4 * st], bv, accT1);
+      }
     }
     PT(11);
     TILE_SYNC();
     RELAUNDER();
     PT(12);
-    {
-      // d B[j][x] += sum_s dproj[j][s] * t[x][s]  (embedding.py:48): thread (p, q) takes 16 samples of pair p
-      const int p = tid >> 3, qq = tid & 7;
-      if (p < 3 * OBJ_NDIR) {
-        const float* tp = stg + (160 + p / 3) * STG_LD + 16 * qq;
-        const float* xp = stg + (32 + p % 3) * STG_LD + 16 * qq;
-        float acc = 0.f;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) acc = fmaf(tp[s], xp[s], acc);
-        g_dB += acc;
-      }
-      wgrad_pair(accB0, accB1, lane_rd + 128 * STG_LD, lane_rd + (16 * w) * STG_LD);
-    }
+    wgrad_pair(accB0, accB1, lane_rd + 128 * STG_LD, lane_rd + (16 * w) * STG_LD);
     PT(13);
     TILE_SYNC();
     RELAUNDER();
@@ -606,15 +606,6 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
   if (w < 6) write_pair(slab, accC0, accC1, c, g, w, L.in_w, OBJ_E1, L.in_b);
   else write_pair(slab, accC0, accC1, c, g, w - 6, L.m1_w, H, -1);
   if (FEAT && w < 5) write_pair(slab, accF0, accF1, c, g, w, L.fl_w, H + OBJ_E2, L.fl_b);
-  {
-    // d B: the 8 threads of pair p sit in one wave
-    float v = g_dB;
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    const int p = tid >> 3;
-    if ((tid & 7) == 0 && p < 3 * OBJ_NDIR) slab[L.pe_b + p] = v;
-  }
   // slot registers -> LDS (per wave), then sum the 8 waves
   __syncthreads();    // the last tile's weight-gradient reads of the staging area are done
   float* red = stg;   // [NWAVE][NRED]
@@ -629,8 +620,22 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
     const float e0 = wave_sum64(l_d), e1 = wave_sum64(l_c), e2 = wave_sum64(l_o);
     const float e3 = wave_sum64(l_f);
     if (lane == 0) { mine[196] = e0; mine[197] = e1; mine[198] = e2; mine[199] = e3; }
+    if (c < 3) {
+      float* dbw = red + NWAVE * NRED + w * 64;            // d B partial of this wave: [21 * 3]
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        dbw[(4 * g + r) * 3 + c] = accT0[r];
+        if (16 + 4 * g + r < OBJ_NDIR) dbw[(16 + 4 * g + r) * 3 + c] = accT1[r];
+      }
+    }
   }
   __syncthreads();
+  if (tid < 3 * OBJ_NDIR) {
+    float v = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < NWAVE; ++ww) v += red[NWAVE * NRED + ww * 64 + tid];
+    slab[L.pe_b + tid] = v;
+  }
   for (int i = tid; i < NRED; i += NTHR) {
     float v = 0.f;
 #pragma unroll

@@ -181,6 +181,18 @@ __device__ __forceinline__ void write_pair_b(float* slab, const f32x4& a0, const
   }
 }
 
+#ifdef PHASE_TIMING
+__device__ unsigned long long g_phase_b[8][24];
+#define PT_INIT() unsigned long long pt_acc[18]; for (int i_ = 0; i_ < 18; ++i_) pt_acc[i_] = 0; \
+  unsigned long long pt_t0 = __builtin_amdgcn_s_memtime()
+#define PT(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pt_acc[i] += t_ - pt_t0; pt_t0 = t_; } while (0)
+#define PT_FLUSH() do { if (blockIdx.x == 0 && lane == 0) for (int i_ = 0; i_ < 18; ++i_) g_phase_b[w][i_] = pt_acc[i_]; } while (0)
+#else
+#define PT_INIT() do {} while (0)
+#define PT(i) do {} while (0)
+#define PT_FLUSH() do {} while (0)
+#endif
+
 __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a) {
   extern __shared__ __attribute__((aligned(16))) char ldsb[];
   const int tid = threadIdx.x;
@@ -208,7 +220,7 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
   f32x4 accA0 = zero4(), accA1 = zero4(), accB0 = zero4(), accB1 = zero4(), accC0 = zero4(), accC1 = zero4();
   float gS0 = 0.f, gS1 = 0.f, gS2 = 0.f;
   float g_ba = 0.f, g_boc0 = 0.f, g_boc1 = 0.f, g_boc2 = 0.f;
-  float g_dB = 0.f;
+  f32x4 accT0 = zero4(), accT1 = zero4();   // d B: rows j = 4g + r (accT1: 16 + 4g + r), column x = c < 3
   float l_d = 0.f, l_c = 0.f, l_o = 0.f;
 
   char* stg_lane = stg + (4 * g) * STG_PITCH + (16 * w + c) * 2;
@@ -226,31 +238,41 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
 
   const bool rows_mode = seg_is_rows(a.S);
   const SegRows seg_rows = SegRows::make(rows_mode ? a.S : 64, lane);
+  // sample position of (tile, slot); issued one tile ahead (phase C), as in objnerf_train.hip
+  auto fetch_point = [&](const int tile_, const int slot_, float& x, float& y, float& z_) {
+    const int q_ = slot_ / a.S, si_ = slot_ - q_ * a.S;
+    const int ray_ = tile_ * a.TR + q_;
+    x = 0.f; y = 0.f; z_ = 0.f;
+    if (tile_ < a.NT && q_ < a.TR && ray_ < a.R) {
+      const long rr = (long)k * a.R + ray_;
+      if (a.pts) {
+        const float* p = a.pts + (rr * a.S + si_) * 3;
+        x = p[0]; y = p[1]; z_ = p[2];
+      } else {
+        const float zz = a.z[rr * a.S + si_];
+        const float* o = a.origins + rr * 3;
+        const float* d = a.dirs + rr * 3;
+        x = (o[0] + d[0] * zz) - a.obj_center;
+        y = (o[1] + d[1] * zz) - a.obj_center;
+        z_ = (o[2] + d[2] * zz) - a.obj_center;
+      }
+    }
+  };
+  float nx, ny, nz;
+  fetch_point(gi, 16 * w + c, nx, ny, nz);
+  PT_INIT();
   for (int tile = gi; tile < a.NT; tile += a.G) {
     asm volatile("" ::: "memory");
     const int ray0 = tile * TR;
     // ---------------------------------------------------------------- 1. forward
     const int slot = 16 * w + c;
-    const int q = slot / S, si = slot - q * S;
+    const int q = slot / S;
     const int ray = ray0 + q;
     const bool valid = (q < TR) && (ray < R);
-    float px = 0.f, py = 0.f, pz = 0.f;
-    if (valid) {
-      const long rr = (long)k * R + ray;
-      if (a.pts) {
-        const float* p = a.pts + (rr * S + si) * 3;
-        px = p[0]; py = p[1]; pz = p[2];
-      } else {
-        const float zz = a.z[rr * S + si];
-        const float* o = a.origins + rr * 3;
-        const float* d = a.dirs + rr * 3;
-        px = (o[0] + d[0] * zz) - a.obj_center;
-        py = (o[1] + d[1] * zz) - a.obj_center;
-        pz = (o[2] + d[2] * zz) - a.obj_center;
-      }
-    }
+    const float px = nx, py = ny, pz = nz;       // fetched during the previous tile's phase C
     Pe pe;
     pe_project_b(sm, g, px, py, pz, scale, pe);
+    PT(0);
     T32 h1, h2, h3, h4, hc;
     float alpha_v, col_v[3];
     {
@@ -325,7 +347,9 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
     float pf_zz = 0.f, pf_gtd = 0.f, pf_gr = 0.f, pf_gg = 0.f, pf_gb = 0.f;
     int pf_lab = 2;
     if (w * (64 / S) < TR) ray_inputs(w, pf_zz, pf_gtd, pf_gr, pf_gg, pf_gb, pf_lab);
+    PT(2);
     __syncthreads();
+    PT(3);
     // ---------------------------------------------------------------- 2. composite + loss (fp32, as objnerf_train.hip)
     auto composite_passes = [&](const auto& sg) {
       const int rpp = 64 / S;
@@ -383,7 +407,9 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
       }
     };
     if (rows_mode) composite_passes(seg_rows); else composite_passes(SegGeneric{S});
+    PT(4);
     __syncthreads();
+    PT(5);
     // ---------------------------------------------------------------- 3. backward
     const float da = valid ? s_alpha[slot] : 0.0f;
     const float dc0 = valid ? s_col[slot] : 0.0f;
@@ -436,13 +462,17 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
     bwd_tile(d_h3.t[0], t_m2, 0, d_h4_b);
     bwd_tile(d_h3.t[1], t_m2, 16, d_h4_b);
     d_h3 = relu_mask32(d_h3, h3);
+    PT(6);
     __syncthreads();
+    PT(7);
     if (w < 7) {
       const int dTr = (w < 5) ? 128 : 160;
       const int aTr = (w < 5) ? 16 * w : 96 + 16 * (w - 5);
       wgrad_pair_b(accA0, accA1, lane_rd + dTr * STG_PITCH, lane_rd + aTr * STG_PITCH);
     }
+    PT(8);
     __syncthreads();
+    PT(9);
     // ---- phase B
     store32_b(stg_lane, 0, h2);
     store32_b(stg_lane, 128, d_h3);
@@ -496,33 +526,43 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
         trow[33 * TB_LD] = pe.t[1];
         trow[34 * TB_LD] = pe.t[2];
       }
-    }
-    __syncthreads();
-    {
-      const int p = tid >> 3, qq = tid & 7;
-      if (p < 3 * OBJ_NDIR) {
-        const float* tp = tbuf + (p / 3) * TB_LD + 16 * qq;
-        const float* xp = tbuf + (32 + p % 3) * TB_LD + 16 * qq;
-        float acc = 0.f;
+      // d B[j][x] += sum over THIS wave's 16 samples of dproj[j][s] t[x][s] (embedding.py:48): the wave re-reads
+      // its own columns as MFMA operands (A = table rows, B = the three t rows), no barrier, no strided reduce
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("" ::: "memory");
+      const float* ta = tbuf + c * TB_LD + 16 * w + g;
+      const float* tb = tbuf + (32 + (c < 3 ? c : 2)) * TB_LD + 16 * w + g;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) acc = fmaf(tp[s], xp[s], acc);
-        g_dB += acc;
+      for (int st = 0; st < 4; ++st) {
+        const float bv = (c < 3) ? tb[4 * st] : 0.0f;
+        accT0 = OBJ_MFMA(ta[4 * st], bv, accT0);
+        accT1 = OBJ_MFMA(ta[16 * TB_LD + 4 * st], bv, accT1);
       }
-      wgrad_pair_b(accB0, accB1, lane_rd + 128 * STG_PITCH, lane_rd + (16 * w) * STG_PITCH);
     }
+    PT(11);
+    __syncthreads();
+    PT(12);
+    wgrad_pair_b(accB0, accB1, lane_rd + 128 * STG_PITCH, lane_rd + (16 * w) * STG_PITCH);
+    PT(13);
     __syncthreads();
     // ---- phase C
+    fetch_point(tile + a.G, slot, nx, ny, nz);
     store32_b(stg_lane, 0, h1);
     store32_b(stg_lane, 128, d_h1);
     store32_b(stg_lane, 160, d_h2);
+    PT(14);
     __syncthreads();
+    PT(15);
     {
       const int dTr = (w < 6) ? 128 : 160;
       const int aTr = (w < 6) ? 32 + 16 * w : 16 * (w - 6);
       wgrad_pair_b(accC0, accC1, lane_rd + dTr * STG_PITCH, lane_rd + aTr * STG_PITCH);
     }
+    PT(16);
     __syncthreads();
+    PT(17);
   }
+  PT_FLUSH();
 
   float* slab = a.slab + ((long)k * a.G + gi) * a.slab_stride;
   const Layout& L = a.L;
@@ -531,14 +571,6 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
   write_pair_b(slab, accB0, accB1, c, g, w, L.cat_w, H + OBJ_E1, L.cat_b);
   if (w < 6) write_pair_b(slab, accC0, accC1, c, g, w, L.in_w, OBJ_E1, L.in_b);
   else write_pair_b(slab, accC0, accC1, c, g, w - 6, L.m1_w, H, -1);
-  {
-    float v = g_dB;
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    const int p = tid >> 3;
-    if ((tid & 7) == 0 && p < 3 * OBJ_NDIR) slab[L.pe_b + p] = v;
-  }
   float* red = reinterpret_cast<float*>(stg);   // [NWAVE][NRED]
   {
     float* mine = red + w * NRED;
@@ -550,8 +582,22 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
     if (lane == 0) { mine[192] = s0; mine[193] = s1; mine[194] = s2; mine[195] = s3; }
     const float e0 = wave_sum64(l_d), e1 = wave_sum64(l_c), e2 = wave_sum64(l_o);
     if (lane == 0) { mine[196] = e0; mine[197] = e1; mine[198] = e2; mine[199] = 0.0f; }
+    if (c < 3) {
+      float* dbw = red + NWAVE * NRED + w * 64;            // [NWAVE][21 * 3]
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        dbw[(4 * g + r) * 3 + c] = accT0[r];
+        if (16 + 4 * g + r < OBJ_NDIR) dbw[(16 + 4 * g + r) * 3 + c] = accT1[r];
+      }
+    }
   }
   __syncthreads();
+  if (tid < 3 * OBJ_NDIR) {
+    float v = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < NWAVE; ++ww) v += red[NWAVE * NRED + ww * 64 + tid];
+    slab[L.pe_b + tid] = v;
+  }
   for (int i = tid; i < NRED; i += NTHR) {
     float v = 0.f;
 #pragma unroll
@@ -569,6 +615,14 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
 }  // namespace
 
 size_t bf16_lds_bytes() { return LDS_BYTES; }
+
+#ifdef PHASE_TIMING
+extern "C" int objnerf_debug_phase_bf16(unsigned long long* out_host) {
+  if (hipDeviceSynchronize() != hipSuccess) return OBJNERF_ELAUNCH;
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_phase_b), sizeof(unsigned long long) * 8 * 24) == hipSuccess
+             ? OBJNERF_OK : OBJNERF_ELAUNCH;
+}
+#endif
 
 void launch_train_bf16(const TrainDev& d, void* stream) {
   static bool attr_set = false;

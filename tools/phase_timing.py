@@ -16,14 +16,15 @@ K, R, n1, n2 = 50, 4096, 16, 48
 arena = ops.ParamArena(K, ops.NetShape(), dev)
 arena.load_stacked(obj_init.init_stacked(K, 32, 512, seed=1000))
 FEAT = "--feat" in sys.argv
+BF16 = "--bf16" in sys.argv
 ws = ops.TrainWorkspace(arena, K, R, n1 + n2, FEAT)
 b = synthetic.random_batch(K, R, n1, n2, seed=4242, feat_dim=512 if FEAT else 0)
 batch = {k: torch.from_numpy(b[k]).to(dev) for k in ["pts", "z", "gt_depth", "gt_rgb", "labels"] + (["gt_feat"] if FEAT else [])}
 for _ in range(3):
-    ops.train_step(arena, ws, batch, with_feat=FEAT)
+    ops.train_step(arena, ws, batch, with_feat=FEAT, bf16=BF16)
 torch.cuda.synchronize()
 out = (C.c_ulonglong * (8 * 24))()
-f = _lib.lib().objnerf_debug_phase
+f = _lib.lib().objnerf_debug_phase_bf16 if BF16 else _lib.lib().objnerf_debug_phase
 f.restype = C.c_int
 assert f(out) == 0
 a = np.array(list(out), dtype=np.float64).reshape(8, 24)[:, :18]
