@@ -10,6 +10,7 @@
 // Master weights, embedding, activations, compositing, losses, gradient accumulators stay fp32; only MFMA
 // operands (weights, activations, staged transposes) are rounded to bf16 (round-to-nearest-even).
 // The reference is fp32-only (train.py:74 AMP = False): this path is gated by PSNR, not by 1e-4.
+#define OBJ_HW_SINCOS 1      // embedding sin / cos on the transcendental unit (see objnerf_device.h)
 #include "objnerf_train_common.h"
 #include "../../include/objnerf_hip.h"
 
