@@ -500,22 +500,29 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
       store16_b(stg_lane, 32 + 16 * T, pe_x1_tile_fb(pe, T, g, d_x, dps));
     }
     {
-      // cross-group sum of d ps on the matrix core (see objnerf_train.hip), then rows j of the fp32 table
+      // cross-group sum of d ps on the matrix core (see objnerf_train.hip), then rows j of the fp32 table;
+      // eight registers per bf16 MFMA: k-slot (g, e) = register 8 blk + e of lane group g, A = 0/1/2 selection
       T32 dpj = zero32();
 #pragma unroll
-      for (int i = 0; i < OBJ_NDIR; ++i) {
-        bool need[2] = {false, false};
+      for (int blk = 0; blk < 3; ++blk) {
+        bf16x8 bv, a0, a1;
 #pragma unroll
-        for (int gg = 0; gg < 4; ++gg) {
-          const int mm = 4 * gg + i;
-          need[((i > 8 && mm >= OBJ_NDIR) ? mm - OBJ_NDIR : mm) >> 4] = true;
+        for (int e = 0; e < 8; ++e) {
+          const int i = 8 * blk + e;
+          if (i < OBJ_NDIR) {
+            const int m = 4 * g + i;
+            const bool wrap = (i > 8) && (m >= OBJ_NDIR);
+            const int j = wrap ? m - OBJ_NDIR : m;
+            const float f = wrap ? 2.0f : 1.0f;
+            bv[e] = (__bf16)dps[i];
+            a0[e] = (__bf16)((j == c) ? f : 0.0f);
+            a1[e] = (__bf16)((j - 16 == c) ? f : 0.0f);
+          } else {
+            bv[e] = (__bf16)0.0f; a0[e] = (__bf16)0.0f; a1[e] = (__bf16)0.0f;
+          }
         }
-        const int m = 4 * g + i;
-        const bool wrap = (i > 8) && (m >= OBJ_NDIR);
-        const int j = wrap ? m - OBJ_NDIR : m;
-        const float f = wrap ? 2.0f : 1.0f;
-        if (need[0]) dpj.t[0] = OBJ_MFMA((j == c) ? f : 0.0f, dps[i], dpj.t[0]);
-        if (need[1]) dpj.t[1] = OBJ_MFMA((j - 16 == c) ? f : 0.0f, dps[i], dpj.t[1]);
+        dpj.t[0] = MFMA_BF16(a0, bv, dpj.t[0]);
+        dpj.t[1] = MFMA_BF16(a1, bv, dpj.t[1]);
       }
       float* trow = tbuf + (4 * g) * TB_LD + 16 * w + c;
 #pragma unroll
