@@ -26,7 +26,10 @@ struct Gemm {
   float* rowsum; long bsrs;   // optional: rowsum[m] += sum_k A(m,k)  (bias gradient riding on the weight-gradient GEMM)
 };
 
-constexpr int BK = 16;
+#ifndef OBJ_GEMM_BK
+#define OBJ_GEMM_BK 16
+#endif
+constexpr int BK = OBJ_GEMM_BK;
 
 // Workgroup tile (32*TM*2) x (32*TN*2): 4 waves as 2 x 2, each wave TM x TN MFMA tiles of 16 x 16.
 // <1,1> = 64 x 64 (small problems), <2,2> = 128 x 128 (the n x H x H layer GEMMs: 2 MFMAs per LDS read).
@@ -59,7 +62,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Gemm g) {
     for (int i = 0; i < NA; ++i) {
       const int e = tid + 256 * i;
       int am, ak;
-      if (g.sak == 1) { ak = e & 15; am = e >> 4; } else { am = e % BM; ak = e / BM; }
+      if (g.sak == 1) { ak = e % BK; am = e / BK; } else { am = e % BM; ak = e / BM; }
       const int gm = m0 + am, gk = k0 + ak;
       ra[i] = (gm < g.M && gk < kend) ? A[gm * g.sam + gk * g.sak] : 0.f;
     }
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Gemm g) {
     for (int i = 0; i < NB; ++i) {
       const int e = tid + 256 * i;
       int bn, bk;
-      if (g.sbk == 1) { bk = e & 15; bn = e >> 4; } else { bn = e % BN; bk = e / BN; }
+      if (g.sbk == 1) { bk = e % BK; bn = e / BK; } else { bn = e % BN; bk = e / BN; }
       const int gn = n0 + bn, gk2 = k0 + bk;
       rb[i] = (gn < g.N && gk2 < kend) ? B[gk2 * g.sbk + gn * g.sbn] : 0.f;
     }
@@ -77,14 +80,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Gemm g) {
     for (int i = 0; i < NA; ++i) {
       const int e = tid + 256 * i;
       int am, ak;
-      if (g.sak == 1) { ak = e & 15; am = e >> 4; } else { am = e % BM; ak = e / BM; }
+      if (g.sak == 1) { ak = e % BK; am = e / BK; } else { am = e % BM; ak = e / BM; }
       As[ak][am] = ra[i];
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int e = tid + 256 * i;
       int bn, bk;
-      if (g.sbk == 1) { bk = e & 15; bn = e >> 4; } else { bn = e % BN; bk = e / BN; }
+      if (g.sbk == 1) { bk = e % BK; bn = e / BK; } else { bn = e % BN; bk = e / BN; }
       Bs[bk][bn] = rb[i];
     }
   };
@@ -149,7 +152,9 @@ static void gemm(hipStream_t st, int batch, int M, int N, int Kd, const float* A
   g.accumulate = accumulate; g.relu = relu; g.splitk = splitk;
   g.rowsum = rowsum; g.bsrs = bsrs;
   const int nz = batch * (splitk > 1 ? splitk : 1);
-  if (M >= 256 && N >= 96) {          // tall layer GEMMs: 128 x 128 tiles
+  if (M >= 256 && N >= 192) {         // wide layer GEMMs (hidden 256): 128 x 128 tiles.  Up to N = 128 the
+                                      // 64 x 64 tiles win (measured, hidden 128): 4x the workgroups, 16 instead
+                                      // of 64 accumulator registers -> occupancy hides the operand latency
     dim3 grid((N + 127) / 128, (M + 127) / 128, nz);
     hipLaunchKernelGGL((gemm_kernel<4, 4>), grid, dim3(256), 0, st, g);
   } else {
