@@ -4,9 +4,19 @@ Objects are independent networks with independent rays, gradients and Adam state
 the K objects are split into contiguous blocks and NO data-path collective is needed.  The one
 coupling is render_rays.py:89-94: if ANY object of the batch has an empty mask, that loss term is zero
 for ALL objects -- a pair of flags that must be global (2-int all_reduce(MAX))."""
+import os
 from typing import Optional, Tuple
 
 import torch
+
+
+def _active(group=None) -> bool:
+    """Collectives run when a process group spans more than one rank -- or, with OBJNERF_DIST_SELFTEST=1, also on
+    a single-rank group (lets one GPU exercise the RCCL code path: `torchrun --nproc-per-node 1 bench.py`)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or os.environ.get("OBJNERF_DIST_SELFTEST") == "1"
 
 
 def shard_objects(K: int, world: int, rank: int) -> Tuple[int, int]:
@@ -19,7 +29,7 @@ def shard_objects(K: int, world: int, rank: int) -> Tuple[int, int]:
 def global_flags(local_flags: torch.Tensor, group=None) -> torch.Tensor:
     """MAX-reduce the two early-return flags over all ranks (in place)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _active(group):
         dist.all_reduce(local_flags, op=dist.ReduceOp.MAX, group=group)
     return local_flags
 
@@ -31,7 +41,7 @@ def total_loss(local_terms: torch.Tensor, color_scaling=5.0, opacity_scaling=10.
     import torch.distributed as dist
     w = torch.tensor([1.0, color_scaling, opacity_scaling, feat_scaling], device=local_terms.device)
     t = (local_terms * w).sum().reshape(1)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _active(group):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
 
@@ -39,7 +49,7 @@ def total_loss(local_terms: torch.Tensor, color_scaling=5.0, opacity_scaling=10.
 def allreduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:
     """In-place SUM all-reduce (RCCL when the tensor is on a GPU); no-op for a single process."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _active(group):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
 
