@@ -29,6 +29,9 @@ class cameraInfo:
                              float(self.cy), self.device)
 
 
+RENDER_SAMPLES_PER_CHUNK = 1 << 23      # samples per launch chain of sceneObject.render_2D_syn
+
+
 class sceneObject:
     """Keyframe ring buffers of one object + its Trainer (networks)."""
 
@@ -199,7 +202,8 @@ class sceneObject:
         n pixels that hit the box, terminate inside it (near <= depth <= far) and reach opacity 0.9 -- or
         (None, None, None).  The whole view is ONE launch chain on the device: box sampler -> fused PE + MLP ->
         compositing (depth, rgb, opacity and the H-wide feature hidden) -> the linear 512-d head applied to the
-        composited hidden (exact, the head is linear); chunk_size is accepted for signature parity only."""
+        composited hidden (exact, the head is linear).  Rays are processed in chunks of RENDER_SAMPLES_PER_CHUNK
+        samples; the reference's chunk_size (points per network call) is accepted for signature parity only."""
         tr = self.trainer
         W, H = tr.W_vis, tr.H_vis
         _, bbox = self.get_bound(intrinsic_open3d, final=True)
@@ -219,10 +223,22 @@ class sceneObject:
             return None, None, None
         tr.arena.scale.fill_(float(tr.obj_scale))
         with torch.no_grad():
-            alpha, color, hfeat, _ = ops.eval_points(tr.arena, tr.input_pcs.reshape(1, -1, 3), want_hfeat=render_part)
-            out = ops.composite(alpha.reshape(n_pts, S), color.reshape(n_pts, S, 3), tr.z_vals,
-                                vals=hfeat.reshape(n_pts, S, -1) if render_part else None)
-            depth, opacity = out["depth"], out["opacity"]
+            # ray chunks bound the live activations (the H-wide feature hidden is 128 B per sample at hidden 32)
+            rays_per_chunk = max(1, RENDER_SAMPLES_PER_CHUNK // S)
+            depth = torch.empty(n_pts, device=dev)
+            opacity = torch.empty(n_pts, device=dev)
+            rgb = torch.empty(n_pts, 3, device=dev)
+            fh = torch.empty(n_pts, tr.hidden_feature_size, device=dev) if render_part else None
+            for r0 in range(0, n_pts, rays_per_chunk):
+                r1 = min(n_pts, r0 + rays_per_chunk)
+                alpha, color, hfeat, _ = ops.eval_points(tr.arena, tr.input_pcs[r0:r1].reshape(1, -1, 3),
+                                                         want_hfeat=render_part)
+                o = ops.composite(alpha.reshape(r1 - r0, S), color.reshape(r1 - r0, S, 3), tr.z_vals[r0:r1],
+                                  vals=hfeat.reshape(r1 - r0, S, -1) if render_part else None)
+                depth[r0:r1], opacity[r0:r1], rgb[r0:r1] = o["depth"], o["opacity"], o["rgb"]
+                if render_part:
+                    fh[r0:r1] = o["vals"]
+            out = dict(rgb=rgb, vals=fh)
             bad = (depth < obj_near) | (depth > obj_far) | (opacity < 0.9)          # :665,672
             keep = ~bad
             render_color = (out["rgb"] * 255).to(torch.uint8)                       # :671 (truncation)
