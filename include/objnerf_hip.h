@@ -207,12 +207,16 @@ int objnerf_label_counts(int32_t K, int32_t R, const uint8_t* labels, int32_t* c
  * GPUs first -- the early return spans every object of the batch).
  * Outputs: grads [K][P_stride] (same layout as params; entries of tensors without gradient are
  * left untouched), loss_terms [K][4], status [1].
- * workspace: objnerf_train_workspace_bytes() bytes, 256-byte aligned.
+ * workspace: objnerf_train_workspace_bytes() bytes, 256-byte aligned (its with_feat argument: bit 0 = feature
+ * loss, bit 1 = size for OBJNERF_TRAIN_LAYERWISE).
  */
 #define OBJNERF_TRAIN_BF16 1   /* mode bit: MFMA operands rounded to bf16 (fp32 accumulate, fp32 master weights,
                                 * fp32 embedding/compositing/losses).  NOT the reference's arithmetic (fp32,
                                 * train.py:74) -- an opt-in throughput mode gated by PSNR; hidden 32, S <= 64,
                                 * no feature loss, else OBJNERF_ENOTSUP. */
+#define OBJNERF_TRAIN_LAYERWISE 2   /* mode bit: take the layer-wise (any width) path even for hidden 32 / S <= 64 --
+                                     * a second, independent implementation of the same iteration; the tests use
+                                     * it to cross-check the fused kernel at sizes no CPU oracle reaches. */
 typedef struct objnerf_train_args {
   int32_t K, R, S, mode;
   float color_scaling, opacity_scaling, feat_scaling, obj_center;

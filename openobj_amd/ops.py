@@ -272,10 +272,10 @@ def step_batch_loss(alpha, color, gt_depth, gt_rgb, labels, z, color_scaling=5.0
 class TrainWorkspace:
     """Caller-owned buffers of the fused training step, allocated once per (K,R,S)."""
 
-    def __init__(self, arena: ParamArena, K: int, R: int, S: int, with_feat: bool):
+    def __init__(self, arena: ParamArena, K: int, R: int, S: int, with_feat: bool, layerwise: bool = False):
         dev = arena.params.device
         net = arena.net.c()
-        nbytes = lib().objnerf_train_workspace_bytes(C.byref(net), K, R, S, int(with_feat))
+        nbytes = lib().objnerf_train_workspace_bytes(C.byref(net), K, R, S, int(with_feat) | (2 if layerwise else 0))
         if nbytes == 0:
             raise _lib.ObjnerfError("objnerf_train_workspace_bytes returned 0")
         self.nbytes = int(nbytes)
@@ -291,8 +291,11 @@ class TrainWorkspace:
 def train_step(arena: ParamArena, ws: TrainWorkspace, batch: Dict[str, torch.Tensor], color_scaling=5.0,
                opacity_scaling=10.0, feat_scaling=5.0, with_feat=False, obj_center=0.0,
                global_flags: Optional[torch.Tensor] = None, global_counts: Optional[torch.Tensor] = None,
-               bf16: bool = False) -> None:
+               bf16: bool = False, layerwise: bool = False) -> None:
     """One fused iteration (train.py:424-472): fills ws.grads, ws.loss_terms, ws.status.
+
+    layerwise: OBJNERF_TRAIN_LAYERWISE -- run the layer-wise (any width) implementation even where the fused
+    kernel applies (cross-check of two independent implementations; ws must be built with layerwise=True).
 
     bf16: opt-in OBJNERF_TRAIN_BF16 mode (bf16 MFMA operands, fp32 accumulate / master weights); the default
     is the reference's fp32 arithmetic.
@@ -319,7 +322,7 @@ def train_step(arena: ParamArena, ws: TrainWorkspace, batch: Dict[str, torch.Ten
     if global_counts is not None:       # one object's rays split over ranks (background): global mask counts
         counts = _req(global_counts, torch.int32, "global_counts")
     net = arena.net.c()
-    a = TrainArgs(K, R, S, 1 if bf16 else 0, color_scaling, opacity_scaling, feat_scaling, obj_center, _ptr(arena.params),
+    a = TrainArgs(K, R, S, (1 if bf16 else 0) | (2 if layerwise else 0), color_scaling, opacity_scaling, feat_scaling, obj_center, _ptr(arena.params),
                   arena.p_stride, _ptr(arena.scale), _ptr(pts), _ptr(origins), _ptr(dirs), _ptr(z), _ptr(gt_depth),
                   _ptr(gt_rgb), _ptr(labels), _ptr(gt_feat), _ptr(counts), _ptr(flags), _ptr(ws.grads),
                   _ptr(ws.loss_terms), _ptr(ws.status), _ptr(ws.buf), ws.nbytes)

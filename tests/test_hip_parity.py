@@ -456,3 +456,64 @@ def test_train_step_rejects_bad_arguments(golden, dev):
     ws.nbytes = 16                                # lie about the workspace size
     with pytest.raises(_lib.ObjnerfError):
         ops.train_step(arena, ws, batch)
+
+
+def _full_size_setup(dev, K, R, n1, n2, feat):
+    arena = ops.ParamArena(K, ops.NetShape(), dev)
+    arena.load_stacked(obj_init.init_stacked(K, 32, 512, seed=123))
+    b = synthetic.random_batch(K, R, n1, n2, seed=321, feat_dim=512 if feat else 0)
+    keys = ["pts", "z", "gt_depth", "gt_rgb", "labels"] + (["gt_feat"] if feat else [])
+    return arena, {k: T(b[k]).to(dev) for k in keys}
+
+
+@pytest.mark.parametrize("feat", [False, True])
+def test_full_size_two_implementations_agree(dev, feat):
+    """BASELINE size per object (4096 rays x 64 samples; 12 objects to keep the layer-wise activations at a few GB):
+    no CPU oracle reaches it, but the fused kernel and the layer-wise path are independent implementations of the
+    same iteration (different kernels, different summation orders) -- they must agree."""
+    K, R, n1, n2 = 12, 4096, 16, 48
+    arena, batch = _full_size_setup(dev, K, R, n1, n2, feat)
+    ws_f = ops.TrainWorkspace(arena, K, R, n1 + n2, feat)
+    ws_l = ops.TrainWorkspace(arena, K, R, n1 + n2, feat, layerwise=True)
+    ops.train_step(arena, ws_f, batch, with_feat=feat)
+    ops.train_step(arena, ws_l, batch, with_feat=feat, layerwise=True)
+    torch.cuda.synchronize()
+    assert int(ws_f.status.item()) == 0 and int(ws_l.status.item()) == 0
+    tf, tl = ws_f.loss_terms.double().cpu(), ws_l.loss_terms.double().cpu()
+    assert float((tf - tl).abs().max()) < 1e-4 * max(1.0, float(tl.abs().max()))
+    gf, gl = arena.views(ws_f.grads), arena.views(ws_l.grads)
+    for i in range(19):
+        if i in ops.FEAT_TENSORS and not feat:
+            continue
+        scale = max(1e-3, float(gl[i].abs().max()))
+        assert maxerr(gf[i], gl[i]) < 3e-4 * scale, (i, ops.TENSOR_NAMES[i], maxerr(gf[i], gl[i]), scale)
+
+
+def test_full_size_gradient_is_additive_over_ray_halves(dev):
+    """BASELINE configs[1] size (50 objects x 4096 rays x 64 samples): with the mask counts and early-return flags of
+    the WHOLE batch, the gradient of the batch equals the sum of the gradients of its two ray halves -- the property
+    the background network's ray sharding over GPUs relies on (train.BackgroundLoop)."""
+    K, R, n1, n2 = 50, 4096, 16, 48
+    arena, batch = _full_size_setup(dev, K, R, n1, n2, False)
+    ws = ops.TrainWorkspace(arena, K, R, n1 + n2, False)
+    ops.train_step(arena, ws, batch)
+    full = ws.grads.clone()
+    full_terms = ws.loss_terms.clone()
+    counts, flags = ws.counts.clone(), ws.flags.clone()
+    ws_h = ops.TrainWorkspace(arena, K, R // 2, n1 + n2, False)
+    acc = torch.zeros_like(full)
+    terms = torch.zeros_like(full_terms)
+    for h in range(2):
+        sl = slice(h * (R // 2), (h + 1) * (R // 2))
+        half = {k: v[:, sl].contiguous() for k, v in batch.items()}
+        ops.train_step(arena, ws_h, half, global_flags=flags, global_counts=counts)
+        acc += ws_h.grads
+        terms += ws_h.loss_terms
+    torch.cuda.synchronize()
+    assert float((terms - full_terms).abs().max()) < 1e-4 * max(1.0, float(full_terms.abs().max()))
+    gv, av = arena.views(full), arena.views(acc)
+    for i in range(19):
+        if i in ops.FEAT_TENSORS:
+            continue
+        scale = max(1e-3, float(gv[i].abs().max()))
+        assert maxerr(av[i], gv[i]) < 2e-4 * scale, (i, ops.TENSOR_NAMES[i], maxerr(av[i], gv[i]), scale)
