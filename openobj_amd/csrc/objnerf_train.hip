@@ -349,8 +349,21 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
               // one ray per pass (S = 33..64): both 32-lane halves work on it, half the samples each
               const bool on1 = (qb < rpp) && (ps * rpp + qb < TR) && (ray0 + ps * rpp + qb < R);
               const int q1 = ps * rpp + qb;
-              if (on1)
-                for (int s2 = half; s2 < S; s2 += 2) fh = fmaf(s_w[q1 * S + s2], stg[(q1 * S + s2) * HF_LD + hh], fh);
+              if (on1) {
+                // four independent partial sums: the LDS reads of several steps are in flight together
+                float f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f;
+                const float* wp = s_w + q1 * S;
+                const float* hp = stg + (q1 * S) * HF_LD + hh;
+                int s2 = half;
+                for (; s2 + 6 < S; s2 += 8) {
+                  f0 = fmaf(wp[s2], hp[s2 * HF_LD], f0);
+                  f1 = fmaf(wp[s2 + 2], hp[(s2 + 2) * HF_LD], f1);
+                  f2 = fmaf(wp[s2 + 4], hp[(s2 + 4) * HF_LD], f2);
+                  f3 = fmaf(wp[s2 + 6], hp[(s2 + 6) * HF_LD], f3);
+                }
+                for (; s2 < S; s2 += 2) f0 = fmaf(wp[s2], hp[s2 * HF_LD], f0);
+                fh = (f0 + f1) + (f2 + f3);
+              }
               fh += __shfl_xor(fh, 32, 64);
             } else if (on2) {
               for (int s2 = 0; s2 < S; ++s2) fh = fmaf(s_w[qq2 * S + s2], stg[(qq2 * S + s2) * HF_LD + hh], fh);
