@@ -176,6 +176,7 @@ def main():
         step_no[0] += 1
         ops.adamw_step(arena, ws.grads, m, v, mask, step_no[0], 1e-3, 0.013)
         if bg_loop is not None:
+            bg_loop.bf16 = use_bf16              # the mode applies to the whole step
             bg_loop.step(bg_batches[i & 1])
 
     def timed(use_bf16):

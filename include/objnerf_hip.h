@@ -212,8 +212,9 @@ int objnerf_label_counts(int32_t K, int32_t R, const uint8_t* labels, int32_t* c
  */
 #define OBJNERF_TRAIN_BF16 1   /* mode bit: MFMA operands rounded to bf16 (fp32 accumulate, fp32 master weights,
                                 * fp32 embedding/compositing/losses).  NOT the reference's arithmetic (fp32,
-                                * train.py:74) -- an opt-in throughput mode gated by PSNR; hidden 32, S <= 64,
-                                * no feature loss, else OBJNERF_ENOTSUP. */
+                                * train.py:74) -- an opt-in throughput mode gated by PSNR.  Fused kernel: hidden 32,
+                                * S <= 64, no feature loss (else OBJNERF_ENOTSUP); layer-wise path (other widths,
+                                * longer rays): bf16 GEMM operands, any configuration. */
 #define OBJNERF_TRAIN_LAYERWISE 2   /* mode bit: take the layer-wise (any width) path even for hidden 32 / S <= 64 --
                                      * a second, independent implementation of the same iteration; the tests use
                                      * it to cross-check the fused kernel at sizes no CPU oracle reaches. */

@@ -138,6 +138,117 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Gemm g) {
       }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// bf16-operand variant (OBJNERF_TRAIN_BF16 on the layer-wise path): same interface and epilogue, operands are
+// rounded to bf16 when they are staged in LDS ([row][k], k contiguous: one ds_read_b128 per MFMA operand),
+// v_mfma_f32_16x16x32_bf16, fp32 accumulation.  64 x 64 tiles, 32-deep k steps: 4 MFMAs per wave and step, so the
+// kernel is bound by the operand traffic, not by the matrix core.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(const Gemm g) {
+  constexpr int TM = 2, TN = 2, BM = 64, BN = 64, BKB = 32, LDK = BKB + 8;
+  __shared__ __attribute__((aligned(16))) __bf16 As[BM][LDK];
+  __shared__ __attribute__((aligned(16))) __bf16 Bs[BN][LDK];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int c = lane & 15, gg = lane >> 4;
+  const int wm = w >> 1, wn = w & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int sk = g.splitk > 1 ? g.splitk : 1;
+  const long z = blockIdx.z / sk;
+  const int slice = blockIdx.z % sk;
+  const float* A = g.A + z * g.bsa;
+  const float* B = g.B + z * g.bsb;
+  float* C = g.C + z * g.bsc;
+  const int kper = ((g.Kd + sk - 1) / sk + BKB - 1) / BKB * BKB;
+  const int kbeg = slice * kper, kend = min(g.Kd, kbeg + kper);
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int NA = BM * BKB / 256, NB = BN * BKB / 256;
+  float ra[NA], rb[NB];
+  auto load_tiles = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int e = tid + 256 * i;
+      int am, ak;
+      if (g.sak == 1) { ak = e % BKB; am = e / BKB; } else { am = e % BM; ak = e / BM; }
+      const int gm = m0 + am, gk = k0 + ak;
+      ra[i] = (gm < g.M && gk < kend) ? A[gm * g.sam + gk * g.sak] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int e = tid + 256 * i;
+      int bn, bk;
+      if (g.sbk == 1) { bk = e % BKB; bn = e / BKB; } else { bn = e % BN; bk = e / BN; }
+      const int gn = n0 + bn, gk2 = k0 + bk;
+      rb[i] = (gn < g.N && gk2 < kend) ? B[gk2 * g.sbk + gn * g.sbn] : 0.f;
+    }
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int e = tid + 256 * i;
+      int am, ak;
+      if (g.sak == 1) { ak = e % BKB; am = e / BKB; } else { am = e % BM; ak = e / BM; }
+      As[am][ak] = (__bf16)ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int e = tid + 256 * i;
+      int bn, bk;
+      if (g.sbk == 1) { bk = e % BKB; bn = e / BKB; } else { bn = e % BN; bk = e / BN; }
+      Bs[bn][bk] = (__bf16)rb[i];
+    }
+  };
+  float rs = 0.f;
+  const bool do_rs = g.rowsum != nullptr && blockIdx.x == 0 && tid < BM;
+  if (kbeg < kend) load_tiles(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += BKB) {
+    store_tiles();
+    __syncthreads();
+    if (k0 + BKB < kend) load_tiles(k0 + BKB);
+    if (do_rs) {
+#pragma unroll
+      for (int kk = 0; kk < BKB; ++kk) rs += (float)As[tid][kk];
+    }
+    bf16x8 a[TM], b[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(&As[16 * TM * wm + 16 * i + c][8 * gg]);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8*>(&Bs[16 * TN * wn + 16 * j + c][8 * gg]);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    __syncthreads();
+  }
+  if (do_rs && m0 + tid < g.M) atomicAdd(g.rowsum + z * g.bsrs + m0 + tid, rs);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + 16 * TM * wm + 16 * i + 4 * gg + r, n = n0 + 16 * TN * wn + 16 * j + c;
+        if (m < g.M && n < g.N) {
+          float* cp = C + m * g.scm + n * g.scn;
+          float v = acc[i][j][r];
+          if (sk > 1) { atomicAdd(cp, v); continue; }
+          if (g.accumulate) v += *cp;
+          if (g.bias) v += g.bias[z * g.bsbias + n];
+          if (g.relu) v = fmaxf(v, 0.f);
+          if (g.mask) v = g.mask[z * g.bsm + m * g.smm + n * g.smn] > 0.f ? v : 0.f;
+          *cp = v;
+        }
+      }
+}
+
+// selected for the duration of one train_step call (single host thread per device)
+static thread_local bool t_bf16_operands = false;
+
 static void gemm(hipStream_t st, int batch, int M, int N, int Kd, const float* A, long sam, long sak, long bsa,
                  const float* B, long sbk, long sbn, long bsb, float* C, long scm, long scn, long bsc,
                  bool accumulate = false, const float* bias = nullptr, long bsbias = 0, bool relu = false,
@@ -152,6 +263,11 @@ static void gemm(hipStream_t st, int batch, int M, int N, int Kd, const float* A
   g.accumulate = accumulate; g.relu = relu; g.splitk = splitk;
   g.rowsum = rowsum; g.bsrs = bsrs;
   const int nz = batch * (splitk > 1 ? splitk : 1);
+  if (t_bf16_operands) {
+    dim3 grid((N + 63) / 64, (M + 63) / 64, nz);
+    hipLaunchKernelGGL(gemm_bf16_kernel, grid, dim3(256), 0, st, g);
+    return;
+  }
   if (M >= 256 && N >= 192) {         // wide layer GEMMs (hidden 256): 128 x 128 tiles.  Up to N = 128 the
                                       // 64 x 64 tiles win (measured, hidden 128): 4x the workgroups, 16 instead
                                       // of 64 accumulator registers -> occupancy hides the operand latency
@@ -343,7 +459,15 @@ size_t train_workspace_bytes(const objnerf_net* net, int K, int R, int S, int fe
   return w.bytes + 256;
 }
 
+namespace {
+struct Bf16Scope {
+  explicit Bf16Scope(bool on) { t_bf16_operands = on; }
+  ~Bf16Scope() { t_bf16_operands = false; }
+};
+}  // namespace
+
 int train_step(const objnerf_net* net, const objnerf_train_args* a, void* stream) {
+  const Bf16Scope bf16_scope((a->mode & OBJNERF_TRAIN_BF16) != 0);
   const int H = net->hidden, C = net->feat_dim, K = a->K;
   if (H % 32 != 0 || net->n_freqs != 6) return OBJNERF_ENOTSUP;
   if (!a->pts) return OBJNERF_ENOTSUP;            // origins/dirs form: fused hidden-32 path only

@@ -19,8 +19,10 @@ class BackgroundLoop:
     mask counts (an 2-int SUM all-reduce), the gradient (182 339 floats at hidden 128) is SUM
     all-reduced over RCCL and every rank applies the same AdamW update."""
 
-    def __init__(self, cfg, bg_trainer, with_feat: bool = False, group=None):
+    def __init__(self, cfg, bg_trainer, with_feat: bool = False, group=None, bf16: bool = False):
+        """bf16: opt-in OBJNERF_TRAIN_BF16 mode (bf16 GEMM operands, fp32 accumulation and everything else)."""
         self.cfg, self.trainer, self.with_feat, self.group = cfg, bg_trainer, with_feat, group
+        self.bf16 = bf16
         self.arena = bg_trainer.arena           # K = 1: trained in place, no copy-back needed
         self.arena.scale.fill_(float(bg_trainer.obj_scale))
         self.opt = optim.ArenaAdamW(self.arena, lr=cfg.learning_rate, weight_decay=cfg.weight_decay)
@@ -36,7 +38,7 @@ class BackgroundLoop:
         odist.allreduce_sum_(counts, self.group)                  # global n(label==1), n(label!=2)
         flags = ((counts.reshape(-1, 2) == 0).any(dim=0)).to(torch.int32)
         ops.train_step(self.arena, self.ws, batch, with_feat=self.with_feat, global_flags=flags,
-                       global_counts=counts)
+                       global_counts=counts, bf16=self.bf16)
         odist.allreduce_sum_(self.ws.grads, self.group)           # the one data-path collective
         odist.allreduce_sum_(self.ws.loss_terms, self.group)
         self.opt.step(self.ws.grads, self.mask)

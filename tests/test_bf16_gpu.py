@@ -76,3 +76,29 @@ def test_bf16_psnr_matches_fp32_ensemble(golden, dev):
     assert abs(np.median(ens[True]) - np.median(ens[False])) < 0.4
     assert abs(ens[True].mean() - ens[False].mean()) < 0.5
     assert np.median(ens[True]) > np.median(g["psnr_ensemble"]) - 0.4
+
+
+@pytest.mark.parametrize("feat", [False, True])
+def test_bf16_background_step_close_to_fp32(dev, feat):
+    """The layer-wise path (hidden 128, the background network) with bf16 GEMM operands against its fp32 self."""
+    from openobj_amd import init as obj_init
+    K, R, n1, n2, H = 1, 600, 16, 48, 128
+    arena = ops.ParamArena(K, ops.NetShape(H, 512, 6), dev)
+    arena.load_stacked(obj_init.init_stacked(K, H, 512, seed=3))
+    arena.scale.fill_(5.0)
+    b = synthetic.random_batch(K, R, n1, n2, seed=12, feat_dim=512 if feat else 0)
+    keys = ["pts", "z", "gt_depth", "gt_rgb", "labels"] + (["gt_feat"] if feat else [])
+    batch = {k: T(b[k]).to(dev) for k in keys}
+    ws32 = ops.TrainWorkspace(arena, K, R, n1 + n2, feat)
+    ws16 = ops.TrainWorkspace(arena, K, R, n1 + n2, feat)
+    ops.train_step(arena, ws32, batch, with_feat=feat)
+    ops.train_step(arena, ws16, batch, with_feat=feat, bf16=True)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(ws16.loss_terms.cpu(), ws32.loss_terms.cpu(), rtol=3e-2, atol=3e-3)
+    g32, g16 = arena.views(ws32.grads), arena.views(ws16.grads)
+    for i in range(19):
+        if i in ops.FEAT_TENSORS and not feat:
+            continue
+        a, r = g16[i].double().cpu(), g32[i].double().cpu()
+        rel = float((a - r).norm() / (r.norm() + 1e-12))
+        assert rel < 0.15, (i, ops.TENSOR_NAMES[i], rel)
