@@ -517,3 +517,35 @@ def test_full_size_gradient_is_additive_over_ray_halves(dev):
             continue
         scale = max(1e-3, float(gv[i].abs().max()))
         assert maxerr(av[i], gv[i]) < 2e-4 * scale, (i, ops.TENSOR_NAMES[i], maxerr(av[i], gv[i]), scale)
+
+
+def test_more_objects_than_compute_units(dev):
+    """K = 300 objects on a 256-CU part (one workgroup per object, several rounds) against the layer-wise path."""
+    K, R, n1, n2 = 300, 8, 1, 9
+    arena, batch = _full_size_setup(dev, K, R, n1, n2, False)
+    ws_f = ops.TrainWorkspace(arena, K, R, n1 + n2, False)
+    ws_l = ops.TrainWorkspace(arena, K, R, n1 + n2, False, layerwise=True)
+    ops.train_step(arena, ws_f, batch)
+    ops.train_step(arena, ws_l, batch, layerwise=True)
+    torch.cuda.synchronize()
+    assert float((ws_f.loss_terms - ws_l.loss_terms).abs().max()) < 1e-4 * max(1.0, float(ws_l.loss_terms.abs().max()))
+    gf, gl = arena.views(ws_f.grads), arena.views(ws_l.grads)
+    for i in list(range(14)) + [18]:
+        scale = max(1e-3, float(gl[i].abs().max()))
+        assert maxerr(gf[i], gl[i]) < 3e-4 * scale, (i, ops.TENSOR_NAMES[i], maxerr(gf[i], gl[i]), scale)
+
+
+def test_single_object_many_rays(dev):
+    """K = 1, 60 000 rays: the object is swept by every compute unit (256 slabs), fused vs layer-wise."""
+    K, R, n1, n2 = 1, 60000, 8, 24
+    arena, batch = _full_size_setup(dev, K, R, n1, n2, False)
+    ws_f = ops.TrainWorkspace(arena, K, R, n1 + n2, False)
+    ws_l = ops.TrainWorkspace(arena, K, R, n1 + n2, False, layerwise=True)
+    ops.train_step(arena, ws_f, batch)
+    ops.train_step(arena, ws_l, batch, layerwise=True)
+    torch.cuda.synchronize()
+    assert float((ws_f.loss_terms - ws_l.loss_terms).abs().max()) < 1e-4 * max(1.0, float(ws_l.loss_terms.abs().max()))
+    gf, gl = arena.views(ws_f.grads), arena.views(ws_l.grads)
+    for i in list(range(14)) + [18]:
+        scale = max(1e-3, float(gl[i].abs().max()))
+        assert maxerr(gf[i], gl[i]) < 3e-4 * scale, (i, ops.TENSOR_NAMES[i], maxerr(gf[i], gl[i]), scale)
