@@ -913,7 +913,6 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
   const bool feat = a->gt_feat != nullptr;
   if (feat && (TS / a->S) > 16) return OBJNERF_ENOTSUP;
   const bool bf16 = (a->mode & OBJNERF_TRAIN_BF16) != 0;
-  if (bf16 && feat) return OBJNERF_ENOTSUP;
   if (a->workspace_bytes < objnerf_train_workspace_bytes(net, a->K, a->R, a->S, a->gt_feat != nullptr))
     return OBJNERF_EINVAL;
   int64_t offs[OBJNERF_N_TENSORS + 1];
@@ -981,7 +980,8 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
                      (long)a->p_stride, rayin, RAYIN, 1, (long)a->R * RAYIN, false);
     hipLaunchKernelGGL(feat_rowstats_kernel, dim3((a->R + 15) / 16, a->K), dim3(256), 0, st, a->params,
                        (long)a->p_stride, d.L.of_b, C, a->R, a->gt_feat, rayin);
-    hipLaunchKernelGGL(train_fused_kernel<true>, dim3(a->K * d.G), dim3(NTHR), lds_bytes, st, d);
+    if (bf16) launch_train_bf16(d, stream, true);
+    else hipLaunchKernelGGL(train_fused_kernel<true>, dim3(a->K * d.G), dim3(NTHR), lds_bytes, st, d);
     if (hipGetLastError() != hipSuccess) return OBJNERF_ELAUNCH;
     // 512-d head gradient from the per-ray (fh, O, a, c): two split-K GEMMs over the rays + a small finish
     const long nr = (long)a->K * a->R;
@@ -994,7 +994,7 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
     hipLaunchKernelGGL(feat_finish_kernel, dim3((C * XCOLS + 255) / 256, a->K), dim3(256), 0, st, a->params,
                        (long)a->p_stride, d.L.of_w, d.L.of_b, C, Tm, mom, a->grads);
   } else if (bf16) {
-    launch_train_bf16(d, stream);
+    launch_train_bf16(d, stream, false);
   } else {
     hipLaunchKernelGGL(train_fused_kernel<false>, dim3(a->K * d.G), dim3(NTHR), lds_bytes, st, d);
   }

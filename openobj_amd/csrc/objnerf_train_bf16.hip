@@ -33,7 +33,9 @@ constexpr int T_M1 = T_IN + 96 * RST;         // 32 rows
 constexpr int T_CAT = T_M1 + 32 * RST;        // 128 rows: h2 (32) | x1 (96)
 constexpr int T_M2 = T_CAT + 128 * RST;       // 32 rows
 constexpr int T_CL = T_M2 + 32 * RST;         // 80 rows:  h4 (32) | x2 (48)
-constexpr int B_SMALL = T_CL + 80 * RST;      // fp32: bm1[32] bm2[32] wa[32] woc[96] hb[4] peb[99]
+constexpr int B_FL = T_CL + 80 * RST;         // feature layer, forward image (32 rows, as B_CL)
+constexpr int T_FL = B_FL + 32 * RS_CL;       // feature layer, transposed image (80 rows, as T_CL)
+constexpr int B_SMALL = T_FL + 80 * RST;      // fp32: bm1[32] bm2[32] wa[32] woc[96] hb[4] peb[99]
 constexpr int S_BM1 = 0, S_BM2 = 32, S_WA = 64, S_WOC = 96, S_HB = 192, S_PEB = 196;
 constexpr int B_SM = B_SMALL + 1280;          // s_alpha | s_col[3]  (fp32, 2 KB)
 constexpr int TB_LD = 130;
@@ -42,7 +44,14 @@ constexpr int B_TBUF = B_SM + 2048;           // fp32 [35][130]: d proj rows 0..
 constexpr int STG_PITCH = 288;                // bf16 staging row: 128 samples + pad
 constexpr int B_STG = (B_TBUF + TB_ROWS * TB_LD * 4 + 15) / 16 * 16;
 constexpr int STG_ROWS_B = 192;
-constexpr int LDS_BYTES = B_STG + STG_ROWS_B * STG_PITCH;
+// feature branch, fp32: s_w [128] | gfh [16][32] | gof [32]  (live from the compositing into phase A)
+constexpr int B_FEAT = B_STG + STG_ROWS_B * STG_PITCH;
+constexpr int LDS_BYTES = B_FEAT + (128 + 16 * 32 + 32) * 4;
+// fp32 aliases inside the staging area, live from the forward pass to the end of the compositing (float offsets)
+constexpr int FA_HF = 0;                      // hidden feature of the tile [128][33]
+constexpr int FA_G = TS * HF_LD;              // Gram matrix [32][33] | wb [32] | bb
+constexpr int FA_FHB = FA_G + 32 * 33 + 64;   // fh exchange buffer [NWAVE][64]
+static_assert((FA_FHB + 64 * NWAVE) * 4 <= STG_ROWS_B * STG_PITCH, "bf16 feat aliases");
 static_assert(B_SMALL % 16 == 0 && B_STG % 16 == 0 && LDS_BYTES <= 163840, "bf16 lds layout");
 
 __device__ __forceinline__ int phi(int g, int e) { return e < 4 ? 4 * g + e : 16 + 4 * g + e - 4; }
@@ -62,7 +71,14 @@ __device__ __forceinline__ float w_cl(const float* P, const Layout& L, int i, in
   return f2 < OBJ_E2 ? P[L.cl_w + i * (H + OBJ_E2) + H + f2] : (f2 == OBJ_E2 ? P[L.cl_b + i] : 0.f);
 }
 
-__device__ __forceinline__ void stage_weights_bf16(char* lds, const float* __restrict__ P, const Layout& L, int tid) {
+__device__ __forceinline__ float w_fl(const float* P, const Layout& L, int i, int f) {
+  if (f < H) return P[L.fl_w + i * (H + OBJ_E2) + f];
+  const int f2 = f - H;
+  return f2 < OBJ_E2 ? P[L.fl_w + i * (H + OBJ_E2) + H + f2] : (f2 == OBJ_E2 ? P[L.fl_b + i] : 0.f);
+}
+
+__device__ __forceinline__ void stage_weights_bf16(char* lds, const float* __restrict__ P, const Layout& L, int tid,
+                                                   const bool feat) {
   __bf16* img = reinterpret_cast<__bf16*>(lds);
   // forward images: element (i, b, g, e) <- W[i][32 b + phi(g, e)]
   for (int x = tid; x < 32 * 3 * 32; x += NTHR) {
@@ -70,6 +86,7 @@ __device__ __forceinline__ void stage_weights_bf16(char* lds, const float* __res
     const int f = 32 * b + phi(ge >> 3, ge & 7);
     img[(B_IN + i * RS_IN) / 2 + rem] = (__bf16)w_in(P, L, i, f);
     img[(B_CL + i * RS_CL) / 2 + rem] = (__bf16)w_cl(P, L, i, f);
+    if (feat) img[(B_FL + i * RS_CL) / 2 + rem] = (__bf16)w_fl(P, L, i, f);
   }
   for (int x = tid; x < 32 * 4 * 32; x += NTHR) {
     const int i = x >> 7, rem = x & 127, b = rem >> 5, ge = rem & 31;
@@ -87,6 +104,7 @@ __device__ __forceinline__ void stage_weights_bf16(char* lds, const float* __res
     img[(T_CAT + f * RST) / 2 + ge] = (__bf16)w_cat(P, L, o, f);
     if (f < 96) img[(T_IN + f * RST) / 2 + ge] = (__bf16)w_in(P, L, o, f);
     if (f < 80) img[(T_CL + f * RST) / 2 + ge] = (__bf16)w_cl(P, L, o, f);
+    if (feat && f < 80) img[(T_FL + f * RST) / 2 + ge] = (__bf16)w_fl(P, L, o, f);
     if (f < 32) {
       img[(T_M1 + f * RST) / 2 + ge] = (__bf16)P[L.m1_w + o * H + f];
       img[(T_M2 + f * RST) / 2 + ge] = (__bf16)P[L.m2_w + o * H + f];
@@ -194,6 +212,7 @@ __device__ unsigned long long g_phase_b[8][24];
 #define PT_FLUSH() do {} while (0)
 #endif
 
+template <bool FEAT>
 __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a) {
   extern __shared__ __attribute__((aligned(16))) char ldsb[];
   const int tid = threadIdx.x;
@@ -209,7 +228,7 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
 
   for (int i = tid; i < LDS_BYTES / 4; i += NTHR) reinterpret_cast<float*>(ldsb)[i] = 0.0f;
   __syncthreads();
-  stage_weights_bf16(ldsb, a.params + (long)k * a.p_stride, a.L, tid);
+  stage_weights_bf16(ldsb, a.params + (long)k * a.p_stride, a.L, tid, FEAT);
   __syncthreads();
 
   const float scale = a.scale[k];
@@ -222,7 +241,12 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
   float gS0 = 0.f, gS1 = 0.f, gS2 = 0.f;
   float g_ba = 0.f, g_boc0 = 0.f, g_boc1 = 0.f, g_boc2 = 0.f;
   f32x4 accT0 = zero4(), accT1 = zero4();   // d B: rows j = 4g + r (accT1: 16 + 4g + r), column x = c < 3
-  float l_d = 0.f, l_c = 0.f, l_o = 0.f;
+  float l_d = 0.f, l_c = 0.f, l_o = 0.f, l_f = 0.f;
+  f32x4 accF0 = zero4(), accF1 = zero4();
+  float* stgf = reinterpret_cast<float*>(stg);                       // fp32 view (feature aliases)
+  float* s_w = reinterpret_cast<float*>(ldsb + B_FEAT);
+  float* s_gfh = s_w + 128;
+  float* s_gof = s_gfh + 16 * 32;
 
   char* stg_lane = stg + (4 * g) * STG_PITCH + (16 * w + c) * 2;
   const char* lane_rd = stg + c * STG_PITCH + 16 * g;
@@ -236,6 +260,8 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
   const char* t_cat = ldsb + T_CAT + c * RST + 16 * g;
   const char* t_m2 = ldsb + T_M2 + c * RST + 16 * g;
   const char* t_cl = ldsb + T_CL + c * RST + 16 * g;
+  const char* f_fl = ldsb + B_FL + c * RS_CL + 16 * g;
+  const char* t_fl = ldsb + T_FL + c * RST + 16 * g;
 
   const bool rows_mode = seg_is_rows(a.S);
   const SegRows seg_rows = SegRows::make(rows_mode ? a.S : 64, lane);
@@ -274,7 +300,7 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
     Pe pe;
     pe_project_b(sm, g, px, py, pz, scale, pe);
     PT(0);
-    T32 h1, h2, h3, h4, hc;
+    T32 h1, h2, h3, h4, hc, hf;
     float alpha_v, col_v[3];
     {
       bf16x8 xb1[3], xb2[2];
@@ -308,6 +334,13 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
       fwd_blk<RS_CL>(acc, f_cl, 1, xb2[0]);
       fwd_blk<RS_CL>(acc, f_cl, 2, xb2[1]);
       hc = relu32(acc);
+      if (FEAT) {
+        acc = zero32();
+        fwd_blk<RS_CL>(acc, f_fl, 0, pack32(h4));
+        fwd_blk<RS_CL>(acc, f_fl, 1, xb2[0]);
+        fwd_blk<RS_CL>(acc, f_fl, 2, xb2[1]);
+        hf = relu32(acc);
+      }
       float pa = 0.f, pc0 = 0.f, pc1 = 0.f, pc2 = 0.f;
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt)
@@ -330,6 +363,17 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
       s_col[TS + slot] = col_v[1];
       s_col[2 * TS + slot] = col_v[2];
     }
+    if (FEAT) {
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) stgf[FA_HF + slot * HF_LD + 16 * tt + 4 * g + r] = hf.t[tt][r];
+      for (int i = tid; i < 32 * 32 + 33; i += NTHR) {       // this object's Gram matrix (+ wb, bb) for the tile
+        const float v = a.gram[(long)k * GRAM + i];
+        if (i < 1024) stgf[FA_G + (i >> 5) * 33 + (i & 31)] = v;
+        else stgf[FA_G + 32 * 33 + (i - 1024)] = v;
+      }
+    }
     // ray inputs of this wave's compositing pass, requested BEFORE the barrier so their latency hides behind it
     auto ray_inputs = [&](const int ps_, float& zz_, float& gtd_, float& gr_, float& gg_, float& gb_, int& lab_) {
       const int rpp_ = 64 / S;
@@ -348,6 +392,23 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
     float pf_zz = 0.f, pf_gtd = 0.f, pf_gr = 0.f, pf_gg = 0.f, pf_gb = 0.f;
     int pf_lab = 2;
     if (w * (64 / S) < TR) ray_inputs(w, pf_zz, pf_gtd, pf_gr, pf_gg, pf_gb, pf_lab);
+    auto feat_inputs = [&](const int ps_, const int qb_, float& uh_, float& beta_, float& ngv_, int& lab_) {
+      const int rpp_ = 64 / S;
+      const int ql2_ = qb_ + (lane >> 5);
+      const int qq2_ = ps_ * rpp_ + ql2_;
+      const int ray2_ = ray0 + qq2_;
+      uh_ = 0.f; beta_ = 0.f; ngv_ = 1.f; lab_ = 2;
+      if ((ql2_ < rpp_) && (qq2_ < TR) && (ray2_ < R)) {
+        const long rr2_ = (long)k * R + ray2_;
+        uh_ = a.rayin[rr2_ * RAYIN + (lane & 31)];
+        beta_ = a.rayin[rr2_ * RAYIN + 32];
+        ngv_ = a.rayin[rr2_ * RAYIN + 33];
+        lab_ = (int)a.labels[rr2_];
+      }
+    };
+    float pf_uh = 0.f, pf_beta = 0.f, pf_ngv = 1.f;
+    int pf_lab2 = 2;
+    if (FEAT && w * (64 / S) < TR) feat_inputs(w, 0, pf_uh, pf_beta, pf_ngv, pf_lab2);
     PT(2);
     __syncthreads();
     PT(3);
@@ -395,7 +456,85 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
           l_c += m1 * (fabsf(r0) + fabsf(r1) + fabsf(r2)) * inv1;
           l_o += m2 * fabsf(ro) * inv2;
         }
-        const float dw = gD * zz + gO + gC0 * c0 + gC1 * c1 + gC2 * c2;
+        float dw = gD * zz + gO + gC0 * c0 + gC1 * c1 + gC2 * c2;
+        if (FEAT) {
+          // feature-distillation term with the 512-d head hoisted past the compositing (objnerf_train.hip, 4.3 of
+          // DESIGN.md): fp32 throughout, only the hidden feature itself came out of bf16 MFMAs
+          float* s_fhb = stgf + FA_FHB + 64 * w;
+          const float* Gb = stgf + FA_G;
+          if (on) s_w[sl] = wgt;
+          if (on && pos == 0) s_gof[16 + qq] = O;
+          __builtin_amdgcn_wave_barrier();
+          asm volatile("" ::: "memory");
+          const int half = lane >> 5, hh = lane & 31;
+          for (int qb = 0; qb < rpp; qb += 2) {
+            const int ql2 = qb + half;
+            const int qq2 = ps * rpp + ql2;
+            const int ray2 = ray0 + qq2;
+            const bool on2 = (ql2 < rpp) && (qq2 < TR) && (ray2 < R);
+            const long rr2 = (long)k * R + (on2 ? ray2 : 0);
+            float fh = 0.f;
+            if (rpp == 1) {
+              const bool on1 = (qb < rpp) && (ps * rpp + qb < TR) && (ray0 + ps * rpp + qb < R);
+              const int q1 = ps * rpp + qb;
+              if (on1) {
+                float f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f;
+                const float* wp = s_w + q1 * S;
+                const float* hp = stgf + FA_HF + (q1 * S) * HF_LD + hh;
+                int s2 = half;
+                for (; s2 + 6 < S; s2 += 8) {
+                  f0 = fmaf(wp[s2], hp[s2 * HF_LD], f0);
+                  f1 = fmaf(wp[s2 + 2], hp[(s2 + 2) * HF_LD], f1);
+                  f2 = fmaf(wp[s2 + 4], hp[(s2 + 4) * HF_LD], f2);
+                  f3 = fmaf(wp[s2 + 6], hp[(s2 + 6) * HF_LD], f3);
+                }
+                for (; s2 < S; s2 += 2) f0 = fmaf(wp[s2], hp[s2 * HF_LD], f0);
+                fh = (f0 + f1) + (f2 + f3);
+              }
+              fh += __shfl_xor(fh, 32, 64);
+            } else if (on2) {
+              for (int s2 = 0; s2 < S; ++s2) fh = fmaf(s_w[qq2 * S + s2], stgf[FA_HF + (qq2 * S + s2) * HF_LD + hh], fh);
+            }
+            s_fhb[half * 32 + hh] = fh;
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("" ::: "memory");
+            float Gfh = 0.f;
+#pragma unroll 8
+            for (int h2 = 0; h2 < 32; ++h2) Gfh = fmaf(Gb[hh * 33 + h2], s_fhb[half * 32 + h2], Gfh);
+            const float wbh = Gb[32 * 33 + hh], bb = Gb[32 * 33 + 32];
+            float uh = pf_uh, beta = pf_beta, ngv = pf_ngv;
+            int lab2 = pf_lab2;
+            if (ps != w || qb != 0) feat_inputs(ps, qb, uh, beta, ngv, lab2);
+            const float O2 = on2 ? s_gof[16 + qq2] : 0.f;
+            const float fu = wave_sum32(fh * uh), fGf = wave_sum32(fh * Gfh), fwb = wave_sum32(fh * wbh);
+            const float dotFg = fu + O2 * beta;
+            const float nF2 = fmaxf(fGf + 2.0f * O2 * fwb + O2 * O2 * bb, 0.0f);
+            const float nF = fmaxf(sqrtf(nF2), 1e-8f), ngc = fmaxf(ngv, 1e-8f);
+            const float cosv = dotFg / (nF * ngc);
+            const float mm1 = (lab2 == 1) ? 1.0f : 0.0f;
+            const float gam = -a.feat_scaling * mm1 * inv1;
+            const float ar = gam / (nF * ngc), cr = -gam * cosv / (nF * nF);
+            if (on2) {
+              if (hh == 0) {
+                l_f += mm1 * (1.0f - cosv) * inv1;
+                s_gof[qq2] = ar * beta + cr * (fwb + O2 * bb);
+                a.rayfeat[rr2 * RAYFEAT + 32] = O2;
+                a.rayfeat[rr2 * RAYFEAT + 33] = ar;
+                a.rayfeat[rr2 * RAYFEAT + 34] = cr;
+              }
+              s_gfh[qq2 * 32 + hh] = ar * uh + cr * (Gfh + O2 * wbh);
+              a.rayfeat[rr2 * RAYFEAT + hh] = fh;
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("" ::: "memory");
+          }
+          if (on) {
+            float dwf = s_gof[qq];
+#pragma unroll 8
+            for (int h2 = 0; h2 < 32; ++h2) dwf = fmaf(s_gfh[qq * 32 + h2], stgf[FA_HF + sl * HF_LD + h2], dwf);
+            dw += dwf;
+          }
+        }
         const float qv = dw * wgt;
         const float suf = sg.rscan_add(qv, pos) - qv;
         const float docc = dw * T - suf / fr;
@@ -424,6 +563,17 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
     for (int j = 0; j < OBJ_NDIR; ++j) dps[j] = 0.f;
 
     // ---- phase A
+    T32 d_hf = zero32();
+    if (FEAT) {
+      const float wv = valid ? s_w[slot] : 0.0f;
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float gv = valid ? s_gfh[q * 32 + 16 * tt + 4 * g + r] : 0.0f;
+          d_hf.t[tt][r] = hf.t[tt][r] > 0.0f ? wv * gv : 0.0f;
+        }
+    }
     T32 d_hc, d_h4;
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
@@ -446,6 +596,11 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
     const bf16x8 d_hc_b = pack32(d_hc);
     bwd_tile(d_h4.t[0], t_cl, 0, d_hc_b);
     bwd_tile(d_h4.t[1], t_cl, 16, d_hc_b);
+    const bf16x8 d_hf_b = pack32(d_hf);
+    if (FEAT) {
+      bwd_tile(d_h4.t[0], t_fl, 0, d_hf_b);
+      bwd_tile(d_h4.t[1], t_fl, 16, d_hf_b);
+    }
     d_h4 = relu_mask32(d_h4, h4);
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
@@ -456,6 +611,7 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
     for (int T = 0; T < 3; ++T) {
       f32x4 d_x = zero4();
       bwd_tile(d_x, t_cl, 32 + 16 * T, d_hc_b);
+      if (FEAT) bwd_tile(d_x, t_fl, 32 + 16 * T, d_hf_b);
       store16_b(stg_lane, 32 + 16 * T, pe_x2_tile_fb(pe, T, g, d_x, dps));
     }
     const bf16x8 d_h4_b = pack32(d_h4);
@@ -473,6 +629,12 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
     }
     PT(8);
     __syncthreads();
+    if (FEAT) {             // feature layer weight gradient: same inputs [h4 | x2], d_hf in place of d_hc
+      store32_b(stg_lane, 128, d_hf);
+      __syncthreads();
+      if (w < 5) wgrad_pair_b(accF0, accF1, lane_rd + 128 * STG_PITCH, lane_rd + (16 * w) * STG_PITCH);
+      __syncthreads();
+    }
     PT(9);
     // ---- phase B
     store32_b(stg_lane, 0, h2);
@@ -579,6 +741,7 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
   write_pair_b(slab, accB0, accB1, c, g, w, L.cat_w, H + OBJ_E1, L.cat_b);
   if (w < 6) write_pair_b(slab, accC0, accC1, c, g, w, L.in_w, OBJ_E1, L.in_b);
   else write_pair_b(slab, accC0, accC1, c, g, w - 6, L.m1_w, H, -1);
+  if (FEAT && w < 5) write_pair_b(slab, accF0, accF1, c, g, w, L.fl_w, H + OBJ_E2, L.fl_b);
   float* red = reinterpret_cast<float*>(stg);   // [NWAVE][NRED]
   {
     float* mine = red + w * NRED;
@@ -589,7 +752,8 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
     const float s0 = wave_sum64(g_ba), s1 = wave_sum64(g_boc0), s2 = wave_sum64(g_boc1), s3 = wave_sum64(g_boc2);
     if (lane == 0) { mine[192] = s0; mine[193] = s1; mine[194] = s2; mine[195] = s3; }
     const float e0 = wave_sum64(l_d), e1 = wave_sum64(l_c), e2 = wave_sum64(l_o);
-    if (lane == 0) { mine[196] = e0; mine[197] = e1; mine[198] = e2; mine[199] = 0.0f; }
+    const float e3 = wave_sum64(l_f);
+    if (lane == 0) { mine[196] = e0; mine[197] = e1; mine[198] = e2; mine[199] = e3; }
     if (c < 3) {
       float* dbw = red + NWAVE * NRED + w * 64;            // [NWAVE][21 * 3]
 #pragma unroll
@@ -632,14 +796,19 @@ extern "C" int objnerf_debug_phase_bf16(unsigned long long* out_host) {
 }
 #endif
 
-void launch_train_bf16(const TrainDev& d, void* stream) {
+void launch_train_bf16(const TrainDev& d, void* stream, bool feat) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)train_fused_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void*)train_fused_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)train_fused_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               LDS_BYTES);
     attr_set = true;
   }
-  hipLaunchKernelGGL(train_fused_bf16_kernel, dim3(d.K * d.G), dim3(NTHR), LDS_BYTES, (hipStream_t)stream, d);
+  if (feat)
+    hipLaunchKernelGGL(train_fused_bf16_kernel<true>, dim3(d.K * d.G), dim3(NTHR), LDS_BYTES, (hipStream_t)stream, d);
+  else
+    hipLaunchKernelGGL(train_fused_bf16_kernel<false>, dim3(d.K * d.G), dim3(NTHR), LDS_BYTES, (hipStream_t)stream, d);
 }
 
 }  // namespace objtrain

@@ -42,6 +42,6 @@ static_assert(OFF_FHB + 64 * NWAVE <= 80 * STG_LD && OFF_GOF + 32 <= 96 * STG_LD
 
 // bf16 MFMA variant (objnerf_train_bf16.hip): same tile structure, bf16 operands, fp32 accumulation
 size_t bf16_lds_bytes();
-void launch_train_bf16(const TrainDev& d, void* stream);
+void launch_train_bf16(const TrainDev& d, void* stream, bool feat);
 
 }  // namespace objtrain
