@@ -248,20 +248,6 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
   float* s_gfh = s_w + 128;
   float* s_gof = s_gfh + 16 * 32;
 
-  char* stg_lane = stg + (4 * g) * STG_PITCH + (16 * w + c) * 2;
-  const char* lane_rd = stg + c * STG_PITCH + 16 * g;
-  const char* f_in = ldsb + B_IN + c * RS_IN + 16 * g;
-  const char* f_m1 = ldsb + B_M1 + c * RS_M + 16 * g;
-  const char* f_cat = ldsb + B_CAT + c * RS_CAT + 16 * g;
-  const char* f_m2 = ldsb + B_M2 + c * RS_M + 16 * g;
-  const char* f_cl = ldsb + B_CL + c * RS_CL + 16 * g;
-  const char* t_in = ldsb + T_IN + c * RST + 16 * g;
-  const char* t_m1 = ldsb + T_M1 + c * RST + 16 * g;
-  const char* t_cat = ldsb + T_CAT + c * RST + 16 * g;
-  const char* t_m2 = ldsb + T_M2 + c * RST + 16 * g;
-  const char* t_cl = ldsb + T_CL + c * RST + 16 * g;
-  const char* f_fl = ldsb + B_FL + c * RS_CL + 16 * g;
-  const char* t_fl = ldsb + T_FL + c * RST + 16 * g;
 
   const bool rows_mode = seg_is_rows(a.S);
   const SegRows seg_rows = SegRows::make(rows_mode ? a.S : 64, lane);
@@ -285,11 +271,32 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
       }
     }
   };
+  // (c, g) and every per-lane LDS pointer are macros over an opaque copy of the lane id that is re-defined at the
+  // phase boundaries: addresses are recomputed next to their use instead of living in (spilled) registers
+  int lane_l = lane;
+#define RELAUNDER() do { if (FEAT) asm volatile("" : "+v"(lane_l)); } while (0)   // (only the feature build is short of registers)
+#define c (lane_l & 15)
+#define g (lane_l >> 4)
+#define stg_lane (stg + (4 * g) * STG_PITCH + (16 * w + c) * 2)
+#define lane_rd (stg + c * STG_PITCH + 16 * g)
+#define f_in (ldsb + B_IN + c * RS_IN + 16 * g)
+#define f_m1 (ldsb + B_M1 + c * RS_M + 16 * g)
+#define f_cat (ldsb + B_CAT + c * RS_CAT + 16 * g)
+#define f_m2 (ldsb + B_M2 + c * RS_M + 16 * g)
+#define f_cl (ldsb + B_CL + c * RS_CL + 16 * g)
+#define t_in (ldsb + T_IN + c * RST + 16 * g)
+#define t_m1 (ldsb + T_M1 + c * RST + 16 * g)
+#define t_cat (ldsb + T_CAT + c * RST + 16 * g)
+#define t_m2 (ldsb + T_M2 + c * RST + 16 * g)
+#define t_cl (ldsb + T_CL + c * RST + 16 * g)
+#define f_fl (ldsb + B_FL + c * RS_CL + 16 * g)
+#define t_fl (ldsb + T_FL + c * RST + 16 * g)
   float nx, ny, nz;
   fetch_point(gi, 16 * w + c, nx, ny, nz);
   PT_INIT();
   for (int tile = gi; tile < a.NT; tile += a.G) {
     asm volatile("" ::: "memory");
+    RELAUNDER();
     const int ray0 = tile * TR;
     // ---------------------------------------------------------------- 1. forward
     const int slot = 16 * w + c;
@@ -300,7 +307,9 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
     Pe pe;
     pe_project_b(sm, g, px, py, pz, scale, pe);
     PT(0);
-    T32 h1, h2, h3, h4, hc, hf;
+    T32 h1, h2, h3, h4, hc;
+    T32 hf = zero32();           // (feature build) dead after the forward: the backward keeps its sign mask only
+    unsigned hf_mask = 0;
     float alpha_v, col_v[3];
     {
       bf16x8 xb1[3], xb2[2];
@@ -367,17 +376,26 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) stgf[FA_HF + slot * HF_LD + 16 * tt + 4 * g + r] = hf.t[tt][r];
-      for (int i = tid; i < 32 * 32 + 33; i += NTHR) {       // this object's Gram matrix (+ wb, bb) for the tile
-        const float v = a.gram[(long)k * GRAM + i];
-        if (i < 1024) stgf[FA_G + (i >> 5) * 33 + (i & 31)] = v;
-        else stgf[FA_G + 32 * 33 + (i - 1024)] = v;
+        for (int r = 0; r < 4; ++r) {
+          stgf[FA_HF + slot * HF_LD + 16 * tt + 4 * g + r] = hf.t[tt][r];
+          hf_mask |= (hf.t[tt][r] > 0.0f ? 1u : 0u) << (4 * tt + r);      // all the backward needs of hf
+        }
+      // this object's Gram matrix (+ wb, bb) for the tile.  Fixed trip count: a real loop in the middle of the tile
+      // body splits every live range around it and costs ~80 spilled registers.
+#pragma unroll
+      for (int it = 0; it < (32 * 32 + 33 + NTHR - 1) / NTHR; ++it) {
+        const int i = tid + NTHR * it;
+        if (i < 32 * 32 + 33) {
+          const float v = a.gram[(long)k * GRAM + i];
+          if (i < 1024) stgf[FA_G + (i >> 5) * 33 + (i & 31)] = v;
+          else stgf[FA_G + 32 * 33 + (i - 1024)] = v;
+        }
       }
     }
     // ray inputs of this wave's compositing pass, requested BEFORE the barrier so their latency hides behind it
     auto ray_inputs = [&](const int ps_, float& zz_, float& gtd_, float& gr_, float& gg_, float& gb_, int& lab_) {
       const int rpp_ = 64 / S;
-      const int ql_ = lane / S, pos_ = lane - ql_ * S;
+      const int ql_ = lane_l / S, pos_ = lane_l - ql_ * S;
       const int qq_ = ps_ * rpp_ + ql_;
       const int rayq_ = ray0 + qq_;
       zz_ = 0.f; gtd_ = 0.f; gr_ = 0.f; gg_ = 0.f; gb_ = 0.f; lab_ = 2;
@@ -394,13 +412,13 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
     if (w * (64 / S) < TR) ray_inputs(w, pf_zz, pf_gtd, pf_gr, pf_gg, pf_gb, pf_lab);
     auto feat_inputs = [&](const int ps_, const int qb_, float& uh_, float& beta_, float& ngv_, int& lab_) {
       const int rpp_ = 64 / S;
-      const int ql2_ = qb_ + (lane >> 5);
+      const int ql2_ = qb_ + (lane_l >> 5);
       const int qq2_ = ps_ * rpp_ + ql2_;
       const int ray2_ = ray0 + qq2_;
       uh_ = 0.f; beta_ = 0.f; ngv_ = 1.f; lab_ = 2;
       if ((ql2_ < rpp_) && (qq2_ < TR) && (ray2_ < R)) {
         const long rr2_ = (long)k * R + ray2_;
-        uh_ = a.rayin[rr2_ * RAYIN + (lane & 31)];
+        uh_ = a.rayin[rr2_ * RAYIN + (lane_l & 31)];
         beta_ = a.rayin[rr2_ * RAYIN + 32];
         ngv_ = a.rayin[rr2_ * RAYIN + 33];
         lab_ = (int)a.labels[rr2_];
@@ -411,13 +429,14 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
     if (FEAT && w * (64 / S) < TR) feat_inputs(w, 0, pf_uh, pf_beta, pf_ngv, pf_lab2);
     PT(2);
     __syncthreads();
+    RELAUNDER();
     PT(3);
     // ---------------------------------------------------------------- 2. composite + loss (fp32, as objnerf_train.hip)
     auto composite_passes = [&](const auto& sg) {
       const int rpp = 64 / S;
       const int npass = (TR + rpp - 1) / rpp;
       for (int ps = w; ps < npass; ps += NWAVE) {
-        const int ql = lane / S, pos = lane - ql * S;
+        const int ql = lane_l / S, pos = lane_l - ql * S;
         const int qq = ps * rpp + ql;
         const int rayq = ray0 + qq;
         const bool on = (ql < rpp) && (qq < TR) && (rayq < R);
@@ -466,7 +485,7 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
           if (on && pos == 0) s_gof[16 + qq] = O;
           __builtin_amdgcn_wave_barrier();
           asm volatile("" ::: "memory");
-          const int half = lane >> 5, hh = lane & 31;
+          const int half = lane_l >> 5, hh = lane_l & 31;
           for (int qb = 0; qb < rpp; qb += 2) {
             const int ql2 = qb + half;
             const int qq2 = ps * rpp + ql2;
@@ -549,6 +568,7 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
     if (rows_mode) composite_passes(seg_rows); else composite_passes(SegGeneric{S});
     PT(4);
     __syncthreads();
+    RELAUNDER();
     PT(5);
     // ---------------------------------------------------------------- 3. backward
     const float da = valid ? s_alpha[slot] : 0.0f;
@@ -571,7 +591,7 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float gv = valid ? s_gfh[q * 32 + 16 * tt + 4 * g + r] : 0.0f;
-          d_hf.t[tt][r] = hf.t[tt][r] > 0.0f ? wv * gv : 0.0f;
+          d_hf.t[tt][r] = ((hf_mask >> (4 * tt + r)) & 1u) ? wv * gv : 0.0f;
         }
     }
     T32 d_hc, d_h4;
@@ -621,6 +641,7 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
     d_h3 = relu_mask32(d_h3, h3);
     PT(6);
     __syncthreads();
+    RELAUNDER();
     PT(7);
     if (w < 7) {
       const int dTr = (w < 5) ? 128 : 160;
@@ -629,11 +650,16 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
     }
     PT(8);
     __syncthreads();
+    RELAUNDER();
     if (FEAT) {             // feature layer weight gradient: same inputs [h4 | x2], d_hf in place of d_hc
       store32_b(stg_lane, 128, d_hf);
       __syncthreads();
+      RELAUNDER();
+    RELAUNDER();
       if (w < 5) wgrad_pair_b(accF0, accF1, lane_rd + 128 * STG_PITCH, lane_rd + (16 * w) * STG_PITCH);
       __syncthreads();
+      RELAUNDER();
+    RELAUNDER();
     }
     PT(9);
     // ---- phase B
@@ -711,10 +737,12 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
     }
     PT(11);
     __syncthreads();
+    RELAUNDER();
     PT(12);
     wgrad_pair_b(accB0, accB1, lane_rd + 128 * STG_PITCH, lane_rd + (16 * w) * STG_PITCH);
     PT(13);
     __syncthreads();
+    RELAUNDER();
     // ---- phase C
     fetch_point(tile + a.G, slot, nx, ny, nz);
     store32_b(stg_lane, 0, h1);
@@ -722,6 +750,7 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
     store32_b(stg_lane, 160, d_h2);
     PT(14);
     __syncthreads();
+    RELAUNDER();
     PT(15);
     {
       const int dTr = (w < 6) ? 128 : 160;
@@ -730,9 +759,26 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
     }
     PT(16);
     __syncthreads();
+    RELAUNDER();
     PT(17);
   }
   PT_FLUSH();
+#undef c
+#undef g
+#undef stg_lane
+#undef lane_rd
+#undef f_in
+#undef f_m1
+#undef f_cat
+#undef f_m2
+#undef f_cl
+#undef t_in
+#undef t_m1
+#undef t_cat
+#undef t_m2
+#undef t_cl
+#undef f_fl
+#undef t_fl
 
   float* slab = a.slab + ((long)k * a.G + gi) * a.slab_stride;
   const Layout& L = a.L;
