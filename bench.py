@@ -213,9 +213,9 @@ def main():
 
     dt, kern_ms = timed(bf16)
     status = int(ws.status.item())
-    # the opt-in bf16-operand mode beside the fp32 headline (same step, same batches; not available with --feat)
+    # the opt-in bf16-operand mode beside the fp32 headline (same step, same batches)
     bf16_extra = None
-    if not bf16 and not feat and args.bf16_line:
+    if not bf16 and args.bf16_line:
         bdt, bk = timed(True)
         bf16_extra = (bdt, bk)
 
@@ -225,7 +225,7 @@ def main():
         fpr = flop_per_ray(S, feat=feat)
         achieved = K * R * fpr / (kern_ms * 1e-3) / 1e12
         peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
-        kname = "train_fused_bf16_kernel" if bf16 else f"train_fused_kernel<{'true' if feat else 'false'}>"
+        kname = f"train_fused_bf16_kernel<{'true' if feat else 'false'}>" if bf16 else f"train_fused_kernel<{'true' if feat else 'false'}>"
         out = {
             "metric": "training rays/sec/GPU @64 samples/ray, 50 obj; PSNR delta vs ref",
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -247,7 +247,7 @@ def main():
         if bf16_extra is not None:
             bdt, bk = bf16_extra
             out["bf16_mode"] = {"value": rays_per_step * args.steps / bdt, "unit": "rays/s",
-                                "ms_per_step": bdt / args.steps * 1e3, "kernel": "train_fused_bf16_kernel",
+                                "ms_per_step": bdt / args.steps * 1e3, "kernel": f"train_fused_bf16_kernel<{'true' if feat else 'false'}>",
                                 "kernel_ms": bk, "mfma_tflops": K * R * fpr / (bk * 1e-3) / 1e12,
                                 "note": "OBJNERF_TRAIN_BF16: bf16 MFMA operands, fp32 accumulate / master weights / "
                                         "compositing / AdamW; PSNR-gated (tests/test_bf16_gpu.py), not 1e-4 parity"}
