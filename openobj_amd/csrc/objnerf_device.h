@@ -105,6 +105,50 @@ __device__ __forceinline__ void slot_accum16(float& acc, const float v, const in
   asm volatile("" : "+v"(acc));   // consume the row sum NOW (deferred adds keep dozens of partial sums live)
 }
 
+// The same for 16 (or 8) values at once, as a transposing butterfly: every step halves the number of live values
+// while doubling the lanes each one has been summed over, so 16 row sums cost ~57 VALU ops instead of 16 x 7.
+//   slot_sums16(A, B, c): lane c < 8 returns sum_row A[c], lane c >= 8 returns sum_row B[c - 8]
+//   slot_sums8(A, c):     every lane returns sum_row A[c & 7]
+template <int CTRL>
+__device__ __forceinline__ float dpp_get(const float v) {   // v of the lane selected by the DPP control
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float slot_fold4(float (&v)[8], const int c) {
+  // in: v[k] already summed over {c, c ^ 8}.  lane c ^ 4 is c + 4 (bit 2 clear) or c - 4 (set): two row shifts
+  const bool b2 = (c & 4) != 0, b1 = (c & 2) != 0, b0 = (c & 1) != 0;
+  float w4[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float keep = b2 ? v[k + 4] : v[k], send = b2 ? v[k] : v[k + 4];
+    const float up = dpp_get<0x104>(send), dn = dpp_get<0x114>(send);     // row_shl:4 reads lane c + 4, row_shr:4 lane c - 4
+    w4[k] = keep + (b2 ? dn : up);
+  }
+  float w2[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const float keep = b1 ? w4[k + 2] : w4[k], send = b1 ? w4[k] : w4[k + 2];
+    w2[k] = keep + dpp_get<0x4E>(send);                                   // quad_perm [2,3,0,1]: lane c ^ 2
+  }
+  const float keep = b0 ? w2[1] : w2[0], send = b0 ? w2[0] : w2[1];
+  return keep + dpp_get<0xB1>(send);                                      // quad_perm [1,0,3,2]: lane c ^ 1
+}
+__device__ __forceinline__ float slot_sums16(const float (&A)[8], const float (&B)[8], const int c) {
+  const bool b3 = (c & 8) != 0;
+  float v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float keep = b3 ? B[k] : A[k], send = b3 ? A[k] : B[k];
+    v[k] = keep + dpp_get<0x128>(send);                                   // row_ror:8: lane c ^ 8
+  }
+  return slot_fold4(v, c);
+}
+__device__ __forceinline__ float slot_sums8(const float (&A)[8], const int c) {
+  float v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = A[k] + dpp_get<0x128>(A[k]);
+  return slot_fold4(v, c);
+}
+
 // Segmented scans over the 64 lanes of a wave; a segment = `seg` consecutive lanes starting at a multiple of seg
 // (one ray of seg samples).  Two interchangeable policies:
 //   SegRows    seg in {16, 32, 64}: row_shr / row_shl DPP steps inside each 16-lane row, rows linked by three

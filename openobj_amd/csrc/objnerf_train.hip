@@ -452,6 +452,7 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
       // (rows 80..95, where s_w / gfh live, are not touched by the phase-A staging below)
     }
     T32 d_hc, d_h4;
+    float pa_[8], pb_[8], pc_[8], pd_[8];       // head-weight gradient products, summed over the samples below
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
@@ -459,15 +460,18 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
         const int row = 16 * tt + 4 * g + r;
         const int s = 4 * tt + r;
         const float hv = act.hc.t[tt][r];
-        slot_accum16(gS0, da * act.h4.t[tt][r], s, c);
-        slot_accum16(gS0, dc0 * hv, 8 + s, c);
-        slot_accum16(gS1, dc1 * hv, s, c);
-        slot_accum16(gS1, dc2 * hv, 8 + s, c);
+        pa_[s] = da * act.h4.t[tt][r];
+        pb_[s] = dc0 * hv;
+        pc_[s] = dc1 * hv;
+        pd_[s] = dc2 * hv;
         const float dv = fmaf(lds[OFF_WOC + 2 * H + row], dc2, fmaf(lds[OFF_WOC + H + row], dc1, lds[OFF_WOC + row] * dc0));
         d_hc.t[tt][r] = hv > 0.0f ? dv : 0.0f;
         d_h4.t[tt][r] = lds[OFF_WA + row] * da;
       }
     // group A staging: [h4 | x2] rows 0..79, h3 rows 96..127, d_hc rows 128.., d_h4pre rows 160..
+    gS0 += slot_sums16(pa_, pb_, c);
+    gS1 += slot_sums16(pc_, pd_, c);
+    asm volatile("" : "+v"(gS0), "+v"(gS1));
     store_T32(stg_lane, 0, act.h4);
     store_T32(stg_lane, 96, act.h3);
     store_T32(stg_lane, 128, d_hc);
@@ -477,7 +481,12 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) slot_accum16(gS2, d_h4.t[tt][r], 8 + 4 * tt + r, c);
+      for (int r = 0; r < 4; ++r) pa_[4 * tt + r] = d_h4.t[tt][r];
+    {
+      const float sv = slot_sums8(pa_, c);
+      gS2 += (c >= 8) ? sv : 0.0f;
+      asm volatile("" : "+v"(gS2));
+    }
     store_T32(stg_lane, 160, d_h4);
     // PE backward, x2 part, one 16-row tile at a time
 #pragma unroll
@@ -517,10 +526,16 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
     T32 d_h2 = zero32();
     mma_bwd32<ST_CAT>(d_h2, wt_cat, 0, d_h3);
     d_h2 = relu_mask32(d_h2, act.h2);
+    float pa2_[8];
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) slot_accum16(gS2, d_h2.t[tt][r], 4 * tt + r, c);
+      for (int r = 0; r < 4; ++r) pa2_[4 * tt + r] = d_h2.t[tt][r];
+    {
+      const float sv = slot_sums8(pa2_, c);
+      gS2 += (c < 8) ? sv : 0.0f;
+      asm volatile("" : "+v"(gS2));
+    }
     T32 d_h1 = zero32();
     mma_bwd32<ST_M>(d_h1, wt_m1, 0, d_h2);
     d_h1 = relu_mask32(d_h1, act.h1);

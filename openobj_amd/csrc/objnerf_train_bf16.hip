@@ -595,6 +595,7 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
         }
     }
     T32 d_hc, d_h4;
+    float pa_[8], pb_[8], pc_[8], pd_[8];       // head-weight gradient products, summed over the samples below
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
@@ -602,14 +603,17 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
         const int row = 16 * tt + 4 * g + r;
         const int s = 4 * tt + r;
         const float hv = hc.t[tt][r];
-        slot_accum16(gS0, da * h4.t[tt][r], s, c);
-        slot_accum16(gS0, dc0 * hv, 8 + s, c);
-        slot_accum16(gS1, dc1 * hv, s, c);
-        slot_accum16(gS1, dc2 * hv, 8 + s, c);
+        pa_[s] = da * h4.t[tt][r];
+        pb_[s] = dc0 * hv;
+        pc_[s] = dc1 * hv;
+        pd_[s] = dc2 * hv;
         const float dv = fmaf(sm[S_WOC + 2 * H + row], dc2, fmaf(sm[S_WOC + H + row], dc1, sm[S_WOC + row] * dc0));
         d_hc.t[tt][r] = hv > 0.0f ? dv : 0.0f;
         d_h4.t[tt][r] = sm[S_WA + row] * da;
       }
+    gS0 += slot_sums16(pa_, pb_, c);
+    gS1 += slot_sums16(pc_, pd_, c);
+    asm volatile("" : "+v"(gS0), "+v"(gS1));
     store32_b(stg_lane, 0, h4);
     store32_b(stg_lane, 96, h3);
     store32_b(stg_lane, 128, d_hc);
@@ -625,7 +629,12 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) slot_accum16(gS2, d_h4.t[tt][r], 8 + 4 * tt + r, c);
+      for (int r = 0; r < 4; ++r) pa_[4 * tt + r] = d_h4.t[tt][r];
+    {
+      const float sv = slot_sums8(pa_, c);
+      gS2 += (c >= 8) ? sv : 0.0f;
+      asm volatile("" : "+v"(gS2));
+    }
     store32_b(stg_lane, 160, d_h4);
 #pragma unroll
     for (int T = 0; T < 3; ++T) {
@@ -670,10 +679,16 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
     bwd_tile(d_h2.t[0], t_cat, 0, d_h3_b);
     bwd_tile(d_h2.t[1], t_cat, 16, d_h3_b);
     d_h2 = relu_mask32(d_h2, h2);
+    float pa2_[8];
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) slot_accum16(gS2, d_h2.t[tt][r], 4 * tt + r, c);
+      for (int r = 0; r < 4; ++r) pa2_[4 * tt + r] = d_h2.t[tt][r];
+    {
+      const float sv = slot_sums8(pa2_, c);
+      gS2 += (c < 8) ? sv : 0.0f;
+      asm volatile("" : "+v"(gS2));
+    }
     const bf16x8 d_h2_b = pack32(d_h2);
     T32 d_h1 = zero32();
     bwd_tile(d_h1.t[0], t_m1, 0, d_h2_b);
