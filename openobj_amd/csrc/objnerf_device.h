@@ -70,7 +70,13 @@ __device__ __forceinline__ void sincos_acc(float x, float& s, float& c) {
   c = __uint_as_float(__float_as_uint(cos_poly(r2)) ^ sg);
 }
 
-__device__ __forceinline__ float sigmoid_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float sigmoid_acc(float x) {
+#ifdef OBJ_HW_SINCOS      // bf16 mode only: v_exp_f32 + v_rcp_f32 (~1e-6 relative) instead of expf and an IEEE division
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.442695041f * x));
+#else
+  return 1.0f / (1.0f + expf(-x));
+#endif
+}
 
 #define OBJ_PI_F 3.14159274f
 

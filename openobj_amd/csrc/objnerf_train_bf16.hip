@@ -149,9 +149,9 @@ __device__ __forceinline__ void bwd_tile(f32x4& acc, const char* timg_lane, cons
 
 __device__ __forceinline__ void pe_project_b(const float* sm, const int g, const float px, const float py,
                                              const float pz, const float scale, Pe& pe) {
-  pe.t[0] = px / scale;
-  pe.t[1] = py / scale;
-  pe.t[2] = pz / scale;
+  pe.t[0] = px * scale;      // `scale` is 1 / obj_scale here (one division per workgroup instead of three per sample)
+  pe.t[1] = py * scale;
+  pe.t[2] = pz * scale;
   const float* bl = sm + S_PEB + 12 * g;
 #pragma unroll
   for (int i = 0; i < OBJ_NDIR; ++i) {
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
   stage_weights_bf16(ldsb, a.params + (long)k * a.p_stride, a.L, tid, FEAT);
   __syncthreads();
 
-  const float scale = a.scale[k];
+  const float inv_scale = 1.0f / a.scale[k];
   const int S = a.S, R = a.R, TR = a.TR;
   const float n1 = (float)a.counts[2 * k], n2 = (float)a.counts[2 * k + 1];
   const float inv1 = a.flags[0] ? 0.0f : 1.0f / (n1 + 1e-10f);
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
     const bool valid = (q < TR) && (ray < R);
     const float px = nx, py = ny, pz = nz;       // fetched during the previous tile's phase C
     Pe pe;
-    pe_project_b(sm, g, px, py, pz, scale, pe);
+    pe_project_b(sm, g, px, py, pz, inv_scale, pe);
     PT(0);
     T32 h1, h2, h3, h4, hc;
     T32 hf = zero32();           // (feature build) dead after the forward: the backward keeps its sign mask only
