@@ -70,6 +70,30 @@ __device__ __forceinline__ void sincos_acc(float x, float& s, float& c) {
   c = __uint_as_float(__float_as_uint(cos_poly(r2)) ^ sg);
 }
 
+#define OBJ_PI_F 3.14159274f
+
+// Embedding band and its derivative for a projection p and a compile-time octave scale sc:
+//   band = sin(fp32(fp32(p * sc) * pi))  (the reference's roundings, embedding.py:49-52),  dband/dp = cos(.) * pi * sc.
+// In the hardware mode the argument in revolutions is p * (sc / 2) directly and pi * sc is one constant.
+__device__ __forceinline__ float band_sin(const float p, const float sc) {
+#ifdef OBJ_HW_SINCOS
+  return __builtin_amdgcn_sinf(p * (0.5f * sc));
+#else
+  return sin_acc((p * sc) * OBJ_PI_F);
+#endif
+}
+__device__ __forceinline__ void band_sincos(const float p, const float sc, float& s, float& dcos) {
+#ifdef OBJ_HW_SINCOS
+  const float rev = p * (0.5f * sc);
+  s = __builtin_amdgcn_sinf(rev);
+  dcos = __builtin_amdgcn_cosf(rev) * (OBJ_PI_F * sc);
+#else
+  float cv;
+  sincos_acc((p * sc) * OBJ_PI_F, s, cv);
+  dcos = (cv * OBJ_PI_F) * sc;
+#endif
+}
+
 __device__ __forceinline__ float sigmoid_acc(float x) {
 #ifdef OBJ_HW_SINCOS      // bf16 mode only: v_exp_f32 + v_rcp_f32 (~1e-6 relative) instead of expf and an IEEE division
   return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.442695041f * x));
@@ -78,7 +102,6 @@ __device__ __forceinline__ float sigmoid_acc(float x) {
 #endif
 }
 
-#define OBJ_PI_F 3.14159274f
 
 // ----------------------------------------------------------------------------------------------
 // wave64 helpers

@@ -217,11 +217,10 @@ __device__ __forceinline__ float pe_band(const Pe& pe, const int q0) {
   const int qq = q0 + OBJ_NDIR;                 // >= 18
   const int j0 = qq % OBJ_NDIR, f0 = qq / OBJ_NDIR - 1;
   const float sc = f0 < 0 ? 0.5f : (float)(1 << (f0 < 0 ? 0 : f0));
-  const float arg = (pe.ps[j0] * sc) * OBJ_PI_F;
-  if (!WANT_COS) return sin_acc(arg);
-  float sv, cv;
-  sincos_acc(arg, sv, cv);
-  return (cv * OBJ_PI_F) * sc;
+  if (!WANT_COS) return band_sin(pe.ps[j0], sc);
+  float sv, dc;
+  band_sincos(pe.ps[j0], sc, sv, dc);
+  return dc;
 }
 
 // x1 tile T (0..5): entries e = 16 T + 4 g + r  (87 = constant 1, >= 88 zero)
@@ -293,9 +292,9 @@ __device__ __forceinline__ f32x4 pe_x1_tile_fb(const Pe& pe, const int T, const 
     const int q0 = 16 * T + r - 3, qq = q0 + OBJ_NDIR;
     const int j0 = qq % OBJ_NDIR, f0 = qq / OBJ_NDIR - 1;
     const float sc = f0 < 0 ? 0.5f : (float)(1 << (f0 < 0 ? 0 : f0));
-    float sv, cv;
-    sincos_acc((pe.ps[j0] * sc) * OBJ_PI_F, sv, cv);
-    float v = dx[r] * ((cv * OBJ_PI_F) * sc);
+    float sv, dc;
+    band_sincos(pe.ps[j0], sc, sv, dc);
+    float v = dx[r] * dc;
     if (T == 0 && r < 3) { v = (g == 0) ? 0.0f : v; sv = (g == 0) ? pe.t[r] : sv; }
     if (T == 5) {
       if (r == 3) { v = (g == 1) ? 0.0f : v; sv = (g == 1) ? 1.0f : sv; }
@@ -316,9 +315,9 @@ __device__ __forceinline__ f32x4 pe_x2_tile_fb(const Pe& pe, const int T, const 
     const int q0 = 84 + 16 * T + r, qq = q0 + OBJ_NDIR;
     const int j0 = qq % OBJ_NDIR, f0 = qq / OBJ_NDIR - 1;
     const float sc = (float)(1 << f0);
-    float sv, cv;
-    sincos_acc((pe.ps[j0] * sc) * OBJ_PI_F, sv, cv);
-    float v = dx[r] * ((cv * OBJ_PI_F) * sc);
+    float sv, dc;
+    band_sincos(pe.ps[j0], sc, sv, dc);
+    float v = dx[r] * dc;
     if (T == 2) {
       if (r == 2) { v = (g == 2) ? 0.0f : v; sv = (g == 2) ? 1.0f : sv; }
       if (r == 3) { v = (g == 2) ? 0.0f : v; sv = (g == 2) ? 0.0f : sv; }
