@@ -13,10 +13,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define OBJ_EMB 129
 
 // ----------------------------------------------------------------------------------------------
-// sin / cos accurate to ~1.3 ulp (1.2e-7 / 1.5e-7 absolute) for |x| < 1e4: 3-term Cody-Waite reduction
-// by pi to r in [-pi/2, pi/2], minimax polynomials, sign = (-1)^n.
-// The reference evaluates torch.sin on fp32(fp32(proj*2^f) * fp32(pi)) (embedding.py:52); the argument
-// reaches a few hundred, so the hardware v_sin_f32 is not accurate enough for the fp32 parity path.
+// sin / cos accurate to ~1.4e-7 / 1.6e-7 absolute for |x| < 1e4: 3-term Cody-Waite reduction by pi to
+// r in [-pi/2, pi/2], then v_sin_f32 / v_cos_f32 on r / 2 pi (measured on gfx950 over 2^20 points of that interval:
+// max abs error 1.35e-7 / 1.61e-7, the same class as degree-9 / degree-10 minimax polynomials, which remain
+// available under OBJ_POLY_SINCOS), sign = (-1)^n.
+// The reference evaluates torch.sin on fp32(fp32(proj*2^f) * fp32(pi)) (embedding.py:52); the argument reaches a
+// few hundred, so v_sin_f32 on the UNREDUCED argument is not accurate enough for the fp32 parity path.
 // ----------------------------------------------------------------------------------------------
 __device__ __forceinline__ float pi_reduce(float x, unsigned& sign) {
   const float n = rintf(x * 0.31830987f);
@@ -51,7 +53,11 @@ __device__ __forceinline__ float sin_acc(float x) {
 #endif
   unsigned sg;
   const float r = pi_reduce(x, sg);
+#ifdef OBJ_POLY_SINCOS
   return __uint_as_float(__float_as_uint(sin_poly(r, r * r)) ^ sg);
+#else
+  return __uint_as_float(__float_as_uint(__builtin_amdgcn_sinf(r * 0.15915494f)) ^ sg);
+#endif
 }
 __device__ __forceinline__ void sincos_acc(float x, float& s, float& c) {
 #ifdef ABL_CHEAP_PE
@@ -65,9 +71,15 @@ __device__ __forceinline__ void sincos_acc(float x, float& s, float& c) {
 #endif
   unsigned sg;
   const float r = pi_reduce(x, sg);
+#ifdef OBJ_POLY_SINCOS
   const float r2 = r * r;
   s = __uint_as_float(__float_as_uint(sin_poly(r, r2)) ^ sg);
   c = __uint_as_float(__float_as_uint(cos_poly(r2)) ^ sg);
+#else
+  const float rr = r * 0.15915494f;
+  s = __uint_as_float(__float_as_uint(__builtin_amdgcn_sinf(rr)) ^ sg);
+  c = __uint_as_float(__float_as_uint(__builtin_amdgcn_cosf(rr)) ^ sg);
+#endif
 }
 
 #define OBJ_PI_F 3.14159274f
