@@ -131,13 +131,17 @@ __device__ __forceinline__ T32 relu_mask32(const T32& gr, const T32& act) {
 
 // acc(32 out rows) += W[:, col0 + 4g + r] * xt     (xt: one 16-feature tile, feature = 4g + r)
 // wl = &W[c * ST + 4 * g]   (c = lane & 15 is the OUTPUT row inside each 16-row out tile)
+// (the second out tile's rows sit 16 * ST floats further: that distance goes through `hi16`, an OPAQUE copy of the
+// constant, so the compiler keeps a second base register for them and addresses both with DS immediates instead of
+// materialising base + large constant with a v_add for every ds_read2 pair)
 template <int ST>
-__device__ __forceinline__ void mma_fwd16(T32& acc, const float* wl, const int col0, const f32x4& xt) {
+__device__ __forceinline__ void mma_fwd16(T32& acc, const float* wl, const int col0, const f32x4& xt, const int hi16) {
   float a0[4], a1[4];
+  const float* wl1 = wl + hi16;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     a0[r] = wl[col0 + r];
-    a1[r] = wl[16 * ST + col0 + r];
+    a1[r] = wl1[col0 + r];
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -146,9 +150,13 @@ __device__ __forceinline__ void mma_fwd16(T32& acc, const float* wl, const int c
   }
 }
 template <int ST>
-__device__ __forceinline__ void mma_fwd32(T32& acc, const float* wl, const int col0, const T32& x) {
-  mma_fwd16<ST>(acc, wl, col0, x.t[0]);
-  mma_fwd16<ST>(acc, wl, col0 + 16, x.t[1]);
+__device__ __forceinline__ void mma_fwd32(T32& acc, const float* wl, const int col0, const T32& x, const int hi16) {
+  mma_fwd16<ST>(acc, wl, col0, x.t[0], hi16);
+  mma_fwd16<ST>(acc, wl, col0 + 16, x.t[1], hi16);
+}
+__device__ __forceinline__ int opaque_const(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
 }
 // acc(16 in rows: col .. col+15) += W[:, col : col+16]^T * d      (d: 32 out rows, D16 layout)
 // wt = &W[(4 * g) * ST + c]   (c = lane & 15 is the INPUT feature of the A operand here)
@@ -382,43 +390,45 @@ __device__ __forceinline__ float xgroup_sum(float v) {   // sum over the 4 lane 
 template <bool FEAT>
 __device__ __forceinline__ void mlp_forward(const float* lds, const int c, const int g, const Emb& e, Acts& a,
                                             Heads& hd) {
-  const float* wl_in = lds + OFF_IN + c * ST_IN + 4 * g;
-  const float* wl_m1 = lds + OFF_M1 + c * ST_M + 4 * g;
-  const float* wl_cat = lds + OFF_CAT + c * ST_CAT + 4 * g;
-  const float* wl_m2 = lds + OFF_M2 + c * ST_M + 4 * g;
-  const float* wl_cl = lds + OFF_CL + c * ST_CL + 4 * g;
+  const float* wl_in = lds + opaque_const(OFF_IN) + c * ST_IN + 4 * g;
+  const float* wl_m1 = lds + opaque_const(OFF_M1) + c * ST_M + 4 * g;
+  const float* wl_cat = lds + opaque_const(OFF_CAT) + c * ST_CAT + 4 * g;
+  const float* wl_m2 = lds + opaque_const(OFF_M2) + c * ST_M + 4 * g;
+  const float* wl_cl = lds + opaque_const(OFF_CL) + c * ST_CL + 4 * g;
+  const int h_in = opaque_const(16 * ST_IN), h_m = opaque_const(16 * ST_M), h_cat = opaque_const(16 * ST_CAT),
+            h_cl = opaque_const(16 * ST_CL);
   T32 acc = zero32();
 #pragma unroll
-  for (int T = 0; T < 6; ++T) mma_fwd16<ST_IN>(acc, wl_in, 16 * T, e.x1[T]);
+  for (int T = 0; T < 6; ++T) mma_fwd16<ST_IN>(acc, wl_in, 16 * T, e.x1[T], h_in);
   a.h1 = relu32(acc);
 #pragma unroll
   for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc.t[tt][r] = lds[OFF_BM1 + 16 * tt + 4 * g + r];
-  mma_fwd32<ST_M>(acc, wl_m1, 0, a.h1);
+  mma_fwd32<ST_M>(acc, wl_m1, 0, a.h1, h_m);
   a.h2 = relu32(acc);
   acc = zero32();
-  mma_fwd32<ST_CAT>(acc, wl_cat, 0, a.h2);
+  mma_fwd32<ST_CAT>(acc, wl_cat, 0, a.h2, h_cat);
 #pragma unroll
-  for (int T = 0; T < 6; ++T) mma_fwd16<ST_CAT>(acc, wl_cat, 32 + 16 * T, e.x1[T]);
+  for (int T = 0; T < 6; ++T) mma_fwd16<ST_CAT>(acc, wl_cat, 32 + 16 * T, e.x1[T], h_cat);
   a.h3 = relu32(acc);
 #pragma unroll
   for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc.t[tt][r] = lds[OFF_BM2 + 16 * tt + 4 * g + r];
-  mma_fwd32<ST_M>(acc, wl_m2, 0, a.h3);
+  mma_fwd32<ST_M>(acc, wl_m2, 0, a.h3, h_m);
   a.h4 = relu32(acc);
   acc = zero32();
-  mma_fwd32<ST_CL>(acc, wl_cl, 0, a.h4);
+  mma_fwd32<ST_CL>(acc, wl_cl, 0, a.h4, h_cl);
 #pragma unroll
-  for (int T = 0; T < 3; ++T) mma_fwd16<ST_CL>(acc, wl_cl, 32 + 16 * T, e.x2[T]);
+  for (int T = 0; T < 3; ++T) mma_fwd16<ST_CL>(acc, wl_cl, 32 + 16 * T, e.x2[T], h_cl);
   a.hc = relu32(acc);
   if (FEAT) {
-    const float* wl_fl = lds + OFF_FL + c * ST_CL + 4 * g;
+    const float* wl_fl = lds + opaque_const(OFF_FL) + c * ST_CL + 4 * g;
     acc = zero32();
-    mma_fwd32<ST_CL>(acc, wl_fl, 0, a.h4);
+    mma_fwd32<ST_CL>(acc, wl_fl, 0, a.h4, h_cl);
 #pragma unroll
-    for (int T = 0; T < 3; ++T) mma_fwd16<ST_CL>(acc, wl_fl, 32 + 16 * T, e.x2[T]);
+    for (int T = 0; T < 3; ++T) mma_fwd16<ST_CL>(acc, wl_fl, 32 + 16 * T, e.x2[T], h_cl);
     a.hf = relu32(acc);
   }
   // heads: each lane group holds 8 of the 32 hidden rows of its sample
