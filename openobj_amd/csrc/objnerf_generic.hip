@@ -428,7 +428,7 @@ struct Offs {
 // workspace carve (floats)
 struct WS {
   float *emb, *h1, *h2, *h3, *h4, *hc, *hf, *clip, *alpha, *color, *d_alpha, *d_color, *d_clip, *dhead;
-  float *dA, *dB_, *d_emb, *dBpe;
+  float *dA, *dB_, *dC, *dD, *dE, *d_emb, *dBpe;
   int* counts;
   size_t bytes;
 };
@@ -447,6 +447,7 @@ static WS carve(char* base, int H, int C, long n, int K, bool feat) {
   w.d_alpha = take((size_t)K * n); w.d_color = take((size_t)K * n * 3);
   w.dhead = take((size_t)K * n * 4);
   w.dA = take((size_t)K * n * H); w.dB_ = take((size_t)K * n * H);
+  w.dC = take((size_t)K * n * H); w.dD = take((size_t)K * n * H); w.dE = take((size_t)K * n * H);
   w.d_emb = take((size_t)K * n * OBJ_EMB);
   w.dBpe = take((size_t)K * 64);
   w.counts = (int*)take((size_t)2 * K + 2);
@@ -460,6 +461,22 @@ size_t train_workspace_bytes(const objnerf_net* net, int K, int R, int S, int fe
 }
 
 namespace {
+// helper stream + events of this host thread (created once; non-blocking so it never syncs with the null stream)
+struct Side {
+  static constexpr int NEV = 16;
+  hipStream_t s = nullptr;
+  hipEvent_t ev[NEV];
+  hipEvent_t done;
+};
+Side& side_stream() {
+  static thread_local Side sd;
+  if (!sd.s) {
+    (void)hipStreamCreateWithFlags(&sd.s, hipStreamNonBlocking);
+    for (int i = 0; i < Side::NEV; ++i) (void)hipEventCreateWithFlags(&sd.ev[i], hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&sd.done, hipEventDisableTiming);
+  }
+  return sd;
+}
 struct Bf16Scope {
   explicit Bf16Scope(bool on) { t_bf16_operands = on; }
   ~Bf16Scope() { t_bf16_operands = false; }
@@ -526,14 +543,26 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a, void* stream
     (void)hipMemsetAsync(G + (long)k * ps, 0, (size_t)off[14] * 4, st);
     if (feat) (void)hipMemsetAsync(G + (long)k * ps + off[14], 0, (size_t)(off[18] - off[14]) * 4, st);
   }
+  // Weight-gradient GEMMs only READ the d-output / activation buffers and write the gradient arena, so they run on a
+  // side stream beside the dgrad chain (each of these GEMMs alone leaves most of the chip idle).  Every d_h has its own
+  // buffer: nothing a side-stream GEMM reads is overwritten before the join at the end.
+  Side& sd = side_stream();
+  int fk = 0;
+  auto fork = [&]() {                       // side stream waits for everything enqueued on `st` so far
+    (void)hipEventRecord(sd.ev[fk], st);
+    (void)hipStreamWaitEvent(sd.s, sd.ev[fk], 0);
+    fk = (fk + 1) % Side::NEV;
+  };
+  hipStream_t ss = sd.s;
   float* d_hc = w.dA;      // [n][H]
   float* d_h4 = w.dB_;
   hipLaunchKernelGGL(heads_bwd_kernel, eg, dim3(256), head_lds, st, H, n, w.hc, w.color, w.d_alpha, w.d_color, P, ps,
                      (int)off[8], (int)off[12], w.dhead, d_hc, d_h4);
   // head weight grads: d wa = dhead[:,0]^T h4, d Woc = dhead[:,1:4]^T hc; biases = column sums of dhead
   // (every bias gradient rides on its layer's weight-gradient GEMM: row sums of the d-output operand tile)
-  wgrad(st, K, 1, H, n, w.dhead, 1, 4, n * 4, w.h4, H, 1, nH, G + off[8], H, ps, G + off[9]);
-  wgrad(st, K, 3, H, n, w.dhead + 1, 1, 4, n * 4, w.hc, H, 1, nH, G + off[12], H, ps, G + off[13]);
+  fork();
+  wgrad(ss, K, 1, H, n, w.dhead, 1, 4, n * 4, w.h4, H, 1, nH, G + off[8], H, ps, G + off[9]);
+  wgrad(ss, K, 3, H, n, w.dhead + 1, 1, 4, n * 4, w.hc, H, 1, nH, G + off[12], H, ps, G + off[13]);
   // d_emb needs no zero fill: the first dgrad into each column block overwrites (x2: feature layer if
   // present, else colour layer; x1: cat layer), later ones accumulate; columns 0..2 (d t) are never read.
   if (feat) {
@@ -541,34 +570,40 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a, void* stream
     float* d_hf = w.clip;   // reuse: clip [n][C] is dead after the loss; d_hf lives there with batch pitch n*C
     gemm(st, K, n, H, C, w.d_clip, C, 1, n * C, P + off[16], H, 1, ps, d_hf, H, 1, n * C, false, nullptr, 0, false, w.hf,
          H, 1, nH);
-    wgrad(st, K, C, H, n, w.d_clip, 1, C, n * C, w.hf, H, 1, nH, G + off[16], H, ps, G + off[17]);
+    fork();
+    wgrad(ss, K, C, H, n, w.d_clip, 1, C, n * C, w.hf, H, 1, nH, G + off[16], H, ps, G + off[17]);
     // feature layer: grads + contributions to d_h4 / d_x2
-    wgrad(st, K, H, H, n, d_hf, 1, H, n * C, w.h4, H, 1, nH, G + off[14], H + E2, ps, G + off[15]);
-    wgrad(st, K, H, E2, n, d_hf, 1, H, n * C, w.emb + E1, EM, 1, n * EM, G + off[14] + H, H + E2, ps);
+    wgrad(ss, K, H, H, n, d_hf, 1, H, n * C, w.h4, H, 1, nH, G + off[14], H + E2, ps, G + off[15]);
+    wgrad(ss, K, H, E2, n, d_hf, 1, H, n * C, w.emb + E1, EM, 1, n * EM, G + off[14] + H, H + E2, ps);
     gemm(st, K, n, H, H, d_hf, H, 1, n * C, P + off[14], H + E2, 1, ps, d_h4, H, 1, nH, true);
     gemm(st, K, n, E2, H, d_hf, H, 1, n * C, P + off[14] + H, H + E2, 1, ps, w.d_emb + E1, EM, 1, n * EM, false);
   }
   // colour layer
-  wgrad(st, K, H, H, n, d_hc, 1, H, nH, w.h4, H, 1, nH, G + off[10], H + E2, ps, G + off[11]);
-  wgrad(st, K, H, E2, n, d_hc, 1, H, nH, w.emb + E1, EM, 1, n * EM, G + off[10] + H, H + E2, ps);
+  fork();
+  wgrad(ss, K, H, H, n, d_hc, 1, H, nH, w.h4, H, 1, nH, G + off[10], H + E2, ps, G + off[11]);
+  wgrad(ss, K, H, E2, n, d_hc, 1, H, nH, w.emb + E1, EM, 1, n * EM, G + off[10] + H, H + E2, ps);
   gemm(st, K, n, H, H, d_hc, H, 1, nH, P + off[10], H + E2, 1, ps, d_h4, H, 1, nH, true, nullptr, 0, false, w.h4, H, 1, nH);
   gemm(st, K, n, E2, H, d_hc, H, 1, nH, P + off[10] + H, H + E2, 1, ps, w.d_emb + E1, EM, 1, n * EM, feat);
   // mid2:  d_h4 (masked above) -> grads, d_h3
-  float* d_h3 = w.dA;     // d_hc is dead
-  wgrad(st, K, H, H, n, d_h4, 1, H, nH, w.h3, H, 1, nH, G + off[6], H, ps, G + off[7]);
+  float* d_h3 = w.dC;
+  fork();
+  wgrad(ss, K, H, H, n, d_h4, 1, H, nH, w.h3, H, 1, nH, G + off[6], H, ps, G + off[7]);
   gemm(st, K, n, H, H, d_h4, H, 1, nH, P + off[6], H, 1, ps, d_h3, H, 1, nH, false, nullptr, 0, false, w.h3, H, 1, nH);
   // cat layer
-  float* d_h2 = w.dB_;    // d_h4 is dead
-  wgrad(st, K, H, H, n, d_h3, 1, H, nH, w.h2, H, 1, nH, G + off[4], H + E1, ps, G + off[5]);
-  wgrad(st, K, H, E1, n, d_h3, 1, H, nH, w.emb, EM, 1, n * EM, G + off[4] + H, H + E1, ps);
+  float* d_h2 = w.dD;
+  fork();
+  wgrad(ss, K, H, H, n, d_h3, 1, H, nH, w.h2, H, 1, nH, G + off[4], H + E1, ps, G + off[5]);
+  wgrad(ss, K, H, E1, n, d_h3, 1, H, nH, w.emb, EM, 1, n * EM, G + off[4] + H, H + E1, ps);
   gemm(st, K, n, H, H, d_h3, H, 1, nH, P + off[4], H + E1, 1, ps, d_h2, H, 1, nH, false, nullptr, 0, false, w.h2, H, 1, nH);
   gemm(st, K, n, E1, H, d_h3, H, 1, nH, P + off[4] + H, H + E1, 1, ps, w.d_emb, EM, 1, n * EM, false);
   // mid1
-  float* d_h1 = w.dA;     // d_h3 is dead
-  wgrad(st, K, H, H, n, d_h2, 1, H, nH, w.h1, H, 1, nH, G + off[2], H, ps, G + off[3]);
+  float* d_h1 = w.dE;
+  fork();
+  wgrad(ss, K, H, H, n, d_h2, 1, H, nH, w.h1, H, 1, nH, G + off[2], H, ps, G + off[3]);
   gemm(st, K, n, H, H, d_h2, H, 1, nH, P + off[2], H, 1, ps, d_h1, H, 1, nH, false, nullptr, 0, false, w.h1, H, 1, nH);
   // in layer
-  wgrad(st, K, H, E1, n, d_h1, 1, H, nH, w.emb, EM, 1, n * EM, G + off[0], E1, ps, G + off[1]);
+  fork();
+  wgrad(ss, K, H, E1, n, d_h1, 1, H, nH, w.emb, EM, 1, n * EM, G + off[0], E1, ps, G + off[1]);
   gemm(st, K, n, E1, H, d_h1, H, 1, nH, P + off[0], E1, 1, ps, w.d_emb, EM, 1, n * EM, true);
   // embedding directions
   (void)hipMemsetAsync(w.dBpe, 0, (size_t)K * 64 * 4, st);
@@ -579,6 +614,8 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a, void* stream
                      w.dBpe);
   hipLaunchKernelGGL(copy_cols_kernel, dim3((unsigned)((K * 63 + 255) / 256)), dim3(256), 0, st, (long)K, 63, w.dBpe, 63L,
                      G + off[18], ps);
+  (void)hipEventRecord(sd.done, sd.s);          // join: the caller's stream continues after the weight gradients
+  (void)hipStreamWaitEvent(st, sd.done, 0);
   if (hipGetLastError() != hipSuccess) return OBJNERF_ELAUNCH;
   return OBJNERF_OK;
 }
