@@ -886,12 +886,28 @@ int64_t objnerf_param_layout(const objnerf_net* net, int64_t offsets[OBJNERF_N_T
   return (o + 63) / 64 * 64;
 }
 
+// Workgroups per object.  One workgroup per compute unit at a time (LDS), each sweeps NT / G tiles of its object and
+// pays a fixed cost (weight staging, slab write + reduction) of about TILE_EQUIV tiles.  G = #CU / K fills the chip
+// in one round when K divides it well (K = 50 -> 5 x 50 = 250 of 256); otherwise (K = 100, 130, 300 ...) more,
+// shorter workgroups in several rounds come closer to K * NT / #CU tiles per compute unit.
+static int grid_cap(int K) {
+  const int g = num_cu() / (K > 0 ? K : 1);
+  return g > 32 ? g : 32;
+}
 static int train_grid(int K, int NT) {
-  int G = num_cu() / (K > 0 ? K : 1);
-  if (G < 1) G = 1;
-  if (G > NT) G = NT;
-  if (G < 1) G = 1;
-  return G;
+  constexpr long TILE_EQUIV = 4;
+  const int cu = num_cu();
+  int gmax = grid_cap(K);
+  if (gmax > NT) gmax = NT;
+  if (gmax < 1) gmax = 1;
+  int best = 1;
+  long best_cost = -1;
+  for (int G = 1; G <= gmax; ++G) {
+    const long rounds = ((long)K * G + cu - 1) / cu;
+    const long cost = rounds * ((NT + G - 1) / G + TILE_EQUIV);
+    if (best_cost < 0 || cost < best_cost) { best = G; best_cost = cost; }
+  }
+  return best;
 }
 
 size_t objnerf_train_workspace_bytes(const objnerf_net* net, int32_t K, int32_t R, int32_t S, int32_t with_feat) {
@@ -901,7 +917,7 @@ size_t objnerf_train_workspace_bytes(const objnerf_net* net, int32_t K, int32_t 
   with_feat &= 1;
   int64_t offs[OBJNERF_N_TENSORS + 1];
   const int64_t ps = objnerf_param_layout(net, offs);
-  const int Gmax = num_cu();   // upper bound on the workgroups per object
+  const int Gmax = grid_cap(K);   // upper bound on the workgroups per object
   size_t n = align256((size_t)K * Gmax * ps * 4) + align256((size_t)K * Gmax * 4 * 4) + align256((size_t)ps) + 256;
   if (with_feat)
     n += align256((size_t)K * R * RAYIN * 4) + align256((size_t)K * GRAM * 4) + align256((size_t)K * R * RAYFEAT * 4) +
@@ -947,7 +963,7 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
   d.counts = a->counts; d.flags = a->flags;
   d.L = make_layout(net->feat_dim);
   char* ws = (char*)a->workspace;
-  const int Gmax = num_cu();
+  const int Gmax = grid_cap(a->K);
   d.slab = (float*)ws;
   d.slab_stride = ps;
   ws += align256((size_t)a->K * Gmax * ps * 4);
