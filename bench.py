@@ -102,6 +102,9 @@ def main():
     ap.add_argument("--rays", type=int, default=4096, help="rays per object per step")
     ap.add_argument("--n-cam2surf", type=int, default=16)
     ap.add_argument("--n-bins", type=int, default=48)
+    ap.add_argument("--hidden", type=int, default=32,
+                    help="hidden width of the object networks (32 = the fused kernel; other widths, e.g. BASELINE "
+                         "configs[4] hidden 256 with --n-cam2surf 32 --n-bins 96, run the layer-wise path in object chunks)")
     ap.add_argument("--feat", action="store_true",
                     help="BASELINE configs[2]: add the 512-d feature-distillation loss (cfg.part_mode)")
     ap.add_argument("--no-bg", dest="bg", action="store_false",
@@ -132,8 +135,9 @@ def main():
 
     K, R, n1, n2 = args.objects, args.rays, args.n_cam2surf, args.n_bins
     S = n1 + n2
-    arena = ops.ParamArena(K, ops.NetShape(), dev)
-    arena.load_stacked(obj_init.init_stacked(K, 32, 512, seed=1000 + rank))
+    Hd = args.hidden
+    arena = ops.ParamArena(K, ops.NetShape(Hd, 512, 6), dev)
+    arena.load_stacked(obj_init.init_stacked(K, Hd, 512, seed=1000 + rank))
     feat = bool(args.feat)
     bf16 = args.dtype == "bf16"
     ws = ops.TrainWorkspace(arena, K, R, S, feat)
@@ -222,19 +226,21 @@ def main():
     if rank == 0:
         rays_per_step = K * R * world
         value = rays_per_step * args.steps / dt
-        fpr = flop_per_ray(S, feat=feat)
+        fpr = flop_per_ray(S, H=Hd, feat=feat)
         achieved = K * R * fpr / (kern_ms * 1e-3) / 1e12
         peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
         kname = f"train_fused_bf16_kernel<{'true' if feat else 'false'}>" if bf16 else f"train_fused_kernel<{'true' if feat else 'false'}>"
+        if Hd != 32 or S > 64:
+            kname = "objnerf_train_step, layer-wise path (batched MFMA GEMMs)"
         out = {
             "metric": "training rays/sec/GPU @64 samples/ray, 50 obj; PSNR delta vs ref",
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"Replica room_0-shaped, {K} object MLPs/GPU (hidden 32), {R} rays/object/step, "
+            "config": {"workload": f"Replica room_0-shaped, {K} object MLPs/GPU (hidden {Hd}), {R} rays/object/step, "
                                    f"{S} samples/ray ({n1}+{n2}), RGB+depth+opacity"
                                    f"{'+512-d feature' if feat else ''} loss, fused fwd+loss+bwd+AdamW",
-                       "objects_per_gpu": K, "rays_per_object": R, "samples_per_ray": S, "hidden": 32,
+                       "objects_per_gpu": K, "rays_per_object": R, "samples_per_ray": S, "hidden": Hd,
                        "feature_head": feat, "background_mlp": bool(args.bg), "parallelism": f"objects sharded x{world}",
                        "loss_status": status},
             "rays_per_sec_per_gpu": value / world,
@@ -247,7 +253,9 @@ def main():
         if bf16_extra is not None:
             bdt, bk = bf16_extra
             out["bf16_mode"] = {"value": rays_per_step * args.steps / bdt, "unit": "rays/s",
-                                "ms_per_step": bdt / args.steps * 1e3, "kernel": f"train_fused_bf16_kernel<{'true' if feat else 'false'}>",
+                                "ms_per_step": bdt / args.steps * 1e3,
+                                "kernel": (f"train_fused_bf16_kernel<{'true' if feat else 'false'}>" if Hd == 32 and S <= 64
+                                           else "layer-wise path, bf16-operand GEMMs"),
                                 "kernel_ms": bk, "mfma_tflops": K * R * fpr / (bk * 1e-3) / 1e12,
                                 "note": "OBJNERF_TRAIN_BF16: bf16 MFMA operands, fp32 accumulate / master weights / "
                                         "compositing / AdamW; PSNR-gated (tests/test_bf16_gpu.py), not 1e-4 parity"}

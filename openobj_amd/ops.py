@@ -269,13 +269,29 @@ def step_batch_loss(alpha, color, gt_depth, gt_rgb, labels, z, color_scaling=5.0
                 counts=counts)
 
 
-class TrainWorkspace:
-    """Caller-owned buffers of the fused training step, allocated once per (K,R,S)."""
+LAYERWISE_WORKSPACE_BUDGET = 64 << 30      # bytes; the layer-wise path materialises activations per object chunk
 
-    def __init__(self, arena: ParamArena, K: int, R: int, S: int, with_feat: bool, layerwise: bool = False):
+
+class TrainWorkspace:
+    """Caller-owned buffers of the fused training step, allocated once per (K,R,S).
+
+    The layer-wise path (hidden != 32, S > 64 or layerwise=True) keeps every activation of the objects it works on
+    in the workspace; when K objects would need more than `budget` bytes (BASELINE configs[4]: 64 objects x 8192
+    rays x 128 samples x hidden 256 is ~0.7 TB), the workspace is sized for `k_chunk` objects and train_step runs
+    the objects chunk by chunk -- they are independent networks, only the early-return flags span the batch."""
+
+    def __init__(self, arena: ParamArena, K: int, R: int, S: int, with_feat: bool, layerwise: bool = False,
+                 budget: Optional[int] = None):
         dev = arena.params.device
         net = arena.net.c()
-        nbytes = lib().objnerf_train_workspace_bytes(C.byref(net), K, R, S, int(with_feat) | (2 if layerwise else 0))
+        wf = int(with_feat) | (2 if layerwise else 0)
+        budget = LAYERWISE_WORKSPACE_BUDGET if budget is None else budget
+        self.k_chunk = K
+        nbytes = lib().objnerf_train_workspace_bytes(C.byref(net), K, R, S, wf)
+        if (arena.net.hidden != 32 or S > 64 or layerwise) and nbytes > budget and K > 1:
+            per_obj = lib().objnerf_train_workspace_bytes(C.byref(net), 1, R, S, wf)
+            self.k_chunk = max(1, min(K, int(budget // max(1, per_obj))))
+            nbytes = lib().objnerf_train_workspace_bytes(C.byref(net), self.k_chunk, R, S, wf)
         if nbytes == 0:
             raise _lib.ObjnerfError("objnerf_train_workspace_bytes returned 0")
         self.nbytes = int(nbytes)
@@ -283,6 +299,7 @@ class TrainWorkspace:
         self.grads = torch.zeros_like(arena.params)
         self.loss_terms = torch.zeros(K, 4, device=dev)
         self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.status_chunks = torch.zeros((K + self.k_chunk - 1) // self.k_chunk, dtype=torch.int32, device=dev)
         self.counts = torch.zeros(K, 2, dtype=torch.int32, device=dev)
         self.flags = torch.zeros(2, dtype=torch.int32, device=dev)
         self.key = (K, R, S, with_feat)
@@ -322,11 +339,27 @@ def train_step(arena: ParamArena, ws: TrainWorkspace, batch: Dict[str, torch.Ten
     if global_counts is not None:       # one object's rays split over ranks (background): global mask counts
         counts = _req(global_counts, torch.int32, "global_counts")
     net = arena.net.c()
-    a = TrainArgs(K, R, S, (1 if bf16 else 0) | (2 if layerwise else 0), color_scaling, opacity_scaling, feat_scaling, obj_center, _ptr(arena.params),
-                  arena.p_stride, _ptr(arena.scale), _ptr(pts), _ptr(origins), _ptr(dirs), _ptr(z), _ptr(gt_depth),
-                  _ptr(gt_rgb), _ptr(labels), _ptr(gt_feat), _ptr(counts), _ptr(flags), _ptr(ws.grads),
-                  _ptr(ws.loss_terms), _ptr(ws.status), _ptr(ws.buf), ws.nbytes)
-    check(lib().objnerf_train_step(C.byref(net), C.byref(a), st), "objnerf_train_step")
+    mode = (1 if bf16 else 0) | (2 if layerwise else 0)
+    kc = getattr(ws, "k_chunk", K)
+    if kc >= K:
+        a = TrainArgs(K, R, S, mode, color_scaling, opacity_scaling, feat_scaling, obj_center, _ptr(arena.params),
+                      arena.p_stride, _ptr(arena.scale), _ptr(pts), _ptr(origins), _ptr(dirs), _ptr(z), _ptr(gt_depth),
+                      _ptr(gt_rgb), _ptr(labels), _ptr(gt_feat), _ptr(counts), _ptr(flags), _ptr(ws.grads),
+                      _ptr(ws.loss_terms), _ptr(ws.status), _ptr(ws.buf), ws.nbytes)
+        check(lib().objnerf_train_step(C.byref(net), C.byref(a), st), "objnerf_train_step")
+        return
+    # layer-wise path, chunk of objects at a time (leading-dimension slices are contiguous views)
+    sl = lambda t, k0, k1: None if t is None else t[k0:k1]           # noqa: E731
+    for ci, k0 in enumerate(range(0, K, kc)):
+        k1 = min(K, k0 + kc)
+        a = TrainArgs(k1 - k0, R, S, mode, color_scaling, opacity_scaling, feat_scaling, obj_center,
+                      _ptr(arena.params[k0:k1]), arena.p_stride, _ptr(arena.scale[k0:k1]), _ptr(sl(pts, k0, k1)),
+                      _ptr(sl(origins, k0, k1)), _ptr(sl(dirs, k0, k1)), _ptr(z[k0:k1]), _ptr(gt_depth[k0:k1]),
+                      _ptr(gt_rgb[k0:k1]), _ptr(labels[k0:k1]), _ptr(sl(gt_feat, k0, k1)), _ptr(counts[k0:k1]),
+                      _ptr(flags), _ptr(ws.grads[k0:k1]), _ptr(ws.loss_terms[k0:k1]), _ptr(ws.status_chunks[ci:ci + 1]),
+                      _ptr(ws.buf), ws.nbytes)
+        check(lib().objnerf_train_step(C.byref(net), C.byref(a), st), "objnerf_train_step")
+    torch.amax(ws.status_chunks, dim=0, keepdim=True, out=ws.status)
 
 
 def adamw_step(arena: ParamArena, grads: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor,

@@ -549,3 +549,23 @@ def test_single_object_many_rays(dev):
     for i in list(range(14)) + [18]:
         scale = max(1e-3, float(gl[i].abs().max()))
         assert maxerr(gf[i], gl[i]) < 3e-4 * scale, (i, ops.TENSOR_NAMES[i], maxerr(gf[i], gl[i]), scale)
+
+
+def test_layerwise_object_chunks_equal_one_shot(dev):
+    """The layer-wise path run chunk by chunk over the objects (a workspace budget smaller than the batch) gives
+    the gradients of the one-shot run: objects are independent, only the early-return flags span the batch."""
+    K, R, n1, n2, H = 5, 40, 8, 24, 128
+    arena = ops.ParamArena(K, ops.NetShape(H, 512, 6), dev)
+    arena.load_stacked(obj_init.init_stacked(K, H, 512, seed=2))
+    b = synthetic.random_batch(K, R, n1, n2, seed=8, feat_dim=512)
+    batch = {k: T(b[k]).to(dev) for k in ["pts", "z", "gt_depth", "gt_rgb", "labels", "gt_feat"]}
+    ws1 = ops.TrainWorkspace(arena, K, R, n1 + n2, True)
+    one = ops.TrainWorkspace(arena, 1, R, n1 + n2, True).nbytes
+    ws2 = ops.TrainWorkspace(arena, K, R, n1 + n2, True, budget=2 * one + 4096)
+    assert ws1.k_chunk == K and ws2.k_chunk == 2
+    ops.train_step(arena, ws1, batch, with_feat=True)
+    ops.train_step(arena, ws2, batch, with_feat=True)
+    torch.cuda.synchronize()
+    assert int(ws2.status.item()) == int(ws1.status.item()) == 0
+    assert maxerr(ws2.loss_terms, ws1.loss_terms) < 1e-5 * max(1.0, float(ws1.loss_terms.abs().max()))
+    assert maxerr(ws2.grads, ws1.grads) < 1e-5 * max(1.0, float(ws1.grads.abs().max()))
