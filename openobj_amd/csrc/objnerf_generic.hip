@@ -142,11 +142,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Gemm g) {
 // ------------------------------------------------------------------------------------------------
 // bf16-operand variant (OBJNERF_TRAIN_BF16 on the layer-wise path): same interface and epilogue, operands are
 // rounded to bf16 when they are staged in LDS ([row][k], k contiguous: one ds_read_b128 per MFMA operand),
-// v_mfma_f32_16x16x32_bf16, fp32 accumulation.  64 x 64 tiles, 32-deep k steps: 4 MFMAs per wave and step, so the
-// kernel is bound by the operand traffic, not by the matrix core.
+// v_mfma_f32_16x16x32_bf16, fp32 accumulation.  64 x 64 (or, for wide layers, 128 x 128) tiles, 32-deep k steps:
+// 4 (16) MFMAs per wave and step, so the kernel is bound by the operand traffic, not by the matrix core.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+template <int TM, int TN>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const Gemm g) {
-  constexpr int TM = 2, TN = 2, BM = 64, BN = 64, BKB = 32, LDK = BKB + 8;
+  constexpr int BM = 32 * TM, BN = 32 * TN, BKB = 32, LDK = BKB + 8;
   __shared__ __attribute__((aligned(16))) __bf16 As[BM][LDK];
   __shared__ __attribute__((aligned(16))) __bf16 Bs[BN][LDK];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -264,8 +265,13 @@ static void gemm(hipStream_t st, int batch, int M, int N, int Kd, const float* A
   g.rowsum = rowsum; g.bsrs = bsrs;
   const int nz = batch * (splitk > 1 ? splitk : 1);
   if (t_bf16_operands) {
-    dim3 grid((N + 63) / 64, (M + 63) / 64, nz);
-    hipLaunchKernelGGL(gemm_bf16_kernel, grid, dim3(256), 0, st, g);
+    if (M >= 256 && N >= 192) {
+      dim3 grid((N + 127) / 128, (M + 127) / 128, nz);
+      hipLaunchKernelGGL((gemm_bf16_kernel<4, 4>), grid, dim3(256), 0, st, g);
+    } else {
+      dim3 grid((N + 63) / 64, (M + 63) / 64, nz);
+      hipLaunchKernelGGL((gemm_bf16_kernel<2, 2>), grid, dim3(256), 0, st, g);
+    }
     return;
   }
   if (M >= 256 && N >= 192) {         // wide layer GEMMs (hidden 256): 128 x 128 tiles.  Up to N = 128 the
