@@ -1,6 +1,17 @@
 // Internal interface of the layer-wise (any hidden width) training path, objnerf_generic.hip.
 #pragma once
 #include "../../include/objnerf_hip.h"
+// loss with the feature term hoisted past the compositing (objnerf_misc.hip); hz == NULL: the public
+// objnerf_step_batch_loss
+namespace objmisc {
+struct LossHoisted {
+  int Hh;
+  const float* hf; const float* rayin; const float* gram;
+  float* d_hf; float* rayfeat;
+};
+int step_batch_loss_impl(const objnerf_loss_args* a, const LossHoisted* hz, void* stream);
+}  // namespace objmisc
+
 namespace objgen {
 size_t train_workspace_bytes(const objnerf_net* net, int K, int R, int S, int feat);
 int train_step(const objnerf_net* net, const objnerf_train_args* a, void* stream);

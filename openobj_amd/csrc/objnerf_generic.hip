@@ -6,6 +6,7 @@
 //   embedding.py:46-55 -> model.py:61-103 -> loss.py:5-103 (objnerf_step_batch_loss) -> reverse.
 #include "objnerf_device.h"
 #include "../../include/objnerf_hip.h"
+#include "objnerf_generic.h"
 
 namespace objgen {
 
@@ -424,6 +425,79 @@ __global__ void copy_cols_kernel(long rows, int cols, const float* src, long lds
   if (i < rows * cols) dst[(i / cols) * ldd + (i % cols)] = src[(i / cols) * lds_ + (i % cols)];
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Feature-distillation branch with the 512-d head hoisted past the compositing, any hidden width Hh
+// (the hidden-32 fused kernel has its own copies in objnerf_train.hip).
+// beta[r] = b_of . g[r], |g[r]| into rayin[r][Hh], [Hh + 1]  (u = W_of^T g is a GEMM): 16 lanes per ray
+__global__ __launch_bounds__(256) void featg_rowstats_kernel(const float* params, long p_stride, int off_b, int C, int R,
+                                                             int rin_ld, const float* gt_feat, float* rayin) {
+  const int k = blockIdx.y;
+  const int l16 = threadIdx.x & 15;
+  const long r = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const float* B = params + (long)k * p_stride + off_b;
+  float bs = 0.f, gs = 0.f;
+  if (r < R) {
+    const float* gp = gt_feat + ((long)k * R + r) * C;
+    for (int cc = l16; cc < C; cc += 16) {
+      const float gv = gp[cc];
+      bs = fmaf(B[cc], gv, bs);
+      gs = fmaf(gv, gv, gs);
+    }
+  }
+  bs = dpp_rowsum16(bs);
+  gs = dpp_rowsum16(gs);
+  if (r < R && l16 == 0) {
+    float* o = rayin + ((long)k * R + r) * rin_ld;
+    o[rin_ld - 2] = bs;
+    o[rin_ld - 1] = sqrtf(gs);
+  }
+}
+// wb = W_of^T b_of, bb = b_of . b_of appended to the Gram matrix: gram[k][Hh * Hh + h], [Hh * Hh + Hh]
+__global__ void featg_wb_kernel(const float* params, long p_stride, int off_w, int off_b, int C, int Hh, float* gram) {
+  const int k = blockIdx.x;
+  const float* W = params + (long)k * p_stride + off_w;
+  const float* B = params + (long)k * p_stride + off_b;
+  float* o = gram + (long)k * ((long)Hh * Hh + Hh + 1) + (long)Hh * Hh;
+  for (int h = threadIdx.x; h <= Hh; h += blockDim.x) {
+    float acc = 0.f;
+    for (int cc = 0; cc < C; ++cc) acc = fmaf(h < Hh ? W[(long)cc * Hh + h] : B[cc], B[cc], acc);
+    o[h] = acc;
+  }
+}
+// X1 = [a fh | a O], X2 = [c fh | c O] from rayfeat rows (fh[Hh], O, a, c)
+__global__ void featg_scale_kernel(long n, int Hh, const float* rayfeat, float* X1, float* X2) {
+  const int XC = Hh + 1;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * XC) return;
+  const long r = i / XC;
+  const int j = (int)(i - r * XC);
+  const float* rf = rayfeat + r * (Hh + 3);
+  const float v = rf[j];
+  X1[i] = rf[Hh + 1] * v;
+  X2[i] = rf[Hh + 2] * v;
+}
+// d W_of[c][h] = T[c][h] + sum_j W_of[c][j] M[j][h] + b_of[c] M[Hh][h];  d b_of[c] = T[c][Hh] + W_of[c] . M[Hh][:] + b_of[c] M[Hh][Hh]
+__global__ __launch_bounds__(256) void featg_finish_kernel(const float* params, long p_stride, int off_w, int off_b, int C,
+                                                           int Hh, const float* Tm, const float* mom, float* grads) {
+  const int XC = Hh + 1;
+  const int k = blockIdx.y;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)C * XC) return;
+  const int cc = (int)(i / XC), hh = (int)(i - (long)cc * XC);
+  const float* W = params + (long)k * p_stride + off_w + (long)cc * Hh;
+  const float bc = params[(long)k * p_stride + off_b + cc];
+  const float* M = mom + (long)k * XC * XC;
+  float v = Tm[(long)k * C * XC + i];
+  if (hh < Hh) {
+    for (int j = 0; j < Hh; ++j) v = fmaf(W[j], M[(long)j * XC + hh], v);
+    grads[(long)k * p_stride + off_w + (long)cc * Hh + hh] = fmaf(bc, M[(long)Hh * XC + hh], v);
+  } else {
+    for (int j = 0; j < Hh; ++j) v = fmaf(W[j], M[(long)Hh * XC + j], v);
+    grads[(long)k * p_stride + off_b + cc] = fmaf(bc, M[(long)Hh * XC + Hh], v);
+  }
+}
+
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Offs {
@@ -433,13 +507,14 @@ struct Offs {
 
 // workspace carve (floats)
 struct WS {
-  float *emb, *h1, *h2, *h3, *h4, *hc, *hf, *clip, *alpha, *color, *d_alpha, *d_color, *d_clip, *dhead;
+  float *emb, *h1, *h2, *h3, *h4, *hc, *hf, *alpha, *color, *d_alpha, *d_color, *dhead;
+  float *d_hf, *rayin, *gram, *rayfeat, *X1, *X2, *Tm, *mom;      // feature branch (hoisted head)
   float *dA, *dB_, *dC, *dD, *dE, *d_emb, *dBpe;
   int* counts;
   size_t bytes;
 };
 
-static WS carve(char* base, int H, int C, long n, int K, bool feat) {
+static WS carve(char* base, int H, int C, long n, long R, int K, bool feat) {
   WS w;
   char* p = base;
   auto take = [&](size_t floats) { float* r = (float*)p; p += al(floats * 4); return r; };
@@ -447,8 +522,14 @@ static WS carve(char* base, int H, int C, long n, int K, bool feat) {
   w.h1 = take((size_t)K * n * H); w.h2 = take((size_t)K * n * H); w.h3 = take((size_t)K * n * H);
   w.h4 = take((size_t)K * n * H); w.hc = take((size_t)K * n * H);
   w.hf = feat ? take((size_t)K * n * H) : nullptr;
-  w.clip = feat ? take((size_t)K * n * C) : nullptr;
-  w.d_clip = feat ? take((size_t)K * n * C) : nullptr;
+  w.d_hf = feat ? take((size_t)K * n * H) : nullptr;
+  w.rayin = feat ? take((size_t)K * R * (H + 2)) : nullptr;
+  w.gram = feat ? take((size_t)K * ((size_t)H * H + H + 1)) : nullptr;
+  w.rayfeat = feat ? take((size_t)K * R * (H + 3)) : nullptr;
+  w.X1 = feat ? take((size_t)K * R * (H + 1)) : nullptr;
+  w.X2 = feat ? take((size_t)K * R * (H + 1)) : nullptr;
+  w.Tm = feat ? take((size_t)K * C * (H + 1) + (size_t)K * (H + 1) * (H + 1)) : nullptr;   // Tm | mom, zeroed together
+  w.mom = feat ? w.Tm + (size_t)K * C * (H + 1) : nullptr;
   w.alpha = take((size_t)K * n); w.color = take((size_t)K * n * 3);
   w.d_alpha = take((size_t)K * n); w.d_color = take((size_t)K * n * 3);
   w.dhead = take((size_t)K * n * 4);
@@ -462,7 +543,7 @@ static WS carve(char* base, int H, int C, long n, int K, bool feat) {
 }
 
 size_t train_workspace_bytes(const objnerf_net* net, int K, int R, int S, int feat) {
-  WS w = carve(nullptr, net->hidden, net->feat_dim, (long)R * S, K, feat != 0);
+  WS w = carve(nullptr, net->hidden, net->feat_dim, (long)R * S, (long)R, K, feat != 0);
   return w.bytes + 256;
 }
 
@@ -500,7 +581,7 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a, void* stream
   objnerf_param_layout(net, off);
   const long ps = a->p_stride;
   hipStream_t st = (hipStream_t)stream;
-  WS w = carve((char*)a->workspace, H, C, n, K, feat);
+  WS w = carve((char*)a->workspace, H, C, n, (long)a->R, K, feat);
   if (a->workspace_bytes < w.bytes) return OBJNERF_EINVAL;
   const float* P = a->params;
   float* G = a->grads;
@@ -529,7 +610,14 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a, void* stream
     gemm(st, K, n, H, H, w.h4, H, 1, nH, P + off[14], 1, H + E2, ps, w.hf, H, 1, nH);
     gemm(st, K, n, H, E2, w.emb + E1, EM, 1, n * EM, P + off[14] + H, 1, H + E2, ps, w.hf, H, 1, nH, true, P + off[15],
          ps, true);
-    gemm(st, K, n, C, H, w.hf, H, 1, nH, P + off[16], 1, H, ps, w.clip, C, 1, n * C, false, P + off[17], ps, false);
+    // the 512-d head is NOT applied per sample: per object G = W_of^T W_of (+ wb, bb), per ray u = W_of^T g, beta, |g|
+    const long R = a->R;
+    const long gst = (long)H * H + H + 1;
+    gemm(st, K, H, H, C, P + off[16], 1, H, ps, P + off[16], H, 1, ps, w.gram, H, 1, gst);
+    hipLaunchKernelGGL(featg_wb_kernel, dim3(K), dim3(256), 0, st, P, ps, (int)off[16], (int)off[17], C, H, w.gram);
+    gemm(st, K, (int)R, H, C, a->gt_feat, C, 1, R * C, P + off[16], H, 1, ps, w.rayin, H + 2, 1, R * (H + 2));
+    hipLaunchKernelGGL(featg_rowstats_kernel, dim3((unsigned)((R + 15) / 16), K), dim3(256), 0, st, P, ps, (int)off[17], C,
+                       (int)R, H + 2, a->gt_feat, w.rayin);
   }
   // ---- loss + d(alpha, color, clip)      (loss.py:5-103)
   objnerf_loss_args la;
@@ -537,11 +625,13 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a, void* stream
   la.color_scaling = a->color_scaling; la.opacity_scaling = a->opacity_scaling; la.feat_scaling = a->feat_scaling;
   la.reserved = 0;
   la.alpha = w.alpha; la.color = w.color; la.z = a->z; la.gt_depth = a->gt_depth; la.gt_rgb = a->gt_rgb;
-  la.labels = a->labels; la.pred_feat = feat ? w.clip : nullptr; la.gt_feat = a->gt_feat; la.flags_in = a->flags;
+  la.labels = a->labels; la.pred_feat = nullptr; la.gt_feat = a->gt_feat; la.flags_in = a->flags;
   la.counts_in = a->counts;
   la.loss_terms = a->loss_terms; la.total = nullptr; la.d_alpha = w.d_alpha; la.d_color = w.d_color;
-  la.d_pred_feat = feat ? w.d_clip : nullptr; la.counts = w.counts; la.status = a->status;
-  rc = objnerf_step_batch_loss(&la, stream);
+  la.d_pred_feat = nullptr; la.counts = w.counts; la.status = a->status;
+  objmisc::LossHoisted hz;
+  hz.Hh = H; hz.hf = w.hf; hz.rayin = w.rayin; hz.gram = w.gram; hz.d_hf = w.d_hf; hz.rayfeat = w.rayfeat;
+  rc = objmisc::step_batch_loss_impl(&la, feat ? &hz : nullptr, stream);
   if (rc) return rc;
   // ---- backward.  Weight / bias gradients are accumulated with split-K atomics: zero them first
   // (feature-branch entries only when they receive a gradient, so "no gradient" stays "untouched").
@@ -572,17 +662,26 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a, void* stream
   // d_emb needs no zero fill: the first dgrad into each column block overwrites (x2: feature layer if
   // present, else colour layer; x1: cat layer), later ones accumulate; columns 0..2 (d t) are never read.
   if (feat) {
-    // d_hf = relu'(hf) (d_clip W_of); d W_of = d_clip^T hf; d b_of = colsum(d_clip)
-    float* d_hf = w.clip;   // reuse: clip [n][C] is dead after the loss; d_hf lives there with batch pitch n*C
-    gemm(st, K, n, H, C, w.d_clip, C, 1, n * C, P + off[16], H, 1, ps, d_hf, H, 1, n * C, false, nullptr, 0, false, w.hf,
-         H, 1, nH);
+    // d_hf (pre-activation gradient of the feature layer) came out of the loss kernel; the 512-d head's gradient is
+    // d W_of = gt_feat^T [a fh] + W_of M2 + b_of m1^T, d b_of = gt_feat^T [a O] + W_of m1 + b_of s2 with the moments
+    // [M2 m1; . s2] = [c fh | c O]^T [fh | O]: two split-K GEMMs over the rays + a small finish (side stream)
+    float* d_hf = w.d_hf;
+    const long R = a->R;
+    const int XC = H + 1;
+    const long nr = (long)K * R;
     fork();
-    wgrad(ss, K, C, H, n, w.d_clip, 1, C, n * C, w.hf, H, 1, nH, G + off[16], H, ps, G + off[17]);
+    hipLaunchKernelGGL(featg_scale_kernel, dim3((unsigned)((nr * XC + 255) / 256)), dim3(256), 0, ss, nr, H, w.rayfeat, w.X1,
+                       w.X2);
+    (void)hipMemsetAsync(w.Tm, 0, ((size_t)K * C * XC + (size_t)K * XC * XC) * 4, ss);
+    wgrad(ss, K, C, XC, R, a->gt_feat, 1, C, R * C, w.X1, XC, 1, R * XC, w.Tm, XC, (long)C * XC);
+    wgrad(ss, K, XC, XC, R, w.X2, 1, XC, R * XC, w.rayfeat, H + 3, 1, R * (H + 3), w.mom, XC, (long)XC * XC);
+    hipLaunchKernelGGL(featg_finish_kernel, dim3((unsigned)(((long)C * XC + 255) / 256), K), dim3(256), 0, ss, P, ps,
+                       (int)off[16], (int)off[17], C, H, w.Tm, w.mom, G);
     // feature layer: grads + contributions to d_h4 / d_x2
-    wgrad(ss, K, H, H, n, d_hf, 1, H, n * C, w.h4, H, 1, nH, G + off[14], H + E2, ps, G + off[15]);
-    wgrad(ss, K, H, E2, n, d_hf, 1, H, n * C, w.emb + E1, EM, 1, n * EM, G + off[14] + H, H + E2, ps);
-    gemm(st, K, n, H, H, d_hf, H, 1, n * C, P + off[14], H + E2, 1, ps, d_h4, H, 1, nH, true);
-    gemm(st, K, n, E2, H, d_hf, H, 1, n * C, P + off[14] + H, H + E2, 1, ps, w.d_emb + E1, EM, 1, n * EM, false);
+    wgrad(ss, K, H, H, n, d_hf, 1, H, nH, w.h4, H, 1, nH, G + off[14], H + E2, ps, G + off[15]);
+    wgrad(ss, K, H, E2, n, d_hf, 1, H, nH, w.emb + E1, EM, 1, n * EM, G + off[14] + H, H + E2, ps);
+    gemm(st, K, n, H, H, d_hf, H, 1, nH, P + off[14], H + E2, 1, ps, d_h4, H, 1, nH, true);
+    gemm(st, K, n, E2, H, d_hf, H, 1, nH, P + off[14] + H, H + E2, 1, ps, w.d_emb + E1, EM, 1, n * EM, false);
   }
   // colour layer
   fork();

@@ -4,6 +4,7 @@
 // rounds where the reference's separate ATen ops round; fused multiply-adds are written as fmaf.
 #include "objnerf_device.h"
 #include "../../include/objnerf_hip.h"
+#include "objnerf_generic.h"
 
 namespace {
 
@@ -182,15 +183,25 @@ struct LossDev {
   const uint8_t* labels; const float* pred_feat; const float* gt_feat;
   const int* counts; const int* flags;
   float* loss_terms; float* d_alpha; float* d_color; float* d_pred_feat;
+  // hoisted feature term (layer-wise training path): the 512-d head is linear, so F = W_of fh + b_of O with
+  // fh = sum_s w_s hf_s; only hf [K*R*S][Hh] is materialised, never a C-wide tensor
+  int Hh;
+  const float* hf;        // [K][R][S][Hh]  relu output of the feature layer
+  const float* rayin;     // [K][R][Hh + 2] u = W_of^T g, beta = b_of . g, |g|
+  const float* gram;      // [K][Hh * Hh + Hh + 1]  G = W_of^T W_of, wb = W_of^T b_of, bb = b_of . b_of
+  float* d_hf;            // [K][R][S][Hh]  d loss / d (pre-activation of the feature layer)
+  float* rayfeat;         // [K][R][Hh + 3] fh, O, a, c  (-> head gradient GEMMs)
 };
 
 __global__ __launch_bounds__(256) void loss_kernel(const LossDev a) {
   extern __shared__ float sm[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int S = a.S;
-  float* wv = sm + (long)w * 3 * S;      // weights
+  float* wv = sm + (long)w * (3 * S + 2 * a.Hh);      // weights
   float* tv = wv + S;                    // transmittance
   float* dwv = tv + S;                   // feature contribution to dL/dw
+  float* sfh = dwv + S;                  // (hoisted mode) composited hidden feature, then d loss / d fh
+  float* sgf = sfh + a.Hh;               // (hoisted mode) G fh
   const long rr = (long)blockIdx.x * 4 + w;
   if (rr >= (long)a.K * a.R) return;
   const int k = (int)(rr / a.R);
@@ -259,6 +270,62 @@ __global__ __launch_bounds__(256) void loss_kernel(const LossDev a) {
         atomicAdd(&dwv[s], dF * a.pred_feat[idx]);
       }
     }
+  }
+  if (a.hf) {
+    const int Hh = a.Hh;
+    const float* hfr = a.hf + rr * S * (long)Hh;
+    const float* Gk = a.gram + (long)k * ((long)Hh * Hh + Hh + 1);
+    const float* wb = Gk + (long)Hh * Hh;
+    const float bb = wb[Hh];
+    const float* rin = a.rayin + rr * (long)(Hh + 2);
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    for (int h = lane; h < Hh; h += 64) {
+      float f = 0.f;
+      for (int s = 0; s < S; ++s) f = fmaf(wv[s], hfr[(long)s * Hh + h], f);
+      sfh[h] = f;
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    float fu = 0.f, fGf = 0.f, fwb = 0.f;
+    for (int h = lane; h < Hh; h += 64) {
+      float gf = 0.f;
+      for (int h2 = 0; h2 < Hh; ++h2) gf = fmaf(Gk[(long)h * Hh + h2], sfh[h2], gf);
+      sgf[h] = gf;
+      fu = fmaf(sfh[h], rin[h], fu);
+      fGf = fmaf(sfh[h], gf, fGf);
+      fwb = fmaf(sfh[h], wb[h], fwb);
+    }
+    fu = wave_sum64(fu); fGf = wave_sum64(fGf); fwb = wave_sum64(fwb);
+    const float beta = rin[Hh], ngv = rin[Hh + 1];
+    const float dotFg = fu + O * beta;
+    const float nF2 = fmaxf(fGf + 2.0f * O * fwb + O * O * bb, 0.0f);
+    const float nF = fmaxf(sqrtf(nF2), 1e-8f), ngc = fmaxf(ngv, 1e-8f);
+    const float cosv = dotFg / (nF * ngc);
+    lf = m1 * (1.0f - cosv) * inv1;
+    const float gam = -a.fs * m1 * inv1;                 // d total / d cos
+    const float ar = gam / (nF * ngc), cr = -gam * cosv / (nF * nF);
+    const float gof = ar * beta + cr * (fwb + O * bb);   // d total / d opacity (feature part)
+    float* rf = a.rayfeat + rr * (long)(Hh + 3);
+    for (int h = lane; h < Hh; h += 64) {
+      rf[h] = sfh[h];
+      sfh[h] = ar * rin[h] + cr * (sgf[h] + O * wb[h]);  // d total / d fh
+    }
+    if (lane == 0) { rf[Hh] = O; rf[Hh + 1] = ar; rf[Hh + 2] = cr; }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    for (int s = 0; s < S; ++s) {
+      float pp = 0.f;
+      for (int h = lane; h < Hh; h += 64) {
+        const float hv = hfr[(long)s * Hh + h];
+        pp = fmaf(sfh[h], hv, pp);
+        a.d_hf[(rr * S + s) * (long)Hh + h] = hv > 0.0f ? wv[s] * sfh[h] : 0.0f;
+      }
+      pp = wave_sum64(pp);
+      if (lane == 0) dwv[s] = gof + pp;
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
   }
   if (lane == 0) {
     atomicAdd(&a.loss_terms[k * 4 + 0], m1 * fabsf(rd) * info * inv1);
@@ -466,6 +533,46 @@ __global__ void sample_place_kernel(const objnerf_sample_args a, const float* or
 // must not be mistaken for a launch failure
 #define CLEAR_STALE() (void)hipGetLastError()
 
+namespace objmisc {
+int step_batch_loss_impl(const objnerf_loss_args* a, const LossHoisted* hz, void* stream) {
+  CLEAR_STALE();
+  if (!a || !a->alpha || !a->color || !a->z || !a->gt_depth || !a->gt_rgb || !a->labels || !a->loss_terms ||
+      !a->counts || a->K <= 0 || a->R <= 0 || a->S <= 0)
+    return OBJNERF_EINVAL;
+  if (!hz && (a->pred_feat == nullptr) != (a->gt_feat == nullptr)) return OBJNERF_EINVAL;
+  if (hz && (!a->gt_feat || a->pred_feat || !hz->hf || !hz->rayin || !hz->gram || !hz->d_hf || !hz->rayfeat || hz->Hh <= 0))
+    return OBJNERF_EINVAL;
+  if (a->S > 2048) return OBJNERF_ENOTSUP;
+  hipStream_t st = (hipStream_t)stream;
+  int* flags = a->counts + 2 * a->K;     // counts workspace is [K][2] + [2]
+  (void)hipMemsetAsync(flags, 0, 2 * sizeof(int), st);
+  if (a->counts_in) {
+    (void)hipMemcpyAsync(a->counts, a->counts_in, (size_t)2 * a->K * sizeof(int), hipMemcpyDeviceToDevice, st);
+    hipLaunchKernelGGL(flags_from_counts_kernel, dim3(1), dim3(64), 0, st, a->K, a->counts, flags);
+  } else {
+    hipLaunchKernelGGL(label_counts_kernel, dim3(a->K), dim3(256), 0, st, a->K, a->R, a->labels, a->counts, flags);
+  }
+  if (a->flags_in) hipLaunchKernelGGL(merge_flags_kernel, dim3(1), dim3(64), 0, st, flags, a->flags_in);
+  (void)hipMemsetAsync(a->loss_terms, 0, (size_t)a->K * 4 * sizeof(float), st);
+  LossDev d;
+  d.K = a->K; d.R = a->R; d.S = a->S; d.C = a->C;
+  d.cs = a->color_scaling; d.os = a->opacity_scaling; d.fs = a->feat_scaling;
+  d.alpha = a->alpha; d.color = a->color; d.z = a->z; d.gt_depth = a->gt_depth; d.gt_rgb = a->gt_rgb;
+  d.labels = a->labels; d.pred_feat = a->pred_feat; d.gt_feat = a->gt_feat; d.counts = a->counts; d.flags = flags;
+  d.loss_terms = a->loss_terms; d.d_alpha = a->d_alpha; d.d_color = a->d_color; d.d_pred_feat = a->d_pred_feat;
+  d.Hh = hz ? hz->Hh : 0;
+  d.hf = hz ? hz->hf : nullptr; d.rayin = hz ? hz->rayin : nullptr; d.gram = hz ? hz->gram : nullptr;
+  d.d_hf = hz ? hz->d_hf : nullptr; d.rayfeat = hz ? hz->rayfeat : nullptr;
+  const long nr = (long)a->K * a->R;
+  hipLaunchKernelGGL(loss_kernel, dim3((unsigned)((nr + 3) / 4)), dim3(256), (size_t)4 * (3 * a->S + 2 * d.Hh) * 4, st, d);
+  CHECK_LAUNCH();
+  hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(64), 0, st, a->K, a->loss_terms, a->color_scaling,
+                     a->opacity_scaling, (a->pred_feat || hz) ? a->feat_scaling : 0.0f, a->total, a->status);
+  CHECK_LAUNCH();
+  return OBJNERF_OK;
+}
+}  // namespace objmisc
+
 extern "C" {
 
 int objnerf_composite(int64_t n_rays, int32_t S, int32_t flags, const float* alpha, const float* color,
@@ -531,36 +638,7 @@ int objnerf_label_counts(int32_t K, int32_t R, const uint8_t* labels, int32_t* c
 }
 
 int objnerf_step_batch_loss(const objnerf_loss_args* a, void* stream) {
-  CLEAR_STALE();
-  if (!a || !a->alpha || !a->color || !a->z || !a->gt_depth || !a->gt_rgb || !a->labels || !a->loss_terms ||
-      !a->counts || a->K <= 0 || a->R <= 0 || a->S <= 0)
-    return OBJNERF_EINVAL;
-  if ((a->pred_feat == nullptr) != (a->gt_feat == nullptr)) return OBJNERF_EINVAL;
-  if (a->S > 2048) return OBJNERF_ENOTSUP;
-  hipStream_t st = (hipStream_t)stream;
-  int* flags = a->counts + 2 * a->K;     // counts workspace is [K][2] + [2]
-  (void)hipMemsetAsync(flags, 0, 2 * sizeof(int), st);
-  if (a->counts_in) {
-    (void)hipMemcpyAsync(a->counts, a->counts_in, (size_t)2 * a->K * sizeof(int), hipMemcpyDeviceToDevice, st);
-    hipLaunchKernelGGL(flags_from_counts_kernel, dim3(1), dim3(64), 0, st, a->K, a->counts, flags);
-  } else {
-    hipLaunchKernelGGL(label_counts_kernel, dim3(a->K), dim3(256), 0, st, a->K, a->R, a->labels, a->counts, flags);
-  }
-  if (a->flags_in) hipLaunchKernelGGL(merge_flags_kernel, dim3(1), dim3(64), 0, st, flags, a->flags_in);
-  (void)hipMemsetAsync(a->loss_terms, 0, (size_t)a->K * 4 * sizeof(float), st);
-  LossDev d;
-  d.K = a->K; d.R = a->R; d.S = a->S; d.C = a->C;
-  d.cs = a->color_scaling; d.os = a->opacity_scaling; d.fs = a->feat_scaling;
-  d.alpha = a->alpha; d.color = a->color; d.z = a->z; d.gt_depth = a->gt_depth; d.gt_rgb = a->gt_rgb;
-  d.labels = a->labels; d.pred_feat = a->pred_feat; d.gt_feat = a->gt_feat; d.counts = a->counts; d.flags = flags;
-  d.loss_terms = a->loss_terms; d.d_alpha = a->d_alpha; d.d_color = a->d_color; d.d_pred_feat = a->d_pred_feat;
-  const long nr = (long)a->K * a->R;
-  hipLaunchKernelGGL(loss_kernel, dim3((unsigned)((nr + 3) / 4)), dim3(256), (size_t)4 * 3 * a->S * 4, st, d);
-  CHECK_LAUNCH();
-  hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(64), 0, st, a->K, a->loss_terms, a->color_scaling,
-                     a->opacity_scaling, a->pred_feat ? a->feat_scaling : 0.0f, a->total, a->status);
-  CHECK_LAUNCH();
-  return OBJNERF_OK;
+  return objmisc::step_batch_loss_impl(a, nullptr, stream);
 }
 
 int objnerf_adamw_step(int32_t K, int64_t P, int64_t p_stride, float* params, const float* grads, float* exp_avg,
