@@ -17,6 +17,8 @@ size_t train_workspace_bytes(const objnerf_net* net, int K, int R, int S, int fe
 int train_step(const objnerf_net* net, const objnerf_train_args* a, void* stream);
 // the batched fp32 MFMA GEMM of this path, for the feature-head kernels of objnerf_train.hip:
 //   C[z][m][n] (+)= sum_k A(z; m,k) B(z; k,n), element strides (sam, sak), (sbk, sbn), (scm, scn), batch strides bs*
+void feat_gram(void* stream, int K, const float* params, long p_stride, int off_w, int off_b, int C, int Hh, float* gram,
+               long gstride);
 void gemm_f32(void* stream, int batch, int M, int N, int Kd, const float* A, long sam, long sak, long bsa, const float* B,
               long sbk, long sbn, long bsb, float* C, long scm, long scn, long bsc, bool accumulate);
 //   long contraction over n, few output tiles: split-K with float atomics into a PRE-ZEROED C (scn = 1)

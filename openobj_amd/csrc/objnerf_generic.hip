@@ -454,16 +454,15 @@ __global__ __launch_bounds__(256) void featg_rowstats_kernel(const float* params
   }
 }
 // wb = W_of^T b_of, bb = b_of . b_of appended to the Gram matrix: gram[k][Hh * Hh + h], [Hh * Hh + Hh]
-__global__ void featg_wb_kernel(const float* params, long p_stride, int off_w, int off_b, int C, int Hh, float* gram) {
-  const int k = blockIdx.x;
+__global__ __launch_bounds__(64) void featg_wb_kernel(const float* params, long p_stride, int off_w, int off_b, int C,
+                                                      int Hh, float* gram, long gstride) {
+  const int k = blockIdx.y, h = blockIdx.x;            // one wave per entry h (h == Hh: bb)
   const float* W = params + (long)k * p_stride + off_w;
   const float* B = params + (long)k * p_stride + off_b;
-  float* o = gram + (long)k * ((long)Hh * Hh + Hh + 1) + (long)Hh * Hh;
-  for (int h = threadIdx.x; h <= Hh; h += blockDim.x) {
-    float acc = 0.f;
-    for (int cc = 0; cc < C; ++cc) acc = fmaf(h < Hh ? W[(long)cc * Hh + h] : B[cc], B[cc], acc);
-    o[h] = acc;
-  }
+  float acc = 0.f;
+  for (int cc = threadIdx.x; cc < C; cc += 64) acc = fmaf(h < Hh ? W[(long)cc * Hh + h] : B[cc], B[cc], acc);
+  acc = wave_sum64(acc);
+  if (threadIdx.x == 0) gram[(long)k * gstride + (long)Hh * Hh + h] = acc;
 }
 // X1 = [a fh | a O], X2 = [c fh | c O] from rayfeat rows (fh[Hh], O, a, c)
 __global__ void featg_scale_kernel(long n, int Hh, const float* rayfeat, float* X1, float* X2) {
@@ -489,11 +488,25 @@ __global__ __launch_bounds__(256) void featg_finish_kernel(const float* params, 
   const float bc = params[(long)k * p_stride + off_b + cc];
   const float* M = mom + (long)k * XC * XC;
   float v = Tm[(long)k * C * XC + i];
+  // four partial sums: the loads of four steps are in flight together (Hh is a multiple of 32)
+  float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
   if (hh < Hh) {
-    for (int j = 0; j < Hh; ++j) v = fmaf(W[j], M[(long)j * XC + hh], v);
+    for (int j = 0; j < Hh; j += 4) {
+      v0 = fmaf(W[j], M[(long)j * XC + hh], v0);
+      v1 = fmaf(W[j + 1], M[(long)(j + 1) * XC + hh], v1);
+      v2 = fmaf(W[j + 2], M[(long)(j + 2) * XC + hh], v2);
+      v3 = fmaf(W[j + 3], M[(long)(j + 3) * XC + hh], v3);
+    }
+    v += (v0 + v1) + (v2 + v3);
     grads[(long)k * p_stride + off_w + (long)cc * Hh + hh] = fmaf(bc, M[(long)Hh * XC + hh], v);
   } else {
-    for (int j = 0; j < Hh; ++j) v = fmaf(W[j], M[(long)Hh * XC + j], v);
+    for (int j = 0; j < Hh; j += 4) {
+      v0 = fmaf(W[j], M[(long)Hh * XC + j], v0);
+      v1 = fmaf(W[j + 1], M[(long)Hh * XC + j + 1], v1);
+      v2 = fmaf(W[j + 2], M[(long)Hh * XC + j + 2], v2);
+      v3 = fmaf(W[j + 3], M[(long)Hh * XC + j + 3], v3);
+    }
+    v += (v0 + v1) + (v2 + v3);
     grads[(long)k * p_stride + off_b + cc] = fmaf(bc, M[(long)Hh * XC + Hh], v);
   }
 }
@@ -614,7 +627,7 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a, void* stream
     const long R = a->R;
     const long gst = (long)H * H + H + 1;
     gemm(st, K, H, H, C, P + off[16], 1, H, ps, P + off[16], H, 1, ps, w.gram, H, 1, gst);
-    hipLaunchKernelGGL(featg_wb_kernel, dim3(K), dim3(256), 0, st, P, ps, (int)off[16], (int)off[17], C, H, w.gram);
+    hipLaunchKernelGGL(featg_wb_kernel, dim3(H + 1, K), dim3(64), 0, st, P, ps, (int)off[16], (int)off[17], C, H, w.gram, gst);
     gemm(st, K, (int)R, H, C, a->gt_feat, C, 1, R * C, P + off[16], H, 1, ps, w.rayin, H + 2, 1, R * (H + 2));
     hipLaunchKernelGGL(featg_rowstats_kernel, dim3((unsigned)((R + 15) / 16), K), dim3(256), 0, st, P, ps, (int)off[17], C,
                        (int)R, H + 2, a->gt_feat, w.rayin);
@@ -775,6 +788,14 @@ int eval_points(const objnerf_net* net, int K, long N, const float* params, long
   return OBJNERF_OK;
 }
 
+// G = W_of^T W_of, wb = W_of^T b_of, bb = b_of . b_of of K objects: gram[k][Hh * Hh | Hh | 1], batch stride gstride
+void feat_gram(void* stream, int K, const float* params, long p_stride, int off_w, int off_b, int C, int Hh, float* gram,
+               long gstride) {
+  gemm((hipStream_t)stream, K, Hh, Hh, C, params + off_w, 1, Hh, p_stride, params + off_w, Hh, 1, p_stride, gram, Hh, 1,
+       gstride);
+  hipLaunchKernelGGL(featg_wb_kernel, dim3(Hh + 1, K), dim3(64), 0, (hipStream_t)stream, params, p_stride, off_w, off_b, C,
+                     Hh, gram, gstride);
+}
 void gemm_f32(void* stream, int batch, int M, int N, int Kd, const float* A, long sam, long sak, long bsa, const float* B,
               long sbk, long sbn, long bsb, float* C, long scm, long scn, long bsc, bool accumulate) {
   gemm((hipStream_t)stream, batch, M, N, Kd, A, sam, sak, bsa, B, sbk, sbn, bsb, C, scm, scn, bsc, accumulate);

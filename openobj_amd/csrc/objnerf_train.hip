@@ -746,24 +746,6 @@ __global__ __launch_bounds__(256) void eval_kernel(const EvalDev a) {
 
 // ------------------------------------------------------------------------------------------------
 // Feature head hoisting, per-step helper kernels (HBM-bound on gt_feat, read twice per step).
-// gram:  G = W_of^T W_of, wb = W_of^T b_of, bb = b_of . b_of                       per object
-__global__ __launch_bounds__(1024) void feat_gram_kernel(const float* params, long p_stride, int off_w, int off_b, int C,
-                                                         float* gram) {
-  const int k = blockIdx.x;
-  const float* W = params + (long)k * p_stride + off_w;
-  const float* B = params + (long)k * p_stride + off_b;
-  const int h = threadIdx.x >> 5, h2 = threadIdx.x & 31;
-  float acc = 0.f, accb = 0.f, accbb = 0.f;
-  for (int cc = 0; cc < C; ++cc) {
-    const float wv = W[cc * 32 + h], bv = B[cc];
-    acc = fmaf(wv, W[cc * 32 + h2], acc);
-    if (h2 == 0) accb = fmaf(wv, bv, accb);
-    if (threadIdx.x == 0) accbb = fmaf(bv, bv, accbb);
-  }
-  gram[(long)k * GRAM + h * 32 + h2] = acc;
-  if (h2 == 0) gram[(long)k * GRAM + 1024 + h] = accb;
-  if (threadIdx.x == 0) gram[(long)k * GRAM + 1056] = accbb;
-}
 // pre: u[r] = W_of^T g[r] is a batched GEMM (objgen::gemm_f32); this kernel adds beta[r] = b_of . g[r] and |g[r]|:
 // one 16-lane group per ray, float4 loads.
 __global__ __launch_bounds__(256) void feat_rowstats_kernel(const float* params, long p_stride, int off_b, int C, int R,
@@ -1004,8 +986,7 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
     attr_set = true;
   }
   if (feat) {
-    hipLaunchKernelGGL(feat_gram_kernel, dim3(a->K), dim3(1024), 0, st, a->params, (long)a->p_stride, d.L.of_w,
-                       d.L.of_b, C, gram);
+    objgen::feat_gram(stream, a->K, a->params, (long)a->p_stride, d.L.of_w, d.L.of_b, C, 32, gram, GRAM);
     // u = gt_feat W_of  ([R x C] [C x 32] per object) on the batched MFMA GEMM; beta, |g| beside it
     objgen::gemm_f32(stream, a->K, a->R, 32, C, a->gt_feat, C, 1, (long)a->R * C, a->params + d.L.of_w, 32, 1,
                      (long)a->p_stride, rayin, RAYIN, 1, (long)a->R * RAYIN, false);
