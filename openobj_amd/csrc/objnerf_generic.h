@@ -19,6 +19,8 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a, void* stream
 //   C[z][m][n] (+)= sum_k A(z; m,k) B(z; k,n), element strides (sam, sak), (sbk, sbn), (scm, scn), batch strides bs*
 void feat_gram(void* stream, int K, const float* params, long p_stride, int off_w, int off_b, int C, int Hh, float* gram,
                long gstride);
+void feature_head(void* stream, int K, long n, int Hh, int C, const float* params, long p_stride, long off_w, long off_b,
+                  const float* hfeat, const float* weight, float* out);
 void gemm_f32(void* stream, int batch, int M, int N, int Kd, const float* A, long sam, long sak, long bsa, const float* B,
               long sbk, long sbn, long bsb, float* C, long scm, long scn, long bsc, bool accumulate);
 //   long contraction over n, few output tiles: split-K with float atomics into a PRE-ZEROED C (scn = 1)

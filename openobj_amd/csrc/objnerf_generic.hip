@@ -25,6 +25,7 @@ struct Gemm {
   int accumulate, relu;
   int splitk;      // > 1: blockIdx.z = batch * splitk + slice; each slice atomically adds its partial into C
   float* rowsum; long bsrs;   // optional: rowsum[m] += sum_k A(m,k)  (bias gradient riding on the weight-gradient GEMM)
+  const float* biasrow; long bsbr;   // optional per-row factor of the bias: + bias[n] * biasrow[m]
 };
 
 #ifndef OBJ_GEMM_BK
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Gemm g) {
           float v = acc[i][j][r];
           if (sk > 1) { atomicAdd(cp, v); continue; }
           if (g.accumulate) v += *cp;
-          if (g.bias) v += g.bias[z * g.bsbias + n];
+          if (g.bias) v += g.bias[z * g.bsbias + n] * (g.biasrow ? g.biasrow[z * g.bsbr + m] : 1.0f);
           if (g.relu) v = fmaxf(v, 0.f);
           if (g.mask) v = g.mask[z * g.bsm + m * g.smm + n * g.smn] > 0.f ? v : 0.f;
           *cp = v;
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const Gemm g) {
           float v = acc[i][j][r];
           if (sk > 1) { atomicAdd(cp, v); continue; }
           if (g.accumulate) v += *cp;
-          if (g.bias) v += g.bias[z * g.bsbias + n];
+          if (g.bias) v += g.bias[z * g.bsbias + n] * (g.biasrow ? g.biasrow[z * g.bsbr + m] : 1.0f);
           if (g.relu) v = fmaxf(v, 0.f);
           if (g.mask) v = g.mask[z * g.bsm + m * g.smm + n * g.smn] > 0.f ? v : 0.f;
           *cp = v;
@@ -250,6 +251,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const Gemm g) {
 
 // selected for the duration of one train_step call (single host thread per device)
 static thread_local bool t_bf16_operands = false;
+// per-row bias factor of the NEXT gemm() call (feature_head), reset by the caller
+static thread_local const float* t_biasrow = nullptr;
+static thread_local long t_bsbr = 0;
 
 static void gemm(hipStream_t st, int batch, int M, int N, int Kd, const float* A, long sam, long sak, long bsa,
                  const float* B, long sbk, long sbn, long bsb, float* C, long scm, long scn, long bsc,
@@ -264,6 +268,7 @@ static void gemm(hipStream_t st, int batch, int M, int N, int Kd, const float* A
   g.bias = bias; g.bsbias = bsbias; g.mask = mask; g.smm = smm; g.smn = smn; g.bsm = bsm;
   g.accumulate = accumulate; g.relu = relu; g.splitk = splitk;
   g.rowsum = rowsum; g.bsrs = bsrs;
+  g.biasrow = t_biasrow; g.bsbr = t_bsbr;
   const int nz = batch * (splitk > 1 ? splitk : 1);
   if (t_bf16_operands) {
     if (M >= 256 && N >= 192) {
@@ -795,6 +800,14 @@ void feat_gram(void* stream, int K, const float* params, long p_stride, int off_
        gstride);
   hipLaunchKernelGGL(featg_wb_kernel, dim3(Hh + 1, K), dim3(64), 0, (hipStream_t)stream, params, p_stride, off_w, off_b, C,
                      Hh, gram, gstride);
+}
+// out[k][m][:] = W_of[k] hfeat[k][m] + b_of[k] * weight[k][m]   (model.py:101 applied after compositing; weight NULL = 1)
+void feature_head(void* stream, int K, long n, int Hh, int C, const float* params, long p_stride, long off_w, long off_b,
+                  const float* hfeat, const float* weight, float* out) {
+  t_biasrow = weight; t_bsbr = n;
+  gemm((hipStream_t)stream, K, (int)n, C, Hh, hfeat, Hh, 1, n * Hh, params + off_w, 1, Hh, p_stride, out, C, 1, n * C, false,
+       params + off_b, p_stride, false);
+  t_biasrow = nullptr; t_bsbr = 0;
 }
 void gemm_f32(void* stream, int batch, int M, int N, int Kd, const float* A, long sam, long sak, long bsa, const float* B,
               long sbk, long sbn, long bsb, float* C, long scm, long scn, long bsc, bool accumulate) {

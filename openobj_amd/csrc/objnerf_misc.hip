@@ -72,35 +72,7 @@ __global__ __launch_bounds__(256) void composite_kernel(long n_rays, int S, int 
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// out[k][n][c] = sum_h of_w[k][c][h] * hfeat[k][n][h] + of_b[k][c] * weight[k][n]
-// (model.py:101 applied after compositing).  One workgroup: 64 points x all C of one object.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void feature_head_kernel(int K, long n, int Hh, int C, const float* params,
-                                                           long p_stride, long off_w, long off_b, const float* hfeat,
-                                                           const float* weight, float* out) {
-  extern __shared__ float sm[];          // hfeat tile [64][Hh+1]
-  const int k = blockIdx.y;
-  const long n0 = (long)blockIdx.x * 64;
-  const float* W = params + (long)k * p_stride + off_w;
-  const float* B = params + (long)k * p_stride + off_b;
-  for (int i = threadIdx.x; i < 64 * Hh; i += 256) {
-    const int p = i / Hh, h = i % Hh;
-    sm[p * (Hh + 1) + h] = (n0 + p < n) ? hfeat[((long)k * n + n0 + p) * Hh + h] : 0.f;
-  }
-  __syncthreads();
-  for (int cc = threadIdx.x; cc < C; cc += 256) {
-    float wrow[128];
-    for (int h = 0; h < Hh; ++h) wrow[h] = W[(long)cc * Hh + h];
-    const float b = B[cc];
-    for (int p = 0; p < 64 && n0 + p < n; ++p) {
-      float acc = 0.f;
-      for (int h = 0; h < Hh; ++h) acc = fmaf(wrow[h], sm[p * (Hh + 1) + h], acc);
-      const float wgt = weight ? weight[(long)k * n + n0 + p] : 1.0f;
-      out[((long)k * n + n0 + p) * C + cc] = acc + b * wgt;
-    }
-  }
-}
+// (the 512-d head applied after compositing, objnerf_feature_head, is a batched GEMM: objgen::feature_head)
 
 // ------------------------------------------------------------------------------------------------
 // embedding.py:46-55, one thread per output entry (coalesced stores; the row pitch is 129 floats).
@@ -602,13 +574,12 @@ int objnerf_feature_head(const objnerf_net* net, int32_t K, int64_t n, const flo
                          const float* hfeat, const float* weight, float* out, void* stream) {
   CLEAR_STALE();
   if (!net || !params || !hfeat || !out || K <= 0 || n <= 0) return OBJNERF_EINVAL;
-  if (net->hidden > 128) return OBJNERF_ENOTSUP;
+  if (net->hidden % 32 != 0) return OBJNERF_ENOTSUP;
   int64_t offs[OBJNERF_N_TENSORS + 1];
   if (objnerf_param_layout(net, offs) < 0) return OBJNERF_EINVAL;
-  dim3 grid((unsigned)((n + 63) / 64), (unsigned)K);
-  hipLaunchKernelGGL(feature_head_kernel, grid, dim3(256), (size_t)64 * (net->hidden + 1) * 4, (hipStream_t)stream, K,
-                     (long)n, net->hidden, net->feat_dim, params, (long)p_stride, (long)offs[OBJNERF_T_OF_W],
-                     (long)offs[OBJNERF_T_OF_B], hfeat, weight, out);
+  // a batched GEMM [n x H] [H x C] with the bias scaled per row (objnerf_generic.hip)
+  objgen::feature_head(stream, K, (long)n, net->hidden, net->feat_dim, params, (long)p_stride, (long)offs[OBJNERF_T_OF_W],
+                       (long)offs[OBJNERF_T_OF_B], hfeat, weight, out);
   CHECK_LAUNCH();
   return OBJNERF_OK;
 }

@@ -244,8 +244,11 @@ class sceneObject:
             render_color = (out["rgb"] * 255).to(torch.uint8)                       # :671 (truncation)
             feat = None
             if render_part:
-                feat = ops.feature_head(tr.arena, out["vals"].reshape(1, n_pts, -1), opacity.reshape(1, n_pts))[0]
-                feat = feat[keep].cpu().numpy()
+                # the 512-d head only for the rays that survive the masks (it is linear: F = W_of fh + b_of O)
+                fh_k, op_k = out["vals"][keep].contiguous(), opacity[keep].contiguous()
+                nk = fh_k.shape[0]
+                feat = (ops.feature_head(tr.arena, fh_k.reshape(1, nk, -1), op_k.reshape(1, nk))[0].cpu().numpy()
+                        if nk > 0 else np.zeros((0, tr.clip_point_feature_size), np.float32))
             sel = torch.zeros(idx[0].shape[0], dtype=torch.bool, device=dev)
             hit_idx = obj_hit.nonzero(as_tuple=True)[0]
             sel[hit_idx[keep]] = True                                               # :627-629 and :681-683
