@@ -120,15 +120,6 @@ __device__ __forceinline__ float sigmoid_acc(float x) {
 // ----------------------------------------------------------------------------------------------
 __device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 32, 64); }
 
-__device__ __forceinline__ float wave_sum32(float v) {   // sum over the 32 lanes of each half
-  v += __shfl_xor(v, 1, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 4, 64);
-  v += __shfl_xor(v, 8, 64);
-  v += __shfl_xor(v, 16, 64);
-  return v;
-}
-__device__ __forceinline__ float wave_sum64(float v) { return xhalf_sum(wave_sum32(v)); }
 
 // Sum over the 16 lanes of each DPP row (= one lane group g) on the VALU, no LDS traffic; every lane of
 // the row ends with the row total.
@@ -139,6 +130,19 @@ __device__ __forceinline__ float dpp_rowsum16(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));  // row_mirror
   return v;
 }
+// sum over the 32 lanes of each half (rows 0,1 / rows 2,3), on every lane: DPP row sums, then one
+// v_permlane16_swap pairs the rows -- no LDS permutes
+__device__ __forceinline__ float wave_sum32(float v) {
+  const unsigned u = __float_as_uint(dpp_rowsum16(v));
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);      // (r0,r0,r2,r2), (r1,r1,r3,r3)
+  return __uint_as_float(a[0]) + __uint_as_float(a[1]);
+}
+__device__ __forceinline__ float wave_sum64(float v) {
+  const unsigned u = __float_as_uint(wave_sum32(v));
+  const auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 // acc (one register) keeps 16 running row sums per lane group: slot i lives in lane i of the row.
 __device__ __forceinline__ void slot_accum16(float& acc, const float v, const int slot, const int c) {
   const float s = dpp_rowsum16(v);
