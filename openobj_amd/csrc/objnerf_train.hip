@@ -271,7 +271,15 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
     };
     float pf_uh = 0.f, pf_beta = 0.f, pf_ngv = 1.f;
     int pf_lab2 = 2;
-    if (FEAT && w * (64 / S) < TR) feat_inputs(w, 0, pf_uh, pf_beta, pf_ngv, pf_lab2);
+    if (FEAT && S == 64) {
+      if (valid) {        // every wave takes part in its ray's feature term (below)
+        const long rr2_ = (long)k * R + ray;
+        pf_uh = a.rayin[rr2_ * RAYIN + (lane_l & 31)];
+        pf_beta = a.rayin[rr2_ * RAYIN + 32];
+        pf_ngv = a.rayin[rr2_ * RAYIN + 33];
+        pf_lab2 = (int)a.labels[rr2_];
+      }
+    } else if (FEAT && w * (64 / S) < TR) feat_inputs(w, 0, pf_uh, pf_beta, pf_ngv, pf_lab2);
     TILE_SYNC();
     RELAUNDER();
     PT(3);
@@ -419,7 +427,134 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
         }
       }
     };
-    if (rows_mode) composite_passes(seg_rows); else composite_passes(SegGeneric{S});
+    if (FEAT && S == 64) {
+      // 64 samples per ray (the north-star shape): the feature term's reductions over samples and hidden features
+      // are spread over all 8 waves instead of running on the two compositing waves (3 extra barriers, a much
+      // shorter critical path).  Wave w holds samples 16w..16w+15 of ray w >> 2.  Same arithmetic as the
+      // general path above.
+      const SegRows& sg = seg_rows;
+      float* s_w = stg + OFF_SW;
+      float* s_gfh = stg + OFF_GFH;
+      float* s_gof = stg + OFF_GOF;
+      float* s_part = s_gfh + 192;          // [NWAVE][32] partial composited features (s_gfh holds 2 rays here)
+      float* s_dwf = s_gfh + 64;            // [128]
+      const int pos = lane_l;
+      const int sl = w * 64 + pos;
+      const bool on = (w < TR) && (ray0 + w < R);
+      float occ = 0.f, fr = 1.f, T = 1.f, wgt = 0.f, dw = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, gC0 = 0.f, gC1 = 0.f, gC2 = 0.f;
+      if (w < TR) {
+        const float zz = pf_zz;
+        float al = 0.f;
+        if (on) { al = s_alpha[sl]; c0 = s_col[sl]; c1 = s_col[TS + sl]; c2 = s_col[2 * TS + sl]; }
+        occ = on ? sigmoid_acc(al) : 0.0f;
+        fr = on ? (1.0f - occ) + 1e-10f : 1.0f;
+        const float Pinc = sg.scan_mul(fr, pos);
+        T = __shfl_up(Pinc, 1, 64);
+        if (pos == 0) T = 1.0f;
+        wgt = occ * T;
+        const float D = sg.total_add(wgt * zz, pos);
+        const float O = sg.total_add(wgt, pos);
+        const float C0 = sg.total_add(wgt * c0, pos);
+        const float C1 = sg.total_add(wgt * c1, pos);
+        const float C2 = sg.total_add(wgt * c2, pos);
+        const float dz = zz - D;
+        const float V = sg.total_add(wgt * (dz * dz), pos);
+        const float m1 = (pf_lab == 1) ? 1.0f : 0.0f;
+        const float m2 = (pf_lab != 2) ? 1.0f : 0.0f;
+        const float tgt = (pf_lab != 0) ? 1.0f : 0.0f;
+        const float info = 1.0f / (sqrtf(V) + 1e-4f);
+        const float rd = D - pf_gtd, r0 = C0 - pf_gr, r1 = C1 - pf_gg, r2 = C2 - pf_gb, ro = O - tgt;
+        auto sgn = [](float x) { return x > 0.f ? 1.0f : (x < 0.f ? -1.0f : 0.0f); };
+        const float gD = m1 * sgn(rd) * info * inv1;
+        gC0 = a.color_scaling * m1 * sgn(r0) * inv1;
+        gC1 = a.color_scaling * m1 * sgn(r1) * inv1;
+        gC2 = a.color_scaling * m1 * sgn(r2) * inv1;
+        const float gO = a.opacity_scaling * m2 * sgn(ro) * inv2;
+        if (on && pos == 0) {
+          l_d += m1 * fabsf(rd) * info * inv1;
+          l_c += m1 * (fabsf(r0) + fabsf(r1) + fabsf(r2)) * inv1;
+          l_o += m2 * fabsf(ro) * inv2;
+          s_gof[16 + w] = O;
+        }
+        dw = gD * zz + gO + gC0 * c0 + gC1 * c1 + gC2 * c2;
+        if (on) s_w[sl] = wgt;
+      }
+      __syncthreads();
+      {
+        const float wv = valid ? s_w[slot] : 0.0f;
+        float v8[8];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v8[4 * tt + r] = wv * stg[slot * HF_LD + 16 * tt + 4 * g + r];
+        const float psum = slot_sums8(v8, c);
+        if (c < 8) s_part[w * 32 + 16 * ((c & 7) >> 2) + 4 * g + (c & 3)] = psum;
+      }
+      __syncthreads();
+      {
+        float* s_fhb = stg + OFF_FHB + 64 * w;
+        const float* Gb = stg + OFF_GBUF;
+        const int half = lane_l >> 5, hh = lane_l & 31;
+        const int w0 = w & ~3;
+        const float fh = valid ? (s_part[w0 * 32 + hh] + s_part[(w0 + 1) * 32 + hh]) +
+                                 (s_part[(w0 + 2) * 32 + hh] + s_part[(w0 + 3) * 32 + hh]) : 0.0f;
+        if (half == 0) s_fhb[hh] = fh;
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+        float Gp = 0.f;
+#pragma unroll
+        for (int h2 = 0; h2 < 16; ++h2) Gp = fmaf(Gb[hh * 33 + 16 * half + h2], s_fhb[16 * half + h2], Gp);
+        const float Gfh = Gp + __shfl_xor(Gp, 32, 64);
+        const float wbh = Gb[32 * 33 + hh], bb = Gb[32 * 33 + 32];
+        const float uh = pf_uh, beta = pf_beta, ngv = pf_ngv;
+        const float O2 = valid ? s_gof[16 + q] : 0.f;
+        const float fu = wave_sum32(fh * uh), fGf = wave_sum32(fh * Gfh), fwb = wave_sum32(fh * wbh);
+        const float dotFg = fu + O2 * beta;
+        const float nF2 = fmaxf(fGf + 2.0f * O2 * fwb + O2 * O2 * bb, 0.0f);
+        const float nF = fmaxf(sqrtf(nF2), 1e-8f), ngc = fmaxf(ngv, 1e-8f);
+        const float cosv = dotFg / (nF * ngc);
+        const float mm1 = (pf_lab2 == 1) ? 1.0f : 0.0f;
+        const float gam = -a.feat_scaling * mm1 * inv1;
+        const float ar = gam / (nF * ngc), cr = -gam * cosv / (nF * nF);
+        const float gfh = ar * uh + cr * (Gfh + O2 * wbh);
+        const float gof = ar * beta + cr * (fwb + O2 * bb);
+        if (valid && (w & 3) == 0 && half == 0) {
+          const long rr2 = (long)k * R + ray;
+          if (hh == 0) {
+            l_f += mm1 * (1.0f - cosv) * inv1;
+            a.rayfeat[rr2 * RAYFEAT + 32] = O2;
+            a.rayfeat[rr2 * RAYFEAT + 33] = ar;
+            a.rayfeat[rr2 * RAYFEAT + 34] = cr;
+          }
+          s_gfh[q * 32 + hh] = gfh;
+          a.rayfeat[rr2 * RAYFEAT + hh] = fh;
+        }
+        if (half == 0) s_fhb[32 + hh] = gfh;
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+        float dp = 0.f;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            dp = fmaf(s_fhb[32 + 16 * tt + 4 * g + r], stg[slot * HF_LD + 16 * tt + 4 * g + r], dp);
+        const float dwf = xgroup_sum(dp) + gof;
+        if (g == 0 && valid) s_dwf[slot] = dwf;
+      }
+      __syncthreads();
+      if (w < TR) {
+        if (on) dw += s_dwf[sl];
+        const float qv = dw * wgt;
+        const float suf = sg.rscan_add(qv, pos) - qv;
+        const float docc = dw * T - suf / fr;
+        if (on) {
+          s_alpha[sl] = 10.0f * (docc * occ * (1.0f - occ));
+          s_col[sl] = gC0 * wgt * c0 * (1.0f - c0);
+          s_col[TS + sl] = gC1 * wgt * c1 * (1.0f - c1);
+          s_col[2 * TS + sl] = gC2 * wgt * c2 * (1.0f - c2);
+        }
+      }
+    } else if (rows_mode) composite_passes(seg_rows); else composite_passes(SegGeneric{S});
     PT(4);
     TILE_SYNC();
     RELAUNDER();
