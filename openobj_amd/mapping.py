@@ -1,0 +1,249 @@
+"""The incremental mapping loop of the reference's train.py:155-541 around the HIP training iteration
+(frame ingestion either side of the hot path), for offline datasets
+(`cfg.live_mode` False) and `training_strategy == "hip"`:
+
+    for every frame:   ingest (state maps, new sceneObjects / new keyframes)          train.py:172-256
+                       restack the object networks when an object appeared            train.py:272-276
+                       draw the frame's sample pools (objects + background)           train.py:297-392
+                       n_iter_per_frame fused iterations + background steps           train.py:394-474
+                       copy the stacked parameters back                               train.py:478-485
+    every n_vis_iter frames (optional): semantic labels from the accumulated CLIP / caption features
+    and the checkpoint files                                                          train.py:489-541
+
+Everything numerical runs in libobjnerf_hip.so (sampler, fused iteration, AdamW); this file is bookkeeping.
+The class-name text features (CLIP ViT-B/32 and SBERT encoders in the reference, train.py:108-147) are inputs
+here: pass `class_clipfeat` / `class_capfeat` arrays to `assign_semantics`.  Visualisation, meshing and the live
+ROS mode are outside the path.
+"""
+import os
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import train as otrain
+from .vmap import cameraInfo, sceneObject
+
+
+def get_majority_cluster_mean(vectors, eps, min_samples):
+    """utils.py:138-155: DBSCAN the per-frame features, mean of the most populated cluster."""
+    from sklearn.cluster import DBSCAN
+    labels = DBSCAN(eps=eps, min_samples=min_samples).fit_predict(vectors)
+    uniq, counts = np.unique(labels, return_counts=True)
+    return np.mean(vectors[labels == uniq[np.argmax(counts)]], axis=0)
+
+
+def _to_dev(x, dev, dtype=None):
+    t = x if torch.is_tensor(x) else torch.as_tensor(np.asarray(x))
+    return t.to(device=dev, dtype=dtype) if dtype is not None else t.to(dev)
+
+
+class IncrementalMapper:
+    def __init__(self, cfg, bf16: bool = False):
+        self.cfg = cfg
+        self.bf16 = bf16
+        self.cam_info = cameraInfo(cfg)
+        self.obj_dict: Dict[int, sceneObject] = {}      # foreground objects (the stacked networks), creation order
+        self.vis_dict: Dict[int, sceneObject] = {}      # + the background object
+        self.scene_bg: Optional[sceneObject] = None
+        self.global_partfeat: Optional[torch.Tensor] = None
+        self.loop: Optional[otrain.HipTrainLoop] = None
+        self.bg_loop: Optional[otrain.BackgroundLoop] = None
+        self._restack = False
+        self.last_twc = None
+        self.last_frame_id = None
+
+    # ------------------------------------------------------------------ train.py:172-256
+    def ingest(self, sample, frame_id: int) -> List[int]:
+        """Append one dataset sample to the map.  Returns the ids of the objects created by this frame."""
+        cfg = self.cfg
+        dev = cfg.data_device
+        rgb = _to_dev(sample["image"], dev, torch.uint8)
+        depth = _to_dev(sample["depth"], dev, torch.float32)
+        twc = _to_dev(sample["T"], dev, torch.float32)
+        bbox_dict, obj_clip, obj_cap = sample["bbox_dict"], sample["obj_clip"], sample["obj_cap"]
+        live_frame_id = int(sample["frame_id"]) if "frame_id" in sample else frame_id
+        if cfg.part_mode:
+            part = _to_dev(sample["part_feat"], dev, torch.float32)
+            self.global_partfeat = part.unsqueeze(0) if self.global_partfeat is None else \
+                torch.cat((self.global_partfeat, part.unsqueeze(0)), dim=0)
+        inst = _to_dev(sample["obj"], dev)
+        unknown = inst == -1
+        created = []
+        for obj_id in torch.unique(inst).tolist():
+            if obj_id == -1:
+                continue
+            obj_id = int(obj_id)
+            if obj_id not in bbox_dict:
+                continue        # (a label without a box cannot be sampled; the reference would raise KeyError)
+            state = torch.zeros_like(inst, dtype=torch.uint8)            # 0 other, 1 this object, 2 unknown
+            state[inst == obj_id] = 1
+            state[unknown] = 2
+            bbox = _to_dev(bbox_dict[obj_id], dev, torch.float32)
+            clip_feat, cap_feat = _first(obj_clip[obj_id]), obj_cap[obj_id]
+            if obj_id in self.vis_dict:
+                self.vis_dict[obj_id].append_keyframe(rgb, depth, state, bbox, twc, live_frame_id,
+                                                      clip_feat=clip_feat, caption_feat=cap_feat)
+                continue
+            if len(self.obj_dict) >= cfg.max_n_models:
+                continue                                                  # "models full" (train.py:232-234)
+            so = sceneObject(cfg, obj_id, rgb, depth, state, bbox, twc, live_frame_id, clip_feat=clip_feat,
+                             caption_feat=cap_feat)
+            if cfg.do_bg and obj_id == 0:
+                self.scene_bg = so
+                self.bg_loop = otrain.BackgroundLoop(cfg, so.trainer, with_feat=bool(cfg.part_mode), bf16=self.bf16)
+            else:
+                self.obj_dict[obj_id] = so
+                self._restack = True
+            self.vis_dict[obj_id] = so
+            created.append(obj_id)
+        self.last_twc, self.last_frame_id = twc, live_frame_id
+        return created
+
+    # ------------------------------------------------------------------ train.py:272-276
+    def _ensure_stack(self):
+        if self._restack or self.loop is None:
+            if self.loop is not None:
+                self.loop.copy_back()
+            self.loop = otrain.HipTrainLoop(self.cfg, [o.trainer for o in self.obj_dict.values()],
+                                            with_feat=bool(self.cfg.part_mode), bf16=self.bf16)
+            self._restack = False
+
+    # ------------------------------------------------------------------ train.py:297-392
+    def _pool_of(self, so: sceneObject, n_frames: int, n_samples: int):
+        rgb, depth, _valid, labels, pts, z, feat = so.get_training_samples(n_frames, n_samples,
+                                                                           self.cam_info.rays_dir_cache,
+                                                                           self.global_partfeat)
+        n = n_frames * n_samples
+        tdev = self.cfg.training_device
+        pool = {"pts": pts.reshape(n, pts.shape[-2], 3).to(tdev),
+                "z": z.reshape(n, z.shape[-1]).to(tdev),
+                "gt_depth": depth.reshape(n).to(tdev),
+                "gt_rgb": rgb.reshape(n, 3).to(tdev).float() / 255.0,
+                "labels": labels.reshape(n).to(tdev)}
+        if self.cfg.part_mode:
+            pool["gt_feat"] = feat.reshape(n, feat.shape[-1]).to(tdev).float()
+        return pool
+
+    def sample_pools(self):
+        """-> (stacked object pool [K, n_iter*n_per_optim, ...], background pool [1, n_iter*n_per_optim_bg, ...] | None)"""
+        cfg = self.cfg
+        bg_pool = None
+        if cfg.do_bg and self.scene_bg is not None:
+            bp = self._pool_of(self.scene_bg, cfg.n_iter_per_frame * cfg.win_size_bg, cfg.n_samples_per_frame_bg)
+            bg_pool = {k: v[None] for k, v in bp.items()}
+        pools = [self._pool_of(o, cfg.n_iter_per_frame * cfg.win_size, cfg.n_samples_per_frame)
+                 for o in self.obj_dict.values()]
+        assert len(pools) > 0, "no foreground object in the map yet"      # train.py:366
+        return {k: torch.stack([p[k] for p in pools]) for k in pools[0]}, bg_pool
+
+    # ------------------------------------------------------------------ train.py:394-485
+    def train_frame(self):
+        """One frame's optimisation.  Returns {"obj": [n_iter x [K,4] loss terms], "bg": [n_iter x [1,4]]}."""
+        cfg = self.cfg
+        self._ensure_stack()
+        pool, bg_pool = self.sample_pools()
+        out = {"obj": [], "bg": []}
+        npo, npo_bg = cfg.n_per_optim, cfg.n_per_optim_bg
+        for it in range(cfg.n_iter_per_frame):
+            sl = slice(it * npo, (it + 1) * npo)
+            out["obj"].append(self.loop.step({k: v[:, sl].contiguous() for k, v in pool.items()}).clone())
+            if bg_pool is not None:
+                bs = slice(it * npo_bg, (it + 1) * npo_bg)
+                out["bg"].append(self.bg_loop.step({k: v[:, bs].contiguous() for k, v in bg_pool.items()}).clone())
+        if int(self.loop.ws.status.item()) != 0:
+            from .render_rays import LossExplode
+            raise LossExplode("loss explode")
+        self.loop.copy_back()
+        return out
+
+    def step_frame(self, sample, frame_id: int):
+        self.ingest(sample, frame_id)
+        if not self.obj_dict:
+            return None
+        return self.train_frame()
+
+    def run(self, dataloader, n_frames: Optional[int] = None, on_frame=None):
+        """train.py:155-485 over a dataset.init_loader(cfg) stream."""
+        for frame_id, sample in enumerate(dataloader):
+            if n_frames is not None and frame_id >= n_frames:
+                break
+            losses = self.step_frame(sample, frame_id)
+            if on_frame is not None:
+                on_frame(frame_id, losses)
+
+    # ------------------------------------------------------------------ train.py:489-541
+    def assign_semantics(self, class_names: List[str], class_clipfeat: np.ndarray, class_capfeat: np.ndarray,
+                         eps: float = 0.2, min_samples: int = 2) -> Dict[int, int]:
+        """Object id -> class index: wall / floor / ceiling are fixed for ids 0 / 2 / 3, every other object takes the
+        class whose text feature is closest to its majority-cluster caption feature (if that similarity > 0.5) or
+        CLIP feature (train.py:497-524)."""
+        mapping = {0: class_names.index("wall"), 2: class_names.index("floor"), 3: class_names.index("ceiling")}
+        for obj_id, so in self.vis_dict.items():
+            if obj_id not in (0, 2, 3):
+                clip_f, cap_f = so.clip_feat, so.caption_feat
+                if np.ndim(clip_f) == 2:
+                    clip_f = get_majority_cluster_mean(clip_f, eps, min_samples)
+                    cap_f = get_majority_cluster_mean(cap_f, eps, min_samples)
+                sim_clip, sim_cap = class_clipfeat @ clip_f, class_capfeat @ cap_f
+                i_clip, i_cap = int(np.argmax(sim_clip)), int(np.argmax(sim_cap))
+                mapping[obj_id] = i_cap if sim_cap[i_cap] > 0.5 else i_clip
+            so.set_semantic(mapping[obj_id])
+        return mapping
+
+    def save_checkpoints(self, log_dir: str, need_bound: bool = False):
+        """ckpt/<obj_id>/obj_<id>.pth for every object + cam_pose/twc_frame.pth (train.py:527-541).  The reference
+        refreshes each object's 3-D box first (open3d point-cloud fitting, outside this build): with need_bound the
+        caller must have set sceneObject.bbox3dour."""
+        for obj_id, so in self.vis_dict.items():
+            d = os.path.join(log_dir, "ckpt", str(obj_id))
+            os.makedirs(d, exist_ok=True)
+            if need_bound:
+                so.get_bound(None)
+            so.save_checkpoints(d, self.last_frame_id)
+        cam_dir = os.path.join(log_dir, "cam_pose")
+        os.makedirs(cam_dir, exist_ok=True)
+        torch.save({"twc": self.last_twc}, os.path.join(cam_dir, "twc_frame.pth"))
+
+
+def _first(x):
+    """obj_clip[obj_id][0] of train.py:219,226 (the stored CLIP entry is a [1, C] array)."""
+    a = np.asarray(x)
+    return a[0] if a.ndim >= 2 else a
+
+
+def main(argv=None):
+    """The reference's `python train.py --config <json> --logdir <dir>` (train.py:33-46) for the offline formats:
+    map the whole dataset, write the checkpoints every cfg.n_vis_iter frames and at the end."""
+    import argparse
+    import shutil
+    from . import cfg as ocfg
+    from . import dataset
+    ap = argparse.ArgumentParser(description="Incremental object-NeRF mapping on MI355X (offline dataset).")
+    ap.add_argument("--logdir", default="./logs/debug", type=str)
+    ap.add_argument("--config", default="./configs/Replica/config_replica_room0_vMAP.json", type=str)
+    ap.add_argument("--frames", default=None, type=int, help="stop after this many frames")
+    ap.add_argument("--bf16", action="store_true", help="bf16 MFMA operands (fp32 accumulation and weights)")
+    ap.add_argument("--single-worker", action="store_true", help="read frames in this process (no loader workers)")
+    args = ap.parse_args(argv)
+    os.makedirs(args.logdir, exist_ok=True)
+    shutil.copy(args.config, args.logdir)
+    cfg = ocfg.Config(args.config)
+    mapper = IncrementalMapper(cfg, bf16=args.bf16)
+    loader = dataset.init_loader(cfg, multi_worker=not args.single_worker)
+    n_total = len(loader) if args.frames is None else min(len(loader), args.frames)
+
+    def on_frame(frame_id, losses):
+        if losses is not None:
+            t = losses["obj"][-1]
+            print("frame %d: %d objects, last-iteration loss terms (depth, colour, opacity, feature) = %s"
+                  % (frame_id, t.shape[0], [round(float(x), 5) for x in t.sum(0).tolist()]), flush=True)
+        if cfg.if_ckpt and frame_id > 0 and (frame_id % cfg.n_vis_iter == 0 or frame_id == n_total - 1):
+            mapper.save_checkpoints(args.logdir)
+
+    mapper.run(loader, n_frames=args.frames, on_frame=on_frame)
+    return mapper
+
+
+if __name__ == "__main__":
+    main()

@@ -187,6 +187,9 @@ class sceneObject:
                                        torch.floor(idx_h / self.part_down).long()]
         return rgb, depth, valid, labels, pts, z, partfeat
 
+    def set_semantic(self, semantic_id):                                  # vmap.py:284-285
+        self.semantic_id = semantic_id
+
     # ------------------------------------------------------------------ checkpoints (vmap.py:556-602)
     def get_bound(self, intrinsic_open3d=None, final=True):
         """The object's oriented 3-D box (vmap.py:259-384 builds it from the keyframe point cloud with open3d,

@@ -1,0 +1,75 @@
+"""Test helper: write a tiny scene in the reference's on-disk Replica / ScanNet layouts (dataset.py:43-442):
+a textured wall (instance id 1 = background) at 3 m with two boxes in front of it, seen from a camera that pans."""
+import os
+import pickle
+
+import numpy as np
+from PIL import Image
+
+W, H = 64, 48
+FX = FY = 60.0
+CX, CY = 31.5, 23.5
+
+
+def _frame(i, rs):
+    """-> rgb u8 [H,W,3], depth_mm u16 [H,W], inst u16 [H,W] for camera x-offset 0.02*i m (pure translation)."""
+    rgb = np.zeros((H, W, 3), np.uint8)
+    depth = np.full((H, W), 3000, np.uint16)
+    inst = np.ones((H, W), np.uint16)                      # 1 = wall (background class)
+    yy, xx = np.mgrid[0:H, 0:W]
+    rgb[..., 0] = 90 + 40 * ((xx // 8 + yy // 8) % 2)
+    rgb[..., 1] = 80
+    rgb[..., 2] = 70
+    sh = i                                                  # boxes drift by one pixel per frame
+    a = (slice(10, 34), slice(8 + sh, 28 + sh))             # object 4: 24 x 20 px at 1.5 m
+    rgb[a] = (200, 40, 40)
+    depth[a] = 1500
+    inst[a] = 4
+    b = (slice(14, 40), slice(36 + sh, 54 + sh))            # object 7: 26 x 18 px at 2.0 m
+    rgb[b] = (40, 60, 210)
+    depth[b] = 2000
+    inst[b] = 7
+    inst[0:3, :] = 0                                        # a strip nobody labelled (-> unknown)
+    inst[44:47, 2:6] = 5                                    # a 3 x 4 px speck: too small, must become unknown
+    return rgb, depth, inst
+
+
+def write_scene(root, fmt="Replica", n_frames=40, part_dim=0, part_down=5, seed=0):
+    """Frames 0, 10, 20, ... are the ones a stride-10 loader reads; instance / class maps exist per 10 frames."""
+    rs = np.random.RandomState(seed)
+    os.makedirs(root, exist_ok=True)
+    for d in ("depth", "instance_our", "class_our", "rgb" if fmt == "Replica" else "color"):
+        os.makedirs(os.path.join(root, d), exist_ok=True)
+    if part_dim:
+        os.makedirs(os.path.join(root, "partlevel"), exist_ok=True)
+    traj = []
+    clip_all, cap_all = [], []
+    for i in range(n_frames):
+        rgb, depth, inst = _frame(i // 10, rs)
+        if fmt == "Replica":
+            Image.fromarray(rgb).save(os.path.join(root, "rgb", "rgb_%d.png" % i))
+            Image.fromarray(depth).save(os.path.join(root, "depth", "depth_%d.png" % i))
+        else:
+            big = np.repeat(np.repeat(rgb, 2, axis=0), 2, axis=1)          # colour at twice the depth resolution
+            Image.fromarray(big).save(os.path.join(root, "color", "%d.jpg" % i), quality=95)
+            Image.fromarray(depth).save(os.path.join(root, "depth", "%d.png" % i))
+        T = np.eye(4)
+        T[0, 3] = 0.02 * (i // 10)
+        traj.append(T.reshape(-1))
+        if i % 10 == 0:
+            j = i // 10
+            name = "semantic_%s_%d.png" if fmt == "Replica" else "%s%d.png"
+            Image.fromarray(inst).save(os.path.join(root, "instance_our", name % ("instance", j) if fmt == "Replica" else "%d.png" % j))
+            Image.fromarray(inst).save(os.path.join(root, "class_our", name % ("class", j) if fmt == "Replica" else "%d.png" % j))
+            f = lambda k, n: (np.eye(n)[k % n] + 0.01 * rs.randn(n)).astype(np.float32)
+            clip_all.append({k: f(k, 16)[None] for k in (1, 4, 7, 5)})       # [1, C] like the CLIP entries
+            cap_all.append({k: f(k + 1, 12) for k in (1, 4, 7, 5)})
+        if part_dim and i % 10 == 0:
+            pf = rs.randn(H // part_down, W // part_down, part_dim).astype(np.float32)
+            np.save(os.path.join(root, "partlevel", "%d.npy" % i), pf)
+    np.savetxt(os.path.join(root, "traj_w_c.txt"), np.stack(traj), delimiter=" ")
+    with open(os.path.join(root, "object_clipfeat.pkl"), "wb") as fh:
+        pickle.dump(clip_all, fh)
+    with open(os.path.join(root, "object_capfeat.pkl"), "wb") as fh:
+        pickle.dump(cap_all, fh)
+    return dict(W=W, H=H, fx=FX, fy=FY, cx=CX, cy=CY)

@@ -1,0 +1,112 @@
+"""The incremental mapping loop (openobj_amd/mapping.py = train.py:155-541 of the reference) end to end on the GPU:
+files on disk -> dataset adapter -> keyframe stores -> fused training iterations -> checkpoints."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from openobj_amd import cfg as ocfg
+from openobj_amd import dataset as ods
+from openobj_amd import mapping
+from tests import scene_files as SF
+
+pytestmark = pytest.mark.gpu
+
+
+def make_cfg(root, dev, **kw):
+    over = {"dataset.path": str(root), "dataset.format": "Replica", "trainer.part_mode": 0, "camera.w": SF.W,
+            "camera.h": SF.H, "camera.fx": SF.FX, "camera.fy": SF.FY, "camera.cx": SF.CX, "camera.cy": SF.CY,
+            "render.iters_per_frame": 30, "render.n_per_optim_bg": 240, "render.depth_range": [0.0, 8.0]}
+    over.update(kw)
+    return ocfg.Config(ocfg.replica_room0_config(train_device=str(dev), **over))
+
+
+def _total(terms):          # depth + 5 colour + 10 opacity (+ 5 feature), summed over the stacked objects
+    t = torch.stack(terms).double().cpu()
+    return (t[..., 0] + 5 * t[..., 1] + 10 * t[..., 2] + 5 * t[..., 3]).sum(-1)
+
+
+def test_mapping_from_files(dev, tmp_path):
+    root = tmp_path / "scene"
+    SF.write_scene(str(root), "Replica", n_frames=50)
+    c = make_cfg(root, dev)
+    m = mapping.IncrementalMapper(c)
+    hist = []
+    m.run(ods.init_loader(c, multi_worker=False), on_frame=lambda f, l: hist.append(l))
+    assert len(hist) == 5 and list(m.obj_dict) == [4, 7] and sorted(m.vis_dict) == [0, 4, 7]
+    assert m.scene_bg is m.vis_dict[0] and m.scene_bg.trainer.arena.net.hidden == c.hidden_feature_size_bg
+    for so in m.vis_dict.values():                       # 5 frames at keyframe_step 2.5 / 5: live slot + keyframes
+        assert 2 <= so.n_keyframes <= 5 and so.frame_cnt == 4 and np.ndim(so.clip_feat) == 2
+    first, last = _total(hist[0]["obj"]), _total(hist[-1]["obj"])
+    assert torch.isfinite(first).all() and torch.isfinite(last).all()
+    assert float(last[-10:].mean()) < 0.5 * float(first[:10].mean()), (first[:10], last[-10:])
+    bg_first, bg_last = _total(hist[0]["bg"]), _total(hist[-1]["bg"])
+    assert float(bg_last[-10:].mean()) < 0.7 * float(bg_first[:10].mean())
+    # the trained weights are back in each object's own modules (train.py:478-485)
+    for k, so in enumerate(m.obj_dict.values()):
+        assert torch.equal(so.trainer.arena.params[0], m.loop.arena.params[k])
+    # a rendered ray through object 4 stops near its surface (1.5 m): the networks learnt the scene
+    so = m.obj_dict[4]
+    z = torch.linspace(0.5, 3.0, 96, device=dev)
+    u, v = 18 + 4, 22                                     # a pixel inside object 4 in the last frame
+    d = torch.tensor([(u - SF.CX) / SF.FX, (v - SF.CY) / SF.FY, 1.0], device=dev)
+    o = m.last_twc[:3, 3]
+    pts = (o[None] + z[:, None] * d[None]).reshape(1, -1, 3)
+    occ, _, _ = so.trainer.eval_points(pts.reshape(-1, 3))
+    w = occ * torch.cumprod(torch.cat([torch.ones(1, device=dev), 1 - occ[:-1] + 1e-10]), 0)
+    depth = float((w * z).sum() / w.sum().clamp_min(1e-6))
+    assert abs(depth - 1.5) < 0.25 and float(w.sum()) > 0.8, (depth, float(w.sum()))
+
+    # semantics from the accumulated features (train.py:497-524) and the checkpoint files (train.py:527-541)
+    names = ["wall", "floor", "ceiling"] + ["c%d" % i for i in range(3, 9)]
+    sem = m.assign_semantics(names, np.eye(9, 16, dtype=np.float32), np.eye(9, 12, dtype=np.float32))
+    assert sem[0] == 0 and sem[4] == 5 and sem[7] == 8          # caption features e_(id+1) decide (similarity > 0.5)
+    sem = m.assign_semantics(names, np.eye(9, 16, dtype=np.float32), 0.3 * np.eye(9, 12, dtype=np.float32))
+    assert sem[4] == 4 and sem[7] == 7                          # weak caption match: the CLIP feature e_id decides
+    log = tmp_path / "log"
+    m.save_checkpoints(str(log))
+    assert os.path.exists(log / "cam_pose" / "twc_frame.pth")
+    for oid in (0, 4, 7):
+        ck = torch.load(str(log / "ckpt" / str(oid) / ("obj_%d.pth" % oid)), weights_only=False)
+        assert ck["obj_id"] == oid and ck["epoch"] == 40 and ck["semantic_id"] == sem[oid]
+
+
+def test_mapping_with_part_features_and_late_object(dev, tmp_path):
+    """part_mode: the per-frame feature maps feed the 512-d distillation loss; an object that shows up later
+    re-stacks the networks without losing what the others learnt."""
+    root = tmp_path / "scene"
+    SF.write_scene(str(root), "Replica", n_frames=30, part_dim=512, part_down=4)
+    c = make_cfg(root, dev, **{"trainer.part_mode": 1, "trainer.part_down": 4, "render.iters_per_frame": 10})
+    ds = ods.Replica(c)
+    m = mapping.IncrementalMapper(c)
+    s0 = ds[0]
+    s0["obj"][s0["obj"] == 7] = -1                       # hide object 7 in the first frame
+    del s0["bbox_dict"][7]
+    out0 = m.step_frame(s0, 0)
+    assert list(m.obj_dict) == [4] and m.global_partfeat.shape == (1, SF.W // 4, SF.H // 4, 512)
+    assert (torch.stack(out0["obj"])[:, :, 3] > 0).all()            # the feature term is active
+    p2 = m.loop.arena.params[0].clone()
+    assert m.ingest(ds[1], 1) == [7]
+    m._ensure_stack()
+    assert list(m.obj_dict) == [4, 7] and m.loop.arena.params.shape[0] == 2
+    assert torch.equal(m.loop.arena.params[0], p2)                  # object 4 keeps its trained weights
+    out1 = m.train_frame()
+    assert torch.isfinite(torch.stack(out1["obj"])).all() and torch.stack(out1["obj"]).shape == (10, 2, 4)
+    assert m.global_partfeat.shape[0] == 2
+
+
+def test_command_line(dev, tmp_path):
+    """python -m openobj_amd.mapping --config <json> --logdir <dir>  (the reference's train.py entry point)."""
+    import json
+    root = tmp_path / "scene"
+    SF.write_scene(str(root), "ScanNet", n_frames=30)
+    conf = ocfg.replica_room0_config(train_device=str(dev), **{
+        "dataset.path": str(root), "dataset.format": "ScanNet", "trainer.part_mode": 0, "camera.w": SF.W, "camera.h": SF.H,
+        "camera.fx": SF.FX, "camera.fy": SF.FY, "camera.cx": SF.CX, "camera.cy": SF.CY, "render.iters_per_frame": 5,
+        "render.n_per_optim_bg": 240, "vis.n_vis_iter": 1})
+    cf = tmp_path / "scene.json"
+    cf.write_text(json.dumps(conf))
+    m = mapping.main(["--config", str(cf), "--logdir", str(tmp_path / "log"), "--single-worker"])
+    assert sorted(m.vis_dict) == [0, 4, 7] and m.last_frame_id == 20
+    assert os.path.exists(tmp_path / "log" / "scene.json") and os.path.exists(tmp_path / "log" / "ckpt" / "7" / "obj_7.pth")
