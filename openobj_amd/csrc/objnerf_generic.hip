@@ -32,11 +32,15 @@ struct Gemm {
 #define OBJ_GEMM_BK 16
 #endif
 constexpr int BK = OBJ_GEMM_BK;
+#ifndef OBJ_WGRAD_MINPER
+#define OBJ_WGRAD_MINPER 256
+#endif
 
 // Workgroup tile (32*TM*2) x (32*TN*2): 4 waves as 2 x 2, each wave TM x TN MFMA tiles of 16 x 16.
 // <1,1> = 64 x 64 (small problems), <2,2> = 128 x 128 (the n x H x H layer GEMMs: 2 MFMAs per LDS read).
-template <int TM, int TN>
+template <int TM, int TN, int BKT = BK>
 __global__ __launch_bounds__(256) void gemm_kernel(const Gemm g) {
+  constexpr int BK = BKT;      // k depth of one LDS stage (shadows the default)
   constexpr int BM = 32 * TM, BN = 32 * TN;      // (per wave 16*TM x 16*TN, workgroup 2 x 2 waves)
   __shared__ float As[BK][BM + 4];
   __shared__ float Bs[BK][BN + 4];
@@ -287,6 +291,7 @@ static void gemm(hipStream_t st, int batch, int M, int N, int Kd, const float* A
     hipLaunchKernelGGL((gemm_kernel<4, 4>), grid, dim3(256), 0, st, g);
   } else {
     dim3 grid((N + 63) / 64, (M + 63) / 64, nz);
+    // (64-deep k stages for small grids were measured: slower -- the transposed LDS store conflicts dominate)
     hipLaunchKernelGGL((gemm_kernel<2, 2>), grid, dim3(256), 0, st, g);
   }
 }
@@ -296,7 +301,12 @@ static void gemm(hipStream_t st, int batch, int M, int N, int Kd, const float* A
 static void wgrad(hipStream_t st, int batch, int M, int N, long n, const float* A, long sam, long sak, long bsa,
                   const float* B, long sbk, long sbn, long bsb, float* C, long scm, long bsc,
                   float* bias_grad = nullptr) {
-  int sk = (int)((n + 511) / 512);
+  // contraction slice per workgroup: 512 samples; 256 when that would leave most of the chip idle (the background
+  // network at the reference's native batch of 16 800 samples: step 0.55 -> 0.46 ms)
+  const long tiles = (long)batch * ((M + 63) / 64) * ((N + 63) / 64);
+  long per = 512;
+  while (per > OBJ_WGRAD_MINPER && tiles * ((n + per - 1) / per) < 512) per >>= 1;
+  int sk = (int)((n + per - 1) / per);
   if (sk < 1) sk = 1;
   if (sk > 256) sk = 256;
   gemm(st, batch, M, N, (int)n, A, sam, sak, bsa, B, sbk, sbn, bsb, C, scm, 1, bsc, false, nullptr, 0, false, nullptr, 0,

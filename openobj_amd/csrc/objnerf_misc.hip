@@ -140,6 +140,25 @@ __global__ void flags_from_counts_kernel(int K, const int* counts, int* flags) {
   }
 }
 
+// counts_in path of the loss in ONE launch: copy the (global) counts, derive the early-return flags from them,
+// merge the caller's flags, zero the per-object loss terms
+__global__ void loss_prologue_kernel(int K, const int* counts_in, int* counts, int* flags, const int* flags_in,
+                                     float* loss_terms) {
+  __shared__ int f[2];
+  if (threadIdx.x < 2) f[threadIdx.x] = (flags_in && flags_in[threadIdx.x]) ? 1 : 0;
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    const int a = counts_in[2 * k], b = counts_in[2 * k + 1];
+    counts[2 * k] = a;
+    counts[2 * k + 1] = b;
+    if (a == 0) atomicOr(&f[0], 1);
+    if (b == 0) atomicOr(&f[1], 1);
+  }
+  for (int i = threadIdx.x; i < 4 * K; i += blockDim.x) loss_terms[i] = 0.f;
+  __syncthreads();
+  if (threadIdx.x < 2) flags[threadIdx.x] = f[threadIdx.x];
+}
+
 __global__ void merge_flags_kernel(int* flags, const int* flags_in) {
   if (threadIdx.x < 2 && flags_in && flags_in[threadIdx.x]) flags[threadIdx.x] = 1;
 }
@@ -165,17 +184,18 @@ struct LossDev {
   float* rayfeat;         // [K][R][Hh + 3] fh, O, a, c  (-> head gradient GEMMs)
 };
 
-__global__ __launch_bounds__(256) void loss_kernel(const LossDev a) {
+__global__ __launch_bounds__(1024) void loss_kernel(const LossDev a) {
   extern __shared__ float sm[];
+  __shared__ float s_red[16][4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int nw = blockDim.x >> 6;        // rays per block: divides R (host), so a block never straddles two objects
   const int S = a.S;
   float* wv = sm + (long)w * (3 * S + 2 * a.Hh);      // weights
   float* tv = wv + S;                    // transmittance
   float* dwv = tv + S;                   // feature contribution to dL/dw
   float* sfh = dwv + S;                  // (hoisted mode) composited hidden feature, then d loss / d fh
   float* sgf = sfh + a.Hh;               // (hoisted mode) G fh
-  const long rr = (long)blockIdx.x * 4 + w;
-  if (rr >= (long)a.K * a.R) return;
+  const long rr = (long)blockIdx.x * nw + w;
   const int k = (int)(rr / a.R);
   const float n1 = (float)a.counts[2 * k], n2 = (float)a.counts[2 * k + 1];
   const float inv1 = a.flags[0] ? 0.0f : 1.0f / (n1 + 1e-10f);
@@ -299,11 +319,19 @@ __global__ __launch_bounds__(256) void loss_kernel(const LossDev a) {
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");
   }
+  // per-object loss terms: the block's rays are combined in LDS first -- thousands of float atomics on ONE address
+  // (a single object, e.g. the background network) serialise in L2 and were 65 us of a 600 us step
   if (lane == 0) {
-    atomicAdd(&a.loss_terms[k * 4 + 0], m1 * fabsf(rd) * info * inv1);
-    atomicAdd(&a.loss_terms[k * 4 + 1], m1 * (fabsf(r0) + fabsf(r1) + fabsf(r2)) * inv1);
-    atomicAdd(&a.loss_terms[k * 4 + 2], m2 * fabsf(ro) * inv2);
-    atomicAdd(&a.loss_terms[k * 4 + 3], lf);
+    s_red[w][0] = m1 * fabsf(rd) * info * inv1;
+    s_red[w][1] = m1 * (fabsf(r0) + fabsf(r1) + fabsf(r2)) * inv1;
+    s_red[w][2] = m2 * fabsf(ro) * inv2;
+    s_red[w][3] = lf;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    float v = 0.f;
+    for (int i = 0; i < nw; ++i) v += s_red[i][threadIdx.x];
+    atomicAdd(&a.loss_terms[k * 4 + threadIdx.x], v);
   }
   if (!a.d_alpha && !a.d_color) return;
   float sufc = 0.f;
@@ -517,15 +545,15 @@ int step_batch_loss_impl(const objnerf_loss_args* a, const LossHoisted* hz, void
   if (a->S > 2048) return OBJNERF_ENOTSUP;
   hipStream_t st = (hipStream_t)stream;
   int* flags = a->counts + 2 * a->K;     // counts workspace is [K][2] + [2]
-  (void)hipMemsetAsync(flags, 0, 2 * sizeof(int), st);
   if (a->counts_in) {
-    (void)hipMemcpyAsync(a->counts, a->counts_in, (size_t)2 * a->K * sizeof(int), hipMemcpyDeviceToDevice, st);
-    hipLaunchKernelGGL(flags_from_counts_kernel, dim3(1), dim3(64), 0, st, a->K, a->counts, flags);
+    hipLaunchKernelGGL(loss_prologue_kernel, dim3(1), dim3(256), 0, st, a->K, a->counts_in, a->counts, flags, a->flags_in,
+                       a->loss_terms);
   } else {
+    (void)hipMemsetAsync(flags, 0, 2 * sizeof(int), st);
     hipLaunchKernelGGL(label_counts_kernel, dim3(a->K), dim3(256), 0, st, a->K, a->R, a->labels, a->counts, flags);
+    if (a->flags_in) hipLaunchKernelGGL(merge_flags_kernel, dim3(1), dim3(64), 0, st, flags, a->flags_in);
+    (void)hipMemsetAsync(a->loss_terms, 0, (size_t)a->K * 4 * sizeof(float), st);
   }
-  if (a->flags_in) hipLaunchKernelGGL(merge_flags_kernel, dim3(1), dim3(64), 0, st, flags, a->flags_in);
-  (void)hipMemsetAsync(a->loss_terms, 0, (size_t)a->K * 4 * sizeof(float), st);
   LossDev d;
   d.K = a->K; d.R = a->R; d.S = a->S; d.C = a->C;
   d.cs = a->color_scaling; d.os = a->opacity_scaling; d.fs = a->feat_scaling;
@@ -536,7 +564,9 @@ int step_batch_loss_impl(const objnerf_loss_args* a, const LossHoisted* hz, void
   d.hf = hz ? hz->hf : nullptr; d.rayin = hz ? hz->rayin : nullptr; d.gram = hz ? hz->gram : nullptr;
   d.d_hf = hz ? hz->d_hf : nullptr; d.rayfeat = hz ? hz->rayfeat : nullptr;
   const long nr = (long)a->K * a->R;
-  hipLaunchKernelGGL(loss_kernel, dim3((unsigned)((nr + 3) / 4)), dim3(256), (size_t)4 * (3 * a->S + 2 * d.Hh) * 4, st, d);
+  int rb = 16;                                          // rays (waves) per block: the largest power of two dividing R
+  while (rb > 1 && (a->R % rb != 0 || (size_t)rb * (3 * a->S + 2 * d.Hh) * 4 > 60000)) rb >>= 1;
+  hipLaunchKernelGGL(loss_kernel, dim3((unsigned)(nr / rb)), dim3(64 * rb), (size_t)rb * (3 * a->S + 2 * d.Hh) * 4, st, d);
   CHECK_LAUNCH();
   hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(64), 0, st, a->K, a->loss_terms, a->color_scaling,
                      a->opacity_scaling, (a->pred_feat || hz) ? a->feat_scaling : 0.0f, a->total, a->status);

@@ -330,11 +330,12 @@ def train_step(arena: ParamArena, ws: TrainWorkspace, batch: Dict[str, torch.Ten
     gt_rgb = _req(batch["gt_rgb"], torch.float32, "gt_rgb")
     gt_feat = _req(batch["gt_feat"], torch.float32, "gt_feat") if with_feat else None
     st = _stream()
-    check(lib().objnerf_label_counts(K, R, _ptr(labels), _ptr(ws.counts), _ptr(ws.flags), st),
-          "objnerf_label_counts")
+    if global_flags is None or global_counts is None:
+        check(lib().objnerf_label_counts(K, R, _ptr(labels), _ptr(ws.counts), _ptr(ws.flags), st),
+              "objnerf_label_counts")
     flags = ws.flags
     if global_flags is not None:
-        flags = global_flags
+        flags = _req(global_flags, torch.int32, "global_flags")
     counts = ws.counts
     if global_counts is not None:       # one object's rays split over ranks (background): global mask counts
         counts = _req(global_counts, torch.int32, "global_counts")

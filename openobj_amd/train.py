@@ -35,8 +35,9 @@ class BackgroundLoop:
         if self.ws is None or self.ws.key != (K, R, S, self.with_feat):
             self.ws = ops.TrainWorkspace(self.arena, K, R, S, self.with_feat)
         counts, flags = ops.label_counts(batch["labels"])
-        odist.allreduce_sum_(counts, self.group)                  # global n(label==1), n(label!=2)
-        flags = ((counts.reshape(-1, 2) == 0).any(dim=0)).to(torch.int32)
+        if odist._active(self.group):
+            odist.allreduce_sum_(counts, self.group)              # global n(label==1), n(label!=2)
+            flags = ((counts.reshape(-1, 2) == 0).any(dim=0)).to(torch.int32)
         ops.train_step(self.arena, self.ws, batch, with_feat=self.with_feat, global_flags=flags,
                        global_counts=counts, bf16=self.bf16)
         odist.allreduce_sum_(self.ws.grads, self.group)           # the one data-path collective

@@ -1,0 +1,24 @@
+"""Diagnostic: the kernel sequence of ONE background-network step at the reference's native shape
+(hidden 128, 1200 rays x 14 samples).  rocprofv3 --kernel-trace --stats -- python3 tools/bg_trace.py"""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from openobj_amd import cfg as ocfg, synthetic, trainer, train as otrain
+dev = torch.device("cuda:0")
+c = ocfg.Config(ocfg.replica_room0_config(train_device="cuda:0", **{"trainer.part_mode": 0}))
+c.obj_id = 0
+c.hidden_feature_size = c.hidden_feature_size_bg
+c.obj_scale = c.bg_scale
+t = trainer.Trainer(c)
+loop = otrain.BackgroundLoop(c, t, with_feat=False, bf16="--bf16" in sys.argv)
+b = synthetic.random_batch(1, 1200, 5, 9, seed=1)
+batch = {k: torch.from_numpy(b[k]).to(dev) for k in ["pts", "z", "gt_depth", "gt_rgb", "labels"]}
+N = int(os.environ.get("STEPS", "50"))
+for _ in range(5):
+    loop.step(batch)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(N):
+    loop.step(batch)
+torch.cuda.synchronize()
+print("bg step: %.3f ms" % (1e3 * (time.perf_counter() - t0) / N))

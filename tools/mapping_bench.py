@@ -1,0 +1,88 @@
+"""Where does a frame of the mapping loop (openobj_amd/mapping.py) spend its time at the reference's native
+shape?  Synthetic 1200 x 680 frames, N objects on a grid in front of a wall, room_0 hyper-parameters
+(100 iterations x 120 rays x 10 samples per object, background 1200 rays x 14 samples).  Run on the GPU box."""
+import argparse
+import sys
+import os
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from openobj_amd import cfg as ocfg, mapping
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--objects", type=int, default=50)
+ap.add_argument("--frames", type=int, default=6)
+ap.add_argument("--bf16", action="store_true")
+ap.add_argument("--part", action="store_true")
+ap.add_argument("--overlap", action="store_true", help="background steps on a second stream")
+a = ap.parse_args()
+dev = "cuda:0"
+W, H = 1200, 680
+c = ocfg.Config(ocfg.replica_room0_config(train_device=dev, **{"trainer.part_mode": int(a.part)}))
+nx = int(np.ceil(np.sqrt(a.objects * W / H)))
+ny = int(np.ceil(a.objects / nx))
+cw, ch = W // nx, H // ny
+
+
+def sample(i):
+    inst = np.zeros((W, H), np.int32)               # [W, H] like the loader's arrays; 0 = background
+    depth = np.full((W, H), 3.0, np.float32)
+    rgb = np.full((W, H, 3), 90, np.uint8)
+    bbox = {0: torch.tensor([0, W, 0, H])}
+    k = 0
+    for iy in range(ny):
+        for ix in range(nx):
+            if k >= a.objects:
+                break
+            x0, y0 = ix * cw + cw // 6 + i, iy * ch + ch // 6
+            x1, y1 = x0 + 2 * cw // 3, y0 + 2 * ch // 3
+            oid = k + 4
+            inst[x0:x1, y0:y1] = oid
+            depth[x0:x1, y0:y1] = 1.2 + 0.02 * k
+            rgb[x0:x1, y0:y1] = ((37 * k) % 255, (91 * k) % 255, (53 * k) % 255)
+            bbox[oid] = torch.tensor([max(x0 - 8, 0), min(x1 + 8, W - 1), max(y0 - 8, 0), min(y1 + 8, H - 1)])
+            k += 1
+    T = np.eye(4)
+    T[0, 3] = 0.002 * i
+    feats = {oid: np.ones((1, 8), np.float32) for oid in bbox}
+    s = {"image": rgb, "depth": depth, "T": T, "obj": inst, "bbox_dict": bbox, "frame_id": 10 * i,
+         "obj_clip": feats, "obj_cap": {o: np.ones(8, np.float32) for o in bbox}}
+    if a.part:
+        s["part_feat"] = torch.randn(W // 5, H // 5, 512)
+    return s
+
+
+m = mapping.IncrementalMapper(c, bf16=a.bf16)
+sync = torch.cuda.synchronize
+for i in range(a.frames):
+    s = sample(i)
+    sync(); t0 = time.perf_counter()
+    m.ingest(s, i)
+    sync(); t1 = time.perf_counter()
+    m._ensure_stack()
+    pool, bg_pool = m.sample_pools()
+    sync(); t2 = time.perf_counter()
+    npo, npo_bg = c.n_per_optim, c.n_per_optim_bg
+    if a.overlap:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for it in range(c.n_iter_per_frame):
+                m.bg_loop.step({k: v[:, it * npo_bg:(it + 1) * npo_bg].contiguous() for k, v in bg_pool.items()})
+        for it in range(c.n_iter_per_frame):
+            m.loop.step({k: v[:, it * npo:(it + 1) * npo].contiguous() for k, v in pool.items()})
+        torch.cuda.current_stream().wait_stream(side)
+    else:
+        for it in range(c.n_iter_per_frame):
+            m.loop.step({k: v[:, it * npo:(it + 1) * npo].contiguous() for k, v in pool.items()})
+            m.bg_loop.step({k: v[:, it * npo_bg:(it + 1) * npo_bg].contiguous() for k, v in bg_pool.items()})
+    sync(); t3 = time.perf_counter()
+    m.loop.copy_back()
+    sync(); t4 = time.perf_counter()
+    print("frame %d: ingest %.1f ms | stack+sample pools %.1f ms | %d iterations %.1f ms (%.3f ms each) | copy-back %.1f ms"
+          % (i, 1e3 * (t1 - t0), 1e3 * (t2 - t1), c.n_iter_per_frame, 1e3 * (t3 - t2), 1e3 * (t3 - t2) / c.n_iter_per_frame,
+             1e3 * (t4 - t3)), flush=True)
+print("objects:", len(m.obj_dict), "| HBM in use: %.1f GB" % (torch.cuda.memory_allocated() / 2**30))
