@@ -45,9 +45,6 @@ __device__ __forceinline__ float cos_poly(float r2) {
 // ~1e-6 at these arguments -- far below the bf16 rounding (4e-3) the embedding gets in that mode, and 3 instructions
 // instead of ~28; never used on the fp32 parity path.
 __device__ __forceinline__ float sin_acc(float x) {
-#ifdef ABL_CHEAP_PE
-  return x * 0.001f;
-#endif
 #ifdef OBJ_HW_SINCOS
   return __builtin_amdgcn_sinf(x * 0.15915494f);
 #endif
@@ -60,9 +57,6 @@ __device__ __forceinline__ float sin_acc(float x) {
 #endif
 }
 __device__ __forceinline__ void sincos_acc(float x, float& s, float& c) {
-#ifdef ABL_CHEAP_PE
-  s = x * 0.001f; c = 1.0f - x * 0.002f; return;
-#endif
 #ifdef OBJ_HW_SINCOS
   const float rev = x * 0.15915494f;
   s = __builtin_amdgcn_sinf(rev);

@@ -133,13 +133,6 @@ __global__ void label_counts_kernel(int K, int R, const uint8_t* labels, int* co
   }
 }
 
-__global__ void flags_from_counts_kernel(int K, const int* counts, int* flags) {
-  for (int k = threadIdx.x; k < K; k += blockDim.x) {
-    if (counts[2 * k] == 0) atomicOr(&flags[0], 1);
-    if (counts[2 * k + 1] == 0) atomicOr(&flags[1], 1);
-  }
-}
-
 // counts_in path of the loss in ONE launch: copy the (global) counts, derive the early-return flags from them,
 // merge the caller's flags, zero the per-object loss terms
 __global__ void loss_prologue_kernel(int K, const int* counts_in, int* counts, int* flags, const int* flags_in,

@@ -46,9 +46,6 @@ __device__ __forceinline__ void store_T16(float* stg_lane, const int rowbase, co
 // lane walks CONSECUTIVE samples and fetches two steps per ds_read_b64 (8-byte aligned with the 130-float
 // row stride; 2c + 32g + st covers all 64 banks -> conflict-free).  dT / aT point at &stg[(row0 + c) * LD + 32 g].
 __device__ __forceinline__ void wgrad_pair(f32x4& acc0, f32x4& acc1, const float* dT, const float* aT) {
-#ifdef ABL_NO_WGRAD
-  return;
-#endif
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   dT = (const float*)__builtin_assume_aligned(dT, 8);     // row pitch 520 B, 32 g and st even: 8-byte aligned
   aT = (const float*)__builtin_assume_aligned(aT, 8);
@@ -96,28 +93,12 @@ __device__ unsigned long long g_phase[8][24];
 
 // keeps the instruction scheduler from pulling the sincos of later embedding tiles ahead of the current one
 // (which overlaps nicely but needs ~50 more live registers and spills the persistent accumulators)
-#ifdef NO_SCHED_FENCE
-#define SCHED_FENCE() do {} while (0)
-#else
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-#endif
 
-#ifdef ABL_NO_BARRIER
-#define TILE_SYNC() do {} while (0)
-#else
 #define TILE_SYNC() __syncthreads()
-#endif
 
 // ------------------------------------------------------------------------------------------------
-#ifndef X1N
-#define X1N 6
-#endif
-#ifndef X2N
-#define X2N 3
-#endif
-#ifdef ABL_NO_SLOT
-#define slot_accum16(a, b, c_, d) do { a += (b); } while (0)
-#endif
+constexpr int X1N = 6, X2N = 3;       // 16-wide embedding tiles of the two input blocks (96 and 48 padded entries)
 template <bool FEAT>
 __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -286,11 +267,7 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
     // ---------------------------------------------------------------- 2. composite + loss (loss.py:27-101)
     auto composite_passes = [&](const auto& sg) {
       const int rpp = 64 / S;                       // rays per wave pass
-#ifdef ABL_NO_COMPOSITE
-      const int npass = 0;
-#else
       const int npass = (TR + rpp - 1) / rpp;
-#endif
       for (int ps = w; ps < npass; ps += NWAVE) {
         const int ql = lane / S, pos = lane - ql * S;
         const int qq = ps * rpp + ql;

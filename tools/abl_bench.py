@@ -1,5 +1,6 @@
 """Diagnostic: time bench.py with each variant build in openobj_amd/csrc/abl/lib_*.so (OBJNERF_LIB override).
-Ablated builds compute WRONG results; only the time matters.  Extra arguments go to bench.py."""
+Builds come from tools/build_variant.sh / build_variant_generic.sh (e.g. -DPHASE_TIMING, -DOBJ_GEMM_BK=32).
+Extra arguments go to bench.py."""
 import glob, json, os, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 extra = sys.argv[1:] or ["--no-bg"]
