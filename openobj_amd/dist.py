@@ -57,3 +57,19 @@ def allreduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:
 def shard_rays(R: int, world: int, rank: int) -> Tuple[int, int]:
     """Contiguous slice of the R rays of ONE replicated network (the background) owned by `rank`."""
     return shard_objects(R, world, rank)
+
+
+def rank_world(group=None) -> Tuple[int, int]:
+    """(rank, world size) of this process; (0, 1) without an initialised process group."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return 0, 1
+    return dist.get_rank(group), dist.get_world_size(group)
+
+
+def broadcast_(t: torch.Tensor, src: int = 0, group=None) -> torch.Tensor:
+    """In-place broadcast from `src` (replicated networks start from identical weights); no-op for one process."""
+    import torch.distributed as dist
+    if _active(group):
+        dist.broadcast(t, src=src, group=group)
+    return t

@@ -10,6 +10,12 @@
     every n_vis_iter frames (optional): semantic labels from the accumulated CLIP / caption features
     and the checkpoint files                                                          train.py:489-541
 
+Under `torch.distributed` (one process per GPU) the map is OBJECT-SHARDED like the training step:
+every rank reads every frame, foreground objects are dealt round-robin to the ranks in order of first appearance
+and live only on their owner (keyframes, networks, optimiser state, checkpoints); the background network is
+replicated, each rank trains it on its share of the frame's background rays and the gradient is SUM all-reduced
+(`train.BackgroundLoop`).  The only other exchange is the pair of early-return flags per iteration.
+
 Everything numerical runs in libobjnerf_hip.so (sampler, fused iteration, AdamW); this file is bookkeeping.
 The class-name text features (CLIP ViT-B/32 and SBERT encoders in the reference, train.py:108-147) are inputs
 here: pass `class_clipfeat` / `class_capfeat` arrays to `assign_semantics`.  Visualisation, meshing and the live
@@ -21,6 +27,8 @@ from typing import Dict, List, Optional
 import numpy as np
 import torch
 
+from . import dist as odist
+from . import ops
 from . import train as otrain
 from .vmap import cameraInfo, sceneObject
 
@@ -39,9 +47,15 @@ def _to_dev(x, dev, dtype=None):
 
 
 class IncrementalMapper:
-    def __init__(self, cfg, bf16: bool = False):
+    def __init__(self, cfg, bf16: bool = False, group=None):
         self.cfg = cfg
         self.bf16 = bf16
+        self.group = group
+        self.rank, self.world = odist.rank_world(group)
+        if self.world > 1:                      # every rank must draw DIFFERENT pixels of the shared background
+            torch.manual_seed(torch.initial_seed() + 7919 * self.rank)
+        self.remote_ids = set()                 # foreground objects that live on another rank
+        self.n_foreground = 0                   # foreground objects seen so far (identical on every rank)
         self.cam_info = cameraInfo(cfg)
         self.obj_dict: Dict[int, sceneObject] = {}      # foreground objects (the stacked networks), creation order
         self.vis_dict: Dict[int, sceneObject] = {}      # + the background object
@@ -85,13 +99,24 @@ class IncrementalMapper:
                 self.vis_dict[obj_id].append_keyframe(rgb, depth, state, bbox, twc, live_frame_id,
                                                       clip_feat=clip_feat, caption_feat=cap_feat)
                 continue
-            if len(self.obj_dict) >= cfg.max_n_models:
-                continue                                                  # "models full" (train.py:232-234)
+            if obj_id in self.remote_ids:
+                continue
+            is_bg = cfg.do_bg and obj_id == 0
+            if not is_bg:
+                if self.n_foreground >= cfg.max_n_models:
+                    continue                                              # "models full" (train.py:232-234)
+                owner = self.n_foreground % self.world
+                self.n_foreground += 1
+                if owner != self.rank:
+                    self.remote_ids.add(obj_id)
+                    continue
             so = sceneObject(cfg, obj_id, rgb, depth, state, bbox, twc, live_frame_id, clip_feat=clip_feat,
                              caption_feat=cap_feat)
-            if cfg.do_bg and obj_id == 0:
+            if is_bg:
                 self.scene_bg = so
-                self.bg_loop = otrain.BackgroundLoop(cfg, so.trainer, with_feat=bool(cfg.part_mode), bf16=self.bf16)
+                odist.broadcast_(so.trainer.arena.params, 0, self.group)      # identical replicas
+                self.bg_loop = otrain.BackgroundLoop(cfg, so.trainer, with_feat=bool(cfg.part_mode), group=self.group,
+                                                     bf16=self.bf16)
             else:
                 self.obj_dict[obj_id] = so
                 self._restack = True
@@ -102,6 +127,8 @@ class IncrementalMapper:
 
     # ------------------------------------------------------------------ train.py:272-276
     def _ensure_stack(self):
+        if not self.obj_dict:
+            return
         if self._restack or self.loop is None:
             if self.loop is not None:
                 self.loop.copy_back()
@@ -130,11 +157,14 @@ class IncrementalMapper:
         cfg = self.cfg
         bg_pool = None
         if cfg.do_bg and self.scene_bg is not None:
-            bp = self._pool_of(self.scene_bg, cfg.n_iter_per_frame * cfg.win_size_bg, cfg.n_samples_per_frame_bg)
+            lo, hi = odist.shard_rays(cfg.n_samples_per_frame_bg, self.world, self.rank)     # this rank's share
+            bp = self._pool_of(self.scene_bg, cfg.n_iter_per_frame * cfg.win_size_bg, hi - lo)
             bg_pool = {k: v[None] for k, v in bp.items()}
         pools = [self._pool_of(o, cfg.n_iter_per_frame * cfg.win_size, cfg.n_samples_per_frame)
                  for o in self.obj_dict.values()]
-        assert len(pools) > 0, "no foreground object in the map yet"      # train.py:366
+        if not pools:
+            assert self.world > 1, "no foreground object in the map yet"  # train.py:366
+            return None, bg_pool
         return {k: torch.stack([p[k] for p in pools]) for k in pools[0]}, bg_pool
 
     # ------------------------------------------------------------------ train.py:394-485
@@ -144,22 +174,37 @@ class IncrementalMapper:
         self._ensure_stack()
         pool, bg_pool = self.sample_pools()
         out = {"obj": [], "bg": []}
-        npo, npo_bg = cfg.n_per_optim, cfg.n_per_optim_bg
+        npo = cfg.n_per_optim
+        npo_bg = bg_pool["z"].shape[1] // cfg.n_iter_per_frame if bg_pool is not None else 0
+        sharded = odist._active(self.group)
+        gflags = torch.zeros(2, dtype=torch.int32, device=cfg.training_device) if sharded else None
         for it in range(cfg.n_iter_per_frame):
-            sl = slice(it * npo, (it + 1) * npo)
-            out["obj"].append(self.loop.step({k: v[:, sl].contiguous() for k, v in pool.items()}).clone())
+            batch = None
+            if pool is not None:
+                sl = slice(it * npo, (it + 1) * npo)
+                batch = {k: v[:, sl].contiguous() for k, v in pool.items()}
+            if sharded:
+                # render_rays.py:89-94: one empty mask anywhere in the stacked batch zeroes that term for ALL objects
+                if batch is not None:
+                    gflags.copy_(ops.label_counts(batch["labels"])[1])
+                else:
+                    gflags.zero_()
+                odist.global_flags(gflags, self.group)
+            if batch is not None:
+                out["obj"].append(self.loop.step(batch, global_flags=gflags).clone())
             if bg_pool is not None:
                 bs = slice(it * npo_bg, (it + 1) * npo_bg)
                 out["bg"].append(self.bg_loop.step({k: v[:, bs].contiguous() for k, v in bg_pool.items()}).clone())
-        if int(self.loop.ws.status.item()) != 0:
-            from .render_rays import LossExplode
-            raise LossExplode("loss explode")
-        self.loop.copy_back()
+        if self.loop is not None:
+            if int(self.loop.ws.status.item()) != 0:
+                from .render_rays import LossExplode
+                raise LossExplode("loss explode")
+            self.loop.copy_back()
         return out
 
     def step_frame(self, sample, frame_id: int):
         self.ingest(sample, frame_id)
-        if not self.obj_dict:
+        if self.n_foreground == 0:
             return None
         return self.train_frame()
 
@@ -196,11 +241,15 @@ class IncrementalMapper:
         refreshes each object's 3-D box first (open3d point-cloud fitting, outside this build): with need_bound the
         caller must have set sceneObject.bbox3dour."""
         for obj_id, so in self.vis_dict.items():
+            if obj_id == 0 and self.scene_bg is so and self.rank != 0:
+                continue                                  # the replicated background is written by rank 0
             d = os.path.join(log_dir, "ckpt", str(obj_id))
             os.makedirs(d, exist_ok=True)
             if need_bound:
                 so.get_bound(None)
             so.save_checkpoints(d, self.last_frame_id)
+        if self.rank != 0:
+            return
         cam_dir = os.path.join(log_dir, "cam_pose")
         os.makedirs(cam_dir, exist_ok=True)
         torch.save({"twc": self.last_twc}, os.path.join(cam_dir, "twc_frame.pth"))
@@ -226,15 +275,24 @@ def main(argv=None):
     ap.add_argument("--bf16", action="store_true", help="bf16 MFMA operands (fp32 accumulation and weights)")
     ap.add_argument("--single-worker", action="store_true", help="read frames in this process (no loader workers)")
     args = ap.parse_args(argv)
-    os.makedirs(args.logdir, exist_ok=True)
-    shutil.copy(args.config, args.logdir)
     cfg = ocfg.Config(args.config)
+    rank = 0
+    if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:     # torchrun: one process per GPU
+        import torch.distributed as dist
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        cfg.training_device = cfg.data_device = "cuda:%d" % local
+        rank = dist.get_rank()
+    if rank == 0:
+        os.makedirs(args.logdir, exist_ok=True)
+        shutil.copy(args.config, args.logdir)
     mapper = IncrementalMapper(cfg, bf16=args.bf16)
     loader = dataset.init_loader(cfg, multi_worker=not args.single_worker)
     n_total = len(loader) if args.frames is None else min(len(loader), args.frames)
 
     def on_frame(frame_id, losses):
-        if losses is not None:
+        if losses is not None and losses["obj"]:
             t = losses["obj"][-1]
             print("frame %d: %d objects, last-iteration loss terms (depth, colour, opacity, feature) = %s"
                   % (frame_id, t.shape[0], [round(float(x), 5) for x in t.sum(0).tolist()]), flush=True)
