@@ -91,7 +91,10 @@ def _worker(rank, world, port, q):
     odist.allreduce_sum_(counts)
     grads = torch.full((1, 8), float(rank + 1))
     odist.allreduce_sum_(grads)
-    q.put((rank, flags.tolist(), float(tot), counts.tolist(), grads[0, 0].item()))
+    # replicated background network of the sharded mapping loop: identical weights from rank 0
+    w = torch.full((1, 5), float(10 + rank))
+    odist.broadcast_(w, 0)
+    q.put((rank, flags.tolist(), float(tot), counts.tolist(), grads[0, 0].item(), odist.rank_world(), w[0, 0].item()))
     dist.destroy_process_group()
 
 
@@ -107,7 +110,9 @@ def test_two_rank_flags_and_loss_gloo():
     for p in procs:
         p.join(60)
     expect = 2 * (1 + 5 + 10 + 5) * 1.0 + 2 * (1 + 5 + 10 + 5) * 2.0
-    for rank, flags, tot, counts, g0 in res:
+    assert odist.rank_world() == (0, 1)              # no process group in this process
+    for rank, flags, tot, counts, g0, rw, w0 in res:
+        assert rw == (rank, 2) and w0 == 10.0
         assert flags == [1, 0]
         assert abs(tot - expect) < 1e-4
         assert counts == [[1200, 21]] and g0 == 3.0
