@@ -17,6 +17,7 @@ ap.add_argument("--objects", type=int, default=50)
 ap.add_argument("--frames", type=int, default=6)
 ap.add_argument("--bf16", action="store_true")
 ap.add_argument("--part", action="store_true")
+ap.add_argument("--only", choices=["obj", "bg"], default=None, help="time only the object or only the background steps")
 ap.add_argument("--overlap", action="store_true", help="background steps on a second stream")
 a = ap.parse_args()
 dev = "cuda:0"
@@ -77,8 +78,10 @@ for i in range(a.frames):
         torch.cuda.current_stream().wait_stream(side)
     else:
         for it in range(c.n_iter_per_frame):
-            m.loop.step({k: v[:, it * npo:(it + 1) * npo].contiguous() for k, v in pool.items()})
-            m.bg_loop.step({k: v[:, it * npo_bg:(it + 1) * npo_bg].contiguous() for k, v in bg_pool.items()})
+            if a.only != "bg":
+                m.loop.step({k: v[:, it * npo:(it + 1) * npo].contiguous() for k, v in pool.items()})
+            if a.only != "obj":
+                m.bg_loop.step({k: v[:, it * npo_bg:(it + 1) * npo_bg].contiguous() for k, v in bg_pool.items()})
     sync(); t3 = time.perf_counter()
     m.loop.copy_back()
     sync(); t4 = time.perf_counter()
