@@ -92,6 +92,16 @@ typedef struct objnerf_sample_args {
 } objnerf_sample_args;
 int objnerf_sample_rays(const objnerf_sample_args* a, void* stream);
 
+/* The same for K objects in ONE launch chain (train.py:316-330 calls the sampler once per object and stacks the
+ * results, train.py:368-388).  `table`: DEVICE array of K keyframe-store descriptors (the objects share F, W, H and
+ * every scalar of `a`; a->rgbs / depth / t_wc / bbox are ignored).  Every draw and output array of `a` is stacked
+ * [K][...] with the per-object layouts above -- the outputs ARE the stacked batch tensors of the training step --
+ * and max_depth_ws holds K x (1 + 6 n) floats. */
+typedef struct objnerf_kf_store {
+  const uint8_t* rgbs; const float* depth; const float* t_wc; const float* bbox;
+} objnerf_kf_store;
+int objnerf_sample_rays_stacked(const objnerf_sample_args* a, int32_t K, const objnerf_kf_store* table, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * f-1  Trainer.sample_points_bbox (trainer.py:130-198), the sampler of render_2D_syn (vmap.py:604-685).
  * objnerf_box_rays: P camera rays dirs_C [P][3] (un-normalised, rays_dir_cache[pixels]) of ONE view against an

@@ -81,6 +81,7 @@ SIGNATURES = {
     "objnerf_rays_dirs": (C.c_int, [C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float,
                                     C.c_void_p, C.c_void_p]),
     "objnerf_sample_rays": (C.c_int, [C.POINTER(SampleArgs), C.c_void_p]),
+    "objnerf_sample_rays_stacked": (C.c_int, [C.POINTER(SampleArgs), C.c_int32, C.c_void_p, C.c_void_p]),
     "objnerf_box_rays": (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p]),
     "objnerf_box_points": (C.c_int, [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

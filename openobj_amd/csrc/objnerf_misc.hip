@@ -406,10 +406,29 @@ __global__ void rays_dirs_kernel(int W, int H, float fx, float fy, float cx, flo
 // ------------------------------------------------------------------------------------------------
 // vmap.py:386-554: pixel gather (pass 1, also the batch depth maximum) and z placement (pass 2).
 // ------------------------------------------------------------------------------------------------
-__global__ void sample_gather_kernel(const objnerf_sample_args a, float* origins_ws, float* dirs_ws) {
+// object blockIdx.y of a stacked call: its keyframe store from the table, its slices of the stacked arrays
+__device__ __forceinline__ objnerf_sample_args sample_args_of(const objnerf_sample_args& a, const objnerf_kf_store* table,
+                                                              const int k) {
+  objnerf_sample_args b = a;
+  if (table) {
+    b.rgbs = table[k].rgbs; b.depth = table[k].depth; b.t_wc = table[k].t_wc; b.bbox = table[k].bbox;
+    const long n = (long)a.n_frames * a.n_px, S = a.n_cam2surf + a.n_bins;
+    b.kf_ids += (long)k * a.n_frames;
+    b.u_w += k * n; b.u_h += k * n; b.u += k * n * S; b.g += k * n * a.n_bins;
+    b.out_rgb += k * n * 3; b.out_depth += k * n; b.out_valid += k * n; b.out_labels += k * n;
+    b.out_z += k * n * S; b.out_pts += k * n * S * 3;
+    b.max_depth_ws += k * (1 + 6 * n);
+  }
+  return b;
+}
+
+__global__ void sample_gather_kernel(const objnerf_sample_args a_, const objnerf_kf_store* table) {
+  const objnerf_sample_args a = sample_args_of(a_, table, blockIdx.y);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = a.n_frames * a.n_px;
   if (i >= n) return;
+  float* origins_ws = a.max_depth_ws + 1;
+  float* dirs_ws = origins_ws + (size_t)n * 3;
   const int f = i / a.n_px;
   const long kf = a.kf_ids[f];
   const float* bb = a.bbox + kf * 4;
@@ -480,10 +499,13 @@ __global__ void box_points_kernel(long n, int n_bins, const float* origin, const
   for (int x = 0; x < 3; ++x) out_pts[idx * 3 + x] = origin[x] + dirs_W[r * 3 + x] * z;   // :176
 }
 
-__global__ void sample_place_kernel(const objnerf_sample_args a, const float* origins_ws, const float* dirs_ws) {
+__global__ void sample_place_kernel(const objnerf_sample_args a_, const objnerf_kf_store* table) {
+  const objnerf_sample_args a = sample_args_of(a_, table, blockIdx.y);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = a.n_frames * a.n_px;
   if (i >= n) return;
+  const float* origins_ws = a.max_depth_ws + 1;
+  const float* dirs_ws = origins_ws + (size_t)n * 3;
   const int N = a.n_cam2surf, M = a.n_bins, S = N + M;
   const float d = a.out_depth[i];
   const float maxd = *a.max_depth_ws;
@@ -694,13 +716,29 @@ int objnerf_sample_rays(const objnerf_sample_args* a, void* stream) {
     return OBJNERF_EINVAL;
   const int n = a->n_frames * a->n_px;
   hipStream_t st = (hipStream_t)stream;
-  // origins / dirs of the sampled rays live in the tail of the pts output until pass 2 consumes them:
-  // pts has n*S*3 floats with S >= 2, pass 2 reads ray i's 6 floats before writing ray i's points.
-  float* ws = a->max_depth_ws + 1;
+  // (max_depth_ws[0] = the batch depth maximum, then the world-frame origins / directions between the passes)
   (void)hipMemsetAsync(a->max_depth_ws, 0, sizeof(float), st);
-  hipLaunchKernelGGL(sample_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, st, *a, ws, ws + (size_t)n * 3);
+  hipLaunchKernelGGL(sample_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, st, *a, (const objnerf_kf_store*)nullptr);
   CHECK_LAUNCH();
-  hipLaunchKernelGGL(sample_place_kernel, dim3((n + 255) / 256), dim3(256), 0, st, *a, ws, ws + (size_t)n * 3);
+  hipLaunchKernelGGL(sample_place_kernel, dim3((n + 255) / 256), dim3(256), 0, st, *a, (const objnerf_kf_store*)nullptr);
+  CHECK_LAUNCH();
+  return OBJNERF_OK;
+}
+
+int objnerf_sample_rays_stacked(const objnerf_sample_args* a, int32_t K, const objnerf_kf_store* table, void* stream) {
+  CLEAR_STALE();
+  if (!a || !table || K <= 0 || K > 65535 || !a->rays_dir_cache || !a->kf_ids || !a->u_w || !a->u_h || !a->u || !a->g ||
+      !a->out_rgb || !a->out_depth || !a->out_valid || !a->out_labels || !a->out_z || !a->out_pts || !a->max_depth_ws ||
+      a->n_frames <= 0 || a->n_px <= 0 || a->n_cam2surf <= 0 || a->n_bins <= 0)
+    return OBJNERF_EINVAL;
+  const int n = a->n_frames * a->n_px;
+  hipStream_t st = (hipStream_t)stream;
+  // the K depth maxima sit (1 + 6 n) floats apart: clearing the whole scratch is one call
+  (void)hipMemsetAsync(a->max_depth_ws, 0, (size_t)K * (1 + 6 * (size_t)n) * sizeof(float), st);
+  const dim3 grid((n + 255) / 256, K);
+  hipLaunchKernelGGL(sample_gather_kernel, grid, dim3(256), 0, st, *a, table);
+  CHECK_LAUNCH();
+  hipLaunchKernelGGL(sample_place_kernel, grid, dim3(256), 0, st, *a, table);
   CHECK_LAUNCH();
   return OBJNERF_OK;
 }

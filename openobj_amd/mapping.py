@@ -30,7 +30,7 @@ import torch
 from . import dist as odist
 from . import ops
 from . import train as otrain
-from .vmap import cameraInfo, sceneObject
+from .vmap import StackedSampler, cameraInfo, sceneObject
 
 
 def get_majority_cluster_mean(vectors, eps, min_samples):
@@ -64,6 +64,8 @@ class IncrementalMapper:
         self.loop: Optional[otrain.HipTrainLoop] = None
         self.bg_loop: Optional[otrain.BackgroundLoop] = None
         self._restack = False
+        self._sampler: Optional[StackedSampler] = None
+        self._sampler_ids = ()
         self.last_twc = None
         self.last_frame_id = None
 
@@ -160,12 +162,22 @@ class IncrementalMapper:
             lo, hi = odist.shard_rays(cfg.n_samples_per_frame_bg, self.world, self.rank)     # this rank's share
             bp = self._pool_of(self.scene_bg, cfg.n_iter_per_frame * cfg.win_size_bg, hi - lo)
             bg_pool = {k: v[None] for k, v in bp.items()}
-        pools = [self._pool_of(o, cfg.n_iter_per_frame * cfg.win_size, cfg.n_samples_per_frame)
-                 for o in self.obj_dict.values()]
-        if not pools:
+        if not self.obj_dict:
             assert self.world > 1, "no foreground object in the map yet"  # train.py:366
             return None, bg_pool
-        return {k: torch.stack([p[k] for p in pools]) for k in pools[0]}, bg_pool
+        # every foreground object in ONE launch chain, outputs already stacked (train.py:316-330,368-388)
+        if self._sampler_ids != tuple(self.obj_dict):
+            self._sampler = StackedSampler(self.obj_dict.values())
+            self._sampler_ids = tuple(self.obj_dict)
+        rgb, depth, _valid, labels, pts, z, feat = self._sampler.sample(
+            cfg.n_iter_per_frame * cfg.win_size, cfg.n_samples_per_frame, self.cam_info.rays_dir_cache,
+            self.global_partfeat)
+        tdev = cfg.training_device
+        pool = {"pts": pts.to(tdev), "z": z.to(tdev), "gt_depth": depth.to(tdev),
+                "gt_rgb": rgb.to(tdev).float() / 255.0, "labels": labels.to(tdev)}
+        if cfg.part_mode:
+            pool["gt_feat"] = feat.to(tdev).float()
+        return pool, bg_pool
 
     # ------------------------------------------------------------------ train.py:394-485
     def train_frame(self):

@@ -372,6 +372,50 @@ def adamw_step(arena: ParamArena, grads: torch.Tensor, exp_avg: torch.Tensor, ex
                                    _stream()), "objnerf_adamw_step")
 
 
+def keyframe_table(stores) -> torch.Tensor:
+    """Device descriptor table of objnerf_sample_rays_stacked: stores = [(rgbs_batch, depth_batch, t_wc_batch, bbox)]
+    per object (the tensors must stay alive and in place while the table is used).  int64 [K, 4] of device pointers."""
+    rows = []
+    for rgbs, depth, t_wc, bbox in stores:
+        _req(rgbs, torch.uint8, "rgbs_batch"); _req(depth, torch.float32, "depth_batch")
+        _req(t_wc, torch.float32, "t_wc_batch"); _req(bbox, torch.float32, "bbox")
+        rows.append([rgbs.data_ptr(), depth.data_ptr(), t_wc.data_ptr(), bbox.data_ptr()])
+    return torch.tensor(rows, dtype=torch.int64).to(stores[0][0].device)
+
+
+def sample_rays_stacked(table: torch.Tensor, F: int, W: int, H: int, rays_dir_cache, kf_ids, u_w, u_h, u, g,
+                        n_cam2surf: int, n_bins: int, surface_eps: float, stop_eps: float, min_bound: float = 0.0,
+                        obj_center: float = 0.0):
+    """sample_rays for K objects in one launch chain: kf_ids [K, n_frames], u_w / u_h [K, n_frames, n_px],
+    u [K, n, N+M], g [K, n, M].  Returns the STACKED batch tensors (rgb u8 [K,n,3], depth [K,n], valid [K,n] bool,
+    labels u8 [K,n], pts [K,n,S,3], z [K,n,S])."""
+    table = _req(table, torch.int64, "table")
+    rays_dir_cache = _req(rays_dir_cache, torch.float32, "rays_dir_cache")
+    kf_ids = _req(kf_ids, torch.int64, "kf_ids")
+    u_w, u_h = _req(u_w, torch.float32, "u_w"), _req(u_h, torch.float32, "u_h")
+    u, g = _req(u, torch.float32, "u"), _req(g, torch.float32, "g")
+    K, n_frames, n_px = u_w.shape
+    if table.shape != (K, 4) or kf_ids.shape != (K, n_frames):
+        raise ObjnerfError("sample_rays_stacked: table / kf_ids do not match the draws")
+    n = n_frames * n_px
+    S = n_cam2surf + n_bins
+    if u.shape != (K, n, S) or g.shape != (K, n, n_bins):
+        raise ObjnerfError("sample_rays_stacked: u / g shapes")
+    dev = table.device
+    out_rgb = torch.empty(K, n, 3, dtype=torch.uint8, device=dev)
+    out_depth = torch.empty(K, n, device=dev)
+    out_valid = torch.empty(K, n, dtype=torch.uint8, device=dev)
+    out_labels = torch.empty(K, n, dtype=torch.uint8, device=dev)
+    out_z = torch.empty(K, n, S, device=dev)
+    out_pts = torch.empty(K, n, S, 3, device=dev)
+    ws = torch.empty(K, 1 + 6 * n, device=dev)
+    a = SampleArgs(F, W, H, n_frames, n_px, n_cam2surf, n_bins, 0, surface_eps, stop_eps, min_bound, obj_center,
+                   None, None, None, None, _ptr(rays_dir_cache), _ptr(kf_ids), _ptr(u_w), _ptr(u_h), _ptr(u), _ptr(g),
+                   _ptr(out_rgb), _ptr(out_depth), _ptr(out_valid), _ptr(out_labels), _ptr(out_z), _ptr(out_pts), _ptr(ws))
+    check(lib().objnerf_sample_rays_stacked(C.byref(a), K, _ptr(table), _stream()), "objnerf_sample_rays_stacked")
+    return out_rgb, out_depth, out_valid.bool(), out_labels, out_pts, out_z
+
+
 def rays_dirs(W: int, H: int, fx: float, fy: float, cx: float, cy: float, device) -> torch.Tensor:
     out = torch.empty(W, H, 3, device=device)
     check(lib().objnerf_rays_dirs(W, H, fx, fy, cx, cy, _ptr(out), _stream()), "objnerf_rays_dirs")

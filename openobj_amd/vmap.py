@@ -187,6 +187,10 @@ class sceneObject:
                                        torch.floor(idx_h / self.part_down).long()]
         return rgb, depth, valid, labels, pts, z, partfeat
 
+    def keyframe_store(self):
+        """The four device tensors the sampler reads (fixed addresses for the life of the object)."""
+        return self.rgbs_batch, self.depth_batch, self.t_wc_batch, self.bbox
+
     def set_semantic(self, semantic_id):                                  # vmap.py:284-285
         self.semantic_id = semantic_id
 
@@ -292,3 +296,64 @@ class sceneObject:
         self.semantic_id = checkpoint["semantic_id"]
         self.bbox_final = True
         return True
+
+
+class StackedSampler:
+    """get_training_samples for a LIST of objects in one launch chain (train.py:316-330 + the stacking of
+    train.py:368-388): one set of random draws for all objects, objnerf_sample_rays_stacked, outputs already in the
+    [K, n, ...] layout of the training step.  The objects must share the sampler configuration (every foreground
+    object does, vmap.py:53-62).  Rebuild it when the list of objects changes (the descriptor table holds their
+    keyframe-store addresses)."""
+
+    def __init__(self, objs):
+        self.objs = list(objs)
+        o = self.objs[0]
+        for x in self.objs:
+            assert (x.n_bins_cam2surface, x.n_bins, x.keyframe_buffer_size, x.frames_width, x.frames_height) == \
+                   (o.n_bins_cam2surface, o.n_bins, o.keyframe_buffer_size, o.frames_width, o.frames_height)
+        self.table = ops.keyframe_table([x.keyframe_store() for x in self.objs])
+
+    def draw(self, n_frames, n_samples):
+        """kf_ids as draw_keyframe_ids (uniform over the stored keyframes, the latest two always included, LAST),
+        pixel / depth draws as get_training_samples -- for all objects at once."""
+        o, K = self.objs[0], len(self.objs)
+        dev = o.data_device
+        N, M = o.n_bins_cam2surface, o.n_bins
+        n = n_frames * n_samples
+        nk = torch.tensor([x.n_keyframes for x in self.objs], dtype=torch.float32)
+        last = torch.tensor([(x.lastest_kf_queue[-2:] if x.n_keyframes > 2 else [-1, -1]) for x in self.objs],
+                            dtype=torch.int64)
+        meta = torch.cat([nk[:, None], last.float()], dim=1).to(dev)            # one small host -> device copy
+        kf = torch.floor(torch.rand(K, n_frames, device=dev) * meta[:, :1]).long()
+        kf = torch.minimum(kf, (meta[:, :1] - 1).long())                        # (rand() < 1, guard the rounding)
+        if n_frames >= 2:
+            tail = meta[:, 1:].long()
+            kf[:, -2:] = torch.where(tail >= 0, tail, kf[:, -2:])
+        return dict(kf_ids=kf, u_w=torch.rand(K, n_frames, n_samples, device=dev),
+                    u_h=torch.rand(K, n_frames, n_samples, device=dev), u=torch.rand(K, n, N + M, device=dev),
+                    g=torch.empty(K, n, M, device=dev).normal_(mean=0., std=o.surface_eps / 3.))
+
+    def sample(self, n_frames, n_samples, cached_rays_dir, global_partfeat=None, draws=None):
+        """-> (rgb u8 [K,n,3], depth [K,n], valid [K,n], labels u8 [K,n], pts [K,n,S,3], z [K,n,S], partfeat | None)"""
+        o = self.objs[0]
+        if draws is None:
+            draws = self.draw(n_frames, n_samples)
+        rgb, depth, valid, labels, pts, z = ops.sample_rays_stacked(
+            self.table, o.keyframe_buffer_size, o.frames_width, o.frames_height, cached_rays_dir, draws["kf_ids"],
+            draws["u_w"], draws["u_h"], draws["u"], draws["g"], o.n_bins_cam2surface, o.n_bins, o.surface_eps,
+            o.stop_eps, float(o.min_bound), float(o.obj_center))
+        partfeat = None
+        if o.part_mode and global_partfeat is not None:                        # vmap.py:437-452, all objects at once
+            dev = o.data_device
+            K = len(self.objs)
+            kf = draws["kf_ids"]                                                # [K, n_frames]
+            bbox = torch.stack([x.bbox for x in self.objs])                     # [K, F, 4]
+            bb = torch.gather(bbox, 1, kf[:, :, None].expand(-1, -1, 4))[:, :, None, :]      # [K, n_frames, 1, 4]
+            idx_w = draws["u_w"] * (bb[..., 1] - bb[..., 0]) + bb[..., 0]
+            idx_h = draws["u_h"] * (bb[..., 3] - bb[..., 2]) + bb[..., 2]
+            use = torch.tensor(np.stack([x.use_frame for x in self.objs])).to(dev)            # [K, F]
+            fid = (torch.gather(use, 1, kf) / o.stride).long()[:, :, None]
+            partfeat = global_partfeat[fid, torch.floor(idx_w / o.part_down).long(),
+                                       torch.floor(idx_h / o.part_down).long()]
+            partfeat = partfeat.reshape(K, n_frames * n_samples, -1)
+        return rgb, depth, valid, labels, pts, z, partfeat

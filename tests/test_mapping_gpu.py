@@ -159,3 +159,40 @@ def test_files_to_novel_view(dev, tmp_path):
     seen = wall & (buf.maskid.T == 0) & (got.sum(-1) > 0)
     assert seen.mean() > 0.5 * wall.mean()                       # the background network paints most of the wall
     assert np.abs(got[seen] - want[seen]).mean() < 40.0
+
+
+def test_stacked_sampler_equals_per_object(dev, tmp_path):
+    """objnerf_sample_rays_stacked (all objects, one launch chain) against objnerf_sample_rays per object with the same
+    draws: identical bits, including the part-feature gather."""
+    from openobj_amd import vmap as ovmap
+    root = tmp_path / "scene"
+    SF.write_scene(str(root), "Replica", n_frames=40, part_dim=8, part_down=4)
+    c = make_cfg(root, dev, **{"trainer.part_mode": 1, "trainer.part_down": 4, "model.keyframe_step": 10})
+    ds = ods.Replica(c)
+    m = mapping.IncrementalMapper(c)
+    for i in range(4):
+        m.ingest(ds[i], i)
+    objs = list(m.obj_dict.values())
+    assert len(objs) == 2 and objs[0].n_keyframes >= 3
+    objs[1].n_keyframes = 2                                  # one object still without the "latest two" rule
+    sampler = ovmap.StackedSampler(objs)
+    n_frames, n_px = 9, 7
+    draws = sampler.draw(n_frames, n_px)
+    kf = draws["kf_ids"]
+    assert kf.shape == (2, n_frames) and int(kf[0].max()) < objs[0].n_keyframes and int(kf[1].max()) < 2
+    assert kf[0, -2:].tolist() == objs[0].lastest_kf_queue[-2:]
+    out = sampler.sample(n_frames, n_px, m.cam_info.rays_dir_cache, m.global_partfeat, draws=draws)
+    for k, o in enumerate(objs):
+        one = o.get_training_samples(n_frames, n_px, m.cam_info.rays_dir_cache, m.global_partfeat,
+                                     draws={key: v[k] for key, v in draws.items()})
+        names = ["rgb", "depth", "valid", "labels", "pts", "z", "partfeat"]
+        for name, a, b in zip(names, out, one):
+            assert torch.equal(a[k].reshape(-1), b.reshape(-1).to(a.dtype)), (k, name)
+    # the distribution of the un-injected keyframe draws: uniform over the stored keyframes
+    objs[1].n_keyframes = 3
+    objs[1].lastest_kf_queue = [1, 2]
+    kf = torch.stack([sampler.draw(50, 1)["kf_ids"] for _ in range(20)])          # [20, 2, 50]
+    assert kf[:, :, -2:].reshape(-1, 2).unique(dim=0).shape[0] <= 2               # always the latest two, last
+    head = kf[:, 0, :-2].reshape(-1)
+    cnt = torch.bincount(head, minlength=objs[0].n_keyframes).float()
+    assert cnt.min() > 0.5 * cnt.mean()
