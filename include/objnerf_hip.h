@@ -103,6 +103,24 @@ typedef struct objnerf_kf_store {
 int objnerf_sample_rays_stacked(const objnerf_sample_args* a, int32_t K, const objnerf_kf_store* table, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * f-3  Frame ingestion (train.py:196-256 + sceneObject.__init__ / append_keyframe, vmap.py:29-257): one new frame is
+ * written into a keyframe slot of EVERY object that is visible in it, in one launch.  Per object the reference
+ * builds a state map from the instance image (1 = this object, 2 = unknown (-1), 0 = other; train.py:201-203) and
+ * copies rgb + state, depth, the camera pose and the 2-D box into the slot.
+ *   rgb [W][H][3] u8, depth [W][H], inst [W][H] int32, t_wc [16]: the frame (device, images stored transposed)
+ *   items: DEVICE array of K records: the object's four store tensors (layouts of objnerf_sample_rays), the slot
+ *   to write, the instance id that means "this object" and its 2-D box.  Slot selection (keyframe / live frame /
+ *   pruning, vmap.py:166-257) is host bookkeeping and stays with the caller.
+ */
+typedef struct objnerf_ingest_item {
+  uint8_t* rgbs; float* depth; float* t_wc; float* bbox;
+  int32_t slot, obj_id;
+  float box[4];
+} objnerf_ingest_item;
+int objnerf_ingest_frame(int32_t W, int32_t H, const uint8_t* rgb, const float* depth, const int32_t* inst,
+                         const float* t_wc, int32_t K, const objnerf_ingest_item* items, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * f-1  Trainer.sample_points_bbox (trainer.py:130-198), the sampler of render_2D_syn (vmap.py:604-685).
  * objnerf_box_rays: P camera rays dirs_C [P][3] (un-normalised, rays_dir_cache[pixels]) of ONE view against an
  *   oriented box: T_WC, T_OC = inverse(T_WO) @ T_WC (both [4][4] row-major, computed by the caller as

@@ -46,6 +46,11 @@ class SampleArgs(C.Structure):
                 ("max_depth_ws", C.c_void_p)]
 
 
+class IngestItem(C.Structure):
+    _fields_ = [("rgbs", C.c_void_p), ("depth", C.c_void_p), ("t_wc", C.c_void_p), ("bbox", C.c_void_p),
+                ("slot", C.c_int32), ("obj_id", C.c_int32), ("box", C.c_float * 4)]
+
+
 class LossArgs(C.Structure):
     _fields_ = [("K", C.c_int32), ("R", C.c_int32), ("S", C.c_int32), ("C", C.c_int32),
                 ("color_scaling", C.c_float), ("opacity_scaling", C.c_float),
@@ -82,6 +87,8 @@ SIGNATURES = {
                                     C.c_void_p, C.c_void_p]),
     "objnerf_sample_rays": (C.c_int, [C.POINTER(SampleArgs), C.c_void_p]),
     "objnerf_sample_rays_stacked": (C.c_int, [C.POINTER(SampleArgs), C.c_int32, C.c_void_p, C.c_void_p]),
+    "objnerf_ingest_frame": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                       C.c_void_p, C.c_void_p]),
     "objnerf_box_rays": (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p]),
     "objnerf_box_points": (C.c_int, [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -450,6 +450,27 @@ __global__ void sample_gather_kernel(const objnerf_sample_args a_, const objnerf
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// train.py:196-256: one frame into a keyframe slot of every visible object (blockIdx.y = object)
+// ------------------------------------------------------------------------------------------------
+__global__ void ingest_frame_kernel(int W, int H, const uint8_t* rgb, const float* depth, const int32_t* inst,
+                                    const float* t_wc, const objnerf_ingest_item* items) {
+  const objnerf_ingest_item it = items[blockIdx.y];
+  const long npx = (long)W * H;
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.x == 0) {
+    if (threadIdx.x < 16) it.t_wc[(long)it.slot * 16 + threadIdx.x] = t_wc[threadIdx.x];
+    if (threadIdx.x < 4) it.bbox[(long)it.slot * 4 + threadIdx.x] = it.box[threadIdx.x];
+  }
+  if (p >= npx) return;
+  const int id = inst[p];
+  const uint32_t state = id == it.obj_id ? 1u : (id == -1 ? 2u : 0u);        // train.py:201-203
+  const uint32_t px = (uint32_t)rgb[p * 3] | ((uint32_t)rgb[p * 3 + 1] << 8) | ((uint32_t)rgb[p * 3 + 2] << 16) |
+                      (state << 24);
+  reinterpret_cast<uint32_t*>(it.rgbs)[(long)it.slot * npx + p] = px;        // [F][W][H][4] u8: rgb + state
+  it.depth[(long)it.slot * npx + p] = depth[p];
+}
+
 __device__ __forceinline__ float lin01(int i, int n) {           // torch.linspace(0,1,n+1)[i], fp32
   const float step = 1.0f / (float)n;
   return (i < (n + 1) / 2) ? step * (float)i : 1.0f - step * (float)(n - i);
@@ -721,6 +742,17 @@ int objnerf_sample_rays(const objnerf_sample_args* a, void* stream) {
   hipLaunchKernelGGL(sample_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, st, *a, (const objnerf_kf_store*)nullptr);
   CHECK_LAUNCH();
   hipLaunchKernelGGL(sample_place_kernel, dim3((n + 255) / 256), dim3(256), 0, st, *a, (const objnerf_kf_store*)nullptr);
+  CHECK_LAUNCH();
+  return OBJNERF_OK;
+}
+
+int objnerf_ingest_frame(int32_t W, int32_t H, const uint8_t* rgb, const float* depth, const int32_t* inst,
+                         const float* t_wc, int32_t K, const objnerf_ingest_item* items, void* stream) {
+  CLEAR_STALE();
+  if (W <= 0 || H <= 0 || K <= 0 || K > 65535 || !rgb || !depth || !inst || !t_wc || !items) return OBJNERF_EINVAL;
+  const long npx = (long)W * H;
+  hipLaunchKernelGGL(ingest_frame_kernel, dim3((unsigned)((npx + 255) / 256), K), dim3(256), 0, (hipStream_t)stream, W, H,
+                     rgb, depth, inst, t_wc, items);
   CHECK_LAUNCH();
   return OBJNERF_OK;
 }

@@ -83,25 +83,23 @@ class IncrementalMapper:
             part = _to_dev(sample["part_feat"], dev, torch.float32)
             self.global_partfeat = part.unsqueeze(0) if self.global_partfeat is None else \
                 torch.cat((self.global_partfeat, part.unsqueeze(0)), dim=0)
-        inst = _to_dev(sample["obj"], dev)
-        unknown = inst == -1
+        inst = _to_dev(sample["obj"], dev, torch.int32)
         created = []
+        writes = []                     # (object, slot, 2-D box): every slot of this frame is written in ONE launch
         for obj_id in torch.unique(inst).tolist():
             if obj_id == -1:
                 continue
             obj_id = int(obj_id)
             if obj_id not in bbox_dict:
                 continue        # (a label without a box cannot be sampled; the reference would raise KeyError)
-            state = torch.zeros_like(inst, dtype=torch.uint8)            # 0 other, 1 this object, 2 unknown
-            state[inst == obj_id] = 1
-            state[unknown] = 2
-            bbox = _to_dev(bbox_dict[obj_id], dev, torch.float32)
+            if obj_id in self.remote_ids:
+                continue
+            bbox = torch.as_tensor(np.asarray(bbox_dict[obj_id])).float()       # host; the kernel takes it by value
             clip_feat, cap_feat = _first(obj_clip[obj_id]), obj_cap[obj_id]
             if obj_id in self.vis_dict:
-                self.vis_dict[obj_id].append_keyframe(rgb, depth, state, bbox, twc, live_frame_id,
-                                                      clip_feat=clip_feat, caption_feat=cap_feat)
-                continue
-            if obj_id in self.remote_ids:
+                so = self.vis_dict[obj_id]
+                so._defer = writes
+                so.append_keyframe(rgb, depth, None, bbox, twc, live_frame_id, clip_feat=clip_feat, caption_feat=cap_feat)
                 continue
             is_bg = cfg.do_bg and obj_id == 0
             if not is_bg:
@@ -112,8 +110,8 @@ class IncrementalMapper:
                 if owner != self.rank:
                     self.remote_ids.add(obj_id)
                     continue
-            so = sceneObject(cfg, obj_id, rgb, depth, state, bbox, twc, live_frame_id, clip_feat=clip_feat,
-                             caption_feat=cap_feat)
+            so = sceneObject(cfg, obj_id, rgb, depth, None, bbox, twc, live_frame_id, clip_feat=clip_feat,
+                             caption_feat=cap_feat, defer=writes)
             if is_bg:
                 self.scene_bg = so
                 odist.broadcast_(so.trainer.arena.params, 0, self.group)      # identical replicas
@@ -124,6 +122,12 @@ class IncrementalMapper:
                 self._restack = True
             self.vis_dict[obj_id] = so
             created.append(obj_id)
+        if writes:
+            # state map (1 this object / 2 unknown / 0 other, train.py:201-203) + rgb, depth, pose, box -> the slots
+            ops.ingest_frame(rgb, depth, inst, twc, [(so.keyframe_store(), slot, so.obj_id, box.tolist())
+                                                     for so, slot, box in writes])
+            for so, _, _ in writes:
+                so._defer = None
         self.last_twc, self.last_frame_id = twc, live_frame_id
         return created
 

@@ -372,6 +372,29 @@ def adamw_step(arena: ParamArena, grads: torch.Tensor, exp_avg: torch.Tensor, ex
                                    _stream()), "objnerf_adamw_step")
 
 
+def ingest_frame(rgb, depth, inst, t_wc, items) -> None:
+    """One frame into a keyframe slot of every visible object, one launch (train.py:196-256).
+    rgb u8 [W,H,3], depth f32 [W,H], inst int32 [W,H], t_wc f32 [4,4] on the device;
+    items = [(store tensors (rgbs_batch, depth_batch, t_wc_batch, bbox), slot, obj_id, box[4])]."""
+    import numpy as np
+    from ._lib import IngestItem
+    rgb = _req(rgb, torch.uint8, "rgb")
+    depth = _req(depth, torch.float32, "depth")
+    inst = _req(inst, torch.int32, "inst")
+    t_wc = _req(t_wc, torch.float32, "t_wc")
+    W, H = depth.shape
+    arr = (IngestItem * len(items))()
+    for i, ((rgbs_b, depth_b, twc_b, bbox_b), slot, obj_id, box) in enumerate(items):
+        if rgbs_b.shape[1:] != (W, H, 4) or depth_b.shape[1:] != (W, H) or not 0 <= slot < rgbs_b.shape[0]:
+            raise ObjnerfError("ingest_frame: store / frame shapes do not match")
+        arr[i] = IngestItem(rgbs_b.data_ptr(), depth_b.data_ptr(), twc_b.data_ptr(), bbox_b.data_ptr(), int(slot),
+                            int(obj_id), (C.c_float * 4)(*[float(v) for v in box]))
+    host = torch.from_numpy(np.frombuffer(arr, dtype=np.uint8).copy())
+    dev_items = host.to(rgb.device)
+    check(lib().objnerf_ingest_frame(W, H, _ptr(rgb), _ptr(depth), _ptr(inst), _ptr(t_wc), len(items), _ptr(dev_items),
+                                     _stream()), "objnerf_ingest_frame")
+
+
 def keyframe_table(stores) -> torch.Tensor:
     """Device descriptor table of objnerf_sample_rays_stacked: stores = [(rgbs_batch, depth_batch, t_wc_batch, bbox)]
     per object (the tensors must stay alive and in place while the table is used).  int64 [K, 4] of device pointers."""

@@ -36,7 +36,10 @@ class sceneObject:
     """Keyframe ring buffers of one object + its Trainer (networks)."""
 
     def __init__(self, cfg, obj_id, rgb, depth, mask, bbox_2d, t_wc, live_frame_id, clip_feat=None,
-                 caption_feat=None) -> None:
+                 caption_feat=None, defer=None) -> None:
+        """defer: a list -- the frame is NOT written here; (self, slot, bbox_2d) is appended to it and the caller
+        writes every object's slot of this frame in one launch (ops.ingest_frame; mask may then be None)."""
+        self._defer = defer
         self.do_bg = cfg.do_bg
         self.obj_id = obj_id
         self.data_device = cfg.data_device
@@ -44,7 +47,7 @@ class sceneObject:
         self.part_mode = cfg.part_mode
         self.stride = cfg.stride
         assert rgb.shape[:2] == depth.shape
-        assert rgb.shape[:2] == mask.shape
+        assert defer is not None or rgb.shape[:2] == mask.shape
         assert bbox_2d.shape == (4,)
         assert t_wc.shape == (4, 4,)
         if self.do_bg and self.obj_id == 0:      # separate background network (vmap.py:43-52)
@@ -73,7 +76,8 @@ class sceneObject:
         self.clip_feat, self.caption_feat = clip_feat, caption_feat
         dev = self.data_device
         self.bbox = torch.empty(self.keyframe_buffer_size, 4, device=dev)
-        self.bbox[0] = bbox_2d
+        if defer is None:
+            self.bbox[0] = bbox_2d
         self.rgb_idx, self.state_idx = slice(0, 3), slice(3, 4)
         self.rgbs_batch = torch.empty(self.keyframe_buffer_size, self.frames_width, self.frames_height, 4,
                                       dtype=torch.uint8, device=dev)
@@ -83,13 +87,16 @@ class sceneObject:
             self.use_frame[0] = live_frame_id
         self.other_obj, self.this_obj, self.unknown_obj = 0, 1, 2
         self.semantic_id = None
-        self.rgbs_batch[0, :, :, self.rgb_idx] = rgb
-        self.rgbs_batch[0, :, :, self.state_idx] = mask[..., None]
         self.depth_batch = torch.empty(self.keyframe_buffer_size, self.frames_width, self.frames_height,
                                        dtype=torch.float32, device=dev)
-        self.depth_batch[0] = depth
         self.t_wc_batch = torch.empty(self.keyframe_buffer_size, 4, 4, dtype=torch.float32, device=dev)
-        self.t_wc_batch[0] = t_wc
+        if defer is None:
+            self.rgbs_batch[0, :, :, self.rgb_idx] = rgb
+            self.rgbs_batch[0, :, :, self.state_idx] = mask[..., None]
+            self.depth_batch[0] = depth
+            self.t_wc_batch[0] = t_wc
+        else:
+            defer.append((self, 0, bbox_2d))
         trainer_cfg = copy.deepcopy(cfg)
         trainer_cfg.obj_id = self.obj_id
         trainer_cfg.hidden_feature_size = self.hidden_feature_size
@@ -101,6 +108,11 @@ class sceneObject:
 
     # ------------------------------------------------------------------ keyframes (vmap.py:166-257)
     def _write_slot(self, slot, rgb, depth, mask, bbox_2d, t_wc, frame_id):
+        if self._defer is not None:             # the caller writes all objects' slots of this frame in one launch
+            self._defer.append((self, slot, bbox_2d))
+            if self.part_mode:
+                self.use_frame[slot] = frame_id
+            return
         self.rgbs_batch[slot, :, :, self.rgb_idx] = rgb
         self.rgbs_batch[slot, :, :, self.state_idx] = mask[..., None]
         self.depth_batch[slot, ...] = depth
@@ -116,10 +128,11 @@ class sceneObject:
         self.kf_id_dict[frame_id] = slot
 
     def append_keyframe(self, rgb, depth, mask, bbox_2d, t_wc, frame_id=1, clip_feat=None, caption_feat=None):
-        assert rgb.shape[:2] == depth.shape and rgb.shape[:2] == mask.shape
+        assert rgb.shape[:2] == depth.shape and (self._defer is not None or rgb.shape[:2] == mask.shape)
         assert bbox_2d.shape == (4,) and t_wc.shape == (4, 4,)
         assert self.n_keyframes <= self.keyframe_buffer_size - 1
-        assert rgb.dtype == torch.uint8 and mask.dtype == torch.uint8 and depth.dtype == torch.float32
+        assert rgb.dtype == torch.uint8 and depth.dtype == torch.float32
+        assert self._defer is not None or mask.dtype == torch.uint8
         is_kf = (self.frame_cnt % self.keyframe_step == 0) or self.n_keyframes == 1
         if self.n_keyframes == self.keyframe_buffer_size - 1:      # buffer full: overwrite the free slot
             self.kf_buffer_full = True

@@ -196,3 +196,41 @@ def test_stacked_sampler_equals_per_object(dev, tmp_path):
     head = kf[:, 0, :-2].reshape(-1)
     cnt = torch.bincount(head, minlength=objs[0].n_keyframes).float()
     assert cnt.min() > 0.5 * cnt.mean()
+
+
+def test_batched_ingest_equals_per_object(dev, tmp_path):
+    """objnerf_ingest_frame (every visible object's keyframe slot in one launch) against the reference's per-object
+    sequence: state map from the instance image, then sceneObject(...) / append_keyframe (train.py:196-256)."""
+    from openobj_amd import vmap as ovmap
+    root = tmp_path / "scene"
+    SF.write_scene(str(root), "Replica", n_frames=60)
+    c = make_cfg(root, dev, **{"model.keyframe_step": 10})          # keyframe every frame at stride 10
+    ds = ods.Replica(c)
+    m = mapping.IncrementalMapper(c)
+    ref = {}
+    for i in range(6):
+        s = ds[i]
+        m.ingest(s, i)
+        rgb = torch.as_tensor(s["image"]).to(dev)
+        depth = torch.as_tensor(s["depth"]).to(dev)
+        inst = torch.as_tensor(s["obj"]).to(dev)
+        twc = torch.as_tensor(s["T"]).float().to(dev)
+        for oid in torch.unique(inst).tolist():
+            if oid == -1:
+                continue
+            state = torch.zeros_like(inst, dtype=torch.uint8)
+            state[inst == oid] = 1
+            state[inst == -1] = 2
+            bbox = s["bbox_dict"][oid].float().to(dev)
+            if oid in ref:
+                ref[oid].append_keyframe(rgb, depth, state, bbox, twc, s["frame_id"])
+            else:
+                ref[oid] = ovmap.sceneObject(c, oid, rgb, depth, state, bbox, twc, s["frame_id"])
+    assert sorted(ref) == sorted(m.vis_dict) == [0, 4, 7]
+    for oid, r in ref.items():
+        o = m.vis_dict[oid]
+        n = r.n_keyframes
+        assert o.n_keyframes == n and o.kf_id_dict == r.kf_id_dict and o.lastest_kf_queue == r.lastest_kf_queue and n >= 2
+        assert torch.equal(o.rgbs_batch[:n], r.rgbs_batch[:n]) and torch.equal(o.depth_batch[:n], r.depth_batch[:n])
+        assert torch.equal(o.t_wc_batch[:n], r.t_wc_batch[:n]) and torch.equal(o.bbox[:n], r.bbox[:n])
+        assert o._defer is None
