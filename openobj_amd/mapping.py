@@ -192,13 +192,17 @@ class IncrementalMapper:
         out = {"obj": [], "bg": []}
         npo = cfg.n_per_optim
         npo_bg = bg_pool["z"].shape[1] // cfg.n_iter_per_frame if bg_pool is not None else 0
+        if pool is not None:
+            # iteration i trains on rays [i npo, (i+1) npo) of every object (train.py:396-404): re-lay the pool ONCE
+            # as [n_iter, K, npo, ...] so that each iteration's batch is a contiguous view (no per-iteration copies)
+            pool = {k: v.reshape(v.shape[0], cfg.n_iter_per_frame, npo, *v.shape[2:]).transpose(0, 1).contiguous()
+                    for k, v in pool.items()}
         sharded = odist._active(self.group)
         gflags = torch.zeros(2, dtype=torch.int32, device=cfg.training_device) if sharded else None
         for it in range(cfg.n_iter_per_frame):
             batch = None
             if pool is not None:
-                sl = slice(it * npo, (it + 1) * npo)
-                batch = {k: v[:, sl].contiguous() for k, v in pool.items()}
+                batch = {k: v[it] for k, v in pool.items()}
             if sharded:
                 # render_rays.py:89-94: one empty mask anywhere in the stacked batch zeroes that term for ALL objects
                 if batch is not None:

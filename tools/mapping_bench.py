@@ -67,6 +67,8 @@ for i in range(a.frames):
     pool, bg_pool = m.sample_pools()
     sync(); t2 = time.perf_counter()
     npo, npo_bg = c.n_per_optim, c.n_per_optim_bg
+    pool = {k: v.reshape(v.shape[0], c.n_iter_per_frame, npo, *v.shape[2:]).transpose(0, 1).contiguous()
+            for k, v in pool.items()}                   # as IncrementalMapper.train_frame: [n_iter, K, npo, ...]
     if a.overlap:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -74,12 +76,12 @@ for i in range(a.frames):
             for it in range(c.n_iter_per_frame):
                 m.bg_loop.step({k: v[:, it * npo_bg:(it + 1) * npo_bg].contiguous() for k, v in bg_pool.items()})
         for it in range(c.n_iter_per_frame):
-            m.loop.step({k: v[:, it * npo:(it + 1) * npo].contiguous() for k, v in pool.items()})
+            m.loop.step({k: v[it] for k, v in pool.items()})
         torch.cuda.current_stream().wait_stream(side)
     else:
         for it in range(c.n_iter_per_frame):
             if a.only != "bg":
-                m.loop.step({k: v[:, it * npo:(it + 1) * npo].contiguous() for k, v in pool.items()})
+                m.loop.step({k: v[it] for k, v in pool.items()})
             if a.only != "obj":
                 m.bg_loop.step({k: v[:, it * npo_bg:(it + 1) * npo_bg].contiguous() for k, v in bg_pool.items()})
     sync(); t3 = time.perf_counter()
