@@ -21,6 +21,7 @@ The class-name text features (CLIP ViT-B/32 and SBERT encoders in the reference,
 here: pass `class_clipfeat` / `class_capfeat` arrays to `assign_semantics`.  Visualisation, meshing and the live
 ROS mode are outside the path.
 """
+import contextlib
 import os
 from typing import Dict, List, Optional
 
@@ -66,6 +67,7 @@ class IncrementalMapper:
         self._restack = False
         self._sampler: Optional[StackedSampler] = None
         self._sampler_ids = ()
+        self._side = None
         self.last_twc = None
         self.last_frame_id = None
 
@@ -199,6 +201,14 @@ class IncrementalMapper:
                     for k, v in pool.items()}
         sharded = odist._active(self.group)
         gflags = torch.zeros(2, dtype=torch.int32, device=cfg.training_device) if sharded else None
+        # The object stack and the background network are independent chains (own parameters, optimiser state and
+        # batches): on one GPU the background steps run on a second stream beside the fused object kernel.
+        side = None
+        if bg_pool is not None and pool is not None and not sharded and torch.device(cfg.training_device).type == "cuda":
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=cfg.training_device)
+            side = self._side
+            side.wait_stream(torch.cuda.current_stream(cfg.training_device))
         for it in range(cfg.n_iter_per_frame):
             batch = None
             if pool is not None:
@@ -214,7 +224,10 @@ class IncrementalMapper:
                 out["obj"].append(self.loop.step(batch, global_flags=gflags).clone())
             if bg_pool is not None:
                 bs = slice(it * npo_bg, (it + 1) * npo_bg)
-                out["bg"].append(self.bg_loop.step({k: v[:, bs].contiguous() for k, v in bg_pool.items()}).clone())
+                with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                    out["bg"].append(self.bg_loop.step({k: v[:, bs].contiguous() for k, v in bg_pool.items()}).clone())
+        if side is not None:
+            torch.cuda.current_stream(cfg.training_device).wait_stream(side)
         if self.loop is not None:
             if int(self.loop.ws.status.item()) != 0:
                 from .render_rays import LossExplode

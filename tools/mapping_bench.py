@@ -63,6 +63,22 @@ for i in range(a.frames):
     sync(); t0 = time.perf_counter()
     m.ingest(s, i)
     sync(); t1 = time.perf_counter()
+    if a.only is None and not a.overlap:
+        # the mapper's own frame: pools, iterations (background steps on a second stream), copy-back
+        t_s = time.perf_counter()
+        m._ensure_stack()
+        pool, bg_pool = m.sample_pools()
+        sync(); t2 = time.perf_counter()
+        real_sample = m.sample_pools
+        m.sample_pools = lambda: (pool, bg_pool)
+        m.train_frame()
+        m.sample_pools = real_sample
+        sync(); t3 = time.perf_counter()
+        t4 = t3
+        print("frame %d: ingest %.1f ms | stack+sample pools %.1f ms | %d iterations + copy-back %.1f ms (%.3f ms each)"
+              % (i, 1e3 * (t1 - t0), 1e3 * (t2 - t1), c.n_iter_per_frame, 1e3 * (t3 - t2), 1e3 * (t3 - t2) / c.n_iter_per_frame),
+              flush=True)
+        continue
     m._ensure_stack()
     pool, bg_pool = m.sample_pools()
     sync(); t2 = time.perf_counter()
