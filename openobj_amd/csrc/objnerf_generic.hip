@@ -313,6 +313,220 @@ static void wgrad(hipStream_t st, int batch, int M, int N, long n, const float* 
        0, 0, sk > 1 ? sk : 2, bias_grad, bsc);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Small-batch forward for hidden 128 (the background network at the reference's native batch, 1200 rays x 14
+// samples): the layer-by-layer GEMMs above are then a chain of dependent ~15 us launches for ~1 us of MFMA work
+// each.  Here ONE launch runs the whole network: a workgroup owns 16 RT samples (RT chosen so that the grid fills
+// the chip once), keeps their activations in two LDS buffers and streams each layer's weight matrix from L2 into
+// a third.  Every activation is also written to HBM, as the backward pass and the weight-gradient GEMMs read them.
+// Same arithmetic as the GEMM path (fp32 MFMA, k ascending); the concatenated layers accumulate their two parts
+// in one accumulator.  LDS rows have pitch 132 floats: conflict-free operand reads (bank = 4 m + k).
+struct FwdSmall {
+  long n; int feat;
+  const float* params; long ps;
+  const float* emb;                    // [K][n][OBJ_EMB]
+  float *h1, *h2, *h3, *h4, *hc, *hf;  // [K][n][128]
+  float *alpha, *color;                // [K][n], [K][n][3]
+  int o_in_w, o_in_b, o_m1_w, o_m1_b, o_cat_w, o_cat_b, o_m2_w, o_m2_b, o_a_w, o_a_b, o_cl_w, o_cl_b, o_oc_w, o_oc_b,
+      o_fl_w, o_fl_b;
+};
+constexpr int FS_H = 128, FS_P = 132;
+template <int RT> constexpr size_t fs_lds_bytes() { return (size_t)(FS_H + 2 * 16 * RT) * FS_P * sizeof(float); }
+
+template <int RT>
+__global__ __launch_bounds__(512) void mlp_fwd_small_kernel(const FwdSmall a) {
+  constexpr int BM = 16 * RT, H = FS_H, PT = FS_P;
+  extern __shared__ float fs_lds[];
+  float* Wb = fs_lds;                   // [128][132] current layer's weights, [out][in]
+  float* Xa = Wb + H * PT;              // [BM][132]
+  float* Xb = Xa + BM * PT;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;     // 8 waves: wave w owns features 16 w .. 16 w + 15
+  const int c = lane & 15, gg = lane >> 4;
+  const long z = blockIdx.y, n = a.n;
+  const long m0 = (long)blockIdx.x * BM;
+  const float* P = a.params + z * a.ps;
+  const float* emb = a.emb + z * n * OBJ_EMB;
+  const int kk = tid & 127, rg = tid >> 7;          // staging: lanes along k (the contiguous source dimension)
+  // rows [m0, m0 + BM) x cols [col0, col0 + KC) of the embedding -> X (zero-padded to a multiple of 4 columns)
+  auto load_emb = [&](float* X, const int col0, const int KC) {
+    const int KC4 = (KC + 3) & ~3;
+    if (kk < KC4) {
+#pragma unroll
+      for (int i = 0; i < (BM + 3) / 4; ++i) {
+        const int m = rg + 4 * i;
+        if (m < BM) X[m * PT + kk] = (m0 + m < n && kk < KC) ? emb[(m0 + m) * OBJ_EMB + col0 + kk] : 0.f;
+      }
+    }
+  };
+  // The next layer's weights W[out][ld], columns [0, KC), are fetched into registers BEFORE the current layer's MFMA
+  // loop and stored to Wb after it: their L2 latency hides behind the matrix work.
+  float wr[32];
+  auto fetch_w = [&](const float* W, const int ld, const int KC) {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) wr[i] = kk < KC ? W[(rg + 4 * i) * ld + kk] : 0.f;
+  };
+  auto put_w = [&]() {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) Wb[(rg + 4 * i) * PT + kk] = wr[i];
+  };
+  f32x4 acc[RT];
+  auto zero = [&]() {
+#pragma unroll
+    for (int i = 0; i < RT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  // acc += X[:, :KC] Wb^T for this wave's column tile, all RT row tiles
+  auto mma = [&](const float* X, const int KC) {
+    const float* bp = Wb + (16 * w + c) * PT + gg;
+    const float* ap = X + c * PT + gg;
+#pragma unroll 2
+    for (int ks = 0; ks < KC; ks += 4) {
+      const float b = bp[ks];
+#pragma unroll
+      for (int i = 0; i < RT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[16 * i * PT + ks], b, acc[i], 0, 0, 0);
+    }
+  };
+  // relu(acc + bias) -> LDS buffer (next layer's input) and the HBM activation
+  auto store = [&](float* X, float* hbm, const float* bias) {
+    float* out = hbm + z * n * H;
+    const int f = 16 * w + c;
+    const float bv = bias[f];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = 16 * i + 4 * gg + r;
+        const float v = fmaxf(acc[i][r] + bv, 0.f);
+        X[m * PT + f] = v;
+        if (m0 + m < n) out[(m0 + m) * H + f] = v;
+      }
+  };
+  constexpr int E1P = (OBJ_E1 + 3) & ~3, E2P = (OBJ_E2 + 3) & ~3;
+  // ---- h1 = relu(x1 W_in^T + b)                                  (model.py:63-66)
+  fetch_w(P + a.o_in_w, OBJ_E1, OBJ_E1);
+  load_emb(Xa, 0, OBJ_E1);
+  put_w();
+  __syncthreads();
+  fetch_w(P + a.o_m1_w, H, H);
+  zero();
+  mma(Xa, E1P);
+  __syncthreads();
+  store(Xb, a.h1, P + a.o_in_b);
+  put_w();
+  __syncthreads();
+  // ---- h2
+  fetch_w(P + a.o_cat_w, H + OBJ_E1, H);
+  zero();
+  mma(Xb, H);
+  __syncthreads();
+  store(Xa, a.h2, P + a.o_m1_b);
+  put_w();
+  load_emb(Xb, 0, OBJ_E1);
+  __syncthreads();
+  // ---- h3 = relu([h2 | x1] W_cat^T + b)
+  fetch_w(P + a.o_cat_w + H, H + OBJ_E1, OBJ_E1);
+  zero();
+  mma(Xa, H);
+  __syncthreads();
+  put_w();
+  __syncthreads();
+  fetch_w(P + a.o_m2_w, H, H);
+  mma(Xb, E1P);
+  __syncthreads();
+  store(Xa, a.h3, P + a.o_cat_b);
+  put_w();
+  __syncthreads();
+  // ---- h4
+  fetch_w(P + a.o_cl_w, H + OBJ_E2, H);
+  zero();
+  mma(Xa, H);
+  __syncthreads();
+  store(Xb, a.h4, P + a.o_m2_b);
+  put_w();
+  load_emb(Xa, OBJ_E1, OBJ_E2);
+  __syncthreads();
+  // ---- hc = relu([h4 | x2] W_cl^T + b)
+  fetch_w(P + a.o_cl_w + H, H + OBJ_E2, OBJ_E2);
+  zero();
+  mma(Xb, H);
+  __syncthreads();
+  put_w();
+  __syncthreads();
+  if (a.feat) fetch_w(P + a.o_fl_w, H + OBJ_E2, H);
+  mma(Xa, E2P);
+  __syncthreads();
+  // hc goes to a THIRD place: Wb is free until the next put_w and Xa (x2) is needed again by the feature layer
+  float* Xc = Wb;
+  store(Xc, a.hc, P + a.o_cl_b);
+  __syncthreads();
+  // ---- heads: alpha = 10 (h4 . wa + ba), colour = sigmoid(hc Woc^T + boc)      (model.py:81-96); a wave per row
+  {
+    const float* wa = P + a.o_a_w;
+    const float* woc = P + a.o_oc_w;
+    const float wa0 = wa[lane], wa1 = wa[lane + 64];
+    const float w00 = woc[lane], w01 = woc[lane + 64], w10 = woc[H + lane], w11 = woc[H + lane + 64];
+    const float w20 = woc[2 * H + lane], w21 = woc[2 * H + lane + 64];
+    for (int m = w; m < BM; m += 8) {
+      const float x0 = Xb[m * PT + lane], x1 = Xb[m * PT + lane + 64];
+      const float y0 = Xc[m * PT + lane], y1 = Xc[m * PT + lane + 64];
+      const float sa = wave_sum64(fmaf(wa1, x1, wa0 * x0));
+      const float s0 = wave_sum64(fmaf(w01, y1, w00 * y0));
+      const float s1 = wave_sum64(fmaf(w11, y1, w10 * y0));
+      const float s2 = wave_sum64(fmaf(w21, y1, w20 * y0));
+      if (lane == 0 && m0 + m < n) {
+        const long i = z * n + m0 + m;
+        a.alpha[i] = (sa + P[a.o_a_b]) * 10.0f;
+        a.color[i * 3] = sigmoid_acc(s0 + P[a.o_oc_b]);
+        a.color[i * 3 + 1] = sigmoid_acc(s1 + P[a.o_oc_b + 1]);
+        a.color[i * 3 + 2] = sigmoid_acc(s2 + P[a.o_oc_b + 2]);
+      }
+    }
+  }
+  if (!a.feat) return;
+  // ---- hf = relu([h4 | x2] W_fl^T + b)     (feature layer, same inputs as the colour layer: Xb = h4, Xa = x2)
+  __syncthreads();
+  put_w();
+  __syncthreads();
+  fetch_w(P + a.o_fl_w + H, H + OBJ_E2, OBJ_E2);
+  zero();
+  mma(Xb, H);
+  __syncthreads();
+  put_w();
+  __syncthreads();
+  mma(Xa, E2P);
+  float* out = a.hf + z * n * H;
+  {
+    const int f = 16 * w + c;
+    const float bv = P[a.o_fl_b + f];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = 16 * i + 4 * gg + r;
+        if (m0 + m < n) out[(m0 + m) * H + f] = fmaxf(acc[i][r] + bv, 0.f);
+      }
+  }
+}
+
+template <int RT>
+static void launch_fwd_small(hipStream_t st, const FwdSmall& f, int K) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)mlp_fwd_small_kernel<RT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)fs_lds_bytes<RT>());
+    attr_done = true;
+  }
+  dim3 grid((unsigned)((f.n + 16 * RT - 1) / (16 * RT)), (unsigned)K);
+  hipLaunchKernelGGL(mlp_fwd_small_kernel<RT>, grid, dim3(512), fs_lds_bytes<RT>(), st, f);
+}
+
+// row tiles per workgroup so that K * ceil(n / (16 RT)) workgroups fit the chip in one round; 0 = not a small batch
+static int small_batch_rt(int H, long n, int K) {
+  if (H != FS_H || t_bf16_operands) return 0;
+  for (int rt = 1; rt <= 5; ++rt)
+    if ((long)K * ((n + 16 * rt - 1) / (16 * rt)) <= 256) return rt;
+  return 0;
+}
+
 // heads forward: alpha = 10 (h4 . wa + ba), color = sigmoid(hc Woc^T + boc)        (model.py:81-96)
 // 16 lanes per sample row (float4 each, coalesced), the four dot products meet by DPP row sums.
 __global__ __launch_bounds__(256) void heads_fwd_kernel(int Hh, long n, const float* h4, const float* hc,
@@ -619,6 +833,26 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a, void* stream
   // ---- forward
   int rc = objnerf_embed(net, K, n, P, ps, a->scale, a->pts, w.emb, stream);
   if (rc) return rc;
+  dim3 eg((unsigned)((n + 15) / 16), (unsigned)K);      // 16 lanes per sample row
+  const size_t head_lds = (size_t)4 * H * sizeof(float);
+  const int small_rt = small_batch_rt(H, n, K);
+  if (small_rt) {
+    FwdSmall f;
+    f.n = n; f.feat = feat ? 1 : 0; f.params = P; f.ps = ps; f.emb = w.emb;
+    f.h1 = w.h1; f.h2 = w.h2; f.h3 = w.h3; f.h4 = w.h4; f.hc = w.hc; f.hf = feat ? w.hf : nullptr;
+    f.alpha = w.alpha; f.color = w.color;
+    f.o_in_w = (int)off[0]; f.o_in_b = (int)off[1]; f.o_m1_w = (int)off[2]; f.o_m1_b = (int)off[3];
+    f.o_cat_w = (int)off[4]; f.o_cat_b = (int)off[5]; f.o_m2_w = (int)off[6]; f.o_m2_b = (int)off[7];
+    f.o_a_w = (int)off[8]; f.o_a_b = (int)off[9]; f.o_cl_w = (int)off[10]; f.o_cl_b = (int)off[11];
+    f.o_oc_w = (int)off[12]; f.o_oc_b = (int)off[13]; f.o_fl_w = (int)off[14]; f.o_fl_b = (int)off[15];
+    switch (small_rt) {
+      case 1: launch_fwd_small<1>(st, f, K); break;
+      case 2: launch_fwd_small<2>(st, f, K); break;
+      case 3: launch_fwd_small<3>(st, f, K); break;
+      case 4: launch_fwd_small<4>(st, f, K); break;
+      default: launch_fwd_small<5>(st, f, K); break;
+    }
+  } else {
   // h1 = relu(x1 W_in^T + b)
   gemm(st, K, n, H, E1, w.emb, EM, 1, n * EM, P + off[0], 1, E1, ps, w.h1, H, 1, nH, false, P + off[1], ps, true);
   gemm(st, K, n, H, H, w.h1, H, 1, nH, P + off[2], 1, H, ps, w.h2, H, 1, nH, false, P + off[3], ps, true);
@@ -630,14 +864,15 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a, void* stream
   gemm(st, K, n, H, H, w.h4, H, 1, nH, P + off[10], 1, H + E2, ps, w.hc, H, 1, nH);
   gemm(st, K, n, H, E2, w.emb + E1, EM, 1, n * EM, P + off[10] + H, 1, H + E2, ps, w.hc, H, 1, nH, true, P + off[11], ps,
        true);
-  dim3 eg((unsigned)((n + 15) / 16), (unsigned)K);      // 16 lanes per sample row
-  const size_t head_lds = (size_t)4 * H * sizeof(float);
   hipLaunchKernelGGL(heads_fwd_kernel, eg, dim3(256), head_lds, st, H, n, w.h4, w.hc, P, ps, (int)off[8], (int)off[9],
                      (int)off[12], (int)off[13], w.alpha, w.color);
   if (feat) {
     gemm(st, K, n, H, H, w.h4, H, 1, nH, P + off[14], 1, H + E2, ps, w.hf, H, 1, nH);
     gemm(st, K, n, H, E2, w.emb + E1, EM, 1, n * EM, P + off[14] + H, 1, H + E2, ps, w.hf, H, 1, nH, true, P + off[15],
          ps, true);
+  }
+  }
+  if (feat) {
     // the 512-d head is NOT applied per sample: per object G = W_of^T W_of (+ wb, bb), per ray u = W_of^T g, beta, |g|
     const long R = a->R;
     const long gst = (long)H * H + H + 1;
