@@ -4,6 +4,7 @@
 // path materialises activations in the caller's workspace and runs the contraction as batched fp32 MFMA
 // GEMMs (v_mfma_f32_16x16x4_f32, 64x64x16 tiles), with the reference's op order:
 //   embedding.py:46-55 -> model.py:61-103 -> loss.py:5-103 (objnerf_step_batch_loss) -> reverse.
+#include <algorithm>
 #include "objnerf_device.h"
 #include "../../include/objnerf_hip.h"
 #include "objnerf_generic.h"
@@ -39,7 +40,7 @@ constexpr int BK = OBJ_GEMM_BK;
 // Workgroup tile (32*TM*2) x (32*TN*2): 4 waves as 2 x 2, each wave TM x TN MFMA tiles of 16 x 16.
 // <1,1> = 64 x 64 (small problems), <2,2> = 128 x 128 (the n x H x H layer GEMMs: 2 MFMAs per LDS read).
 template <int TM, int TN, int BKT = BK>
-__global__ __launch_bounds__(256) void gemm_kernel(const Gemm g) {
+__device__ __forceinline__ void gemm_tile(const Gemm& g, const int bx, const int by, const int bz) {
   constexpr int BK = BKT;      // k depth of one LDS stage (shadows the default)
   constexpr int BM = 32 * TM, BN = 32 * TN;      // (per wave 16*TM x 16*TN, workgroup 2 x 2 waves)
   __shared__ float As[BK][BM + 4];
@@ -47,10 +48,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Gemm g) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int c = lane & 15, gg = lane >> 4;
   const int wm = w >> 1, wn = w & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int m0 = by * BM, n0 = bx * BN;
   const int sk = g.splitk > 1 ? g.splitk : 1;
-  const long z = blockIdx.z / sk;
-  const int slice = blockIdx.z % sk;
+  const long z = bz / sk;
+  const int slice = bz % sk;
   const float* A = g.A + z * g.bsa;
   const float* B = g.B + z * g.bsb;
   float* C = g.C + z * g.bsc;
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Gemm g) {
     }
   };
   float rs = 0.f;
-  const bool do_rs = g.rowsum != nullptr && blockIdx.x == 0 && tid < BM;
+  const bool do_rs = g.rowsum != nullptr && bx == 0 && tid < BM;
   if (kbeg < kend) load_tiles(kbeg);
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
     store_tiles();
@@ -144,6 +145,27 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Gemm g) {
       }
 }
 
+
+template <int TM, int TN, int BKT = BK>
+__global__ __launch_bounds__(256) void gemm_kernel(const Gemm g) {
+  gemm_tile<TM, TN, BKT>(g, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Several independent GEMMs in ONE launch (the weight-gradient GEMMs of a small-batch step: each alone is ~260
+// workgroups of latency-bound work): blockIdx.z runs over the concatenated (batch x split-K) slices of all of them.
+struct GemmGroup {
+  static constexpr int MAXG = 10;
+  int count;
+  int zbeg[MAXG + 1];
+  Gemm g[MAXG];
+};
+__global__ __launch_bounds__(256) void gemm_group_kernel(const GemmGroup gr) {
+  int i = 0;
+  while (i + 1 < gr.count && (int)blockIdx.z >= gr.zbeg[i + 1]) ++i;
+  const Gemm& g = gr.g[i];
+  if ((int)blockIdx.x * 64 >= g.N || (int)blockIdx.y * 64 >= g.M) return;
+  gemm_tile<2, 2>(g, blockIdx.x, blockIdx.y, blockIdx.z - gr.zbeg[i]);
+}
 
 // ------------------------------------------------------------------------------------------------
 // bf16-operand variant (OBJNERF_TRAIN_BF16 on the layer-wise path): same interface and epilogue, operands are
@@ -256,6 +278,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const Gemm g) {
 // selected for the duration of one train_step call (single host thread per device)
 static thread_local bool t_bf16_operands = false;
 // per-row bias factor of the NEXT gemm() call (feature_head), reset by the caller
+static thread_local GemmGroup* t_group = nullptr;     // non-null: gemm() collects descriptors instead of launching
 static thread_local const float* t_biasrow = nullptr;
 static thread_local long t_bsbr = 0;
 
@@ -274,6 +297,14 @@ static void gemm(hipStream_t st, int batch, int M, int N, int Kd, const float* A
   g.rowsum = rowsum; g.bsrs = bsrs;
   g.biasrow = t_biasrow; g.bsbr = t_bsbr;
   const int nz = batch * (splitk > 1 ? splitk : 1);
+  if (t_group && !t_bf16_operands && !(M >= 256 && N >= 192) && t_group->count < GemmGroup::MAXG) {
+    GemmGroup& gr = *t_group;               // collected; launched by flush_group()
+    if (gr.count == 0) gr.zbeg[0] = 0;
+    gr.g[gr.count] = g;
+    gr.zbeg[gr.count + 1] = gr.zbeg[gr.count] + nz;
+    ++gr.count;
+    return;
+  }
   if (t_bf16_operands) {
     if (M >= 256 && N >= 192) {
       dim3 grid((N + 127) / 128, (M + 127) / 128, nz);
@@ -507,6 +538,196 @@ __global__ __launch_bounds__(512) void mlp_fwd_small_kernel(const FwdSmall a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The matching backward (input-gradient chain) in one launch: d_hc (+ d_hf) -> d_h4 -> d_h3 -> d_h2 -> d_h1 and the
+// embedding gradient, every d_h also written to HBM for the weight-gradient GEMMs.  d_in = d_out W is the same MFMA
+// loop with the weight rows read as they lie in memory: Wb[k = out][n = in], pitch 144 (bank = 16 k + n).
+struct BwdSmall {
+  long n; int feat;
+  const float* params; long ps;
+  const float *h1, *h2, *h3, *h4;      // relu masks
+  const float *d_hc, *d_hf;            // [K][n][128] (d_hf: feature layer, or NULL)
+  float *d_h4, *d_h3, *d_h2, *d_h1;    // d_h4 arrives holding the alpha head's contribution (heads_bwd_kernel)
+  float* d_emb;                        // [K][n][OBJ_EMB]
+  int o_in_w, o_m1_w, o_cat_w, o_m2_w, o_cl_w, o_fl_w;
+};
+constexpr int BS_PW = 144;
+template <int RT> constexpr size_t bs_lds_bytes() { return (size_t)(FS_H * BS_PW + 2 * 16 * RT * FS_P) * sizeof(float); }
+
+template <int RT>
+__global__ __launch_bounds__(512) void mlp_bwd_small_kernel(const BwdSmall a) {
+  constexpr int BM = 16 * RT, H = FS_H, PT = FS_P, PW = BS_PW;
+  extern __shared__ float fs_lds[];
+  float* Wb = fs_lds;                   // [k = out][n = in], pitch 144
+  float* Da = Wb + H * PW;              // [BM][132]
+  float* Db = Da + BM * PT;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;     // wave w owns input features 16 w .. 16 w + 15
+  const int c = lane & 15, gg = lane >> 4;
+  const long z = blockIdx.y, n = a.n;
+  const long m0 = (long)blockIdx.x * BM;
+  const float* P = a.params + z * a.ps;
+  const int kk = tid & 127, rg = tid >> 7;
+  auto load_d = [&](float* X, const float* src) {     // rows [m0, m0 + BM) of a [n][128] tensor
+    const float* sp = src + z * n * H;
+#pragma unroll
+    for (int i = 0; i < (BM + 3) / 4; ++i) {
+      const int m = rg + 4 * i;
+      if (m < BM) X[m * PT + kk] = (m0 + m < n) ? sp[(m0 + m) * H + kk] : 0.f;
+    }
+  };
+  // W[out][ld], columns [col0, col0 + NC): row `out` -> Wb[out][0 .. NC) (zero up to 128), fetched ahead into registers
+  float wr[32];
+  auto fetch_w = [&](const float* W, const int ld, const int NC) {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) wr[i] = kk < NC ? W[(rg + 4 * i) * ld + kk] : 0.f;
+  };
+  auto put_w = [&]() {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) Wb[(rg + 4 * i) * PW + kk] = wr[i];
+  };
+  f32x4 acc[RT], accE[RT];
+  auto zero = [&](f32x4 (&v)[RT]) {
+#pragma unroll
+    for (int i = 0; i < RT; ++i) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  // v += D (all 128 output-feature columns) x Wb -> this wave's 16 input features
+  auto mma = [&](const float* D, f32x4 (&v)[RT]) {
+    const float* bp = Wb + gg * PW + 16 * w + c;
+    const float* ap = D + c * PT + gg;
+#pragma unroll 2
+    for (int ks = 0; ks < H; ks += 4) {
+      const float b = bp[ks * PW];
+#pragma unroll
+      for (int i = 0; i < RT; ++i) v[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[16 * i * PT + ks], b, v[i], 0, 0, 0);
+    }
+  };
+  // masked d_h: (acc [+ prior]) where act > 0 -> LDS (next layer's operand) and HBM
+  float mk[RT][4];
+  auto fetch_mask = [&](const float* act) {
+    const float* hp = act + z * n * H;
+    const int f = 16 * w + c;
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = 16 * i + 4 * gg + r;
+        mk[i][r] = (m0 + m < n) ? hp[(m0 + m) * H + f] : 0.f;
+      }
+  };
+  auto store_dh = [&](float* X, float* hbm, const bool add_prior) {
+    float* out = hbm + z * n * H;
+    const int f = 16 * w + c;
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = 16 * i + 4 * gg + r;
+        const bool in = m0 + m < n;
+        float v = acc[i][r];
+        if (add_prior && in) v += out[(m0 + m) * H + f];
+        v = mk[i][r] > 0.f ? v : 0.f;
+        X[m * PT + f] = v;
+        if (in) out[(m0 + m) * H + f] = v;
+      }
+  };
+  auto store_emb = [&](const int col0, const int NC) {     // accE -> d_emb[:, col0 + f], f < NC
+    float* out = a.d_emb + z * n * OBJ_EMB;
+    const int f = 16 * w + c;
+    if (f < NC) {
+#pragma unroll
+      for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = 16 * i + 4 * gg + r;
+          if (m0 + m < n) out[(m0 + m) * OBJ_EMB + col0 + f] = accE[i][r];
+        }
+    }
+  };
+  const bool e1_wave = 16 * w < OBJ_E1, e2_wave = 16 * w < OBJ_E2;      // waves that own embedding columns
+  zero(acc);
+  zero(accE);
+  if (a.feat) {
+    // ---- feature layer: d_h4 += d_hf W_fl[:, :H], d_x2 = d_hf W_fl[:, H:]
+    fetch_w(P + a.o_fl_w, H + OBJ_E2, H);
+    load_d(Da, a.d_hf);
+    put_w();
+    __syncthreads();
+    fetch_w(P + a.o_fl_w + H, H + OBJ_E2, OBJ_E2);
+    mma(Da, acc);
+    __syncthreads();
+    put_w();
+    __syncthreads();
+    if (e2_wave) mma(Da, accE);
+    __syncthreads();
+  }
+  // ---- colour layer: d_h4 = relu'(h4) (alpha-head part + [d_hf W_fl1] + d_hc W_cl[:, :H]), d_x2 (+)= d_hc W_cl[:, H:]
+  fetch_w(P + a.o_cl_w, H + OBJ_E2, H);
+  load_d(Da, a.d_hc);
+  put_w();
+  __syncthreads();
+  fetch_w(P + a.o_cl_w + H, H + OBJ_E2, OBJ_E2);
+  fetch_mask(a.h4);
+  mma(Da, acc);
+  __syncthreads();
+  store_dh(Db, a.d_h4, true);                    // Db = d_h4
+  put_w();
+  __syncthreads();
+  fetch_w(P + a.o_m2_w, H, H);
+  if (e2_wave) mma(Da, accE);
+  store_emb(OBJ_E1, OBJ_E2);
+  __syncthreads();
+  // ---- mid2: d_h3 = relu'(h3) (d_h4 W_m2)
+  put_w();
+  __syncthreads();
+  fetch_w(P + a.o_cat_w, H + OBJ_E1, H);
+  fetch_mask(a.h3);
+  zero(acc);
+  mma(Db, acc);
+  __syncthreads();
+  store_dh(Da, a.d_h3, false);                   // Da = d_h3
+  put_w();
+  __syncthreads();
+  // ---- cat layer: d_h2 = relu'(h2) (d_h3 W_cat[:, :H]), d_x1 = d_h3 W_cat[:, H:]
+  fetch_w(P + a.o_cat_w + H, H + OBJ_E1, OBJ_E1);
+  fetch_mask(a.h2);
+  zero(acc);
+  mma(Da, acc);
+  __syncthreads();
+  store_dh(Db, a.d_h2, false);                   // Db = d_h2
+  put_w();
+  __syncthreads();
+  fetch_w(P + a.o_m1_w, H, H);
+  zero(accE);
+  if (e1_wave) mma(Da, accE);
+  __syncthreads();
+  // ---- mid1: d_h1 = relu'(h1) (d_h2 W_m1)
+  put_w();
+  __syncthreads();
+  fetch_w(P + a.o_in_w, OBJ_E1, OBJ_E1);
+  fetch_mask(a.h1);
+  zero(acc);
+  mma(Db, acc);
+  __syncthreads();
+  store_dh(Da, a.d_h1, false);                   // Da = d_h1
+  put_w();
+  __syncthreads();
+  // ---- in layer: d_x1 += d_h1 W_in
+  if (e1_wave) mma(Da, accE);
+  store_emb(0, OBJ_E1);
+}
+
+template <int RT>
+static void launch_bwd_small(hipStream_t st, const BwdSmall& f, int K) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)mlp_bwd_small_kernel<RT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)bs_lds_bytes<RT>());
+    attr_done = true;
+  }
+  dim3 grid((unsigned)((f.n + 16 * RT - 1) / (16 * RT)), (unsigned)K);
+  hipLaunchKernelGGL(mlp_bwd_small_kernel<RT>, grid, dim3(512), bs_lds_bytes<RT>(), st, f);
+}
+
 template <int RT>
 static void launch_fwd_small(hipStream_t st, const FwdSmall& f, int K) {
   static bool attr_done = false;
@@ -525,6 +746,18 @@ static int small_batch_rt(int H, long n, int K) {
   for (int rt = 1; rt <= 5; ++rt)
     if ((long)K * ((n + 16 * rt - 1) / (16 * rt)) <= 256) return rt;
   return 0;
+}
+
+static void flush_group(hipStream_t st, GemmGroup& gr) {
+  t_group = nullptr;
+  if (gr.count == 0) return;
+  int mx = 1, my = 1;
+  for (int i = 0; i < gr.count; ++i) {
+    mx = std::max(mx, (gr.g[i].N + 63) / 64);
+    my = std::max(my, (gr.g[i].M + 63) / 64);
+  }
+  hipLaunchKernelGGL(gemm_group_kernel, dim3(mx, my, gr.zbeg[gr.count]), dim3(256), 0, st, gr);
+  gr.count = 0;
 }
 
 // heads forward: alpha = 10 (h4 . wa + ba), color = sigmoid(hc Woc^T + boc)        (model.py:81-96)
@@ -792,15 +1025,20 @@ size_t train_workspace_bytes(const objnerf_net* net, int K, int R, int S, int fe
 namespace {
 // helper stream + events of this host thread (created once; non-blocking so it never syncs with the null stream)
 struct Side {
-  static constexpr int NEV = 16;
-  hipStream_t s = nullptr;
+  static constexpr int NEV = 16, NS = 3;
+  hipStream_t s = nullptr;             // = all[0]
+  hipStream_t all[NS];                 // small batches: the independent weight-gradient GEMMs spread over three streams
   hipEvent_t ev[NEV];
-  hipEvent_t done;
+  hipEvent_t done, done_all[NS];
 };
 Side& side_stream() {
   static thread_local Side sd;
   if (!sd.s) {
-    (void)hipStreamCreateWithFlags(&sd.s, hipStreamNonBlocking);
+    for (int i = 0; i < Side::NS; ++i) {
+      (void)hipStreamCreateWithFlags(&sd.all[i], hipStreamNonBlocking);
+      (void)hipEventCreateWithFlags(&sd.done_all[i], hipEventDisableTiming);
+    }
+    sd.s = sd.all[0];
     for (int i = 0; i < Side::NEV; ++i) (void)hipEventCreateWithFlags(&sd.ev[i], hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&sd.done, hipEventDisableTiming);
   }
@@ -907,12 +1145,19 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a, void* stream
   // buffer: nothing a side-stream GEMM reads is overwritten before the join at the end.
   Side& sd = side_stream();
   int fk = 0;
-  auto fork = [&]() {                       // side stream waits for everything enqueued on `st` so far
+  const int n_side = 1;
+  auto fork = [&]() {                       // the side stream(s) wait for everything enqueued on `st` so far
     (void)hipEventRecord(sd.ev[fk], st);
-    (void)hipStreamWaitEvent(sd.s, sd.ev[fk], 0);
+    for (int i = 0; i < n_side; ++i) (void)hipStreamWaitEvent(sd.all[i], sd.ev[fk], 0);
     fk = (fk + 1) % Side::NEV;
   };
   hipStream_t ss = sd.s;
+  int rr = 0;
+  auto side = [&]() -> hipStream_t {        // stream of the next independent weight-gradient GEMM
+    hipStream_t r = sd.all[rr];
+    rr = (rr + 1) % n_side;
+    return r;
+  };
   float* d_hc = w.dA;      // [n][H]
   float* d_h4 = w.dB_;
   hipLaunchKernelGGL(heads_bwd_kernel, eg, dim3(256), head_lds, st, H, n, w.hc, w.color, w.d_alpha, w.d_color, P, ps,
@@ -941,11 +1186,49 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a, void* stream
     hipLaunchKernelGGL(featg_finish_kernel, dim3((unsigned)(((long)C * XC + 255) / 256), K), dim3(256), 0, ss, P, ps,
                        (int)off[16], (int)off[17], C, H, w.Tm, w.mom, G);
     // feature layer: grads + contributions to d_h4 / d_x2
-    wgrad(ss, K, H, H, n, d_hf, 1, H, nH, w.h4, H, 1, nH, G + off[14], H + E2, ps, G + off[15]);
-    wgrad(ss, K, H, E2, n, d_hf, 1, H, nH, w.emb + E1, EM, 1, n * EM, G + off[14] + H, H + E2, ps);
-    gemm(st, K, n, H, H, d_hf, H, 1, nH, P + off[14], H + E2, 1, ps, d_h4, H, 1, nH, true);
-    gemm(st, K, n, E2, H, d_hf, H, 1, nH, P + off[14] + H, H + E2, 1, ps, w.d_emb + E1, EM, 1, n * EM, false);
+    if (!small_rt) {
+      wgrad(ss, K, H, H, n, d_hf, 1, H, nH, w.h4, H, 1, nH, G + off[14], H + E2, ps, G + off[15]);
+      wgrad(ss, K, H, E2, n, d_hf, 1, H, nH, w.emb + E1, EM, 1, n * EM, G + off[14] + H, H + E2, ps);
+      gemm(st, K, n, H, H, d_hf, H, 1, nH, P + off[14], H + E2, 1, ps, d_h4, H, 1, nH, true);
+      gemm(st, K, n, E2, H, d_hf, H, 1, nH, P + off[14] + H, H + E2, 1, ps, w.d_emb + E1, EM, 1, n * EM, false);
+    }
   }
+  float* d_h3 = w.dC;
+  float* d_h2 = w.dD;
+  float* d_h1 = w.dE;
+  if (small_rt) {
+    // small batch: the whole input-gradient chain in one launch, then the (independent) weight-gradient GEMMs
+    // side by side on three streams
+    BwdSmall b;
+    b.n = n; b.feat = feat ? 1 : 0; b.params = P; b.ps = ps;
+    b.h1 = w.h1; b.h2 = w.h2; b.h3 = w.h3; b.h4 = w.h4; b.d_hc = d_hc; b.d_hf = feat ? w.d_hf : nullptr;
+    b.d_h4 = d_h4; b.d_h3 = d_h3; b.d_h2 = d_h2; b.d_h1 = d_h1; b.d_emb = w.d_emb;
+    b.o_in_w = (int)off[0]; b.o_m1_w = (int)off[2]; b.o_cat_w = (int)off[4]; b.o_m2_w = (int)off[6];
+    b.o_cl_w = (int)off[10]; b.o_fl_w = (int)off[14];
+    switch (small_rt) {
+      case 1: launch_bwd_small<1>(st, b, K); break;
+      case 2: launch_bwd_small<2>(st, b, K); break;
+      case 3: launch_bwd_small<3>(st, b, K); break;
+      case 4: launch_bwd_small<4>(st, b, K); break;
+      default: launch_bwd_small<5>(st, b, K); break;
+    }
+    fork();
+    GemmGroup group;
+    group.count = 0;
+    t_group = &group;
+    if (feat) {
+      wgrad(side(), K, H, H, n, w.d_hf, 1, H, nH, w.h4, H, 1, nH, G + off[14], H + E2, ps, G + off[15]);
+      wgrad(side(), K, H, E2, n, w.d_hf, 1, H, nH, w.emb + E1, EM, 1, n * EM, G + off[14] + H, H + E2, ps);
+    }
+    wgrad(side(), K, H, H, n, d_hc, 1, H, nH, w.h4, H, 1, nH, G + off[10], H + E2, ps, G + off[11]);
+    wgrad(side(), K, H, E2, n, d_hc, 1, H, nH, w.emb + E1, EM, 1, n * EM, G + off[10] + H, H + E2, ps);
+    wgrad(side(), K, H, H, n, d_h4, 1, H, nH, w.h3, H, 1, nH, G + off[6], H, ps, G + off[7]);
+    wgrad(side(), K, H, H, n, d_h3, 1, H, nH, w.h2, H, 1, nH, G + off[4], H + E1, ps, G + off[5]);
+    wgrad(side(), K, H, E1, n, d_h3, 1, H, nH, w.emb, EM, 1, n * EM, G + off[4] + H, H + E1, ps);
+    wgrad(side(), K, H, H, n, d_h2, 1, H, nH, w.h1, H, 1, nH, G + off[2], H, ps, G + off[3]);
+    wgrad(side(), K, H, E1, n, d_h1, 1, H, nH, w.emb, EM, 1, n * EM, G + off[0], E1, ps, G + off[1]);
+    flush_group(ss, group);
+  } else {
   // colour layer
   fork();
   wgrad(ss, K, H, H, n, d_hc, 1, H, nH, w.h4, H, 1, nH, G + off[10], H + E2, ps, G + off[11]);
@@ -953,19 +1236,16 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a, void* stream
   gemm(st, K, n, H, H, d_hc, H, 1, nH, P + off[10], H + E2, 1, ps, d_h4, H, 1, nH, true, nullptr, 0, false, w.h4, H, 1, nH);
   gemm(st, K, n, E2, H, d_hc, H, 1, nH, P + off[10] + H, H + E2, 1, ps, w.d_emb + E1, EM, 1, n * EM, feat);
   // mid2:  d_h4 (masked above) -> grads, d_h3
-  float* d_h3 = w.dC;
   fork();
   wgrad(ss, K, H, H, n, d_h4, 1, H, nH, w.h3, H, 1, nH, G + off[6], H, ps, G + off[7]);
   gemm(st, K, n, H, H, d_h4, H, 1, nH, P + off[6], H, 1, ps, d_h3, H, 1, nH, false, nullptr, 0, false, w.h3, H, 1, nH);
   // cat layer
-  float* d_h2 = w.dD;
   fork();
   wgrad(ss, K, H, H, n, d_h3, 1, H, nH, w.h2, H, 1, nH, G + off[4], H + E1, ps, G + off[5]);
   wgrad(ss, K, H, E1, n, d_h3, 1, H, nH, w.emb, EM, 1, n * EM, G + off[4] + H, H + E1, ps);
   gemm(st, K, n, H, H, d_h3, H, 1, nH, P + off[4], H + E1, 1, ps, d_h2, H, 1, nH, false, nullptr, 0, false, w.h2, H, 1, nH);
   gemm(st, K, n, E1, H, d_h3, H, 1, nH, P + off[4] + H, H + E1, 1, ps, w.d_emb, EM, 1, n * EM, false);
   // mid1
-  float* d_h1 = w.dE;
   fork();
   wgrad(ss, K, H, H, n, d_h2, 1, H, nH, w.h1, H, 1, nH, G + off[2], H, ps, G + off[3]);
   gemm(st, K, n, H, H, d_h2, H, 1, nH, P + off[2], H, 1, ps, d_h1, H, 1, nH, false, nullptr, 0, false, w.h1, H, 1, nH);
@@ -973,6 +1253,7 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a, void* stream
   fork();
   wgrad(ss, K, H, E1, n, d_h1, 1, H, nH, w.emb, EM, 1, n * EM, G + off[0], E1, ps, G + off[1]);
   gemm(st, K, n, E1, H, d_h1, H, 1, nH, P + off[0], E1, 1, ps, w.d_emb, EM, 1, n * EM, true);
+  }
   // embedding directions
   (void)hipMemsetAsync(w.dBpe, 0, (size_t)K * 64 * 4, st);
   int pg = (int)((n + 47) / 48);           // 12 samples per block and pass: at least 4 passes per block
@@ -982,8 +1263,10 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a, void* stream
                      w.dBpe);
   hipLaunchKernelGGL(copy_cols_kernel, dim3((unsigned)((K * 63 + 255) / 256)), dim3(256), 0, st, (long)K, 63, w.dBpe, 63L,
                      G + off[18], ps);
-  (void)hipEventRecord(sd.done, sd.s);          // join: the caller's stream continues after the weight gradients
-  (void)hipStreamWaitEvent(st, sd.done, 0);
+  for (int i = 0; i < n_side; ++i) {            // join: the caller's stream continues after the weight gradients
+    (void)hipEventRecord(sd.done_all[i], sd.all[i]);
+    (void)hipStreamWaitEvent(st, sd.done_all[i], 0);
+  }
   if (hipGetLastError() != hipSuccess) return OBJNERF_ELAUNCH;
   return OBJNERF_OK;
 }
