@@ -367,7 +367,7 @@ template <int RT> constexpr size_t fs_lds_bytes() { return (size_t)(FS_H + 2 * 1
 template <int RT>
 __global__ __launch_bounds__(512) void mlp_fwd_small_kernel(const FwdSmall a) {
   constexpr int BM = 16 * RT, H = FS_H, PT = FS_P;
-  extern __shared__ float fs_lds[];
+  extern __shared__ __attribute__((aligned(16))) float fs_lds[];
   float* Wb = fs_lds;                   // [128][132] current layer's weights, [out][in]
   float* Xa = Wb + H * PT;              // [BM][132]
   float* Xb = Xa + BM * PT;
@@ -380,8 +380,8 @@ __global__ __launch_bounds__(512) void mlp_fwd_small_kernel(const FwdSmall a) {
   const int kk = tid & 127, rg = tid >> 7;          // staging: lanes along k (the contiguous source dimension)
   // rows [m0, m0 + BM) x cols [col0, col0 + KC) of the embedding -> X (zero-padded to a multiple of 4 columns)
   auto load_emb = [&](float* X, const int col0, const int KC) {
-    const int KC4 = (KC + 3) & ~3;
-    if (kk < KC4) {
+    const int KC16 = (KC + 15) & ~15;
+    if (kk < KC16) {
 #pragma unroll
       for (int i = 0; i < (BM + 3) / 4; ++i) {
         const int m = rg + 4 * i;
@@ -405,15 +405,32 @@ __global__ __launch_bounds__(512) void mlp_fwd_small_kernel(const FwdSmall a) {
 #pragma unroll
     for (int i = 0; i < RT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
-  // acc += X[:, :KC] Wb^T for this wave's column tile, all RT row tiles
+  // acc += X[:, :KC] Wb^T for this wave's column tile, all RT row tiles (KC a multiple of 16).  The contraction index
+  // is free to permute: MFMA step j of a 16-block takes k = 16 blk + 4 gg + j from lane group gg, so a lane fetches
+  // four steps of an operand with ONE ds_read_b128 (conflict-free with the 132-float pitch); the next block's
+  // operands are requested before the current block's 4 RT MFMAs are issued.
   auto mma = [&](const float* X, const int KC) {
-    const float* bp = Wb + (16 * w + c) * PT + gg;
-    const float* ap = X + c * PT + gg;
-#pragma unroll 2
-    for (int ks = 0; ks < KC; ks += 4) {
-      const float b = bp[ks];
+    const float* bp = Wb + (16 * w + c) * PT + 4 * gg;
+    const float* ap = X + c * PT + 4 * gg;
+    f32x4 bc = *reinterpret_cast<const f32x4*>(bp), ac[RT];
 #pragma unroll
-      for (int i = 0; i < RT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[16 * i * PT + ks], b, acc[i], 0, 0, 0);
+    for (int i = 0; i < RT; ++i) ac[i] = *reinterpret_cast<const f32x4*>(ap + 16 * i * PT);
+    for (int kb = 0; kb < KC; kb += 16) {
+      f32x4 bn = bc, an[RT];
+#pragma unroll
+      for (int i = 0; i < RT; ++i) an[i] = ac[i];
+      if (kb + 16 < KC) {
+        bn = *reinterpret_cast<const f32x4*>(bp + kb + 16);
+#pragma unroll
+        for (int i = 0; i < RT; ++i) an[i] = *reinterpret_cast<const f32x4*>(ap + 16 * i * PT + kb + 16);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < RT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[i][j], bc[j], acc[i], 0, 0, 0);
+      bc = bn;
+#pragma unroll
+      for (int i = 0; i < RT; ++i) ac[i] = an[i];
     }
   };
   // relu(acc + bias) -> LDS buffer (next layer's input) and the HBM activation
@@ -431,7 +448,7 @@ __global__ __launch_bounds__(512) void mlp_fwd_small_kernel(const FwdSmall a) {
         if (m0 + m < n) out[(m0 + m) * H + f] = v;
       }
   };
-  constexpr int E1P = (OBJ_E1 + 3) & ~3, E2P = (OBJ_E2 + 3) & ~3;
+  constexpr int E1P = (OBJ_E1 + 15) & ~15, E2P = (OBJ_E2 + 15) & ~15;
   // ---- h1 = relu(x1 W_in^T + b)                                  (model.py:63-66)
   fetch_w(P + a.o_in_w, OBJ_E1, OBJ_E1);
   load_emb(Xa, 0, OBJ_E1);
@@ -541,7 +558,7 @@ __global__ __launch_bounds__(512) void mlp_fwd_small_kernel(const FwdSmall a) {
 // ------------------------------------------------------------------------------------------------
 // The matching backward (input-gradient chain) in one launch: d_hc (+ d_hf) -> d_h4 -> d_h3 -> d_h2 -> d_h1 and the
 // embedding gradient, every d_h also written to HBM for the weight-gradient GEMMs.  d_in = d_out W is the same MFMA
-// loop with the weight rows read as they lie in memory: Wb[k = out][n = in], pitch 144 (bank = 16 k + n).
+// loop with the weight rows read as they lie in memory: Wb[k = out][n = in], pitch 130 (bank = 2 k + n).
 struct BwdSmall {
   long n; int feat;
   const float* params; long ps;
@@ -551,14 +568,14 @@ struct BwdSmall {
   float* d_emb;                        // [K][n][OBJ_EMB]
   int o_in_w, o_m1_w, o_cat_w, o_m2_w, o_cl_w, o_fl_w;
 };
-constexpr int BS_PW = 144;
+constexpr int BS_PW = 130;
 template <int RT> constexpr size_t bs_lds_bytes() { return (size_t)(FS_H * BS_PW + 2 * 16 * RT * FS_P) * sizeof(float); }
 
 template <int RT>
 __global__ __launch_bounds__(512) void mlp_bwd_small_kernel(const BwdSmall a) {
   constexpr int BM = 16 * RT, H = FS_H, PT = FS_P, PW = BS_PW;
-  extern __shared__ float fs_lds[];
-  float* Wb = fs_lds;                   // [k = out][n = in], pitch 144
+  extern __shared__ __attribute__((aligned(16))) float fs_lds[];
+  float* Wb = fs_lds;                   // [k = out][n = in], pitch 130
   float* Da = Wb + H * PW;              // [BM][132]
   float* Db = Da + BM * PT;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;     // wave w owns input features 16 w .. 16 w + 15
@@ -590,15 +607,34 @@ __global__ __launch_bounds__(512) void mlp_bwd_small_kernel(const BwdSmall a) {
 #pragma unroll
     for (int i = 0; i < RT; ++i) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
-  // v += D (all 128 output-feature columns) x Wb -> this wave's 16 input features
+  // v += D (all 128 output-feature columns) x Wb -> this wave's 16 input features.  Same k permutation as the
+  // forward kernel (step j of a 16-block takes k = 16 blk + 4 gg + j): D rows by ds_read_b128, the four weight rows
+  // by ds_read_b32 (bank = 8 gg + 2 j + n: two lanes per bank, the minimum for 64 lanes).
   auto mma = [&](const float* D, f32x4 (&v)[RT]) {
-    const float* bp = Wb + gg * PW + 16 * w + c;
-    const float* ap = D + c * PT + gg;
-#pragma unroll 2
-    for (int ks = 0; ks < H; ks += 4) {
-      const float b = bp[ks * PW];
+    const float* bp = Wb + 4 * gg * PW + 16 * w + c;
+    const float* ap = D + c * PT + 4 * gg;
+    f32x4 bc, ac[RT];
 #pragma unroll
-      for (int i = 0; i < RT; ++i) v[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[16 * i * PT + ks], b, v[i], 0, 0, 0);
+    for (int j = 0; j < 4; ++j) bc[j] = bp[j * PW];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) ac[i] = *reinterpret_cast<const f32x4*>(ap + 16 * i * PT);
+    for (int kb = 0; kb < H; kb += 16) {
+      f32x4 bn = bc, an[RT];
+#pragma unroll
+      for (int i = 0; i < RT; ++i) an[i] = ac[i];
+      if (kb + 16 < H) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bn[j] = bp[(kb + 16 + j) * PW];
+#pragma unroll
+        for (int i = 0; i < RT; ++i) an[i] = *reinterpret_cast<const f32x4*>(ap + 16 * i * PT + kb + 16);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < RT; ++i) v[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[i][j], bc[j], v[i], 0, 0, 0);
+      bc = bn;
+#pragma unroll
+      for (int i = 0; i < RT; ++i) ac[i] = an[i];
     }
   };
   // masked d_h: (acc [+ prior]) where act > 0 -> LDS (next layer's operand) and HBM
