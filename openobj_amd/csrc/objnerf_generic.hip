@@ -778,7 +778,7 @@ static void launch_fwd_small(hipStream_t st, const FwdSmall& f, int K) {
 
 // row tiles per workgroup so that K * ceil(n / (16 RT)) workgroups fit the chip in one round; 0 = not a small batch
 static int small_batch_rt(int H, long n, int K) {
-  if (H != FS_H || t_bf16_operands) return 0;
+  if (H != FS_H) return 0;
   for (int rt = 1; rt <= 5; ++rt)
     if ((long)K * ((n + 16 * rt - 1) / (16 * rt)) <= 256) return rt;
   return 0;
@@ -1110,6 +1110,9 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a, void* stream
   dim3 eg((unsigned)((n + 15) / 16), (unsigned)K);      // 16 lanes per sample row
   const size_t head_lds = (size_t)4 * H * sizeof(float);
   const int small_rt = small_batch_rt(H, n, K);
+  // (the small-batch kernels are fp32: in that latency-bound regime they beat the bf16-operand GEMMs as well, so
+  // OBJNERF_TRAIN_BF16 is a no-op there)
+  if (small_rt) t_bf16_operands = false;
   if (small_rt) {
     FwdSmall f;
     f.n = n; f.feat = feat ? 1 : 0; f.params = P; f.ps = ps; f.emb = w.emb;
