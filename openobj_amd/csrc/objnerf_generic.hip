@@ -378,14 +378,25 @@ __global__ __launch_bounds__(512) void mlp_fwd_small_kernel(const FwdSmall a) {
   const float* P = a.params + z * a.ps;
   const float* emb = a.emb + z * n * OBJ_EMB;
   const int kk = tid & 127, rg = tid >> 7;          // staging: lanes along k (the contiguous source dimension)
-  // rows [m0, m0 + BM) x cols [col0, col0 + KC) of the embedding -> X (zero-padded to a multiple of 4 columns)
-  auto load_emb = [&](float* X, const int col0, const int KC) {
+  // The workgroup's slice of the embedding (x1 = columns [0, E1), x2 = [E1, E1 + E2)) is fetched ONCE into
+  // registers at the start -- its HBM latency hides behind the first weight fetch -- and written to an LDS buffer
+  // where a layer needs it (x1 twice): a global load at that point would sit exposed on the critical path.
+  constexpr int ER = (BM + 3) / 4;
+  float er1[ER], er2[ER];
+#pragma unroll
+  for (int i = 0; i < ER; ++i) {
+    const int m = rg + 4 * i;
+    const bool in = m < BM && m0 + m < n;
+    er1[i] = (in && kk < OBJ_E1) ? emb[(m0 + m) * OBJ_EMB + kk] : 0.f;
+    er2[i] = (in && kk < OBJ_E2) ? emb[(m0 + m) * OBJ_EMB + OBJ_E1 + kk] : 0.f;
+  }
+  auto put_emb = [&](float* X, const float (&er)[ER], const int KC) {      // zero-padded to a multiple of 16 columns
     const int KC16 = (KC + 15) & ~15;
     if (kk < KC16) {
 #pragma unroll
-      for (int i = 0; i < (BM + 3) / 4; ++i) {
+      for (int i = 0; i < ER; ++i) {
         const int m = rg + 4 * i;
-        if (m < BM) X[m * PT + kk] = (m0 + m < n && kk < KC) ? emb[(m0 + m) * OBJ_EMB + col0 + kk] : 0.f;
+        if (m < BM) X[m * PT + kk] = er[i];
       }
     }
   };
@@ -451,7 +462,7 @@ __global__ __launch_bounds__(512) void mlp_fwd_small_kernel(const FwdSmall a) {
   constexpr int E1P = (OBJ_E1 + 15) & ~15, E2P = (OBJ_E2 + 15) & ~15;
   // ---- h1 = relu(x1 W_in^T + b)                                  (model.py:63-66)
   fetch_w(P + a.o_in_w, OBJ_E1, OBJ_E1);
-  load_emb(Xa, 0, OBJ_E1);
+  put_emb(Xa, er1, OBJ_E1);
   put_w();
   __syncthreads();
   fetch_w(P + a.o_m1_w, H, H);
@@ -468,7 +479,7 @@ __global__ __launch_bounds__(512) void mlp_fwd_small_kernel(const FwdSmall a) {
   __syncthreads();
   store(Xa, a.h2, P + a.o_m1_b);
   put_w();
-  load_emb(Xb, 0, OBJ_E1);
+  put_emb(Xb, er1, OBJ_E1);
   __syncthreads();
   // ---- h3 = relu([h2 | x1] W_cat^T + b)
   fetch_w(P + a.o_cat_w + H, H + OBJ_E1, OBJ_E1);
@@ -490,7 +501,7 @@ __global__ __launch_bounds__(512) void mlp_fwd_small_kernel(const FwdSmall a) {
   __syncthreads();
   store(Xb, a.h4, P + a.o_m2_b);
   put_w();
-  load_emb(Xa, OBJ_E1, OBJ_E2);
+  put_emb(Xa, er2, OBJ_E2);
   __syncthreads();
   // ---- hc = relu([h4 | x2] W_cl^T + b)
   fetch_w(P + a.o_cl_w + H, H + OBJ_E2, OBJ_E2);
@@ -650,6 +661,18 @@ __global__ __launch_bounds__(512) void mlp_bwd_small_kernel(const BwdSmall a) {
         mk[i][r] = (m0 + m < n) ? hp[(m0 + m) * H + f] : 0.f;
       }
   };
+  float pr[RT][4];                         // d_h4 arrives holding the alpha head's part: fetched with the mask
+  auto fetch_prior = [&](const float* src) {
+    const float* sp = src + z * n * H;
+    const int f = 16 * w + c;
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = 16 * i + 4 * gg + r;
+        pr[i][r] = (m0 + m < n) ? sp[(m0 + m) * H + f] : 0.f;
+      }
+  };
   auto store_dh = [&](float* X, float* hbm, const bool add_prior) {
     float* out = hbm + z * n * H;
     const int f = 16 * w + c;
@@ -660,7 +683,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_small_kernel(const BwdSmall a) {
         const int m = 16 * i + 4 * gg + r;
         const bool in = m0 + m < n;
         float v = acc[i][r];
-        if (add_prior && in) v += out[(m0 + m) * H + f];
+        if (add_prior) v += pr[i][r];
         v = mk[i][r] > 0.f ? v : 0.f;
         X[m * PT + f] = v;
         if (in) out[(m0 + m) * H + f] = v;
@@ -703,6 +726,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_small_kernel(const BwdSmall a) {
   __syncthreads();
   fetch_w(P + a.o_cl_w + H, H + OBJ_E2, OBJ_E2);
   fetch_mask(a.h4);
+  fetch_prior(a.d_h4);
   mma(Da, acc);
   __syncthreads();
   store_dh(Db, a.d_h4, true);                    // Db = d_h4
