@@ -445,10 +445,9 @@ __global__ __launch_bounds__(512) void mlp_fwd_small_kernel(const FwdSmall a) {
     }
   };
   // relu(acc + bias) -> LDS buffer (next layer's input) and the HBM activation
-  auto store = [&](float* X, float* hbm, const float* bias) {
+  auto store = [&](float* X, float* hbm, const float bv) {
     float* out = hbm + z * n * H;
     const int f = 16 * w + c;
-    const float bv = bias[f];
 #pragma unroll
     for (int i = 0; i < RT; ++i)
 #pragma unroll
@@ -460,6 +459,15 @@ __global__ __launch_bounds__(512) void mlp_fwd_small_kernel(const FwdSmall a) {
       }
   };
   constexpr int E1P = (OBJ_E1 + 15) & ~15, E2P = (OBJ_E2 + 15) & ~15;
+  // biases and head weights of this lane, fetched before anything waits on them
+  const int fb = 16 * w + c;
+  const float b_in = P[a.o_in_b + fb], b_m1 = P[a.o_m1_b + fb], b_cat = P[a.o_cat_b + fb], b_m2 = P[a.o_m2_b + fb];
+  const float b_cl = P[a.o_cl_b + fb], b_fl = a.feat ? P[a.o_fl_b + fb] : 0.f;
+  const float wa0 = P[a.o_a_w + lane], wa1 = P[a.o_a_w + lane + 64];
+  const float w00 = P[a.o_oc_w + lane], w01 = P[a.o_oc_w + lane + 64];
+  const float w10 = P[a.o_oc_w + H + lane], w11 = P[a.o_oc_w + H + lane + 64];
+  const float w20 = P[a.o_oc_w + 2 * H + lane], w21 = P[a.o_oc_w + 2 * H + lane + 64];
+  const float ba = P[a.o_a_b], bc0 = P[a.o_oc_b], bc1 = P[a.o_oc_b + 1], bc2 = P[a.o_oc_b + 2];
   // ---- h1 = relu(x1 W_in^T + b)                                  (model.py:63-66)
   fetch_w(P + a.o_in_w, OBJ_E1, OBJ_E1);
   put_emb(Xa, er1, OBJ_E1);
@@ -469,7 +477,7 @@ __global__ __launch_bounds__(512) void mlp_fwd_small_kernel(const FwdSmall a) {
   zero();
   mma(Xa, E1P);
   __syncthreads();
-  store(Xb, a.h1, P + a.o_in_b);
+  store(Xb, a.h1, b_in);
   put_w();
   __syncthreads();
   // ---- h2
@@ -477,7 +485,7 @@ __global__ __launch_bounds__(512) void mlp_fwd_small_kernel(const FwdSmall a) {
   zero();
   mma(Xb, H);
   __syncthreads();
-  store(Xa, a.h2, P + a.o_m1_b);
+  store(Xa, a.h2, b_m1);
   put_w();
   put_emb(Xb, er1, OBJ_E1);
   __syncthreads();
@@ -491,7 +499,7 @@ __global__ __launch_bounds__(512) void mlp_fwd_small_kernel(const FwdSmall a) {
   fetch_w(P + a.o_m2_w, H, H);
   mma(Xb, E1P);
   __syncthreads();
-  store(Xa, a.h3, P + a.o_cat_b);
+  store(Xa, a.h3, b_cat);
   put_w();
   __syncthreads();
   // ---- h4
@@ -499,7 +507,7 @@ __global__ __launch_bounds__(512) void mlp_fwd_small_kernel(const FwdSmall a) {
   zero();
   mma(Xa, H);
   __syncthreads();
-  store(Xb, a.h4, P + a.o_m2_b);
+  store(Xb, a.h4, b_m2);
   put_w();
   put_emb(Xa, er2, OBJ_E2);
   __syncthreads();
@@ -515,15 +523,10 @@ __global__ __launch_bounds__(512) void mlp_fwd_small_kernel(const FwdSmall a) {
   __syncthreads();
   // hc goes to a THIRD place: Wb is free until the next put_w and Xa (x2) is needed again by the feature layer
   float* Xc = Wb;
-  store(Xc, a.hc, P + a.o_cl_b);
+  store(Xc, a.hc, b_cl);
   __syncthreads();
   // ---- heads: alpha = 10 (h4 . wa + ba), colour = sigmoid(hc Woc^T + boc)      (model.py:81-96); a wave per row
   {
-    const float* wa = P + a.o_a_w;
-    const float* woc = P + a.o_oc_w;
-    const float wa0 = wa[lane], wa1 = wa[lane + 64];
-    const float w00 = woc[lane], w01 = woc[lane + 64], w10 = woc[H + lane], w11 = woc[H + lane + 64];
-    const float w20 = woc[2 * H + lane], w21 = woc[2 * H + lane + 64];
     for (int m = w; m < BM; m += 8) {
       const float x0 = Xb[m * PT + lane], x1 = Xb[m * PT + lane + 64];
       const float y0 = Xc[m * PT + lane], y1 = Xc[m * PT + lane + 64];
@@ -533,10 +536,10 @@ __global__ __launch_bounds__(512) void mlp_fwd_small_kernel(const FwdSmall a) {
       const float s2 = wave_sum64(fmaf(w21, y1, w20 * y0));
       if (lane == 0 && m0 + m < n) {
         const long i = z * n + m0 + m;
-        a.alpha[i] = (sa + P[a.o_a_b]) * 10.0f;
-        a.color[i * 3] = sigmoid_acc(s0 + P[a.o_oc_b]);
-        a.color[i * 3 + 1] = sigmoid_acc(s1 + P[a.o_oc_b + 1]);
-        a.color[i * 3 + 2] = sigmoid_acc(s2 + P[a.o_oc_b + 2]);
+        a.alpha[i] = (sa + ba) * 10.0f;
+        a.color[i * 3] = sigmoid_acc(s0 + bc0);
+        a.color[i * 3 + 1] = sigmoid_acc(s1 + bc1);
+        a.color[i * 3 + 2] = sigmoid_acc(s2 + bc2);
       }
     }
   }
@@ -555,13 +558,12 @@ __global__ __launch_bounds__(512) void mlp_fwd_small_kernel(const FwdSmall a) {
   float* out = a.hf + z * n * H;
   {
     const int f = 16 * w + c;
-    const float bv = P[a.o_fl_b + f];
 #pragma unroll
     for (int i = 0; i < RT; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = 16 * i + 4 * gg + r;
-        if (m0 + m < n) out[(m0 + m) * H + f] = fmaxf(acc[i][r] + bv, 0.f);
+        if (m0 + m < n) out[(m0 + m) * H + f] = fmaxf(acc[i][r] + b_fl, 0.f);
       }
   }
 }
