@@ -802,11 +802,16 @@ static void launch_fwd_small(hipStream_t st, const FwdSmall& f, int K) {
   hipLaunchKernelGGL(mlp_fwd_small_kernel<RT>, grid, dim3(512), fs_lds_bytes<RT>(), st, f);
 }
 
-// row tiles per workgroup so that K * ceil(n / (16 RT)) workgroups fit the chip in one round; 0 = not a small batch
+// row tiles per workgroup: the smallest RT for which K * ceil(n / (16 RT)) workgroups fit the chip in one round;
+// 0 = not a small batch
 static int small_batch_rt(int H, long n, int K) {
   if (H != FS_H) return 0;
   for (int rt = 1; rt <= 5; ++rt)
     if ((long)K * ((n + 16 * rt - 1) / (16 * rt)) <= 256) return rt;
+  // up to four rounds of 80-sample workgroups the one-launch kernels still win (76 800 samples: 1.02 vs 1.07 ms per
+  // step, 38 400: 0.53 vs 0.65); beyond that the GEMM path runs near the MFMA peak
+  // (fp32 mode only: with bf16 operands the GEMMs are ahead again from two rounds on)
+  if (!t_bf16_operands && (long)K * ((n + 79) / 80) <= 1024) return 5;
   return 0;
 }
 
