@@ -62,6 +62,7 @@ class IncrementalMapper:
         self.vis_dict: Dict[int, sceneObject] = {}      # + the background object
         self.scene_bg: Optional[sceneObject] = None
         self.global_partfeat: Optional[torch.Tensor] = None
+        self._partfeat_buf: Optional[torch.Tensor] = None
         self.loop: Optional[otrain.HipTrainLoop] = None
         self.bg_loop: Optional[otrain.BackgroundLoop] = None
         self._restack = False
@@ -82,9 +83,17 @@ class IncrementalMapper:
         bbox_dict, obj_clip, obj_cap = sample["bbox_dict"], sample["obj_clip"], sample["obj_cap"]
         live_frame_id = int(sample["frame_id"]) if "frame_id" in sample else frame_id
         if cfg.part_mode:
+            # train.py:187-191 grows the [frames, W', H', C] tensor with torch.cat every frame (67 MB per frame at
+            # 240 x 136 x 512: quadratic copying); here the buffer doubles its capacity and the frame is copied once
             part = _to_dev(sample["part_feat"], dev, torch.float32)
-            self.global_partfeat = part.unsqueeze(0) if self.global_partfeat is None else \
-                torch.cat((self.global_partfeat, part.unsqueeze(0)), dim=0)
+            cnt = 0 if self.global_partfeat is None else self.global_partfeat.shape[0]
+            if self._partfeat_buf is None or cnt == self._partfeat_buf.shape[0]:
+                grown = torch.empty((max(8, 2 * cnt),) + tuple(part.shape), dtype=torch.float32, device=dev)
+                if cnt:
+                    grown[:cnt] = self._partfeat_buf[:cnt]
+                self._partfeat_buf = grown
+            self._partfeat_buf[cnt] = part
+            self.global_partfeat = self._partfeat_buf[:cnt + 1]
         inst = _to_dev(sample["obj"], dev, torch.int32)
         created = []
         writes = []                     # (object, slot, 2-D box): every slot of this frame is written in ONE launch
