@@ -234,3 +234,40 @@ def test_batched_ingest_equals_per_object(dev, tmp_path):
         assert torch.equal(o.rgbs_batch[:n], r.rgbs_batch[:n]) and torch.equal(o.depth_batch[:n], r.depth_batch[:n])
         assert torch.equal(o.t_wc_batch[:n], r.t_wc_batch[:n]) and torch.equal(o.bbox[:n], r.bbox[:n])
         assert o._defer is None
+
+
+def test_batched_ingest_with_full_keyframe_buffers(dev, tmp_path, monkeypatch):
+    """The same comparison when the ring buffers are full (slot re-use, pruning, live-slot replacement:
+    vmap.py:196-240).  Pruning is random in the reference; here both sides drop the oldest entry."""
+    from openobj_amd import vmap as ovmap
+    monkeypatch.setattr(ovmap.sceneObject, "prune_keyframe",
+                        lambda self: list(self.kf_id_dict.items())[:-2][0])
+    root = tmp_path / "scene"
+    SF.write_scene(str(root), "Replica", n_frames=120)
+    c = make_cfg(root, dev, **{"model.keyframe_step": 20, "model.keyframe_step_bg": 30, "model.keyframe_buffer_size": 4})
+    ds = ods.Replica(c)
+    m = mapping.IncrementalMapper(c)
+    ref = {}
+    for i in range(12):
+        s = ds[i]
+        m.ingest(s, i)
+        rgb, depth = torch.as_tensor(s["image"]).to(dev), torch.as_tensor(s["depth"]).to(dev)
+        inst, twc = torch.as_tensor(s["obj"]).to(dev), torch.as_tensor(s["T"]).float().to(dev)
+        for oid in torch.unique(inst).tolist():
+            if oid == -1:
+                continue
+            state = torch.zeros_like(inst, dtype=torch.uint8)
+            state[inst == oid] = 1
+            state[inst == -1] = 2
+            bbox = s["bbox_dict"][oid].float().to(dev)
+            if oid in ref:
+                ref[oid].append_keyframe(rgb, depth, state, bbox, twc, s["frame_id"])
+            else:
+                ref[oid] = ovmap.sceneObject(c, oid, rgb, depth, state, bbox, twc, s["frame_id"])
+    for oid, r in ref.items():
+        o = m.vis_dict[oid]
+        assert r.kf_buffer_full and o.kf_buffer_full and o.kf_pointer == r.kf_pointer
+        assert o.kf_id_dict == r.kf_id_dict and o.lastest_kf_queue == r.lastest_kf_queue and o.n_keyframes == r.n_keyframes
+        used = sorted(r.kf_id_dict.values())
+        assert torch.equal(o.rgbs_batch[used], r.rgbs_batch[used]) and torch.equal(o.depth_batch[used], r.depth_batch[used])
+        assert torch.equal(o.t_wc_batch[used], r.t_wc_batch[used]) and torch.equal(o.bbox[used], r.bbox[used])
