@@ -98,3 +98,15 @@ def test_enlarge_bbox_rules():
     assert ods.enlarge_bbox([10, 20, 30, 60], 0.2, 100, 100) == [8, 16, 32, 64]
     assert ods.enlarge_bbox([0, 0, 99, 99], 0.2, 100, 100) == [0, 0, 99, 99]
     assert ods.enlarge_bbox([10, 10, 15, 60], 0.2, 100, 100) is None          # margin rounds to 0 (utils.py:73-74)
+
+
+def test_majority_cluster_mean_and_imports():
+    """utils.py:138-155 (DBSCAN majority cluster) and that the mapping module imports without a GPU."""
+    from openobj_amd import mapping
+    rs = np.random.RandomState(0)
+    a = np.tile(np.eye(8)[1], (6, 1)) + 0.01 * rs.randn(6, 8)        # the majority cluster
+    b = np.tile(np.eye(8)[5], (3, 1)) + 0.01 * rs.randn(3, 8)
+    v = np.vstack([a[:3], b, a[3:]])
+    m = mapping.get_majority_cluster_mean(v, eps=0.2, min_samples=2)
+    assert np.allclose(m, a.mean(0), atol=1e-12)
+    assert mapping._first(np.ones((1, 4))).shape == (4,) and mapping._first(np.ones(4)).shape == (4,)
