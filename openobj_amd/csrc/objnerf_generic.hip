@@ -1143,6 +1143,31 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a, void* stream
   const int E1 = OBJ_E1, E2 = OBJ_E2, EM = OBJ_EMB;
   const long nH = n * H;
 
+  // helper stream: work that only READS what the main chain produced (or, for the feature preparation below, only
+  // parameters and inputs) runs beside it; fork = the side stream waits for everything enqueued on `st` so far
+  Side& sd = side_stream();
+  int fk = 0;
+  const int n_side = 1;
+  auto fork = [&]() {
+    (void)hipEventRecord(sd.ev[fk], st);
+    for (int i = 0; i < n_side; ++i) (void)hipStreamWaitEvent(sd.all[i], sd.ev[fk], 0);
+    fk = (fk + 1) % Side::NEV;
+  };
+  hipStream_t ss = sd.s;
+  if (feat) {
+    // the 512-d head is NOT applied per sample: per object G = W_of^T W_of (+ wb, bb), per ray u = W_of^T g, beta, |g|.
+    // None of it depends on the forward pass: side stream, joined before the loss.
+    const long R = a->R;
+    const long gst = (long)H * H + H + 1;
+    fork();
+    gemm(ss, K, H, H, C, P + off[16], 1, H, ps, P + off[16], H, 1, ps, w.gram, H, 1, gst);
+    hipLaunchKernelGGL(featg_wb_kernel, dim3(H + 1, K), dim3(64), 0, ss, P, ps, (int)off[16], (int)off[17], C, H, w.gram, gst);
+    gemm(ss, K, (int)R, H, C, a->gt_feat, C, 1, R * C, P + off[16], H, 1, ps, w.rayin, H + 2, 1, R * (H + 2));
+    hipLaunchKernelGGL(featg_rowstats_kernel, dim3((unsigned)((R + 15) / 16), K), dim3(256), 0, ss, P, ps, (int)off[17], C,
+                       (int)R, H + 2, a->gt_feat, w.rayin);
+    (void)hipEventRecord(sd.done, ss);
+  }
+
   // ---- forward
   int rc = objnerf_embed(net, K, n, P, ps, a->scale, a->pts, w.emb, stream);
   if (rc) return rc;
@@ -1188,16 +1213,7 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a, void* stream
          ps, true);
   }
   }
-  if (feat) {
-    // the 512-d head is NOT applied per sample: per object G = W_of^T W_of (+ wb, bb), per ray u = W_of^T g, beta, |g|
-    const long R = a->R;
-    const long gst = (long)H * H + H + 1;
-    gemm(st, K, H, H, C, P + off[16], 1, H, ps, P + off[16], H, 1, ps, w.gram, H, 1, gst);
-    hipLaunchKernelGGL(featg_wb_kernel, dim3(H + 1, K), dim3(64), 0, st, P, ps, (int)off[16], (int)off[17], C, H, w.gram, gst);
-    gemm(st, K, (int)R, H, C, a->gt_feat, C, 1, R * C, P + off[16], H, 1, ps, w.rayin, H + 2, 1, R * (H + 2));
-    hipLaunchKernelGGL(featg_rowstats_kernel, dim3((unsigned)((R + 15) / 16), K), dim3(256), 0, st, P, ps, (int)off[17], C,
-                       (int)R, H + 2, a->gt_feat, w.rayin);
-  }
+  if (feat) (void)hipStreamWaitEvent(st, sd.done, 0);      // the feature preparation (side stream) is needed from here
   // ---- loss + d(alpha, color, clip)      (loss.py:5-103)
   objnerf_loss_args la;
   la.K = K; la.R = a->R; la.S = a->S; la.C = C;
@@ -1221,15 +1237,6 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a, void* stream
   // Weight-gradient GEMMs only READ the d-output / activation buffers and write the gradient arena, so they run on a
   // side stream beside the dgrad chain (each of these GEMMs alone leaves most of the chip idle).  Every d_h has its own
   // buffer: nothing a side-stream GEMM reads is overwritten before the join at the end.
-  Side& sd = side_stream();
-  int fk = 0;
-  const int n_side = 1;
-  auto fork = [&]() {                       // the side stream(s) wait for everything enqueued on `st` so far
-    (void)hipEventRecord(sd.ev[fk], st);
-    for (int i = 0; i < n_side; ++i) (void)hipStreamWaitEvent(sd.all[i], sd.ev[fk], 0);
-    fk = (fk + 1) % Side::NEV;
-  };
-  hipStream_t ss = sd.s;
   int rr = 0;
   auto side = [&]() -> hipStream_t {        // stream of the next independent weight-gradient GEMM
     hipStream_t r = sd.all[rr];
