@@ -414,11 +414,12 @@ def test_stress_shape_step_vs_oracle(dev):
 
 
 @pytest.mark.parametrize("shape,feat_on", [((1, 1200, 5, 9), False), ((1, 700, 5, 9), True), ((3, 260, 5, 9), False),
-                                           ((2, 333, 4, 7), True)])
+                                           ((2, 333, 4, 7), True), ((1, 2500, 5, 9), False)])
 def test_small_batch_one_launch_kernels_vs_oracle(dev, shape, feat_on):
     """Hidden 128 at the reference's native background batch (1200 rays x 14 samples) and around it: the forward and
     the input-gradient chain are ONE launch each (mlp_fwd_small_kernel / mlp_bwd_small_kernel with 5, 3, 4, 3 row
-    tiles per workgroup here, ragged last tiles, several objects) and the weight gradients one grouped launch;
+    tiles per workgroup here, ragged last tiles, several objects; the last case takes two rounds of workgroups) and the
+    weight gradients one grouped launch;
     loss and every gradient against the oracle."""
     K, R, n1, n2 = shape
     H = 128
