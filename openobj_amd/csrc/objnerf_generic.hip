@@ -1154,12 +1154,19 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a, void* stream
     fk = (fk + 1) % Side::NEV;
   };
   hipStream_t ss = sd.s;
+  // Weight / bias gradients are accumulated with split-K atomics by GEMMs on the side stream: zero them there, now,
+  // off the critical path (feature-branch entries only when they receive a gradient, so "no gradient" stays
+  // "untouched").  The previous step's consumer of the gradient arena (AdamW) is ordered before this fork.
+  fork();
+  for (int k = 0; k < K; ++k) {
+    (void)hipMemsetAsync(a->grads + (long)k * ps, 0, (size_t)off[14] * 4, ss);
+    if (feat) (void)hipMemsetAsync(a->grads + (long)k * ps + off[14], 0, (size_t)(off[18] - off[14]) * 4, ss);
+  }
   if (feat) {
     // the 512-d head is NOT applied per sample: per object G = W_of^T W_of (+ wb, bb), per ray u = W_of^T g, beta, |g|.
     // None of it depends on the forward pass: side stream, joined before the loss.
     const long R = a->R;
     const long gst = (long)H * H + H + 1;
-    fork();
     gemm(ss, K, H, H, C, P + off[16], 1, H, ps, P + off[16], H, 1, ps, w.gram, H, 1, gst);
     hipLaunchKernelGGL(featg_wb_kernel, dim3(H + 1, K), dim3(64), 0, ss, P, ps, (int)off[16], (int)off[17], C, H, w.gram, gst);
     gemm(ss, K, (int)R, H, C, a->gt_feat, C, 1, R * C, P + off[16], H, 1, ps, w.rayin, H + 2, 1, R * (H + 2));
@@ -1228,12 +1235,7 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a, void* stream
   hz.Hh = H; hz.hf = w.hf; hz.rayin = w.rayin; hz.gram = w.gram; hz.d_hf = w.d_hf; hz.rayfeat = w.rayfeat;
   rc = objmisc::step_batch_loss_impl(&la, feat ? &hz : nullptr, stream);
   if (rc) return rc;
-  // ---- backward.  Weight / bias gradients are accumulated with split-K atomics: zero them first
-  // (feature-branch entries only when they receive a gradient, so "no gradient" stays "untouched").
-  for (int k = 0; k < K; ++k) {
-    (void)hipMemsetAsync(G + (long)k * ps, 0, (size_t)off[14] * 4, st);
-    if (feat) (void)hipMemsetAsync(G + (long)k * ps + off[14], 0, (size_t)(off[18] - off[14]) * 4, st);
-  }
+  // ---- backward
   // Weight-gradient GEMMs only READ the d-output / activation buffers and write the gradient arena, so they run on a
   // side stream beside the dgrad chain (each of these GEMMs alone leaves most of the chip idle).  Every d_h has its own
   // buffer: nothing a side-stream GEMM reads is overwritten before the join at the end.

@@ -128,8 +128,13 @@ __global__ void label_counts_kernel(int K, int R, const uint8_t* labels, int* co
     const int a = s1[0] + s1[1] + s1[2] + s1[3], b = s2[0] + s2[1] + s2[2] + s2[3];
     counts[2 * k] = a;
     counts[2 * k + 1] = b;
-    if (a == 0) atomicOr(&flags[0], 1);
-    if (b == 0) atomicOr(&flags[1], 1);
+    if (K == 1) {                       // a single object owns the flags: no zero fill, no atomics
+      flags[0] = a == 0;
+      flags[1] = b == 0;
+    } else {
+      if (a == 0) atomicOr(&flags[0], 1);
+      if (b == 0) atomicOr(&flags[1], 1);
+    }
   }
 }
 
@@ -585,7 +590,7 @@ int step_batch_loss_impl(const objnerf_loss_args* a, const LossHoisted* hz, void
     hipLaunchKernelGGL(loss_prologue_kernel, dim3(1), dim3(256), 0, st, a->K, a->counts_in, a->counts, flags, a->flags_in,
                        a->loss_terms);
   } else {
-    (void)hipMemsetAsync(flags, 0, 2 * sizeof(int), st);
+    if (a->K > 1) (void)hipMemsetAsync(flags, 0, 2 * sizeof(int), st);
     hipLaunchKernelGGL(label_counts_kernel, dim3(a->K), dim3(256), 0, st, a->K, a->R, a->labels, a->counts, flags);
     if (a->flags_in) hipLaunchKernelGGL(merge_flags_kernel, dim3(1), dim3(64), 0, st, flags, a->flags_in);
     (void)hipMemsetAsync(a->loss_terms, 0, (size_t)a->K * 4 * sizeof(float), st);
@@ -668,7 +673,7 @@ int objnerf_label_counts(int32_t K, int32_t R, const uint8_t* labels, int32_t* c
                          void* stream) {
   CLEAR_STALE();
   if (K <= 0 || R <= 0 || !labels || !counts || !flags_out) return OBJNERF_EINVAL;
-  (void)hipMemsetAsync(flags_out, 0, 2 * sizeof(int), (hipStream_t)stream);
+  if (K > 1) (void)hipMemsetAsync(flags_out, 0, 2 * sizeof(int), (hipStream_t)stream);
   hipLaunchKernelGGL(label_counts_kernel, dim3(K), dim3(256), 0, (hipStream_t)stream, K, R, labels, counts, flags_out);
   CHECK_LAUNCH();
   return OBJNERF_OK;
