@@ -5,7 +5,10 @@ import torch
 
 from openobj_amd import cfg as ocfg
 from openobj_amd import dataset as ods
-from tests import scene_files as SF
+try:
+    from tests import scene_files as SF
+except ImportError:          # plain `pytest tests/` puts tests/ itself, not the repository root, on sys.path
+    import scene_files as SF
 
 
 def make_cfg(root, fmt, **kw):

@@ -9,7 +9,10 @@ import torch
 from openobj_amd import cfg as ocfg
 from openobj_amd import dataset as ods
 from openobj_amd import mapping
-from tests import scene_files as SF
+try:
+    from tests import scene_files as SF
+except ImportError:          # plain `pytest tests/` puts tests/ itself, not the repository root, on sys.path
+    import scene_files as SF
 
 pytestmark = pytest.mark.gpu
 
