@@ -5,7 +5,7 @@ the K objects are split into contiguous blocks and NO data-path collective is ne
 coupling is render_rays.py:89-94: if ANY object of the batch has an empty mask, that loss term is zero
 for ALL objects -- a pair of flags that must be global (2-int all_reduce(MAX))."""
 import os
-from typing import Optional, Tuple
+from typing import Tuple
 
 import torch
 

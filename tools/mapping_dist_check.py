@@ -6,7 +6,6 @@ ranks while it trains on disjoint ray shares, losses fall, checkpoints are writt
 import os
 import sys
 
-import numpy as np
 import torch
 import torch.distributed as dist
 
