@@ -216,7 +216,7 @@ def test_train_step_vs_oracle(golden, dev, shape, feat_on):
                                        T(b["labels"]), T(b["z"]), gt_feat=T(b["gt_feat"]) if feat_on else None,
                                        return_terms=True)
     grads = torch.autograd.grad(loss, fcr + [Br], allow_unused=True)
-    terms = {k: v.detach() for k, v in terms.items()}
+    terms = {k: (v.detach() if v is not None else None) for k, v in terms.items()}
     t = ws.loss_terms.cpu()
     assert maxerr(t[:, 0], terms["depth"]) < 1e-4 * max(1.0, float(terms["depth"].abs().max()))
     assert maxerr(t[:, 1], terms["color"]) < 1e-4
