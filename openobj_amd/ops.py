@@ -12,7 +12,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import LossArgs, Net, SampleArgs, TrainArgs, check, lib
+from ._lib import LossArgs, Net, ObjnerfError, SampleArgs, TrainArgs, check, lib
 
 EMB1, EMB2, N_DIRS = 87, 42, 21
 TENSOR_NAMES = [

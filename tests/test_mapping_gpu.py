@@ -274,3 +274,37 @@ def test_batched_ingest_with_full_keyframe_buffers(dev, tmp_path, monkeypatch):
         used = sorted(r.kf_id_dict.values())
         assert torch.equal(o.rgbs_batch[used], r.rgbs_batch[used]) and torch.equal(o.depth_batch[used], r.depth_batch[used])
         assert torch.equal(o.t_wc_batch[used], r.t_wc_batch[used]) and torch.equal(o.bbox[used], r.bbox[used])
+
+
+def test_new_entry_points_reject_bad_arguments(dev):
+    """objnerf_ingest_frame / objnerf_sample_rays_stacked: EINVAL on null / empty input, host-side shape checks."""
+    import ctypes as C
+    from openobj_amd import _lib, ops
+    lib = _lib.lib()
+    assert lib.objnerf_ingest_frame(4, 4, None, None, None, None, 1, None, None) == -22
+    z = torch.zeros(4, 4, device=dev)
+    assert lib.objnerf_ingest_frame(4, 4, z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), 0, z.data_ptr(), None) == -22
+    a = _lib.SampleArgs()
+    assert lib.objnerf_sample_rays_stacked(C.byref(a), 1, None, None) == -22
+    W, H, F = 8, 6, 3
+    store = (torch.zeros(F, W, H, 4, dtype=torch.uint8, device=dev), torch.zeros(F, W, H, device=dev),
+             torch.zeros(F, 4, 4, device=dev), torch.zeros(F, 4, device=dev))
+    rgb = torch.zeros(W, H, 3, dtype=torch.uint8, device=dev)
+    depth = torch.ones(W, H, device=dev)
+    inst = torch.full((W, H), 5, dtype=torch.int32, device=dev)
+    inst[0, 0] = -1
+    twc = torch.eye(4, device=dev)
+    with pytest.raises(_lib.ObjnerfError):
+        ops.ingest_frame(rgb, depth, inst, twc, [(store, F, 5, [0, 1, 2, 3])])          # slot out of range
+    with pytest.raises(_lib.ObjnerfError):
+        ops.ingest_frame(rgb, depth[:, :5].contiguous(), inst, twc, [(store, 0, 5, [0, 1, 2, 3])])
+    ops.ingest_frame(rgb, depth, inst, twc, [(store, 2, 5, [0, 7, 0, 5]), (store, 1, 9, [1, 2, 3, 4])])
+    torch.cuda.synchronize()
+    assert int(store[0][2, 1, 1, 3]) == 1 and int(store[0][2, 0, 0, 3]) == 2            # this object / unknown
+    assert int(store[0][1, 1, 1, 3]) == 0 and int(store[0][1, 0, 0, 3]) == 2            # other object / unknown
+    assert store[3][2].tolist() == [0, 7, 0, 5] and torch.equal(store[2][1], twc) and float(store[1][2].min()) == 1.0
+    table = ops.keyframe_table([store])
+    with pytest.raises(_lib.ObjnerfError):
+        ops.sample_rays_stacked(table, F, W, H, torch.zeros(W, H, 3, device=dev), torch.zeros(2, 3, dtype=torch.int64, device=dev),
+                                torch.zeros(1, 3, 2, device=dev), torch.zeros(1, 3, 2, device=dev),
+                                torch.zeros(1, 6, 10, device=dev), torch.zeros(1, 6, 9, device=dev), 1, 9, 0.1, 0.05)
