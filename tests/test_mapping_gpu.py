@@ -308,3 +308,21 @@ def test_new_entry_points_reject_bad_arguments(dev):
         ops.sample_rays_stacked(table, F, W, H, torch.zeros(W, H, 3, device=dev), torch.zeros(2, 3, dtype=torch.int64, device=dev),
                                 torch.zeros(1, 3, 2, device=dev), torch.zeros(1, 3, 2, device=dev),
                                 torch.zeros(1, 6, 10, device=dev), torch.zeros(1, 6, 9, device=dev), 1, 9, 0.1, 0.05)
+
+
+def test_models_full_and_no_background(dev, tmp_path):
+    """train.py:232-234: objects beyond cfg.max_n_models are ignored; do_bg = 0 puts the wall (id 0) into the stack."""
+    root = tmp_path / "scene"
+    SF.write_scene(str(root), "Replica", n_frames=20)
+    c = make_cfg(root, dev, **{"trainer.n_models": 1, "render.iters_per_frame": 3})
+    ds = ods.Replica(c)
+    m = mapping.IncrementalMapper(c)
+    out = m.step_frame(ds[0], 0)
+    assert list(m.obj_dict) == [4] and sorted(m.vis_dict) == [0, 4] and len(out["obj"]) == 3 and len(out["bg"]) == 3
+    m.step_frame(ds[1], 1)
+    assert list(m.obj_dict) == [4] and m.n_foreground == 1
+    c2 = make_cfg(root, dev, **{"trainer.do_bg": 0, "render.iters_per_frame": 3})
+    m2 = mapping.IncrementalMapper(c2)
+    out = m2.step_frame(ods.Replica(c2)[0], 0)
+    assert list(m2.obj_dict) == [0, 4, 7] and m2.scene_bg is None and out["bg"] == []
+    assert torch.stack(out["obj"]).shape == (3, 3, 4)
