@@ -326,3 +326,17 @@ def test_models_full_and_no_background(dev, tmp_path):
     out = m2.step_frame(ods.Replica(c2)[0], 0)
     assert list(m2.obj_dict) == [0, 4, 7] and m2.scene_bg is None and out["bg"] == []
     assert torch.stack(out["obj"]).shape == (3, 3, 4)
+
+
+def test_mapping_bf16_mode(dev, tmp_path):
+    """The opt-in bf16-operand mode through the mapping loop (objects: bf16 fused kernel; small background batches keep
+    the fp32 one-launch kernels)."""
+    root = tmp_path / "scene"
+    SF.write_scene(str(root), "Replica", n_frames=30)
+    c = make_cfg(root, dev, **{"render.iters_per_frame": 40})
+    m = mapping.IncrementalMapper(c, bf16=True)
+    hist = []
+    m.run(ods.init_loader(c, multi_worker=False), on_frame=lambda f, l: hist.append(l))
+    assert m.loop.bf16 and m.bg_loop.bf16
+    first, last = _total(hist[0]["obj"]), _total(hist[-1]["obj"])
+    assert torch.isfinite(last).all() and float(last[-10:].mean()) < 0.5 * float(first[:10].mean())
