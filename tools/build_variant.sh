@@ -7,7 +7,7 @@ name=$1; shift
 mkdir -p abl
 make -s
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off"
-/opt/rocm/bin/hipcc $FLAGS "$@" -c objnerf_train.hip -o abl/train_$name.o &
+/opt/rocm/bin/hipcc $FLAGS -mllvm -amdgpu-sched-strategy=max-ilp "$@" -c objnerf_train.hip -o abl/train_$name.o &
 /opt/rocm/bin/hipcc $FLAGS "$@" -c objnerf_train_bf16.hip -o abl/train_bf16_$name.o &
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o abl/lib_$name.so abl/train_$name.o abl/train_bf16_$name.o objnerf_misc.o objnerf_generic.o
