@@ -23,6 +23,11 @@ Fixtures:
   g10_bg     background-shaped (K=1, H=128, S=14) iteration: loss + grads
   g11_render Trainer.sample_points_bbox + sceneObject.render_2D_syn (novel-view depth / rgb / 512-d feature
              maps of one object inside its oriented box), hidden 32 and 128
+  g12_keyframes  sceneObject.__init__ / append_keyframe / prune_keyframe (vmap.py:29-257) driven frame by frame
+             with the state maps of train.py:197-205: slot trace (kf_id_dict order, lastest_kf_queue, kf_pointer,
+             n_keyframes, use_frame), the recorded random.choice picks and the final keyframe buffers
+  g13_ckpt   sceneObject.save_checkpoints (vmap.py:556-576): the file the reference writes (g13_ref_obj_5.pth)
+             + the saved parameters and the reference's outputs for them on a few points
 """
 import os
 import sys
@@ -251,6 +256,7 @@ def g5_g6():
         "s10_nofeat": (3, 16, 1, 9, False),
         "s10_feat": (3, 16, 1, 9, True),
         "s64_feat": (2, 8, 16, 48, True),
+        "s64_nofeat": (2, 8, 16, 48, False),       # the headline shape: 64 samples per ray, no feature loss
     }.items():
         ts = make_trainers(K, seed=50)
         fc0, B0 = stack_params(ts)
@@ -498,6 +504,169 @@ def g11():
     save("g11_render", rays_dir=rays_dir, T_WC=T_WC, box_center=box.center, box_R=box.R, box_extent=box.extent,
          mask_in=obj_mask, cam=np.array([W, H, fx, fy, cx, cy], np.float32), scale=np.float32(2.0), **out)
 
+# ------------------------------------------------------------------------------------------ G12
+class _Inverse:
+    def __init__(self, b):
+        self._b = b
+
+    def __setitem__(self, val, key):
+        # bidict 0.22.0 `b.inv[val] = key` (BidictBase._write, "just key duplication" in the inverse): the forward
+        # mapping gains `key -> val` as a NEW key (appended: the forward dict is insertion-ordered) and the key that
+        # mapped to `val` before is deleted.
+        f = self._b._f
+        old = [k for k, v in f.items() if v == val]
+        assert key not in f or f[key] == val
+        f[key] = val
+        for k in old:
+            if k != key:
+                del f[k]
+
+    def __getitem__(self, val):
+        return next(k for k, v in self._b._f.items() if v == val)
+
+
+class _Bidict:
+    """Stand-in for `bidict.bidict` (the reference pins bidict==0.22.0, environment.yml:86; the package is not
+    installed here and cannot be).  Only what sceneObject uses (vmap.py:69,193,218,221,253): construction from a dict,
+    forward item assignment of a new key with a new value, `.inv[value] = key`, `.items()`.  Semantics restated from
+    bidict 0.22.0: one insertion-ordered forward dict; see _Inverse.__setitem__ for the one non-obvious rule."""
+
+    def __init__(self, d=()):
+        self._f = dict(d)
+
+    def __setitem__(self, k, v):
+        assert k not in self._f and v not in self._f.values()      # the only use: a new keyframe (vmap.py:221)
+        self._f[k] = v
+
+    def __getitem__(self, k):
+        return self._f[k]
+
+    def __len__(self):
+        return len(self._f)
+
+    def items(self):
+        return self._f.items()
+
+    def keys(self):
+        return self._f.keys()
+
+    def values(self):
+        return self._f.values()
+
+    @property
+    def inv(self):
+        return _Inverse(self)
+
+
+def make_map_cfg(**kw):
+    """The attributes sceneObject.__init__ and Trainer.__init__ read (vmap.py:31-160, trainer.py:12-34)."""
+    c = types.SimpleNamespace(do_bg=1, data_device="cpu", training_device="cpu", part_mode=True, stride=10, part_down=2,
+                              bg_scale=5.0, hidden_feature_size_bg=128, n_bins_cam2surface_bg=5, keyframe_step_bg=5.0,
+                              obj_scale=2.0, hidden_feature_size=32, n_bins_cam2surface=1, keyframe_step=2.5,
+                              min_depth=0.0, max_depth=8.0, n_bins=9, n_unidir_funcs=5, surface_eps=0.1, stop_eps=0.05,
+                              keyframe_buffer_size=6, eps_fine_vis=0.1, n_bins_fine_vis=10,
+                              clip_point_feature_size=512, W=8, H=6, obj_id=1)
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+G12_SCENARIOS = {          # obj_id, cfg overrides, frames
+    "fg_step2p5_buf6": (3, dict(), 30),                              # room_0's keyframe_step (cfg.py: 2.5), prunes
+    "fg_step1_buf5": (7, dict(keyframe_step=1, keyframe_buffer_size=5), 16),    # every frame a keyframe
+    "bg_step5_buf20": (0, dict(keyframe_buffer_size=20), 30),        # the background object: its own step, no prune
+}
+
+
+def g12():
+    import random as pyrandom
+    ref_vmap.bidict = _Bidict
+    out = {}
+    for tag, (obj_id, over, n_frames) in G12_SCENARIOS.items():
+        cfg = make_map_cfg(**over)
+        W, H, Fb = cfg.W, cfg.H, cfg.keyframe_buffer_size
+        rs = np.random.RandomState(1200 + obj_id)
+        rgb = rs.randint(0, 256, (n_frames, W, H, 3)).astype(np.uint8)
+        depth = (rs.rand(n_frames, W, H) * 5).astype(np.float32)
+        inst = rs.choice([-1, 0, 3, 7], size=(n_frames, W, H), p=[.1, .4, .3, .2]).astype(np.int32)
+        t_wc = rs.randn(n_frames, 4, 4).astype(np.float32)
+        bbox = np.sort(rs.rand(n_frames, 2, 2) * np.array([W, H])[None, :, None], axis=-1).reshape(n_frames, 4)
+        bbox = bbox.astype(np.float32)
+        frame_ids = [10 * i for i in range(n_frames)]
+        picks, cands = [], []
+        _choice = pyrandom.choice
+
+        def choice(seq):
+            r = _choice(seq)
+            picks.append(list(r))
+            cands.append(len(seq))
+            return r
+
+        pyrandom.seed(77 + obj_id)
+        ref_vmap.random.choice = choice
+        try:
+            so = None
+            tr_items, tr_queue, tr_meta, tr_use = [], [], [], []
+            for i in range(n_frames):
+                state = torch.zeros((W, H), dtype=torch.uint8)            # train.py:201-203
+                it = torch.from_numpy(inst[i])
+                state[it == obj_id] = 1
+                state[it == -1] = 2
+                args = (torch.from_numpy(rgb[i]), torch.from_numpy(depth[i]), state, torch.from_numpy(bbox[i]),
+                        torch.from_numpy(t_wc[i]), frame_ids[i])
+                if so is None:
+                    torch.manual_seed(5)
+                    so = ref_vmap.sceneObject(cfg, obj_id, *args, clip_feat=np.zeros((1, 4)), caption_feat=np.zeros((1, 4)))
+                else:
+                    so.append_keyframe(*args)
+                items = np.full((Fb, 2), -1, np.int64)
+                cur = np.array(list(so.kf_id_dict.items()), np.int64)
+                items[:len(cur)] = cur
+                q = np.full(2, -1, np.int64)
+                q[:len(so.lastest_kf_queue)] = so.lastest_kf_queue
+                tr_items.append(items)
+                tr_queue.append(q)
+                tr_meta.append([so.n_keyframes, -1 if so.kf_pointer is None else so.kf_pointer, so.frame_cnt,
+                                int(so.kf_buffer_full)])
+                tr_use.append(so.use_frame.copy())
+        finally:
+            ref_vmap.random.choice = _choice
+        live = sorted(set(so.kf_id_dict.values()))
+        out.update({f"{tag}_rgb": rgb, f"{tag}_depth": depth, f"{tag}_inst": inst, f"{tag}_t_wc": t_wc,
+                    f"{tag}_bbox": bbox, f"{tag}_frame_ids": np.array(frame_ids), f"{tag}_items": np.stack(tr_items),
+                    f"{tag}_queue": np.stack(tr_queue), f"{tag}_meta": np.array(tr_meta, np.int64),
+                    f"{tag}_use_frame": np.stack(tr_use), f"{tag}_picks": np.array(picks, np.int64).reshape(-1, 2),
+                    f"{tag}_n_cands": np.array(cands, np.int64), f"{tag}_live_slots": np.array(live),
+                    f"{tag}_rgbs_batch": so.rgbs_batch[live], f"{tag}_depth_batch": so.depth_batch[live],
+                    f"{tag}_t_wc_batch": so.t_wc_batch[live], f"{tag}_bbox_batch": so.bbox[live],
+                    f"{tag}_cfg": np.array([obj_id, Fb, W, H, n_frames], np.int64),
+                    f"{tag}_steps": np.array([so.keyframe_step], np.float64)})
+        print(tag, "keyframes", so.n_keyframes, "picks", len(picks), "live slots", live)
+    save("g12_keyframes", **out)
+
+
+# ------------------------------------------------------------------------------------------ G13
+def g13():
+    torch.manual_seed(13)
+    cfg = make_cfg(hidden=32, scale=2.0)
+    cfg.obj_id = 5
+    t = ref_trainer.Trainer(cfg)
+    with torch.no_grad():
+        t.pe.B_layer.weight.add_(0.02 * torch.randn(21, 3))
+    rs = np.random.RandomState(13)
+    self_ns = types.SimpleNamespace(obj_id=5, trainer=t, bbox3dour=None,       # (open3d box objects are not available)
+                                    clip_feat=rs.randn(3, 512).astype(np.float32),
+                                    caption_feat=rs.randn(3, 384).astype(np.float32), semantic_id=4)
+    ref_vmap.sceneObject.save_checkpoints(self_ns, HERE, 7)
+    os.replace(os.path.join(HERE, "obj_5.pth"), os.path.join(HERE, "g13_ref_obj_5.pth"))
+    pts = torch.from_numpy(rs.uniform(-2, 2, (64, 3)).astype(np.float32))
+    emb = t.pe(pts)
+    alpha, color, clip = t.fc_occ_map(emb)
+    out = {f"p{i}": p for i, p in enumerate(t.fc_occ_map.parameters())}
+    save("g13_ckpt", B=t.pe.B_layer.weight, pts=pts, emb=emb, alpha=alpha, color=color, clip=clip,
+         clip_feat=self_ns.clip_feat, caption_feat=self_ns.caption_feat, **out)
+
+
 # ------------------------------------------------------------------------------------------- G9
 G9 = dict(K=4, R=96, N=4, M=12, steps=300, eval_R=256, eval_S=32, scene_seed=7, weight_seed=90)
 
@@ -579,7 +748,7 @@ def g10():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g7", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
     for w in which:
         {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5": g5_g6, "g7": g7, "g8": g8, "g9": g9, "g11": g11,
-         "g10": g10}[w]()
+         "g10": g10, "g12": g12, "g13": g13}[w]()

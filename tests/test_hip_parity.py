@@ -1,7 +1,10 @@
 """GPU parity: the HIP path (through the C ABI) against the golden fixtures generated from the
-reference and against the CPU oracle on seeded inputs.  Tolerances: 1e-4 absolute on rendered
-outputs / losses (BASELINE.json north_star), tighter where the arithmetic allows; bit-exact for
-integer / index work."""
+reference and against the oracle on seeded inputs.  Tolerances: 1e-4 on rendered outputs / losses /
+gradients (BASELINE.json north_star; relative to the tensor's largest entry), tighter where the
+arithmetic allows; bit-exact for integer / index work.  Gradient comparisons go through
+parity_util.assert_grads: the bound is 1e-4 against the fp64-anchored oracle, see its docstring for
+the one documented exception (a ReLU input within fp32 rounding of zero).  At sizes no CPU oracle
+reaches the same oracle code runs on the GPU through torch (fp64 for the anchor)."""
 import numpy as np
 import pytest
 import torch
@@ -10,8 +13,11 @@ from conftest import T
 from oracle import objnerf_oracle as O
 from openobj_amd import init as obj_init
 from openobj_amd import ops, synthetic
+from parity_util import assert_grads, assert_terms, oracle_step
 
 pytestmark = pytest.mark.gpu
+
+BRANCH_FLIP_FLOOR = 1e-3     # large batches only: what fp32 ReLU branch flips may cost (tests/parity_util.py docstring)
 
 
 def maxerr(a, b):
@@ -122,10 +128,11 @@ def _hip_step(arena, ws, b, dev, with_feat=False):
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("tag", ["s10_nofeat", "s10_feat", "s64_feat"])
+@pytest.mark.parametrize("tag", ["s10_nofeat", "s10_feat", "s64_feat", "s64_nofeat"])
 def test_train_step_g5_grads(golden, dev, tag):
     """One fused iteration == reference loss and gradients of every stacked tensor (train.py:424-472),
-    without and with the 512-d feature-distillation loss (cfg.part_mode)."""
+    without and with the 512-d feature-distillation loss (cfg.part_mode); s64_nofeat is the headline shape
+    (64 samples per ray, RGB + depth + opacity loss)."""
     g = golden(f"g5_step_{tag}")
     K, R, n1, n2, feat_on = [int(x) for x in g["meta"]]
     arena = arena_from_fixture(g, dev)
@@ -179,7 +186,7 @@ def test_train_three_steps_g6(golden, dev):
         _hip_step(arena, ws, b, dev)
         t = ws.loss_terms.cpu()
         total = (t[:, 0] + 5 * t[:, 1] + 10 * t[:, 2]).sum().item()
-        assert abs(total - g["loss"][it]) < 2e-4 * abs(g["loss"][it]), (it, total, g["loss"][it])
+        assert abs(total - g["loss"][it]) < 1e-4 * abs(g["loss"][it]), (it, total, g["loss"][it])
         ops.adamw_step(arena, ws.grads, m, v, mask, it + 1, 1e-3, 0.013)
         pv = arena.views()
         n_bad = n_all = 0
@@ -210,25 +217,10 @@ def test_train_step_vs_oracle(golden, dev, shape, feat_on):
     ws = ops.TrainWorkspace(arena, K, R, n1 + n2, feat_on)
     b = synthetic.random_batch(K, R, n1, n2, seed=77 + R, feat_dim=512)
     _hip_step(arena, ws, b, dev, with_feat=feat_on)
-    fcr = [p.clone().requires_grad_(True) for p in fc]
-    Br = B.clone().requires_grad_(True)
-    loss, terms = O.train_forward_loss(fcr, Br, torch.full((K,), 2.0), T(b["pts"]), T(b["gt_depth"]), T(b["gt_rgb"]),
-                                       T(b["labels"]), T(b["z"]), gt_feat=T(b["gt_feat"]) if feat_on else None,
-                                       return_terms=True)
-    grads = torch.autograd.grad(loss, fcr + [Br], allow_unused=True)
-    terms = {k: (v.detach() if v is not None else None) for k, v in terms.items()}
-    t = ws.loss_terms.cpu()
-    assert maxerr(t[:, 0], terms["depth"]) < 1e-4 * max(1.0, float(terms["depth"].abs().max()))
-    assert maxerr(t[:, 1], terms["color"]) < 1e-4
-    assert maxerr(t[:, 2], terms["opacity"]) < 1e-4
-    if feat_on:
-        assert maxerr(t[:, 3], terms["feat"]) < 1e-4
-    gv = arena.views(ws.grads)
-    for i in range(19):
-        if grads[i] is None:
-            continue
-        scale = max(1e-3, float(grads[i].abs().max()))
-        assert maxerr(gv[i], grads[i]) < 2e-4 * scale, (i, ops.TENSOR_NAMES[i], maxerr(gv[i], grads[i]), scale)
+    o32 = oracle_step(fc, B, 2.0, b, feat_on, do_clip=True)
+    o64 = oracle_step(fc, B, 2.0, b, feat_on, dtype=torch.float64, do_clip=True)
+    assert_terms(ws.loss_terms, o64, o32, feat_on)
+    assert_grads(arena.views(ws.grads), o64, o32, names=ops.TENSOR_NAMES)
 
 
 def test_train_step_early_return_flags(golden, dev):
@@ -322,7 +314,8 @@ def test_rays_dirs_g7(golden, dev):
 @pytest.mark.parametrize("tag", ["nofeat", "feat"])
 def test_background_step_g10(golden, dev, tag):
     """The shared background network (hidden 128, 14 samples/ray, bg_scale 5; train.py:447-463): one
-    iteration through the layer-wise path == the reference's loss and gradients."""
+    iteration through the layer-wise path == the reference's loss and gradients (the fixture holds the
+    reference's own fp32 gradients; the anchor is the oracle in fp64 on the same weights and batch)."""
     g = golden(f"g10_bg_{tag}")
     K, R, N, M, feat_on, H = [int(x) for x in g["meta"]]
     arena = arena_from_fixture(g, dev, scale=5.0, hidden=H)
@@ -332,13 +325,10 @@ def test_background_step_g10(golden, dev, tag):
     t = ws.loss_terms.cpu()
     total = (t[:, 0] + 5 * t[:, 1] + 10 * t[:, 2] + (5 * t[:, 3] if feat_on else 0)).sum().item()
     assert abs(total - g["loss"][0]) < 1e-4 * abs(g["loss"][0]), (total, g["loss"][0])
-    gv = arena.views(ws.grads)
-    for i in range(19):
-        if i in ops.FEAT_TENSORS and not feat_on:
-            continue
-        ref = g[f"grad0_{i}"]
-        scale = max(1e-3, float(np.abs(ref).max()))
-        assert maxerr(gv[i], ref) < 2e-4 * scale, (i, ops.TENSOR_NAMES[i], maxerr(gv[i], ref), scale)
+    fc, B = [T(g[f"fc0_{i}"]) for i in range(18)], T(g["B0"])
+    o64 = oracle_step(fc, B, 5.0, b, bool(feat_on), dtype=torch.float64, do_clip=True)
+    ref = dict(grads=[T(g[f"grad0_{i}"]) for i in range(19)])          # the reference's own run
+    assert_grads(arena.views(ws.grads), o64, ref, names=ops.TENSOR_NAMES)
 
 
 def test_long_ray_step_vs_oracle(golden, dev):
@@ -352,19 +342,10 @@ def test_long_ray_step_vs_oracle(golden, dev):
     ws = ops.TrainWorkspace(arena, K, R, n1 + n2, False)
     b = synthetic.random_batch(K, R, n1, n2, seed=31)
     _hip_step(arena, ws, b, dev)
-    fcr = [p.clone().requires_grad_(True) for p in fc]
-    Br = B.clone().requires_grad_(True)
-    loss, terms = O.train_forward_loss(fcr, Br, torch.full((K,), 2.0), T(b["pts"]), T(b["gt_depth"]), T(b["gt_rgb"]),
-                                       T(b["labels"]), T(b["z"]), return_terms=True)
-    grads = torch.autograd.grad(loss, fcr + [Br], allow_unused=True)
-    t = ws.loss_terms.cpu()
-    assert abs((t[:, 0] + 5 * t[:, 1] + 10 * t[:, 2]).sum().item() - loss.item()) < 1e-4 * abs(loss.item())
-    gv = arena.views(ws.grads)
-    for i in range(19):
-        if grads[i] is None:
-            continue
-        scale = max(1e-3, float(grads[i].abs().max()))
-        assert maxerr(gv[i], grads[i]) < 2e-4 * scale, (i, maxerr(gv[i], grads[i]), scale)
+    o32 = oracle_step(fc, B, 2.0, b, False)
+    o64 = oracle_step(fc, B, 2.0, b, False, dtype=torch.float64)
+    assert_terms(ws.loss_terms, o64, o32, False)
+    assert_grads(arena.views(ws.grads), o64, o32, names=ops.TENSOR_NAMES)
 
 
 @pytest.mark.parametrize("H", [128, 256])
@@ -400,18 +381,10 @@ def test_stress_shape_step_vs_oracle(dev):
     ws = ops.TrainWorkspace(arena, K, R, n1 + n2, True)
     b = synthetic.random_batch(K, R, n1, n2, seed=77, feat_dim=512)
     _hip_step(arena, ws, b, dev, with_feat=True)
-    fcr = [q.clone().requires_grad_(True) for q in fc]
-    Br = B.clone().requires_grad_(True)
-    loss, terms = O.train_forward_loss(fcr, Br, torch.full((K,), 2.0), T(b["pts"]), T(b["gt_depth"]), T(b["gt_rgb"]),
-                                       T(b["labels"]), T(b["z"]), gt_feat=T(b["gt_feat"]), return_terms=True)
-    grads = torch.autograd.grad(loss, fcr + [Br], allow_unused=True)
-    t = ws.loss_terms.cpu()
-    total = (t[:, 0] + 5 * t[:, 1] + 10 * t[:, 2] + 5 * t[:, 3]).sum().item()
-    assert abs(total - loss.item()) < 1e-4 * abs(loss.item())
-    gv = arena.views(ws.grads)
-    for i in range(19):
-        scale = max(1e-3, float(grads[i].abs().max()))
-        assert maxerr(gv[i], grads[i]) < 3e-4 * scale, (i, ops.TENSOR_NAMES[i], maxerr(gv[i], grads[i]), scale)
+    o32 = oracle_step(fc, B, 2.0, b, True)
+    o64 = oracle_step(fc, B, 2.0, b, True, dtype=torch.float64)
+    assert_terms(ws.loss_terms, o64, o32, True)
+    assert_grads(arena.views(ws.grads), o64, o32, names=ops.TENSOR_NAMES)
 
 
 @pytest.mark.parametrize("shape,feat_on", [((1, 1200, 5, 9), False), ((1, 700, 5, 9), True), ((3, 260, 5, 9), False),
@@ -420,8 +393,9 @@ def test_small_batch_one_launch_kernels_vs_oracle(dev, shape, feat_on):
     """Hidden 128 at the reference's native background batch (1200 rays x 14 samples) and around it: the forward and
     the input-gradient chain are ONE launch each (mlp_fwd_small_kernel / mlp_bwd_small_kernel with 5, 3, 4, 3 row
     tiles per workgroup here, ragged last tiles, several objects; the last case takes two rounds of workgroups) and the
-    weight gradients one grouped launch;
-    loss and every gradient against the oracle."""
+    weight gradients one grouped launch; loss and every gradient against the fp64-anchored oracle (with ~0.5 M ReLU
+    inputs per layer one of them lies within fp32 rounding of zero in some of these cases: the reference's own fp32
+    arithmetic is then off by several 1e-4 of the maximum in the layers below it -- parity_util.assert_grads)."""
     K, R, n1, n2 = shape
     H = 128
     st = obj_init.init_stacked(K, H, 512, seed=21)
@@ -432,23 +406,10 @@ def test_small_batch_one_launch_kernels_vs_oracle(dev, shape, feat_on):
     ws = ops.TrainWorkspace(arena, K, R, n1 + n2, feat_on)
     b = synthetic.random_batch(K, R, n1, n2, seed=78, feat_dim=512)
     _hip_step(arena, ws, b, dev, with_feat=feat_on)
-    fcr = [q.clone().requires_grad_(True) for q in fc]
-    Br = B.clone().requires_grad_(True)
-    loss, terms = O.train_forward_loss(fcr, Br, torch.full((K,), 5.0), T(b["pts"]), T(b["gt_depth"]), T(b["gt_rgb"]),
-                                       T(b["labels"]), T(b["z"]), gt_feat=T(b["gt_feat"]) if feat_on else None,
-                                       return_terms=True)
-    grads = torch.autograd.grad(loss, fcr + [Br], allow_unused=True)
-    t = ws.loss_terms.cpu()
-    total = (t[:, 0] + 5 * t[:, 1] + 10 * t[:, 2] + (5 * t[:, 3] if feat_on else 0)).sum().item()
-    assert abs(total - loss.item()) < 1e-4 * abs(loss.item())
-    gv = arena.views(ws.grads)
-    for i in range(19):
-        if grads[i] is None or (i in ops.FEAT_TENSORS and not feat_on):
-            continue
-        scale = max(1e-3, float(grads[i].abs().max()))
-        # (1e-3: with ~0.5 M relu inputs per layer one of them lies within rounding of zero; against an fp64 run of
-        # the oracle the fp32 oracle itself is off by 7e-4 of the maximum in the layers below such a kink)
-        assert maxerr(gv[i], grads[i]) < 1e-3 * scale, (i, ops.TENSOR_NAMES[i], maxerr(gv[i], grads[i]), scale)
+    o32 = oracle_step(fc, B, 5.0, b, feat_on, device=dev)
+    o64 = oracle_step(fc, B, 5.0, b, feat_on, dtype=torch.float64, device=dev)
+    assert_terms(ws.loss_terms, o64, o32, feat_on)
+    _assert_grads(ws.grads, arena, o64, o32)
 
 
 @pytest.mark.parametrize("shape", [(1, 1, 1, 9), (3, 2, 16, 48), (1, 129, 8, 24)])
@@ -464,19 +425,10 @@ def test_train_step_tiny_and_ragged(golden, dev, shape):
     b = synthetic.random_batch(K, R, n1, n2, seed=5 + R)
     b["labels"][:, 0] = 1                        # keep the early return out of this test
     _hip_step(arena, ws, b, dev)
-    fcr = [p.clone().requires_grad_(True) for p in fc]
-    Br = B.clone().requires_grad_(True)
-    loss, _ = O.train_forward_loss(fcr, Br, torch.full((K,), 2.0), T(b["pts"]), T(b["gt_depth"]), T(b["gt_rgb"]),
-                                   T(b["labels"]), T(b["z"]), return_terms=True)
-    grads = torch.autograd.grad(loss, fcr + [Br], allow_unused=True)
-    t = ws.loss_terms.cpu()
-    assert abs((t[:, 0] + 5 * t[:, 1] + 10 * t[:, 2]).sum().item() - loss.item()) < 1e-4 * max(1.0, abs(loss.item()))
-    gv = arena.views(ws.grads)
-    for i in range(19):
-        if grads[i] is None:
-            continue
-        scale = max(1e-3, float(grads[i].abs().max()))
-        assert maxerr(gv[i], grads[i]) < 2e-4 * scale, (i, maxerr(gv[i], grads[i]), scale)
+    o32 = oracle_step(fc, B, 2.0, b, False)
+    o64 = oracle_step(fc, B, 2.0, b, False, dtype=torch.float64)
+    assert_terms(ws.loss_terms, o64, o32, False)
+    assert_grads(arena.views(ws.grads), o64, o32, names=ops.TENSOR_NAMES)
 
 
 def test_train_step_rejects_bad_arguments(golden, dev):
@@ -496,43 +448,65 @@ def test_train_step_rejects_bad_arguments(golden, dev):
         ops.train_step(arena, ws, batch)
 
 
-def _full_size_setup(dev, K, R, n1, n2, feat):
-    arena = ops.ParamArena(K, ops.NetShape(), dev)
-    arena.load_stacked(obj_init.init_stacked(K, 32, 512, seed=123))
+def _full_size_setup(dev, K, R, n1, n2, feat, hidden=32, seed=123):
+    arena = ops.ParamArena(K, ops.NetShape(hidden, 512, 6), dev)
+    st = obj_init.init_stacked(K, hidden, 512, seed=seed)
+    arena.load_stacked(st)
     b = synthetic.random_batch(K, R, n1, n2, seed=321, feat_dim=512 if feat else 0)
     keys = ["pts", "z", "gt_depth", "gt_rgb", "labels"] + (["gt_feat"] if feat else [])
-    return arena, {k: T(b[k]).to(dev) for k in keys}
+    return arena, {k: T(b[k]).to(dev) for k in keys}, st, b
 
 
-@pytest.mark.parametrize("feat", [False, True])
-def test_full_size_two_implementations_agree(dev, feat):
-    """BASELINE size per object (4096 rays x 64 samples; 12 objects to keep the layer-wise activations at a few GB):
-    no CPU oracle reaches it, but the fused kernel and the layer-wise path are independent implementations of the
-    same iteration (different kernels, different summation orders) -- they must agree."""
-    K, R, n1, n2 = 12, 4096, 16, 48
-    arena, batch = _full_size_setup(dev, K, R, n1, n2, feat)
+def _gpu_anchor(st, b, feat, dev, k_chunk, scale=2.0):
+    """The oracle iteration on the GPU through torch: fp32 (the reference's arithmetic) and the fp64 anchor, objects
+    in chunks so that the (chunk, R, S, .) activations of autograd fit."""
+    fc, B = list(st[:18]), st[18]
+    o32 = oracle_step(fc, B, scale, b, feat, device=dev, k_chunk=k_chunk)
+    o64 = oracle_step(fc, B, scale, b, feat, dtype=torch.float64, device=dev, k_chunk=k_chunk)
+    torch.cuda.empty_cache()
+    return o32, o64
+
+
+def _assert_terms(loss_terms, o64, feat, o32=None):
+    assert_terms(loss_terms, o64, o32, feat)
+
+
+def _assert_grads(grads, arena, o64, o32):
+    """Batches of 1e4..1e6 samples per object: parity_util's rule with the branch-flip floor."""
+    assert_grads(arena.views(grads), o64, o32, names=ops.TENSOR_NAMES, regime_floor=BRANCH_FLIP_FLOOR)
+
+
+@pytest.mark.parametrize("K,feat", [(12, False), (15, True)])
+def test_full_size_fused_and_layerwise_vs_anchor(dev, K, feat):
+    """BASELINE size per object (4096 rays x 64 samples).  (15, True) is one GPU's share of BASELINE configs[3]
+    (ScanNet, ~120 objects with part-level features, object-sharded over 8 GPUs: 15 objects each, the 512-d
+    feature-distillation loss on); (12, False) the RGB + depth + opacity loss.
+    The fused kernel and the layer-wise path are independent implementations of the same iteration (different
+    kernels, different summation orders); BOTH are held to 1e-4 of the fp64-anchored oracle, which runs on the GPU
+    through torch at this size."""
+    R, n1, n2 = 4096, 16, 48
+    arena, batch, st, b = _full_size_setup(dev, K, R, n1, n2, feat)
     ws_f = ops.TrainWorkspace(arena, K, R, n1 + n2, feat)
     ws_l = ops.TrainWorkspace(arena, K, R, n1 + n2, feat, layerwise=True)
     ops.train_step(arena, ws_f, batch, with_feat=feat)
     ops.train_step(arena, ws_l, batch, with_feat=feat, layerwise=True)
     torch.cuda.synchronize()
     assert int(ws_f.status.item()) == 0 and int(ws_l.status.item()) == 0
-    tf, tl = ws_f.loss_terms.double().cpu(), ws_l.loss_terms.double().cpu()
-    assert float((tf - tl).abs().max()) < 1e-4 * max(1.0, float(tl.abs().max()))
-    gf, gl = arena.views(ws_f.grads), arena.views(ws_l.grads)
-    for i in range(19):
-        if i in ops.FEAT_TENSORS and not feat:
-            continue
-        scale = max(1e-3, float(gl[i].abs().max()))
-        assert maxerr(gf[i], gl[i]) < 3e-4 * scale, (i, ops.TENSOR_NAMES[i], maxerr(gf[i], gl[i]), scale)
+    o32, o64 = _gpu_anchor(st, b, feat, dev, k_chunk=3 if feat else 6)
+    _assert_terms(ws_f.loss_terms, o64, feat, o32)
+    _assert_terms(ws_l.loss_terms, o64, feat, o32)
+    _assert_grads(ws_f.grads, arena, o64, o32)
+    _assert_grads(ws_l.grads, arena, o64, o32)
 
 
-def test_full_size_gradient_is_additive_over_ray_halves(dev):
-    """BASELINE configs[1] size (50 objects x 4096 rays x 64 samples): with the mask counts and early-return flags of
-    the WHOLE batch, the gradient of the batch equals the sum of the gradients of its two ray halves -- the property
-    the background network's ray sharding over GPUs relies on (train.BackgroundLoop)."""
+def test_headline_config_full_size_vs_anchor_and_additivity(dev):
+    """BASELINE configs[1] at FULL size (50 objects x 4096 rays x 64 samples, the bench workload): the fused iteration
+    against the fp64-anchored oracle (on the GPU through torch, 5 objects at a time), and -- the property the
+    background network's ray sharding over GPUs relies on (train.BackgroundLoop) -- with the mask counts and
+    early-return flags of the WHOLE batch the gradient of the batch equals the sum of the gradients of its two ray
+    halves, held to the same anchor."""
     K, R, n1, n2 = 50, 4096, 16, 48
-    arena, batch = _full_size_setup(dev, K, R, n1, n2, False)
+    arena, batch, st, b = _full_size_setup(dev, K, R, n1, n2, False)
     ws = ops.TrainWorkspace(arena, K, R, n1 + n2, False)
     ops.train_step(arena, ws, batch)
     full = ws.grads.clone()
@@ -548,45 +522,48 @@ def test_full_size_gradient_is_additive_over_ray_halves(dev):
         acc += ws_h.grads
         terms += ws_h.loss_terms
     torch.cuda.synchronize()
-    assert float((terms - full_terms).abs().max()) < 1e-4 * max(1.0, float(full_terms.abs().max()))
-    gv, av = arena.views(full), arena.views(acc)
-    for i in range(19):
-        if i in ops.FEAT_TENSORS:
-            continue
-        scale = max(1e-3, float(gv[i].abs().max()))
-        assert maxerr(av[i], gv[i]) < 2e-4 * scale, (i, ops.TENSOR_NAMES[i], maxerr(av[i], gv[i]), scale)
+    o32, o64 = _gpu_anchor(st, b, False, dev, k_chunk=5)
+    _assert_terms(full_terms, o64, False, o32)
+    _assert_terms(terms, o64, False, o32)
+    _assert_grads(full, arena, o64, o32)
+    _assert_grads(acc, arena, o64, o32)
 
 
 def test_more_objects_than_compute_units(dev):
-    """K = 300 objects on a 256-CU part (one workgroup per object, several rounds) against the layer-wise path."""
+    """K = 300 objects on a 256-CU part (one workgroup per object, several rounds): fused and layer-wise paths
+    against the anchored oracle."""
     K, R, n1, n2 = 300, 8, 1, 9
-    arena, batch = _full_size_setup(dev, K, R, n1, n2, False)
+    arena, batch, st, b = _full_size_setup(dev, K, R, n1, n2, False)
+    lab = batch["labels"]
+    lab[:, 0] = 1                                  # 8 rays per object: keep the early return out of this test
+    b["labels"] = lab.cpu().numpy()
     ws_f = ops.TrainWorkspace(arena, K, R, n1 + n2, False)
     ws_l = ops.TrainWorkspace(arena, K, R, n1 + n2, False, layerwise=True)
     ops.train_step(arena, ws_f, batch)
     ops.train_step(arena, ws_l, batch, layerwise=True)
     torch.cuda.synchronize()
-    assert float((ws_f.loss_terms - ws_l.loss_terms).abs().max()) < 1e-4 * max(1.0, float(ws_l.loss_terms.abs().max()))
-    gf, gl = arena.views(ws_f.grads), arena.views(ws_l.grads)
-    for i in list(range(14)) + [18]:
-        scale = max(1e-3, float(gl[i].abs().max()))
-        assert maxerr(gf[i], gl[i]) < 3e-4 * scale, (i, ops.TENSOR_NAMES[i], maxerr(gf[i], gl[i]), scale)
+    o32, o64 = _gpu_anchor(st, b, False, dev, k_chunk=K)
+    _assert_terms(ws_f.loss_terms, o64, False, o32)
+    _assert_terms(ws_l.loss_terms, o64, False, o32)
+    _assert_grads(ws_f.grads, arena, o64, o32)
+    _assert_grads(ws_l.grads, arena, o64, o32)
 
 
 def test_single_object_many_rays(dev):
-    """K = 1, 60 000 rays: the object is swept by every compute unit (256 slabs), fused vs layer-wise."""
+    """K = 1, 60 000 rays: the object is swept by every compute unit (256 slabs); fused and layer-wise paths against
+    the anchored oracle."""
     K, R, n1, n2 = 1, 60000, 8, 24
-    arena, batch = _full_size_setup(dev, K, R, n1, n2, False)
+    arena, batch, st, b = _full_size_setup(dev, K, R, n1, n2, False)
     ws_f = ops.TrainWorkspace(arena, K, R, n1 + n2, False)
     ws_l = ops.TrainWorkspace(arena, K, R, n1 + n2, False, layerwise=True)
     ops.train_step(arena, ws_f, batch)
     ops.train_step(arena, ws_l, batch, layerwise=True)
     torch.cuda.synchronize()
-    assert float((ws_f.loss_terms - ws_l.loss_terms).abs().max()) < 1e-4 * max(1.0, float(ws_l.loss_terms.abs().max()))
-    gf, gl = arena.views(ws_f.grads), arena.views(ws_l.grads)
-    for i in list(range(14)) + [18]:
-        scale = max(1e-3, float(gl[i].abs().max()))
-        assert maxerr(gf[i], gl[i]) < 3e-4 * scale, (i, ops.TENSOR_NAMES[i], maxerr(gf[i], gl[i]), scale)
+    o32, o64 = _gpu_anchor(st, b, False, dev, k_chunk=1)
+    _assert_terms(ws_f.loss_terms, o64, False, o32)
+    _assert_terms(ws_l.loss_terms, o64, False, o32)
+    _assert_grads(ws_f.grads, arena, o64, o32)
+    _assert_grads(ws_l.grads, arena, o64, o32)
 
 
 def test_layerwise_object_chunks_equal_one_shot(dev):
@@ -607,3 +584,56 @@ def test_layerwise_object_chunks_equal_one_shot(dev):
     assert int(ws2.status.item()) == int(ws1.status.item()) == 0
     assert maxerr(ws2.loss_terms, ws1.loss_terms) < 1e-5 * max(1.0, float(ws1.loss_terms.abs().max()))
     assert maxerr(ws2.grads, ws1.grads) < 1e-5 * max(1.0, float(ws1.grads.abs().max()))
+
+
+@pytest.mark.parametrize("feat", [False, True])
+def test_config_c5_object_at_full_size(dev, feat):
+    """BASELINE configs[4], one object at its full size: hidden 256, 8192 rays x 128 samples (32 + 96), without and
+    with the feature loss, through the layer-wise path; loss terms and all 19 gradients against the fp64-anchored
+    oracle (GPU, torch), and the gradient is additive over the two ray halves under shared mask counts."""
+    K, R, n1, n2, H = 1, 8192, 32, 96, 256
+    arena, batch, st, b = _full_size_setup(dev, K, R, n1, n2, feat, hidden=H, seed=41)
+    ws = ops.TrainWorkspace(arena, K, R, n1 + n2, feat)
+    ops.train_step(arena, ws, batch, with_feat=feat)
+    torch.cuda.synchronize()
+    assert int(ws.status.item()) == 0
+    full, counts, flags = ws.grads.clone(), ws.counts.clone(), ws.flags.clone()
+    o32, o64 = _gpu_anchor(st, b, feat, dev, k_chunk=1)
+    _assert_terms(ws.loss_terms, o64, feat, o32)
+    _assert_grads(full, arena, o64, o32)
+    ws_h = ops.TrainWorkspace(arena, K, R // 2, n1 + n2, feat)
+    acc = torch.zeros_like(full)
+    for h in range(2):
+        sl = slice(h * (R // 2), (h + 1) * (R // 2))
+        half = {k: v[:, sl].contiguous() for k, v in batch.items()}
+        ops.train_step(arena, ws_h, half, with_feat=feat, global_flags=flags, global_counts=counts)
+        acc += ws_h.grads
+    torch.cuda.synchronize()
+    _assert_grads(acc, arena, o64, o32)
+
+
+def test_config_c5_gpu_share_runs_in_object_chunks(dev):
+    """BASELINE configs[4], one GPU's whole share: 64 objects x 8192 rays x 128 samples, hidden 256 (512 objects
+    sharded over 8 GPUs).  The layer-wise path runs it in object chunks that fit the workspace budget; three of the
+    64 objects (first, middle, last chunk) are checked against the fp64-anchored oracle."""
+    K, R, n1, n2, H = 64, 8192, 32, 96, 256
+    arena = ops.ParamArena(K, ops.NetShape(H, 512, 6), dev)
+    st = obj_init.init_stacked(K, H, 512, seed=43)
+    arena.load_stacked(st)
+    b8 = synthetic.random_batch(8, R, n1, n2, seed=99)           # 8 objects of rays, reused by 8 networks each
+    keys = ["pts", "z", "gt_depth", "gt_rgb", "labels"]
+    batch = {k: T(b8[k]).to(dev).repeat(8, *([1] * (b8[k].ndim - 1))) for k in keys}
+    ws = ops.TrainWorkspace(arena, K, R, n1 + n2, False, budget=24 << 30)
+    assert 1 <= ws.k_chunk < K
+    ops.train_step(arena, ws, batch)
+    torch.cuda.synchronize()
+    assert int(ws.status.item()) == 0
+    gv = arena.views(ws.grads)
+    for k in (0, 37, 63):
+        fc, B = [p[k:k + 1] for p in st[:18]], st[18][k:k + 1]
+        bk = {kk: b8[kk][k % 8:k % 8 + 1] for kk in keys}
+        o32 = oracle_step(fc, B, 2.0, bk, False, device=dev)
+        o64 = oracle_step(fc, B, 2.0, bk, False, dtype=torch.float64, device=dev)
+        torch.cuda.empty_cache()
+        _assert_terms(ws.loss_terms[k:k + 1], o64, False, o32)
+        assert_grads([g[k:k + 1] for g in gv], o64, o32, names=ops.TENSOR_NAMES, regime_floor=BRANCH_FLIP_FLOOR)
