@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define OBJNERF_ABI_VERSION 1
+#define OBJNERF_ABI_VERSION 2
 
 #define OBJNERF_OK 0
 #define OBJNERF_EINVAL (-22)       /* bad shape / null pointer / unsupported size        */
@@ -255,6 +255,12 @@ typedef struct objnerf_train_args {
   const int32_t* counts; const int32_t* flags;
   float* grads; float* loss_terms; int32_t* status;
   void* workspace; size_t workspace_bytes;
+  uint8_t* relu_masks;   /* NULL in production.  Test hook, [K][R][S][6][hidden / 8] bytes: bit (f & 7) of byte
+                          * f >> 3 of layer l (h1, h2, h3, h4, colour hidden, feature hidden -- the last only with
+                          * gt_feat) is set iff that ReLU passed its input for the sample.  The parity tests evaluate
+                          * the oracle on the SAME branches (an fp32 implementation and the reference legitimately
+                          * disagree about inputs within rounding of zero; tests/parity_util.py).  Not with
+                          * OBJNERF_TRAIN_BF16. */
 } objnerf_train_args;
 size_t objnerf_train_workspace_bytes(const objnerf_net* net, int32_t K, int32_t R, int32_t S,
                                      int32_t with_feat);

@@ -1125,6 +1125,20 @@ struct Bf16Scope {
 };
 }  // namespace
 
+// test hook (objnerf_train_args.relu_masks): one thread per (object, sample, byte of 8 features)
+__global__ void relu_mask_kernel(long nb, int H, const float* act /* [K n][H] */, uint8_t* masks /* [K n][6][H/8] */,
+                                 int layer) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nb) return;
+  const int hb = H / 8;
+  const long s = i / hb;
+  const int b = (int)(i - s * hb);
+  const float* p = act + s * H + 8 * b;
+  unsigned m = 0;
+  for (int j = 0; j < 8; ++j) m |= (p[j] > 0.0f ? 1u : 0u) << j;
+  masks[(s * 6 + layer) * hb + b] = (uint8_t)m;
+}
+
 int train_step(const objnerf_net* net, const objnerf_train_args* a, void* stream) {
   const Bf16Scope bf16_scope((a->mode & OBJNERF_TRAIN_BF16) != 0);
   const int H = net->hidden, C = net->feat_dim, K = a->K;
@@ -1219,6 +1233,14 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a, void* stream
     gemm(st, K, n, H, E2, w.emb + E1, EM, 1, n * EM, P + off[14] + H, 1, H + E2, ps, w.hf, H, 1, nH, true, P + off[15],
          ps, true);
   }
+  }
+  if (a->relu_masks) {       // test hook: the ReLU branch bits of this iteration (objnerf_train_args.relu_masks)
+    const float* acts[6] = {w.h1, w.h2, w.h3, w.h4, w.hc, feat ? w.hf : nullptr};
+    const long nb = (long)K * n * (H / 8);
+    for (int l = 0; l < 6; ++l)
+      if (acts[l])
+        hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, nb, H, acts[l],
+                           a->relu_masks, l);
   }
   if (feat) (void)hipStreamWaitEvent(st, sd.done, 0);      // the feature preparation (side stream) is needed from here
   // ---- loss + d(alpha, color, clip)      (loss.py:5-103)

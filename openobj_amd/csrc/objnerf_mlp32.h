@@ -1,0 +1,344 @@
+// Per-object MLP (hidden = 32), fp32, second generation of the register-resident MFMA chain (gfx950).
+//
+// What changed against objnerf_mlp.h (which the bf16 kernel still uses) and why -- tools/ubench_alu.hip measured that a
+// v_mfma_f32_16x16x4_f32 occupies the SIMD's vector ALU for its whole 32 cycles (VALU work of either wave of the SIMD
+// does not overlap it), so the fused kernel's time is  34 * #MFMA + ~3..5 * #VALU  cycles and every VALU instruction
+// and every non-algorithmic MFMA counts:
+//
+//  * DIRECTION-OWNER positional encoding.  Lane group g of a sample owns directions j = 4 i + g (slot i = 0..5) in ALL
+//    six octaves.  The reference's argument fp32(fp32(p 2^f) pi) equals 2^f fp32(p pi) exactly, so one double-float
+//    division by 2 pi per direction serves all octaves (4 VALU + v_sin / v_cos per entry instead of ~14 + 2), the
+//    projection gradient d p_j is complete inside the owning lane (no cross-group sum: the 34 selection MFMAs and the
+//    staging round trip of the first generation are gone) and d B accumulates in 18 registers per lane.
+//  * IN-MAJOR weight image  W^T[input k][32 outputs]  with 40-float rows: the forward A operand of a k-step is ONE
+//    ds_read_b64 (both 16-row output tiles) at a compile-time offset from a per-lane base, the transposed (input
+//    gradient) operand TWO ds_read_b128 per 16-input tile; both conflict-free (row pitch 40 floats = 32 banks (mod 64)
+//    for rows 4 apart; 16-byte chunks rotated by lane-group parity for the b128 groups).  The first generation issued
+//    one 2-way-conflicted ds_read2_b32 per k-step and eight ds_read_b32 per transposed tile (36 % LDS bank conflicts).
+//
+// K-order: k-step (T, r) of a 16-feature tile T takes feature kappa = 16 T + 4 g + r from lane group g (so a layer's
+// 32 x 16 accumulator block is the next layer's B operand without moving).  Hidden features use kappa = feature.
+// Embedding entries: lane (sample c, group g) holds x1[t], t = 0..23 (kappa = 16 (t >> 2) + 4 g + (t & 3)):
+//   t = 6 f + i, octave f = 0..3, slot i:  sin(2^f a_j), j = 4 i + g  (valid while j < 21, i.e. i < 5 or g == 0);
+//   the 12 free places carry  x / scale (f = 0, i = 5, g = 1..3),  the constant 1 that multiplies the bias column
+//   (f = 1, i = 5, g = 1)  and zeros;   x2[t], t = 0..11: octaves 4, 5 the same way, the constant at (f = 4, i = 5, g = 1).
+// Reference: OccupancyMap.forward (model.py:61-103) on UniDirsEmbed.forward (embedding.py:46-55).
+#pragma once
+#include "objnerf_mlp.h"
+
+namespace obj32n {
+using namespace obj32;
+
+constexpr int WROW = 40;                 // floats per image row (32 outputs + 8 pad)
+constexpr int R_IN = 0;                  // image rows: in-layer  [x1 96]
+constexpr int R_M1 = R_IN + 96;          //             mid1      [h1 32]
+constexpr int R_CAT = R_M1 + 32;         //             cat       [h2 32 | x1 96]
+constexpr int R_M2 = R_CAT + 128;        //             mid2      [h3 32]
+constexpr int R_CL = R_M2 + 32;          //             colour    [h4 32 | x2 48]
+constexpr int R_FL = R_CL + 80;          //             feature   [h4 32 | x2 48]   (only if used)
+constexpr int ROWS_NOFEAT = R_FL, ROWS_FEAT = R_FL + 80;
+// small vectors behind the image (float offsets from the start of the image)
+constexpr int SV_BM1 = 0, SV_BM2 = 32, SV_WA = 64, SV_WOC = 96, SV_HB = 192, SV_PEB = 196, SV_FLOATS = 196 + 72 + 4;
+__host__ __device__ constexpr int img_floats(bool feat) { return (feat ? ROWS_FEAT : ROWS_NOFEAT) * WROW + SV_FLOATS; }
+__host__ __device__ constexpr int sv_base(bool feat) { return (feat ? ROWS_FEAT : ROWS_NOFEAT) * WROW; }
+
+constexpr int BIAS_COL = -2, ZERO_COL = -1;
+// reference column (inside emb[:87]) of x1 entry (t, g); BIAS_COL for the constant-1 entry, ZERO_COL for padding
+__host__ __device__ inline int x1_col(int t, int g) {
+  const int f = t / 6, i = t - 6 * f, j = 4 * i + g;
+  if (j < OBJ_NDIR) return 3 + OBJ_NDIR * f + j;
+  if (f == 0) return g - 1;                      // x / scale, components 0..2 (i == 5, g = 1..3)
+  if (f == 1 && g == 1) return BIAS_COL;
+  return ZERO_COL;
+}
+// reference column (inside emb[87:]) of x2 entry (t, g)
+__host__ __device__ inline int x2_col(int t, int g) {
+  const int f = t / 6, i = t - 6 * f, j = 4 * i + g;
+  if (j < OBJ_NDIR) return OBJ_NDIR * f + j;
+  if (f == 0 && g == 1) return BIAS_COL;
+  return ZERO_COL;
+}
+// kappa (0..95 / 0..47) -> (t, g)
+__host__ __device__ inline void kappa_tg(int kappa, int& t, int& g) {
+  t = 4 * (kappa >> 4) + (kappa & 3);
+  g = (kappa >> 2) & 3;
+}
+// float position of output o inside an image row: the pair (o, o + 16) is adjacent (one ds_read_b64 in the forward),
+// the pairs r = 0..3 of a 4-output group are contiguous (two ds_read_b128 in the transposed direction) and rotated by
+// two pairs for odd groups, which puts the b128 lane groups on disjoint banks (see the header comment)
+__host__ __device__ inline int out_pos(int o) {
+  const int tt = o >> 4, cc = o & 15, gg = cc >> 2, rr = cc & 3;
+  return 8 * gg + 2 * ((rr + 2 * (gg & 1)) & 3) + tt;
+}
+
+// Stage one object's weights into the LDS image.  All threads of the workgroup call this.
+__device__ __forceinline__ void stage_weights32(float* lds, const float* __restrict__ P, const Layout& L, bool with_feat,
+                                                int tid, int nthr) {
+  const int rows = with_feat ? ROWS_FEAT : ROWS_NOFEAT;
+  const int total = rows * WROW + SV_FLOATS;
+  for (int i = tid; i < total; i += nthr) lds[i] = 0.0f;
+  __syncthreads();
+  for (int e = tid; e < rows * H; e += nthr) {
+    const int row = e >> 5, o = e & 31;
+    float v = 0.0f;
+    int w_off, b_off, ncols, col;
+    int local;
+    if (row < R_M1) {                      // in-layer: x1 rows
+      local = row - R_IN; w_off = L.in_w; b_off = L.in_b; ncols = OBJ_E1;
+      int t, g; kappa_tg(local, t, g); col = x1_col(t, g);
+    } else if (row < R_CAT) {
+      local = row - R_M1; w_off = L.m1_w; b_off = -1; ncols = H; col = local;
+    } else if (row < R_M2) {
+      local = row - R_CAT; w_off = L.cat_w; b_off = L.cat_b; ncols = H + OBJ_E1;
+      if (local < H) col = local;
+      else { int t, g; kappa_tg(local - H, t, g); col = x1_col(t, g); if (col >= 0) col += H; }
+    } else if (row < R_CL) {
+      local = row - R_M2; w_off = L.m2_w; b_off = -1; ncols = H; col = local;
+    } else {
+      const bool fl = row >= R_FL;
+      local = row - (fl ? R_FL : R_CL); w_off = fl ? L.fl_w : L.cl_w; b_off = fl ? L.fl_b : L.cl_b; ncols = H + OBJ_E2;
+      if (local < H) col = local;
+      else { int t, g; kappa_tg(local - H, t, g); col = x2_col(t, g); if (col >= 0) col += H; }
+    }
+    if (col >= 0) v = P[w_off + o * ncols + col];
+    else if (col == BIAS_COL && b_off >= 0) v = P[b_off + o];
+    lds[row * WROW + out_pos(o)] = v;
+  }
+  float* sv = lds + rows * WROW;
+  for (int i = tid; i < H; i += nthr) {
+    sv[SV_BM1 + i] = P[L.m1_b + i];
+    sv[SV_BM2 + i] = P[L.m2_b + i];
+    sv[SV_WA + i] = P[L.a_w + i];
+  }
+  for (int i = tid; i < 3 * H; i += nthr) sv[SV_WOC + i] = P[L.oc_w + i];
+  if (tid == 0) sv[SV_HB] = P[L.a_b];
+  if (tid < 3) sv[SV_HB + 1 + tid] = P[L.oc_b + tid];
+  // B rows in slot order: [slot i][group g][3], zero for j = 4 i + g >= 21
+  for (int i = tid; i < 72; i += nthr) {
+    const int j = i / 3;              // = 4 * slot + g
+    sv[SV_PEB + i] = j < OBJ_NDIR ? P[L.pe_b + i] : 0.0f;
+  }
+  __syncthreads();
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// MFMA building blocks.  wf = lds + 4 g * WROW + out_pos(c) (forward base), wt0 / wt1 = transposed bases (below).
+// ----------------------------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// acc(32 outputs) += W[:, features of tile (row0 .. row0 + 15)] * xt     (xt: one 16-feature tile in K-order)
+__device__ __forceinline__ void mma_f16(T32& acc, const float* wf, const int row0, const f32x4& xt) {
+  f32x2 a[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) a[r] = *reinterpret_cast<const f32x2*>(wf + (row0 + r) * WROW);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    acc.t[0] = OBJ_MFMA(a[r][0], xt[r], acc.t[0]);
+    acc.t[1] = OBJ_MFMA(a[r][1], xt[r], acc.t[1]);
+  }
+}
+__device__ __forceinline__ void mma_f32(T32& acc, const float* wf, const int row0, const T32& x) {
+  mma_f16(acc, wf, row0, x.t[0]);
+  mma_f16(acc, wf, row0 + 16, x.t[1]);
+}
+// acc(16 inputs: image rows row0 .. row0 + 15) += W[:, those inputs]^T * d    (d: 32 outputs)
+// wt0 = lds + c * WROW + 8 g + 4 (g & 1), wt1 = lds + c * WROW + 8 g + 4 (1 - (g & 1)): after the rotation of out_pos
+// both lane-group parities find the pairs r = 0, 1 at wt0 and r = 2, 3 at wt1
+__device__ __forceinline__ void mma_t16(f32x4& acc, const float* wt0, const float* wt1, const int row0, const T32& d) {
+  const f32x4 lo = *reinterpret_cast<const f32x4*>(wt0 + row0 * WROW);    // (r0 t0, r0 t1, r1 t0, r1 t1)
+  const f32x4 hi = *reinterpret_cast<const f32x4*>(wt1 + row0 * WROW);    // (r2 t0, r2 t1, r3 t0, r3 t1)
+  f32x4 acc2 = zero4();
+  acc = OBJ_MFMA(lo[0], d.t[0][0], acc);
+  acc2 = OBJ_MFMA(lo[1], d.t[1][0], acc2);
+  acc = OBJ_MFMA(lo[2], d.t[0][1], acc);
+  acc2 = OBJ_MFMA(lo[3], d.t[1][1], acc2);
+  acc = OBJ_MFMA(hi[0], d.t[0][2], acc);
+  acc2 = OBJ_MFMA(hi[1], d.t[1][2], acc2);
+  acc = OBJ_MFMA(hi[2], d.t[0][3], acc);
+  acc2 = OBJ_MFMA(hi[3], d.t[1][3], acc2);
+  acc += acc2;
+}
+__device__ __forceinline__ void mma_t32(T32& acc, const float* wt0, const float* wt1, const int row0, const T32& d) {
+  mma_t16(acc.t[0], wt0, wt1, row0, d);
+  mma_t16(acc.t[1], wt0, wt1, row0 + 16, d);
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Positional encoding, direction-owner layout.
+// ----------------------------------------------------------------------------------------------------------------
+struct Pe32 {
+  float t[3];          // x / scale (embedding.py:47)
+  float vh[6], vl[6];  // a_j / (2 pi) as an unevaluated sum, a_j = fp32(proj_j * pi), j = 4 i + g
+};
+
+#define OBJ_INV2PI_HI 0.15915494f            // fp32(1 / (2 pi))
+#define OBJ_INV2PI_LO 4.4620826e-09f         // 1 / (2 pi) - OBJ_INV2PI_HI
+
+__device__ __forceinline__ void pe32_project(const float* sv, const int g, const float px, const float py, const float pz,
+                                             const float scale, Pe32& pe) {
+  pe.t[0] = px / scale;        // embedding.py:47
+  pe.t[1] = py / scale;
+  pe.t[2] = pz / scale;
+  const float* bl = sv + SV_PEB + 3 * g;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const float p = fmaf(pe.t[2], bl[12 * i + 2], fmaf(pe.t[1], bl[12 * i + 1], pe.t[0] * bl[12 * i]));   // :48
+    const float a0 = p * OBJ_PI_F;                 // :52 at octave 0; octave f is 2^f a0 exactly
+    const float vh = a0 * OBJ_INV2PI_HI;
+    pe.vh[i] = vh;
+    pe.vl[i] = fmaf(a0, OBJ_INV2PI_LO, fmaf(a0, OBJ_INV2PI_HI, -vh));
+  }
+}
+// sin (and cos) of 2^f a for the angle held as revolutions (vh + vl); exact range reduction, then v_sin / v_cos
+template <bool WANT_COS>
+__device__ __forceinline__ void pe32_sincos(const float vh, const float vl, const int f, float& s, float& c) {
+  const float sc = (float)(1 << f);
+  const float u = vh * sc;                       // exact
+  const float r = u - rintf(u);                  // exact, |r| <= 1/2
+  const float w = fmaf(vl, sc, r);
+  s = __builtin_amdgcn_sinf(w);
+  if (WANT_COS) c = __builtin_amdgcn_cosf(w);
+}
+
+// forward value of x1 entry t (x2 entry t) of this lane
+__device__ __forceinline__ float pe32_x1(const Pe32& pe, const int t, const int g) {
+  const int f = t / 6, i = t - 6 * f;
+  float s, c;
+  pe32_sincos<false>(pe.vh[i], pe.vl[i], f, s, c);
+  if (i == 5) {                                  // only group 0 has a sixth direction
+    if (f == 0) s = (g == 0) ? s : ((g == 1) ? pe.t[0] : ((g == 2) ? pe.t[1] : pe.t[2]));
+    else if (f == 1) s = (g == 0) ? s : ((g == 1) ? 1.0f : 0.0f);
+    else s = (g == 0) ? s : 0.0f;
+  }
+  return s;
+}
+__device__ __forceinline__ float pe32_x2(const Pe32& pe, const int t, const int g) {
+  const int f = t / 6, i = t - 6 * f;
+  float s, c;
+  pe32_sincos<false>(pe.vh[i], pe.vl[i], 4 + f, s, c);
+  if (i == 5) {
+    if (f == 0) s = (g == 0) ? s : ((g == 1) ? 1.0f : 0.0f);
+    else s = (g == 0) ? s : 0.0f;
+  }
+  return s;
+}
+// backward of entry t that also re-creates its forward value: returns the value, adds d_x * d sin / d proj to dps[i]
+// (d arg / d proj = pi 2^f, embedding.py:49-52)
+__device__ __forceinline__ float pe32_x1_fb(const Pe32& pe, const int t, const int g, const float dx, float (&dps)[6]) {
+  const int f = t / 6, i = t - 6 * f;
+  float s, c;
+  pe32_sincos<true>(pe.vh[i], pe.vl[i], f, s, c);
+  float v = dx * ((c * OBJ_PI_F) * (float)(1 << f));
+  if (i == 5) {
+    v = (g == 0) ? v : 0.0f;
+    if (f == 0) s = (g == 0) ? s : ((g == 1) ? pe.t[0] : ((g == 2) ? pe.t[1] : pe.t[2]));
+    else if (f == 1) s = (g == 0) ? s : ((g == 1) ? 1.0f : 0.0f);
+    else s = (g == 0) ? s : 0.0f;
+  }
+  dps[i] += v;
+  asm volatile("" : "+v"(dps[i]));     // consume v now (a deferred add keeps d_x and the cosine live)
+  return s;
+}
+__device__ __forceinline__ float pe32_x2_fb(const Pe32& pe, const int t, const int g, const float dx, float (&dps)[6]) {
+  const int f = t / 6, i = t - 6 * f;
+  float s, c;
+  pe32_sincos<true>(pe.vh[i], pe.vl[i], 4 + f, s, c);
+  float v = dx * ((c * OBJ_PI_F) * (float)(16 << f));
+  if (i == 5) {
+    v = (g == 0) ? v : 0.0f;
+    if (f == 0) s = (g == 0) ? s : ((g == 1) ? 1.0f : 0.0f);
+    else s = (g == 0) ? s : 0.0f;
+  }
+  dps[i] += v;
+  asm volatile("" : "+v"(dps[i]));
+  return s;
+}
+
+struct Emb32 {
+  f32x4 x1[6];     // x1[T][r] = entry t = 4 T + r
+  f32x4 x2[3];
+};
+__device__ __forceinline__ void embed32(Emb32& e, const Pe32& pe, const int g) {
+#pragma unroll
+  for (int T = 0; T < 6; ++T)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) e.x1[T][r] = pe32_x1(pe, 4 * T + r, g);
+#pragma unroll
+  for (int T = 0; T < 3; ++T)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) e.x2[T][r] = pe32_x2(pe, 4 * T + r, g);
+}
+// embedding supplied by the caller in the reference's order (OccupancyMap.forward on an explicit embedding tensor)
+__device__ __forceinline__ void embed32_load(Emb32& e, const float* __restrict__ emb, const int g) {
+#pragma unroll
+  for (int T = 0; T < 6; ++T)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int col = x1_col(4 * T + r, g);
+      e.x1[T][r] = col >= 0 ? emb[col] : (col == BIAS_COL ? 1.0f : 0.0f);
+    }
+#pragma unroll
+  for (int T = 0; T < 3; ++T)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int col = x2_col(4 * T + r, g);
+      e.x2[T][r] = col >= 0 ? emb[OBJ_E1 + col] : (col == BIAS_COL ? 1.0f : 0.0f);
+    }
+}
+
+// Forward chain of one 16-sample block.  wf: forward base of this lane, sv: small vectors.  Heads: every lane group
+// ends with ONE of the four outputs of its sample -- group 0: 10 * raw alpha (model.py:88), groups 1..3: the colour
+// channel g - 1 after the sigmoid (model.py:96) -- so only one sigmoid per lane is evaluated.
+template <bool FEAT>
+__device__ __forceinline__ float mlp32_forward(const float* wf, const float* sv, const int g, const Emb32& e, Acts& a) {
+  T32 acc = zero32();
+#pragma unroll
+  for (int T = 0; T < 6; ++T) mma_f16(acc, wf, R_IN + 16 * T, e.x1[T]);
+  a.h1 = relu32(acc);
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc.t[tt][r] = sv[SV_BM1 + 16 * tt + 4 * g + r];
+  mma_f32(acc, wf, R_M1, a.h1);
+  a.h2 = relu32(acc);
+  acc = zero32();
+  mma_f32(acc, wf, R_CAT, a.h2);
+#pragma unroll
+  for (int T = 0; T < 6; ++T) mma_f16(acc, wf, R_CAT + 32 + 16 * T, e.x1[T]);
+  a.h3 = relu32(acc);
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc.t[tt][r] = sv[SV_BM2 + 16 * tt + 4 * g + r];
+  mma_f32(acc, wf, R_M2, a.h3);
+  a.h4 = relu32(acc);
+  acc = zero32();
+  mma_f32(acc, wf, R_CL, a.h4);
+#pragma unroll
+  for (int T = 0; T < 3; ++T) mma_f16(acc, wf, R_CL + 32 + 16 * T, e.x2[T]);
+  a.hc = relu32(acc);
+  if (FEAT) {
+    acc = zero32();
+    mma_f32(acc, wf, R_FL, a.h4);
+#pragma unroll
+    for (int T = 0; T < 3; ++T) mma_f16(acc, wf, R_FL + 32 + 16 * T, e.x2[T]);
+    a.hf = relu32(acc);
+  }
+  float pa = 0.f, pc0 = 0.f, pc1 = 0.f, pc2 = 0.f;
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * tt + 4 * g + r;
+      pa = fmaf(sv[SV_WA + row], a.h4.t[tt][r], pa);
+      pc0 = fmaf(sv[SV_WOC + row], a.hc.t[tt][r], pc0);
+      pc1 = fmaf(sv[SV_WOC + H + row], a.hc.t[tt][r], pc1);
+      pc2 = fmaf(sv[SV_WOC + 2 * H + row], a.hc.t[tt][r], pc2);
+    }
+  const float sa = xgroup_sum(pa), s0 = xgroup_sum(pc0), s1 = xgroup_sum(pc1), s2 = xgroup_sum(pc2);
+  const float mine = (g == 0) ? sa : ((g == 1) ? s0 : ((g == 2) ? s1 : s2));
+  const float z = mine + sv[SV_HB + g];
+  return (g == 0) ? z * 10.0f : sigmoid_acc(z);
+}
+
+}  // namespace obj32n

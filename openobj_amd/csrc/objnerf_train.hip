@@ -13,6 +13,8 @@
 //      group), accumulating in registers across the whole sweep.
 // Each workgroup then writes one partial-gradient slab; finalize_kernel sums the slabs (no atomics on
 // global memory, bit-reproducible run to run).
+#include <mutex>
+#include "objnerf_mlp32.h"
 #include "objnerf_train_common.h"
 #include "objnerf_generic.h"
 #include "../../include/objnerf_hip.h"
@@ -99,7 +101,7 @@ __device__ unsigned long long g_phase[8][24];
 
 // ------------------------------------------------------------------------------------------------
 constexpr int X1N = 6, X2N = 3;       // 16-wide embedding tiles of the two input blocks (96 and 48 padded entries)
-template <bool FEAT>
+template <bool FEAT, bool MASKS>
 __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
@@ -200,6 +202,15 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
       mlp_forward<FEAT>(lds, c, g, e, act, hd);
     }
     PT(2);
+    if (MASKS) {                      // test hook: ReLU branch bits of this lane's sample
+      uint8_t* dst = a.relu_masks + (((long)k * R + (valid ? ray : 0)) * S + (slot - q * S)) * 24;
+      write_relu_mask(dst, 0, lane >> 4, act.h1, valid);
+      write_relu_mask(dst, 1, lane >> 4, act.h2, valid);
+      write_relu_mask(dst, 2, lane >> 4, act.h3, valid);
+      write_relu_mask(dst, 3, lane >> 4, act.h4, valid);
+      write_relu_mask(dst, 4, lane >> 4, act.hc, valid);
+      if (FEAT) write_relu_mask(dst, 5, lane >> 4, act.hf, valid);
+    }
     if (g == 0) {
       s_alpha[slot] = hd.alpha;
       s_col[slot] = hd.col[0];
@@ -810,15 +821,18 @@ __global__ void finalize_kernel(const float* slab, const float* loss_part, int K
 }
 
 // ------------------------------------------------------------------------------------------------
-// Inference: 4 independent waves per workgroup, 16 points per wave per step.
+// Inference: 4 independent waves per workgroup, 16 points per wave per step (second-generation chain, objnerf_mlp32.h).
 template <bool FEAT, bool FROM_EMB>
 __global__ __launch_bounds__(256) void eval_kernel(const EvalDev a) {
+  using namespace obj32n;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, g = lane >> 4;
   const int k = blockIdx.x / a.G, gi = blockIdx.x % a.G;
-  stage_weights(lds, a.params + (long)k * a.p_stride, a.L, FEAT, tid, 256);
+  stage_weights32(lds, a.params + (long)k * a.p_stride, a.L, FEAT, tid, 256);
+  const float* sv = lds + sv_base(FEAT);
+  const float* wf = (const float*)__builtin_assume_aligned(lds + 4 * g * WROW + out_pos(c), 8);
   const float scale = FROM_EMB ? 1.0f : a.scale[k];
   const long ntiles = (a.N + 63) / 64;
   for (long tile = gi; tile < ntiles; tile += a.G) {
@@ -826,25 +840,20 @@ __global__ __launch_bounds__(256) void eval_kernel(const EvalDev a) {
     const long n = tile * 64 + 16 * w + c;
     const bool valid = n < a.N;
     const long o = (long)k * a.N + (valid ? n : 0);
-    Emb e;
+    Emb32 e;
     if (FROM_EMB) {
-      embed_load(e, a.emb + o * OBJ_EMB, g);
+      embed32_load(e, a.emb + o * OBJ_EMB, g);
     } else {
       const float* p = a.pts + o * 3;
-      Pe pe;
-      pe_project(lds, g, p[0], p[1], p[2], scale, pe);
-      embed(e, pe, g);
+      Pe32 pe;
+      pe32_project(sv, g, p[0], p[1], p[2], scale, pe);
+      embed32(e, pe, g);
     }
     Acts act;
-    Heads hd;
-    mlp_forward<FEAT>(lds, c, g, e, act, hd);
+    const float hout = mlp32_forward<FEAT>(wf, sv, g, e, act);    // group 0: 10 * raw alpha, groups 1..3: colour g - 1
     if (valid) {
-      if (g == 0) {
-        a.alpha[o] = hd.alpha;
-        a.color[o * 3] = hd.col[0];
-        a.color[o * 3 + 1] = hd.col[1];
-        a.color[o * 3 + 2] = hd.col[2];
-      }
+      if (g == 0) a.alpha[o] = hout;
+      else a.color[o * 3 + g - 1] = hout;
       if (FEAT) {
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
@@ -948,7 +957,14 @@ int eval_launch(const objnerf_net* net, int32_t K, int64_t N, const float* param
   d.G = (int)G;
   hipStream_t st = (hipStream_t)stream;
   const bool feat = out_hfeat != nullptr;
-  const size_t lds_bytes = (size_t)(feat ? W_FLOATS_FEAT : W_FLOATS_NOFEAT) * 4;
+  const size_t lds_bytes = (size_t)obj32n::img_floats(feat) * 4;
+  static std::once_flag eval_attr;         // the image with the feature layer exceeds the 64 KB default
+  std::call_once(eval_attr, [] {
+    (void)hipFuncSetAttribute((const void*)eval_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              obj32n::img_floats(true) * 4);
+    (void)hipFuncSetAttribute((const void*)eval_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              obj32n::img_floats(true) * 4);
+  });
   const dim3 grid(K * d.G), blk(256);
   if (emb) {
     if (feat) hipLaunchKernelGGL((eval_kernel<true, true>), grid, blk, lds_bytes, st, d);
@@ -1038,6 +1054,7 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
   const bool feat = a->gt_feat != nullptr;
   if (feat && (TS / a->S) > 16) return OBJNERF_ENOTSUP;
   const bool bf16 = (a->mode & OBJNERF_TRAIN_BF16) != 0;
+  if (bf16 && a->relu_masks) return OBJNERF_ENOTSUP;
   if (a->workspace_bytes < objnerf_train_workspace_bytes(net, a->K, a->R, a->S, a->gt_feat != nullptr))
     return OBJNERF_EINVAL;
   int64_t offs[OBJNERF_N_TENSORS + 1];
@@ -1078,6 +1095,7 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
     mom = Tm + (size_t)a->K * C * XCOLS;
   }
   d.rayin = rayin; d.gram = gram; d.rayfeat = rayfeat;
+  d.relu_masks = a->relu_masks;
 
   hipStream_t st = (hipStream_t)stream;
   // slab-reduced entries: everything except what this launch does not differentiate.  Without gt_feat the
@@ -1089,14 +1107,13 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
   (void)hipMemsetAsync(a->status, 0, sizeof(int), st);
 
   const size_t lds_bytes = (size_t)((feat ? W_FLOATS_FEAT : W_FLOATS_NOFEAT) + SM_FLOATS + STG_ROWS * STG_LD) * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)train_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)((W_FLOATS_NOFEAT + SM_FLOATS + STG_ROWS * STG_LD) * 4));
-    (void)hipFuncSetAttribute((const void*)train_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+  static std::once_flag attr;
+  std::call_once(attr, [] {
+    (void)hipFuncSetAttribute((const void*)train_fused_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)((W_FLOATS_FEAT + SM_FLOATS + STG_ROWS * STG_LD) * 4));
-    attr_set = true;
-  }
+    (void)hipFuncSetAttribute((const void*)train_fused_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)((W_FLOATS_FEAT + SM_FLOATS + STG_ROWS * STG_LD) * 4));
+  });
   if (feat) {
     objgen::feat_gram(stream, a->K, a->params, (long)a->p_stride, d.L.of_w, d.L.of_b, C, 32, gram, GRAM);
     // u = gt_feat W_of  ([R x C] [C x 32] per object) on the batched MFMA GEMM; beta, |g| beside it
@@ -1105,7 +1122,8 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
     hipLaunchKernelGGL(feat_rowstats_kernel, dim3((a->R + 15) / 16, a->K), dim3(256), 0, st, a->params,
                        (long)a->p_stride, d.L.of_b, C, a->R, a->gt_feat, rayin);
     if (bf16) launch_train_bf16(d, stream, true);
-    else hipLaunchKernelGGL(train_fused_kernel<true>, dim3(a->K * d.G), dim3(NTHR), lds_bytes, st, d);
+    else if (d.relu_masks) hipLaunchKernelGGL((train_fused_kernel<true, true>), dim3(a->K * d.G), dim3(NTHR), lds_bytes, st, d);
+    else hipLaunchKernelGGL((train_fused_kernel<true, false>), dim3(a->K * d.G), dim3(NTHR), lds_bytes, st, d);
     if (hipGetLastError() != hipSuccess) return OBJNERF_ELAUNCH;
     // 512-d head gradient from the per-ray (fh, O, a, c): two split-K GEMMs over the rays + a small finish
     const long nr = (long)a->K * a->R;
@@ -1120,7 +1138,7 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
   } else if (bf16) {
     launch_train_bf16(d, stream, false);
   } else {
-    hipLaunchKernelGGL(train_fused_kernel<false>, dim3(a->K * d.G), dim3(NTHR), lds_bytes, st, d);
+    launch_train32(d, stream);
   }
   if (hipGetLastError() != hipSuccess) return OBJNERF_ELAUNCH;
   const long P = offs[OBJNERF_N_TENSORS];

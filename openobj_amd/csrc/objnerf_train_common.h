@@ -27,6 +27,7 @@ struct TrainDev {
   const float* rayin;   // [K][R][RAYIN]  u = W_of^T g (32), beta = b_of . g, |g|     (feat_pre_kernel)
   const float* gram;    // [K][GRAM]      G = W_of^T W_of (32x32), wb = W_of^T b_of (32), b_of . b_of
   float* rayfeat;       // [K][R][RAYFEAT] composited hidden fh (32), a, c, opacity   (-> feat_post kernels)
+  uint8_t* relu_masks;  // objnerf_train_args.relu_masks (test hook) or NULL
   Layout L;
 };
 constexpr int RAYIN = 34, GRAM = 1088, RAYFEAT = 36;
@@ -39,6 +40,28 @@ constexpr int OFF_GFH = OFF_SW + TS;            // gfh [16][32]
 constexpr int OFF_GOF = OFF_GFH + 16 * 32;      // gO_feat [16], O [16]
 static_assert(OFF_FHB + 64 * NWAVE <= 80 * STG_LD && OFF_GOF + 32 <= 96 * STG_LD, "feat lds aliases");
 
+
+// ReLU branch bits of one 16-sample block (test hook, objnerf_train_args.relu_masks): lane (c, g) holds features
+// 4 g + r (tile 0) and 16 + 4 g + r (tile 1) of its sample; the lane groups g, g ^ 1 share bytes g >> 1 and 2 + (g >> 1).
+__device__ __forceinline__ void write_relu_mask(uint8_t* dst /* masks of this lane's sample */, const int layer,
+                                                const int g, const T32& act, const bool valid) {
+  unsigned n0 = 0, n1 = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    n0 |= (act.t[0][r] > 0.0f ? 1u : 0u) << r;
+    n1 |= (act.t[1][r] > 0.0f ? 1u : 0u) << r;
+  }
+  const unsigned v = (n0 << (4 * (g & 1))) | (n1 << (8 + 4 * (g & 1)));
+  const unsigned o = v | (unsigned)__shfl_xor((int)v, 16, 64);
+  if (valid && (g & 1) == 0) {
+    dst[layer * 4 + (g >> 1)] = (uint8_t)(o & 0xff);
+    dst[layer * 4 + 2 + (g >> 1)] = (uint8_t)(o >> 8);
+  }
+}
+
+// second-generation fp32 kernel (objnerf_train32.hip): RGB + depth + opacity loss, hidden 32, S <= 64
+size_t fused32_lds_bytes();
+void launch_train32(const TrainDev& d, void* stream);
 
 // bf16 MFMA variant (objnerf_train_bf16.hip): same tile structure, bf16 operands, fp32 accumulation
 size_t bf16_lds_bytes();

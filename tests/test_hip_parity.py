@@ -13,11 +13,10 @@ from conftest import T
 from oracle import objnerf_oracle as O
 from openobj_amd import init as obj_init
 from openobj_amd import ops, synthetic
-from parity_util import assert_grads, assert_terms, oracle_step
+from parity_util import assert_grads, assert_terms, check_flips, oracle_step, unpack_masks
 
 pytestmark = pytest.mark.gpu
 
-BRANCH_FLIP_FLOOR = 1e-3     # large batches only: what fp32 ReLU branch flips may cost (tests/parity_util.py docstring)
 
 
 def maxerr(a, b):
@@ -393,9 +392,8 @@ def test_small_batch_one_launch_kernels_vs_oracle(dev, shape, feat_on):
     """Hidden 128 at the reference's native background batch (1200 rays x 14 samples) and around it: the forward and
     the input-gradient chain are ONE launch each (mlp_fwd_small_kernel / mlp_bwd_small_kernel with 5, 3, 4, 3 row
     tiles per workgroup here, ragged last tiles, several objects; the last case takes two rounds of workgroups) and the
-    weight gradients one grouped launch; loss and every gradient against the fp64-anchored oracle (with ~0.5 M ReLU
-    inputs per layer one of them lies within fp32 rounding of zero in some of these cases: the reference's own fp32
-    arithmetic is then off by several 1e-4 of the maximum in the layers below it -- parity_util.assert_grads)."""
+    weight gradients one grouped launch; loss and every gradient against the fp64-anchored oracle on the iteration's
+    own ReLU branches (parity_util)."""
     K, R, n1, n2 = shape
     H = 128
     st = obj_init.init_stacked(K, H, 512, seed=21)
@@ -405,11 +403,13 @@ def test_small_batch_one_launch_kernels_vs_oracle(dev, shape, feat_on):
     arena.scale.fill_(5.0)
     ws = ops.TrainWorkspace(arena, K, R, n1 + n2, feat_on)
     b = synthetic.random_batch(K, R, n1, n2, seed=78, feat_dim=512)
-    _hip_step(arena, ws, b, dev, with_feat=feat_on)
-    o32 = oracle_step(fc, B, 5.0, b, feat_on, device=dev)
-    o64 = oracle_step(fc, B, 5.0, b, feat_on, dtype=torch.float64, device=dev)
+    keys = ["pts", "z", "gt_depth", "gt_rgb", "labels"] + (["gt_feat"] if feat_on else [])
+    mb = _mask_buf(dev, K, R, n1 + n2, H)
+    ops.train_step(arena, ws, to_dev(b, dev, keys), with_feat=feat_on, relu_masks=mb)
+    torch.cuda.synchronize()
+    o32, o64 = _gpu_anchor(st, b, feat_on, dev, k_chunk=K, scale=5.0, masks=unpack_masks(mb, H))
     assert_terms(ws.loss_terms, o64, o32, feat_on)
-    _assert_grads(ws.grads, arena, o64, o32)
+    _assert_matched(ws.grads, arena, o64, o32)
 
 
 @pytest.mark.parametrize("shape", [(1, 1, 1, 9), (3, 2, 16, 48), (1, 129, 8, 24)])
@@ -457,23 +457,31 @@ def _full_size_setup(dev, K, R, n1, n2, feat, hidden=32, seed=123):
     return arena, {k: T(b[k]).to(dev) for k in keys}, st, b
 
 
-def _gpu_anchor(st, b, feat, dev, k_chunk, scale=2.0):
+def _gpu_anchor(st, b, feat, dev, k_chunk, scale=2.0, masks=None):
     """The oracle iteration on the GPU through torch: fp32 (the reference's arithmetic) and the fp64 anchor, objects
-    in chunks so that the (chunk, R, S, .) activations of autograd fit."""
+    in chunks so that the (chunk, R, S, .) activations of autograd fit.  masks: the HIP iteration's ReLU branches
+    (objnerf_train_args.relu_masks, unpacked): both runs take THOSE branches, and every branch that differs from the
+    fp64 run's own is checked to belong to an input within rounding of zero (parity_util.check_flips)."""
     fc, B = list(st[:18]), st[18]
-    o32 = oracle_step(fc, B, scale, b, feat, device=dev, k_chunk=k_chunk)
-    o64 = oracle_step(fc, B, scale, b, feat, dtype=torch.float64, device=dev, k_chunk=k_chunk)
+    o32 = oracle_step(fc, B, scale, b, feat, device=dev, k_chunk=k_chunk, masks=masks)
+    o64 = oracle_step(fc, B, scale, b, feat, dtype=torch.float64, device=dev, k_chunk=k_chunk, masks=masks)
+    if masks is not None:
+        check_flips(o64)
     torch.cuda.empty_cache()
     return o32, o64
 
 
+def _mask_buf(dev, K, R, S, hidden=32):
+    return torch.zeros(K, R, S, 6, hidden // 8, dtype=torch.uint8, device=dev)
+
+
+def _assert_matched(grads, arena, o64, o32):
+    """ReLU branches matched: the plain 1e-4 rule of parity_util.assert_grads, no branch-flip allowance."""
+    assert_grads(arena.views(grads), o64, o32, names=ops.TENSOR_NAMES)
+
+
 def _assert_terms(loss_terms, o64, feat, o32=None):
     assert_terms(loss_terms, o64, o32, feat)
-
-
-def _assert_grads(grads, arena, o64, o32):
-    """Batches of 1e4..1e6 samples per object: parity_util's rule with the branch-flip floor."""
-    assert_grads(arena.views(grads), o64, o32, names=ops.TENSOR_NAMES, regime_floor=BRANCH_FLIP_FLOOR)
 
 
 @pytest.mark.parametrize("K,feat", [(12, False), (15, True)])
@@ -482,35 +490,39 @@ def test_full_size_fused_and_layerwise_vs_anchor(dev, K, feat):
     (ScanNet, ~120 objects with part-level features, object-sharded over 8 GPUs: 15 objects each, the 512-d
     feature-distillation loss on); (12, False) the RGB + depth + opacity loss.
     The fused kernel and the layer-wise path are independent implementations of the same iteration (different
-    kernels, different summation orders); BOTH are held to 1e-4 of the fp64-anchored oracle, which runs on the GPU
-    through torch at this size."""
+    kernels, different summation orders); BOTH are held to 1e-4 of the fp64-anchored oracle evaluated on their own
+    ReLU branches (the oracle runs on the GPU through torch at this size)."""
     R, n1, n2 = 4096, 16, 48
     arena, batch, st, b = _full_size_setup(dev, K, R, n1, n2, feat)
-    ws_f = ops.TrainWorkspace(arena, K, R, n1 + n2, feat)
-    ws_l = ops.TrainWorkspace(arena, K, R, n1 + n2, feat, layerwise=True)
-    ops.train_step(arena, ws_f, batch, with_feat=feat)
-    ops.train_step(arena, ws_l, batch, with_feat=feat, layerwise=True)
-    torch.cuda.synchronize()
-    assert int(ws_f.status.item()) == 0 and int(ws_l.status.item()) == 0
-    o32, o64 = _gpu_anchor(st, b, feat, dev, k_chunk=3 if feat else 6)
-    _assert_terms(ws_f.loss_terms, o64, feat, o32)
-    _assert_terms(ws_l.loss_terms, o64, feat, o32)
-    _assert_grads(ws_f.grads, arena, o64, o32)
-    _assert_grads(ws_l.grads, arena, o64, o32)
+    for layerwise in (False, True):
+        ws = ops.TrainWorkspace(arena, K, R, n1 + n2, feat, layerwise=layerwise)
+        mb = _mask_buf(dev, K, R, n1 + n2)
+        ops.train_step(arena, ws, batch, with_feat=feat, layerwise=layerwise, relu_masks=mb)
+        torch.cuda.synchronize()
+        assert int(ws.status.item()) == 0
+        o32, o64 = _gpu_anchor(st, b, feat, dev, k_chunk=3 if feat else 6, masks=unpack_masks(mb, 32))
+        _assert_terms(ws.loss_terms, o64, feat, o32)
+        _assert_matched(ws.grads, arena, o64, o32)
+        del ws, mb, o32, o64
+        torch.cuda.empty_cache()
 
 
 def test_headline_config_full_size_vs_anchor_and_additivity(dev):
     """BASELINE configs[1] at FULL size (50 objects x 4096 rays x 64 samples, the bench workload): the fused iteration
-    against the fp64-anchored oracle (on the GPU through torch, 5 objects at a time), and -- the property the
-    background network's ray sharding over GPUs relies on (train.BackgroundLoop) -- with the mask counts and
-    early-return flags of the WHOLE batch the gradient of the batch equals the sum of the gradients of its two ray
-    halves, held to the same anchor."""
+    against the fp64-anchored oracle on the iteration's own ReLU branches (on the GPU through torch, 5 objects at a
+    time), and -- the property the background network's ray sharding over GPUs relies on (train.BackgroundLoop) --
+    with the mask counts and early-return flags of the WHOLE batch the gradient of the batch equals the sum of the
+    gradients of its two ray halves, held to the same anchor."""
     K, R, n1, n2 = 50, 4096, 16, 48
     arena, batch, st, b = _full_size_setup(dev, K, R, n1, n2, False)
     ws = ops.TrainWorkspace(arena, K, R, n1 + n2, False)
-    ops.train_step(arena, ws, batch)
+    mb = _mask_buf(dev, K, R, n1 + n2)
+    ops.train_step(arena, ws, batch, relu_masks=mb)
     full = ws.grads.clone()
     full_terms = ws.loss_terms.clone()
+    ops.train_step(arena, ws, batch)                     # the production launch (no hook): bit-identical result
+    torch.cuda.synchronize()
+    assert torch.equal(ws.grads, full) and torch.equal(ws.loss_terms, full_terms)
     counts, flags = ws.counts.clone(), ws.flags.clone()
     ws_h = ops.TrainWorkspace(arena, K, R // 2, n1 + n2, False)
     acc = torch.zeros_like(full)
@@ -522,11 +534,11 @@ def test_headline_config_full_size_vs_anchor_and_additivity(dev):
         acc += ws_h.grads
         terms += ws_h.loss_terms
     torch.cuda.synchronize()
-    o32, o64 = _gpu_anchor(st, b, False, dev, k_chunk=5)
+    o32, o64 = _gpu_anchor(st, b, False, dev, k_chunk=5, masks=unpack_masks(mb, 32))
     _assert_terms(full_terms, o64, False, o32)
     _assert_terms(terms, o64, False, o32)
-    _assert_grads(full, arena, o64, o32)
-    _assert_grads(acc, arena, o64, o32)
+    _assert_matched(full, arena, o64, o32)
+    _assert_matched(acc, arena, o64, o32)
 
 
 def test_more_objects_than_compute_units(dev):
@@ -537,16 +549,14 @@ def test_more_objects_than_compute_units(dev):
     lab = batch["labels"]
     lab[:, 0] = 1                                  # 8 rays per object: keep the early return out of this test
     b["labels"] = lab.cpu().numpy()
-    ws_f = ops.TrainWorkspace(arena, K, R, n1 + n2, False)
-    ws_l = ops.TrainWorkspace(arena, K, R, n1 + n2, False, layerwise=True)
-    ops.train_step(arena, ws_f, batch)
-    ops.train_step(arena, ws_l, batch, layerwise=True)
-    torch.cuda.synchronize()
-    o32, o64 = _gpu_anchor(st, b, False, dev, k_chunk=K)
-    _assert_terms(ws_f.loss_terms, o64, False, o32)
-    _assert_terms(ws_l.loss_terms, o64, False, o32)
-    _assert_grads(ws_f.grads, arena, o64, o32)
-    _assert_grads(ws_l.grads, arena, o64, o32)
+    for layerwise in (False, True):
+        ws = ops.TrainWorkspace(arena, K, R, n1 + n2, False, layerwise=layerwise)
+        mb = _mask_buf(dev, K, R, n1 + n2)
+        ops.train_step(arena, ws, batch, layerwise=layerwise, relu_masks=mb)
+        torch.cuda.synchronize()
+        o32, o64 = _gpu_anchor(st, b, False, dev, k_chunk=K, masks=unpack_masks(mb, 32))
+        _assert_terms(ws.loss_terms, o64, False, o32)
+        _assert_matched(ws.grads, arena, o64, o32)
 
 
 def test_single_object_many_rays(dev):
@@ -554,16 +564,14 @@ def test_single_object_many_rays(dev):
     the anchored oracle."""
     K, R, n1, n2 = 1, 60000, 8, 24
     arena, batch, st, b = _full_size_setup(dev, K, R, n1, n2, False)
-    ws_f = ops.TrainWorkspace(arena, K, R, n1 + n2, False)
-    ws_l = ops.TrainWorkspace(arena, K, R, n1 + n2, False, layerwise=True)
-    ops.train_step(arena, ws_f, batch)
-    ops.train_step(arena, ws_l, batch, layerwise=True)
-    torch.cuda.synchronize()
-    o32, o64 = _gpu_anchor(st, b, False, dev, k_chunk=1)
-    _assert_terms(ws_f.loss_terms, o64, False, o32)
-    _assert_terms(ws_l.loss_terms, o64, False, o32)
-    _assert_grads(ws_f.grads, arena, o64, o32)
-    _assert_grads(ws_l.grads, arena, o64, o32)
+    for layerwise in (False, True):
+        ws = ops.TrainWorkspace(arena, K, R, n1 + n2, False, layerwise=layerwise)
+        mb = _mask_buf(dev, K, R, n1 + n2)
+        ops.train_step(arena, ws, batch, layerwise=layerwise, relu_masks=mb)
+        torch.cuda.synchronize()
+        o32, o64 = _gpu_anchor(st, b, False, dev, k_chunk=1, masks=unpack_masks(mb, 32))
+        _assert_terms(ws.loss_terms, o64, False, o32)
+        _assert_matched(ws.grads, arena, o64, o32)
 
 
 def test_layerwise_object_chunks_equal_one_shot(dev):
@@ -590,17 +598,19 @@ def test_layerwise_object_chunks_equal_one_shot(dev):
 def test_config_c5_object_at_full_size(dev, feat):
     """BASELINE configs[4], one object at its full size: hidden 256, 8192 rays x 128 samples (32 + 96), without and
     with the feature loss, through the layer-wise path; loss terms and all 19 gradients against the fp64-anchored
-    oracle (GPU, torch), and the gradient is additive over the two ray halves under shared mask counts."""
+    oracle on the iteration's own ReLU branches (GPU, torch), and the gradient is additive over the two ray halves
+    under shared mask counts."""
     K, R, n1, n2, H = 1, 8192, 32, 96, 256
     arena, batch, st, b = _full_size_setup(dev, K, R, n1, n2, feat, hidden=H, seed=41)
     ws = ops.TrainWorkspace(arena, K, R, n1 + n2, feat)
-    ops.train_step(arena, ws, batch, with_feat=feat)
+    mb = _mask_buf(dev, K, R, n1 + n2, H)
+    ops.train_step(arena, ws, batch, with_feat=feat, relu_masks=mb)
     torch.cuda.synchronize()
     assert int(ws.status.item()) == 0
     full, counts, flags = ws.grads.clone(), ws.counts.clone(), ws.flags.clone()
-    o32, o64 = _gpu_anchor(st, b, feat, dev, k_chunk=1)
+    o32, o64 = _gpu_anchor(st, b, feat, dev, k_chunk=1, masks=unpack_masks(mb, H))
     _assert_terms(ws.loss_terms, o64, feat, o32)
-    _assert_grads(full, arena, o64, o32)
+    _assert_matched(full, arena, o64, o32)
     ws_h = ops.TrainWorkspace(arena, K, R // 2, n1 + n2, feat)
     acc = torch.zeros_like(full)
     for h in range(2):
@@ -609,13 +619,13 @@ def test_config_c5_object_at_full_size(dev, feat):
         ops.train_step(arena, ws_h, half, with_feat=feat, global_flags=flags, global_counts=counts)
         acc += ws_h.grads
     torch.cuda.synchronize()
-    _assert_grads(acc, arena, o64, o32)
+    _assert_matched(acc, arena, o64, o32)
 
 
 def test_config_c5_gpu_share_runs_in_object_chunks(dev):
     """BASELINE configs[4], one GPU's whole share: 64 objects x 8192 rays x 128 samples, hidden 256 (512 objects
     sharded over 8 GPUs).  The layer-wise path runs it in object chunks that fit the workspace budget; three of the
-    64 objects (first, middle, last chunk) are checked against the fp64-anchored oracle."""
+    64 objects (first, middle, last chunk) are checked against the fp64-anchored oracle on their own ReLU branches."""
     K, R, n1, n2, H = 64, 8192, 32, 96, 256
     arena = ops.ParamArena(K, ops.NetShape(H, 512, 6), dev)
     st = obj_init.init_stacked(K, H, 512, seed=43)
@@ -625,15 +635,14 @@ def test_config_c5_gpu_share_runs_in_object_chunks(dev):
     batch = {k: T(b8[k]).to(dev).repeat(8, *([1] * (b8[k].ndim - 1))) for k in keys}
     ws = ops.TrainWorkspace(arena, K, R, n1 + n2, False, budget=24 << 30)
     assert 1 <= ws.k_chunk < K
-    ops.train_step(arena, ws, batch)
+    mb = _mask_buf(dev, K, R, n1 + n2, H)
+    ops.train_step(arena, ws, batch, relu_masks=mb)
     torch.cuda.synchronize()
     assert int(ws.status.item()) == 0
     gv = arena.views(ws.grads)
     for k in (0, 37, 63):
-        fc, B = [p[k:k + 1] for p in st[:18]], st[18][k:k + 1]
+        stk = [p[k:k + 1] for p in st]
         bk = {kk: b8[kk][k % 8:k % 8 + 1] for kk in keys}
-        o32 = oracle_step(fc, B, 2.0, bk, False, device=dev)
-        o64 = oracle_step(fc, B, 2.0, bk, False, dtype=torch.float64, device=dev)
-        torch.cuda.empty_cache()
+        o32, o64 = _gpu_anchor(stk, bk, False, dev, k_chunk=1, masks=unpack_masks(mb[k:k + 1], H))
         _assert_terms(ws.loss_terms[k:k + 1], o64, False, o32)
-        assert_grads([g[k:k + 1] for g in gv], o64, o32, names=ops.TENSOR_NAMES, regime_floor=BRANCH_FLIP_FLOOR)
+        assert_grads([g[k:k + 1] for g in gv], o64, o32, names=ops.TENSOR_NAMES)
