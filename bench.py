@@ -229,7 +229,7 @@ def main():
         fpr = flop_per_ray(S, H=Hd, feat=feat)
         achieved = K * R * fpr / (kern_ms * 1e-3) / 1e12
         peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
-        kname = f"train_fused_bf16_kernel<{'true' if feat else 'false'}>" if bf16 else f"train_fused_kernel<{'true' if feat else 'false'}>"
+        kname = (f"train_fused_bf16_kernel<{'true' if feat else 'false'}>" if bf16 else ("train_fused_kernel<true, false>" if feat else "train_fused32_kernel<false>"))
         if Hd != 32 or S > 64:
             kname = "objnerf_train_step, layer-wise path (batched MFMA GEMMs)"
         out = {

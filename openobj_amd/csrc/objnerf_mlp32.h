@@ -19,9 +19,14 @@
 // K-order: k-step (T, r) of a 16-feature tile T takes feature kappa = 16 T + 4 g + r from lane group g (so a layer's
 // 32 x 16 accumulator block is the next layer's B operand without moving).  Hidden features use kappa = feature.
 // Embedding entries: lane (sample c, group g) holds x1[t], t = 0..23 (kappa = 16 (t >> 2) + 4 g + (t & 3)):
-//   t = 6 f + i, octave f = 0..3, slot i:  sin(2^f a_j), j = 4 i + g  (valid while j < 21, i.e. i < 5 or g == 0);
+//   t = 4 i + f, slot i, octave f = 0..3:  sin(2^f a_j), j = 4 i + g  (valid while j < 21, i.e. i < 5 or g == 0) -- a
+//   16-row tile of the embedding is ONE direction slot with its four octaves;
 //   the 12 free places carry  x / scale (f = 0, i = 5, g = 1..3),  the constant 1 that multiplies the bias column
-//   (f = 1, i = 5, g = 1)  and zeros;   x2[t], t = 0..11: octaves 4, 5 the same way, the constant at (f = 4, i = 5, g = 1).
+//   (f = 1, i = 5, g = 1)  and zeros;   x2[t] = octave 4 + (t & 1) of slot t >> 1, the constant at (slot 5, octave 4, g = 1).
+// OBJ_PE_ANCHORS (bit f set: octave f gets its own exact range reduction + v_sin / v_cos; clear: it is derived from
+// octave f - 1 by angle doubling, 3 VALU instead of 4 + 2 transcendentals, error doubling per step).  Default 17 =
+// octaves 0 and 4 anchored: embedding error <= ~2e-6 (octave 3) against ~3e-7 with all six anchored; measured on the
+// 50 x 4096 x 64 step (MI355X): 63 -> 10.08 ms, 21 -> 9.89, 17 -> 9.77, 1 -> 9.65; every parity test passes with each.
 // Reference: OccupancyMap.forward (model.py:61-103) on UniDirsEmbed.forward (embedding.py:46-55).
 #pragma once
 #include "objnerf_mlp.h"
@@ -45,7 +50,7 @@ __host__ __device__ constexpr int sv_base(bool feat) { return (feat ? ROWS_FEAT 
 constexpr int BIAS_COL = -2, ZERO_COL = -1;
 // reference column (inside emb[:87]) of x1 entry (t, g); BIAS_COL for the constant-1 entry, ZERO_COL for padding
 __host__ __device__ inline int x1_col(int t, int g) {
-  const int f = t / 6, i = t - 6 * f, j = 4 * i + g;
+  const int i = t >> 2, f = t & 3, j = 4 * i + g;
   if (j < OBJ_NDIR) return 3 + OBJ_NDIR * f + j;
   if (f == 0) return g - 1;                      // x / scale, components 0..2 (i == 5, g = 1..3)
   if (f == 1 && g == 1) return BIAS_COL;
@@ -53,7 +58,7 @@ __host__ __device__ inline int x1_col(int t, int g) {
 }
 // reference column (inside emb[87:]) of x2 entry (t, g)
 __host__ __device__ inline int x2_col(int t, int g) {
-  const int f = t / 6, i = t - 6 * f, j = 4 * i + g;
+  const int i = t >> 1, f = t & 1, j = 4 * i + g;
   if (j < OBJ_NDIR) return OBJ_NDIR * f + j;
   if (f == 0 && g == 1) return BIAS_COL;
   return ZERO_COL;
@@ -189,84 +194,103 @@ __device__ __forceinline__ void pe32_project(const float* sv, const int g, const
     pe.vl[i] = fmaf(a0, OBJ_INV2PI_LO, fmaf(a0, OBJ_INV2PI_HI, -vh));
   }
 }
-// sin (and cos) of 2^f a for the angle held as revolutions (vh + vl); exact range reduction, then v_sin / v_cos
-template <bool WANT_COS>
-__device__ __forceinline__ void pe32_sincos(const float vh, const float vl, const int f, float& s, float& c) {
-  const float sc = (float)(1 << f);
-  const float u = vh * sc;                       // exact
-  const float r = u - rintf(u);                  // exact, |r| <= 1/2
-  const float w = fmaf(vl, sc, r);
-  s = __builtin_amdgcn_sinf(w);
-  if (WANT_COS) c = __builtin_amdgcn_cosf(w);
+#ifndef OBJ_PE_ANCHORS
+#define OBJ_PE_ANCHORS 17
+#endif
+constexpr unsigned PE_ANCHORS = (OBJ_PE_ANCHORS) | 1u;
+
+// sin / cos of 2^f a, f = F0 .. F1, for the angle held as revolutions (vh + vl).  An anchor octave: exact range
+// reduction (vh 2^f and the subtraction of its nearest integer are exact), then v_sin / v_cos; a derived octave:
+// sin 2x = 2 sin x cos x, cos 2x = 1 - 2 sin^2 x from the octave below.  s[f], c[f] are written for f in [F0, F1]
+// (c only where WANT_COS or a later doubling needs it).
+template <int F0, int F1, bool WANT_COS>
+__device__ __forceinline__ void pe32_octaves(const float vh, const float vl, float (&s)[6], float (&c)[6]) {
+  int A = F0;                                   // the anchor at or below F0 (octave 0 always is one)
+  while (!((PE_ANCHORS >> A) & 1)) --A;
+  float sp = 0.f, cp = 0.f;
+#pragma unroll
+  for (int f = 0; f <= F1; ++f) {
+    if (f < A) continue;
+    const bool anchor = (f == A) || ((PE_ANCHORS >> f) & 1);
+    const bool next_derived = (f < F1) && !((PE_ANCHORS >> (f + 1)) & 1);
+    const bool need_cos = next_derived || (WANT_COS && f >= F0);
+    float sn, cn = 0.f;
+    if (anchor) {
+      const float sc = (float)(1 << f);
+      const float u = vh * sc;                   // exact
+      const float r = u - rintf(u);              // exact, |r| <= 1/2
+      const float w = fmaf(vl, sc, r);
+      sn = __builtin_amdgcn_sinf(w);
+      if (need_cos) cn = __builtin_amdgcn_cosf(w);
+    } else {
+      const float t2 = sp + sp;
+      sn = t2 * cp;
+      if (need_cos) cn = fmaf(-t2, sp, 1.0f);
+    }
+    sp = sn; cp = cn;
+    if (f >= F0) { s[f] = sn; c[f] = cn; }
+  }
 }
 
-// forward value of x1 entry t (x2 entry t) of this lane
-__device__ __forceinline__ float pe32_x1(const Pe32& pe, const int t, const int g) {
-  const int f = t / 6, i = t - 6 * f;
-  float s, c;
-  pe32_sincos<false>(pe.vh[i], pe.vl[i], f, s, c);
+// x1 tile i = slot i (octaves 0..3 in the four registers), forward values
+__device__ __forceinline__ f32x4 pe32_x1_tile(const Pe32& pe, const int i, const int g, const float (&s)[6]) {
+  f32x4 o = {s[0], s[1], s[2], s[3]};
   if (i == 5) {                                  // only group 0 has a sixth direction
-    if (f == 0) s = (g == 0) ? s : ((g == 1) ? pe.t[0] : ((g == 2) ? pe.t[1] : pe.t[2]));
-    else if (f == 1) s = (g == 0) ? s : ((g == 1) ? 1.0f : 0.0f);
-    else s = (g == 0) ? s : 0.0f;
+    o[0] = (g == 0) ? o[0] : ((g == 1) ? pe.t[0] : ((g == 2) ? pe.t[1] : pe.t[2]));
+    o[1] = (g == 0) ? o[1] : ((g == 1) ? 1.0f : 0.0f);
+    o[2] = (g == 0) ? o[2] : 0.0f;
+    o[3] = (g == 0) ? o[3] : 0.0f;
   }
-  return s;
+  return o;
 }
-__device__ __forceinline__ float pe32_x2(const Pe32& pe, const int t, const int g) {
-  const int f = t / 6, i = t - 6 * f;
-  float s, c;
-  pe32_sincos<false>(pe.vh[i], pe.vl[i], 4 + f, s, c);
+// the two x2 entries (octaves 4, 5) of slot i
+__device__ __forceinline__ void pe32_x2_pair(const int i, const int g, const float (&s)[6], float& v4, float& v5) {
+  v4 = s[4]; v5 = s[5];
   if (i == 5) {
-    if (f == 0) s = (g == 0) ? s : ((g == 1) ? 1.0f : 0.0f);
-    else s = (g == 0) ? s : 0.0f;
+    v4 = (g == 0) ? v4 : ((g == 1) ? 1.0f : 0.0f);
+    v5 = (g == 0) ? v5 : 0.0f;
   }
-  return s;
 }
-// backward of entry t that also re-creates its forward value: returns the value, adds d_x * d sin / d proj to dps[i]
-// (d arg / d proj = pi 2^f, embedding.py:49-52)
-__device__ __forceinline__ float pe32_x1_fb(const Pe32& pe, const int t, const int g, const float dx, float (&dps)[6]) {
-  const int f = t / 6, i = t - 6 * f;
-  float s, c;
-  pe32_sincos<true>(pe.vh[i], pe.vl[i], f, s, c);
-  float v = dx * ((c * OBJ_PI_F) * (float)(1 << f));
-  if (i == 5) {
-    v = (g == 0) ? v : 0.0f;
-    if (f == 0) s = (g == 0) ? s : ((g == 1) ? pe.t[0] : ((g == 2) ? pe.t[1] : pe.t[2]));
-    else if (f == 1) s = (g == 0) ? s : ((g == 1) ? 1.0f : 0.0f);
-    else s = (g == 0) ? s : 0.0f;
-  }
-  dps[i] += v;
-  asm volatile("" : "+v"(dps[i]));     // consume v now (a deferred add keeps d_x and the cosine live)
-  return s;
+// backward of the x1 tile of slot i that also re-creates its forward values: returns the values, adds
+// sum_f d_x[f] * d sin / d proj to dps  (d arg / d proj = pi 2^f, embedding.py:49-52)
+__device__ __forceinline__ f32x4 pe32_x1_tile_fb(const Pe32& pe, const int i, const int g, const f32x4& dx, float& dps) {
+  float s[6], c[6];
+  pe32_octaves<0, 3, true>(pe.vh[i], pe.vl[i], s, c);
+  float v = 0.f;
+#pragma unroll
+  for (int f = 0; f < 4; ++f) v = fmaf(dx[f], (c[f] * OBJ_PI_F) * (float)(1 << f), v);
+  if (i == 5) v = (g == 0) ? v : 0.0f;
+  dps += v;
+  asm volatile("" : "+v"(dps));        // consume v now (a deferred add keeps d_x and the cosines live)
+  return pe32_x1_tile(pe, i, g, s);
 }
-__device__ __forceinline__ float pe32_x2_fb(const Pe32& pe, const int t, const int g, const float dx, float (&dps)[6]) {
-  const int f = t / 6, i = t - 6 * f;
-  float s, c;
-  pe32_sincos<true>(pe.vh[i], pe.vl[i], 4 + f, s, c);
-  float v = dx * ((c * OBJ_PI_F) * (float)(16 << f));
-  if (i == 5) {
-    v = (g == 0) ? v : 0.0f;
-    if (f == 0) s = (g == 0) ? s : ((g == 1) ? 1.0f : 0.0f);
-    else s = (g == 0) ? s : 0.0f;
-  }
-  dps[i] += v;
-  asm volatile("" : "+v"(dps[i]));
-  return s;
+// the same for the x2 pair of slot i (d_x4, d_x5: gradients of its octave-4 and octave-5 entries)
+__device__ __forceinline__ void pe32_x2_pair_fb(const Pe32& pe, const int i, const int g, const float dx4, const float dx5,
+                                                float& dps, float& v4, float& v5) {
+  float s[6], c[6];
+  pe32_octaves<4, 5, true>(pe.vh[i], pe.vl[i], s, c);
+  float v = fmaf(dx5, (c[5] * OBJ_PI_F) * 32.0f, dx4 * ((c[4] * OBJ_PI_F) * 16.0f));
+  if (i == 5) v = (g == 0) ? v : 0.0f;
+  dps += v;
+  asm volatile("" : "+v"(dps));
+  pe32_x2_pair(i, g, s, v4, v5);
 }
 
 struct Emb32 {
-  f32x4 x1[6];     // x1[T][r] = entry t = 4 T + r
-  f32x4 x2[3];
+  f32x4 x1[6];     // x1[i][f] = entry t = 4 i + f
+  f32x4 x2[3];     // x2[T][r] = entry t = 4 T + r = 2 (slot) + (octave - 4)
 };
 __device__ __forceinline__ void embed32(Emb32& e, const Pe32& pe, const int g) {
 #pragma unroll
-  for (int T = 0; T < 6; ++T)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) e.x1[T][r] = pe32_x1(pe, 4 * T + r, g);
-#pragma unroll
-  for (int T = 0; T < 3; ++T)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) e.x2[T][r] = pe32_x2(pe, 4 * T + r, g);
+  for (int i = 0; i < 6; ++i) {
+    float s[6], c[6];
+    pe32_octaves<0, 5, false>(pe.vh[i], pe.vl[i], s, c);
+    e.x1[i] = pe32_x1_tile(pe, i, g, s);
+    float v4, v5;
+    pe32_x2_pair(i, g, s, v4, v5);
+    e.x2[i >> 1][2 * (i & 1)] = v4;
+    e.x2[i >> 1][2 * (i & 1) + 1] = v5;
+  }
 }
 // embedding supplied by the caller in the reference's order (OccupancyMap.forward on an explicit embedding tensor)
 __device__ __forceinline__ void embed32_load(Emb32& e, const float* __restrict__ emb, const int g) {

@@ -15,6 +15,10 @@
 using namespace obj32n;
 using namespace objtrain;
 
+#if !defined(OBJ_LAZY_HEADS) && !defined(OBJ_BUTTERFLY_HEADS)
+#define OBJ_LAZY_HEADS
+#endif
+
 namespace {
 
 __device__ __forceinline__ void st_T32(float* stg_lane, const int rowbase, const T32& v) {
@@ -114,9 +118,27 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
   f32x4 accA0 = zero4(), accA1 = zero4(), accB0 = zero4(), accB1 = zero4(), accC0 = zero4(), accC1 = zero4();
   // row-wise sums over samples: slot s of a register = lane s of each lane group; feature of slot s (< 8) is
   // 16 (s >> 2) + 4 g + (s & 3); lanes 8..15 carry a second quantity
+  // Row sums over the samples (head weights, mid1 / mid2 biases).  Two forms: transposing DPP butterflies into "slot"
+  // registers (slot s of a register = lane s of each lane group; feature of slot s (< 8) is 16 (s >> 2) + 4 g + (s & 3);
+  // lanes 8..15 carry a second quantity) -- or, OBJ_LAZY_HEADS / OBJ_LAZY_BIAS, per-lane partial sums over this
+  // lane's samples, reduced over the 16 lanes of the group once at the end (fewer instructions, 32 / 16 more
+  // registers).  The head weights are lazy by default (10.08 -> 9.78 ms on the 50 x 4096 x 64 step); both together
+  // do not fit the 256 registers of a 512-thread workgroup (OBJ_LAZY_BIAS alone: 9.91 ms).
+#ifdef OBJ_LAZY_HEADS
+  float hW[4][8];     // d W_alpha, d W_oc[0..2];  [.][4 tt + r] <-> feature 16 tt + 4 g + r
+#pragma unroll
+  for (int s_ = 0; s_ < 8; ++s_) hW[0][s_] = hW[1][s_] = hW[2][s_] = hW[3][s_] = 0.f;
+#else
   float gS0 = 0.f;   // [0..7] d W_alpha   | [8..15] d W_oc[0]
   float gS1 = 0.f;   // [0..7] d W_oc[1]   | [8..15] d W_oc[2]
+#endif
+#ifdef OBJ_LAZY_BIAS
+  float bS[2][8];     // d b_mid1, d b_mid2
+#pragma unroll
+  for (int s_ = 0; s_ < 8; ++s_) bS[0][s_] = bS[1][s_] = 0.f;
+#else
   float gS2 = 0.f;   // [0..7] d b_mid1    | [8..15] d b_mid2
+#endif
   float g_hb = 0.f;  // d (alpha bias | colour bias g - 1) of this lane's head output, summed over its samples
   float dB[6][3];    // d B[4 i + g][x], summed over this lane's samples
 #pragma unroll
@@ -272,7 +294,10 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
 
     // ---- phase A: heads, colour layer, mid2
     T32 d_hc, d_h4;
-    float pa_[8], pb_[8], pc_[8], pd_[8];       // head-weight gradient products, summed over the samples below
+    float pa_[8];
+#ifndef OBJ_LAZY_HEADS
+    float pb_[8], pc_[8], pd_[8];       // head-weight gradient products, summed over the samples below
+#endif
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
@@ -280,23 +305,38 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
         const int row = 16 * tt + 4 * g + r;
         const int s = 4 * tt + r;
         const float hv = act.hc.t[tt][r];
+#ifdef OBJ_LAZY_HEADS
+        hW[0][s] = fmaf(da, act.h4.t[tt][r], hW[0][s]);
+        hW[1][s] = fmaf(dc0, hv, hW[1][s]);
+        hW[2][s] = fmaf(dc1, hv, hW[2][s]);
+        hW[3][s] = fmaf(dc2, hv, hW[3][s]);
+#else
         pa_[s] = da * act.h4.t[tt][r];
         pb_[s] = dc0 * hv;
         pc_[s] = dc1 * hv;
         pd_[s] = dc2 * hv;
+#endif
         const float dv = fmaf(sv[SV_WOC + 2 * H + row], dc2, fmaf(sv[SV_WOC + H + row], dc1, sv[SV_WOC + row] * dc0));
         d_hc.t[tt][r] = hv > 0.0f ? dv : 0.0f;
         d_h4.t[tt][r] = sv[SV_WA + row] * da;
       }
     // group A staging: [h4 | x2] rows 0..79, h3 rows 96..127, d_hc rows 128.., d_h4pre rows 160..
+#ifndef OBJ_LAZY_HEADS
     gS0 += slot_sums16(pa_, pb_, c);
     gS1 += slot_sums16(pc_, pd_, c);
     asm volatile("" : "+v"(gS0), "+v"(gS1));
+#endif
     st_T32(stg_lane, 0, act.h4);
     st_T32(stg_lane, 96, act.h3);
     st_T32(stg_lane, 128, d_hc);
     mma_t32(d_h4, wt0, wt1, R_CL, d_hc);
     d_h4 = relu_mask32(d_h4, act.h4);
+#ifdef OBJ_LAZY_BIAS
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bS[1][4 * tt + r] += d_h4.t[tt][r];
+#else
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
@@ -306,16 +346,17 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
       gS2 += (c >= 8) ? sv8 : 0.0f;
       asm volatile("" : "+v"(gS2));
     }
+#endif
     st_T32(stg_lane, 160, d_h4);
-    // PE backward, x2 part (octaves 4, 5), one 16-row tile at a time
+    // PE backward, x2 part (octaves 4, 5): a 16-row tile = two direction slots
 #pragma unroll
     for (int T = 0; T < 3; ++T) {
       f32x4 d_x = zero4();
       mma_t16(d_x, wt0, wt1, R_CL + 32 + 16 * T, d_hc);
-      f32x4 o;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) o[r] = pe32_x2_fb(pe, 4 * T + r, g, d_x[r], dps);
-      st_T16(stg_lane, 32 + 16 * T, o);
+      float o0, o1, o2, o3;
+      pe32_x2_pair_fb(pe, 2 * T, g, d_x[0], d_x[1], dps[2 * T], o0, o1);
+      pe32_x2_pair_fb(pe, 2 * T + 1, g, d_x[2], d_x[3], dps[2 * T + 1], o2, o3);
+      st_T16(stg_lane, 32 + 16 * T, f32x4{o0, o1, o2, o3});
     }
     T32 d_h3 = zero32();
     mma_t32(d_h3, wt0, wt1, R_M2, d_h4);
@@ -337,6 +378,12 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
     T32 d_h2 = zero32();
     mma_t32(d_h2, wt0, wt1, R_CAT, d_h3);
     d_h2 = relu_mask32(d_h2, act.h2);
+#ifdef OBJ_LAZY_BIAS
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bS[0][4 * tt + r] += d_h2.t[tt][r];
+#else
     float pa2_[8];
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
@@ -347,19 +394,17 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
       gS2 += (c < 8) ? sv8 : 0.0f;
       asm volatile("" : "+v"(gS2));
     }
+#endif
     T32 d_h1 = zero32();
     mma_t32(d_h1, wt0, wt1, R_M1, d_h2);
     d_h1 = relu_mask32(d_h1, act.h1);
-    // PE backward, x1 part (octaves 0..3): d x1 tile = cat^T d_h3 + in^T d_h1, consumed tile by tile
+    // PE backward, x1 part (octaves 0..3): d x1 tile = cat^T d_h3 + in^T d_h1; a tile = one direction slot
 #pragma unroll
     for (int T = 0; T < 6; ++T) {
       f32x4 d_x = zero4();
       mma_t16(d_x, wt0, wt1, R_CAT + 32 + 16 * T, d_h3);
       mma_t16(d_x, wt0, wt1, R_IN + 16 * T, d_h1);
-      f32x4 o;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) o[r] = pe32_x1_fb(pe, 4 * T + r, g, d_x[r], dps);
-      st_T16(stg_lane, 32 + 16 * T, o);
+      st_T16(stg_lane, 32 + 16 * T, pe32_x1_tile_fb(pe, T, g, d_x, dps[T]));
     }
     // d B[j][x] += d proj_j * t_x (embedding.py:48); j = 4 i + g lives in this lane only
 #pragma unroll
@@ -427,10 +472,32 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
   constexpr int NRED32 = 6 * 32 + 4 + 4 + 72;     // row sums | head biases | loss terms | d B [slot][g][3]
   {
     float* mine = red + w * NRED32;
-    const int s = c & 7;
-    const int row = 16 * (s >> 2) + 4 * g + (s & 3);
-    if (c < 8) { mine[64 + row] = gS0; mine[128 + row] = gS1; mine[row] = gS2; }          // wa, woc1, bm1
-    else { mine[96 + row] = gS0; mine[160 + row] = gS1; mine[32 + row] = gS2; }           // woc0, woc2, bm2
+    {
+      const int s = c & 7;
+      const int row = 16 * (s >> 2) + 4 * g + (s & 3);
+#ifdef OBJ_LAZY_HEADS
+#pragma unroll
+      for (int s_ = 0; s_ < 8; ++s_) {
+        const int rw = 16 * (s_ >> 2) + 4 * g + (s_ & 3);
+        const float v2 = dpp_rowsum16(hW[0][s_]), v3 = dpp_rowsum16(hW[1][s_]);
+        const float v4 = dpp_rowsum16(hW[2][s_]), v5 = dpp_rowsum16(hW[3][s_]);
+        if (c == 0) { mine[64 + rw] = v2; mine[96 + rw] = v3; mine[128 + rw] = v4; mine[160 + rw] = v5; }
+      }
+#else
+      if (c < 8) { mine[64 + row] = gS0; mine[128 + row] = gS1; }          // wa, woc1
+      else { mine[96 + row] = gS0; mine[160 + row] = gS1; }                // woc0, woc2
+#endif
+#ifdef OBJ_LAZY_BIAS
+#pragma unroll
+      for (int s_ = 0; s_ < 8; ++s_) {
+        const int rw = 16 * (s_ >> 2) + 4 * g + (s_ & 3);
+        const float v0 = dpp_rowsum16(bS[0][s_]), v1 = dpp_rowsum16(bS[1][s_]);
+        if (c == 0) { mine[rw] = v0; mine[32 + rw] = v1; }
+      }
+#else
+      mine[(c < 8 ? 0 : 32) + row] = gS2;                                  // bm1 | bm2
+#endif
+    }
     const float hb = dpp_rowsum16(g_hb);                 // this lane group's head-bias gradient
     if (c == 0) mine[192 + g] = hb;
     const float e0 = wave_sum64(l_d), e1 = wave_sum64(l_c), e2 = wave_sum64(l_o);
@@ -479,11 +546,11 @@ void launch_train32(const TrainDev& d, void* stream) {
     hipLaunchKernelGGL(train_fused32_kernel<false>, dim3(d.K * d.G), dim3(NTHR), fused32_lds_bytes(), (hipStream_t)stream, d);
 }
 
+}  // namespace objtrain
+
 #ifdef PHASE_TIMING
-int debug_phase32(unsigned long long* out_host) {
+extern "C" int objnerf_debug_phase32(unsigned long long* out_host) {
   if (hipDeviceSynchronize() != hipSuccess) return -1;
   return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_phase32), sizeof(unsigned long long) * 8 * 24) == hipSuccess ? 0 : -1;
 }
 #endif
-
-}  // namespace objtrain

@@ -9,7 +9,7 @@ import torch
 from openobj_amd import _lib, ops, synthetic, init as obj_init
 
 NAMES = ["load+project", "embed(sincos fwd)", "mlp fwd", "sync1", "composite", "sync2", "phaseA compute", "sync3",
-         "wgrad A", "sync4", "phaseB compute", "dB atomics", "sync5", "dB reduce+wgrad B", "sync6+phaseC stores",
+         "wgrad A", "sync4", "phaseB compute", "(dB, first generation)", "sync5", "wgrad B", "sync6+phaseC stores",
          "sync7", "wgrad C", "sync8"]
 dev = torch.device("cuda:0")
 K, R, n1, n2 = 50, 4096, 16, 48
@@ -24,7 +24,7 @@ for _ in range(3):
     ops.train_step(arena, ws, batch, with_feat=FEAT, bf16=BF16)
 torch.cuda.synchronize()
 out = (C.c_ulonglong * (8 * 24))()
-f = _lib.lib().objnerf_debug_phase_bf16 if BF16 else _lib.lib().objnerf_debug_phase
+f = _lib.lib().objnerf_debug_phase_bf16 if BF16 else (_lib.lib().objnerf_debug_phase if FEAT else _lib.lib().objnerf_debug_phase32)
 f.restype = C.c_int
 assert f(out) == 0
 a = np.array(list(out), dtype=np.float64).reshape(8, 24)[:, :18]
