@@ -1,26 +1,30 @@
 #!/usr/bin/env python3
 """Throughput bench of the hot path: training rays/s of the vectorised object-NeRF iteration.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config c2|c3|c4|c5]
 
-One "step" = one complete training iteration of train.py:394-474: the K_obj stacked object networks of
-THIS rank (label statistics -> fused forward/loss/backward kernel -> gradient finalize -> AdamW) plus
-the shared background network (hidden 128, its 1200 rays split over the ranks, gradient all-reduce),
-inputs already resident in HBM.  Workload (BASELINE.json configs[1]): 50 objects per GPU,
-hidden 32, 64 samples per ray (n_bins_cam2surface 16 + n_bins 48), RGB + depth + opacity loss,
-synthetic Replica-shaped rays (openobj_amd.synthetic.random_batch), reference-initialised weights.
-Objects shard across ranks with no data-path collective (the per-step early-return flags are a
-2-int all-reduce); the replicated background network's gradient (182 339 floats) is the one RCCL
-all-reduce.  Scaling is weak: every rank trains its own 50 objects.  `value` counts object rays only.
+One "step" = one complete training iteration of train.py:394-474: the stacked object networks of THIS rank (label
+statistics -> fused forward / loss / backward kernel -> gradient finalize -> AdamW) plus the shared background network
+(hidden 128, its 1200 rays split over the ranks), inputs already resident in HBM.  `value` counts object rays only.
 
-dtype: the headline line is fp32 -- the reference's arithmetic (train.py:74, AMP off) and the only mode held to
-the 1e-4 parity bar.  BASELINE.json configs[1] names bf16: the opt-in bf16-operand mode of the same kernel
-(fp32 accumulation, master weights, compositing and AdamW; PSNR-gated) is timed in the same run and reported
-as the `bf16_mode` object of the line (or as the headline with --dtype bf16).
+Workloads (BASELINE.json configs; SURVEY.md 8 shape table):
+  c2 (default)  50 objects per GPU, hidden 32, 4096 rays x 64 samples (16 + 48), RGB + depth + opacity loss   weak
+  c3            c2 + the 512-d feature-distillation loss (cfg.part_mode)                                         weak
+  c4            ScanNet-shaped: 120 objects IN TOTAL with the feature loss, sharded over the GPUs (15 each at 8)  strong
+  c5            512-object stress: 64 objects per GPU, hidden 256, 8192 rays x 128 samples (32 + 96)              weak
+Objects shard across ranks with no data-path collective.  An iteration has exactly two collectives
+(openobj_amd.train.ShardedIteration): one int32[4] SUM before the step (early-return flags + background mask counts)
+and one fp32 SUM of the replicated background network's gradient (182 339 floats + 4 loss terms) that is in flight
+under the object kernel.
 
-Prints ONE JSON line (rank 0).  `roofline` is the fused kernel against the dense fp32 MFMA peak,
-`cpu_baseline` is the oracle (the reference's op sequence in PyTorch on the host cores) on a bounded
-sample of the same workload.
+dtype: the headline line is fp32 -- the reference's arithmetic (train.py:74, AMP off) and the only mode held to the
+1e-4 parity bar.  BASELINE.json's configs name bf16: the opt-in bf16-operand mode of the same step (fp32 accumulation,
+master weights, compositing and AdamW; PSNR-gated) is timed in the same run and reported as the `bf16_mode` object
+(or as the headline with --dtype bf16).
+
+Prints ONE JSON line (rank 0): `roofline` = the dominant kernel against the dense fp32 MFMA peak (spec and measured),
+`cpu_baseline` = the oracle (the reference's op sequence in PyTorch on the host cores) at BASELINE.md section 3's
+shapes, `psnr` = the reconstruction quality of the same kernels on the G9 scene against the reference's ensemble.
 """
 import argparse
 import json
@@ -39,6 +43,10 @@ from openobj_amd import ops, synthetic    # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA
+VALU_SIMDS = 256 * 4              # SIMDs of the chip
+VALU_CYCLES_PER_INST = 2.0        # a wave64 VALU instruction occupies its SIMD-32 for 2 cycles (cycle-constants table)
+CLOCK_HZ = 2.4e9
+RECORDED = os.path.join(ROOT, "profiles", "r02_counters.json")
 
 
 def flop_per_ray(S: int, H: int = 32, feat: bool = False) -> float:
@@ -47,25 +55,40 @@ def flop_per_ray(S: int, H: int = 32, feat: bool = False) -> float:
     return 3.0 * 2.0 * (S * ms + (512 * H if feat else 0))
 
 
-def measured_traffic(K, R, S, feat, dtype):
-    """HBM bytes per launch of the fused kernel from the PMC passes committed under profiles/ (FETCH_SIZE and
-    WRITE_SIZE in separate rocprofv3 --pmc runs, gfx950 correction applied; tools/gpu_profile_round.sh).
-    Counters cannot be read from inside this process, so the figure is the recorded one for the same workload;
-    None when the workload differs from the profiled one."""
+def recorded_counters(kernel: str, K, R, S):
+    """PMC figures of `kernel` for this workload from the profile passes committed under profiles/ (rocprofv3 --pmc in
+    separate runs, gfx950 FETCH_SIZE correction applied: tools/gpu_profile_round.sh).  Hardware counters cannot be
+    read from inside this process: these are RECORDED values of the same launch, None when the workload differs."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic_v5.json")) as f:
-            t = json.load(f)
-        wl = t["workload"]
-        if (wl["objects"], wl["rays"], wl["samples"], wl["feat"], wl["dtype"]) == (K, R, S, feat, dtype):
-            return t["traffic_bytes_per_launch"]
+        with open(RECORDED) as f:
+            for e in json.load(f)["kernels"]:
+                if e["kernel"] == kernel and (e["objects"], e["rays"], e["samples"]) == (K, R, S):
+                    return e
     except (OSError, KeyError, ValueError):
         pass
     return None
 
 
-def cpu_baseline(K, R, n1, n2, seed, steps=2, feat=False):
-    """Oracle = the reference's op sequence (vmap(pe) -> vmap(fc) -> step_batch_loss -> backward -> AdamW),
-    fp32, on the host cores.  Bounded sample: same K, S, H; fewer rays per object."""
+def measured_mfma_peak(dev, dtype_id):
+    """TFLOP/s of a saturated MFMA loop (objnerf_mfma_peak: one wave per SIMD, four independent accumulators, operands
+    in registers, non-trivial data) on THIS device -- the denominator a kernel can actually reach."""
+    from openobj_amd import _lib
+    n_wg, iters = 1024, 20000
+    sink = torch.empty(n_wg * 256, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    for it in (2000, iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(_lib.lib().objnerf_mfma_peak(dtype_id, it, n_wg, sink.data_ptr(), st), "objnerf_mfma_peak")
+        e1.record()
+        torch.cuda.synchronize()
+    flop = (2048.0 if dtype_id == 0 else 16384.0) * 4 * iters * 4 * n_wg
+    return flop / (e0.elapsed_time(e1) * 1e-3) / 1e12
+
+
+def cpu_step_time(K, R, n1, n2, seed, steps, feat):
+    """ms per step of the oracle = the reference's op sequence (vmap(pe) -> vmap(fc) -> step_batch_loss -> backward
+    -> AdamW), fp32, on the host cores: 1 warm-up + `steps` timed, median."""
     from oracle import objnerf_oracle as O
     stacked = obj_init.init_stacked(K, 32, 512, seed=0)
     fc = [p.clone().requires_grad_(True) for p in stacked[:18]]
@@ -87,10 +110,50 @@ def cpu_baseline(K, R, n1, n2, seed, steps=2, feat=False):
                 if g is not None:
                     O.adamw_step(p, g, mm, vv, it + 1, 1e-3, 0.013)
         times.append(time.perf_counter() - t0)
-    t = float(np.median(times[1:]))
-    return dict(value=K * R / t, unit="rays/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"K={K} objects x R={R} rays x S={n1 + n2} samples, hidden 32, {steps} timed steps, "
-                       f"{t * 1e3:.0f} ms/step (oracle/objnerf_oracle.py, torch {torch.__version__} CPU fp32)")
+    return float(np.median(times[1:])) * 1e3
+
+
+def cpu_baseline(feat, seed=4242):
+    """c1 (K=1, R=256, S=32) in full; the 50-object stack at the reference-native R=120, S=10
+    and at R=1024, S=64 (the metric's sample count); >= 3 timed steps after one warm-up.  `value` is the S=64 shape."""
+    shapes = [("c1", 1, 256, 8, 24, 5), ("c2/c3 native", 50, 120, 1, 9, 3), ("c2/c3 metric", 50, 1024, 16, 48, 3)]
+    rows = []
+    for name, K, R, n1, n2, steps in shapes:
+        f = feat and K > 1
+        ms = cpu_step_time(K, R, n1, n2, seed, steps, f)
+        rows.append({"shape": f"{name}: K={K} R={R} S={n1 + n2}{' +feat' if f else ''}", "ms_per_step": ms,
+                     "rays_per_s": K * R / (ms * 1e-3), "timed_steps": steps})
+    return dict(value=rows[-1]["rays_per_s"], unit="rays/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{rows[-1]['shape']}, hidden 32, {rows[-1]['timed_steps']} timed steps after 1 warm-up, "
+                       f"{rows[-1]['ms_per_step']:.0f} ms/step (oracle/objnerf_oracle.py, torch {torch.__version__} CPU fp32)",
+                shapes=rows)
+
+
+def psnr_block(dev, n_seeds, with_bf16):
+    """PSNR of the G9 scene after 300 fused iterations, ensemble over weight seeds, against the reference's own
+    ensemble for the same seeds (tests/golden/g9_ensemble.npz)."""
+    from openobj_amd import psnr_scene
+    ref = psnr_scene.reference_ensemble()
+    if ref is None:
+        return None
+    n = min(n_seeds, len(ref["seeds"]))
+    seeds = [int(s) for s in ref["seeds"][:n]]
+    sc = psnr_scene.PsnrScene(dev)
+    out = {"scene": "G9: 4 analytic ellipsoids, 96 rays x 16 samples per object and iteration, 300 iterations, "
+                    "PSNR of the rendered colour on 256 held-out rays per object",
+           "reference": "the reference's own modules, same seeds (tests/golden/g9_ensemble.npz)"}
+    out["f32"] = psnr_scene.delta_report(sc.ensemble(seeds, bf16=False), ref["psnr"][:n])
+    if with_bf16:
+        out["bf16"] = psnr_scene.delta_report(sc.ensemble(seeds, bf16=True), ref["psnr"][:n])
+    return out
+
+
+CONFIGS = {
+    "c2": dict(objects=50, rays=4096, n1=16, n2=48, hidden=32, feat=False, scaling="weak"),
+    "c3": dict(objects=50, rays=4096, n1=16, n2=48, hidden=32, feat=True, scaling="weak"),
+    "c4": dict(objects=120, rays=4096, n1=16, n2=48, hidden=32, feat=True, scaling="strong"),
+    "c5": dict(objects=64, rays=8192, n1=32, n2=96, hidden=256, feat=False, scaling="weak"),
+}
 
 
 def main():
@@ -98,18 +161,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--objects", type=int, default=50, help="object networks per GPU")
-    ap.add_argument("--rays", type=int, default=4096, help="rays per object per step")
-    ap.add_argument("--n-cam2surf", type=int, default=16)
-    ap.add_argument("--n-bins", type=int, default=48)
-    ap.add_argument("--hidden", type=int, default=32,
-                    help="hidden width of the object networks (32 = the fused kernel; other widths, e.g. BASELINE "
-                         "configs[4] hidden 256 with --n-cam2surf 32 --n-bins 96, run the layer-wise path in object chunks)")
-    ap.add_argument("--feat", action="store_true",
-                    help="BASELINE configs[2]: add the 512-d feature-distillation loss (cfg.part_mode)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default=None,
+                    help="BASELINE.json configuration (default c2; the explicit shape flags below override it)")
+    ap.add_argument("--objects", type=int, default=None, help="object networks per GPU (c4: in total)")
+    ap.add_argument("--rays", type=int, default=None, help="rays per object per step")
+    ap.add_argument("--n-cam2surf", type=int, default=None)
+    ap.add_argument("--n-bins", type=int, default=None)
+    ap.add_argument("--hidden", type=int, default=None,
+                    help="hidden width of the object networks (32 = the fused kernels; other widths run the layer-wise "
+                         "path in object chunks)")
+    ap.add_argument("--feat", action="store_true", default=None,
+                    help="add the 512-d feature-distillation loss (cfg.part_mode)")
     ap.add_argument("--no-bg", dest="bg", action="store_false",
                     help="skip the shared background network.  Default (do_bg = 1, room_0.json:21): every step also "
-                         "trains it (hidden 128, n_per_optim_bg = 1200 rays split over the ranks, 64 samples/ray, "
+                         "trains it (hidden 128, n_per_optim_bg = 1200 rays split over the ranks, same samples per ray, "
                          "gradient all-reduce over RCCL), as train.py:447-463 does; `value` counts object rays only")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="f32 = the reference's arithmetic (default, the headline line).  bf16 = opt-in mode: MFMA "
@@ -117,8 +182,17 @@ def main():
     ap.add_argument("--no-bf16-line", dest="bf16_line", action="store_false",
                     help="do not also time the bf16 mode (reported as the `bf16_mode` object of the fp32 line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rays", type=int, default=192)
+    ap.add_argument("--no-psnr", action="store_true")
+    ap.add_argument("--psnr-seeds", type=int, default=64)
+    ap.add_argument("--no-peak", action="store_true", help="skip the saturated-MFMA measurement")
     args = ap.parse_args()
+
+    cfgname = args.config or "c2"
+    wl = dict(CONFIGS[cfgname])
+    for k_arg, k_wl in (("objects", "objects"), ("rays", "rays"), ("n_cam2surf", "n1"), ("n_bins", "n2"),
+                        ("hidden", "hidden"), ("feat", "feat")):
+        if getattr(args, k_arg) is not None:
+            wl[k_wl] = getattr(args, k_arg)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -133,26 +207,45 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    K, R, n1, n2 = args.objects, args.rays, args.n_cam2surf, args.n_bins
+    from openobj_amd import cfg as ocfg, dist as odist, trainer as otrainer, train as otrain
+    R, n1, n2, Hd, feat = wl["rays"], wl["n1"], wl["n2"], wl["hidden"], bool(wl["feat"])
     S = n1 + n2
-    Hd = args.hidden
+    if wl["scaling"] == "strong":                       # a fixed population of objects dealt to the ranks
+        lo, hi = odist.shard_objects(wl["objects"], world, rank)
+        K, K_total = hi - lo, wl["objects"]
+    else:
+        K, K_total = wl["objects"], wl["objects"] * world
+    bf16 = args.dtype == "bf16"
+
     arena = ops.ParamArena(K, ops.NetShape(Hd, 512, 6), dev)
     arena.load_stacked(obj_init.init_stacked(K, Hd, 512, seed=1000 + rank))
-    feat = bool(args.feat)
-    bf16 = args.dtype == "bf16"
-    ws = ops.TrainWorkspace(arena, K, R, S, feat)
-    m = torch.zeros_like(arena.params)
-    v = torch.zeros_like(arena.params)
-    mask = arena.has_grad_mask(feat)
     keys = ["pts", "z", "gt_depth", "gt_rgb", "labels"] + (["gt_feat"] if feat else [])
+    nb = 2 if Hd == 32 else 1       # resident batches, alternated so no step re-reads its own outputs
     batches = []
-    for i in range(2):      # two resident batches, alternated, so no step re-reads its own outputs
-        b = synthetic.random_batch(K, R, n1, n2, seed=4242 + 17 * rank + i, feat_dim=512 if feat else 0)
-        batches.append({k: torch.from_numpy(b[k]).to(dev) for k in keys})
-    gflags = torch.zeros(2, dtype=torch.int32, device=dev)
-    bg_loop = None
+    for i in range(nb):
+        src_k = K if Hd == 32 else min(K, 8)            # (the stress shape re-uses 8 objects' rays for its 64 networks)
+        b = synthetic.random_batch(src_k, R, n1, n2, seed=4242 + 17 * rank + i, feat_dim=512 if feat else 0)
+        reps = (K + src_k - 1) // src_k
+        batches.append({k: torch.from_numpy(b[k]).to(dev).repeat(reps, *([1] * (b[k].ndim - 1)))[:K].contiguous()
+                        for k in keys})
+
+    class ObjLoop:                  # the object stack of this rank: fused step + AdamW over the arena
+        def __init__(self):
+            self.ws = ops.TrainWorkspace(arena, K, R, S, feat)
+            self.m, self.v = torch.zeros_like(arena.params), torch.zeros_like(arena.params)
+            self.mask = arena.has_grad_mask(feat)
+            self.n = 0
+            self.bf16 = False
+
+        def step(self, batch, global_flags=None):
+            ops.train_step(arena, self.ws, batch, global_flags=global_flags, with_feat=feat, bf16=self.bf16)
+            self.n += 1
+            ops.adamw_step(arena, self.ws.grads, self.m, self.v, self.mask, self.n, 1e-3, 0.013)
+            return self.ws.loss_terms
+
+    obj_loop = ObjLoop()
+    bg_loop, bg_batches = None, [None, None]
     if args.bg:
-        from openobj_amd import cfg as ocfg, dist as odist, trainer as otrainer, train as otrain
         c = ocfg.Config(ocfg.replica_room0_config(train_device=str(dev)))
         c.obj_id, c.hidden_feature_size, c.obj_scale = 0, c.hidden_feature_size_bg, c.bg_scale
         torch.manual_seed(7)                               # identical replica on every rank
@@ -162,31 +255,18 @@ def main():
         for i in range(2):
             b = synthetic.random_batch(1, c.n_per_optim_bg, n1, n2, seed=777 + i, feat_dim=512 if feat else 0)
             bg_batches.append({k: torch.from_numpy(b[k][:, lo:hi]).contiguous().to(dev) for k in keys})
-
-    step_no = [0]
+    iteration = otrain.ShardedIteration(obj_loop, bg_loop)
 
     def step(i, use_bf16):
-        from openobj_amd import _lib
-        b = batches[i & 1]
-        if use_dist:
-            # the early return of render_rays.py:89-94 spans every object of the batch -> global flags
-            _lib.check(_lib.lib().objnerf_label_counts(K, R, b["labels"].data_ptr(), ws.counts.data_ptr(),
-                                                      gflags.data_ptr(), torch.cuda.current_stream().cuda_stream),
-                       "label_counts")
-            dist.all_reduce(gflags, op=dist.ReduceOp.MAX)
-            ops.train_step(arena, ws, b, global_flags=gflags, with_feat=feat, bf16=use_bf16)
-        else:
-            ops.train_step(arena, ws, b, with_feat=feat, bf16=use_bf16)
-        step_no[0] += 1
-        ops.adamw_step(arena, ws.grads, m, v, mask, step_no[0], 1e-3, 0.013)
+        obj_loop.bf16 = use_bf16
         if bg_loop is not None:
             bg_loop.bf16 = use_bf16              # the mode applies to the whole step
-            bg_loop.step(bg_batches[i & 1])
+        iteration.step(batches[i % nb], bg_batches[i & 1])
 
     def timed(use_bf16):
-        """W warm-up steps, then exactly K steps between barrier + synchronize; max over ranks.  Then the
-        dominant kernel alone: HIP events on the launch stream around objnerf_train_step (fused kernel +
-        finalize; the finalize is <1 % of it)."""
+        """W warm-up steps, then exactly K steps between barrier + synchronize; max over ranks.  Then the dominant
+        kernel alone: HIP events on the launch stream (torch's current stream, which the C ABI is handed) around
+        objnerf_train_step = fused kernel + its slab reduction (the reduction is < 1 % of it)."""
         for i in range(args.warmup):
             step(i, use_bf16)
         torch.cuda.synchronize()
@@ -207,60 +287,86 @@ def main():
             dt_ = float(tt.item())
         ev0 = torch.cuda.Event(enable_timing=True)
         ev1 = torch.cuda.Event(enable_timing=True)
-        nk = max(5, min(args.steps, 20))
+        nk = max(3, min(args.steps, 20))
         ev0.record()
         for i in range(nk):
-            ops.train_step(arena, ws, batches[i & 1], with_feat=feat, bf16=use_bf16)
+            ops.train_step(arena, obj_loop.ws, batches[i % nb], with_feat=feat, bf16=use_bf16)
         ev1.record()
         torch.cuda.synchronize()
         return dt_, ev0.elapsed_time(ev1) / nk
 
     dt, kern_ms = timed(bf16)
-    status = int(ws.status.item())
+    status = int(obj_loop.ws.status.item())
     # the opt-in bf16-operand mode beside the fp32 headline (same step, same batches)
     bf16_extra = None
     if not bf16 and args.bf16_line:
-        bdt, bk = timed(True)
-        bf16_extra = (bdt, bk)
+        bf16_extra = timed(True)
 
     if rank == 0:
-        rays_per_step = K * R * world
+        rays_per_step = K_total * R if wl["scaling"] == "strong" else K * R * world
         value = rays_per_step * args.steps / dt
         fpr = flop_per_ray(S, H=Hd, feat=feat)
+        fused = Hd == 32 and S <= 64
+        k32 = "train_fused_kernel<true, false>" if feat else ("train_fused32_kernel<false, 64>" if S == 64
+                                                               else "train_fused32_kernel<false, 0>")
+        kbf = f"train_fused_bf16_kernel<{'true' if feat else 'false'}>"
+        kname = (kbf if bf16 else k32) if fused else "objnerf_train_step, layer-wise path (batched MFMA GEMMs)"
         achieved = K * R * fpr / (kern_ms * 1e-3) / 1e12
         peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
-        kname = (f"train_fused_bf16_kernel<{'true' if feat else 'false'}>" if bf16 else ("train_fused_kernel<true, false>" if feat else "train_fused32_kernel<false>"))
-        if Hd != 32 or S > 64:
-            kname = "objnerf_train_step, layer-wise path (batched MFMA GEMMs)"
+        rec = recorded_counters(kname, K, R, S)
+        roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                "traffic": rec["hbm_bytes_per_launch"] if rec else None,
+                "traffic_note": ("RECORDED, not measured by this run: " + rec["source"]) if rec else
+                                "no recorded PMC pass for this workload",
+                "kernel": kname, "kernel_ms": kern_ms, "flop_per_ray": fpr,
+                "algorithmic_bytes_per_launch": K * R * (S * 16 + 17 + (2048 * 2 if feat else 0))}
+        if not args.no_peak:
+            pm = measured_mfma_peak(dev, 1 if bf16 else 0)
+            roof["peak_measured"] = pm
+            roof["frac_of_measured_peak"] = achieved / pm
         out = {
             "metric": "training rays/sec/GPU @64 samples/ray, 50 obj; PSNR delta vs ref",
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": wl["scaling"],
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"Replica room_0-shaped, {K} object MLPs/GPU (hidden {Hd}), {R} rays/object/step, "
-                                   f"{S} samples/ray ({n1}+{n2}), RGB+depth+opacity"
+            "config": {"workload": f"{cfgname}: Replica room_0-shaped, {K} object MLPs on this GPU"
+                                   f"{' of %d in total' % K_total if wl['scaling'] == 'strong' else ''} (hidden {Hd}), "
+                                   f"{R} rays/object/step, {S} samples/ray ({n1}+{n2}), RGB+depth+opacity"
                                    f"{'+512-d feature' if feat else ''} loss, fused fwd+loss+bwd+AdamW",
-                       "objects_per_gpu": K, "rays_per_object": R, "samples_per_ray": S, "hidden": Hd,
-                       "feature_head": feat, "background_mlp": bool(args.bg), "parallelism": f"objects sharded x{world}",
+                       "objects_per_gpu": K, "objects_total": K_total, "rays_per_object": R, "samples_per_ray": S,
+                       "hidden": Hd, "feature_head": feat, "background_mlp": bool(args.bg),
+                       "parallelism": f"objects sharded x{world}", "collectives_per_step": 2 if use_dist else 0,
                        "loss_status": status},
             "rays_per_sec_per_gpu": value / world,
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": measured_traffic(K, R, S, feat, args.dtype),
-                         "traffic_unit": "bytes/launch (PMC, profiles/r01_traffic_v5.json)",
-                         "kernel": kname, "kernel_ms": kern_ms,
-                         "flop_per_ray": fpr},
+            "roofline": roof,
         }
         if bf16_extra is not None:
             bdt, bk = bf16_extra
+            bkname = kbf if fused else "layer-wise path, bf16-operand GEMMs"
+            mf = K * R * fpr / (bk * 1e-3) / 1e12
+            brec = recorded_counters(bkname, K, R, S)
+            broof = {"bound": "valu", "unit": "wave instructions", "kernel": bkname, "kernel_ms": bk,
+                     "mfma_tflops": mf, "frac_of_bf16_mfma_peak": mf / PEAK_BF16_MFMA_TFLOPS}
+            if brec:
+                floor_ms = brec["valu_insts_per_launch"] * VALU_CYCLES_PER_INST / (VALU_SIMDS * CLOCK_HZ) * 1e3
+                broof.update({"valu_insts_per_launch": brec["valu_insts_per_launch"],
+                              "valu_insts_per_sample": brec["valu_insts_per_launch"] * 64.0 / (K * R * S),
+                              "valu_floor_ms": floor_ms, "frac": floor_ms / bk,
+                              "note": "VALU issue floor = wave instructions x 2 cycles / (1024 SIMDs x 2.4 GHz); "
+                                      "instruction count RECORDED: " + brec["source"]})
             out["bf16_mode"] = {"value": rays_per_step * args.steps / bdt, "unit": "rays/s",
-                                "ms_per_step": bdt / args.steps * 1e3,
-                                "kernel": (f"train_fused_bf16_kernel<{'true' if feat else 'false'}>" if Hd == 32 and S <= 64
-                                           else "layer-wise path, bf16-operand GEMMs"),
-                                "kernel_ms": bk, "mfma_tflops": K * R * fpr / (bk * 1e-3) / 1e12,
+                                "ms_per_step": bdt / args.steps * 1e3, "roofline": broof,
                                 "note": "OBJNERF_TRAIN_BF16: bf16 MFMA operands, fp32 accumulate / master weights / "
                                         "compositing / AdamW; PSNR-gated (tests/test_bf16_gpu.py), not 1e-4 parity"}
+        if world == 1 and not args.no_psnr and Hd == 32:
+            ps = psnr_block(dev, args.psnr_seeds, with_bf16=args.bf16_line or bf16)
+            if ps is not None:
+                out["psnr"] = ps
+                key = "bf16" if bf16 else "f32"
+                out["psnr_delta_db"] = ps[key]["delta_db"]
+                out["psnr_delta_ci95_db"] = ps[key]["ci95_db"]
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(K, args.cpu_rays, n1, n2, seed=4242, feat=feat)
+            out["cpu_baseline"] = cpu_baseline(feat)
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

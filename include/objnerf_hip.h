@@ -165,6 +165,14 @@ int objnerf_mlp_forward(const objnerf_net* net, int32_t K, int64_t N, const floa
                         int64_t p_stride, const float* emb, float* out_alpha, float* out_color,
                         float* out_hfeat, float* out_clip, void* stream);
 
+/* The same for any hidden width that is a multiple of 32 (the reference calls scene_bg.trainer.fc_occ_map(bg_embedding)
+ * on the 128-wide background network, train.py:449-450): hidden 32 runs the fused kernel and needs no workspace, wider
+ * networks the layer-wise chain with objnerf_eval_workspace_bytes(net, K, N) bytes of caller workspace. */
+int objnerf_mlp_forward_ws(const objnerf_net* net, int32_t K, int64_t N, const float* params,
+                           int64_t p_stride, const float* emb, float* out_alpha, float* out_color,
+                           float* out_hfeat, float* out_clip, void* workspace, size_t workspace_bytes,
+                           void* stream);
+
 /* A6 alone: emb [K][N][3+21*n_freqs]. */
 int objnerf_embed(const objnerf_net* net, int32_t K, int64_t N, const float* params,
                   int64_t p_stride, const float* scale, const float* pts, float* out_emb,
@@ -182,6 +190,11 @@ int objnerf_composite(int64_t n_rays, int32_t S, int32_t flags, const float* alp
                       const float* z, const float* vals, int32_t V, float* out_term,
                       float* out_depth, float* out_var, float* out_rgb, float* out_opacity,
                       float* out_vals, void* stream);
+
+/* Measurement support (bench.py `roofline.peak_measured`; nothing in the reference): a saturated-MFMA loop, n_wg
+ * workgroups of 4 waves x iters x 4 MFMAs; dtype 0: v_mfma_f32_16x16x4_f32 (2048 FLOP each), 1: v_mfma_f32_16x16x32_bf16
+ * (16384 FLOP each).  sink: n_wg * 256 floats. */
+int objnerf_mfma_peak(int32_t dtype, int32_t iters, int32_t n_wg, float* sink, void* stream);
 
 /* A8 alone: occupancy_activation(alpha) = sigmoid(alpha), n elements (render_rays.py:6-14). */
 int objnerf_occupancy(int64_t n, const float* alpha, float* out, void* stream);
@@ -275,6 +288,40 @@ int objnerf_adamw_step(int32_t K, int64_t P, int64_t p_stride, float* params, co
                        float* exp_avg, float* exp_avg_sq, const uint8_t* has_grad, int32_t step,
                        float lr, float beta1, float beta2, float eps, float weight_decay,
                        void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Helper functions of the reference's call surface that a caller may use outside the fused iteration
+ * (objnerf_helpers.hip).  All take / return device pointers; small HBM-bound kernels.
+ */
+/* render_rays.render_loss (render_rays.py:65-83).  mode 0 "L1": |render - gt|, 1 "L2": squared, n elements;
+ * mode 2 "cos": 1 - cosine_similarity over rows of C entries (norms clamped at 1e-8), n rows.  normalise: / gt. */
+int objnerf_render_loss(int64_t n, int32_t C, int32_t mode, int32_t normalise, const float* render, const float* gt,
+                        float* out, void* stream);
+/* render_rays.reduce_batch_loss (render_rays.py:85-117): loss_mat [K][R], var [K][R] or NULL (information weight
+ * 1 / (sqrt(var) + 1e-4), or 1 / (var + 1e-4) with l2), mask [K][R] u8.  avg: out [K] = masked means, all zero when
+ * ANY object's mask is empty (:89-94); status bit 0 set when a mean exceeds 1e5 (:109-111, the reference exits).
+ * avg == 0: out [K][R] = the weighted matrix.  counts_ws: K + 1 ints of scratch. */
+int objnerf_reduce_batch_loss(int32_t K, int32_t R, const float* loss_mat, const float* var, const uint8_t* mask,
+                              int32_t l2, int32_t avg, int32_t* counts_ws, float* out, int32_t* status, void* stream);
+/* render_rays.make_3D_grid (render_rays.py:119-146): out [dim][dim][dim][3] = lattice on [lo, hi]^3, optionally
+ * scaled per axis (scale [3]) and moved by transform [4][4] (row-major). */
+int objnerf_make_grid(int32_t dim, float lo, float hi, const float* scale, const float* transform, float* out,
+                      void* stream);
+/* utils.ray_box_intersection (utils.py:309-319): n rays against the axis-aligned box [bmin, bmax] ([3] each). */
+int objnerf_ray_box(int64_t n, const float* origins, const float* dirs, const float* bmin, const float* bmax,
+                    float* out_near, float* out_far, uint8_t* out_hit, void* stream);
+/* utils.origin_dirs_W (utils.py:324-336): out_dirs_W [F][P][3] = R_wc[f] dirs_C[f][p]  (T_WC [F][4][4]; the
+ * origins are T_WC[:, :3, 3], a view on the caller's side). */
+int objnerf_dirs_w(int64_t F, int64_t P, const float* T_WC, const float* dirs_C, float* out_dirs_W, void* stream);
+/* utils.stratified_bins (utils.py:342-379): out [n_rays][n_bins] = lo + range * i / n + U * range / n; lo / hi per
+ * ray or NULL (then the scalar); U = u [n_rays][n_bins] (injected draws) or, with u == NULL, the counter-based
+ * generator of objnerf_philox.h under (seed, offset). */
+int objnerf_stratified_bins(int64_t n_rays, int32_t n_bins, const float* lo, float lo_scalar, const float* hi,
+                            float hi_scalar, const float* u, uint64_t seed, uint64_t offset, float* out, void* stream);
+/* utils.normal_bins_sampling (utils.py:382-397): out [n_rays][n_bins] = depth + clip(sort(N(0, (delta/3)^2)), +-delta);
+ * g = injected draws (already scaled) or NULL for the counter-based generator. */
+int objnerf_normal_bins(int64_t n_rays, int32_t n_bins, const float* depth, float delta, const float* g, uint64_t seed,
+                        uint64_t offset, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -104,9 +104,25 @@ SIGNATURES = {
     "objnerf_mlp_forward": (C.c_int, [C.POINTER(Net), C.c_int32, C.c_int64, C.c_void_p, C.c_int64,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p]),
+    "objnerf_mlp_forward_ws": (C.c_int, [C.POINTER(Net), C.c_int32, C.c_int64, C.c_void_p, C.c_int64,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_size_t, C.c_void_p]),
     "objnerf_embed": (C.c_int, [C.POINTER(Net), C.c_int32, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                 C.c_void_p, C.c_void_p, C.c_void_p]),
     "objnerf_occupancy": (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "objnerf_render_loss": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p]),
+    "objnerf_reduce_batch_loss": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "objnerf_make_grid": (C.c_int, [C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "objnerf_ray_box": (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p]),
+    "objnerf_dirs_w": (C.c_int, [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "objnerf_stratified_bins": (C.c_int, [C.c_int64, C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p,
+                                          C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "objnerf_normal_bins": (C.c_int, [C.c_int64, C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_uint64, C.c_uint64,
+                                      C.c_void_p, C.c_void_p]),
+    "objnerf_mfma_peak": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "objnerf_composite": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p]),

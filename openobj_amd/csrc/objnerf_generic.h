@@ -27,7 +27,8 @@ void gemm_f32(void* stream, int batch, int M, int N, int Kd, const float* A, lon
 void wgrad_f32(void* stream, int batch, int M, int N, long n, const float* A, long sam, long sak, long bsa, const float* B,
                long sbk, long sbn, long bsb, float* C, long scm, long bsc);
 size_t eval_workspace_bytes(const objnerf_net* net, int K, long N);
+// pts == NULL: emb_in [K][N][129] is the embedding (OccupancyMap.forward on a caller-supplied tensor)
 int eval_points(const objnerf_net* net, int K, long N, const float* params, long p_stride, const float* scale,
                 const float* pts, float* out_alpha, float* out_color, float* out_hfeat, float* out_clip,
-                void* workspace, size_t workspace_bytes, void* stream);
+                void* workspace, size_t workspace_bytes, void* stream, const float* emb_in = nullptr);
 }

@@ -1389,7 +1389,7 @@ size_t eval_workspace_bytes(const objnerf_net* net, int K, long N) {
 
 int eval_points(const objnerf_net* net, int K, long N, const float* params, long p_stride, const float* scale,
                 const float* pts, float* out_alpha, float* out_color, float* out_hfeat, float* out_clip,
-                void* workspace, size_t workspace_bytes, void* stream) {
+                void* workspace, size_t workspace_bytes, void* stream, const float* emb_in) {
   const int H = net->hidden, C = net->feat_dim;
   if (H % 32 != 0 || net->n_freqs != 6) return OBJNERF_ENOTSUP;
   if (!workspace || workspace_bytes < eval_workspace_bytes(net, K, N) - 256) return OBJNERF_EINVAL;
@@ -1397,15 +1397,19 @@ int eval_points(const objnerf_net* net, int K, long N, const float* params, long
   objnerf_param_layout(net, off);
   hipStream_t st = (hipStream_t)stream;
   char* p = (char*)workspace;
-  float* emb = (float*)p; p += al((size_t)K * N * OBJ_EMB * 4);
+  float* emb_ws = (float*)p; p += al((size_t)K * N * OBJ_EMB * 4);
   float* bA = (float*)p;  p += al((size_t)K * N * H * 4);
   float* bB = (float*)p;  p += al((size_t)K * N * H * 4);
   float* bC = (float*)p;
   const float* P = params;
   const long ps = p_stride, n = N, nH = N * H;
   const int E1 = OBJ_E1, E2 = OBJ_E2, EM = OBJ_EMB;
-  int rc = objnerf_embed(net, K, N, params, p_stride, scale, pts, emb, stream);
-  if (rc) return rc;
+  const float* emb = emb_in;
+  if (!emb_in) {
+    int rc = objnerf_embed(net, K, N, params, p_stride, scale, pts, emb_ws, stream);
+    if (rc) return rc;
+    emb = emb_ws;
+  }
   float *h1 = bA, *h2 = bB, *h3 = bA, *h4 = bB, *hc = bA;
   gemm(st, K, n, H, E1, emb, EM, 1, n * EM, P + off[0], 1, E1, ps, h1, H, 1, nH, false, P + off[1], ps, true);
   gemm(st, K, n, H, H, h1, H, 1, nH, P + off[2], 1, H, ps, h2, H, 1, nH, false, P + off[3], ps, true);

@@ -616,6 +616,36 @@ int step_batch_loss_impl(const objnerf_loss_args* a, const LossHoisted* hz, void
 }
 }  // namespace objmisc
 
+// Saturated-MFMA loop for bench.py's `roofline.peak_measured`: 256-thread workgroups (one wave per SIMD), four
+// independent 16x16 accumulators, operands in registers, lane-dependent non-trivial data (the clock the chip holds
+// depends on the operands: MI355X_MICROARCH.md, DVFS give-back).  DT 0: v_mfma_f32_16x16x4_f32, 1: v_mfma_f32_16x16x32_bf16.
+template <int DT>
+__global__ __launch_bounds__(256) void mfma_peak_kernel(int iters, float* sink) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+  const int lane = threadIdx.x & 63;
+  f4 a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+  const float av = 0.37f + 0.011f * lane, bv = -0.52f + 0.007f * (lane ^ 21);
+  bf8 ab, bb;
+  for (int i = 0; i < 8; ++i) { ab[i] = (__bf16)(av + 0.05f * i); bb[i] = (__bf16)(bv - 0.03f * i); }
+  for (int i = 0; i < iters; ++i) {
+    if (DT == 0) {
+      a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av, a1, 0, 0, 0);
+      a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, av, a2, 0, 0, 0);
+      a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, bv, a3, 0, 0, 0);
+    } else {
+      a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, bb, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bb, ab, a1, 0, 0, 0);
+      a2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, ab, a2, 0, 0, 0);
+      a3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bb, bb, a3, 0, 0, 0);
+    }
+    // keep the accumulators bounded without leaving the MFMA-only regime: rescale once in a while
+    if ((i & 63) == 63) { a0 *= 1e-3f; a1 *= 1e-3f; a2 *= 1e-3f; a3 *= 1e-3f; }
+  }
+  sink[blockIdx.x * 256 + threadIdx.x] = a0[0] + a1[1] + a2[2] + a3[3];
+}
+
 extern "C" {
 
 int objnerf_composite(int64_t n_rays, int32_t S, int32_t flags, const float* alpha, const float* color,
@@ -628,6 +658,15 @@ int objnerf_composite(int64_t n_rays, int32_t S, int32_t flags, const float* alp
   hipLaunchKernelGGL(composite_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), (size_t)4 * S * 4,
                      (hipStream_t)stream, (long)n_rays, S, (int)(flags & OBJNERF_COMPOSITE_INPUT_IS_OCCUPANCY), alpha,
                      color, z, vals, V, out_term, out_depth, out_var, out_rgb, out_opacity, out_vals);
+  CHECK_LAUNCH();
+  return OBJNERF_OK;
+}
+
+int objnerf_mfma_peak(int32_t dtype, int32_t iters, int32_t n_wg, float* sink, void* stream) {
+  CLEAR_STALE();
+  if (!sink || iters <= 0 || n_wg <= 0 || (dtype != 0 && dtype != 1)) return OBJNERF_EINVAL;
+  if (dtype == 0) hipLaunchKernelGGL(mfma_peak_kernel<0>, dim3(n_wg), dim3(256), 0, (hipStream_t)stream, iters, sink);
+  else hipLaunchKernelGGL(mfma_peak_kernel<1>, dim3(n_wg), dim3(256), 0, (hipStream_t)stream, iters, sink);
   CHECK_LAUNCH();
   return OBJNERF_OK;
 }

@@ -1195,4 +1195,15 @@ int objnerf_mlp_forward(const objnerf_net* net, int32_t K, int64_t N, const floa
                      stream);
 }
 
+int objnerf_mlp_forward_ws(const objnerf_net* net, int32_t K, int64_t N, const float* params, int64_t p_stride,
+                           const float* emb, float* out_alpha, float* out_color, float* out_hfeat, float* out_clip,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+  (void)hipGetLastError();
+  if (!net || !params || !emb || !out_alpha || !out_color || K <= 0 || N <= 0) return OBJNERF_EINVAL;
+  if (net->hidden == 32)
+    return objnerf_mlp_forward(net, K, N, params, p_stride, emb, out_alpha, out_color, out_hfeat, out_clip, stream);
+  return objgen::eval_points(net, K, (long)N, params, (long)p_stride, nullptr, nullptr, out_alpha, out_color, out_hfeat,
+                             out_clip, workspace, workspace_bytes, stream, emb);
+}
+
 }  // extern "C"

@@ -84,7 +84,9 @@ constexpr int LDS_FLOATS32 = IMG + SM_FLOATS + STG_ROWS * STG_LD;
 static_assert(LDS_FLOATS32 * 4 <= 163840, "LDS budget");
 static_assert((IMG * 4) % 16 == 0, "staging area alignment");
 
-template <bool MASKS>
+// SS: samples per ray when known at compile time (64 = the metric shape: no integer divisions by S, only the row-scan
+// compositing is compiled in), 0 = any S <= 64 at run time.
+template <bool MASKS, int SS>
 __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
   __syncthreads();
 
   const float scale = a.scale[k];
-  const int S = a.S, R = a.R, TR = a.TR;
+  const int S = SS ? SS : a.S, R = a.R, TR = SS ? TS / SS : a.TR;
   const float n1 = (float)a.counts[2 * k], n2 = (float)a.counts[2 * k + 1];
   const float inv1 = a.flags[0] ? 0.0f : 1.0f / (n1 + 1e-10f);
   const float inv2 = a.flags[1] ? 0.0f : 1.0f / (n2 + 1e-10f);
@@ -148,16 +150,16 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
   // sample position of (tile, slot); issued one tile ahead (phase C) so that the HBM latency is off the tile's
   // critical path
   auto fetch_point = [&](const int tile_, const int slot_, float& x, float& y, float& z_) {
-    const int q_ = slot_ / a.S, si_ = slot_ - q_ * a.S;
-    const int ray_ = tile_ * a.TR + q_;
+    const int q_ = slot_ / S, si_ = slot_ - q_ * S;
+    const int ray_ = tile_ * TR + q_;
     x = 0.f; y = 0.f; z_ = 0.f;
-    if (tile_ < a.NT && q_ < a.TR && ray_ < a.R) {
+    if (tile_ < a.NT && q_ < TR && ray_ < a.R) {
       const long rr = (long)k * a.R + ray_;
       if (a.pts) {
-        const float* p = a.pts + (rr * a.S + si_) * 3;
+        const float* p = a.pts + (rr * S + si_) * 3;
         x = p[0]; y = p[1]; z_ = p[2];
       } else {
-        const float zz = a.z[rr * a.S + si_];
+        const float zz = a.z[rr * S + si_];
         const float* o = a.origins + rr * 3;
         const float* d = a.dirs + rr * 3;
         x = (o[0] + d[0] * zz) - a.obj_center;   // vmap.py:548-551 (two roundings: -ffp-contract=off)
@@ -166,8 +168,8 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
       }
     }
   };
-  const bool rows_mode = seg_is_rows(a.S);
-  const SegRows seg_rows = SegRows::make(rows_mode ? a.S : 64, lane);
+  const bool rows_mode = SS ? true : seg_is_rows(S);
+  const SegRows seg_rows = SegRows::make(rows_mode ? S : 64, lane);
   const int slot = 16 * w + c;
   float nx, ny, nz;
   fetch_point(gi, slot, nx, ny, nz);
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
         }
       }
     };
-    if (rows_mode) composite_passes(seg_rows); else composite_passes(SegGeneric{S});
+    if (SS || rows_mode) composite_passes(seg_rows); else composite_passes(SegGeneric{S});
     PT(4);
     __syncthreads();
     PT(5);
@@ -535,15 +537,16 @@ size_t fused32_lds_bytes() { return (size_t)LDS_FLOATS32 * 4; }
 void launch_train32(const TrainDev& d, void* stream) {
   static std::once_flag attr;
   std::call_once(attr, [] {
-    (void)hipFuncSetAttribute((const void*)train_fused32_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)fused32_lds_bytes());
-    (void)hipFuncSetAttribute((const void*)train_fused32_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)fused32_lds_bytes());
+    const int n = (int)fused32_lds_bytes();
+    (void)hipFuncSetAttribute((const void*)train_fused32_kernel<false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
+    (void)hipFuncSetAttribute((const void*)train_fused32_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
+    (void)hipFuncSetAttribute((const void*)train_fused32_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
   });
-  if (d.relu_masks)
-    hipLaunchKernelGGL(train_fused32_kernel<true>, dim3(d.K * d.G), dim3(NTHR), fused32_lds_bytes(), (hipStream_t)stream, d);
-  else
-    hipLaunchKernelGGL(train_fused32_kernel<false>, dim3(d.K * d.G), dim3(NTHR), fused32_lds_bytes(), (hipStream_t)stream, d);
+  const dim3 grid(d.K * d.G), blk(NTHR);
+  hipStream_t st = (hipStream_t)stream;
+  if (d.relu_masks) hipLaunchKernelGGL((train_fused32_kernel<true, 0>), grid, blk, fused32_lds_bytes(), st, d);
+  else if (d.S == 64) hipLaunchKernelGGL((train_fused32_kernel<false, 64>), grid, blk, fused32_lds_bytes(), st, d);
+  else hipLaunchKernelGGL((train_fused32_kernel<false, 0>), grid, blk, fused32_lds_bytes(), st, d);
 }
 
 }  // namespace objtrain

@@ -209,38 +209,48 @@ class IncrementalMapper:
             pool = {k: v.reshape(v.shape[0], cfg.n_iter_per_frame, npo, *v.shape[2:]).transpose(0, 1).contiguous()
                     for k, v in pool.items()}
         sharded = odist._active(self.group)
-        gflags = torch.zeros(2, dtype=torch.int32, device=cfg.training_device) if sharded else None
         # The object stack and the background network are independent chains (own parameters, optimiser state and
-        # batches): on one GPU the background steps run on a second stream beside the fused object kernel.
+        # batches).  On one GPU the background steps run on a second stream beside the fused object kernel; under
+        # object sharding train.ShardedIteration orders them around the iteration's two collectives (the background
+        # gradient's all-reduce is in flight under the object kernel).
         side = None
         if bg_pool is not None and pool is not None and not sharded and torch.device(cfg.training_device).type == "cuda":
             if self._side is None:
                 self._side = torch.cuda.Stream(device=cfg.training_device)
             side = self._side
             side.wait_stream(torch.cuda.current_stream(cfg.training_device))
+        sharded_it = otrain.ShardedIteration(self.loop if pool is not None else None, self.bg_loop, self.group) if sharded else None
         for it in range(cfg.n_iter_per_frame):
-            batch = None
-            if pool is not None:
-                batch = {k: v[it] for k, v in pool.items()}
+            batch = {k: v[it] for k, v in pool.items()} if pool is not None else None
+            bs = slice(it * npo_bg, (it + 1) * npo_bg)
+            bg_slice = (lambda: {k: v[:, bs].contiguous() for k, v in bg_pool.items()}) if bg_pool is not None else None
             if sharded:
-                # render_rays.py:89-94: one empty mask anywhere in the stacked batch zeroes that term for ALL objects
-                if batch is not None:
-                    gflags.copy_(ops.label_counts(batch["labels"])[1])
-                else:
-                    gflags.zero_()
-                odist.global_flags(gflags, self.group)
+                ot, bt = sharded_it.step(batch, bg_slice() if bg_slice is not None else None)
+                if ot is not None:
+                    out["obj"].append(ot.clone())
+                if bt is not None:
+                    out["bg"].append(bt.clone())
+                continue
             if batch is not None:
-                out["obj"].append(self.loop.step(batch, global_flags=gflags).clone())
-            if bg_pool is not None:
-                bs = slice(it * npo_bg, (it + 1) * npo_bg)
+                out["obj"].append(self.loop.step(batch).clone())
+            if bg_slice is not None:
                 with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
-                    out["bg"].append(self.bg_loop.step({k: v[:, bs].contiguous() for k, v in bg_pool.items()}).clone())
+                    out["bg"].append(self.bg_loop.step(bg_slice()).clone())       # (the slice copies run on `side` too)
         if side is not None:
             torch.cuda.current_stream(cfg.training_device).wait_stream(side)
+        # render_rays.py:109-111 ("loss explode" -> exit): every rank must leave together, so the status is MAX-reduced
+        # before anyone raises (a rank-local raise would leave the others hanging in their next collective)
+        status = torch.zeros(1, dtype=torch.int32, device=cfg.training_device)
+        if self.loop is not None and self.loop.ws is not None:
+            status = torch.maximum(status, self.loop.ws.status)
+        if self.bg_loop is not None and self.bg_loop.ws is not None:
+            status = torch.maximum(status, self.bg_loop.ws.status)
+        if sharded:
+            odist.allreduce_max_(status, self.group)
+        if int(status.item()) != 0:
+            from .render_rays import LossExplode
+            raise LossExplode("loss explode")
         if self.loop is not None:
-            if int(self.loop.ws.status.item()) != 0:
-                from .render_rays import LossExplode
-                raise LossExplode("loss explode")
             self.loop.copy_back()
         return out
 

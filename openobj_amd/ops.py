@@ -163,8 +163,11 @@ def mlp_forward(arena: ParamArena, emb: torch.Tensor, want_hfeat: bool = False, 
     hfeat = torch.empty(K, N, arena.net.hidden, device=dev) if (want_hfeat or want_clip) else None
     clip = torch.empty(K, N, arena.net.feat_dim, device=dev) if want_clip else None
     net = arena.net.c()
-    check(lib().objnerf_mlp_forward(C.byref(net), K, N, _ptr(arena.params), arena.p_stride, _ptr(emb), _ptr(alpha),
-                                    _ptr(color), _ptr(hfeat), _ptr(clip), _stream()), "objnerf_mlp_forward")
+    nbytes = int(lib().objnerf_eval_workspace_bytes(C.byref(net), K, N))      # 0 for hidden 32 (fused kernel)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev) if nbytes else None
+    check(lib().objnerf_mlp_forward_ws(C.byref(net), K, N, _ptr(arena.params), arena.p_stride, _ptr(emb), _ptr(alpha),
+                                       _ptr(color), _ptr(hfeat), _ptr(clip), _ptr(ws), nbytes, _stream()),
+          "objnerf_mlp_forward_ws")
     return alpha, color, hfeat, clip
 
 
@@ -484,3 +487,105 @@ def sample_rays(rgbs_batch, depth_batch, t_wc_batch, bbox, rays_dir_cache, kf_id
                    _ptr(out_valid), _ptr(out_labels), _ptr(out_z), _ptr(out_pts), _ptr(ws))
     check(lib().objnerf_sample_rays(C.byref(a), _stream()), "objnerf_sample_rays")
     return out_rgb, out_depth, out_valid.bool(), out_labels, out_pts, out_z
+
+
+# ------------------------------------------------------------------------------------------------
+# helper functions of the reference's call surface (objnerf_helpers.hip)
+# ------------------------------------------------------------------------------------------------
+def render_loss(render: torch.Tensor, gt: torch.Tensor, mode: int, normalise: bool = False) -> torch.Tensor:
+    """render_rays.render_loss: mode 0 L1, 1 L2 (elementwise, any shape); 2 cos (over the last axis)."""
+    render = _req(render, torch.float32, "render")
+    gt = _req(gt.expand_as(render) if gt.shape != render.shape else gt, torch.float32, "gt")
+    if mode == 2:
+        Cdim = render.shape[-1]
+        out = torch.empty(render.shape[:-1], device=render.device)
+        n = out.numel()
+    else:
+        Cdim, out = 1, torch.empty_like(render)
+        n = out.numel()
+    if n:
+        check(lib().objnerf_render_loss(n, Cdim, mode, int(normalise), _ptr(render), _ptr(gt), _ptr(out), _stream()),
+              "objnerf_render_loss")
+    return out
+
+
+def reduce_batch_loss(loss_mat: torch.Tensor, var, mask: torch.Tensor, l2: bool, avg: bool):
+    """render_rays.reduce_batch_loss on [K,R] tensors -> (out [K] or [K,R], status int32[1])."""
+    loss_mat = _req(loss_mat, torch.float32, "loss_mat")
+    K, R = loss_mat.shape
+    var = _req(var, torch.float32, "var") if var is not None else None
+    mask = _req(mask.to(torch.uint8), torch.uint8, "mask")
+    dev = loss_mat.device
+    out = torch.empty(K if avg else (K, R), device=dev) if avg else torch.empty(K, R, device=dev)
+    ws = torch.empty(K + 1, dtype=torch.int32, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    check(lib().objnerf_reduce_batch_loss(K, R, _ptr(loss_mat), _ptr(var), _ptr(mask), int(l2), int(avg), _ptr(ws), _ptr(out),
+                                          _ptr(status), _stream()), "objnerf_reduce_batch_loss")
+    return out, status
+
+
+def make_grid(dim: int, lo: float, hi: float, scale, transform, device) -> torch.Tensor:
+    out = torch.empty(dim, dim, dim, 3, device=device)
+    scale = _req(scale.to(device).float().reshape(3), torch.float32, "scale") if scale is not None else None
+    transform = _req(transform.to(device).float().reshape(4, 4), torch.float32, "transform") if transform is not None else None
+    check(lib().objnerf_make_grid(dim, float(lo), float(hi), _ptr(scale), _ptr(transform), _ptr(out), _stream()),
+          "objnerf_make_grid")
+    return out
+
+
+def ray_box(origins, directions, bounds_min, bounds_max):
+    origins = _req(origins, torch.float32, "origins")
+    directions = _req(directions, torch.float32, "directions")
+    n, dev = origins.shape[0], origins.device
+    bmin = _req(torch.as_tensor(bounds_min, dtype=torch.float32, device=dev).reshape(3), torch.float32, "bounds_min")
+    bmax = _req(torch.as_tensor(bounds_max, dtype=torch.float32, device=dev).reshape(3), torch.float32, "bounds_max")
+    near, far = torch.empty(n, device=dev), torch.empty(n, device=dev)
+    hit = torch.empty(n, dtype=torch.uint8, device=dev)
+    check(lib().objnerf_ray_box(n, _ptr(origins), _ptr(directions), _ptr(bmin), _ptr(bmax), _ptr(near), _ptr(far), _ptr(hit),
+                                _stream()), "objnerf_ray_box")
+    return near, far, hit.bool()
+
+
+def dirs_w(T_WC: torch.Tensor, dirs_C: torch.Tensor) -> torch.Tensor:
+    T_WC = _req(T_WC, torch.float32, "T_WC")
+    dirs_C = _req(dirs_C, torch.float32, "dirs_C")
+    F = T_WC.shape[0]
+    P = dirs_C.numel() // (3 * F)
+    out = torch.empty_like(dirs_C)
+    check(lib().objnerf_dirs_w(F, P, _ptr(T_WC), _ptr(dirs_C), _ptr(out), _stream()), "objnerf_dirs_w")
+    return out
+
+
+_draw_offset = [0]
+
+
+def _next_offset() -> int:
+    _draw_offset[0] += 1
+    return _draw_offset[0]
+
+
+def stratified_bins(lo, hi, n_bins: int, n_rays: int, device, u: Optional[torch.Tensor] = None,
+                    seed: Optional[int] = None) -> torch.Tensor:
+    """lo / hi: python scalars or [n_rays] tensors.  u: injected uniforms [n_rays, n_bins]; otherwise the counter-based
+    generator under `seed` (default: torch's initial seed) and a per-call offset."""
+    lo_t = _req(lo.to(device), torch.float32, "min_depth") if torch.is_tensor(lo) else None
+    hi_t = _req(hi.to(device), torch.float32, "max_depth") if torch.is_tensor(hi) else None
+    u = _req(u, torch.float32, "u") if u is not None else None
+    out = torch.empty(n_rays, n_bins, device=device)
+    sd = torch.initial_seed() if seed is None else seed
+    check(lib().objnerf_stratified_bins(n_rays, n_bins, _ptr(lo_t), 0.0 if lo_t is not None else float(lo), _ptr(hi_t),
+                                        0.0 if hi_t is not None else float(hi), _ptr(u), sd & (2 ** 64 - 1), _next_offset(),
+                                        _ptr(out), _stream()), "objnerf_stratified_bins")
+    return out
+
+
+def normal_bins(depth: torch.Tensor, n_bins: int, delta: float, g: Optional[torch.Tensor] = None,
+                seed: Optional[int] = None) -> torch.Tensor:
+    depth = _req(depth, torch.float32, "depth")
+    n_rays = depth.shape[0]
+    g = _req(g, torch.float32, "g") if g is not None else None
+    out = torch.empty(n_rays, n_bins, device=depth.device)
+    sd = torch.initial_seed() if seed is None else seed
+    check(lib().objnerf_normal_bins(n_rays, n_bins, _ptr(depth), float(delta), _ptr(g), sd & (2 ** 64 - 1), _next_offset(),
+                                    _ptr(out), _stream()), "objnerf_normal_bins")
+    return out

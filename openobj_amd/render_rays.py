@@ -1,12 +1,11 @@
 """render_rays -- the reference's compositing helpers (render_rays.py:6-146) on the HIP kernels.
 
-occupancy_activation / occupancy_to_termination / render run objnerf_occupancy / objnerf_composite.
-render_loss / reduce_batch_loss / make_3D_grid are elementwise glue the fused iteration does not use
-(its loss lives inside train_fused_kernel and objnerf_step_batch_loss); they are provided for callers
-of the reference API and operate on device tensors.
+occupancy_activation / occupancy_to_termination / render run objnerf_occupancy / objnerf_composite;
+render_loss / reduce_batch_loss / make_3D_grid run the small kernels of objnerf_helpers.hip.  The fused
+iteration uses none of them (its loss lives inside the training kernels and objnerf_step_batch_loss); they
+are provided for callers of the reference API and operate on device tensors.
 """
 import torch
-import torch.nn.functional as F
 
 from . import ops
 
@@ -30,63 +29,34 @@ def render(termination, vals, dim=-1):
     return (termination * vals).sum(dim=dim)
 
 
-def render_loss(render, gt, loss="L1", normalise=False):   # render_rays.py:65-83
-    residual = render - gt
-    if loss == "L2":
-        loss_mat = residual ** 2
-    elif loss == "L1":
-        loss_mat = torch.abs(residual)
-    elif loss == "cos":
-        loss_mat = 1 - F.cosine_similarity(render, gt, dim=-1)
-    else:
+_LOSS_MODES = {"L1": 0, "L2": 1, "cos": 2}
+
+
+def render_loss(render, gt, loss="L1", normalise=False):
+    """Per-element residual of a rendered quantity against its target (reference render_rays.py:65-83): "L1"
+    absolute, "L2" squared, "cos" one minus the cosine similarity over the last axis; objnerf_render_loss."""
+    if loss not in _LOSS_MODES:
         raise ValueError("loss type {} not implemented!".format(loss))
-    if normalise:
-        loss_mat = loss_mat / gt
-    return loss_mat
+    return ops.render_loss(render, gt, _LOSS_MODES[loss], normalise)
 
 
 class LossExplode(RuntimeError):
     """The reference prints 'loss explode' and exit(-1)s (render_rays.py:109-111)."""
 
 
-def reduce_batch_loss(loss_mat, var=None, avg=True, mask=None, loss_type="L1"):   # render_rays.py:85-117
-    mask_num = torch.sum(mask, dim=-1)
-    if (mask_num == 0).any():          # cross-object early return
-        loss = torch.zeros_like(loss_mat)
-        if avg:
-            loss = torch.mean(loss, dim=-1)
-        return loss
-    if var is not None:
-        eps = 1e-4
-        information = 1.0 / (var + eps) if loss_type == "L2" else 1.0 / (torch.sqrt(var) + eps)
-        loss_weighted = loss_mat * information
-    else:
-        loss_weighted = loss_mat
-    if avg:
-        if mask is not None:
-            loss = torch.sum(loss_weighted, dim=-1) / (torch.sum(mask, dim=-1) + 1e-10)
-            if (loss > 100000).any():
-                raise LossExplode("loss explode")
-        else:
-            loss = torch.mean(loss_weighted, dim=-1).sum()
-    else:
-        loss = loss_weighted
-    return loss
+def reduce_batch_loss(loss_mat, var=None, avg=True, mask=None, loss_type="L1"):
+    """Masked, optionally information-weighted reduction of a [K, R] loss matrix to one value per object
+    (reference render_rays.py:85-117) on objnerf_reduce_batch_loss: if ANY object's mask is empty the result is zero
+    for ALL objects (the reference's early return), a mean above 1e5 raises LossExplode where the reference exits."""
+    if mask is None:
+        raise ValueError("reduce_batch_loss needs a mask (the reference sums it unconditionally, render_rays.py:88)")
+    out, status = ops.reduce_batch_loss(loss_mat, var, mask, l2=(loss_type == "L2"), avg=bool(avg))
+    if avg and int(status.item()) != 0:
+        raise LossExplode("loss explode")
+    return out
 
 
-def make_3D_grid(occ_range=[-1., 1.], dim=256, device="cuda:0", transform=None, scale=None):   # :119-146
-    t = torch.linspace(occ_range[0], occ_range[1], steps=dim, device=device)
-    grid = torch.meshgrid(t, t, t, indexing="ij")
-    grid_3d = torch.cat((grid[0][..., None], grid[1][..., None], grid[2][..., None]), dim=3)
-    if scale is not None:
-        grid_3d = grid_3d * scale
-    if transform is not None:
-        R1 = transform[None, None, None, 0, :3]
-        R2 = transform[None, None, None, 1, :3]
-        R3 = transform[None, None, None, 2, :3]
-        grid1 = (R1 * grid_3d).sum(-1, keepdim=True)
-        grid2 = (R2 * grid_3d).sum(-1, keepdim=True)
-        grid3 = (R3 * grid_3d).sum(-1, keepdim=True)
-        grid_3d = torch.cat([grid1, grid2, grid3], dim=-1)
-        grid_3d = grid_3d + transform[None, None, None, :3, 3]
-    return grid_3d
+def make_3D_grid(occ_range=[-1., 1.], dim=256, device="cuda:0", transform=None, scale=None):
+    """[dim, dim, dim, 3] lattice over occ_range^3, scaled per axis and moved into the world by `transform` [4,4]
+    (reference render_rays.py:119-146); one objnerf_make_grid launch."""
+    return ops.make_grid(int(dim), float(occ_range[0]), float(occ_range[1]), scale, transform, device)

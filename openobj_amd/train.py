@@ -16,8 +16,10 @@ class BackgroundLoop:
 
     It is NOT in the vmap stack.  Under object sharding it is replicated on every rank: each rank trains
     on its slice of the iteration's n_per_optim_bg rays, the per-ray loss is normalised by the GLOBAL
-    mask counts (an 2-int SUM all-reduce), the gradient (182 339 floats at hidden 128) is SUM
-    all-reduced over RCCL and every rank applies the same AdamW update."""
+    mask counts (a 2-int SUM all-reduce before the step), the gradient (182 339 floats at hidden 128) with the
+    four loss terms appended is SUM all-reduced over RCCL in ONE collective and every rank applies the same
+    AdamW update.  `begin` / `finish` split the step around that collective so that a caller can run other work
+    (the object kernel) while it is in flight -- ShardedIteration does."""
 
     def __init__(self, cfg, bg_trainer, with_feat: bool = False, group=None, bf16: bool = False):
         """bf16: opt-in OBJNERF_TRAIN_BF16 mode (bf16 GEMM operands, fp32 accumulation and everything else)."""
@@ -29,28 +31,99 @@ class BackgroundLoop:
         self.mask = self.arena.has_grad_mask(with_feat)
         self.ws = None
 
-    def step(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
-        """batch: THIS rank's slice of the background rays, tensors shaped [1, R_local, ...]."""
+    def _workspace(self, batch):
         K, R, S = batch["z"].shape
         if self.ws is None or self.ws.key != (K, R, S, self.with_feat):
             self.ws = ops.TrainWorkspace(self.arena, K, R, S, self.with_feat)
-        counts, flags = ops.label_counts(batch["labels"])
-        if odist._active(self.group):
-            odist.allreduce_sum_(counts, self.group)              # global n(label==1), n(label!=2)
-            flags = ((counts.reshape(-1, 2) == 0).any(dim=0)).to(torch.int32)
-        ops.train_step(self.arena, self.ws, batch, with_feat=self.with_feat, global_flags=flags,
-                       global_counts=counts, bf16=self.bf16)
-        odist.allreduce_sum_(self.ws.grads, self.group)           # the one data-path collective
-        odist.allreduce_sum_(self.ws.loss_terms, self.group)
+            # gradient and loss terms in ONE buffer: one collective moves both
+            self.flat = torch.zeros(self.arena.p_stride + 4, device=self.arena.params.device)
+            self.ws.grads = self.flat[:self.arena.p_stride].view(1, -1)
+            self.ws.loss_terms = self.flat[self.arena.p_stride:].view(1, 4)
+        return self.ws
+
+    def local_counts(self, batch):
+        """n(label == 1), n(label != 2) of this rank's ray slice (int32 [1,2], device)."""
+        return ops.label_counts(batch["labels"])[0]
+
+    def begin(self, batch: Dict[str, torch.Tensor], counts: torch.Tensor, flags: torch.Tensor):
+        """Launch the step with the GLOBAL mask counts / flags and start the gradient all-reduce; returns its handle."""
+        ws = self._workspace(batch)
+        ops.train_step(self.arena, ws, batch, with_feat=self.with_feat, global_flags=flags, global_counts=counts,
+                       bf16=self.bf16)
+        return odist.allreduce_sum_async(self.flat, self.group)    # the one data-path collective
+
+    def finish(self, work) -> torch.Tensor:
+        if work is not None:
+            work.wait()
         self.opt.step(self.ws.grads, self.mask)
         return self.ws.loss_terms
+
+    def step(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """batch: THIS rank's slice of the background rays, tensors shaped [1, R_local, ...]."""
+        counts = self.local_counts(batch)
+        odist.allreduce_sum_(counts, self.group)                  # global n(label==1), n(label!=2)
+        flags = ((counts.reshape(-1, 2) == 0).any(dim=0)).to(torch.int32)
+        return self.finish(self.begin(batch, counts, flags))
+
+
+class ShardedIteration:
+    """One iteration of the object-sharded step (train.py:424-474 over several GPUs) with TWO collectives:
+
+      1. pre-step, ONE int32[4] SUM: the early-return flags of the stacked objects (render_rays.py:89-94 spans every
+         object of the batch, wherever it lives) and the background's global mask counts (dist.pack_pre);
+      2. post-step, ONE fp32 SUM of the background gradient with its loss terms appended, started right after the
+         background kernels and in flight while the object kernel and its AdamW run (RCCL's stream); the
+         background AdamW waits for it.
+
+    obj_loop / bg_loop may be None (a rank without foreground objects, do_bg = 0)."""
+
+    def __init__(self, obj_loop=None, bg_loop=None, group=None):
+        self.obj_loop, self.bg_loop, self.group = obj_loop, bg_loop, group
+
+    def step(self, obj_batch=None, bg_batch=None):
+        """-> (object loss terms [K,4] | None, background loss terms [1,4] | None)"""
+        ref = obj_batch if obj_batch is not None else bg_batch
+        dev = ref["z"].device
+        sharded = odist._active(self.group)
+        obj_flags = bg_counts = None
+        if obj_batch is not None and self.obj_loop is not None and sharded:
+            obj_flags = ops.label_counts(obj_batch["labels"])[1]
+        if bg_batch is not None and self.bg_loop is not None:
+            bg_counts = self.bg_loop.local_counts(bg_batch)
+        gflags = None
+        work = None
+        if sharded:
+            pre = odist.pack_pre(obj_flags, bg_counts, dev)
+            odist.allreduce_sum_(pre, self.group)                  # collective 1
+            gflags, bg_counts, bg_flags = odist.unpack_pre(pre)
+        elif bg_counts is not None:
+            bg_flags = (bg_counts.reshape(-1, 2) == 0).any(dim=0).to(torch.int32)
+        if bg_batch is not None and self.bg_loop is not None:
+            work = self.bg_loop.begin(bg_batch, bg_counts, bg_flags)      # collective 2 starts here
+        obj_terms = bg_terms = None
+        if obj_batch is not None and self.obj_loop is not None:
+            obj_terms = self.obj_loop.step(obj_batch, global_flags=gflags)     # overlaps the transfer
+        if bg_batch is not None and self.bg_loop is not None:
+            bg_terms = self.bg_loop.finish(work)
+        return obj_terms, bg_terms
 
 
 class HipTrainLoop:
     def __init__(self, cfg, trainers: List, with_feat: bool = False, bf16: bool = False):
         """trainers: the per-object Trainer instances in obj_dict order (train.py:255-256).
-        bf16: opt-in bf16-operand MFMA mode of the fused kernel (ops.train_step); default = reference fp32."""
+        bf16: opt-in bf16-operand MFMA mode of the fused kernel (ops.train_step); default = reference fp32.
+
+        cfg.training_strategy (cfg.py:25, train.py:405-429) selects how the K objects are driven:
+          "vmap" / "hip"  ONE fused launch over the stacked copies of the parameters (copied back after the frame's
+                          iterations, train.py:478-485) -- the reference's vmap path;
+          "forloop"       the reference's fallback: every object's OWN modules are trained in place, one
+                          objnerf_train_step (K = 1) and one AdamW per object and iteration, under the batch's
+                          cross-object early-return flags (the outputs are stacked before the loss, train.py:417-419);
+          anything else   the reference prints and exits (train.py:427-429): ValueError here."""
         self.cfg, self.trainers, self.with_feat, self.bf16 = cfg, list(trainers), with_feat, bf16
+        self.strategy = getattr(cfg, "training_strategy", "hip")
+        if self.strategy not in ("hip", "vmap", "forloop"):
+            raise ValueError("training strategy {} is not implemented ".format(self.strategy))
         self.arena = None
         self.opt = None
         self.ws = None
@@ -61,6 +134,16 @@ class HipTrainLoop:
         blocks; Adam moments restart because the reference adds a fresh param group."""
         K = len(self.trainers)
         t0 = self.trainers[0]
+        if self.strategy == "forloop":          # per-object param groups (train.py:240-251): own moments, trained in place
+            self.arena = None
+            self.opts = [optim.ArenaAdamW(t.arena, lr=self.cfg.learning_rate, weight_decay=self.cfg.weight_decay)
+                         for t in self.trainers]
+            for t in self.trainers:
+                t.arena.scale.fill_(float(t.obj_scale))
+            self.mask = t0.arena.has_grad_mask(self.with_feat)
+            self.wss = None
+            self.ws = None
+            return
         self.arena = ops.ParamArena(K, t0.arena.net, t0.arena.params.device)
         with torch.no_grad():
             for k, t in enumerate(self.trainers):
@@ -70,8 +153,30 @@ class HipTrainLoop:
         self.mask = self.arena.has_grad_mask(self.with_feat)
         self.ws = None
 
+    def _step_forloop(self, batch, global_flags):
+        K, R, S = batch["z"].shape
+        if self.wss is None or self.wss[0].key != (1, R, S, self.with_feat):
+            self.wss = [ops.TrainWorkspace(t.arena, 1, R, S, self.with_feat) for t in self.trainers]
+            self.loss_terms = torch.zeros(K, 4, device=batch["z"].device)
+            self.status = torch.zeros(1, dtype=torch.int32, device=batch["z"].device)
+            self.ws = self                      # (status holder for train_frame)
+        counts, flags = ops.label_counts(batch["labels"])           # over the WHOLE stacked batch
+        if global_flags is not None:
+            flags = global_flags
+        self.status.zero_()
+        for k, t in enumerate(self.trainers):
+            bk = {key: v[k:k + 1] for key, v in batch.items()}
+            ops.train_step(t.arena, self.wss[k], bk, with_feat=self.with_feat, global_flags=flags,
+                           global_counts=counts[k:k + 1], bf16=self.bf16)
+            self.opts[k].step(self.wss[k].grads, self.mask)
+            self.loss_terms[k] = self.wss[k].loss_terms[0]
+            torch.maximum(self.status, self.wss[k].status, out=self.status)
+        return self.loss_terms
+
     def step(self, batch: Dict[str, torch.Tensor], global_flags: Optional[torch.Tensor] = None) -> torch.Tensor:
         """One iteration (train.py:424-474).  Returns the per-object loss terms [K,4] (device tensor)."""
+        if self.strategy == "forloop":
+            return self._step_forloop(batch, global_flags)
         K, R, S = batch["z"].shape
         if self.ws is None or self.ws.key != (K, R, S, self.with_feat):
             self.ws = ops.TrainWorkspace(self.arena, K, R, S, self.with_feat)
@@ -97,6 +202,8 @@ class HipTrainLoop:
 
     def copy_back(self):
         """train.py:478-485: stacked parameters -> each object's modules (their arena block)."""
+        if self.strategy == "forloop":
+            return                              # the modules themselves were trained
         with torch.no_grad():
             for k, t in enumerate(self.trainers):
                 t.arena.params[0].copy_(self.arena.params[k])

@@ -81,43 +81,28 @@ def update_vmap(models, optimiser=None, arena=None):
     return StackedModel(arena, "pe" if is_pe else "fc"), params, buffers
 
 
-def ray_box_intersection(origins, directions, bounds_min, bounds_max):   # utils.py:309-319
-    tmin = (bounds_min - origins) / directions
-    tmax = (bounds_max - origins) / directions
-    t1 = torch.min(tmin, tmax)
-    t2 = torch.max(tmin, tmax)
-    near = torch.amax(t1, dim=1)
-    far = torch.amin(t2, dim=1)
-    hit = (near <= far) & (far > 0)
-    return near, far, hit
+def ray_box_intersection(origins, directions, bounds_min, bounds_max):
+    """Slab test of [n,3] rays against an axis-aligned box -> (near, far, hit) (reference utils.py:309-319)."""
+    return ops.ray_box(origins, directions, bounds_min, bounds_max)
 
 
-def origin_dirs_W(T_WC, dirs_C):                                          # utils.py:324-336
+def origin_dirs_W(T_WC, dirs_C):
+    """Camera poses [F,4,4] and camera-frame ray directions [F,3] or [F,P,3] -> (origins [F,3], world directions)
+    (reference utils.py:324-336); the rotation runs in objnerf_dirs_w, the origins are a view of the poses."""
     assert T_WC.shape[0] == dirs_C.shape[0]
     assert T_WC.shape[1:] == (4, 4)
-    if dirs_C.shape[1] == 3 and dirs_C.dim() == 2:
-        dirs_W = torch.matmul(T_WC[:, :3, :3], dirs_C.unsqueeze(-1)).squeeze(-1)
-    else:
-        dirs_W = (T_WC[:, None, :3, :3] @ dirs_C[..., None]).squeeze()
-    return T_WC[:, :3, -1], dirs_W
+    return T_WC[:, :3, -1], ops.dirs_w(T_WC, dirs_C)
 
 
-def stratified_bins(min_depth, max_depth, n_bins, n_rays, type=torch.float32, device="cuda:0"):   # :342-379
-    lim = torch.linspace(0, 1, n_bins + 1, dtype=type, device=device)
-    if not torch.is_tensor(min_depth):
-        min_depth = torch.ones(n_rays, dtype=type, device=device) * min_depth
-    if not torch.is_tensor(max_depth):
-        max_depth = torch.ones(n_rays, dtype=type, device=device) * max_depth
-    depth_range = max_depth - min_depth
-    lower = (depth_range[..., None] * lim + min_depth[..., None])[:, :-1]
-    assert lower.shape == (n_rays, n_bins)
-    inc = torch.rand(n_rays, n_bins, device=device, dtype=torch.float32) * (depth_range / n_bins)[..., None]
-    return lower + inc
+def stratified_bins(min_depth, max_depth, n_bins, n_rays, type=torch.float32, device="cuda:0", u=None):
+    """One uniform draw per bin of an even partition of [min_depth, max_depth] (scalars or per-ray tensors) ->
+    [n_rays, n_bins] (reference utils.py:342-379).  `u`: injected uniforms; otherwise drawn by the counter-based
+    generator of the library under torch's seed."""
+    return ops.stratified_bins(min_depth, max_depth, int(n_bins), int(n_rays), device, u=u)
 
 
-def normal_bins_sampling(depth, n_bins, n_rays, delta, device="cuda:0"):                          # :382-397
-    bins = torch.empty(n_rays, n_bins, dtype=torch.float32, device=device).normal_(mean=0., std=delta / 3.)
-    bins = torch.clip(bins.sort().values, -delta, delta)
-    z_vals = depth[:, None] + bins
-    assert z_vals.shape == (n_rays, n_bins)
-    return z_vals
+def normal_bins_sampling(depth, n_bins, n_rays, delta, device="cuda:0", g=None):
+    """Sorted N(0, (delta/3)^2) offsets clipped to +-delta around each ray's depth -> [n_rays, n_bins] (reference
+    utils.py:382-397).  `g`: injected draws."""
+    assert depth.shape[0] == n_rays
+    return ops.normal_bins(depth.to(device), int(n_bins), float(delta), g=g)

@@ -285,3 +285,67 @@ def test_render_2d_syn_g11(golden, dev, H):
     assert maxerr(depth, g[f"{tag}_depth"]) < 1e-4 * max(1.0, float(np.abs(g[f"{tag}_depth"]).max()))
     assert np.abs(color.astype(int) - g[f"{tag}_color"].astype(int)).max() <= 1      # uint8 truncation of rgb*255
     assert maxerr(feat, g[f"{tag}_feat"]) < 1e-4 * max(1.0, float(np.abs(g[f"{tag}_feat"]).max()))
+
+
+def test_forloop_strategy_equals_vmap(dev):
+    """A14: cfg.training_strategy == "forloop" (train.py:405-420: every object's own modules, outputs stacked before
+    the loss) against the stacked launch: same loss terms and, after three iterations, the same parameters -- the
+    reference's two strategies agree to 1.9e-6.  One object has no label-1 ray in the second
+    batch: the cross-object early return (render_rays.py:89-94) must reach the per-object launches too."""
+    K, R, N, M = 3, 40, 1, 9
+    loops, tss = [], []
+    for strategy in ("vmap", "forloop"):
+        ts = make_trainers(K, dev, 321)
+        c = make_cfg(dev)
+        c.training_strategy = strategy
+        loops.append(otrain.HipTrainLoop(c, ts, with_feat=False))
+        tss.append(ts)
+    for it in range(3):
+        b = synthetic.random_batch(K, R, N, M, seed=60 + it)
+        if it == 1:
+            b["labels"][2][b["labels"][2] == 1] = 0
+        batch = {k: T(b[k]).to(dev) for k in ["pts", "z", "gt_depth", "gt_rgb", "labels"]}
+        t_v = loops[0].step(batch).clone()
+        t_f = loops[1].step(batch).clone()
+        assert maxerr(t_v, t_f) < 1e-6 * max(1.0, float(t_v.abs().max())), it
+        if it == 1:
+            assert float(t_f[:, :2].abs().max()) == 0.0
+    loops[0].copy_back()
+    loops[1].copy_back()
+    for tv, tf in zip(tss[0], tss[1]):
+        assert maxerr(tv.arena.params, tf.arena.params) < 2e-6
+
+
+def test_unknown_training_strategy_is_refused(dev):
+    c = make_cfg(dev)
+    c.training_strategy = "jit"
+    with pytest.raises(ValueError):
+        otrain.HipTrainLoop(c, make_trainers(1, dev, 1))
+
+
+@pytest.mark.parametrize("H", [128, 256])
+def test_module_forward_wide_networks(golden, dev, H):
+    """scene_bg.trainer.fc_occ_map(bg_embedding) (train.py:449-450): OccupancyMap.forward on an embedding for the
+    128-wide background network (G2 holds the reference's outputs for it) and the 256-wide stress network (oracle)."""
+    from openobj_amd import model as omodel
+    g = golden("g2_mlp")
+    if H == 128:
+        p = [T(g[f"h128_p{i}"]) for i in range(18)]
+        emb = T(g["h128_emb"])
+    else:
+        from openobj_amd import init as obj_init
+        p = [q[0] for q in obj_init.init_stacked(1, H, 512, seed=5)[:18]]
+        emb = T(g["h128_emb"])
+    m = omodel.OccupancyMap(87, 42, hidden_size=H, clip_size=512, device=dev)
+    with torch.no_grad():
+        for q, v in zip(m.parameters(), p):
+            q.copy_(v.to(dev))
+    alpha, color, clip = m(emb.to(dev))
+    if H == 128:
+        ra, rc, rf = T(g["h128_alpha"]), T(g["h128_color"]), T(g["h128_clip"])
+    else:
+        ra, rc, rf = O.mlp_forward(p, emb)
+    assert tuple(alpha.shape) == tuple(ra.shape) and tuple(clip.shape) == tuple(rf.shape)
+    assert maxerr(alpha, ra) < 1e-4 * max(1.0, float(ra.abs().max()))
+    assert maxerr(color, rc) < 1e-5
+    assert maxerr(clip, rf) < 1e-4 * max(1.0, float(rf.abs().max()))

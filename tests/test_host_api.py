@@ -94,7 +94,46 @@ def _worker(rank, world, port, q):
     # replicated background network of the sharded mapping loop: identical weights from rank 0
     w = torch.full((1, 5), float(10 + rank))
     odist.broadcast_(w, 0)
-    q.put((rank, flags.tolist(), float(tot), counts.tolist(), grads[0, 0].item(), odist.rank_world(), w[0, 0].item()))
+    # the iteration's two collectives (train.ShardedIteration): packed pre-step SUM, then gradient + loss terms in one
+    pre = odist.pack_pre(torch.tensor([1 if rank == 1 else 0, 0], dtype=torch.int32),
+                         torch.tensor([[hi - lo, 7 * (rank + 1)]], dtype=torch.int32), "cpu")
+    odist.allreduce_sum_(pre)
+    gflags, bg_counts, bg_flags = odist.unpack_pre(pre)
+    flat = torch.cat([torch.full((8,), float(rank + 1)), torch.full((4,), 0.5 * (rank + 1))])
+    work = odist.allreduce_sum_async(flat)
+    work.wait()
+    # ... and the whole orchestration with stand-in loops (the kernels need a GPU; the ORDER of operations does not)
+    from openobj_amd import ops as oops, train as otrain
+
+    class ObjLoop:
+        def step(self, batch, global_flags=None):
+            self.seen_flags = global_flags.tolist()
+            return torch.full((2, 4), float(rank))
+
+    class BgLoop:
+        def local_counts(self, batch):
+            return torch.tensor([[hi - lo, 0 if rank == 0 else 5]], dtype=torch.int32)
+
+        def begin(self, batch, counts, flags):
+            self.seen = (counts.tolist(), flags.tolist())
+            self.flat = torch.full((6,), float(rank + 1))
+            return odist.allreduce_sum_async(self.flat)
+
+        def finish(self, work):
+            work.wait()
+            return self.flat[-4:].view(1, 4)
+
+    _lc = oops.label_counts
+    oops.label_counts = lambda labels: (None, torch.tensor([0, 1 if rank == 0 else 0], dtype=torch.int32))
+    try:
+        ol, bl = ObjLoop(), BgLoop()
+        ot, bt = otrain.ShardedIteration(ol, bl).step({"z": torch.zeros(2, 3, 4), "labels": None},
+                                                      {"z": torch.zeros(1, 3, 4), "labels": None})
+    finally:
+        oops.label_counts = _lc
+    q.put((rank, flags.tolist(), float(tot), counts.tolist(), grads[0, 0].item(), odist.rank_world(), w[0, 0].item(),
+           (gflags.tolist(), bg_counts.tolist(), bg_flags.tolist(), flat.tolist()),
+           (ol.seen_flags, bl.seen, bt.tolist())))
     dist.destroy_process_group()
 
 
@@ -111,11 +150,16 @@ def test_two_rank_flags_and_loss_gloo():
         p.join(60)
     expect = 2 * (1 + 5 + 10 + 5) * 1.0 + 2 * (1 + 5 + 10 + 5) * 2.0
     assert odist.rank_world() == (0, 1)              # no process group in this process
-    for rank, flags, tot, counts, g0, rw, w0 in res:
+    for rank, flags, tot, counts, g0, rw, w0, packed, orch in res:
         assert rw == (rank, 2) and w0 == 10.0
         assert flags == [1, 0]
         assert abs(tot - expect) < 1e-4
         assert counts == [[1200, 21]] and g0 == 3.0
+        # packed pre-step exchange: flags as counts of empty-mask objects, background counts summed
+        assert packed[0] == [1, 0] and packed[1] == [[1200, 21]] and packed[2] == [0, 0]
+        assert packed[3] == [3.0] * 8 + [1.5] * 4                      # gradient and loss terms in ONE all-reduce
+        # orchestration: both ranks see rank 0's empty mask, the background's GLOBAL counts, and the summed buffer
+        assert orch[0] == [0, 1] and orch[1] == ([[1200, 5]], [0, 0]) and orch[2] == [[3.0, 3.0, 3.0, 3.0]]
 
 
 def test_view_buffers_zbuffer_merge():

@@ -12,5 +12,5 @@ SCHED32=${SCHED32--mllvm -amdgpu-sched-strategy=max-ilp}
 /opt/rocm/bin/hipcc $FLAGS $SCHED32 "$@" -c objnerf_train32.hip -o abl/train32_$name.o &
 /opt/rocm/bin/hipcc $FLAGS "$@" -c objnerf_train_bf16.hip -o abl/train_bf16_$name.o &
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o abl/lib_$name.so abl/train_$name.o abl/train32_$name.o abl/train_bf16_$name.o objnerf_misc.o objnerf_generic.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o abl/lib_$name.so abl/train_$name.o abl/train32_$name.o abl/train_bf16_$name.o objnerf_misc.o objnerf_generic.o objnerf_helpers.o
 echo built abl/lib_$name.so
