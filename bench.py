@@ -194,6 +194,12 @@ def main():
         if getattr(args, k_arg) is not None:
             wl[k_wl] = getattr(args, k_arg)
 
+    # stdout carries exactly ONE line (the JSON, rank 0).  Libraries print there too (RCCL's version banner at the
+    # first collective): file descriptor 1 is pointed at stderr for the run and the line goes to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -207,7 +213,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    from openobj_amd import cfg as ocfg, dist as odist, trainer as otrainer, train as otrain
+    from openobj_amd import cfg as ocfg, dist as odist, optim as ooptim, trainer as otrainer, train as otrain
     R, n1, n2, Hd, feat = wl["rays"], wl["n1"], wl["n2"], wl["hidden"], bool(wl["feat"])
     S = n1 + n2
     if wl["scaling"] == "strong":                       # a fixed population of objects dealt to the ranks
@@ -232,15 +238,13 @@ def main():
     class ObjLoop:                  # the object stack of this rank: fused step + AdamW over the arena
         def __init__(self):
             self.ws = ops.TrainWorkspace(arena, K, R, S, feat)
-            self.m, self.v = torch.zeros_like(arena.params), torch.zeros_like(arena.params)
+            self.opt = ooptim.ArenaAdamW(arena, lr=1e-3, weight_decay=0.013)
             self.mask = arena.has_grad_mask(feat)
-            self.n = 0
             self.bf16 = False
 
         def step(self, batch, global_flags=None):
             ops.train_step(arena, self.ws, batch, global_flags=global_flags, with_feat=feat, bf16=self.bf16)
-            self.n += 1
-            ops.adamw_step(arena, self.ws.grads, self.m, self.v, self.mask, self.n, 1e-3, 0.013)
+            self.opt.step(self.ws.grads, self.mask, flags=global_flags if global_flags is not None else self.ws.flags)
             return self.ws.loss_terms
 
     obj_loop = ObjLoop()
@@ -367,7 +371,8 @@ def main():
                 out["psnr_delta_ci95_db"] = ps[key]["ci95_db"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(feat)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()
 

@@ -289,6 +289,18 @@ int objnerf_adamw_step(int32_t K, int64_t P, int64_t p_stride, float* params, co
                        float lr, float beta1, float beta2, float eps, float weight_decay,
                        void* stream);
 
+/* The same step with the early-return quirk of render_rays.py:89-94 carried through to the optimiser: `flags` is the
+ * iteration's device flag pair (objnerf_label_counts / the all-reduced flags).  flags[0] set = the depth, colour and
+ * feature terms were constants this iteration: the colour branch [colour_lo, feature_lo) and the feature branch
+ * [feature_lo, feature_hi) of every object had .grad = None in the reference, and torch.optim.AdamW skips such
+ * parameters entirely (no decay, no moment update, no step increment); both flags set = nothing is updated.
+ * group_steps: device int32[3] per-group step counters (trunk + density head + B | colour | feature), zero-initialised by
+ * the caller, advanced here.  has_grad still masks what a configuration never differentiates. */
+int objnerf_adamw_step_flags(int32_t K, int64_t P, int64_t p_stride, float* params, const float* grads, float* exp_avg,
+                             float* exp_avg_sq, const uint8_t* has_grad, const int32_t* flags, int32_t* group_steps,
+                             int64_t colour_lo, int64_t feature_lo, int64_t feature_hi, float lr, float beta1, float beta2,
+                             float eps, float weight_decay, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Helper functions of the reference's call surface that a caller may use outside the fused iteration
  * (objnerf_helpers.hip).  All take / return device pointers; small HBM-bound kernels.

@@ -396,6 +396,49 @@ __global__ void adamw_kernel(long P, long p_stride, float* params, const float* 
   v[idx] = vn;
 }
 
+// The same with the "did this tensor receive a gradient?" decision made ON THE DEVICE from the iteration's early-return
+// flags (render_rays.py:89-94).  When the label-1 masks trigger the early return, the depth / colour / feature terms are
+// constants: the colour and feature branches get .grad = None and torch.optim.AdamW skips them entirely (no decay, no
+// moment update, and their per-parameter step count does not advance); with both flags set nothing has a gradient.
+// Three groups with their own step counters (device int32[3]): 0 = trunk + density head + B, 1 = colour branch
+// [lo1, lo2), 2 = feature branch [lo2, hi2).
+__global__ void adamw_dyn_kernel(long P, long p_stride, float* params, const float* grads, float* m, float* v,
+                                 const uint8_t* has_grad, const int* flags, const int* steps, long lo1, long lo2, long hi2,
+                                 double lr, double b1, double b2, float eps, double wd) {
+  __shared__ float s_step_size[3], s_bc2_sqrt[3];
+  __shared__ int s_active[3];
+  if (threadIdx.x < 3) {
+    const int g = threadIdx.x;
+    const bool f0 = flags[0] != 0, f1 = flags[1] != 0;
+    s_active[g] = g == 0 ? !(f0 && f1) : !f0;
+    const double st = (double)(steps[g] + 1);
+    s_step_size[g] = (float)(lr / (1.0 - pow(b1, st)));
+    s_bc2_sqrt[g] = (float)sqrt(1.0 - pow(b2, st));
+  }
+  __syncthreads();
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P || (has_grad && !has_grad[i])) return;
+  const int g = (i >= lo1 && i < lo2) ? 1 : ((i >= lo2 && i < hi2) ? 2 : 0);
+  if (!s_active[g]) return;
+  const float decay = (float)(1.0 - lr * wd), w1 = (float)(1.0 - b1), w2 = (float)(1.0 - b2), beta2 = (float)b2;
+  const long idx = (long)blockIdx.y * p_stride + i;
+  const float gr = grads[idx];
+  float p = params[idx] * decay;
+  const float mo = m[idx];
+  const float mn = mo + w1 * (gr - mo);
+  const float vn = v[idx] * beta2 + (w2 * gr) * gr;
+  const float denom = sqrtf(vn) / s_bc2_sqrt[g] + eps;
+  p = p + (-s_step_size[g]) * (mn / denom);
+  params[idx] = p;
+  m[idx] = mn;
+  v[idx] = vn;
+}
+__global__ void adamw_bump_kernel(const int* flags, int* steps) {
+  const bool f0 = flags[0] != 0, f1 = flags[1] != 0;
+  if (!(f0 && f1)) steps[0] += 1;
+  if (!f0) { steps[1] += 1; steps[2] += 1; }
+}
+
 // ------------------------------------------------------------------------------------------------
 // vmap.py:701-720
 // ------------------------------------------------------------------------------------------------
@@ -737,6 +780,23 @@ int objnerf_adamw_step(int32_t K, int64_t P, int64_t p_stride, float* params, co
   dim3 grid((unsigned)((P + 255) / 256), (unsigned)K);
   hipLaunchKernelGGL(adamw_kernel, grid, dim3(256), 0, (hipStream_t)stream, (long)P, (long)p_stride, params, grads,
                      exp_avg, exp_avg_sq, has_grad, decay, w1, beta2, w2, step_size, bc2_sqrt, eps);
+  CHECK_LAUNCH();
+  return OBJNERF_OK;
+}
+
+int objnerf_adamw_step_flags(int32_t K, int64_t P, int64_t p_stride, float* params, const float* grads, float* exp_avg,
+                             float* exp_avg_sq, const uint8_t* has_grad, const int32_t* flags, int32_t* group_steps,
+                             int64_t colour_lo, int64_t feature_lo, int64_t feature_hi, float lr, float beta1, float beta2,
+                             float eps, float weight_decay, void* stream) {
+  CLEAR_STALE();
+  if (K <= 0 || P <= 0 || p_stride < P || !params || !grads || !exp_avg || !exp_avg_sq || !flags || !group_steps ||
+      colour_lo > feature_lo || feature_lo > feature_hi || feature_hi > P)
+    return OBJNERF_EINVAL;
+  dim3 grid((unsigned)((P + 255) / 256), (unsigned)K);
+  hipLaunchKernelGGL(adamw_dyn_kernel, grid, dim3(256), 0, (hipStream_t)stream, (long)P, (long)p_stride, params, grads,
+                     exp_avg, exp_avg_sq, has_grad, flags, group_steps, (long)colour_lo, (long)feature_lo, (long)feature_hi,
+                     (double)lr, (double)beta1, (double)beta2, eps, (double)weight_decay);
+  hipLaunchKernelGGL(adamw_bump_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, flags, group_steps);
   CHECK_LAUNCH();
   return OBJNERF_OK;
 }

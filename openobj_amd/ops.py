@@ -382,6 +382,21 @@ def adamw_step(arena: ParamArena, grads: torch.Tensor, exp_avg: torch.Tensor, ex
                                    _stream()), "objnerf_adamw_step")
 
 
+def adamw_step_flags(arena: ParamArena, grads: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor,
+                     has_grad: Optional[torch.Tensor], flags: torch.Tensor, group_steps: torch.Tensor, lr: float,
+                     weight_decay: float, beta1=0.9, beta2=0.999, eps=1e-8, params: Optional[torch.Tensor] = None) -> None:
+    """AdamW with the iteration's early-return flags deciding on the device which tensor groups received a gradient
+    (objnerf_adamw_step_flags); group_steps: int32[3] device counters owned by the caller."""
+    p = arena.params if params is None else params
+    flags = _req(flags, torch.int32, "flags")
+    group_steps = _req(group_steps, torch.int32, "group_steps")
+    o = arena.offsets
+    check(lib().objnerf_adamw_step_flags(arena.K, arena.P, arena.p_stride, _ptr(p), _ptr(grads), _ptr(exp_avg),
+                                         _ptr(exp_avg_sq), _ptr(has_grad), _ptr(flags), _ptr(group_steps), int(o[10]),
+                                         int(o[14]), int(o[18]), lr, beta1, beta2, eps, weight_decay, _stream()),
+          "objnerf_adamw_step_flags")
+
+
 def ingest_frame(rgb, depth, inst, t_wc, items) -> None:
     """One frame into a keyframe slot of every visible object, one launch (train.py:196-256).
     rgb u8 [W,H,3], depth f32 [W,H], inst int32 [W,H], t_wc f32 [4,4] on the device;

@@ -18,8 +18,18 @@ class ArenaAdamW:
         self.exp_avg = torch.zeros_like(self.arena.params)
         self.exp_avg_sq = torch.zeros_like(self.arena.params)
         self.step_count = 0
+        # per-group step counters of the flag-aware step (trunk + density head + B | colour branch | feature branch)
+        self.group_steps = torch.zeros(3, dtype=torch.int32, device=self.arena.params.device)
 
-    def step(self, grads: torch.Tensor, has_grad: Optional[torch.Tensor] = None):
+    def step(self, grads: torch.Tensor, has_grad: Optional[torch.Tensor] = None, flags: Optional[torch.Tensor] = None):
+        """flags: the iteration's early-return flag pair (device int32[2]).  With it, tensors whose loss terms were
+        constants this iteration are skipped like parameters with .grad = None in torch.optim.AdamW (no decay, no moment
+        update, their own step count) -- decided on the device, no host sync.  Without it every tensor of `has_grad`
+        is stepped with one global step count."""
+        if flags is not None:
+            ops.adamw_step_flags(self.arena, grads, self.exp_avg, self.exp_avg_sq, has_grad, flags, self.group_steps,
+                                 self.lr, self.weight_decay, self.betas[0], self.betas[1], self.eps)
+            return
         self.step_count += 1
         ops.adamw_step(self.arena, grads, self.exp_avg, self.exp_avg_sq, has_grad, self.step_count, self.lr,
                        self.weight_decay, self.betas[0], self.betas[1], self.eps)

@@ -48,6 +48,7 @@ class BackgroundLoop:
     def begin(self, batch: Dict[str, torch.Tensor], counts: torch.Tensor, flags: torch.Tensor):
         """Launch the step with the GLOBAL mask counts / flags and start the gradient all-reduce; returns its handle."""
         ws = self._workspace(batch)
+        self._flags = flags
         ops.train_step(self.arena, ws, batch, with_feat=self.with_feat, global_flags=flags, global_counts=counts,
                        bf16=self.bf16)
         return odist.allreduce_sum_async(self.flat, self.group)    # the one data-path collective
@@ -55,7 +56,7 @@ class BackgroundLoop:
     def finish(self, work) -> torch.Tensor:
         if work is not None:
             work.wait()
-        self.opt.step(self.ws.grads, self.mask)
+        self.opt.step(self.ws.grads, self.mask, flags=self._flags)
         return self.ws.loss_terms
 
     def step(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
@@ -168,7 +169,7 @@ class HipTrainLoop:
             bk = {key: v[k:k + 1] for key, v in batch.items()}
             ops.train_step(t.arena, self.wss[k], bk, with_feat=self.with_feat, global_flags=flags,
                            global_counts=counts[k:k + 1], bf16=self.bf16)
-            self.opts[k].step(self.wss[k].grads, self.mask)
+            self.opts[k].step(self.wss[k].grads, self.mask, flags=flags)
             self.loss_terms[k] = self.wss[k].loss_terms[0]
             torch.maximum(self.status, self.wss[k].status, out=self.status)
         return self.loss_terms
@@ -182,7 +183,8 @@ class HipTrainLoop:
             self.ws = ops.TrainWorkspace(self.arena, K, R, S, self.with_feat)
         ops.train_step(self.arena, self.ws, batch, with_feat=self.with_feat, global_flags=global_flags,
                        bf16=self.bf16)
-        self.opt.step(self.ws.grads, self.mask)
+        # (ws.flags holds the batch's own flags when no global pair was supplied)
+        self.opt.step(self.ws.grads, self.mask, flags=global_flags if global_flags is not None else self.ws.flags)
         return self.ws.loss_terms
 
     def train_frame(self, pool: Dict[str, torch.Tensor], n_iter: Optional[int] = None,

@@ -349,3 +349,29 @@ def test_module_forward_wide_networks(golden, dev, H):
     assert maxerr(alpha, ra) < 1e-4 * max(1.0, float(ra.abs().max()))
     assert maxerr(color, rc) < 1e-5
     assert maxerr(clip, rf) < 1e-4 * max(1.0, float(rf.abs().max()))
+
+
+def test_adamw_skips_gradless_groups_like_torch(dev):
+    """When an object of the batch has no label-1 ray, depth / colour / feature terms are constants (render_rays.py:89-94):
+    color_linear / out_color keep .grad = None and torch.optim.AdamW leaves them alone -- no decay, no moment update, no
+    step increment.  Three iterations (the second one with the early return) against torch.optim.AdamW itself, fed
+    the SAME gradients with .grad = None for the skipped tensors."""
+    K, R, N, M = 2, 48, 1, 9
+    ts = make_trainers(K, dev, 77)
+    loop = otrain.HipTrainLoop(make_cfg(dev), ts, with_feat=False)
+    ref_p = [v.detach().cpu().clone().requires_grad_(True) for v in loop.arena.views()]
+    ref_opt = torch.optim.AdamW(ref_p, lr=loop.cfg.learning_rate, weight_decay=loop.cfg.weight_decay)
+    colour = (10, 11, 12, 13)
+    for it in range(3):
+        b = synthetic.random_batch(K, R, N, M, seed=90 + it)
+        if it == 1:
+            b["labels"][1][b["labels"][1] == 1] = 0
+        loop.step({k: T(b[k]).to(dev) for k in ["pts", "z", "gt_depth", "gt_rgb", "labels"]})
+        gv = loop.arena.views(loop.ws.grads)
+        for i, p in enumerate(ref_p):
+            skipped = i in ops.FEAT_TENSORS or (it == 1 and i in colour)
+            p.grad = None if skipped else gv[i].detach().cpu().clone()
+        ref_opt.step()
+        for i, (p, v) in enumerate(zip(ref_p, loop.arena.views())):
+            assert maxerr(v, p.detach()) < 3e-7, (it, i, ops.TENSOR_NAMES[i])
+    assert loop.opt.group_steps.tolist() == [3, 2, 2]
