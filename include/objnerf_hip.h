@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define OBJNERF_ABI_VERSION 2
+#define OBJNERF_ABI_VERSION 3
 
 #define OBJNERF_OK 0
 #define OBJNERF_EINVAL (-22)       /* bad shape / null pointer / unsupported size        */
@@ -72,30 +72,48 @@ int objnerf_rays_dirs(int32_t W, int32_t H, float fx, float fy, float cx, float 
 /* ------------------------------------------------------------------------------------------
  * A2+A3+A4  sceneObject.get_training_samples + sample_3d_points (vmap.py:386-554,
  * utils.py:324-397) for ONE object: gather pixels from the keyframe buffers and place the
- * depth-guided z-values.  Randomness is INJECTED (the reference's torch.rand / normal_ draws):
+ * depth-guided z-values.
+ * Randomness, INJECTED form (exact parity with the reference's torch.rand / normal_ draws):
  *   kf_ids [n_frames] int64, u_w,u_h [n_frames][n_px] in [0,1),
  *   u [n_frames*n_px][N+M] uniforms, g [n_frames*n_px][M] draws of N(0,(eps/3)^2).
+ * Randomness, SEEDED form (u_w = u_h = u = g = NULL): every draw is Philox4x32-10 of
+ *   (seed; purpose, draw; object index, ray, bin) computed in place -- no random number is ever stored.  `draw` is
+ *   the caller's call counter (a new value = new draws, 29 bits), the object index identifies the object's random
+ *   stream (kf_meta[3]; without kf_meta: obj_index, + k for object k of a stacked call), so that objects,
+ *   iterations and GPUs holding different objects never share a draw.
+ *   kf_ids may then be NULL too: kf_meta [4] int32 = {n_keyframes, slot of the second-latest keyframe, slot of the
+ *   latest (-1, -1 while n_keyframes <= 2), object index} selects the keyframes as vmap.py:390-401 does (uniform
+ *   over the stored keyframes, the latest two always included, LAST).  out_kf [n_frames] int64 / out_px [n][2] int32 (pixel
+ *   (w, h) of each ray) are optional records of what was drawn (the part-feature gather of vmap.py:437-452 needs
+ *   them).
  * Keyframe buffers: rgbs [F][W][H][4] u8 (rgb+state), depth [F][W][H], t_wc [F][4][4],
  * bbox [F][4] = [u lo,u hi,v lo,v hi], rays_dir_cache [W][H][3].
  * Outputs: rgb [n][3] u8, gt_depth [n], valid [n] u8, labels [n] u8, z [n][N+M], pts [n][N+M][3]
- * (n = n_frames*n_px).  max_depth_ws: device scratch of 1 + 6*n floats ([0] receives the batch depth
+ * (n = n_frames*n_px).  out_pts may be NULL when out_origins / out_dirs [n][3] are given: the world-frame ray
+ * origins and directions go there and objnerf_train_step (pts == NULL form) forms the points in registers --
+ * the [n][N+M][3] point tensor is then never written or read.
+ * max_depth_ws: device scratch of 1 + 6*n floats ([0] receives the batch depth
  * maximum of vmap.py:489, the rest holds the world-frame origins / directions between the passes).
  */
 typedef struct objnerf_sample_args {
-  int32_t F, W, H, n_frames, n_px, n_cam2surf, n_bins, reserved;
+  int32_t F, W, H, n_frames, n_px, n_cam2surf, n_bins, obj_index;
   float surface_eps, stop_eps, min_bound, obj_center;
   const uint8_t* rgbs; const float* depth; const float* t_wc; const float* bbox;
   const float* rays_dir_cache;
   const int64_t* kf_ids; const float* u_w; const float* u_h; const float* u; const float* g;
   uint8_t* out_rgb; float* out_depth; uint8_t* out_valid; uint8_t* out_labels;
   float* out_z; float* out_pts; float* max_depth_ws;
+  /* ABI 3 */
+  uint64_t seed; uint32_t draw; uint32_t reserved;
+  const int32_t* kf_meta; int64_t* out_kf; int32_t* out_px;
+  float* out_origins; float* out_dirs;
 } objnerf_sample_args;
 int objnerf_sample_rays(const objnerf_sample_args* a, void* stream);
 
 /* The same for K objects in ONE launch chain (train.py:316-330 calls the sampler once per object and stacks the
  * results, train.py:368-388).  `table`: DEVICE array of K keyframe-store descriptors (the objects share F, W, H and
- * every scalar of `a`; a->rgbs / depth / t_wc / bbox are ignored).  Every draw and output array of `a` is stacked
- * [K][...] with the per-object layouts above -- the outputs ARE the stacked batch tensors of the training step --
+ * every scalar of `a`; a->rgbs / depth / t_wc / bbox are ignored).  Every draw and output array of `a` (kf_meta,
+ * out_kf, out_px, out_origins, out_dirs included) is stacked [K][...] with the per-object layouts above -- the outputs ARE the stacked batch tensors of the training step --
  * and max_depth_ws holds K x (1 + 6 n) floats. */
 typedef struct objnerf_kf_store {
   const uint8_t* rgbs; const float* depth; const float* t_wc; const float* bbox;
@@ -127,15 +145,16 @@ int objnerf_ingest_frame(int32_t W, int32_t H, const uint8_t* rgb, const float* 
  *   trainer.py:152-157 does), half = extent / 2.  Outputs: dirs_W [P][3] (origin_dirs_W, utils.py:324-336),
  *   near [P] (clipped at 0), far [P] (+0.2, :166-167), hit [P] u8 (ray_box_intersection, utils.py:309-319).
  * objnerf_box_points: for the n hit rays (compacted by the caller): z_vals [n][n_bins-1] = mid-points of
- *   stratified_bins(near, far, n_bins) with the injected draw u [n][n_bins] (utils.py:342-379, trainer.py:171-175)
- *   and pts [n][n_bins-1][3] = origin + dirs_W * z (:176).
+ *   stratified_bins(near, far, n_bins) with the injected draw u [n][n_bins] (utils.py:342-379, trainer.py:171-175;
+ *   u == NULL: Philox draws of (seed; draw; ray, bin) generated in place) and pts [n][n_bins-1][3] = origin +
+ *   dirs_W * z (:176).
  */
 int objnerf_box_rays(int64_t P, const float* T_WC, const float* T_OC, const float* half_extent,
                      const float* dirs_C, float* out_dirs_W, float* out_near, float* out_far,
                      uint8_t* out_hit, void* stream);
 int objnerf_box_points(int64_t n, int32_t n_bins, const float* origin /* [3] */, const float* dirs_W,
-                       const float* near, const float* far, const float* u, float* out_z, float* out_pts,
-                       void* stream);
+                       const float* near, const float* far, const float* u, uint64_t seed, uint32_t draw,
+                       float* out_z, float* out_pts, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * A6+A7  UniDirsEmbed.forward + OccupancyMap.forward (embedding.py:46-55, model.py:61-103),

@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OBJNERF_LIB") or os.path.join(_HERE, "csrc", "libobjnerf_hip.so")   # OBJNERF_LIB: diagnostic builds
 
 OBJNERF_N_TENSORS = 19
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class ObjnerfError(RuntimeError):
@@ -34,7 +34,7 @@ class Net(C.Structure):
 class SampleArgs(C.Structure):
     _fields_ = [("F", C.c_int32), ("W", C.c_int32), ("H", C.c_int32), ("n_frames", C.c_int32),
                 ("n_px", C.c_int32), ("n_cam2surf", C.c_int32), ("n_bins", C.c_int32),
-                ("reserved", C.c_int32),
+                ("obj_index", C.c_int32),
                 ("surface_eps", C.c_float), ("stop_eps", C.c_float), ("min_bound", C.c_float),
                 ("obj_center", C.c_float),
                 ("rgbs", C.c_void_p), ("depth", C.c_void_p), ("t_wc", C.c_void_p), ("bbox", C.c_void_p),
@@ -43,7 +43,10 @@ class SampleArgs(C.Structure):
                 ("g", C.c_void_p),
                 ("out_rgb", C.c_void_p), ("out_depth", C.c_void_p), ("out_valid", C.c_void_p),
                 ("out_labels", C.c_void_p), ("out_z", C.c_void_p), ("out_pts", C.c_void_p),
-                ("max_depth_ws", C.c_void_p)]
+                ("max_depth_ws", C.c_void_p),
+                ("seed", C.c_uint64), ("draw", C.c_uint32), ("reserved", C.c_uint32),
+                ("kf_meta", C.c_void_p), ("out_kf", C.c_void_p), ("out_px", C.c_void_p),
+                ("out_origins", C.c_void_p), ("out_dirs", C.c_void_p)]
 
 
 class IngestItem(C.Structure):
@@ -93,7 +96,7 @@ SIGNATURES = {
     "objnerf_box_rays": (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p]),
     "objnerf_box_points": (C.c_int, [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                     C.c_void_p, C.c_void_p, C.c_void_p]),
+                                     C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "objnerf_eval_points": (C.c_int, [C.POINTER(Net), C.c_int32, C.c_int64, C.c_void_p, C.c_int64,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p]),

@@ -1059,7 +1059,7 @@ struct Offs {
 struct WS {
   float *emb, *h1, *h2, *h3, *h4, *hc, *hf, *alpha, *color, *d_alpha, *d_color, *dhead;
   float *d_hf, *rayin, *gram, *rayfeat, *X1, *X2, *Tm, *mom;      // feature branch (hoisted head)
-  float *dA, *dB_, *dC, *dD, *dE, *d_emb, *dBpe;
+  float *dA, *dB_, *dC, *dD, *dE, *d_emb, *dBpe, *pts;
   int* counts;
   size_t bytes;
 };
@@ -1087,6 +1087,7 @@ static WS carve(char* base, int H, int C, long n, long R, int K, bool feat) {
   w.dC = take((size_t)K * n * H); w.dD = take((size_t)K * n * H); w.dE = take((size_t)K * n * H);
   w.d_emb = take((size_t)K * n * OBJ_EMB);
   w.dBpe = take((size_t)K * 64);
+  w.pts = take((size_t)K * n * 3);          // sample positions of the origins / directions form of the batch
   w.counts = (int*)take((size_t)2 * K + 2);
   w.bytes = (size_t)(p - base);
   return w;
@@ -1139,11 +1140,24 @@ __global__ void relu_mask_kernel(long nb, int H, const float* act /* [K n][H] */
   masks[(s * 6 + layer) * hb + b] = (uint8_t)m;
 }
 
-int train_step(const objnerf_net* net, const objnerf_train_args* a, void* stream) {
+// pts = (origin + dir * z) - centre, two roundings as vmap.py:548-551 (the fused kernels form it in registers; the
+// layer-wise path reads the points three times and keeps them in its workspace)
+__global__ void form_points_kernel(long total, int S, const float* origins, const float* dirs, const float* z, float centre,
+                                   float* pts) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const long ray = i / S;
+  const float zz = z[i];
+#pragma unroll
+  for (int x = 0; x < 3; ++x) pts[i * 3 + x] = (origins[ray * 3 + x] + dirs[ray * 3 + x] * zz) - centre;
+}
+
+int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* stream) {
+  objnerf_train_args a_local = *a_in;
+  const objnerf_train_args* a = &a_local;
   const Bf16Scope bf16_scope((a->mode & OBJNERF_TRAIN_BF16) != 0);
   const int H = net->hidden, C = net->feat_dim, K = a->K;
   if (H % 32 != 0 || net->n_freqs != 6) return OBJNERF_ENOTSUP;
-  if (!a->pts) return OBJNERF_ENOTSUP;            // origins/dirs form: fused hidden-32 path only
   const bool feat = a->gt_feat != nullptr;
   const long n = (long)a->R * a->S;
   int64_t off[OBJNERF_N_TENSORS + 1];
@@ -1152,6 +1166,12 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a, void* stream
   hipStream_t st = (hipStream_t)stream;
   WS w = carve((char*)a->workspace, H, C, n, (long)a->R, K, feat);
   if (a->workspace_bytes < w.bytes) return OBJNERF_EINVAL;
+  if (!a->pts) {
+    const long total = (long)K * n;
+    hipLaunchKernelGGL(form_points_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, a->S, a->origins,
+                       a->dirs, a->z, a->obj_center, w.pts);
+    a_local.pts = w.pts;
+  }
   const float* P = a->params;
   float* G = a->grads;
   const int E1 = OBJ_E1, E2 = OBJ_E2, EM = OBJ_EMB;

@@ -3,6 +3,7 @@
 // directions and the depth-guided ray sampler.  Built with -ffp-contract=off: every product/sum below
 // rounds where the reference's separate ATen ops round; fused multiply-adds are written as fmaf.
 #include "objnerf_device.h"
+#include "objnerf_philox.h"
 #include "../../include/objnerf_hip.h"
 #include "objnerf_generic.h"
 
@@ -461,12 +462,19 @@ __device__ __forceinline__ objnerf_sample_args sample_args_of(const objnerf_samp
   if (table) {
     b.rgbs = table[k].rgbs; b.depth = table[k].depth; b.t_wc = table[k].t_wc; b.bbox = table[k].bbox;
     const long n = (long)a.n_frames * a.n_px, S = a.n_cam2surf + a.n_bins;
-    b.kf_ids += (long)k * a.n_frames;
-    b.u_w += k * n; b.u_h += k * n; b.u += k * n * S; b.g += k * n * a.n_bins;
+    if (b.kf_ids) b.kf_ids += (long)k * a.n_frames;
+    if (b.u_w) { b.u_w += k * n; b.u_h += k * n; b.u += k * n * S; b.g += k * n * a.n_bins; }
+    if (b.kf_meta) b.kf_meta += 4 * k;
+    if (b.out_kf) b.out_kf += (long)k * a.n_frames;
+    if (b.out_px) b.out_px += k * n * 2;
+    if (b.out_origins) { b.out_origins += k * n * 3; b.out_dirs += k * n * 3; }
+    if (b.out_pts) b.out_pts += k * n * S * 3;
+    b.obj_index = a.obj_index + k;
     b.out_rgb += k * n * 3; b.out_depth += k * n; b.out_valid += k * n; b.out_labels += k * n;
-    b.out_z += k * n * S; b.out_pts += k * n * S * 3;
+    b.out_z += k * n * S;
     b.max_depth_ws += k * (1 + 6 * n);
   }
+  if (b.kf_meta) b.obj_index = b.kf_meta[3];      // the object's own random-stream id
   return b;
 }
 
@@ -475,14 +483,37 @@ __global__ void sample_gather_kernel(const objnerf_sample_args a_, const objnerf
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = a.n_frames * a.n_px;
   if (i >= n) return;
-  float* origins_ws = a.max_depth_ws + 1;
-  float* dirs_ws = origins_ws + (size_t)n * 3;
+  float* origins_ws = a.out_origins ? a.out_origins : a.max_depth_ws + 1;
+  float* dirs_ws = a.out_origins ? a.out_dirs : a.max_depth_ws + 1 + (size_t)n * 3;
   const int f = i / a.n_px;
-  const long kf = a.kf_ids[f];
+  const uint32_t tag = (uint32_t)a.draw << 3;
+  long kf;
+  if (a.kf_ids) {
+    kf = a.kf_ids[f];
+  } else {                                                       // vmap.py:390-401
+    const int nk = a.kf_meta[0];
+    const int tail = f - (a.n_frames - 2);                       // 0 / 1 for the last two frames of the draw
+    if (tail >= 0 && a.kf_meta[1 + tail] >= 0) {
+      kf = a.kf_meta[1 + tail];
+    } else {
+      const float uk = objrng::uniform1(a.seed, objrng::S_KEYFRAME | tag, (uint32_t)a.obj_index, 0u, (uint32_t)f);
+      kf = min((int)(uk * (float)nk), nk - 1);
+    }
+    if (a.out_kf && i == f * a.n_px) a.out_kf[f] = kf;
+  }
   const float* bb = a.bbox + kf * 4;
-  const float fw = a.u_w[i] * (bb[1] - bb[0]) + bb[0];
-  const float fh = a.u_h[i] * (bb[3] - bb[2]) + bb[2];
+  float uw, uh;
+  if (a.u_w) {
+    uw = a.u_w[i]; uh = a.u_h[i];
+  } else {
+    float r4[4];
+    objrng::uniform4(a.seed, objrng::S_PIXEL_W | tag, (uint32_t)a.obj_index, (uint32_t)i, 0u, r4);
+    uw = r4[0]; uh = r4[1];
+  }
+  const float fw = uw * (bb[1] - bb[0]) + bb[0];
+  const float fh = uh * (bb[3] - bb[2]) + bb[2];
   const long iw = (long)fw, ih = (long)fh;                       // .long() truncation (vmap.py:418-419)
+  if (a.out_px) { a.out_px[2 * i] = (int)iw; a.out_px[2 * i + 1] = (int)ih; }
   const long pix = (kf * a.W + iw) * a.H + ih;
   const uint8_t* px = a.rgbs + pix * 4;
   a.out_rgb[i * 3] = px[0]; a.out_rgb[i * 3 + 1] = px[1]; a.out_rgb[i * 3 + 2] = px[2];
@@ -553,15 +584,19 @@ __global__ void box_rays_kernel(long P, const float* T_WC, const float* T_OC, co
 }
 
 __global__ void box_points_kernel(long n, int n_bins, const float* origin, const float* dirs_W, const float* near_i,
-                                  const float* far_i, const float* u, float* out_z, float* out_pts) {
+                                  const float* far_i, const float* u, uint64_t seed, uint32_t draw, float* out_z,
+                                  float* out_pts) {
   const int S = n_bins - 1;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n * S) return;
   const long r = idx / S;
   const int s = (int)(idx - r * S);
   const float lo = near_i[r], hi = far_i[r];
-  const float z0 = strat(lo, hi, s, n_bins, u[r * n_bins + s]);
-  const float z1 = strat(lo, hi, s + 1, n_bins, u[r * n_bins + s + 1]);
+  const uint32_t st = objrng::S_BOX_U | (draw << 3);
+  const float u0 = u ? u[r * n_bins + s] : objrng::uniform1(seed, st, (uint32_t)(r >> 32), (uint32_t)r, (uint32_t)s);
+  const float u1 = u ? u[r * n_bins + s + 1] : objrng::uniform1(seed, st, (uint32_t)(r >> 32), (uint32_t)r, (uint32_t)s + 1);
+  const float z0 = strat(lo, hi, s, n_bins, u0);
+  const float z1 = strat(lo, hi, s + 1, n_bins, u1);
   const float z = 0.5f * (z1 + z0);                                       // trainer.py:175
   out_z[idx] = z;
 #pragma unroll
@@ -573,33 +608,66 @@ __global__ void sample_place_kernel(const objnerf_sample_args a_, const objnerf_
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = a.n_frames * a.n_px;
   if (i >= n) return;
-  const float* origins_ws = a.max_depth_ws + 1;
-  const float* dirs_ws = origins_ws + (size_t)n * 3;
+  const float* origins_ws = a.out_origins ? a.out_origins : a.max_depth_ws + 1;
+  const float* dirs_ws = a.out_origins ? a.out_dirs : a.max_depth_ws + 1 + (size_t)n * 3;
   const int N = a.n_cam2surf, M = a.n_bins, S = N + M;
   const float d = a.out_depth[i];
   const float maxd = *a.max_depth_ws;
   const uint8_t lab = a.out_labels[i];
   float* z = a.out_z + (long)i * S;
-  const float* u = a.u + (long)i * S;
   const bool invalid = d <= a.min_bound;
   a.out_valid[i] = invalid ? 0 : 1;
-  if (invalid) {
-    for (int s = 0; s < S; ++s) z[s] = strat(a.min_bound, maxd, s, S, u[s]);
-  } else {
-    for (int s = 0; s < N; ++s) z[s] = strat(a.min_bound, d - a.surface_eps, s, N, u[s]);
-    if (lab == 1) {
-      // sorted N(0,(eps/3)^2) draws, clipped to +-eps, around the surface (utils.py:382-397)
-      const float* g = a.g + (long)i * M;
-      for (int s = 0; s < M; ++s) {          // rank sort: stable for ties
-        const float v = g[s];
-        int rank = 0;
-        for (int j = 0; j < M; ++j) rank += (g[j] < v) || (g[j] == v && j < s);
-        z[N + rank] = d + fminf(fmaxf(v, -a.surface_eps), a.surface_eps);
-      }
+  if (a.u) {
+    const float* u = a.u + (long)i * S;
+    if (invalid) {
+      for (int s = 0; s < S; ++s) z[s] = strat(a.min_bound, maxd, s, S, u[s]);
     } else {
-      for (int s = 0; s < M; ++s) z[N + s] = strat(d - a.surface_eps, d + a.stop_eps, s, M, u[N + s]);
+      for (int s = 0; s < N; ++s) z[s] = strat(a.min_bound, d - a.surface_eps, s, N, u[s]);
+      if (lab == 1) {
+        // sorted N(0,(eps/3)^2) draws, clipped to +-eps, around the surface (utils.py:382-397)
+        const float* g = a.g + (long)i * M;
+        for (int s = 0; s < M; ++s) {          // rank sort: stable for ties
+          const float v = g[s];
+          int rank = 0;
+          for (int j = 0; j < M; ++j) rank += (g[j] < v) || (g[j] == v && j < s);
+          z[N + rank] = d + fminf(fmaxf(v, -a.surface_eps), a.surface_eps);
+        }
+      } else {
+        for (int s = 0; s < M; ++s) z[N + s] = strat(d - a.surface_eps, d + a.stop_eps, s, M, u[N + s]);
+      }
+    }
+  } else {
+    // seeded: the same placement, every draw a function of (seed; purpose, draw; object, ray, bin)
+    const uint32_t tag = (uint32_t)a.draw << 3, ko = (uint32_t)a.obj_index;
+    const bool normal = !invalid && lab == 1;
+    const int n_u = invalid ? S : (normal ? N : S);
+    for (int s0 = 0; s0 < n_u; s0 += 4) {
+      float r4[4];
+      objrng::uniform4(a.seed, objrng::S_BINS_U | tag, ko, (uint32_t)i, (uint32_t)(s0 >> 2), r4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int s = s0 + j;
+        if (s >= n_u) break;
+        z[s] = invalid ? strat(a.min_bound, maxd, s, S, r4[j])
+               : s < N ? strat(a.min_bound, d - a.surface_eps, s, N, r4[j])
+                       : strat(d - a.surface_eps, d + a.stop_eps, s - N, M, r4[j]);
+      }
+    }
+    if (normal) {
+      const float sd = a.surface_eps / 3.0f;
+      for (int s = 0; s < M; ++s)
+        z[N + s] = fminf(fmaxf(sd * objrng::normal1(a.seed, objrng::S_BINS_G | tag, ko, (uint32_t)i, (uint32_t)s),
+                               -a.surface_eps), a.surface_eps);
+      for (int s = 1; s < M; ++s) {          // insertion sort in place (clipping is monotone: sort after it)
+        const float v = z[N + s];
+        int j = s - 1;
+        while (j >= 0 && z[N + j] > v) { z[N + j + 1] = z[N + j]; --j; }
+        z[N + j + 1] = v;
+      }
+      for (int s = 0; s < M; ++s) z[N + s] += d;
     }
   }
+  if (!a.out_pts) return;
   const float* o = origins_ws + (long)i * 3;
   const float* dr = dirs_ws + (long)i * 3;
   for (int s = 0; s < S; ++s) {
@@ -823,22 +891,31 @@ int objnerf_box_rays(int64_t P, const float* T_WC, const float* T_OC, const floa
 }
 
 int objnerf_box_points(int64_t n, int32_t n_bins, const float* origin, const float* dirs_W, const float* near,
-                       const float* far, const float* u, float* out_z, float* out_pts, void* stream) {
+                       const float* far, const float* u, uint64_t seed, uint32_t draw, float* out_z, float* out_pts,
+                       void* stream) {
   CLEAR_STALE();
-  if (n <= 0 || n_bins < 2 || !origin || !dirs_W || !near || !far || !u || !out_z || !out_pts) return OBJNERF_EINVAL;
+  if (n <= 0 || n_bins < 2 || !origin || !dirs_W || !near || !far || !out_z || !out_pts) return OBJNERF_EINVAL;
   const long total = (long)n * (n_bins - 1);
   hipLaunchKernelGGL(box_points_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (long)n,
-                     n_bins, origin, dirs_W, near, far, u, out_z, out_pts);
+                     n_bins, origin, dirs_W, near, far, u, seed, draw, out_z, out_pts);
   CHECK_LAUNCH();
   return OBJNERF_OK;
 }
 
+// the injected draws come all together or not at all; seeded keyframes need kf_meta; points or origins + directions
+static bool sample_args_ok(const objnerf_sample_args* a) {
+  const int n_inj = (a->u_w != nullptr) + (a->u_h != nullptr) + (a->u != nullptr) + (a->g != nullptr);
+  if (n_inj != 0 && n_inj != 4) return false;
+  if (!a->kf_ids && (n_inj != 0 || !a->kf_meta)) return false;
+  if (!a->out_pts && (!a->out_origins || !a->out_dirs)) return false;
+  if ((a->out_origins != nullptr) != (a->out_dirs != nullptr)) return false;
+  return a->rays_dir_cache && a->out_rgb && a->out_depth && a->out_valid && a->out_labels && a->out_z &&
+         a->max_depth_ws && a->n_frames > 0 && a->n_px > 0 && a->n_cam2surf > 0 && a->n_bins > 0;
+}
+
 int objnerf_sample_rays(const objnerf_sample_args* a, void* stream) {
   CLEAR_STALE();
-  if (!a || !a->rgbs || !a->depth || !a->t_wc || !a->bbox || !a->rays_dir_cache || !a->kf_ids || !a->u_w || !a->u_h ||
-      !a->u || !a->g || !a->out_rgb || !a->out_depth || !a->out_valid || !a->out_labels || !a->out_z || !a->out_pts ||
-      !a->max_depth_ws || a->n_frames <= 0 || a->n_px <= 0 || a->n_cam2surf <= 0 || a->n_bins <= 0)
-    return OBJNERF_EINVAL;
+  if (!a || !a->rgbs || !a->depth || !a->t_wc || !a->bbox || !sample_args_ok(a)) return OBJNERF_EINVAL;
   const int n = a->n_frames * a->n_px;
   hipStream_t st = (hipStream_t)stream;
   // (max_depth_ws[0] = the batch depth maximum, then the world-frame origins / directions between the passes)
@@ -863,10 +940,7 @@ int objnerf_ingest_frame(int32_t W, int32_t H, const uint8_t* rgb, const float* 
 
 int objnerf_sample_rays_stacked(const objnerf_sample_args* a, int32_t K, const objnerf_kf_store* table, void* stream) {
   CLEAR_STALE();
-  if (!a || !table || K <= 0 || K > 65535 || !a->rays_dir_cache || !a->kf_ids || !a->u_w || !a->u_h || !a->u || !a->g ||
-      !a->out_rgb || !a->out_depth || !a->out_valid || !a->out_labels || !a->out_z || !a->out_pts || !a->max_depth_ws ||
-      a->n_frames <= 0 || a->n_px <= 0 || a->n_cam2surf <= 0 || a->n_bins <= 0)
-    return OBJNERF_EINVAL;
+  if (!a || !table || K <= 0 || K > 65535 || !sample_args_ok(a)) return OBJNERF_EINVAL;
   const int n = a->n_frames * a->n_px;
   hipStream_t st = (hipStream_t)stream;
   // the K depth maxima sit (1 + 6 n) floats apart: clearing the whole scratch is one call

@@ -42,6 +42,6 @@ __device__ inline float normal1(uint64_t seed, uint32_t stream, uint32_t a, uint
   return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
 }
 
-enum Stream : uint32_t { S_KEYFRAME = 1, S_PIXEL_W = 2, S_PIXEL_H = 3, S_BINS_U = 4, S_BINS_G = 5, S_HELPER_U = 6, S_HELPER_G = 7 };
+enum Stream : uint32_t { S_KEYFRAME = 1, S_PIXEL_W = 2, S_PIXEL_H = 3, S_BINS_U = 4, S_BINS_G = 5, S_HELPER_U = 6, S_HELPER_G = 7, S_BOX_U = 0 };
 
 }  // namespace objrng

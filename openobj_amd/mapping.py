@@ -155,12 +155,12 @@ class IncrementalMapper:
 
     # ------------------------------------------------------------------ train.py:297-392
     def _pool_of(self, so: sceneObject, n_frames: int, n_samples: int):
-        rgb, depth, _valid, labels, pts, z, feat = so.get_training_samples(n_frames, n_samples,
-                                                                           self.cam_info.rays_dir_cache,
-                                                                           self.global_partfeat)
+        # seeded draws generated inside the sampler kernels; origins + directions instead of the point tensor
+        rgb, depth, _valid, labels, (origins, dirs), z, feat = so.get_training_samples(
+            n_frames, n_samples, self.cam_info.rays_dir_cache, self.global_partfeat, compact=True)
         n = n_frames * n_samples
         tdev = self.cfg.training_device
-        pool = {"pts": pts.reshape(n, pts.shape[-2], 3).to(tdev),
+        pool = {"origins": origins.to(tdev), "dirs": dirs.to(tdev),
                 "z": z.reshape(n, z.shape[-1]).to(tdev),
                 "gt_depth": depth.reshape(n).to(tdev),
                 "gt_rgb": rgb.reshape(n, 3).to(tdev).float() / 255.0,
@@ -184,11 +184,11 @@ class IncrementalMapper:
         if self._sampler_ids != tuple(self.obj_dict):
             self._sampler = StackedSampler(self.obj_dict.values())
             self._sampler_ids = tuple(self.obj_dict)
-        rgb, depth, _valid, labels, pts, z, feat = self._sampler.sample(
+        rgb, depth, _valid, labels, (origins, dirs), z, feat = self._sampler.sample(
             cfg.n_iter_per_frame * cfg.win_size, cfg.n_samples_per_frame, self.cam_info.rays_dir_cache,
-            self.global_partfeat)
+            self.global_partfeat, compact=True)
         tdev = cfg.training_device
-        pool = {"pts": pts.to(tdev), "z": z.to(tdev), "gt_depth": depth.to(tdev),
+        pool = {"origins": origins.to(tdev), "dirs": dirs.to(tdev), "z": z.to(tdev), "gt_depth": depth.to(tdev),
                 "gt_rgb": rgb.to(tdev).float() / 255.0, "labels": labels.to(tdev)}
         if cfg.part_mode:
             pool["gt_feat"] = feat.to(tdev).float()

@@ -136,20 +136,26 @@ def box_rays(T_WC: torch.Tensor, T_OC: torch.Tensor, half_extent: torch.Tensor, 
     return dirs_W, near, far, hit.bool()
 
 
-def box_points(origin: torch.Tensor, dirs_W: torch.Tensor, near: torch.Tensor, far: torch.Tensor, u: torch.Tensor):
-    """Mid-points of the stratified bins of [near, far] (trainer.py:171-176): u [n, n_bins] ->
-    z_vals [n, n_bins-1], pts [n, n_bins-1, 3]."""
+def box_points(origin: torch.Tensor, dirs_W: torch.Tensor, near: torch.Tensor, far: torch.Tensor,
+               u: Optional[torch.Tensor] = None, n_bins: Optional[int] = None, seed: Optional[int] = None):
+    """Mid-points of the stratified bins of [near, far] (trainer.py:171-176): u [n, n_bins] (injected draws; None:
+    generated in the kernel under `seed` and a per-call counter, n_bins required) -> z_vals [n, n_bins-1],
+    pts [n, n_bins-1, 3]."""
     dirs_W = _req(dirs_W, torch.float32, "dirs_W")
     near = _req(near, torch.float32, "near")
     far = _req(far, torch.float32, "far")
-    u = _req(u, torch.float32, "u")
     dev = dirs_W.device
-    n, n_bins = u.shape
+    if u is not None:
+        u = _req(u, torch.float32, "u")
+        n, n_bins = u.shape
+    else:
+        n, n_bins = near.shape[0], int(n_bins)
     origin = origin.to(dev, torch.float32).contiguous()
     z = torch.empty(n, n_bins - 1, device=dev)
     pts = torch.empty(n, n_bins - 1, 3, device=dev)
-    check(lib().objnerf_box_points(n, n_bins, _ptr(origin), _ptr(dirs_W), _ptr(near), _ptr(far), _ptr(u), _ptr(z),
-                                   _ptr(pts), _stream()), "objnerf_box_points")
+    check(lib().objnerf_box_points(n, n_bins, _ptr(origin), _ptr(dirs_W), _ptr(near), _ptr(far), _ptr(u), _seed_of(seed),
+                                   0 if u is not None else _next_offset() & 0x1FFFFFFF, _ptr(z), _ptr(pts), _stream()),
+          "objnerf_box_points")
     return z, pts
 
 
@@ -431,12 +437,31 @@ def keyframe_table(stores) -> torch.Tensor:
     return torch.tensor(rows, dtype=torch.int64).to(stores[0][0].device)
 
 
+def _sample_common(K, n_frames, n_px, n_cam2surf, n_bins, dev, want_pts, record, stacked):
+    n, S = n_frames * n_px, n_cam2surf + n_bins
+    lead = (K,) if stacked else ()
+    o = {"rgb": torch.empty(*lead, n, 3, dtype=torch.uint8, device=dev), "depth": torch.empty(*lead, n, device=dev),
+         "valid": torch.empty(*lead, n, dtype=torch.uint8, device=dev),
+         "labels": torch.empty(*lead, n, dtype=torch.uint8, device=dev), "z": torch.empty(*lead, n, S, device=dev),
+         "pts": torch.empty(*lead, n, S, 3, device=dev) if want_pts else None,
+         "origins": None if want_pts else torch.empty(*lead, n, 3, device=dev),
+         "dirs": None if want_pts else torch.empty(*lead, n, 3, device=dev),
+         "kf": torch.empty(*lead, n_frames, dtype=torch.int64, device=dev) if record else None,
+         "px": torch.empty(*lead, n, 2, dtype=torch.int32, device=dev) if record else None,
+         "ws": torch.empty(*lead, 1 + 6 * n, device=dev)}
+    return o
+
+
+def _seed_of(seed):
+    return (torch.initial_seed() if seed is None else int(seed)) & (2 ** 64 - 1)
+
+
 def sample_rays_stacked(table: torch.Tensor, F: int, W: int, H: int, rays_dir_cache, kf_ids, u_w, u_h, u, g,
                         n_cam2surf: int, n_bins: int, surface_eps: float, stop_eps: float, min_bound: float = 0.0,
                         obj_center: float = 0.0):
-    """sample_rays for K objects in one launch chain: kf_ids [K, n_frames], u_w / u_h [K, n_frames, n_px],
-    u [K, n, N+M], g [K, n, M].  Returns the STACKED batch tensors (rgb u8 [K,n,3], depth [K,n], valid [K,n] bool,
-    labels u8 [K,n], pts [K,n,S,3], z [K,n,S])."""
+    """sample_rays for K objects in one launch chain, INJECTED draws: kf_ids [K, n_frames], u_w / u_h
+    [K, n_frames, n_px], u [K, n, N+M], g [K, n, M].  Returns the STACKED batch tensors (rgb u8 [K,n,3], depth [K,n],
+    valid [K,n] bool, labels u8 [K,n], pts [K,n,S,3], z [K,n,S])."""
     table = _req(table, torch.int64, "table")
     rays_dir_cache = _req(rays_dir_cache, torch.float32, "rays_dir_cache")
     kf_ids = _req(kf_ids, torch.int64, "kf_ids")
@@ -449,19 +474,60 @@ def sample_rays_stacked(table: torch.Tensor, F: int, W: int, H: int, rays_dir_ca
     S = n_cam2surf + n_bins
     if u.shape != (K, n, S) or g.shape != (K, n, n_bins):
         raise ObjnerfError("sample_rays_stacked: u / g shapes")
-    dev = table.device
-    out_rgb = torch.empty(K, n, 3, dtype=torch.uint8, device=dev)
-    out_depth = torch.empty(K, n, device=dev)
-    out_valid = torch.empty(K, n, dtype=torch.uint8, device=dev)
-    out_labels = torch.empty(K, n, dtype=torch.uint8, device=dev)
-    out_z = torch.empty(K, n, S, device=dev)
-    out_pts = torch.empty(K, n, S, 3, device=dev)
-    ws = torch.empty(K, 1 + 6 * n, device=dev)
+    o = _sample_common(K, n_frames, n_px, n_cam2surf, n_bins, table.device, True, False, True)
     a = SampleArgs(F, W, H, n_frames, n_px, n_cam2surf, n_bins, 0, surface_eps, stop_eps, min_bound, obj_center,
                    None, None, None, None, _ptr(rays_dir_cache), _ptr(kf_ids), _ptr(u_w), _ptr(u_h), _ptr(u), _ptr(g),
-                   _ptr(out_rgb), _ptr(out_depth), _ptr(out_valid), _ptr(out_labels), _ptr(out_z), _ptr(out_pts), _ptr(ws))
+                   _ptr(o["rgb"]), _ptr(o["depth"]), _ptr(o["valid"]), _ptr(o["labels"]), _ptr(o["z"]), _ptr(o["pts"]),
+                   _ptr(o["ws"]), 0, 0, 0, None, None, None, None, None)
     check(lib().objnerf_sample_rays_stacked(C.byref(a), K, _ptr(table), _stream()), "objnerf_sample_rays_stacked")
-    return out_rgb, out_depth, out_valid.bool(), out_labels, out_pts, out_z
+    return o["rgb"], o["depth"], o["valid"].bool(), o["labels"], o["pts"], o["z"]
+
+
+def sample_rays_seeded(stores, F: int, W: int, H: int, rays_dir_cache, kf_meta: torch.Tensor, n_frames: int, n_px: int,
+                       n_cam2surf: int, n_bins: int, surface_eps: float, stop_eps: float, min_bound: float = 0.0,
+                       obj_center: float = 0.0, seed: Optional[int] = None, draw: Optional[int] = None,
+                       obj_index: int = 0, want_pts: bool = False, record: bool = False,
+                       kf_ids: Optional[torch.Tensor] = None) -> Dict[str, Optional[torch.Tensor]]:
+    """The sampler with its random numbers generated in the kernels (Philox keyed on seed / draw / object / ray / bin;
+    nothing random is stored).  stores: a keyframe table [K, 4] (ops.keyframe_table -> stacked call, tensors
+    [K, ...]) or the four store tensors of ONE object (tensors without the leading K).  kf_meta int32 [K, 4] | [4]:
+    n_keyframes, the slots of the latest two keyframes (-1 while n_keyframes <= 2), the object's random-stream id
+    (without kf_meta: obj_index (+ k)); kf_ids overrides the seeded
+    keyframe choice.  want_pts = False returns origins / dirs / z -- the pts == NULL form of ops.train_step, the
+    [.., n, S, 3] point tensor is never written; record = True adds the drawn keyframes `kf` and pixels `px`.
+    Returns a dict: rgb u8, depth, valid (bool), labels u8, z, pts | origins + dirs, kf, px."""
+    stacked = torch.is_tensor(stores)
+    rays_dir_cache = _req(rays_dir_cache, torch.float32, "rays_dir_cache")
+    kf_meta = _req(kf_meta, torch.int32, "kf_meta") if kf_meta is not None else None
+    kf_ids = _req(kf_ids, torch.int64, "kf_ids") if kf_ids is not None else None
+    if stacked:
+        table = _req(stores, torch.int64, "table")
+        K, dev = table.shape[0], table.device
+        if (kf_meta is not None and kf_meta.shape != (K, 4)) or (kf_ids is not None and kf_ids.shape != (K, n_frames)):
+            raise ObjnerfError("sample_rays_seeded: kf_meta / kf_ids do not match the table")
+        ptrs = [None] * 4
+    else:
+        rgbs, depth, t_wc, bbox = stores
+        ptrs = [_ptr(_req(rgbs, torch.uint8, "rgbs_batch")), _ptr(_req(depth, torch.float32, "depth_batch")),
+                _ptr(_req(t_wc, torch.float32, "t_wc_batch")), _ptr(_req(bbox, torch.float32, "bbox"))]
+        K, dev = 1, rgbs.device
+    if kf_meta is None and kf_ids is None:
+        raise ObjnerfError("sample_rays_seeded: kf_meta or kf_ids")
+    o = _sample_common(K, n_frames, n_px, n_cam2surf, n_bins, dev, want_pts, record, stacked)
+    a = SampleArgs(F, W, H, n_frames, n_px, n_cam2surf, n_bins, int(obj_index), surface_eps, stop_eps, min_bound,
+                   obj_center, *ptrs, _ptr(rays_dir_cache), _ptr(kf_ids), None, None, None, None,
+                   _ptr(o["rgb"]), _ptr(o["depth"]), _ptr(o["valid"]), _ptr(o["labels"]), _ptr(o["z"]), _ptr(o["pts"]),
+                   _ptr(o["ws"]), _seed_of(seed), (_next_offset() if draw is None else int(draw)) & 0x1FFFFFFF, 0,
+                   _ptr(kf_meta), _ptr(o["kf"]), _ptr(o["px"]), _ptr(o["origins"]), _ptr(o["dirs"]))
+    if stacked:
+        check(lib().objnerf_sample_rays_stacked(C.byref(a), K, _ptr(table), _stream()), "objnerf_sample_rays_stacked")
+    else:
+        check(lib().objnerf_sample_rays(C.byref(a), _stream()), "objnerf_sample_rays")
+    if kf_ids is not None and record:
+        o["kf"] = kf_ids
+    o["valid"] = o["valid"].bool()
+    del o["ws"]
+    return o
 
 
 def rays_dirs(W: int, H: int, fx: float, fy: float, cx: float, cy: float, device) -> torch.Tensor:
@@ -499,7 +565,8 @@ def sample_rays(rgbs_batch, depth_batch, t_wc_batch, bbox, rays_dir_cache, kf_id
     a = SampleArgs(F, W, H, n_frames, n_px, n_cam2surf, n_bins, 0, surface_eps, stop_eps, min_bound, obj_center,
                    _ptr(rgbs_batch), _ptr(depth_batch), _ptr(t_wc_batch), _ptr(bbox), _ptr(rays_dir_cache),
                    _ptr(kf_ids), _ptr(u_w), _ptr(u_h), _ptr(u), _ptr(g), _ptr(out_rgb), _ptr(out_depth),
-                   _ptr(out_valid), _ptr(out_labels), _ptr(out_z), _ptr(out_pts), _ptr(ws))
+                   _ptr(out_valid), _ptr(out_labels), _ptr(out_z), _ptr(out_pts), _ptr(ws), 0, 0, 0, None, None, None,
+                   None, None)
     check(lib().objnerf_sample_rays(C.byref(a), _stream()), "objnerf_sample_rays")
     return out_rgb, out_depth, out_valid.bool(), out_labels, out_pts, out_z
 

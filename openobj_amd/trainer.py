@@ -77,8 +77,8 @@ class Trainer:
         self.dirs_W = dirs_W[hit]
         self.origins = T_WC[:3, 3].to(dev).expand(n_rays, 3)
         near_h, far_h = near[hit].contiguous(), far[hit].contiguous()
-        u = torch.rand(n_rays, n_bins, device=dev) if draws is None else torch.as_tensor(draws).to(dev)
-        self.z_vals, self.input_pcs = ops.box_points(T_WC[:3, 3], self.dirs_W.contiguous(), near_h, far_h, u)
+        u = None if draws is None else torch.as_tensor(draws).to(dev)     # None: drawn inside the kernel (seeded)
+        self.z_vals, self.input_pcs = ops.box_points(T_WC[:3, 3], self.dirs_W.contiguous(), near_h, far_h, u, n_bins)
         return hit, near_h, far_h
 
     def meshing(self, *a, **k):

@@ -171,19 +171,46 @@ class sceneObject:
             return torch.cat([ids, torch.tensor(self.lastest_kf_queue[-2:], dtype=torch.long, device=dev)])
         return torch.randint(low=0, high=self.n_keyframes, size=(n_frames,), dtype=torch.long, device=dev)
 
-    def get_training_samples(self, n_frames, n_samples, cached_rays_dir, global_partfeat=None, draws=None):
+    def kf_meta(self):
+        """[n_keyframes, slot of the second-latest keyframe, slot of the latest (-1, -1 while n_keyframes <= 2), object
+        id]: what the seeded sampler needs to choose keyframes as draw_keyframe_ids does, and the object's
+        random-stream id."""
+        return [self.n_keyframes] + (list(self.lastest_kf_queue[-2:]) if self.n_keyframes > 2 else [-1, -1]) + \
+               [int(self.obj_id) & 0x7FFFFFFF]
+
+    def _partfeat(self, kf, px, global_partfeat):
+        """vmap.py:437-452 from the drawn keyframes kf [n_frames] and pixels px [n, 2] (floor(idx / part_down) of the
+        float index equals the integer division of its truncation)."""
+        use_frame = torch.tensor(self.use_frame).to(kf.device)
+        n_px = px.shape[0] // kf.shape[0]
+        fid = (use_frame[kf] / self.stride).long().repeat_interleave(n_px)
+        pd = int(self.part_down)
+        return global_partfeat[fid, torch.div(px[:, 0].long(), pd, rounding_mode="floor"),
+                               torch.div(px[:, 1].long(), pd, rounding_mode="floor")]
+
+    def get_training_samples(self, n_frames, n_samples, cached_rays_dir, global_partfeat=None, draws=None, seed=None,
+                             compact=False):
         """Returns the reference's 7-tuple (rgb u8, depth, valid_depth_mask[flat], obj_labels[flat] u8,
-        input_pcs, sampled_z, sampled_partfeat).  `draws` = dict(kf_ids, u_w, u_h, u, g) injects the
-        random numbers; otherwise they are drawn on the device (torch generator)."""
+        input_pcs, sampled_z, sampled_partfeat).  `draws` = dict(kf_ids, u_w, u_h, u, g) injects the reference's
+        random numbers (exact parity); otherwise every draw is generated inside the sampler kernels (Philox under
+        `seed`, default torch.initial_seed(), and a per-call counter) and no random tensor exists.
+        compact (seeded form only): input_pcs is returned as the pair (origins [n,3], dirs [n,3]) -- the point tensor
+        is never written, ops.train_step forms the points in registers."""
         dev = self.data_device
         N, M = self.n_bins_cam2surface, self.n_bins
         n = n_frames * n_samples
         if draws is None:
-            draws = dict(kf_ids=self.draw_keyframe_ids(n_frames),
-                         u_w=torch.rand(n_frames, n_samples, device=dev),
-                         u_h=torch.rand(n_frames, n_samples, device=dev),
-                         u=torch.rand(n, N + M, device=dev),
-                         g=torch.empty(n, M, device=dev).normal_(mean=0., std=self.surface_eps / 3.))
+            want_feat = self.part_mode and global_partfeat is not None
+            meta = torch.tensor(self.kf_meta(), dtype=torch.int32).to(dev)
+            o = ops.sample_rays_seeded(self.keyframe_store(), self.keyframe_buffer_size, self.frames_width,
+                                       self.frames_height, cached_rays_dir, meta, n_frames, n_samples, N, M,
+                                       self.surface_eps, self.stop_eps, float(self.min_bound), float(self.obj_center),
+                                       seed=seed, want_pts=not compact, record=want_feat)
+            partfeat = self._partfeat(o["kf"], o["px"], global_partfeat) if want_feat else None
+            S = N + M
+            pcs = (o["origins"], o["dirs"]) if compact else o["pts"].reshape(n_frames, n_samples, S, 3)
+            return (o["rgb"].reshape(n_frames, n_samples, 3), o["depth"].reshape(n_frames, n_samples), o["valid"],
+                    o["labels"], pcs, o["z"].reshape(n_frames, n_samples, S), partfeat)
         rgb, depth, valid, labels, pts, z = ops.sample_rays(
             self.rgbs_batch, self.depth_batch, self.t_wc_batch, self.bbox, cached_rays_dir, draws["kf_ids"],
             draws["u_w"], draws["u_h"], draws["u"], draws["g"], N, M, self.surface_eps, self.stop_eps,
@@ -346,11 +373,30 @@ class StackedSampler:
                     u_h=torch.rand(K, n_frames, n_samples, device=dev), u=torch.rand(K, n, N + M, device=dev),
                     g=torch.empty(K, n, M, device=dev).normal_(mean=0., std=o.surface_eps / 3.))
 
-    def sample(self, n_frames, n_samples, cached_rays_dir, global_partfeat=None, draws=None):
-        """-> (rgb u8 [K,n,3], depth [K,n], valid [K,n], labels u8 [K,n], pts [K,n,S,3], z [K,n,S], partfeat | None)"""
+    def sample(self, n_frames, n_samples, cached_rays_dir, global_partfeat=None, draws=None, seed=None, compact=False):
+        """-> (rgb u8 [K,n,3], depth [K,n], valid [K,n], labels u8 [K,n], pts [K,n,S,3], z [K,n,S], partfeat | None)
+        draws: the injected random numbers of draw() (exact parity with the reference's generator); default: seeded,
+        generated inside the kernels (see sceneObject.get_training_samples).  compact (seeded only): `pts` is the
+        pair (origins [K,n,3], dirs [K,n,3])."""
         o = self.objs[0]
         if draws is None:
-            draws = self.draw(n_frames, n_samples)
+            dev = o.data_device
+            K = len(self.objs)
+            want_feat = o.part_mode and global_partfeat is not None
+            meta = torch.tensor([x.kf_meta() for x in self.objs], dtype=torch.int32).to(dev)   # one small H2D copy
+            r = ops.sample_rays_seeded(self.table, o.keyframe_buffer_size, o.frames_width, o.frames_height,
+                                       cached_rays_dir, meta, n_frames, n_samples, o.n_bins_cam2surface, o.n_bins,
+                                       o.surface_eps, o.stop_eps, float(o.min_bound), float(o.obj_center), seed=seed,
+                                       want_pts=not compact, record=want_feat)
+            partfeat = None
+            if want_feat:                                                       # vmap.py:437-452, all objects at once
+                use = torch.tensor(np.stack([x.use_frame for x in self.objs])).to(dev)            # [K, F]
+                fid = (torch.gather(use, 1, r["kf"]) / o.stride).long().repeat_interleave(n_samples, dim=1)   # [K, n]
+                pd = int(o.part_down)
+                partfeat = global_partfeat[fid, torch.div(r["px"][..., 0].long(), pd, rounding_mode="floor"),
+                                           torch.div(r["px"][..., 1].long(), pd, rounding_mode="floor")]
+            pcs = (r["origins"], r["dirs"]) if compact else r["pts"]
+            return r["rgb"], r["depth"], r["valid"], r["labels"], pcs, r["z"], partfeat
         rgb, depth, valid, labels, pts, z = ops.sample_rays_stacked(
             self.table, o.keyframe_buffer_size, o.frames_width, o.frames_height, cached_rays_dir, draws["kf_ids"],
             draws["u_w"], draws["u_h"], draws["u"], draws["g"], o.n_bins_cam2surface, o.n_bins, o.surface_eps,
