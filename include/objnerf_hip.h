@@ -7,7 +7,11 @@
  * that call sequence to; each entry point cites the reference interface it replaces.  All
  * pointers are DEVICE pointers unless named host_*; all tensors are contiguous row-major fp32
  * unless stated; outputs and workspaces are caller-allocated; nothing here allocates, frees or
- * synchronises; every launch goes to `stream` (a hipStream_t passed as void*).  Return value:
+ * synchronises, and every launch goes to `stream` (a hipStream_t passed as void*) -- with ONE explicit
+ * exception: an objnerf_context (below) holds helper streams and events the caller creates and hands to
+ * objnerf_train_step so that the layer-wise path can run independent GEMMs side by side; its work is
+ * forked from and joined back into `stream` with events, so `stream` order still describes completion.
+ * Kernel attributes (the opt-in to > 64 KB LDS) are set once per device, thread-safely, at first use.  Return value:
  * 0 on success, a negative OBJNERF_E* code otherwise (the reference's assert / exit(-1) paths).
  *
  * Symbols (paths relative to the reference's objnerf/):
@@ -278,6 +282,12 @@ int objnerf_label_counts(int32_t K, int32_t R, const uint8_t* labels, int32_t* c
 #define OBJNERF_TRAIN_LAYERWISE 2   /* mode bit: take the layer-wise (any width) path even for hidden 32 / S <= 64 --
                                      * a second, independent implementation of the same iteration; the tests use
                                      * it to cross-check the fused kernel at sizes no CPU oracle reaches. */
+/* Helper streams + events for objnerf_train_step (see the preamble): create on the device that will run the steps,
+ * destroy when no step using it is in flight.  The only entries of the library that create or free anything. */
+struct objnerf_context;
+int objnerf_context_create(struct objnerf_context** out);
+int objnerf_context_destroy(struct objnerf_context* ctx);
+
 typedef struct objnerf_train_args {
   int32_t K, R, S, mode;
   float color_scaling, opacity_scaling, feat_scaling, obj_center;
@@ -293,6 +303,9 @@ typedef struct objnerf_train_args {
                           * the oracle on the SAME branches (an fp32 implementation and the reference legitimately
                           * disagree about inputs within rounding of zero; tests/parity_util.py).  Not with
                           * OBJNERF_TRAIN_BF16. */
+  struct objnerf_context* context;   /* NULL: everything on `stream`.  Else the layer-wise path (hidden != 32,
+                                      * S > 64, OBJNERF_TRAIN_LAYERWISE) forks its weight-gradient GEMMs and the feature
+                                      * preparation onto the context's streams; one context serves one call at a time. */
 } objnerf_train_args;
 size_t objnerf_train_workspace_bytes(const objnerf_net* net, int32_t K, int32_t R, int32_t S,
                                      int32_t with_feat);

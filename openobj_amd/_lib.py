@@ -80,12 +80,14 @@ class TrainArgs(C.Structure):
                 ("counts", C.c_void_p), ("flags", C.c_void_p),
                 ("grads", C.c_void_p), ("loss_terms", C.c_void_p), ("status", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
-                ("relu_masks", C.c_void_p)]
+                ("relu_masks", C.c_void_p), ("context", C.c_void_p)]
 
 
 # name -> (restype, argtypes); every symbol include/objnerf_hip.h declares
 SIGNATURES = {
     "objnerf_abi_version": (C.c_int, []),
+    "objnerf_context_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "objnerf_context_destroy": (C.c_int, [C.c_void_p]),
     "objnerf_param_layout": (C.c_int64, [C.POINTER(Net), C.POINTER(C.c_int64)]),
     "objnerf_rays_dirs": (C.c_int, [C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float,
                                     C.c_void_p, C.c_void_p]),

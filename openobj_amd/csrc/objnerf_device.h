@@ -4,6 +4,16 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
+// Kernel attributes (the opt-in to more than 64 KB of dynamic LDS) belong to a device: set them once per device of
+// this process, thread-safely.  (Every lambda has its own type, hence every call site its own set of flags.)
+template <class F>
+inline void objnerf_once_per_device(F&& fn) {
+  static std::once_flag flags[64];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::call_once(flags[dev & 63], fn);
+}
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

@@ -788,24 +788,20 @@ __global__ __launch_bounds__(512) void mlp_bwd_small_kernel(const BwdSmall a) {
 
 template <int RT>
 static void launch_bwd_small(hipStream_t st, const BwdSmall& f, int K) {
-  static bool attr_done = false;
-  if (!attr_done) {
+  objnerf_once_per_device([] {
     (void)hipFuncSetAttribute((const void*)mlp_bwd_small_kernel<RT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)bs_lds_bytes<RT>());
-    attr_done = true;
-  }
+  });
   dim3 grid((unsigned)((f.n + 16 * RT - 1) / (16 * RT)), (unsigned)K);
   hipLaunchKernelGGL(mlp_bwd_small_kernel<RT>, grid, dim3(512), bs_lds_bytes<RT>(), st, f);
 }
 
 template <int RT>
 static void launch_fwd_small(hipStream_t st, const FwdSmall& f, int K) {
-  static bool attr_done = false;
-  if (!attr_done) {
+  objnerf_once_per_device([] {
     (void)hipFuncSetAttribute((const void*)mlp_fwd_small_kernel<RT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)fs_lds_bytes<RT>());
-    attr_done = true;
-  }
+  });
   dim3 grid((unsigned)((f.n + 16 * RT - 1) / (16 * RT)), (unsigned)K);
   hipLaunchKernelGGL(mlp_fwd_small_kernel<RT>, grid, dim3(512), fs_lds_bytes<RT>(), st, f);
 }
@@ -1098,28 +1094,50 @@ size_t train_workspace_bytes(const objnerf_net* net, int K, int R, int S, int fe
   return w.bytes + 256;
 }
 
-namespace {
-// helper stream + events of this host thread (created once; non-blocking so it never syncs with the null stream)
-struct Side {
+}  // namespace objgen
+
+// objnerf_context: the helper streams + events of the layer-wise path, owned by the CALLER (objnerf_context_create /
+// _destroy are the only entries of the library that create anything).  Without one every launch stays on `stream`.
+struct objnerf_context {
   static constexpr int NEV = 16, NS = 3;
   hipStream_t s = nullptr;             // = all[0]
   hipStream_t all[NS];                 // small batches: the independent weight-gradient GEMMs spread over three streams
   hipEvent_t ev[NEV];
   hipEvent_t done, done_all[NS];
+  bool own = false;                    // false: single-stream stand-in (all[] = the caller's stream, no events)
 };
-Side& side_stream() {
-  static thread_local Side sd;
-  if (!sd.s) {
-    for (int i = 0; i < Side::NS; ++i) {
-      (void)hipStreamCreateWithFlags(&sd.all[i], hipStreamNonBlocking);
-      (void)hipEventCreateWithFlags(&sd.done_all[i], hipEventDisableTiming);
-    }
-    sd.s = sd.all[0];
-    for (int i = 0; i < Side::NEV; ++i) (void)hipEventCreateWithFlags(&sd.ev[i], hipEventDisableTiming);
-    (void)hipEventCreateWithFlags(&sd.done, hipEventDisableTiming);
+
+extern "C" int objnerf_context_create(objnerf_context** out) {
+  if (!out) return OBJNERF_EINVAL;
+  objnerf_context* c = new objnerf_context();
+  bool ok = true;
+  for (int i = 0; i < objnerf_context::NS; ++i) {   // non-blocking: never synchronises with the null stream
+    ok &= hipStreamCreateWithFlags(&c->all[i], hipStreamNonBlocking) == hipSuccess;
+    ok &= hipEventCreateWithFlags(&c->done_all[i], hipEventDisableTiming) == hipSuccess;
   }
-  return sd;
+  for (int i = 0; i < objnerf_context::NEV; ++i) ok &= hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming) == hipSuccess;
+  ok &= hipEventCreateWithFlags(&c->done, hipEventDisableTiming) == hipSuccess;
+  c->s = c->all[0];
+  c->own = true;
+  if (!ok) { delete c; return OBJNERF_ELAUNCH; }
+  *out = c;
+  return OBJNERF_OK;
 }
+
+extern "C" int objnerf_context_destroy(objnerf_context* c) {
+  if (!c) return OBJNERF_OK;
+  if (c->own) {
+    for (int i = 0; i < objnerf_context::NS; ++i) { (void)hipStreamDestroy(c->all[i]); (void)hipEventDestroy(c->done_all[i]); }
+    for (int i = 0; i < objnerf_context::NEV; ++i) (void)hipEventDestroy(c->ev[i]);
+    (void)hipEventDestroy(c->done);
+  }
+  delete c;
+  return OBJNERF_OK;
+}
+
+namespace objgen {
+namespace {
+typedef objnerf_context Side;
 struct Bf16Scope {
   explicit Bf16Scope(bool on) { t_bf16_operands = on; }
   ~Bf16Scope() { t_bf16_operands = false; }
@@ -1179,10 +1197,15 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
 
   // helper stream: work that only READS what the main chain produced (or, for the feature preparation below, only
   // parameters and inputs) runs beside it; fork = the side stream waits for everything enqueued on `st` so far
-  Side& sd = side_stream();
+  Side single;                                   // no context: one stream, program order replaces every event
+  for (int i = 0; i < Side::NS; ++i) single.all[i] = st;
+  single.s = st;
+  Side& sd = a->context ? *(Side*)a->context : single;
+  const bool multi = sd.own;
   int fk = 0;
   const int n_side = 1;
   auto fork = [&]() {
+    if (!multi) return;
     (void)hipEventRecord(sd.ev[fk], st);
     for (int i = 0; i < n_side; ++i) (void)hipStreamWaitEvent(sd.all[i], sd.ev[fk], 0);
     fk = (fk + 1) % Side::NEV;
@@ -1206,7 +1229,7 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
     gemm(ss, K, (int)R, H, C, a->gt_feat, C, 1, R * C, P + off[16], H, 1, ps, w.rayin, H + 2, 1, R * (H + 2));
     hipLaunchKernelGGL(featg_rowstats_kernel, dim3((unsigned)((R + 15) / 16), K), dim3(256), 0, ss, P, ps, (int)off[17], C,
                        (int)R, H + 2, a->gt_feat, w.rayin);
-    (void)hipEventRecord(sd.done, ss);
+    if (multi) (void)hipEventRecord(sd.done, ss);
   }
 
   // ---- forward
@@ -1262,7 +1285,7 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
         hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, nb, H, acts[l],
                            a->relu_masks, l);
   }
-  if (feat) (void)hipStreamWaitEvent(st, sd.done, 0);      // the feature preparation (side stream) is needed from here
+  if (feat && multi) (void)hipStreamWaitEvent(st, sd.done, 0);      // the feature preparation (side stream) is needed from here
   // ---- loss + d(alpha, color, clip)      (loss.py:5-103)
   objnerf_loss_args la;
   la.K = K; la.R = a->R; la.S = a->S; la.C = C;
@@ -1392,7 +1415,7 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
                      w.dBpe);
   hipLaunchKernelGGL(copy_cols_kernel, dim3((unsigned)((K * 63 + 255) / 256)), dim3(256), 0, st, (long)K, 63, w.dBpe, 63L,
                      G + off[18], ps);
-  for (int i = 0; i < n_side; ++i) {            // join: the caller's stream continues after the weight gradients
+  for (int i = 0; multi && i < n_side; ++i) {   // join: the caller's stream continues after the weight gradients
     (void)hipEventRecord(sd.done_all[i], sd.all[i]);
     (void)hipStreamWaitEvent(st, sd.done_all[i], 0);
   }

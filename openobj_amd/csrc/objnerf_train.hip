@@ -958,8 +958,8 @@ int eval_launch(const objnerf_net* net, int32_t K, int64_t N, const float* param
   hipStream_t st = (hipStream_t)stream;
   const bool feat = out_hfeat != nullptr;
   const size_t lds_bytes = (size_t)obj32n::img_floats(feat) * 4;
-  static std::once_flag eval_attr;         // the image with the feature layer exceeds the 64 KB default
-  std::call_once(eval_attr, [] {
+  // the image with the feature layer exceeds the 64 KB default
+  objnerf_once_per_device([] {
     (void)hipFuncSetAttribute((const void*)eval_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               obj32n::img_floats(true) * 4);
     (void)hipFuncSetAttribute((const void*)eval_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1107,8 +1107,7 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
   (void)hipMemsetAsync(a->status, 0, sizeof(int), st);
 
   const size_t lds_bytes = (size_t)((feat ? W_FLOATS_FEAT : W_FLOATS_NOFEAT) + SM_FLOATS + STG_ROWS * STG_LD) * 4;
-  static std::once_flag attr;
-  std::call_once(attr, [] {
+  objnerf_once_per_device([] {
     (void)hipFuncSetAttribute((const void*)train_fused_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)((W_FLOATS_FEAT + SM_FLOATS + STG_ROWS * STG_LD) * 4));
     (void)hipFuncSetAttribute((const void*)train_fused_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -535,8 +535,7 @@ namespace objtrain {
 size_t fused32_lds_bytes() { return (size_t)LDS_FLOATS32 * 4; }
 
 void launch_train32(const TrainDev& d, void* stream) {
-  static std::once_flag attr;
-  std::call_once(attr, [] {
+  objnerf_once_per_device([] {
     const int n = (int)fused32_lds_bytes();
     (void)hipFuncSetAttribute((const void*)train_fused32_kernel<false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
     (void)hipFuncSetAttribute((const void*)train_fused32_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, n);

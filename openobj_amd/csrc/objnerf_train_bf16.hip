@@ -990,14 +990,12 @@ extern "C" int objnerf_debug_phase_bf16(unsigned long long* out_host) {
 #endif
 
 void launch_train_bf16(const TrainDev& d, void* stream, bool feat) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  objnerf_once_per_device([] {
     (void)hipFuncSetAttribute((const void*)train_fused_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)train_fused_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               LDS_BYTES);
-    attr_set = true;
-  }
+  });
   if (feat)
     hipLaunchKernelGGL(train_fused_bf16_kernel<true>, dim3(d.K * d.G), dim3(NTHR), LDS_BYTES, (hipStream_t)stream, d);
   else

@@ -281,6 +281,27 @@ def step_batch_loss(alpha, color, gt_depth, gt_rgb, labels, z, color_scaling=5.0
 LAYERWISE_WORKSPACE_BUDGET = 64 << 30      # bytes; the layer-wise path materialises activations per object chunk
 
 
+class StreamContext:
+    """objnerf_context: the helper streams + events the layer-wise path forks onto.  Created on the current device;
+    freed with the object (after a device synchronisation, so no step using it is in flight)."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib().objnerf_context_create(C.byref(h)), "objnerf_context_create")
+        self.handle = h
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            try:
+                torch.cuda.synchronize(self.device)
+                lib().objnerf_context_destroy(h)
+            except Exception:      # interpreter shutdown
+                pass
+
+
 class TrainWorkspace:
     """Caller-owned buffers of the fused training step, allocated once per (K,R,S).
 
@@ -304,6 +325,8 @@ class TrainWorkspace:
         if nbytes == 0:
             raise _lib.ObjnerfError("objnerf_train_workspace_bytes returned 0")
         self.nbytes = int(nbytes)
+        # the layer-wise path runs independent GEMMs side by side on the context's streams
+        self.context = StreamContext(dev) if (arena.net.hidden != 32 or S > 64 or layerwise) and dev.type == "cuda" else None
         self.buf = torch.empty(self.nbytes, dtype=torch.uint8, device=dev)
         self.grads = torch.zeros_like(arena.params)
         self.loss_terms = torch.zeros(K, 4, device=dev)
@@ -358,11 +381,12 @@ def train_step(arena: ParamArena, ws: TrainWorkspace, batch: Dict[str, torch.Ten
         if tuple(relu_masks.shape) != (K, R, S, 6, arena.net.hidden // 8):
             raise ObjnerfError("relu_masks must be uint8 [K,R,S,6,hidden/8]")
     kc = getattr(ws, "k_chunk", K)
+    ctx = ws.context.handle if getattr(ws, "context", None) is not None else None
     if kc >= K:
         a = TrainArgs(K, R, S, mode, color_scaling, opacity_scaling, feat_scaling, obj_center, _ptr(arena.params),
                       arena.p_stride, _ptr(arena.scale), _ptr(pts), _ptr(origins), _ptr(dirs), _ptr(z), _ptr(gt_depth),
                       _ptr(gt_rgb), _ptr(labels), _ptr(gt_feat), _ptr(counts), _ptr(flags), _ptr(ws.grads),
-                      _ptr(ws.loss_terms), _ptr(ws.status), _ptr(ws.buf), ws.nbytes, _ptr(relu_masks))
+                      _ptr(ws.loss_terms), _ptr(ws.status), _ptr(ws.buf), ws.nbytes, _ptr(relu_masks), ctx)
         check(lib().objnerf_train_step(C.byref(net), C.byref(a), st), "objnerf_train_step")
         return
     # layer-wise path, chunk of objects at a time (leading-dimension slices are contiguous views)
@@ -374,7 +398,7 @@ def train_step(arena: ParamArena, ws: TrainWorkspace, batch: Dict[str, torch.Ten
                       _ptr(sl(origins, k0, k1)), _ptr(sl(dirs, k0, k1)), _ptr(z[k0:k1]), _ptr(gt_depth[k0:k1]),
                       _ptr(gt_rgb[k0:k1]), _ptr(labels[k0:k1]), _ptr(sl(gt_feat, k0, k1)), _ptr(counts[k0:k1]),
                       _ptr(flags), _ptr(ws.grads[k0:k1]), _ptr(ws.loss_terms[k0:k1]), _ptr(ws.status_chunks[ci:ci + 1]),
-                      _ptr(ws.buf), ws.nbytes, _ptr(sl(relu_masks, k0, k1)))
+                      _ptr(ws.buf), ws.nbytes, _ptr(sl(relu_masks, k0, k1)), ctx)
         check(lib().objnerf_train_step(C.byref(net), C.byref(a), st), "objnerf_train_step")
     torch.amax(ws.status_chunks, dim=0, keepdim=True, out=ws.status)
 
@@ -647,27 +671,29 @@ def _next_offset() -> int:
 
 
 def stratified_bins(lo, hi, n_bins: int, n_rays: int, device, u: Optional[torch.Tensor] = None,
-                    seed: Optional[int] = None) -> torch.Tensor:
+                    seed: Optional[int] = None, draw: Optional[int] = None) -> torch.Tensor:
     """lo / hi: python scalars or [n_rays] tensors.  u: injected uniforms [n_rays, n_bins]; otherwise the counter-based
-    generator under `seed` (default: torch's initial seed) and a per-call offset."""
+    generator under `seed` (default: torch's initial seed) and the call counter `draw` (default: advances per call)."""
     lo_t = _req(lo.to(device), torch.float32, "min_depth") if torch.is_tensor(lo) else None
     hi_t = _req(hi.to(device), torch.float32, "max_depth") if torch.is_tensor(hi) else None
     u = _req(u, torch.float32, "u") if u is not None else None
     out = torch.empty(n_rays, n_bins, device=device)
     sd = torch.initial_seed() if seed is None else seed
     check(lib().objnerf_stratified_bins(n_rays, n_bins, _ptr(lo_t), 0.0 if lo_t is not None else float(lo), _ptr(hi_t),
-                                        0.0 if hi_t is not None else float(hi), _ptr(u), sd & (2 ** 64 - 1), _next_offset(),
+                                        0.0 if hi_t is not None else float(hi), _ptr(u), sd & (2 ** 64 - 1),
+                                        _next_offset() if draw is None else int(draw),
                                         _ptr(out), _stream()), "objnerf_stratified_bins")
     return out
 
 
 def normal_bins(depth: torch.Tensor, n_bins: int, delta: float, g: Optional[torch.Tensor] = None,
-                seed: Optional[int] = None) -> torch.Tensor:
+                seed: Optional[int] = None, draw: Optional[int] = None) -> torch.Tensor:
     depth = _req(depth, torch.float32, "depth")
     n_rays = depth.shape[0]
     g = _req(g, torch.float32, "g") if g is not None else None
     out = torch.empty(n_rays, n_bins, device=depth.device)
     sd = torch.initial_seed() if seed is None else seed
-    check(lib().objnerf_normal_bins(n_rays, n_bins, _ptr(depth), float(delta), _ptr(g), sd & (2 ** 64 - 1), _next_offset(),
-                                    _ptr(out), _stream()), "objnerf_normal_bins")
+    check(lib().objnerf_normal_bins(n_rays, n_bins, _ptr(depth), float(delta), _ptr(g), sd & (2 ** 64 - 1),
+                                    _next_offset() if draw is None else int(draw), _ptr(out), _stream()),
+          "objnerf_normal_bins")
     return out

@@ -375,3 +375,26 @@ def test_adamw_skips_gradless_groups_like_torch(dev):
         for i, (p, v) in enumerate(zip(ref_p, loop.arena.views())):
             assert maxerr(v, p.detach()) < 3e-7, (it, i, ops.TENSOR_NAMES[i])
     assert loop.opt.group_steps.tolist() == [3, 2, 2]
+
+
+def test_layerwise_step_with_and_without_stream_context(dev):
+    """objnerf_context is an optimisation, not a semantic: the layer-wise iteration on the caller's stream alone
+    (context NULL -- 'every launch goes to `stream`') and forked over a caller-created context agree (the split-K
+    atomics make the weight gradients order-dependent in the last bits)."""
+    from openobj_amd import init as obj_init
+    K, R, N, M = 3, 64, 2, 9
+    arena = ops.ParamArena(K, ops.NetShape(64, 512, 6), dev)
+    arena.load_stacked(obj_init.init_stacked(K, 64, 512, seed=5))
+    b = synthetic.random_batch(K, R, N, M, seed=12, feat_dim=512)
+    batch = {k: T(b[k]).to(dev) for k in ["pts", "z", "gt_depth", "gt_rgb", "labels", "gt_feat"]}
+    ws = ops.TrainWorkspace(arena, K, R, N + M, True)
+    assert ws.context is not None and ws.context.handle
+    ops.train_step(arena, ws, batch, with_feat=True)
+    torch.cuda.synchronize()
+    g_ctx, l_ctx = ws.grads.clone(), ws.loss_terms.clone()
+    ws.context = None
+    ws.grads.zero_()
+    ops.train_step(arena, ws, batch, with_feat=True)
+    torch.cuda.synchronize()
+    assert torch.equal(l_ctx, ws.loss_terms)
+    assert maxerr(g_ctx, ws.grads) <= 2e-6 * g_ctx.abs().max().item()
