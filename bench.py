@@ -183,7 +183,7 @@ def main():
                     help="do not also time the bf16 mode (reported as the `bf16_mode` object of the fp32 line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-psnr", action="store_true")
-    ap.add_argument("--psnr-seeds", type=int, default=64)
+    ap.add_argument("--psnr-seeds", type=int, default=128)
     ap.add_argument("--no-peak", action="store_true", help="skip the saturated-MFMA measurement")
     args = ap.parse_args()
 

@@ -72,23 +72,18 @@ def test_bf16_feature_step_close_to_fp32(golden, dev, shape):
         assert rel < 0.15, (i, ops.TENSOR_NAMES[i], rel)
 
 
-def test_bf16_psnr_matches_fp32_ensemble(golden, dev):
-    """Same fixture as test_train_loop_psnr_g9 (300 iterations from reference-initialised weights).  Training is
-    chaotic (sigma ~0.6 dB over weight seeds in fp32), so the two modes are compared as distributions over the
-    same 12 seeds.  Measured over 32 seeds (tools/psnr_ensemble.py): fp32 mean 34.14 / median 34.24 dB,
-    bf16 mean 34.07 / median 34.30 dB; the reference's own 6-seed ensemble has mean 33.91 dB."""
-    g = golden("g9_psnr_nofeat")
-    K, R, N, M, steps, eval_R, eval_S, scene_seed = [int(x) for x in g["meta"]]
-    scene = synthetic.EllipsoidScene.make(K, 512, seed=scene_seed)
-    ev = scene.eval_rays(eval_R, eval_S)
-    ens = {}
-    for mode in (False, True):
-        ens[mode] = np.array([_train_and_psnr(dev, scene, (K, R, N, M), 90 + i, steps, ev, bf16=mode)[0]
-                              for i in range(12)])
-    print("PSNR fp32", np.round(ens[False], 2), "bf16", np.round(ens[True], 2), "reference", np.round(g["psnr_ensemble"], 2))
-    assert abs(np.median(ens[True]) - np.median(ens[False])) < 0.4
-    assert abs(ens[True].mean() - ens[False].mean()) < 0.5
-    assert np.median(ens[True]) > np.median(g["psnr_ensemble"]) - 0.4
+def test_bf16_psnr_matches_reference_ensemble(dev):
+    """The bf16-operand mode is gated by reconstruction quality, not by 1e-4 parity: 300 iterations of the G9 scene from
+    the reference's initial weights, 128 weight seeds, against the reference's own 128-seed ensemble (fixture
+    g9_ensemble.npz).  Training is chaotic (sigma 0.6 dB over seeds), so the gate is the 99.9 % interval of the
+    difference of ensemble means (standard error 0.075 dB): a systematic loss of 0.25 dB or more fails."""
+    from openobj_amd import psnr_scene
+    ref = psnr_scene.reference_ensemble()
+    ens = psnr_scene.PsnrScene(dev).ensemble([int(x) for x in ref["seeds"]], bf16=True)
+    rep = psnr_scene.delta_report(ens, ref["psnr"])
+    print("bf16 PSNR delta vs reference ensemble:", rep)
+    assert abs(rep["delta_db"]) < 3.29 * rep["ci95_db"] / 1.96 < 0.26, rep
+    assert abs(rep["hip_std_db"] - rep["ref_std_db"]) < 0.2 and ens.min() > ref["psnr"].min() - 1.0, rep
 
 
 @pytest.mark.parametrize("feat", [False, True])
