@@ -176,7 +176,7 @@ def main():
                     help="skip the shared background network.  Default (do_bg = 1, room_0.json:21): every step also "
                          "trains it (hidden 128, n_per_optim_bg = 1200 rays split over the ranks, same samples per ray, "
                          "gradient all-reduce over RCCL), as train.py:447-463 does; `value` counts object rays only")
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+    ap.add_argument("--dtype", choices=["f32", "bf16", "fp16"], default="f32",
                     help="f32 = the reference's arithmetic (default, the headline line).  bf16 = opt-in mode: MFMA "
                          "operands rounded to bf16, fp32 accumulation / master weights / compositing / AdamW")
     ap.add_argument("--no-bf16-line", dest="bf16_line", action="store_false",
@@ -221,7 +221,7 @@ def main():
         K, K_total = hi - lo, wl["objects"]
     else:
         K, K_total = wl["objects"], wl["objects"] * world
-    bf16 = args.dtype == "bf16"
+    bf16 = {"f32": False, "bf16": True, "fp16": "fp16"}[args.dtype]      # ops.precision_bits
 
     arena = ops.ParamArena(K, ops.NetShape(Hd, 512, 6), dev)
     arena.load_stacked(obj_init.init_stacked(K, Hd, 512, seed=1000 + rank))
@@ -237,7 +237,7 @@ def main():
 
     class ObjLoop:                  # the object stack of this rank: fused step + AdamW over the arena
         def __init__(self):
-            self.ws = ops.TrainWorkspace(arena, K, R, S, feat)
+            self.ws = ops.TrainWorkspace(arena, K, R, S, feat, precision=bf16)
             self.opt = ooptim.ArenaAdamW(arena, lr=1e-3, weight_decay=0.013)
             self.mask = arena.has_grad_mask(feat)
             self.bf16 = False
@@ -310,7 +310,7 @@ def main():
         rays_per_step = K_total * R if wl["scaling"] == "strong" else K * R * world
         value = rays_per_step * args.steps / dt
         fpr = flop_per_ray(S, H=Hd, feat=feat)
-        fused = Hd == 32 and S <= 64
+        fused = Hd == 32 and S <= 64 and bf16 != "fp16"
         k32 = "train_fused_kernel<true, false>" if feat else ("train_fused32_kernel<false, 64>" if S == 64
                                                                else "train_fused32_kernel<false, 0>")
         kbf = f"train_fused_bf16_kernel<{'true' if feat else 'false'}>"

@@ -279,6 +279,12 @@ int objnerf_label_counts(int32_t K, int32_t R, const uint8_t* labels, int32_t* c
                                 * train.py:74) -- an opt-in throughput mode gated by PSNR.  Fused kernel: hidden 32,
                                 * S <= 64, no feature loss (else OBJNERF_ENOTSUP); layer-wise path (other widths,
                                 * longer rays): bf16 GEMM operands, any configuration. */
+#define OBJNERF_TRAIN_FP16 4   /* mode bit: the layer-wise path with fp16 GEMM operands (v_mfma_f32_16x16x32_f16), fp32
+                                * accumulate, fp32 master weights / activations / losses (BASELINE configs[4] names
+                                * fp16).  Any width and ray length; implies the layer-wise path.  Operands saturate at
+                                * +-65504 and the backward GEMMs scale their gradient operand by ~8 R (a power of two)
+                                * so that it stays in fp16's normal range.  PSNR-gated like OBJNERF_TRAIN_BF16; not
+                                * together with it (OBJNERF_EINVAL). */
 #define OBJNERF_TRAIN_LAYERWISE 2   /* mode bit: take the layer-wise (any width) path even for hidden 32 / S <= 64 --
                                      * a second, independent implementation of the same iteration; the tests use
                                      * it to cross-check the fused kernel at sizes no CPU oracle reaches. */

@@ -27,6 +27,8 @@ struct Gemm {
   int splitk;      // > 1: blockIdx.z = batch * splitk + slice; each slice atomically adds its partial into C
   float* rowsum; long bsrs;   // optional: rowsum[m] += sum_k A(m,k)  (bias gradient riding on the weight-gradient GEMM)
   const float* biasrow; long bsbr;   // optional per-row factor of the bias: + bias[n] * biasrow[m]
+  float a_scale;   // 16-bit operand kernels: A is multiplied by this power of two before it is rounded and the result
+                   // divided by it (keeps back-propagated gradients out of fp16's subnormal range); 1 elsewhere
 };
 
 #ifndef OBJ_GEMM_BK
@@ -179,12 +181,30 @@ __global__ __launch_bounds__(512) void gemm_group_kernel(const GemmGroup gr) {
 // rounded to bf16 when they are staged in LDS ([row][k], k contiguous: one ds_read_b128 per MFMA operand),
 // v_mfma_f32_16x16x32_bf16, fp32 accumulation.  64 x 64 (or, for wide layers, 128 x 128) tiles, 32-deep k steps:
 // 4 (16) MFMAs per wave and step, so the kernel is bound by the operand traffic, not by the matrix core.
+//
+// OT = _Float16 is the OBJNERF_TRAIN_FP16 mode (v_mfma_f32_16x16x32_f16): 11 significant bits instead of 8, but a
+// narrow exponent -- operands are clamped to +-65504 when rounded, and the backward GEMMs scale their gradient
+// operand (Gemm::a_scale).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-template <int TM, int TN>
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <typename OT> struct Op16;
+template <> struct Op16<__bf16> {
+  typedef bf16x8 V;
+  static __device__ __forceinline__ __bf16 cvt(float x) { return (__bf16)x; }
+  static __device__ __forceinline__ f32x4 mfma(V a, V b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct Op16<_Float16> {
+  typedef f16x8 V;
+  static __device__ __forceinline__ _Float16 cvt(float x) { return (_Float16)fminf(fmaxf(x, -65504.0f), 65504.0f); }
+  static __device__ __forceinline__ f32x4 mfma(V a, V b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+template <int TM, int TN, typename OT>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const Gemm g) {
   constexpr int BM = 32 * TM, BN = 32 * TN, BKB = 32, LDK = BKB + 8;
-  __shared__ __attribute__((aligned(16))) __bf16 As[BM][LDK];
-  __shared__ __attribute__((aligned(16))) __bf16 Bs[BN][LDK];
+  typedef typename Op16<OT>::V OV;
+  __shared__ __attribute__((aligned(16))) OT As[BM][LDK];
+  __shared__ __attribute__((aligned(16))) OT Bs[BN][LDK];
+  const float a_scale = g.a_scale, inv_scale = 1.0f / g.a_scale;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int c = lane & 15, gg = lane >> 4;
   const int wm = w >> 1, wn = w & 1;
@@ -228,14 +248,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const Gemm g) {
       const int e = tid + 256 * i;
       int am, ak;
       if (g.sak == 1) { ak = e % BKB; am = e / BKB; } else { am = e % BM; ak = e / BM; }
-      As[am][ak] = (__bf16)ra[i];
+      As[am][ak] = Op16<OT>::cvt(ra[i] * a_scale);
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int e = tid + 256 * i;
       int bn, bk;
       if (g.sbk == 1) { bk = e % BKB; bn = e / BKB; } else { bn = e % BN; bk = e / BN; }
-      Bs[bn][bk] = (__bf16)rb[i];
+      Bs[bn][bk] = Op16<OT>::cvt(rb[i]);
     }
   };
   float rs = 0.f;
@@ -249,19 +269,19 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const Gemm g) {
 #pragma unroll
       for (int kk = 0; kk < BKB; ++kk) rs += (float)As[tid][kk];
     }
-    bf16x8 a[TM], b[TN];
+    OV a[TM], b[TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(&As[16 * TM * wm + 16 * i + c][8 * gg]);
+    for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const OV*>(&As[16 * TM * wm + 16 * i + c][8 * gg]);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8*>(&Bs[16 * TN * wn + 16 * j + c][8 * gg]);
+    for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const OV*>(&Bs[16 * TN * wn + 16 * j + c][8 * gg]);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = Op16<OT>::mfma(a[i], b[j], acc[i][j]);
     __syncthreads();
   }
-  if (do_rs && m0 + tid < g.M) atomicAdd(g.rowsum + z * g.bsrs + m0 + tid, rs);
+  if (do_rs && m0 + tid < g.M) atomicAdd(g.rowsum + z * g.bsrs + m0 + tid, rs * inv_scale);
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -271,7 +291,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const Gemm g) {
         const int m = m0 + 16 * TM * wm + 16 * i + 4 * gg + r, n = n0 + 16 * TN * wn + 16 * j + c;
         if (m < g.M && n < g.N) {
           float* cp = C + m * g.scm + n * g.scn;
-          float v = acc[i][j][r];
+          float v = acc[i][j][r] * inv_scale;
           if (sk > 1) { atomicAdd(cp, v); continue; }
           if (g.accumulate) v += *cp;
           if (g.bias) v += g.bias[z * g.bsbias + n] * (g.biasrow ? g.biasrow[z * g.bsbr + m] : 1.0f);
@@ -283,7 +303,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const Gemm g) {
 }
 
 // selected for the duration of one train_step call (single host thread per device)
-static thread_local bool t_bf16_operands = false;
+static thread_local int t_bf16_operands = 0;      // 0: fp32 GEMMs, 1: bf16 operands, 2: fp16 operands
+static thread_local float t_a_scale = 1.0f;       // Gemm::a_scale of the next gemm() calls (fp16 backward)
 // per-row bias factor of the NEXT gemm() call (feature_head), reset by the caller
 static thread_local GemmGroup* t_group = nullptr;     // non-null: gemm() collects descriptors instead of launching
 static thread_local const float* t_biasrow = nullptr;
@@ -303,6 +324,7 @@ static void gemm(hipStream_t st, int batch, int M, int N, int Kd, const float* A
   g.accumulate = accumulate; g.relu = relu; g.splitk = splitk;
   g.rowsum = rowsum; g.bsrs = bsrs;
   g.biasrow = t_biasrow; g.bsbr = t_bsbr;
+  g.a_scale = t_bf16_operands == 2 ? t_a_scale : 1.0f;
   const int nz = batch * (splitk > 1 ? splitk : 1);
   if (t_group && !t_bf16_operands && !(M >= 256 && N >= 192) && t_group->count < GemmGroup::MAXG) {
     GemmGroup& gr = *t_group;               // collected; launched by flush_group()
@@ -313,13 +335,12 @@ static void gemm(hipStream_t st, int batch, int M, int N, int Kd, const float* A
     return;
   }
   if (t_bf16_operands) {
-    if (M >= 256 && N >= 192) {
-      dim3 grid((N + 127) / 128, (M + 127) / 128, nz);
-      hipLaunchKernelGGL((gemm_bf16_kernel<4, 4>), grid, dim3(256), 0, st, g);
-    } else {
-      dim3 grid((N + 63) / 64, (M + 63) / 64, nz);
-      hipLaunchKernelGGL((gemm_bf16_kernel<2, 2>), grid, dim3(256), 0, st, g);
-    }
+    const bool wide = M >= 256 && N >= 192, f16 = t_bf16_operands == 2;
+    const dim3 grid(wide ? (N + 127) / 128 : (N + 63) / 64, wide ? (M + 127) / 128 : (M + 63) / 64, nz);
+    if (wide && f16) hipLaunchKernelGGL((gemm_bf16_kernel<4, 4, _Float16>), grid, dim3(256), 0, st, g);
+    else if (wide) hipLaunchKernelGGL((gemm_bf16_kernel<4, 4, __bf16>), grid, dim3(256), 0, st, g);
+    else if (f16) hipLaunchKernelGGL((gemm_bf16_kernel<2, 2, _Float16>), grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<2, 2, __bf16>), grid, dim3(256), 0, st, g);
     return;
   }
   if (M >= 256 && N >= 192) {         // wide layer GEMMs (hidden 256): 128 x 128 tiles on 8 waves (3.5 % faster than the
@@ -1139,8 +1160,8 @@ namespace objgen {
 namespace {
 typedef objnerf_context Side;
 struct Bf16Scope {
-  explicit Bf16Scope(bool on) { t_bf16_operands = on; }
-  ~Bf16Scope() { t_bf16_operands = false; }
+  explicit Bf16Scope(int operands) { t_bf16_operands = operands; t_a_scale = 1.0f; }
+  ~Bf16Scope() { t_bf16_operands = 0; t_a_scale = 1.0f; }
 };
 }  // namespace
 
@@ -1173,7 +1194,7 @@ __global__ void form_points_kernel(long total, int S, const float* origins, cons
 int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* stream) {
   objnerf_train_args a_local = *a_in;
   const objnerf_train_args* a = &a_local;
-  const Bf16Scope bf16_scope((a->mode & OBJNERF_TRAIN_BF16) != 0);
+  const Bf16Scope bf16_scope((a->mode & OBJNERF_TRAIN_FP16) ? 2 : (a->mode & OBJNERF_TRAIN_BF16) ? 1 : 0);
   const int H = net->hidden, C = net->feat_dim, K = a->K;
   if (H % 32 != 0 || net->n_freqs != 6) return OBJNERF_ENOTSUP;
   const bool feat = a->gt_feat != nullptr;
@@ -1240,7 +1261,7 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
   const int small_rt = small_batch_rt(H, n, K);
   // (the small-batch kernels are fp32: in that latency-bound regime they beat the bf16-operand GEMMs as well, so
   // OBJNERF_TRAIN_BF16 is a no-op there)
-  if (small_rt) t_bf16_operands = false;
+  if (small_rt) t_bf16_operands = 0;
   if (small_rt) {
     FwdSmall f;
     f.n = n; f.feat = feat ? 1 : 0; f.params = P; f.ps = ps; f.emb = w.emb;
@@ -1304,6 +1325,11 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
   // Weight-gradient GEMMs only READ the d-output / activation buffers and write the gradient arena, so they run on a
   // side stream beside the dgrad chain (each of these GEMMs alone leaves most of the chip idle).  Every d_h has its own
   // buffer: nothing a side-stream GEMM reads is overwritten before the join at the end.
+  // fp16 operands: every backward GEMM has the back-propagated gradient as its A operand.  Those values are of order
+  // (loss scale) / R per ray times a per-sample weight -- mostly below fp16's smallest normal number (6.1e-5) -- so A is
+  // scaled by ~8 R (a power of two: exact) before rounding and the product scaled back (Gemm::a_scale).
+  const float grad_scale = exp2f(floorf(log2f((float)a->R)) + 3.0f);
+  t_a_scale = grad_scale;
   int rr = 0;
   auto side = [&]() -> hipStream_t {        // stream of the next independent weight-gradient GEMM
     hipStream_t r = sd.all[rr];
@@ -1333,8 +1359,10 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
     hipLaunchKernelGGL(featg_scale_kernel, dim3((unsigned)((nr * XC + 255) / 256)), dim3(256), 0, ss, nr, H, w.rayfeat, w.X1,
                        w.X2);
     (void)hipMemsetAsync(w.Tm, 0, ((size_t)K * C * XC + (size_t)K * XC * XC) * 4, ss);
+    t_a_scale = 1.0f;                       // (targets and moments of the feature head: not gradients)
     wgrad(ss, K, C, XC, R, a->gt_feat, 1, C, R * C, w.X1, XC, 1, R * XC, w.Tm, XC, (long)C * XC);
     wgrad(ss, K, XC, XC, R, w.X2, 1, XC, R * XC, w.rayfeat, H + 3, 1, R * (H + 3), w.mom, XC, (long)XC * XC);
+    t_a_scale = grad_scale;
     hipLaunchKernelGGL(featg_finish_kernel, dim3((unsigned)(((long)C * XC + 255) / 256), K), dim3(256), 0, ss, P, ps,
                        (int)off[16], (int)off[17], C, H, w.Tm, w.mom, G);
     // feature layer: grads + contributions to d_h4 / d_x2

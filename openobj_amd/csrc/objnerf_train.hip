@@ -1044,7 +1044,8 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
   if (!a->pts && (!a->origins || !a->dirs)) return OBJNERF_EINVAL;
   if (a->K <= 0 || a->R <= 0 || a->S <= 0) return OBJNERF_EINVAL;
   if (net->n_freqs != 6) return OBJNERF_ENOTSUP;
-  if (net->hidden != 32 || a->S > 64 || (a->mode & OBJNERF_TRAIN_LAYERWISE)) {
+  if ((a->mode & OBJNERF_TRAIN_FP16) && (a->mode & OBJNERF_TRAIN_BF16)) return OBJNERF_EINVAL;
+  if (net->hidden != 32 || a->S > 64 || (a->mode & (OBJNERF_TRAIN_LAYERWISE | OBJNERF_TRAIN_FP16))) {
     // wider networks (background: hidden 128) and long rays: layer-wise path, activations in the workspace
     if (a->workspace_bytes < objgen::train_workspace_bytes(net, a->K, a->R, a->S, a->gt_feat != nullptr))
       return OBJNERF_EINVAL;

@@ -281,6 +281,18 @@ def step_batch_loss(alpha, color, gt_depth, gt_rgb, labels, z, color_scaling=5.0
 LAYERWISE_WORKSPACE_BUDGET = 64 << 30      # bytes; the layer-wise path materialises activations per object chunk
 
 
+def precision_bits(p) -> int:
+    """The opt-in operand precision of a training step -> objnerf_train_args.mode bits.  False / None / "fp32": the
+    reference's arithmetic; True / "bf16": OBJNERF_TRAIN_BF16; "fp16": OBJNERF_TRAIN_FP16 (layer-wise path)."""
+    if p in (False, None, "fp32"):
+        return 0
+    if p in (True, "bf16"):
+        return 1
+    if p == "fp16":
+        return 4
+    raise ValueError("precision must be fp32 / bf16 / fp16, not {!r}".format(p))
+
+
 class StreamContext:
     """objnerf_context: the helper streams + events the layer-wise path forks onto.  Created on the current device;
     freed with the object (after a device synchronisation, so no step using it is in flight)."""
@@ -311,7 +323,8 @@ class TrainWorkspace:
     the objects chunk by chunk -- they are independent networks, only the early-return flags span the batch."""
 
     def __init__(self, arena: ParamArena, K: int, R: int, S: int, with_feat: bool, layerwise: bool = False,
-                 budget: Optional[int] = None):
+                 budget: Optional[int] = None, precision=None):
+        layerwise = layerwise or precision_bits(precision) == 4          # the fp16 mode lives on the layer-wise path
         dev = arena.params.device
         net = arena.net.c()
         wf = int(with_feat) | (2 if layerwise else 0)
@@ -346,8 +359,9 @@ def train_step(arena: ParamArena, ws: TrainWorkspace, batch: Dict[str, torch.Ten
     layerwise: OBJNERF_TRAIN_LAYERWISE -- run the layer-wise (any width) implementation even where the fused
     kernel applies (cross-check of two independent implementations; ws must be built with layerwise=True).
 
-    bf16: opt-in OBJNERF_TRAIN_BF16 mode (bf16 MFMA operands, fp32 accumulate / master weights); the default
-    is the reference's fp32 arithmetic.
+    bf16: operand precision (precision_bits): True / "bf16" = OBJNERF_TRAIN_BF16 (bf16 MFMA operands, fp32 accumulate /
+    master weights), "fp16" = OBJNERF_TRAIN_FP16 (layer-wise path; ws built with precision="fp16"); the default is
+    the reference's fp32 arithmetic.
 
     relu_masks: test hook -- uint8 [K,R,S,6,hidden/8] receiving the ReLU branch bits of the iteration
     (objnerf_train_args.relu_masks); None in production.
@@ -375,7 +389,7 @@ def train_step(arena: ParamArena, ws: TrainWorkspace, batch: Dict[str, torch.Ten
     if global_counts is not None:       # one object's rays split over ranks (background): global mask counts
         counts = _req(global_counts, torch.int32, "global_counts")
     net = arena.net.c()
-    mode = (1 if bf16 else 0) | (2 if layerwise else 0)
+    mode = precision_bits(bf16) | (2 if layerwise else 0)
     if relu_masks is not None:
         relu_masks = _req(relu_masks, torch.uint8, "relu_masks")
         if tuple(relu_masks.shape) != (K, R, S, 6, arena.net.hidden // 8):

@@ -44,8 +44,9 @@ class PsnrScene:
         c.obj_id = 1
         self.cfg = c
 
-    def run(self, seed: int, bf16: bool = False) -> float:
-        """Train K fresh object networks (the reference's initialisation for `seed`) and return the PSNR [dB]."""
+    def run(self, seed: int, bf16=False) -> float:
+        """Train K fresh object networks (the reference's initialisation for `seed`) and return the PSNR [dB].
+        bf16: operand precision (ops.precision_bits: False, True / "bf16", "fp16")."""
         torch.manual_seed(seed)
         ts = [trainer.Trainer(self.cfg) for _ in range(G9["K"])]
         loop = otrain.HipTrainLoop(self.cfg, ts, with_feat=False, bf16=bf16)
@@ -56,7 +57,7 @@ class PsnrScene:
         out = ops.composite(a.reshape(-1, S), c.reshape(-1, S, 3), self.ev["z"].reshape(-1, S))
         return _psnr(out["rgb"].reshape(G9["K"], R, 3), self.ev["gt_rgb"])
 
-    def ensemble(self, seeds: List[int], bf16: bool = False) -> np.ndarray:
+    def ensemble(self, seeds: List[int], bf16=False) -> np.ndarray:
         return np.array([self.run(s, bf16) for s in seeds])
 
 

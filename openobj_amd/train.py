@@ -34,7 +34,7 @@ class BackgroundLoop:
     def _workspace(self, batch):
         K, R, S = batch["z"].shape
         if self.ws is None or self.ws.key != (K, R, S, self.with_feat):
-            self.ws = ops.TrainWorkspace(self.arena, K, R, S, self.with_feat)
+            self.ws = ops.TrainWorkspace(self.arena, K, R, S, self.with_feat, precision=self.bf16)
             # gradient and loss terms in ONE buffer: one collective moves both
             self.flat = torch.zeros(self.arena.p_stride + 4, device=self.arena.params.device)
             self.ws.grads = self.flat[:self.arena.p_stride].view(1, -1)
@@ -157,7 +157,7 @@ class HipTrainLoop:
     def _step_forloop(self, batch, global_flags):
         K, R, S = batch["z"].shape
         if self.wss is None or self.wss[0].key != (1, R, S, self.with_feat):
-            self.wss = [ops.TrainWorkspace(t.arena, 1, R, S, self.with_feat) for t in self.trainers]
+            self.wss = [ops.TrainWorkspace(t.arena, 1, R, S, self.with_feat, precision=self.bf16) for t in self.trainers]
             self.loss_terms = torch.zeros(K, 4, device=batch["z"].device)
             self.status = torch.zeros(1, dtype=torch.int32, device=batch["z"].device)
             self.ws = self                      # (status holder for train_frame)
@@ -180,7 +180,7 @@ class HipTrainLoop:
             return self._step_forloop(batch, global_flags)
         K, R, S = batch["z"].shape
         if self.ws is None or self.ws.key != (K, R, S, self.with_feat):
-            self.ws = ops.TrainWorkspace(self.arena, K, R, S, self.with_feat)
+            self.ws = ops.TrainWorkspace(self.arena, K, R, S, self.with_feat, precision=self.bf16)
         ops.train_step(self.arena, self.ws, batch, with_feat=self.with_feat, global_flags=global_flags,
                        bf16=self.bf16)
         # (ws.flags holds the batch's own flags when no global pair was supplied)

@@ -1,0 +1,70 @@
+"""OBJNERF_TRAIN_FP16 -- fp16 GEMM operands on the layer-wise path (BASELINE configs[4] names fp16).  Like the bf16
+mode it is not the reference's arithmetic (fp32, train.py:74), so it is gated by closeness to the fp32 step and by
+reconstruction quality, not by the 1e-4 parity bound."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import T
+from openobj_amd import init as obj_init
+from openobj_amd import ops, psnr_scene, synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 16, 48, 256, False), (2, 200, 5, 9, 128, True), (3, 96, 8, 24, 32, False),
+                                   (1, 4096, 16, 48, 64, False)])
+def test_fp16_step_close_to_fp32(dev, shape):
+    """One iteration, fp16 operands against the same path in fp32: loss terms within 1e-3, every gradient tensor within
+    2 % in norm (fp16 rounds operands to 11 bits; bf16's bound on this test is 15 %), no overflow in the status word.
+    R = 4096 exercises the gradient-operand scaling (un-scaled, those gradients sit in fp16's subnormal range)."""
+    K, R, n1, n2, H, feat = shape
+    arena = ops.ParamArena(K, ops.NetShape(H, 512, 6), dev)
+    arena.load_stacked(obj_init.init_stacked(K, H, 512, seed=7))
+    b = synthetic.random_batch(K, R, n1, n2, seed=5 + R, feat_dim=512 if feat else 0)
+    batch = {k: T(b[k]).to(dev) for k in ["pts", "z", "gt_depth", "gt_rgb", "labels"] + (["gt_feat"] if feat else [])}
+    ws32 = ops.TrainWorkspace(arena, K, R, n1 + n2, feat, layerwise=True)
+    ws16 = ops.TrainWorkspace(arena, K, R, n1 + n2, feat, precision="fp16")
+    ops.train_step(arena, ws32, batch, with_feat=feat, layerwise=True)
+    ops.train_step(arena, ws16, batch, with_feat=feat, bf16="fp16")
+    torch.cuda.synchronize()
+    assert int(ws16.status.item()) == 0 and bool(torch.isfinite(ws16.grads).all())
+    np.testing.assert_allclose(ws16.loss_terms.cpu(), ws32.loss_terms.cpu(), rtol=1e-3, atol=1e-4)
+    g32, g16 = arena.views(ws32.grads), arena.views(ws16.grads)
+    for i in range(19):
+        if i in ops.FEAT_TENSORS and not feat:
+            assert float(g16[i].abs().max()) == 0.0
+            continue
+        a, r = g16[i].double().cpu(), g32[i].double().cpu()
+        rel = float((a - r).norm() / (r.norm() + 1e-30))
+        assert rel < 0.02, (i, ops.TENSOR_NAMES[i], rel)
+
+
+def test_fp16_and_bf16_together_are_refused(dev):
+    arena = ops.ParamArena(1, ops.NetShape(64, 512, 6), dev)
+    arena.load_stacked(obj_init.init_stacked(1, 64, 512, seed=1))
+    b = synthetic.random_batch(1, 16, 2, 6, seed=1)
+    batch = {k: T(b[k]).to(dev) for k in ["pts", "z", "gt_depth", "gt_rgb", "labels"]}
+    ws = ops.TrainWorkspace(arena, 1, 16, 8, False, precision="fp16")
+    import ctypes as C
+    from openobj_amd import _lib
+    a = _lib.TrainArgs(1, 16, 8, 1 | 4, 5.0, 10.0, 5.0, 0.0, arena.params.data_ptr(), arena.p_stride,
+                       arena.scale.data_ptr(), batch["pts"].data_ptr(), None, None, batch["z"].data_ptr(),
+                       batch["gt_depth"].data_ptr(), batch["gt_rgb"].data_ptr(), batch["labels"].data_ptr(), None,
+                       ws.counts.data_ptr(), ws.flags.data_ptr(), ws.grads.data_ptr(), ws.loss_terms.data_ptr(),
+                       ws.status.data_ptr(), ws.buf.data_ptr(), ws.nbytes, None, None)
+    net = arena.net.c()
+    assert _lib.lib().objnerf_train_step(C.byref(net), C.byref(a), None) == -22
+    with pytest.raises(ValueError):
+        ops.precision_bits("fp8")
+
+
+def test_fp16_psnr_matches_reference_ensemble(dev):
+    """Quality gate of the mode (as tests/test_bf16_gpu.py): G9 scene, 300 iterations, 128 weight seeds against the
+    reference's 128-seed ensemble; 99.9 % interval of the difference of means (standard error 0.08 dB)."""
+    ref = psnr_scene.reference_ensemble()
+    ens = psnr_scene.PsnrScene(dev).ensemble([int(x) for x in ref["seeds"]], bf16="fp16")
+    rep = psnr_scene.delta_report(ens, ref["psnr"])
+    print("fp16 PSNR delta vs reference ensemble:", rep)
+    assert abs(rep["delta_db"]) < 3.29 * rep["ci95_db"] / 1.96 < 0.28, rep
+    assert abs(rep["hip_std_db"] - rep["ref_std_db"]) < 0.25, rep
