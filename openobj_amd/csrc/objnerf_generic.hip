@@ -926,6 +926,49 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(int Hh, long n, const fl
   }
 }
 
+// Head weight gradients: d wa[f] = sum_i dhead[i][0] h4[i][f], d Woc[x][f] = sum_i dhead[i][1+x] hc[i][f], biases =
+// column sums of dhead.  A 4 x H output: a GEMM tile would be 94 % padding, so this is a plain reduction over the
+// samples (reads h4 and hc once, coalesced along f); one atomic per block and entry into the pre-zeroed gradient.
+__global__ __launch_bounds__(256) void head_wgrad_kernel(int Hh, long n, const float* dhead, const float* h4, const float* hc,
+                                                         float* grads, long p_stride, int off_wa, int off_ba, int off_woc,
+                                                         int off_boc) {
+  __shared__ float red[4][256];
+  const long z = blockIdx.y;
+  const int rows = 256 / Hh > 0 ? 256 / Hh : 1;            // sample rows per pass (H <= 256)
+  const int f = threadIdx.x % Hh, row = threadIdx.x / Hh;
+  const bool live = row < rows;
+  const long per = (n + gridDim.x - 1) / gridDim.x;
+  const long i0 = (long)blockIdx.x * per, i1 = i0 + per < n ? i0 + per : n;
+  float a = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
+  if (live)
+    for (long i = i0 + row; i < i1; i += rows) {
+      const long o = z * n + i;
+      const float4 d = *reinterpret_cast<const float4*>(dhead + o * 4);
+      const float hv = h4[o * Hh + f], cv = hc[o * Hh + f];
+      a = fmaf(d.x, hv, a); c0 = fmaf(d.y, cv, c0); c1 = fmaf(d.z, cv, c1); c2 = fmaf(d.w, cv, c2);
+    }
+  red[0][threadIdx.x] = a; red[1][threadIdx.x] = c0; red[2][threadIdx.x] = c1; red[3][threadIdx.x] = c2;
+  __syncthreads();
+  float* G = grads + z * p_stride;
+  if (row == 0) {
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < rows; ++r)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s[q] += red[q][r * Hh + f];
+    atomicAdd(G + off_wa + f, s[0]);
+#pragma unroll
+    for (int x = 0; x < 3; ++x) atomicAdd(G + off_woc + x * Hh + f, s[1 + x]);
+  }
+  // biases: lanes 0..3 of the last wave sum their dhead column over the block's samples
+  if (threadIdx.x >= 192) {
+    const int lane = threadIdx.x - 192, q = lane & 3;
+    float b = 0.f;
+    for (long i = i0 + (lane >> 2); i < i1; i += 16) b += dhead[(z * n + i) * 4 + q];
+    b += __shfl_xor(b, 4); b += __shfl_xor(b, 8); b += __shfl_xor(b, 16); b += __shfl_xor(b, 32);
+    if (lane < 4) atomicAdd(G + (q == 0 ? off_ba : off_boc + q - 1), b);
+  }
+}
+
 __global__ void relu_mask_kernel(long n, float* d, const float* act) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) d[i] = act[i] > 0.f ? d[i] : 0.f;
@@ -1343,8 +1386,16 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
   // head weight grads: d wa = dhead[:,0]^T h4, d Woc = dhead[:,1:4]^T hc; biases = column sums of dhead
   // (every bias gradient rides on its layer's weight-gradient GEMM: row sums of the d-output operand tile)
   fork();
-  wgrad(ss, K, 1, H, n, w.dhead, 1, 4, n * 4, w.h4, H, 1, nH, G + off[8], H, ps, G + off[9]);
-  wgrad(ss, K, 3, H, n, w.dhead + 1, 1, 4, n * 4, w.hc, H, 1, nH, G + off[12], H, ps, G + off[13]);
+  if (H > 256) {
+    wgrad(ss, K, 1, H, n, w.dhead, 1, 4, n * 4, w.h4, H, 1, nH, G + off[8], H, ps, G + off[9]);
+    wgrad(ss, K, 3, H, n, w.dhead + 1, 1, 4, n * 4, w.hc, H, 1, nH, G + off[12], H, ps, G + off[13]);
+  } else {
+    int hb = (int)((n + 511) / 512);                      // >= 512 samples per block, about two blocks per CU in all
+    const int cap = (512 + K - 1) / K;
+    if (hb > cap) hb = cap;
+    hipLaunchKernelGGL(head_wgrad_kernel, dim3((unsigned)hb, (unsigned)K), dim3(256), 0, ss, H, n, w.dhead, w.h4, w.hc, G, ps,
+                       (int)off[8], (int)off[9], (int)off[12], (int)off[13]);
+  }
   // d_emb needs no zero fill: the first dgrad into each column block overwrites (x2: feature layer if
   // present, else colour layer; x1: cat layer), later ones accumulate; columns 0..2 (d t) are never read.
   if (feat) {

@@ -401,5 +401,5 @@ def test_layerwise_step_with_and_without_stream_context(dev):
     ws.grads.zero_()
     ops.train_step(arena, ws, batch, with_feat=True)
     torch.cuda.synchronize()
-    assert torch.equal(l_ctx, ws.loss_terms)
+    assert maxerr(l_ctx, ws.loss_terms) <= 1e-6 * l_ctx.abs().max().item()          # (atomic partial sums)
     assert maxerr(g_ctx, ws.grads) <= 2e-6 * g_ctx.abs().max().item()
