@@ -34,7 +34,7 @@ def _frame(i, rs):
     return rgb, depth, inst
 
 
-def write_scene(root, fmt="Replica", n_frames=40, part_dim=0, part_down=5, seed=0):
+def write_scene(root, fmt="Replica", n_frames=40, part_dim=0, part_down=5, seed=0, color_scale=2):
     """Frames 0, 10, 20, ... are the ones a stride-10 loader reads; instance / class maps exist per 10 frames."""
     rs = np.random.RandomState(seed)
     os.makedirs(root, exist_ok=True)
@@ -50,7 +50,7 @@ def write_scene(root, fmt="Replica", n_frames=40, part_dim=0, part_down=5, seed=
             Image.fromarray(rgb).save(os.path.join(root, "rgb", "rgb_%d.png" % i))
             Image.fromarray(depth).save(os.path.join(root, "depth", "depth_%d.png" % i))
         else:
-            big = np.repeat(np.repeat(rgb, 2, axis=0), 2, axis=1)          # colour at twice the depth resolution
+            big = np.repeat(np.repeat(rgb, color_scale, axis=0), color_scale, axis=1)   # colour at (twice) the depth resolution
             Image.fromarray(big).save(os.path.join(root, "color", "%d.jpg" % i), quality=95)
             Image.fromarray(depth).save(os.path.join(root, "depth", "%d.png" % i))
         T = np.eye(4)

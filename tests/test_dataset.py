@@ -113,3 +113,34 @@ def test_majority_cluster_mean_and_imports():
     m = mapping.get_majority_cluster_mean(v, eps=0.2, min_samples=2)
     assert np.allclose(m, a.mean(0), atol=1e-12)
     assert mapping._first(np.ones((1, 4))).shape == (4,) and mapping._first(np.ones(4)).shape == (4,)
+
+
+G14_CASES = [("Replica", dict(n_frames=30, part_dim=4, part_down=4), 4),
+             ("ScanNet", dict(n_frames=30, part_dim=4, part_down=4, color_scale=1), 4),
+             ("ScanNet", dict(n_frames=20, part_dim=6, part_down=2, color_scale=1), 10)]
+
+
+@pytest.mark.parametrize("ci", [0, 1, 2])
+def test_samples_equal_the_reference_classes_g14(tmp_path, golden, ci):
+    """Fixture G14 = the reference's own Replica / ScanNet classes run on this helper scene (tests/golden/
+    make_g14_dataset.py; image decoding through stand-ins, see its header): every field of every sample, exactly."""
+    g = golden("g14_dataset")
+    fmt, kw, cfg_pd = G14_CASES[ci]
+    SF.write_scene(str(tmp_path), fmt, seed=3 + ci, **kw)
+    c = make_cfg(tmp_path, fmt, **{"trainer.part_mode": 1, "trainer.part_down": cfg_pd})
+    assert (c.stride, c.start, c.depth_scale, c.max_depth) == (10, 0, 1 / 1000.0, 8.0)      # the generator's cfg
+    ds = ods.Replica(c) if fmt == "Replica" else ods.ScanNet(c)
+    assert len(ds) == int(g[f"c{ci}_len"])
+    for i in range(len(ds)):
+        s, pre = ds[i], f"c{ci}_s{i}_"
+        for k in ("image", "depth", "T", "T_obj", "obj"):
+            ref = g[pre + k]
+            assert s[k].dtype == ref.dtype and s[k].shape == ref.shape and np.array_equal(s[k], ref), (i, k)
+        assert s["frame_id"] == int(g[pre + "frame_id"])
+        keys = sorted(s["bbox_dict"])
+        assert keys == g[pre + "keys"].tolist() == sorted(s["obj_clip"]) == sorted(s["obj_cap"])
+        assert np.array_equal(np.stack([s["bbox_dict"][k].numpy() for k in keys]), g[pre + "boxes"])
+        assert np.array_equal(np.stack([np.asarray(s["obj_clip"][k]).reshape(-1) for k in keys]), g[pre + "clip"])
+        assert np.array_equal(np.stack([np.asarray(s["obj_cap"][k]).reshape(-1) for k in keys]), g[pre + "cap"])
+        pf = s["part_feat"].numpy()
+        assert pf.shape == g[pre + "part_feat"].shape and np.array_equal(pf, g[pre + "part_feat"])
