@@ -185,6 +185,12 @@ __global__ __launch_bounds__(512) void gemm_group_kernel(const GemmGroup gr) {
 // OT = _Float16 is the OBJNERF_TRAIN_FP16 mode (v_mfma_f32_16x16x32_f16): 11 significant bits instead of 8, but a
 // narrow exponent -- operands are clamped to +-65504 when rounded, and the backward GEMMs scale their gradient
 // operand (Gemm::a_scale).
+#ifndef OBJ_G16_BK
+#define OBJ_G16_BK 32
+#endif
+#ifndef OBJ_G16_BK_WIDE
+#define OBJ_G16_BK_WIDE 32
+#endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 template <typename OT> struct Op16;
@@ -198,9 +204,12 @@ template <> struct Op16<_Float16> {
   static __device__ __forceinline__ _Float16 cvt(float x) { return (_Float16)fminf(fmaxf(x, -65504.0f), 65504.0f); }
   static __device__ __forceinline__ f32x4 mfma(V a, V b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 };
-template <int TM, int TN, typename OT>
+// BKB: k-stage depth (OBJ_G16_BK / OBJ_G16_BK_WIDE).  Measured on MI355X (tools/gemm16_ab.sh): deeper stages LOSE --
+// background step in bf16 mode 0.92 ms at 32, 1.19 ms at 64, 2.2 ms at 128; configs[4] share in fp16 2.18 / 2.37 /
+// 2.60 s -- the prefetch registers and the larger LDS tiles cost more occupancy than the saved barriers return.
+template <int TM, int TN, typename OT, int BKB>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const Gemm g) {
-  constexpr int BM = 32 * TM, BN = 32 * TN, BKB = 32, LDK = BKB + 8;
+  constexpr int BM = 32 * TM, BN = 32 * TN, LDK = BKB + 8;
   typedef typename Op16<OT>::V OV;
   __shared__ __attribute__((aligned(16))) OT As[BM][LDK];
   __shared__ __attribute__((aligned(16))) OT Bs[BN][LDK];
@@ -269,16 +278,19 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const Gemm g) {
 #pragma unroll
       for (int kk = 0; kk < BKB; ++kk) rs += (float)As[tid][kk];
     }
-    OV a[TM], b[TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const OV*>(&As[16 * TM * wm + 16 * i + c][8 * gg]);
+    for (int ks = 0; ks < BKB; ks += 32) {
+      OV a[TM], b[TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const OV*>(&Bs[16 * TN * wn + 16 * j + c][8 * gg]);
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const OV*>(&As[16 * TM * wm + 16 * i + c][ks + 8 * gg]);
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const OV*>(&Bs[16 * TN * wn + 16 * j + c][ks + 8 * gg]);
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
-        acc[i][j] = Op16<OT>::mfma(a[i], b[j], acc[i][j]);
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = Op16<OT>::mfma(a[i], b[j], acc[i][j]);
+    }
     __syncthreads();
   }
   if (do_rs && m0 + tid < g.M) atomicAdd(g.rowsum + z * g.bsrs + m0 + tid, rs * inv_scale);
@@ -337,10 +349,10 @@ static void gemm(hipStream_t st, int batch, int M, int N, int Kd, const float* A
   if (t_bf16_operands) {
     const bool wide = M >= 256 && N >= 192, f16 = t_bf16_operands == 2;
     const dim3 grid(wide ? (N + 127) / 128 : (N + 63) / 64, wide ? (M + 127) / 128 : (M + 63) / 64, nz);
-    if (wide && f16) hipLaunchKernelGGL((gemm_bf16_kernel<4, 4, _Float16>), grid, dim3(256), 0, st, g);
-    else if (wide) hipLaunchKernelGGL((gemm_bf16_kernel<4, 4, __bf16>), grid, dim3(256), 0, st, g);
-    else if (f16) hipLaunchKernelGGL((gemm_bf16_kernel<2, 2, _Float16>), grid, dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<2, 2, __bf16>), grid, dim3(256), 0, st, g);
+    if (wide && f16) hipLaunchKernelGGL((gemm_bf16_kernel<4, 4, _Float16, OBJ_G16_BK_WIDE>), grid, dim3(256), 0, st, g);
+    else if (wide) hipLaunchKernelGGL((gemm_bf16_kernel<4, 4, __bf16, OBJ_G16_BK_WIDE>), grid, dim3(256), 0, st, g);
+    else if (f16) hipLaunchKernelGGL((gemm_bf16_kernel<2, 2, _Float16, OBJ_G16_BK>), grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<2, 2, __bf16, OBJ_G16_BK>), grid, dim3(256), 0, st, g);
     return;
   }
   if (M >= 256 && N >= 192) {         // wide layer GEMMs (hidden 256): 128 x 128 tiles on 8 waves (3.5 % faster than the
