@@ -343,6 +343,11 @@ int objnerf_adamw_step_flags(int32_t K, int64_t P, int64_t p_stride, float* para
  * Helper functions of the reference's call surface that a caller may use outside the fused iteration
  * (objnerf_helpers.hip).  All take / return device pointers; small HBM-bound kernels.
  */
+/* render_rays.render (render_rays.py:56-63): out [n_rays][C] = sum over the S samples of termination [n_rays][S] *
+ * vals [n_rays][S][C] (C = 1 for depth-like quantities). */
+int objnerf_render(int64_t n_rays, int32_t S, int32_t C, const float* termination, const float* vals, float* out,
+                   void* stream);
+
 /* render_rays.render_loss (render_rays.py:65-83).  mode 0 "L1": |render - gt|, 1 "L2": squared, n elements;
  * mode 2 "cos": 1 - cosine_similarity over rows of C entries (norms clamped at 1e-8), n rows.  normalise: / gt. */
 int objnerf_render_loss(int64_t n, int32_t C, int32_t mode, int32_t normalise, const float* render, const float* gt,

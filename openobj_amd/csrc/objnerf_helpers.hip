@@ -154,7 +154,30 @@ __global__ void normal_bins_kernel(long n_rays, int n_bins, const float* depth, 
 
 }  // namespace
 
+// render_rays.render (render_rays.py:56-63): out[ray][c] = sum_s termination[ray][s] * vals[ray][s][c]; one thread per
+// output, the samples of a ray are read in order (the reference's torch.sum order is unspecified)
+__global__ void render_kernel(long n_out, int S, int C, const float* term, const float* vals, float* out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_out) return;
+  const long ray = i / C;
+  const int ch = (int)(i - ray * C);
+  float acc = 0.f;
+  for (int s = 0; s < S; ++s) acc = fmaf(term[ray * S + s], vals[(ray * S + s) * C + ch], acc);
+  out[i] = acc;
+}
+
 extern "C" {
+
+int objnerf_render(int64_t n_rays, int32_t S, int32_t C, const float* termination, const float* vals, float* out,
+                   void* stream) {
+  (void)hipGetLastError();
+  if (n_rays <= 0 || S <= 0 || C <= 0 || !termination || !vals || !out) return OBJNERF_EINVAL;
+  const long n_out = (long)n_rays * C;
+  hipLaunchKernelGGL(render_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n_out, S, C,
+                     termination, vals, out);
+  CHECK_LAUNCH();
+  return OBJNERF_OK;
+}
 
 int objnerf_render_loss(int64_t n, int32_t C, int32_t mode, int32_t normalise, const float* render, const float* gt,
                         float* out, void* stream) {

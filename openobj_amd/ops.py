@@ -612,6 +612,22 @@ def sample_rays(rgbs_batch, depth_batch, t_wc_batch, bbox, rays_dir_cache, kf_id
 # ------------------------------------------------------------------------------------------------
 # helper functions of the reference's call surface (objnerf_helpers.hip)
 # ------------------------------------------------------------------------------------------------
+def render(termination: torch.Tensor, vals: torch.Tensor) -> torch.Tensor:
+    """render_rays.render over the last axis of termination [..., S] with vals [..., S] or [..., S, C] (objnerf_render)."""
+    termination = _req(termination, torch.float32, "termination")
+    S = termination.shape[-1]
+    scalar = vals.dim() == termination.dim()
+    Cdim = 1 if scalar else vals.shape[-1]
+    vals = _req(vals, torch.float32, "vals")
+    if tuple(vals.shape[:termination.dim()]) != tuple(termination.shape):
+        raise ObjnerfError("render: vals must be termination's shape (+ a channel axis)")
+    n = termination.numel() // S
+    out = torch.empty(termination.shape[:-1] + (() if scalar else (Cdim,)), device=termination.device)
+    if n:
+        check(lib().objnerf_render(n, S, Cdim, _ptr(termination), _ptr(vals), _ptr(out), _stream()), "objnerf_render")
+    return out
+
+
 def render_loss(render: torch.Tensor, gt: torch.Tensor, mode: int, normalise: bool = False) -> torch.Tensor:
     """render_rays.render_loss: mode 0 L1, 1 L2 (elementwise, any shape); 2 cos (over the last axis)."""
     render = _req(render, torch.float32, "render")

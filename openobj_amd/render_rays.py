@@ -1,6 +1,6 @@
 """render_rays -- the reference's compositing helpers (render_rays.py:6-146) on the HIP kernels.
 
-occupancy_activation / occupancy_to_termination / render run objnerf_occupancy / objnerf_composite;
+occupancy_activation / occupancy_to_termination / render run objnerf_occupancy / objnerf_composite / objnerf_render;
 render_loss / reduce_batch_loss / make_3D_grid run the small kernels of objnerf_helpers.hip.  The fused
 iteration uses none of them (its loss lives inside the training kernels and objnerf_step_batch_loss); they
 are provided for callers of the reference API and operate on device tensors.
@@ -25,8 +25,12 @@ def occupancy_to_termination(occupancy, is_batch=False):
 
 
 def render(termination, vals, dim=-1):
-    """render_rays.py:56-63: weighted sum over the sample axis."""
-    return (termination * vals).sum(dim=dim)
+    """Weighted sum of per-sample values along a ray (reference render_rays.py:56-63; the reference multiplies tensors
+    of equal shape and sums over `dim`): objnerf_render.  vals may also carry a trailing channel axis [..., S, C]."""
+    if dim not in (-1, termination.dim() - 1):
+        raise ValueError("render: the sample axis must be termination's last axis")
+    return ops.render(termination.contiguous(), vals.expand_as(termination).contiguous()
+                      if vals.dim() == termination.dim() else vals.contiguous())
 
 
 _LOSS_MODES = {"L1": 0, "L2": 1, "cos": 2}

@@ -83,6 +83,8 @@ def test_render_rays_helpers_g3(golden, dev):
     assert maxerr(render_rays.occupancy_to_termination(occ[0]), g["term_nb"]) < 1e-6
     term = T(g["term_b"]).to(dev)
     assert maxerr(render_rays.render(term, T(g["z"]).to(dev)), g["depth"]) < 1e-5
+    col = torch.rand(*term.shape, 3, generator=torch.Generator().manual_seed(1)).to(dev)      # [.., S, C] values
+    assert maxerr(render_rays.render(term, col), (term[..., None] * col).sum(dim=-2)) < 1e-5
 
 
 @pytest.mark.parametrize("feat_on", [False, True])
