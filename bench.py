@@ -311,8 +311,7 @@ def main():
         value = rays_per_step * args.steps / dt
         fpr = flop_per_ray(S, H=Hd, feat=feat)
         fused = Hd == 32 and S <= 64 and bf16 != "fp16"
-        k32 = "train_fused_kernel<true, false>" if feat else ("train_fused32_kernel<false, 64>" if S == 64
-                                                               else "train_fused32_kernel<false, 0>")
+        k32 = "train_fused32_kernel<%s, false, %d>" % ("true" if feat else "false", 64 if S == 64 else 0)
         kbf = f"train_fused_bf16_kernel<{'true' if feat else 'false'}>"
         kname = (kbf if bf16 else k32) if fused else "objnerf_train_step, layer-wise path (batched MFMA GEMMs)"
         achieved = K * R * fpr / (kern_ms * 1e-3) / 1e12

@@ -1122,8 +1122,13 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
     hipLaunchKernelGGL(feat_rowstats_kernel, dim3((a->R + 15) / 16, a->K), dim3(256), 0, st, a->params,
                        (long)a->p_stride, d.L.of_b, C, a->R, a->gt_feat, rayin);
     if (bf16) launch_train_bf16(d, stream, true);
+#ifdef OBJ_FEAT_GEN1      // diagnostic builds: the first-generation feature kernel (tools/build_variant.sh)
     else if (d.relu_masks) hipLaunchKernelGGL((train_fused_kernel<true, true>), dim3(a->K * d.G), dim3(NTHR), lds_bytes, st, d);
     else hipLaunchKernelGGL((train_fused_kernel<true, false>), dim3(a->K * d.G), dim3(NTHR), lds_bytes, st, d);
+#else
+    else launch_train32(d, stream, true);
+    (void)lds_bytes;
+#endif
     if (hipGetLastError() != hipSuccess) return OBJNERF_ELAUNCH;
     // 512-d head gradient from the per-ray (fh, O, a, c): two split-K GEMMs over the rays + a small finish
     const long nr = (long)a->K * a->R;
@@ -1138,7 +1143,7 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
   } else if (bf16) {
     launch_train_bf16(d, stream, false);
   } else {
-    launch_train32(d, stream);
+    launch_train32(d, stream, false);
   }
   if (hipGetLastError() != hipSuccess) return OBJNERF_ELAUNCH;
   const long P = offs[OBJNERF_N_TENSORS];

@@ -1,7 +1,7 @@
 // Fused fp32 training iteration for K stacked hidden-32 object networks, second generation (gfx950).
 //
-// Same contract and tile structure as the first generation (objnerf_train.hip, which still serves the 512-d feature
-// loss): one launch = forward, compositing, losses, backward (dgrad + wgrad) of train.py:424-472; a 512-thread
+// Same contract and tile structure as the first generation (objnerf_train.hip: its forward-only / eval kernels and
+// the host entry points): one launch = forward, compositing, losses, backward (dgrad + wgrad) of train.py:424-472; a 512-thread
 // workgroup owns one object's weights in LDS and sweeps its rays in tiles of 128 samples; partial gradients leave as
 // one slab per workgroup (no global atomics, bit-reproducible).  What is new is in objnerf_mlp32.h: the
 // direction-owner positional encoding (no cross-group sums, d B in registers, one range reduction per direction for
@@ -50,6 +50,19 @@ __device__ __forceinline__ void wg_pair(f32x4& acc0, f32x4& acc1, const float* d
   }
 }
 
+// one 16-output half of a tile pair (the feature variant balances its 28 tile pairs over the waves in halves)
+__device__ __forceinline__ void wg_half(f32x4& acc0, const float* dT, const float* aT) {
+  dT = (const float*)__builtin_assume_aligned(dT, 8);
+  aT = (const float*)__builtin_assume_aligned(aT, 8);
+#pragma unroll 8
+  for (int st = 0; st < 32; st += 2) {
+    const f32x2 b = *reinterpret_cast<const f32x2*>(aT + st);
+    const f32x2 a0 = *reinterpret_cast<const f32x2*>(dT + st);
+    acc0 = OBJ_MFMA(a0[0], b[0], acc0);
+    acc0 = OBJ_MFMA(a0[1], b[1], acc0);
+  }
+}
+
 // one weight-gradient tile pair -> slab.  col: reference column of this lane's staged input row (>= 0), BIAS_COL
 // (-> b_off) or ZERO_COL (padding: nothing to write)
 __device__ __forceinline__ void wr_pair(float* slab, const f32x4& a0, const f32x4& a1, const int g, const int col,
@@ -67,6 +80,17 @@ __device__ __forceinline__ void wr_pair(float* slab, const f32x4& a0, const f32x
   }
 }
 
+// outputs 16 half + 4 g + r of one half pair
+__device__ __forceinline__ void wr_half(float* slab, const f32x4& a0, const int half, const int g, const int col,
+                                        const int w_off, const int ncols, const int b_off) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int o = 16 * half + 4 * g + r;
+    if (col >= 0) slab[w_off + o * ncols + col] = a0[r];
+    else if (col == BIAS_COL && b_off >= 0) slab[b_off + o] = a0[r];
+  }
+}
+
 #ifdef PHASE_TIMING
 __device__ unsigned long long g_phase32[8][24];
 #define PT_INIT() unsigned long long pt_acc[18]; for (int i_ = 0; i_ < 18; ++i_) pt_acc[i_] = 0; \
@@ -79,28 +103,55 @@ __device__ unsigned long long g_phase32[8][24];
 #define PT_FLUSH() do {} while (0)
 #endif
 
-constexpr int IMG = img_floats(false);
-constexpr int LDS_FLOATS32 = IMG + SM_FLOATS + STG_ROWS * STG_LD;
-static_assert(LDS_FLOATS32 * 4 <= 163840, "LDS budget");
-static_assert((IMG * 4) % 16 == 0, "staging area alignment");
+// LDS: weight image | sigma / rgb strip | staging area.  With the feature layer the image is 72.8 KB, so the staging area
+// has 160 rows instead of 192 and the weight-gradient rounds are laid out differently (rows of the (d_out | input)
+// operands per round; a round = one barrier-separated set of tile (half) pairs, one per wave):
+//   no feature loss  A  [h4 | x2] 0..79, h3 96.., d_hc 128.., d_h4 160..      colour 5 + mid2 2 pairs
+//                    B  [h2 | x1] 0..127, d_h3 128..                           cat 8
+//                    C  h1 0.., x1 32..127 (stays), d_h1 128.., d_h2 160..     in 6 + mid1 2
+//   feature loss     A  [h4 | x2] 0..79, d_hc 80.., d_hf 112..                 colour 5 + feature 3 pairs
+//                    A2 h3 0.., x2 48..79 (stays), d_h4 80.., d_hf (stays)     feature 2 + mid2 2 pairs, as 8 halves
+//                    B  as above                                               cat 8
+//                    C  x1 (stays), d_h1 128..                                 in 6
+//                    C2 h1 0.., d_h2 128..                                     mid1 2 pairs as 4 halves
+template <bool FEAT>
+struct Lay {
+  static constexpr int IMG = img_floats(FEAT);
+  static constexpr int ROWS = FEAT ? 160 : STG_ROWS;
+  static constexpr int LDS_FLOATS = IMG + SM_FLOATS + ROWS * STG_LD;
+  static constexpr int A_H3 = FEAT ? 0 : 96, A_DHC = FEAT ? 80 : 128, A_DHF = 112, A_DH4 = FEAT ? 80 : 160;
+  static constexpr int C_DH2 = FEAT ? 128 : 160;
+  static_assert(LDS_FLOATS * 4 <= 163840, "LDS budget");
+  static_assert((IMG * 4) % 16 == 0, "staging area alignment");
+};
+// feature branch: aliases inside the staging area (float offsets), live from the forward pass to the start of phase A.
+// hidden-feature buffer [128][33] at 0, Gram matrix + wb + bb, per-wave exchange buffers (objnerf_train_common.h
+// OFF_GBUF / OFF_FHB: rows 0..45); compositing weights, d loss / d fh, opacity terms in rows 144..159, which no round
+// of the feature layout stages.
+constexpr int F_SW = 144 * STG_LD;          // s_w [128]
+constexpr int F_GFH = F_SW + TS;            // gfh [16][32]
+constexpr int F_GOF = F_GFH + 16 * 32;      // gO_feat [16], O [16]
+static_assert(F_GOF + 32 <= 160 * STG_LD && OFF_FHB + 64 * NWAVE <= 80 * STG_LD, "feature aliases");
 
 // SS: samples per ray when known at compile time (64 = the metric shape: no integer divisions by S, only the row-scan
 // compositing is compiled in), 0 = any S <= 64 at run time.
-template <bool MASKS, int SS>
+template <bool FEAT, bool MASKS, int SS>
 __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
+  typedef Lay<FEAT> LY;
+  constexpr int IMG = LY::IMG;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, g = lane >> 4;
   const int k = blockIdx.x / a.G, gi = blockIdx.x % a.G;
-  float* sv = lds + sv_base(false);
+  float* sv = lds + sv_base(FEAT);
   float* s_alpha = lds + IMG;            // [4][TS]: 10 * raw alpha | colour[3]; overwritten in place by their gradients
   float* s_col = s_alpha + TS;
   float* stg = lds + IMG + SM_FLOATS;
 
-  stage_weights32(lds, a.params + (long)k * a.p_stride, a.L, false, tid, NTHR);
-  for (int i = tid; i < STG_ROWS * STG_LD; i += NTHR) stg[i] = 0.0f;
+  stage_weights32(lds, a.params + (long)k * a.p_stride, a.L, FEAT, tid, NTHR);
+  for (int i = tid; i < LY::ROWS * STG_LD; i += NTHR) stg[i] = 0.0f;
   __syncthreads();
 
   const float scale = a.scale[k];
@@ -118,6 +169,7 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
 
   // persistent gradient accumulators
   f32x4 accA0 = zero4(), accA1 = zero4(), accB0 = zero4(), accB1 = zero4(), accC0 = zero4(), accC1 = zero4();
+  f32x4 accA2 = zero4(), accC2 = zero4();    // feature layout: the half pairs of rounds A2 and C2
   // row-wise sums over samples: slot s of a register = lane s of each lane group; feature of slot s (< 8) is
   // 16 (s >> 2) + 4 g + (s & 3); lanes 8..15 carry a second quantity
   // Row sums over the samples (head weights, mid1 / mid2 biases).  Two forms: transposing DPP butterflies into "slot"
@@ -126,14 +178,17 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
   // lane's samples, reduced over the 16 lanes of the group once at the end (fewer instructions, 32 / 16 more
   // registers).  The head weights are lazy by default (10.08 -> 9.78 ms on the 50 x 4096 x 64 step); both together
   // do not fit the 256 registers of a 512-thread workgroup (OBJ_LAZY_BIAS alone: 9.91 ms).
+  // (the feature variant needs the 30 registers: butterfly form there; whichever form is unused is dead code)
 #ifdef OBJ_LAZY_HEADS
+  constexpr bool LAZY_H = !FEAT;
+#else
+  constexpr bool LAZY_H = false;
+#endif
   float hW[4][8];     // d W_alpha, d W_oc[0..2];  [.][4 tt + r] <-> feature 16 tt + 4 g + r
 #pragma unroll
   for (int s_ = 0; s_ < 8; ++s_) hW[0][s_] = hW[1][s_] = hW[2][s_] = hW[3][s_] = 0.f;
-#else
   float gS0 = 0.f;   // [0..7] d W_alpha   | [8..15] d W_oc[0]
   float gS1 = 0.f;   // [0..7] d W_oc[1]   | [8..15] d W_oc[2]
-#endif
 #ifdef OBJ_LAZY_BIAS
   float bS[2][8];     // d b_mid1, d b_mid2
 #pragma unroll
@@ -145,7 +200,7 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
   float dB[6][3];    // d B[4 i + g][x], summed over this lane's samples
 #pragma unroll
   for (int i = 0; i < 6; ++i) dB[i][0] = dB[i][1] = dB[i][2] = 0.f;
-  float l_d = 0.f, l_c = 0.f, l_o = 0.f;
+  float l_d = 0.f, l_c = 0.f, l_o = 0.f, l_f = 0.f;
 
   // sample position of (tile, slot); issued one tile ahead (phase C) so that the HBM latency is off the tile's
   // critical path
@@ -189,7 +244,7 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
       Emb32 e;                        // forward-only: the backward re-creates the embedding tile by tile
       embed32(e, pe, g);
       PT(1);
-      s_alpha[g * TS + slot] = mlp32_forward<false>(wf, sv, g, e, act);
+      s_alpha[g * TS + slot] = mlp32_forward<FEAT>(wf, sv, g, e, act);
     }
     if (MASKS) {                      // test hook: ReLU branch bits of this lane's sample
       uint8_t* dst = a.relu_masks + (((long)k * R + (valid ? ray : 0)) * S + (slot - q * S)) * 24;
@@ -198,6 +253,20 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
       write_relu_mask(dst, 2, g, act.h3, valid);
       write_relu_mask(dst, 3, g, act.h4, valid);
       write_relu_mask(dst, 4, g, act.hc, valid);
+      if (FEAT) write_relu_mask(dst, 5, g, act.hf, valid);
+    }
+    if (FEAT) {
+      // hidden feature of the tile -> [128][33] buffer; this object's Gram matrix (+ wb, bb) beside it (section 4.3 of
+      // the 512-d head is hoisted past the compositing)
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) stg[slot * HF_LD + 16 * tt + 4 * g + r] = act.hf.t[tt][r];
+      for (int i = tid; i < 32 * 32 + 33; i += NTHR) {
+        const float v = a.gram[(long)k * GRAM + i];
+        if (i < 1024) stg[OFF_GBUF + (i >> 5) * 33 + (i & 31)] = v;
+        else stg[OFF_GBUF + 32 * 33 + (i - 1024)] = v;
+      }
     }
     PT(2);
     // ray inputs of this wave's compositing pass, requested BEFORE the barrier so their latency hides behind it
@@ -218,6 +287,32 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
     float pf_zz = 0.f, pf_gtd = 0.f, pf_gr = 0.f, pf_gg = 0.f, pf_gb = 0.f;
     int pf_lab = 2;
     if (w * (64 / S) < TR) ray_inputs(w, pf_zz, pf_gtd, pf_gr, pf_gg, pf_gb, pf_lab);
+    // feature term: (u[hh], beta, |g|, label) of ray pair (qb, half) -- same idea, first pair of the pass
+    auto feat_inputs = [&](const int ps_, const int qb_, float& uh_, float& beta_, float& ngv_, int& lab_) {
+      const int rpp_ = 64 / S;
+      const int ql2_ = qb_ + (lane >> 5);
+      const int qq2_ = ps_ * rpp_ + ql2_;
+      const int ray2_ = ray0 + qq2_;
+      uh_ = 0.f; beta_ = 0.f; ngv_ = 1.f; lab_ = 2;
+      if ((ql2_ < rpp_) && (qq2_ < TR) && (ray2_ < R)) {
+        const long rr2_ = (long)k * R + ray2_;
+        uh_ = a.rayin[rr2_ * RAYIN + (lane & 31)];
+        beta_ = a.rayin[rr2_ * RAYIN + 32];
+        ngv_ = a.rayin[rr2_ * RAYIN + 33];
+        lab_ = (int)a.labels[rr2_];
+      }
+    };
+    float pf_uh = 0.f, pf_beta = 0.f, pf_ngv = 1.f;
+    int pf_lab2 = 2;
+    if (FEAT && S == 64) {
+      if (valid) {        // every wave takes part in its ray's feature term (below)
+        const long rr2_ = (long)k * R + ray;
+        pf_uh = a.rayin[rr2_ * RAYIN + (lane & 31)];
+        pf_beta = a.rayin[rr2_ * RAYIN + 32];
+        pf_ngv = a.rayin[rr2_ * RAYIN + 33];
+        pf_lab2 = (int)a.labels[rr2_];
+      }
+    } else if (FEAT && w * (64 / S) < TR) feat_inputs(w, 0, pf_uh, pf_beta, pf_ngv, pf_lab2);
     __syncthreads();
     PT(3);
     // ---------------------------------------------------------------- 2. composite + loss (loss.py:27-101)
@@ -264,7 +359,90 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
           l_c += m1 * (fabsf(r0) + fabsf(r1) + fabsf(r2)) * inv1;
           l_o += m2 * fabsf(ro) * inv2;
         }
-        const float dw = gD * zz + gO + gC0 * c0 + gC1 * c1 + gC2 * c2;
+        float dw = gD * zz + gO + gC0 * c0 + gC1 * c1 + gC2 * c2;
+        if (FEAT) {
+          // ---- feature-distillation term (loss.py:82-99) with the linear 512-d head hoisted past the
+          // compositing: F = W_of fh + b_of O,  fh = sum_s w_s hf_s.  cos(F, g) only needs
+          //   F.g = fh.u + O beta,   |F|^2 = fh^T G fh + 2 O wb.fh + O^2 bb     (u, beta, G, wb, bb precomputed)
+          float* s_w = stg + F_SW;
+          float* s_gfh = stg + F_GFH;
+          float* s_gof = stg + F_GOF;
+          float* s_fhb = stg + OFF_FHB + 64 * w;
+          const float* Gb = stg + OFF_GBUF;
+          if (on) s_w[sl] = wgt;
+          if (on && pos == 0) s_gof[16 + qq] = O;
+          __builtin_amdgcn_wave_barrier();
+          asm volatile("" ::: "memory");
+          const int half = lane >> 5, hh = lane & 31;
+          for (int qb = 0; qb < rpp; qb += 2) {
+            const int ql2 = qb + half;
+            const int qq2 = ps * rpp + ql2;
+            const int ray2 = ray0 + qq2;
+            const bool on2 = (ql2 < rpp) && (qq2 < TR) && (ray2 < R);
+            const long rr2 = (long)k * R + (on2 ? ray2 : 0);
+            float fh = 0.f;
+            if (rpp == 1) {
+              // one ray per pass (S = 33..64): both 32-lane halves work on it, half the samples each
+              const bool on1 = (qb < rpp) && (ps * rpp + qb < TR) && (ray0 + ps * rpp + qb < R);
+              const int q1 = ps * rpp + qb;
+              if (on1) {
+                float f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f;
+                const float* wp = s_w + q1 * S;
+                const float* hp = stg + (q1 * S) * HF_LD + hh;
+                int s2 = half;
+                for (; s2 + 6 < S; s2 += 8) {
+                  f0 = fmaf(wp[s2], hp[s2 * HF_LD], f0);
+                  f1 = fmaf(wp[s2 + 2], hp[(s2 + 2) * HF_LD], f1);
+                  f2 = fmaf(wp[s2 + 4], hp[(s2 + 4) * HF_LD], f2);
+                  f3 = fmaf(wp[s2 + 6], hp[(s2 + 6) * HF_LD], f3);
+                }
+                for (; s2 < S; s2 += 2) f0 = fmaf(wp[s2], hp[s2 * HF_LD], f0);
+                fh = (f0 + f1) + (f2 + f3);
+              }
+              fh += __shfl_xor(fh, 32, 64);
+            } else if (on2) {
+              for (int s2 = 0; s2 < S; ++s2) fh = fmaf(s_w[qq2 * S + s2], stg[(qq2 * S + s2) * HF_LD + hh], fh);
+            }
+            s_fhb[half * 32 + hh] = fh;
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("" ::: "memory");
+            float Gfh = 0.f;
+#pragma unroll 8
+            for (int h2 = 0; h2 < 32; ++h2) Gfh = fmaf(Gb[hh * 33 + h2], s_fhb[half * 32 + h2], Gfh);
+            const float wbh = Gb[32 * 33 + hh], bb = Gb[32 * 33 + 32];
+            float uh = pf_uh, beta = pf_beta, ngv = pf_ngv;
+            int lab2 = pf_lab2;
+            if (ps != w || qb != 0) feat_inputs(ps, qb, uh, beta, ngv, lab2);
+            const float O2 = on2 ? s_gof[16 + qq2] : 0.f;
+            const float fu = wave_sum32(fh * uh), fGf = wave_sum32(fh * Gfh), fwb = wave_sum32(fh * wbh);
+            const float dotFg = fu + O2 * beta;
+            const float nF2 = fmaxf(fGf + 2.0f * O2 * fwb + O2 * O2 * bb, 0.0f);
+            const float nF = fmaxf(sqrtf(nF2), 1e-8f), ngc = fmaxf(ngv, 1e-8f);
+            const float cosv = dotFg / (nF * ngc);
+            const float mm1 = (lab2 == 1) ? 1.0f : 0.0f;
+            const float gam = -a.feat_scaling * mm1 * inv1;         // d total / d cos
+            const float ar = gam / (nF * ngc), cr = -gam * cosv / (nF * nF);
+            if (on2) {
+              if (hh == 0) {
+                l_f += mm1 * (1.0f - cosv) * inv1;
+                s_gof[qq2] = ar * beta + cr * (fwb + O2 * bb);       // d total / d opacity (feature part)
+                a.rayfeat[rr2 * RAYFEAT + 32] = O2;      // layout (fh[32], O, a, c): [fh | O] is a GEMM operand
+                a.rayfeat[rr2 * RAYFEAT + 33] = ar;
+                a.rayfeat[rr2 * RAYFEAT + 34] = cr;
+              }
+              s_gfh[qq2 * 32 + hh] = ar * uh + cr * (Gfh + O2 * wbh);   // d total / d fh
+              a.rayfeat[rr2 * RAYFEAT + hh] = fh;
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("" ::: "memory");
+          }
+          if (on) {
+            float dwf = s_gof[qq];
+#pragma unroll 8
+            for (int h2 = 0; h2 < 32; ++h2) dwf = fmaf(s_gfh[qq * 32 + h2], stg[sl * HF_LD + h2], dwf);
+            dw += dwf;
+          }
+        }
         const float qv = dw * wgt;
         const float suf = sg.rscan_add(qv, pos) - qv;            // sum_{j>i} dL/dw_j * w_j
         const float docc = dw * T - suf / fr;
@@ -276,7 +454,134 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
         }
       }
     };
-    if (SS || rows_mode) composite_passes(seg_rows); else composite_passes(SegGeneric{S});
+    if (FEAT && S == 64) {
+      // 64 samples per ray (the north-star shape): the feature term's reductions over samples and hidden features
+      // are spread over all 8 waves instead of running on the two compositing waves (3 extra barriers, a much
+      // shorter critical path).  Wave w holds samples 16w..16w+15 of ray w >> 2.  Same arithmetic as the
+      // general path above.
+      const SegRows& sg = seg_rows;
+      float* s_w = stg + F_SW;
+      float* s_gfh = stg + F_GFH;
+      float* s_gof = stg + F_GOF;
+      float* s_part = s_gfh + 192;          // [NWAVE][32] partial composited features (s_gfh holds 2 rays here)
+      float* s_dwf = s_gfh + 64;            // [128]
+      const int pos = lane;
+      const int sl = w * 64 + pos;
+      const bool on = (w < TR) && (ray0 + w < R);
+      float occ = 0.f, fr = 1.f, T = 1.f, wgt = 0.f, dw = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, gC0 = 0.f, gC1 = 0.f, gC2 = 0.f;
+      if (w < TR) {
+        const float zz = pf_zz;
+        float al = 0.f;
+        if (on) { al = s_alpha[sl]; c0 = s_col[sl]; c1 = s_col[TS + sl]; c2 = s_col[2 * TS + sl]; }
+        occ = on ? sigmoid_acc(al) : 0.0f;
+        fr = on ? (1.0f - occ) + 1e-10f : 1.0f;
+        const float Pinc = sg.scan_mul(fr, pos);
+        T = __shfl_up(Pinc, 1, 64);
+        if (pos == 0) T = 1.0f;
+        wgt = occ * T;
+        const float D = sg.total_add(wgt * zz, pos);
+        const float O = sg.total_add(wgt, pos);
+        const float C0 = sg.total_add(wgt * c0, pos);
+        const float C1 = sg.total_add(wgt * c1, pos);
+        const float C2 = sg.total_add(wgt * c2, pos);
+        const float dz = zz - D;
+        const float V = sg.total_add(wgt * (dz * dz), pos);
+        const float m1 = (pf_lab == 1) ? 1.0f : 0.0f;
+        const float m2 = (pf_lab != 2) ? 1.0f : 0.0f;
+        const float tgt = (pf_lab != 0) ? 1.0f : 0.0f;
+        const float info = 1.0f / (sqrtf(V) + 1e-4f);
+        const float rd = D - pf_gtd, r0 = C0 - pf_gr, r1 = C1 - pf_gg, r2 = C2 - pf_gb, ro = O - tgt;
+        auto sgn = [](float x) { return x > 0.f ? 1.0f : (x < 0.f ? -1.0f : 0.0f); };
+        const float gD = m1 * sgn(rd) * info * inv1;
+        gC0 = a.color_scaling * m1 * sgn(r0) * inv1;
+        gC1 = a.color_scaling * m1 * sgn(r1) * inv1;
+        gC2 = a.color_scaling * m1 * sgn(r2) * inv1;
+        const float gO = a.opacity_scaling * m2 * sgn(ro) * inv2;
+        if (on && pos == 0) {
+          l_d += m1 * fabsf(rd) * info * inv1;
+          l_c += m1 * (fabsf(r0) + fabsf(r1) + fabsf(r2)) * inv1;
+          l_o += m2 * fabsf(ro) * inv2;
+          s_gof[16 + w] = O;
+        }
+        dw = gD * zz + gO + gC0 * c0 + gC1 * c1 + gC2 * c2;
+        if (on) s_w[sl] = wgt;
+      }
+      __syncthreads();
+      {
+        const float wv = valid ? s_w[slot] : 0.0f;
+        float v8[8];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v8[4 * tt + r] = wv * stg[slot * HF_LD + 16 * tt + 4 * g + r];
+        const float psum = slot_sums8(v8, c);
+        if (c < 8) s_part[w * 32 + 16 * ((c & 7) >> 2) + 4 * g + (c & 3)] = psum;
+      }
+      __syncthreads();
+      {
+        float* s_fhb = stg + OFF_FHB + 64 * w;
+        const float* Gb = stg + OFF_GBUF;
+        const int half = lane >> 5, hh = lane & 31;
+        const int w0 = w & ~3;
+        const float fh = valid ? (s_part[w0 * 32 + hh] + s_part[(w0 + 1) * 32 + hh]) +
+                                 (s_part[(w0 + 2) * 32 + hh] + s_part[(w0 + 3) * 32 + hh]) : 0.0f;
+        if (half == 0) s_fhb[hh] = fh;
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+        float Gp = 0.f;
+#pragma unroll
+        for (int h2 = 0; h2 < 16; ++h2) Gp = fmaf(Gb[hh * 33 + 16 * half + h2], s_fhb[16 * half + h2], Gp);
+        const float Gfh = Gp + __shfl_xor(Gp, 32, 64);
+        const float wbh = Gb[32 * 33 + hh], bb = Gb[32 * 33 + 32];
+        const float uh = pf_uh, beta = pf_beta, ngv = pf_ngv;
+        const float O2 = valid ? s_gof[16 + q] : 0.f;
+        const float fu = wave_sum32(fh * uh), fGf = wave_sum32(fh * Gfh), fwb = wave_sum32(fh * wbh);
+        const float dotFg = fu + O2 * beta;
+        const float nF2 = fmaxf(fGf + 2.0f * O2 * fwb + O2 * O2 * bb, 0.0f);
+        const float nF = fmaxf(sqrtf(nF2), 1e-8f), ngc = fmaxf(ngv, 1e-8f);
+        const float cosv = dotFg / (nF * ngc);
+        const float mm1 = (pf_lab2 == 1) ? 1.0f : 0.0f;
+        const float gam = -a.feat_scaling * mm1 * inv1;
+        const float ar = gam / (nF * ngc), cr = -gam * cosv / (nF * nF);
+        const float gfh = ar * uh + cr * (Gfh + O2 * wbh);
+        const float gof = ar * beta + cr * (fwb + O2 * bb);
+        if (valid && (w & 3) == 0 && half == 0) {
+          const long rr2 = (long)k * R + ray;
+          if (hh == 0) {
+            l_f += mm1 * (1.0f - cosv) * inv1;
+            a.rayfeat[rr2 * RAYFEAT + 32] = O2;
+            a.rayfeat[rr2 * RAYFEAT + 33] = ar;
+            a.rayfeat[rr2 * RAYFEAT + 34] = cr;
+          }
+          s_gfh[q * 32 + hh] = gfh;
+          a.rayfeat[rr2 * RAYFEAT + hh] = fh;
+        }
+        if (half == 0) s_fhb[32 + hh] = gfh;
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+        float dp = 0.f;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            dp = fmaf(s_fhb[32 + 16 * tt + 4 * g + r], stg[slot * HF_LD + 16 * tt + 4 * g + r], dp);
+        const float dwf = xgroup_sum(dp) + gof;
+        if (g == 0 && valid) s_dwf[slot] = dwf;
+      }
+      __syncthreads();
+      if (w < TR) {
+        if (on) dw += s_dwf[sl];
+        const float qv = dw * wgt;
+        const float suf = sg.rscan_add(qv, pos) - qv;
+        const float docc = dw * T - suf / fr;
+        if (on) {
+          s_alpha[sl] = 10.0f * (docc * occ * (1.0f - occ));
+          s_col[sl] = gC0 * wgt * c0 * (1.0f - c0);
+          s_col[TS + sl] = gC1 * wgt * c1 * (1.0f - c1);
+          s_col[2 * TS + sl] = gC2 * wgt * c2 * (1.0f - c2);
+        }
+      }
+    } else if (SS || rows_mode) composite_passes(seg_rows); else composite_passes(SegGeneric{S});
     PT(4);
     __syncthreads();
     PT(5);
@@ -294,12 +599,22 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
 #pragma unroll
     for (int i = 0; i < 6; ++i) asm volatile("" : "+v"(pe.vh[i]), "+v"(pe.vl[i]));
 
-    // ---- phase A: heads, colour layer, mid2
+    // ---- phase A: heads, colour layer, (feature layer,) mid2
+    T32 d_hf = zero32();
+    if (FEAT) {           // d loss / d hf_s = w_s * (d loss / d fh of the sample's ray), through the ReLU
+      const float wv = valid ? stg[F_SW + slot] : 0.0f;
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float gv = valid ? stg[F_GFH + q * 32 + 16 * tt + 4 * g + r] : 0.0f;
+          // (the hidden feature is re-read from its LDS buffer: 8 registers less across the compositing)
+          d_hf.t[tt][r] = stg[slot * HF_LD + 16 * tt + 4 * g + r] > 0.0f ? wv * gv : 0.0f;
+        }
+    }
     T32 d_hc, d_h4;
     float pa_[8];
-#ifndef OBJ_LAZY_HEADS
-    float pb_[8], pc_[8], pd_[8];       // head-weight gradient products, summed over the samples below
-#endif
+    float pb_[8], pc_[8], pd_[8];       // head-weight gradient products, summed over the samples below (butterfly form)
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
@@ -307,31 +622,33 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
         const int row = 16 * tt + 4 * g + r;
         const int s = 4 * tt + r;
         const float hv = act.hc.t[tt][r];
-#ifdef OBJ_LAZY_HEADS
-        hW[0][s] = fmaf(da, act.h4.t[tt][r], hW[0][s]);
-        hW[1][s] = fmaf(dc0, hv, hW[1][s]);
-        hW[2][s] = fmaf(dc1, hv, hW[2][s]);
-        hW[3][s] = fmaf(dc2, hv, hW[3][s]);
-#else
-        pa_[s] = da * act.h4.t[tt][r];
-        pb_[s] = dc0 * hv;
-        pc_[s] = dc1 * hv;
-        pd_[s] = dc2 * hv;
-#endif
+        if (LAZY_H) {
+          hW[0][s] = fmaf(da, act.h4.t[tt][r], hW[0][s]);
+          hW[1][s] = fmaf(dc0, hv, hW[1][s]);
+          hW[2][s] = fmaf(dc1, hv, hW[2][s]);
+          hW[3][s] = fmaf(dc2, hv, hW[3][s]);
+        } else {
+          pa_[s] = da * act.h4.t[tt][r];
+          pb_[s] = dc0 * hv;
+          pc_[s] = dc1 * hv;
+          pd_[s] = dc2 * hv;
+        }
         const float dv = fmaf(sv[SV_WOC + 2 * H + row], dc2, fmaf(sv[SV_WOC + H + row], dc1, sv[SV_WOC + row] * dc0));
         d_hc.t[tt][r] = hv > 0.0f ? dv : 0.0f;
         d_h4.t[tt][r] = sv[SV_WA + row] * da;
       }
-    // group A staging: [h4 | x2] rows 0..79, h3 rows 96..127, d_hc rows 128.., d_h4pre rows 160..
-#ifndef OBJ_LAZY_HEADS
-    gS0 += slot_sums16(pa_, pb_, c);
-    gS1 += slot_sums16(pc_, pd_, c);
-    asm volatile("" : "+v"(gS0), "+v"(gS1));
-#endif
+    // round A staging (row maps: Lay)
+    if (!LAZY_H) {
+      gS0 += slot_sums16(pa_, pb_, c);
+      gS1 += slot_sums16(pc_, pd_, c);
+      asm volatile("" : "+v"(gS0), "+v"(gS1));
+    }
     st_T32(stg_lane, 0, act.h4);
-    st_T32(stg_lane, 96, act.h3);
-    st_T32(stg_lane, 128, d_hc);
+    if (!FEAT) st_T32(stg_lane, LY::A_H3, act.h3);
+    st_T32(stg_lane, LY::A_DHC, d_hc);
+    if (FEAT) st_T32(stg_lane, LY::A_DHF, d_hf);
     mma_t32(d_h4, wt0, wt1, R_CL, d_hc);
+    if (FEAT) mma_t32(d_h4, wt0, wt1, R_FL, d_hf);
     d_h4 = relu_mask32(d_h4, act.h4);
 #ifdef OBJ_LAZY_BIAS
 #pragma unroll
@@ -349,12 +666,13 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
       asm volatile("" : "+v"(gS2));
     }
 #endif
-    st_T32(stg_lane, 160, d_h4);
+    if (!FEAT) st_T32(stg_lane, LY::A_DH4, d_h4);
     // PE backward, x2 part (octaves 4, 5): a 16-row tile = two direction slots
 #pragma unroll
     for (int T = 0; T < 3; ++T) {
       f32x4 d_x = zero4();
       mma_t16(d_x, wt0, wt1, R_CL + 32 + 16 * T, d_hc);
+      if (FEAT) mma_t16(d_x, wt0, wt1, R_FL + 32 + 16 * T, d_hf);
       float o0, o1, o2, o3;
       pe32_x2_pair_fb(pe, 2 * T, g, d_x[0], d_x[1], dps[2 * T], o0, o1);
       pe32_x2_pair_fb(pe, 2 * T + 1, g, d_x[2], d_x[3], dps[2 * T + 1], o2, o3);
@@ -366,7 +684,24 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
     PT(6);
     __syncthreads();
     PT(7);
-    if (w < 7) {
+    if (FEAT) {
+      // round A: colour tiles 0..4 (waves 0..4), feature tiles 0..2 (waves 5..7)
+      const int dTr = (w < 5) ? LY::A_DHC : LY::A_DHF;
+      const int aTr = (w < 5) ? 16 * w : 16 * (w - 5);
+      wg_pair(accA0, accA1, lane_rd + dTr * STG_LD, lane_rd + aTr * STG_LD);
+      __syncthreads();
+      // round A2: h3 over the h4 rows, d_h4 over the d_hc rows; feature tiles 3, 4 (x2 rows 48..79, d_hf still in
+      // place) and the two mid2 tiles, one 16-output half per wave
+      st_T32(stg_lane, LY::A_H3, act.h3);
+      st_T32(stg_lane, LY::A_DH4, d_h4);
+      __syncthreads();
+      {
+        const int half = w & 1, t2 = (w & 3) >> 1;
+        const int dTr = ((w < 4) ? LY::A_DHF : LY::A_DH4) + 16 * half;
+        const int aTr = (w < 4) ? 48 + 16 * t2 : LY::A_H3 + 16 * t2;
+        wg_half(accA2, lane_rd + dTr * STG_LD, lane_rd + aTr * STG_LD);
+      }
+    } else if (w < 7) {
       const int dTr = (w < 5) ? 128 : 160;
       const int aTr = (w < 5) ? 16 * w : 96 + 16 * (w - 5);
       wg_pair(accA0, accA1, lane_rd + dTr * STG_LD, lane_rd + aTr * STG_LD);
@@ -426,17 +761,26 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
     fetch_point(tile + a.G, slot, nx, ny, nz);
     st_T32(stg_lane, 0, act.h1);
     st_T32(stg_lane, 128, d_h1);
-    st_T32(stg_lane, 160, d_h2);
+    if (!FEAT) st_T32(stg_lane, LY::C_DH2, d_h2);
     PT(14);
     __syncthreads();
     PT(15);
-    {
+    if (FEAT) {
+      // round C: the six in-layer tiles; round C2: d_h2 over the d_h1 rows, the two mid1 tiles as four halves
+      if (w < 6) wg_pair(accC0, accC1, lane_rd + 128 * STG_LD, lane_rd + (32 + 16 * w) * STG_LD);
+      __syncthreads();
+      st_T32(stg_lane, LY::C_DH2, d_h2);
+      __syncthreads();
+      if (w < 4) wg_half(accC2, lane_rd + (LY::C_DH2 + 16 * (w & 1)) * STG_LD, lane_rd + (16 * (w >> 1)) * STG_LD);
+      // the next tile's forward pass writes its hidden-feature buffer into rows this round is reading
+      __syncthreads();
+    } else {
       const int dTr = (w < 6) ? 128 : 160;
       const int aTr = (w < 6) ? 32 + 16 * w : 16 * (w - 6);
       wg_pair(accC0, accC1, lane_rd + dTr * STG_LD, lane_rd + aTr * STG_LD);
     }
     PT(16);
-    // The staging area is next written in phase A of the following tile, two barriers from here.
+    // (no feature loss: the staging area is next written in phase A of the following tile, two barriers from here)
     PT(17);
   }
   PT_FLUSH();
@@ -447,11 +791,20 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
   {
     // reference column of the staged input row this lane's accumulator column stands for
     int t_, g_;
-    if (w < 5) {                                  // colour layer: [h4 | x2]
-      const int rho = 16 * w + c;
+    // reference column of row rho of a [h4 | x2] operand (colour and feature layers)
+    auto cl_col = [&](const int rho) {
       int col = rho;
       if (rho >= H) { kappa_tg(rho - H, t_, g_); col = x2_col(t_, g_); if (col >= 0) col += H; }
-      wr_pair(slab, accA0, accA1, g, col, L.cl_w, H + OBJ_E2, L.cl_b);
+      return col;
+    };
+    if (FEAT) {
+      if (w < 5) wr_pair(slab, accA0, accA1, g, cl_col(16 * w + c), L.cl_w, H + OBJ_E2, L.cl_b);
+      else wr_pair(slab, accA0, accA1, g, cl_col(16 * (w - 5) + c), L.fl_w, H + OBJ_E2, L.fl_b);
+      const int half = w & 1, t2 = (w & 3) >> 1;
+      if (w < 4) wr_half(slab, accA2, half, g, cl_col(48 + 16 * t2 + c), L.fl_w, H + OBJ_E2, L.fl_b);
+      else wr_half(slab, accA2, half, g, 16 * t2 + c, L.m2_w, H, -1);
+    } else if (w < 5) {                           // colour layer: [h4 | x2]
+      wr_pair(slab, accA0, accA1, g, cl_col(16 * w + c), L.cl_w, H + OBJ_E2, L.cl_b);
     } else if (w < 7) {
       wr_pair(slab, accA0, accA1, g, 16 * (w - 5) + c, L.m2_w, H, -1);
     }
@@ -464,9 +817,10 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
     if (w < 6) {                                  // in layer: x1
       kappa_tg(16 * w + c, t_, g_);
       wr_pair(slab, accC0, accC1, g, x1_col(t_, g_), L.in_w, OBJ_E1, L.in_b);
-    } else {
+    } else if (!FEAT) {
       wr_pair(slab, accC0, accC1, g, 16 * (w - 6) + c, L.m1_w, H, -1);
     }
+    if (FEAT && w < 4) wr_half(slab, accC2, w & 1, g, 16 * (w >> 1) + c, L.m1_w, H, -1);
   }
   // slot registers -> LDS (per wave), then sum the 8 waves
   __syncthreads();    // the last tile's weight-gradient reads of the staging area are done
@@ -477,18 +831,18 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
     {
       const int s = c & 7;
       const int row = 16 * (s >> 2) + 4 * g + (s & 3);
-#ifdef OBJ_LAZY_HEADS
+      if (LAZY_H) {
 #pragma unroll
-      for (int s_ = 0; s_ < 8; ++s_) {
-        const int rw = 16 * (s_ >> 2) + 4 * g + (s_ & 3);
-        const float v2 = dpp_rowsum16(hW[0][s_]), v3 = dpp_rowsum16(hW[1][s_]);
-        const float v4 = dpp_rowsum16(hW[2][s_]), v5 = dpp_rowsum16(hW[3][s_]);
-        if (c == 0) { mine[64 + rw] = v2; mine[96 + rw] = v3; mine[128 + rw] = v4; mine[160 + rw] = v5; }
+        for (int s_ = 0; s_ < 8; ++s_) {
+          const int rw = 16 * (s_ >> 2) + 4 * g + (s_ & 3);
+          const float v2 = dpp_rowsum16(hW[0][s_]), v3 = dpp_rowsum16(hW[1][s_]);
+          const float v4 = dpp_rowsum16(hW[2][s_]), v5 = dpp_rowsum16(hW[3][s_]);
+          if (c == 0) { mine[64 + rw] = v2; mine[96 + rw] = v3; mine[128 + rw] = v4; mine[160 + rw] = v5; }
+        }
+      } else {
+        if (c < 8) { mine[64 + row] = gS0; mine[128 + row] = gS1; }          // wa, woc1
+        else { mine[96 + row] = gS0; mine[160 + row] = gS1; }                // woc0, woc2
       }
-#else
-      if (c < 8) { mine[64 + row] = gS0; mine[128 + row] = gS1; }          // wa, woc1
-      else { mine[96 + row] = gS0; mine[160 + row] = gS1; }                // woc0, woc2
-#endif
 #ifdef OBJ_LAZY_BIAS
 #pragma unroll
       for (int s_ = 0; s_ < 8; ++s_) {
@@ -503,7 +857,8 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
     const float hb = dpp_rowsum16(g_hb);                 // this lane group's head-bias gradient
     if (c == 0) mine[192 + g] = hb;
     const float e0 = wave_sum64(l_d), e1 = wave_sum64(l_c), e2 = wave_sum64(l_o);
-    if (lane == 0) { mine[196] = e0; mine[197] = e1; mine[198] = e2; mine[199] = 0.0f; }
+    const float e3 = FEAT ? wave_sum64(l_f) : 0.0f;
+    if (lane == 0) { mine[196] = e0; mine[197] = e1; mine[198] = e2; mine[199] = e3; }
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
@@ -532,20 +887,27 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
 
 namespace objtrain {
 
-size_t fused32_lds_bytes() { return (size_t)LDS_FLOATS32 * 4; }
+size_t fused32_lds_bytes() { return (size_t)Lay<false>::LDS_FLOATS * 4; }
 
-void launch_train32(const TrainDev& d, void* stream) {
+void launch_train32(const TrainDev& d, void* stream, bool feat) {
+  constexpr int n0 = Lay<false>::LDS_FLOATS * 4, n1 = Lay<true>::LDS_FLOATS * 4;
   objnerf_once_per_device([] {
-    const int n = (int)fused32_lds_bytes();
-    (void)hipFuncSetAttribute((const void*)train_fused32_kernel<false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
-    (void)hipFuncSetAttribute((const void*)train_fused32_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
-    (void)hipFuncSetAttribute((const void*)train_fused32_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
+    (void)hipFuncSetAttribute((const void*)train_fused32_kernel<false, false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, n0);
+    (void)hipFuncSetAttribute((const void*)train_fused32_kernel<false, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, n0);
+    (void)hipFuncSetAttribute((const void*)train_fused32_kernel<false, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, n0);
+    (void)hipFuncSetAttribute((const void*)train_fused32_kernel<true, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, n1);
+    (void)hipFuncSetAttribute((const void*)train_fused32_kernel<true, false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, n1);
+    (void)hipFuncSetAttribute((const void*)train_fused32_kernel<true, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, n1);
   });
   const dim3 grid(d.K * d.G), blk(NTHR);
   hipStream_t st = (hipStream_t)stream;
-  if (d.relu_masks) hipLaunchKernelGGL((train_fused32_kernel<true, 0>), grid, blk, fused32_lds_bytes(), st, d);
-  else if (d.S == 64) hipLaunchKernelGGL((train_fused32_kernel<false, 64>), grid, blk, fused32_lds_bytes(), st, d);
-  else hipLaunchKernelGGL((train_fused32_kernel<false, 0>), grid, blk, fused32_lds_bytes(), st, d);
+  if (feat) {
+    if (d.relu_masks) hipLaunchKernelGGL((train_fused32_kernel<true, true, 0>), grid, blk, n1, st, d);
+    else if (d.S == 64) hipLaunchKernelGGL((train_fused32_kernel<true, false, 64>), grid, blk, n1, st, d);
+    else hipLaunchKernelGGL((train_fused32_kernel<true, false, 0>), grid, blk, n1, st, d);
+  } else if (d.relu_masks) hipLaunchKernelGGL((train_fused32_kernel<false, true, 0>), grid, blk, n0, st, d);
+  else if (d.S == 64) hipLaunchKernelGGL((train_fused32_kernel<false, false, 64>), grid, blk, n0, st, d);
+  else hipLaunchKernelGGL((train_fused32_kernel<false, false, 0>), grid, blk, n0, st, d);
 }
 
 }  // namespace objtrain

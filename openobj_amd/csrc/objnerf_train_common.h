@@ -59,9 +59,9 @@ __device__ __forceinline__ void write_relu_mask(uint8_t* dst /* masks of this la
   }
 }
 
-// second-generation fp32 kernel (objnerf_train32.hip): RGB + depth + opacity loss, hidden 32, S <= 64
+// second-generation fp32 kernel (objnerf_train32.hip): hidden 32, S <= 64, with or without the feature loss
 size_t fused32_lds_bytes();
-void launch_train32(const TrainDev& d, void* stream);
+void launch_train32(const TrainDev& d, void* stream, bool feat);
 
 // bf16 MFMA variant (objnerf_train_bf16.hip): same tile structure, bf16 operands, fp32 accumulation
 size_t bf16_lds_bytes();

@@ -20,7 +20,7 @@ kernels = []
 if f and w:
     # FETCH_SIZE / WRITE_SIZE are in KB; gfx950 reports half of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM)
     hbm = 2.0 * f["FETCH_SIZE"] * 1024 + w["WRITE_SIZE"] * 1024
-    kernels.append({"kernel": "train_fused32_kernel<false, 64>", "objects": 50, "rays": 4096, "samples": 64,
+    kernels.append({"kernel": "train_fused32_kernel<false, false, 64>", "objects": 50, "rays": 4096, "samples": 64,
                     "hbm_bytes_per_launch": hbm, "valu_insts_per_launch": sq.get("SQ_INSTS_VALU"),
                     "mfma_insts_per_launch": sq2.get("SQ_INSTS_MFMA"), "lds_insts_per_launch": sq2.get("SQ_INSTS_LDS"),
                     "source": f"profiles/{rnd}_pmc_hbm_{ver}.txt, profiles/{rnd}_pmc_sq_{ver}.txt (FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc passes)"})
