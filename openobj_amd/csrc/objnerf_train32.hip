@@ -255,7 +255,13 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
       write_relu_mask(dst, 4, g, act.hc, valid);
       if (FEAT) write_relu_mask(dst, 5, g, act.hf, valid);
     }
+    unsigned hf_pos = 0;              // ReLU branch bits of this lane's 8 hidden-feature entries (all the backward needs
+                                      // of them: one register instead of eight across the compositing)
     if (FEAT) {
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hf_pos |= (act.hf.t[tt][r] > 0.0f ? 1u : 0u) << (4 * tt + r);
       // hidden feature of the tile -> [128][33] buffer; this object's Gram matrix (+ wb, bb) beside it (section 4.3 of
       // the 512-d head is hoisted past the compositing)
 #pragma unroll
@@ -608,8 +614,7 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float gv = valid ? stg[F_GFH + q * 32 + 16 * tt + 4 * g + r] : 0.0f;
-          // (the hidden feature is re-read from its LDS buffer: 8 registers less across the compositing)
-          d_hf.t[tt][r] = stg[slot * HF_LD + 16 * tt + 4 * g + r] > 0.0f ? wv * gv : 0.0f;
+          d_hf.t[tt][r] = ((hf_pos >> (4 * tt + r)) & 1u) ? wv * gv : 0.0f;
         }
     }
     T32 d_hc, d_h4;

@@ -24,7 +24,7 @@ for _ in range(3):
     ops.train_step(arena, ws, batch, with_feat=FEAT, bf16=BF16)
 torch.cuda.synchronize()
 out = (C.c_ulonglong * (8 * 24))()
-f = _lib.lib().objnerf_debug_phase_bf16 if BF16 else (_lib.lib().objnerf_debug_phase if FEAT else _lib.lib().objnerf_debug_phase32)
+f = _lib.lib().objnerf_debug_phase_bf16 if BF16 else _lib.lib().objnerf_debug_phase32
 f.restype = C.c_int
 assert f(out) == 0
 a = np.array(list(out), dtype=np.float64).reshape(8, 24)[:, :18]
