@@ -9,7 +9,8 @@ struct LossHoisted {
   const float* hf; const float* rayin; const float* gram;
   float* d_hf; float* rayfeat;
 };
-int step_batch_loss_impl(const objnerf_loss_args* a, const LossHoisted* hz, void* stream);
+// loss_part: NULL or K * R * 4 floats of scratch -> bit-reproducible per-object loss terms (no float atomics)
+int step_batch_loss_impl(const objnerf_loss_args* a, const LossHoisted* hz, void* stream, float* loss_part);
 }  // namespace objmisc
 
 namespace objgen {
@@ -24,8 +25,11 @@ void feature_head(void* stream, int K, long n, int Hh, int C, const float* param
 void gemm_f32(void* stream, int batch, int M, int N, int Kd, const float* A, long sam, long sak, long bsa, const float* B,
               long sbk, long sbn, long bsb, float* C, long scm, long scn, long bsc, bool accumulate);
 //   long contraction over n, few output tiles: split-K with float atomics into a PRE-ZEROED C (scn = 1)
+// split-K weight gradient over n samples (C pre-zeroed only for the atomics fallback).  parts: scratch of
+// wgrad_parts_floats(batch, M, N, n) floats for the deterministic slab-and-reduce form; NULL = float atomics
+size_t wgrad_parts_floats(int batch, int M, int N, long n);
 void wgrad_f32(void* stream, int batch, int M, int N, long n, const float* A, long sam, long sak, long bsa, const float* B,
-               long sbk, long sbn, long bsb, float* C, long scm, long bsc);
+               long sbk, long sbn, long bsb, float* C, long scm, long bsc, float* parts, size_t parts_floats);
 size_t eval_workspace_bytes(const objnerf_net* net, int K, long N);
 // pts == NULL: emb_in [K][N][129] is the embedding (OccupancyMap.forward on a caller-supplied tensor)
 int eval_points(const objnerf_net* net, int K, long N, const float* params, long p_stride, const float* scale,

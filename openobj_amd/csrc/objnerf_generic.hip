@@ -27,6 +27,9 @@ struct Gemm {
   int splitk;      // > 1: blockIdx.z = batch * splitk + slice; each slice atomically adds its partial into C
   float* rowsum; long bsrs;   // optional: rowsum[m] += sum_k A(m,k)  (bias gradient riding on the weight-gradient GEMM)
   const float* biasrow; long bsbr;   // optional per-row factor of the bias: + bias[n] * biasrow[m]
+  float* part; float* rs_part;   // split-K with these set: slice s of batch z STORES its partial tile at part[((z sk + s) M + m)
+                                 // N + n] (row sums: rs_part[(z sk + s) M + m]) and reduce_parts_kernel adds the slices in
+                                 // order -- bit-reproducible; NULL: float atomics into C / rowsum
   float a_scale;   // 16-bit operand kernels: A is multiplied by this power of two before it is rounded and the result
                    // divided by it (keeps back-propagated gradients out of fp16's subnormal range); 1 elsewhere
 };
@@ -126,7 +129,10 @@ __device__ __forceinline__ void gemm_tile(const Gemm& g, const int bx, const int
     }
     __syncthreads();
   }
-  if (do_rs && m0 + tid < g.M) atomicAdd(g.rowsum + z * g.bsrs + m0 + tid, rs);
+  if (do_rs && m0 + tid < g.M) {
+    if (g.rs_part) g.rs_part[(z * sk + slice) * g.M + m0 + tid] = rs;
+    else atomicAdd(g.rowsum + z * g.bsrs + m0 + tid, rs);
+  }
   // epilogue: D layout: col n = lane & 15, row m = 4 * (lane >> 4) + r
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -138,7 +144,11 @@ __device__ __forceinline__ void gemm_tile(const Gemm& g, const int bx, const int
         if (m < g.M && n < g.N) {
           float* cp = C + m * g.scm + n * g.scn;
           float v = acc[i][j][r];
-          if (sk > 1) { atomicAdd(cp, v); continue; }
+          if (sk > 1) {
+            if (g.part) g.part[((z * sk + slice) * g.M + m) * g.N + n] = v;
+            else atomicAdd(cp, v);
+            continue;
+          }
           if (g.accumulate) v += *cp;
           if (g.bias) v += g.bias[z * g.bsbias + n] * (g.biasrow ? g.biasrow[z * g.bsbr + m] : 1.0f);
           if (g.relu) v = fmaxf(v, 0.f);
@@ -293,7 +303,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const Gemm g) {
     }
     __syncthreads();
   }
-  if (do_rs && m0 + tid < g.M) atomicAdd(g.rowsum + z * g.bsrs + m0 + tid, rs * inv_scale);
+  if (do_rs && m0 + tid < g.M) {
+    if (g.rs_part) g.rs_part[(z * sk + slice) * g.M + m0 + tid] = rs * inv_scale;
+    else atomicAdd(g.rowsum + z * g.bsrs + m0 + tid, rs * inv_scale);
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -304,7 +317,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const Gemm g) {
         if (m < g.M && n < g.N) {
           float* cp = C + m * g.scm + n * g.scn;
           float v = acc[i][j][r] * inv_scale;
-          if (sk > 1) { atomicAdd(cp, v); continue; }
+          if (sk > 1) {
+            if (g.part) g.part[((z * sk + slice) * g.M + m) * g.N + n] = v;
+            else atomicAdd(cp, v);
+            continue;
+          }
           if (g.accumulate) v += *cp;
           if (g.bias) v += g.bias[z * g.bsbias + n] * (g.biasrow ? g.biasrow[z * g.bsbr + m] : 1.0f);
           if (g.relu) v = fmaxf(v, 0.f);
@@ -322,6 +339,85 @@ static thread_local GemmGroup* t_group = nullptr;     // non-null: gemm() collec
 static thread_local const float* t_biasrow = nullptr;
 static thread_local long t_bsbr = 0;
 
+// ---- deterministic split-K: partial-tile slabs + an ordered reduction (instead of float atomics)
+#ifndef OBJ_WGRAD_MAXSLICES
+#define OBJ_WGRAD_MAXSLICES 128      // (32 was measured: the background step in bf16 mode 0.92 -> 1.4 ms, too few workgroups)
+#endif
+// split-K slices of a weight-gradient GEMM over n samples: 512 samples per slice; 256 when that would leave most of the
+// chip idle (the background network at the reference's native batch of 16 800 samples: step 0.55 -> 0.46 ms)
+static int wgrad_slices(int batch, int M, int N, long n) {
+  const long tiles = (long)batch * ((M + 63) / 64) * ((N + 63) / 64);
+  long per = 512;
+  while (per > OBJ_WGRAD_MINPER && tiles * ((n + per - 1) / per) < 512) per >>= 1;
+  int sk = (int)((n + per - 1) / per);
+  if (sk < 2) sk = 2;
+  if (sk > 256) sk = 256;
+#ifndef OBJ_WGRAD_ATOMICS
+  if (sk > OBJ_WGRAD_MAXSLICES) sk = OBJ_WGRAD_MAXSLICES;
+#endif
+  return sk;
+}
+struct RedItem {
+  const float* part; const float* rs_part; float* C; float* rowsum;
+  int M, N, sk, batch;
+  long scm, bsc, bsrs;
+};
+struct RedGroup {
+  static constexpr int MAXG = GemmGroup::MAXG;
+  int count;
+  int beg[MAXG + 1];      // first block of each item
+  RedItem it[MAXG];
+};
+// one thread per output (m, n) of a batch entry (+ one per row sum): adds the sk slices in slice order
+__global__ __launch_bounds__(256) void reduce_parts_kernel(const RedGroup gr) {
+  int i = 0;
+  while (i + 1 < gr.count && (int)blockIdx.x >= gr.beg[i + 1]) ++i;
+  const RedItem& r = gr.it[i];
+  const long per = (long)r.M * r.N, nrs = r.rs_part ? r.M : 0;
+  const long e = ((long)blockIdx.x - gr.beg[i]) * 256 + threadIdx.x;
+  if (e >= (long)r.batch * (per + nrs)) return;
+  const long z = e / (per + nrs), q = e - z * (per + nrs);
+  // slices are added in slice order; 16 loads are in flight at a time (a plain loop is one HBM latency per slice)
+  auto ordered_sum = [&](const float* p, const long stride) {
+    float v = 0.f;
+    int s = 0;
+    for (; s + 16 <= r.sk; s += 16) {
+      float t[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) t[j] = p[(s + j) * stride];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v += t[j];
+    }
+    for (; s < r.sk; ++s) v += p[s * stride];
+    return v;
+  };
+  if (q < per) {
+    const float v = ordered_sum(r.part + z * r.sk * per + q, per);
+    const long m = q / r.N, n = q - m * r.N;
+    r.C[z * r.bsc + m * r.scm + n] = v;
+  } else {
+    const long m = q - per;
+    r.rowsum[z * r.bsrs + m] = ordered_sum(r.rs_part + z * r.sk * r.M + m, r.M);
+  }
+}
+static int red_blocks(const RedItem& r) {
+  return (int)(((long)r.batch * ((long)r.M * r.N + (r.rs_part ? r.M : 0)) + 255) / 256);
+}
+// bump allocator over the caller's workspace region for the partial slabs of ONE train_step (the weight-gradient GEMMs
+// of a step run side by side, so each has its own slab); exhausted or absent -> atomics
+static thread_local float* t_parts = nullptr;
+static thread_local size_t t_parts_cap = 0, t_parts_off = 0;
+static thread_local float* t_next_part = nullptr;       // Gemm::part / rs_part of the next gemm() call
+static thread_local float* t_next_rs_part = nullptr;
+static thread_local RedGroup* t_red_group = nullptr;    // non-null: reductions are collected (grouped launch)
+static float* parts_alloc(size_t floats) {
+  floats = (floats + 63) / 64 * 64;
+  if (!t_parts || t_parts_off + floats > t_parts_cap) return nullptr;
+  float* p = t_parts + t_parts_off;
+  t_parts_off += floats;
+  return p;
+}
+
 static void gemm(hipStream_t st, int batch, int M, int N, int Kd, const float* A, long sam, long sak, long bsa,
                  const float* B, long sbk, long sbn, long bsb, float* C, long scm, long scn, long bsc,
                  bool accumulate = false, const float* bias = nullptr, long bsbias = 0, bool relu = false,
@@ -337,6 +433,8 @@ static void gemm(hipStream_t st, int batch, int M, int N, int Kd, const float* A
   g.rowsum = rowsum; g.bsrs = bsrs;
   g.biasrow = t_biasrow; g.bsbr = t_bsbr;
   g.a_scale = t_bf16_operands == 2 ? t_a_scale : 1.0f;
+  g.part = t_next_part; g.rs_part = t_next_rs_part;
+  t_next_part = t_next_rs_part = nullptr;
   const int nz = batch * (splitk > 1 ? splitk : 1);
   if (t_group && !t_bf16_operands && !(M >= 256 && N >= 192) && t_group->count < GemmGroup::MAXG) {
     GemmGroup& gr = *t_group;               // collected; launched by flush_group()
@@ -373,16 +471,35 @@ static void gemm(hipStream_t st, int batch, int M, int N, int Kd, const float* A
 static void wgrad(hipStream_t st, int batch, int M, int N, long n, const float* A, long sam, long sak, long bsa,
                   const float* B, long sbk, long sbn, long bsb, float* C, long scm, long bsc,
                   float* bias_grad = nullptr) {
-  // contraction slice per workgroup: 512 samples; 256 when that would leave most of the chip idle (the background
-  // network at the reference's native batch of 16 800 samples: step 0.55 -> 0.46 ms)
-  const long tiles = (long)batch * ((M + 63) / 64) * ((N + 63) / 64);
-  long per = 512;
-  while (per > OBJ_WGRAD_MINPER && tiles * ((n + per - 1) / per) < 512) per >>= 1;
-  int sk = (int)((n + per - 1) / per);
-  if (sk < 1) sk = 1;
-  if (sk > 256) sk = 256;
+  const int sk = wgrad_slices(batch, M, N, n);
+#ifndef OBJ_WGRAD_ATOMICS
+  // deterministic form: every slice stores its partial tile; an ordered reduction follows
+  const int skd = sk;
+  float* part = parts_alloc((size_t)batch * skd * M * N);
+  float* rs_part = (part && bias_grad) ? parts_alloc((size_t)batch * skd * M) : nullptr;
+  if (part && (!bias_grad || rs_part)) {
+    t_next_part = part; t_next_rs_part = rs_part;
+    gemm(st, batch, M, N, (int)n, A, sam, sak, bsa, B, sbk, sbn, bsb, C, scm, 1, bsc, false, nullptr, 0, false, nullptr, 0,
+         0, 0, skd, bias_grad, bsc);
+    RedItem r;
+    r.part = part; r.rs_part = rs_part; r.C = C; r.rowsum = bias_grad;
+    r.M = M; r.N = N; r.sk = skd; r.batch = batch; r.scm = scm; r.bsc = bsc; r.bsrs = bsc;
+    if (t_red_group && t_red_group->count < RedGroup::MAXG) {
+      RedGroup& rg = *t_red_group;
+      if (rg.count == 0) rg.beg[0] = 0;
+      rg.it[rg.count] = r;
+      rg.beg[rg.count + 1] = rg.beg[rg.count] + red_blocks(r);
+      ++rg.count;
+    } else {
+      RedGroup rg;
+      rg.count = 1; rg.beg[0] = 0; rg.beg[1] = red_blocks(r); rg.it[0] = r;
+      hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)rg.beg[1]), dim3(256), 0, st, rg);
+    }
+    return;
+  }
+#endif
   gemm(st, batch, M, N, (int)n, A, sam, sak, bsa, B, sbk, sbn, bsb, C, scm, 1, bsc, false, nullptr, 0, false, nullptr, 0,
-       0, 0, sk > 1 ? sk : 2, bias_grad, bsc);
+       0, 0, sk, bias_grad, bsc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -862,6 +979,12 @@ static void flush_group(hipStream_t st, GemmGroup& gr) {
   }
   hipLaunchKernelGGL(gemm_group_kernel, dim3((mx + 1) / 2, (my + 1) / 2, gr.zbeg[gr.count]), dim3(512), 0, st, gr);
   gr.count = 0;
+  if (t_red_group) {                     // the ordered reductions of the group's split-K GEMMs, one launch
+    RedGroup& rg = *t_red_group;
+    t_red_group = nullptr;
+    if (rg.count) hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)rg.beg[rg.count]), dim3(256), 0, st, rg);
+    rg.count = 0;
+  }
 }
 
 // heads forward: alpha = 10 (h4 . wa + ba), color = sigmoid(hc Woc^T + boc)        (model.py:81-96)
@@ -943,7 +1066,7 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(int Hh, long n, const fl
 // samples (reads h4 and hc once, coalesced along f); one atomic per block and entry into the pre-zeroed gradient.
 __global__ __launch_bounds__(256) void head_wgrad_kernel(int Hh, long n, const float* dhead, const float* h4, const float* hc,
                                                          float* grads, long p_stride, int off_wa, int off_ba, int off_woc,
-                                                         int off_boc) {
+                                                         int off_boc, float* partA, float* partW, float* rsA, float* rsW) {
   __shared__ float red[4][256];
   const long z = blockIdx.y;
   const int rows = 256 / Hh > 0 ? 256 / Hh : 1;            // sample rows per pass (H <= 256)
@@ -962,14 +1085,21 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(int Hh, long n, const f
   red[0][threadIdx.x] = a; red[1][threadIdx.x] = c0; red[2][threadIdx.x] = c1; red[3][threadIdx.x] = c2;
   __syncthreads();
   float* G = grads + z * p_stride;
+  const long zb = z * gridDim.x + blockIdx.x;       // partial slot (reduce_parts_kernel layout: [z][slice][M][N])
   if (row == 0) {
     float s[4] = {0.f, 0.f, 0.f, 0.f};
     for (int r = 0; r < rows; ++r)
 #pragma unroll
       for (int q = 0; q < 4; ++q) s[q] += red[q][r * Hh + f];
-    atomicAdd(G + off_wa + f, s[0]);
+    if (partA) {
+      partA[zb * Hh + f] = s[0];
 #pragma unroll
-    for (int x = 0; x < 3; ++x) atomicAdd(G + off_woc + x * Hh + f, s[1 + x]);
+      for (int x = 0; x < 3; ++x) partW[(zb * 3 + x) * Hh + f] = s[1 + x];
+    } else {
+      atomicAdd(G + off_wa + f, s[0]);
+#pragma unroll
+      for (int x = 0; x < 3; ++x) atomicAdd(G + off_woc + x * Hh + f, s[1 + x]);
+    }
   }
   // biases: lanes 0..3 of the last wave sum their dhead column over the block's samples
   if (threadIdx.x >= 192) {
@@ -977,7 +1107,10 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(int Hh, long n, const f
     float b = 0.f;
     for (long i = i0 + (lane >> 2); i < i1; i += 16) b += dhead[(z * n + i) * 4 + q];
     b += __shfl_xor(b, 4); b += __shfl_xor(b, 8); b += __shfl_xor(b, 16); b += __shfl_xor(b, 32);
-    if (lane < 4) atomicAdd(G + (q == 0 ? off_ba : off_boc + q - 1), b);
+    if (lane < 4) {
+      if (partA) { if (q == 0) rsA[zb] = b; else rsW[zb * 3 + q - 1] = b; }
+      else atomicAdd(G + (q == 0 ? off_ba : off_boc + q - 1), b);
+    }
   }
 }
 
@@ -991,7 +1124,8 @@ __global__ void relu_mask_kernel(long n, float* d, const float* act) {
 // over j; three accumulators per thread, LDS reduction per block, one atomic per block and entry.
 __global__ __launch_bounds__(256) void pe_bwd_kernel(long n, const float* params, long p_stride, int off_B,
                                                      const float* scale, const float* pts, const float* d_emb,
-                                                     float* dB /* [K][63], pre-zeroed */) {
+                                                     float* dB /* [K][63], pre-zeroed */,
+                                                     float* part /* NULL or [K][gridDim.x][63] block partials */) {
   __shared__ float red[4][63][3];
   const long z = blockIdx.y;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1025,7 +1159,8 @@ __global__ __launch_bounds__(256) void pe_bwd_kernel(long n, const float* params
     float v = 0.f;
     for (int ww = 0; ww < 4; ++ww)
       for (int ss = 0; ss < 3; ++ss) v += red[ww][ss * OBJ_NDIR + jj][x];
-    atomicAdd(&dB[z * 63 + threadIdx.x], v);
+    if (part) part[(z * gridDim.x + blockIdx.x) * 63 + threadIdx.x] = v;
+    else atomicAdd(&dB[z * 63 + threadIdx.x], v);
   }
 }
 
@@ -1132,6 +1267,8 @@ struct WS {
   float *emb, *h1, *h2, *h3, *h4, *hc, *hf, *alpha, *color, *d_alpha, *d_color, *dhead;
   float *d_hf, *rayin, *gram, *rayfeat, *X1, *X2, *Tm, *mom;      // feature branch (hoisted head)
   float *dA, *dB_, *dC, *dD, *dE, *d_emb, *dBpe, *pts;
+  float* parts; size_t parts_floats;      // split-K partial slabs of the step's weight-gradient GEMMs (wgrad())
+  float* loss_part;                       // [K R][4] block partials of the loss terms
   int* counts;
   size_t bytes;
 };
@@ -1160,6 +1297,28 @@ static WS carve(char* base, int H, int C, long n, long R, int K, bool feat) {
   w.d_emb = take((size_t)K * n * OBJ_EMB);
   w.dBpe = take((size_t)K * 64);
   w.pts = take((size_t)K * n * 3);          // sample positions of the origins / directions form of the batch
+  {
+    // every weight-gradient GEMM of the step with its own slice count (wgrad()): (M, N, samples, has bias)
+    const size_t XC = (size_t)H + 1, Hs = (size_t)H;
+    size_t tot = 0;
+    auto add = [&](int M, int N, long ns, bool bias) {
+      tot += (size_t)K * wgrad_slices(K, M, N, ns) * ((size_t)M * N + (bias ? M : 0)) + 128;
+    };
+    add(H, H, n, true); add(H, OBJ_E2, n, false);          // colour layer
+    add(H, H, n, true);                                    // mid2
+    add(H, H, n, true); add(H, OBJ_E1, n, false);          // cat layer
+    add(H, H, n, true);                                    // mid1
+    add(H, OBJ_E1, n, true);                               // in layer
+    add(1, H, n, true); add(3, H, n, true);                // heads (H > 256 only)
+    if (feat) {
+      add(H, H, n, true); add(H, OBJ_E2, n, false);        // feature layer
+      add(C, (int)XC, R, false); add((int)XC, (int)XC, R, false);   // 512-d head moments
+    }
+    // (+ the block partials of the head weight gradients and of d B: at most 512 + 1024 blocks of 4 H + 4 / 63 floats)
+    w.parts_floats = tot + (size_t)(512 + K) * (4 * Hs + 68) + (size_t)K * 1024 * 64;
+    w.parts = take(w.parts_floats);
+    w.loss_part = take((size_t)K * R * 4);
+  }
   w.counts = (int*)take((size_t)2 * K + 2);
   w.bytes = (size_t)(p - base);
   return w;
@@ -1260,6 +1419,8 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
   hipStream_t st = (hipStream_t)stream;
   WS w = carve((char*)a->workspace, H, C, n, (long)a->R, K, feat);
   if (a->workspace_bytes < w.bytes) return OBJNERF_EINVAL;
+  t_parts = w.parts; t_parts_cap = w.parts_floats; t_parts_off = 0;
+  struct PartsScope { ~PartsScope() { t_parts = nullptr; t_parts_cap = t_parts_off = 0; t_red_group = nullptr; } } parts_scope;
   if (!a->pts) {
     const long total = (long)K * n;
     hipLaunchKernelGGL(form_points_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, a->S, a->origins,
@@ -1374,7 +1535,7 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
   la.d_pred_feat = nullptr; la.counts = w.counts; la.status = a->status;
   objmisc::LossHoisted hz;
   hz.Hh = H; hz.hf = w.hf; hz.rayin = w.rayin; hz.gram = w.gram; hz.d_hf = w.d_hf; hz.rayfeat = w.rayfeat;
-  rc = objmisc::step_batch_loss_impl(&la, feat ? &hz : nullptr, stream);
+  rc = objmisc::step_batch_loss_impl(&la, feat ? &hz : nullptr, stream, w.loss_part);
   if (rc) return rc;
   // ---- backward
   // Weight-gradient GEMMs only READ the d-output / activation buffers and write the gradient arena, so they run on a
@@ -1405,8 +1566,24 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
     int hb = (int)((n + 511) / 512);                      // >= 512 samples per block, about two blocks per CU in all
     const int cap = (512 + K - 1) / K;
     if (hb > cap) hb = cap;
+    // block partials + an ordered reduction (reduce_parts_kernel: "GEMMs" of M = 1 / 3 rows with hb slices)
+    float* pA = parts_alloc((size_t)K * hb * H), *pW = parts_alloc((size_t)K * hb * 3 * H);
+    float* rA = parts_alloc((size_t)K * hb), *rW = parts_alloc((size_t)K * hb * 3);
+    if (!(pA && pW && rA && rW)) pA = pW = rA = rW = nullptr;        // no scratch: float atomics
     hipLaunchKernelGGL(head_wgrad_kernel, dim3((unsigned)hb, (unsigned)K), dim3(256), 0, ss, H, n, w.dhead, w.h4, w.hc, G, ps,
-                       (int)off[8], (int)off[9], (int)off[12], (int)off[13]);
+                       (int)off[8], (int)off[9], (int)off[12], (int)off[13], pA, pW, rA, rW);
+    if (pA) {
+      RedGroup rg;
+      rg.count = 2; rg.beg[0] = 0;
+      RedItem& a0 = rg.it[0];
+      a0.part = pA; a0.rs_part = rA; a0.C = G + off[8]; a0.rowsum = G + off[9];
+      a0.M = 1; a0.N = H; a0.sk = hb; a0.batch = K; a0.scm = H; a0.bsc = ps; a0.bsrs = ps;
+      RedItem& a1 = rg.it[1];
+      a1.part = pW; a1.rs_part = rW; a1.C = G + off[12]; a1.rowsum = G + off[13];
+      a1.M = 3; a1.N = H; a1.sk = hb; a1.batch = K; a1.scm = H; a1.bsc = ps; a1.bsrs = ps;
+      rg.beg[1] = red_blocks(a0); rg.beg[2] = rg.beg[1] + red_blocks(a1);
+      hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)rg.beg[2]), dim3(256), 0, ss, rg);
+    }
   }
   // d_emb needs no zero fill: the first dgrad into each column block overwrites (x2: feature layer if
   // present, else colour layer; x1: cat layer), later ones accumulate; columns 0..2 (d t) are never read.
@@ -1459,6 +1636,9 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
     GemmGroup group;
     group.count = 0;
     t_group = &group;
+    RedGroup red_group;
+    red_group.count = 0;
+    t_red_group = &red_group;
     if (feat) {
       wgrad(side(), K, H, H, n, w.d_hf, 1, H, nH, w.h4, H, 1, nH, G + off[14], H + E2, ps, G + off[15]);
       wgrad(side(), K, H, E2, n, w.d_hf, 1, H, nH, w.emb + E1, EM, 1, n * EM, G + off[14] + H, H + E2, ps);
@@ -1497,15 +1677,27 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
   wgrad(ss, K, H, E1, n, d_h1, 1, H, nH, w.emb, EM, 1, n * EM, G + off[0], E1, ps, G + off[1]);
   gemm(st, K, n, E1, H, d_h1, H, 1, nH, P + off[0], E1, 1, ps, w.d_emb, EM, 1, n * EM, true);
   }
-  // embedding directions
-  (void)hipMemsetAsync(w.dBpe, 0, (size_t)K * 64 * 4, st);
+  // embedding directions: block partials + ordered reduction straight into the gradient arena (float atomics into dBpe
+  // and a copy when the scratch is exhausted)
   int pg = (int)((n + 47) / 48);           // 12 samples per block and pass: at least 4 passes per block
   if (pg > 1024) pg = 1024;
   if (pg < 1) pg = 1;
+  float* pe_part = parts_alloc((size_t)K * pg * 63);
+  if (!pe_part) (void)hipMemsetAsync(w.dBpe, 0, (size_t)K * 64 * 4, st);
   hipLaunchKernelGGL(pe_bwd_kernel, dim3(pg, K), dim3(256), 0, st, n, P, ps, (int)off[18], a->scale, a->pts, w.d_emb,
-                     w.dBpe);
-  hipLaunchKernelGGL(copy_cols_kernel, dim3((unsigned)((K * 63 + 255) / 256)), dim3(256), 0, st, (long)K, 63, w.dBpe, 63L,
-                     G + off[18], ps);
+                     w.dBpe, pe_part);
+  if (pe_part) {
+    RedGroup rg;
+    rg.count = 1; rg.beg[0] = 0;
+    RedItem& r = rg.it[0];
+    r.part = pe_part; r.rs_part = nullptr; r.C = G + off[18]; r.rowsum = nullptr;
+    r.M = 1; r.N = 63; r.sk = pg; r.batch = K; r.scm = 63; r.bsc = ps; r.bsrs = 0;
+    rg.beg[1] = red_blocks(r);
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)rg.beg[1]), dim3(256), 0, st, rg);
+  } else {
+    hipLaunchKernelGGL(copy_cols_kernel, dim3((unsigned)((K * 63 + 255) / 256)), dim3(256), 0, st, (long)K, 63, w.dBpe, 63L,
+                       G + off[18], ps);
+  }
   for (int i = 0; multi && i < n_side; ++i) {   // join: the caller's stream continues after the weight gradients
     (void)hipEventRecord(sd.done_all[i], sd.all[i]);
     (void)hipStreamWaitEvent(st, sd.done_all[i], 0);
@@ -1588,9 +1780,14 @@ void gemm_f32(void* stream, int batch, int M, int N, int Kd, const float* A, lon
               long sbk, long sbn, long bsb, float* C, long scm, long scn, long bsc, bool accumulate) {
   gemm((hipStream_t)stream, batch, M, N, Kd, A, sam, sak, bsa, B, sbk, sbn, bsb, C, scm, scn, bsc, accumulate);
 }
+size_t wgrad_parts_floats(int batch, int M, int N, long n) {
+  return (size_t)batch * wgrad_slices(batch, M, N, n) * M * N + 64;
+}
 void wgrad_f32(void* stream, int batch, int M, int N, long n, const float* A, long sam, long sak, long bsa, const float* B,
-               long sbk, long sbn, long bsb, float* C, long scm, long bsc) {
+               long sbk, long sbn, long bsb, float* C, long scm, long bsc, float* parts, size_t parts_floats) {
+  t_parts = parts; t_parts_cap = parts ? parts_floats : 0; t_parts_off = 0;
   wgrad((hipStream_t)stream, batch, M, N, n, A, sam, sak, bsa, B, sbk, sbn, bsb, C, scm, bsc);
+  t_parts = nullptr; t_parts_cap = t_parts_off = 0;
 }
 
 }  // namespace objgen

@@ -181,6 +181,8 @@ struct LossDev {
   const float* gram;      // [K][Hh * Hh + Hh + 1]  G = W_of^T W_of, wb = W_of^T b_of, bb = b_of . b_of
   float* d_hf;            // [K][R][S][Hh]  d loss / d (pre-activation of the feature layer)
   float* rayfeat;         // [K][R][Hh + 3] fh, O, a, c  (-> head gradient GEMMs)
+  float* loss_part;       // NULL: block sums go to loss_terms by float atomics; else [blocks][4] partials, added in block
+                          // order by loss_total_kernel (bit-reproducible)
 };
 
 __global__ __launch_bounds__(1024) void loss_kernel(const LossDev a) {
@@ -330,7 +332,8 @@ __global__ __launch_bounds__(1024) void loss_kernel(const LossDev a) {
   if (threadIdx.x < 4) {
     float v = 0.f;
     for (int i = 0; i < nw; ++i) v += s_red[i][threadIdx.x];
-    atomicAdd(&a.loss_terms[k * 4 + threadIdx.x], v);
+    if (a.loss_part) a.loss_part[(long)blockIdx.x * 4 + threadIdx.x] = v;
+    else atomicAdd(&a.loss_terms[k * 4 + threadIdx.x], v);
   }
   if (!a.d_alpha && !a.d_color) return;
   float sufc = 0.f;
@@ -361,7 +364,17 @@ __global__ __launch_bounds__(1024) void loss_kernel(const LossDev a) {
   }
 }
 
-__global__ void loss_total_kernel(int K, const float* terms, float cs, float os, float fs, float* total, int* status) {
+__global__ void loss_total_kernel(int K, float* terms, float cs, float os, float fs, float* total, int* status,
+                                  const float* loss_part, int blocks_per_obj) {
+  if (loss_part) {         // the objects' terms from the blocks' partial sums, in block order
+    for (int i = threadIdx.x; i < 4 * K; i += blockDim.x) {
+      const float* p = loss_part + (long)(i >> 2) * blocks_per_obj * 4 + (i & 3);
+      float v = 0.f;
+      for (int b = 0; b < blocks_per_obj; ++b) v += p[4 * b];
+      terms[i] = v;
+    }
+    __syncthreads();
+  }
   // single thread: K is small; sequential sum keeps the result run-to-run deterministic
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     float t = 0.f;
@@ -686,7 +699,7 @@ __global__ void sample_place_kernel(const objnerf_sample_args a_, const objnerf_
 #define CLEAR_STALE() (void)hipGetLastError()
 
 namespace objmisc {
-int step_batch_loss_impl(const objnerf_loss_args* a, const LossHoisted* hz, void* stream) {
+int step_batch_loss_impl(const objnerf_loss_args* a, const LossHoisted* hz, void* stream, float* loss_part) {
   CLEAR_STALE();
   if (!a || !a->alpha || !a->color || !a->z || !a->gt_depth || !a->gt_rgb || !a->labels || !a->loss_terms ||
       !a->counts || a->K <= 0 || a->R <= 0 || a->S <= 0)
@@ -718,10 +731,12 @@ int step_batch_loss_impl(const objnerf_loss_args* a, const LossHoisted* hz, void
   const long nr = (long)a->K * a->R;
   int rb = 16;                                          // rays (waves) per block: the largest power of two dividing R
   while (rb > 1 && (a->R % rb != 0 || (size_t)rb * (3 * a->S + 2 * d.Hh) * 4 > 60000)) rb >>= 1;
+  d.loss_part = loss_part;
   hipLaunchKernelGGL(loss_kernel, dim3((unsigned)(nr / rb)), dim3(64 * rb), (size_t)rb * (3 * a->S + 2 * d.Hh) * 4, st, d);
   CHECK_LAUNCH();
-  hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(64), 0, st, a->K, a->loss_terms, a->color_scaling,
-                     a->opacity_scaling, (a->pred_feat || hz) ? a->feat_scaling : 0.0f, a->total, a->status);
+  hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(256), 0, st, a->K, a->loss_terms, a->color_scaling,
+                     a->opacity_scaling, (a->pred_feat || hz) ? a->feat_scaling : 0.0f, a->total, a->status,
+                     (const float*)loss_part, a->R / rb);
   CHECK_LAUNCH();
   return OBJNERF_OK;
 }
@@ -830,7 +845,7 @@ int objnerf_label_counts(int32_t K, int32_t R, const uint8_t* labels, int32_t* c
 }
 
 int objnerf_step_batch_loss(const objnerf_loss_args* a, void* stream) {
-  return objmisc::step_batch_loss_impl(a, nullptr, stream);
+  return objmisc::step_batch_loss_impl(a, nullptr, stream, nullptr);
 }
 
 int objnerf_adamw_step(int32_t K, int64_t P, int64_t p_stride, float* params, const float* grads, float* exp_avg,

@@ -1032,7 +1032,9 @@ size_t objnerf_train_workspace_bytes(const objnerf_net* net, int32_t K, int32_t 
   if (with_feat)
     n += align256((size_t)K * R * RAYIN * 4) + align256((size_t)K * GRAM * 4) + align256((size_t)K * R * RAYFEAT * 4) +
          2 * align256((size_t)K * R * XCOLS * 4) +
-         align256(((size_t)K * net->feat_dim * XCOLS + (size_t)K * XCOLS * XCOLS) * 4);
+         align256(((size_t)K * net->feat_dim * XCOLS + (size_t)K * XCOLS * XCOLS) * 4) +
+         align256(objgen::wgrad_parts_floats(K, net->feat_dim, XCOLS, R) * 4) +
+         align256(objgen::wgrad_parts_floats(K, XCOLS, XCOLS, R) * 4);
   return n;
 }
 
@@ -1084,7 +1086,7 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
   uint8_t* has_grad = (uint8_t*)ws;
   ws += align256((size_t)ps) + 256;
   float* rayin = nullptr; float* gram = nullptr; float* rayfeat = nullptr;
-  float *X1 = nullptr, *X2 = nullptr, *Tm = nullptr, *mom = nullptr;
+  float *X1 = nullptr, *X2 = nullptr, *Tm = nullptr, *mom = nullptr, *parts_t = nullptr, *parts_m = nullptr;
   const int C = net->feat_dim;
   if (feat) {
     rayin = (float*)ws;   ws += align256((size_t)a->K * a->R * RAYIN * 4);
@@ -1094,6 +1096,9 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
     X2 = (float*)ws;      ws += align256((size_t)a->K * a->R * XCOLS * 4);
     Tm = (float*)ws;
     mom = Tm + (size_t)a->K * C * XCOLS;
+    ws += align256(((size_t)a->K * C * XCOLS + (size_t)a->K * XCOLS * XCOLS) * 4);
+    parts_t = (float*)ws; ws += align256(objgen::wgrad_parts_floats(a->K, C, XCOLS, a->R) * 4);
+    parts_m = (float*)ws;
   }
   d.rayin = rayin; d.gram = gram; d.rayfeat = rayfeat;
   d.relu_masks = a->relu_masks;
@@ -1135,9 +1140,10 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
     hipLaunchKernelGGL(feat_scale_kernel, dim3((unsigned)((nr * XCOLS + 255) / 256)), dim3(256), 0, st, nr, rayfeat, X1, X2);
     (void)hipMemsetAsync(Tm, 0, ((size_t)a->K * C * XCOLS + (size_t)a->K * XCOLS * XCOLS) * 4, st);
     objgen::wgrad_f32(stream, a->K, C, XCOLS, a->R, a->gt_feat, 1, C, (long)a->R * C, X1, XCOLS, 1, (long)a->R * XCOLS, Tm,
-                      XCOLS, (long)C * XCOLS);
+                      XCOLS, (long)C * XCOLS, parts_t, objgen::wgrad_parts_floats(a->K, C, XCOLS, a->R));
     objgen::wgrad_f32(stream, a->K, XCOLS, XCOLS, a->R, X2, 1, XCOLS, (long)a->R * XCOLS, rayfeat, RAYFEAT, 1,
-                      (long)a->R * RAYFEAT, mom, XCOLS, (long)XCOLS * XCOLS);
+                      (long)a->R * RAYFEAT, mom, XCOLS, (long)XCOLS * XCOLS, parts_m,
+                      objgen::wgrad_parts_floats(a->K, XCOLS, XCOLS, a->R));
     hipLaunchKernelGGL(feat_finish_kernel, dim3((C * XCOLS + 255) / 256, a->K), dim3(256), 0, st, a->params,
                        (long)a->p_stride, d.L.of_w, d.L.of_b, C, Tm, mom, a->grads);
   } else if (bf16) {
