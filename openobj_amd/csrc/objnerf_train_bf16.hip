@@ -11,6 +11,12 @@
 // operands (weights, activations, staged transposes) are rounded to bf16 (round-to-nearest-even).
 // The reference is fp32-only (train.py:74 AMP = False): this path is gated by PSNR, not by 1e-4.
 #define OBJ_HW_SINCOS 1      // embedding sin / cos on the transcendental unit (see objnerf_device.h)
+// Positional encoding: the direction-owner layout of the second-generation fp32 kernel (objnerf_mlp32.h): lane group g
+// owns directions 4 i + g in all octaves, so a sample's projection gradients are complete inside the owning lane (no
+// cross-group sum on the matrix core, no fp32 table in LDS) and d B accumulates in 18 registers.  Only octave 0 gets
+// its own range reduction here; the others follow by angle doubling (error <= ~1e-5, far below the bf16 rounding).
+#define OBJ_PE_ANCHORS 1
+#include "objnerf_mlp32.h"
 #include "objnerf_train_common.h"
 #include "../../include/objnerf_hip.h"
 
@@ -56,25 +62,31 @@ static_assert(B_SMALL % 16 == 0 && B_STG % 16 == 0 && LDS_BYTES <= 163840, "bf16
 
 __device__ __forceinline__ int phi(int g, int e) { return e < 4 ? 4 * g + e : 16 + 4 * g + e - 4; }
 
-// value of layer weight (out i, input feature f), bias riding on the constant-1 embedding row
+// value of layer weight (out i, K-order input feature f).  Embedding features are in the direction-owner order of
+// objnerf_mlp32.h: feature kappa <-> entry (t, g) <-> reference column x1_col / x2_col, the layer's bias on the
+// constant-1 entry, zero on the padding entries.
+__device__ __forceinline__ float w_emb(const float* P, const int w_off, const int b_off, const int ncols, const int hid,
+                                       const bool x2, const int i, const int kappa) {
+  int t, g;
+  obj32n::kappa_tg(kappa, t, g);
+  const int col = x2 ? obj32n::x2_col(t, g) : obj32n::x1_col(t, g);
+  if (col >= 0) return P[w_off + i * ncols + hid + col];
+  return col == obj32n::BIAS_COL ? P[b_off + i] : 0.f;
+}
 __device__ __forceinline__ float w_in(const float* P, const Layout& L, int i, int f) {
-  return f < OBJ_E1 ? P[L.in_w + i * OBJ_E1 + f] : (f == OBJ_E1 ? P[L.in_b + i] : 0.f);
+  return w_emb(P, L.in_w, L.in_b, OBJ_E1, 0, false, i, f);
 }
 __device__ __forceinline__ float w_cat(const float* P, const Layout& L, int i, int f) {
   if (f < H) return P[L.cat_w + i * (H + OBJ_E1) + f];
-  const int f2 = f - H;
-  return f2 < OBJ_E1 ? P[L.cat_w + i * (H + OBJ_E1) + H + f2] : (f2 == OBJ_E1 ? P[L.cat_b + i] : 0.f);
+  return w_emb(P, L.cat_w, L.cat_b, H + OBJ_E1, H, false, i, f - H);
 }
 __device__ __forceinline__ float w_cl(const float* P, const Layout& L, int i, int f) {
   if (f < H) return P[L.cl_w + i * (H + OBJ_E2) + f];
-  const int f2 = f - H;
-  return f2 < OBJ_E2 ? P[L.cl_w + i * (H + OBJ_E2) + H + f2] : (f2 == OBJ_E2 ? P[L.cl_b + i] : 0.f);
+  return w_emb(P, L.cl_w, L.cl_b, H + OBJ_E2, H, true, i, f - H);
 }
-
 __device__ __forceinline__ float w_fl(const float* P, const Layout& L, int i, int f) {
   if (f < H) return P[L.fl_w + i * (H + OBJ_E2) + f];
-  const int f2 = f - H;
-  return f2 < OBJ_E2 ? P[L.fl_w + i * (H + OBJ_E2) + H + f2] : (f2 == OBJ_E2 ? P[L.fl_b + i] : 0.f);
+  return w_emb(P, L.fl_w, L.fl_b, H + OBJ_E2, H, true, i, f - H);
 }
 
 __device__ __forceinline__ void stage_weights_bf16(char* lds, const float* __restrict__ P, const Layout& L, int tid,
@@ -119,7 +131,8 @@ __device__ __forceinline__ void stage_weights_bf16(char* lds, const float* __res
   for (int i = tid; i < 3 * H; i += NTHR) sm[S_WOC + i] = P[L.oc_w + i];
   if (tid == 0) sm[S_HB] = P[L.a_b];
   if (tid < 3) sm[S_HB + 1 + tid] = P[L.oc_b + tid];
-  for (int i = tid; i < 33 * 3; i += NTHR) sm[S_PEB + i] = P[L.pe_b + ((i / 3) % OBJ_NDIR) * 3 + (i % 3)];
+  // B rows in slot order [slot i][group g][3] (= B's own row-major order), zero for j = 4 i + g >= 21
+  for (int i = tid; i < 72; i += NTHR) sm[S_PEB + i] = (i / 3) < OBJ_NDIR ? P[L.pe_b + i] : 0.0f;
 }
 
 __device__ __forceinline__ bf16x8 pack8(const f32x4& lo, const f32x4& hi) {
@@ -148,15 +161,16 @@ __device__ __forceinline__ void bwd_tile(f32x4& acc, const char* timg_lane, cons
 }
 
 __device__ __forceinline__ void pe_project_b(const float* sm, const int g, const float px, const float py,
-                                             const float pz, const float scale, Pe& pe) {
+                                             const float pz, const float scale, obj32n::Pe32& pe) {
   pe.t[0] = px * scale;      // `scale` is 1 / obj_scale here (one division per workgroup instead of three per sample)
   pe.t[1] = py * scale;
   pe.t[2] = pz * scale;
-  const float* bl = sm + S_PEB + 12 * g;
+  const float* bl = sm + S_PEB + 3 * g;
 #pragma unroll
-  for (int i = 0; i < OBJ_NDIR; ++i) {
-    const float p = fmaf(pe.t[2], bl[3 * i + 2], fmaf(pe.t[1], bl[3 * i + 1], pe.t[0] * bl[3 * i]));
-    pe.ps[i] = (i > 8 && 4 * g + i >= OBJ_NDIR) ? 2.0f * p : p;
+  for (int i = 0; i < 6; ++i) {
+    const float p = fmaf(pe.t[2], bl[12 * i + 2], fmaf(pe.t[1], bl[12 * i + 1], pe.t[0] * bl[12 * i]));
+    pe.vh[i] = p * 0.5f;     // revolutions of a = p pi: a / (2 pi) = p / 2, exact -- no low part needed
+    pe.vl[i] = 0.0f;
   }
 }
 
@@ -184,16 +198,25 @@ __device__ __forceinline__ void wgrad_pair_b(f32x4& acc0, f32x4& acc1, const cha
   }
 }
 
+// hid: number of hidden-feature rows in front of the embedding rows of this operand; x2: which embedding half
 __device__ __forceinline__ void write_pair_b(float* slab, const f32x4& a0, const f32x4& a1, const int c, const int g,
-                                             const int ct, const int w_off, const int ncols, const int b_off) {
-  const int col = 16 * ct + c;
+                                             const int ct, const int w_off, const int ncols, const int b_off,
+                                             const int hid = 1 << 20, const bool x2 = false) {
+  const int rho = 16 * ct + c;
+  int col = rho;
+  if (rho >= hid) {
+    int t_, g_;
+    obj32n::kappa_tg(rho - hid, t_, g_);
+    col = x2 ? obj32n::x2_col(t_, g_) : obj32n::x1_col(t_, g_);
+    if (col >= 0) col += hid;
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int o0 = 4 * g + r, o1 = 16 + 4 * g + r;
-    if (col < ncols) {
+    if (col >= 0) {
       slab[w_off + o0 * ncols + col] = a0[r];
       slab[w_off + o1 * ncols + col] = a1[r];
-    } else if (col == ncols && b_off >= 0) {
+    } else if (col == obj32n::BIAS_COL && b_off >= 0) {
       slab[b_off + o0] = a0[r];
       slab[b_off + o1] = a1[r];
     }
@@ -223,7 +246,6 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
   const float* sm = reinterpret_cast<const float*>(ldsb + B_SMALL);
   float* s_alpha = reinterpret_cast<float*>(ldsb + B_SM);
   float* s_col = s_alpha + TS;
-  float* tbuf = reinterpret_cast<float*>(ldsb + B_TBUF);
   char* stg = ldsb + B_STG;
 
   for (int i = tid; i < LDS_BYTES / 4; i += NTHR) reinterpret_cast<float*>(ldsb)[i] = 0.0f;
@@ -240,7 +262,9 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
   f32x4 accA0 = zero4(), accA1 = zero4(), accB0 = zero4(), accB1 = zero4(), accC0 = zero4(), accC1 = zero4();
   float gS0 = 0.f, gS1 = 0.f, gS2 = 0.f;
   float g_ba = 0.f, g_boc0 = 0.f, g_boc1 = 0.f, g_boc2 = 0.f;
-  f32x4 accT0 = zero4(), accT1 = zero4();   // d B: rows j = 4g + r (accT1: 16 + 4g + r), column x = c < 3
+  float dB[6][3];                           // d B[4 i + g][x], summed over this lane's samples
+#pragma unroll
+  for (int i = 0; i < 6; ++i) dB[i][0] = dB[i][1] = dB[i][2] = 0.f;
   float l_d = 0.f, l_c = 0.f, l_o = 0.f, l_f = 0.f;
   f32x4 accF0 = zero4(), accF1 = zero4();
   float* stgf = reinterpret_cast<float*>(stg);                       // fp32 view (feature aliases)
@@ -304,7 +328,7 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
     const int ray = ray0 + q;
     const bool valid = (q < TR) && (ray < R);
     const float px = nx, py = ny, pz = nz;       // fetched during the previous tile's phase C
-    Pe pe;
+    obj32n::Pe32 pe;
     pe_project_b(sm, g, px, py, pz, inv_scale, pe);
     PT(0);
     T32 h1, h2, h3, h4, hc;
@@ -313,10 +337,14 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
     float alpha_v, col_v[3];
     {
       bf16x8 xb1[3], xb2[2];
+      {
+        obj32n::Emb32 e;               // forward-only: the backward re-creates the embedding tile by tile
+        obj32n::embed32(e, pe, g);
 #pragma unroll
-      for (int b = 0; b < 3; ++b) xb1[b] = pack8(pe_x1_tile(pe, 2 * b, g), pe_x1_tile(pe, 2 * b + 1, g));
-      xb2[0] = pack8(pe_x2_tile(pe, 0, g), pe_x2_tile(pe, 1, g));
-      xb2[1] = pack8(pe_x2_tile(pe, 2, g), zero4());
+        for (int b = 0; b < 3; ++b) xb1[b] = pack8(e.x1[2 * b], e.x1[2 * b + 1]);
+        xb2[0] = pack8(e.x2[0], e.x2[1]);
+        xb2[1] = pack8(e.x2[2], zero4());
+      }
       T32 acc = zero32();
 #pragma unroll
       for (int b = 0; b < 3; ++b) fwd_blk<RS_IN>(acc, f_in, b, xb1[b]);
@@ -709,10 +737,10 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
     const float dc2 = valid ? s_col[2 * TS + slot] : 0.0f;
     if (g == 0) { g_ba += da; g_boc0 += dc0; g_boc1 += dc1; g_boc2 += dc2; }
 #pragma unroll
-    for (int j = 0; j < OBJ_NDIR; ++j) asm volatile("" : "+v"(pe.ps[j]));
-    float dps[OBJ_NDIR];
+    for (int i = 0; i < 6; ++i) asm volatile("" : "+v"(pe.vh[i]));
+    float dps[6];
 #pragma unroll
-    for (int j = 0; j < OBJ_NDIR; ++j) dps[j] = 0.f;
+    for (int i = 0; i < 6; ++i) dps[i] = 0.f;
 
     // ---- phase A
     T32 d_hf = zero32();
@@ -773,7 +801,10 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
       f32x4 d_x = zero4();
       bwd_tile(d_x, t_cl, 32 + 16 * T, d_hc_b);
       if (FEAT) bwd_tile(d_x, t_fl, 32 + 16 * T, d_hf_b);
-      store16_b(stg_lane, 32 + 16 * T, pe_x2_tile_fb(pe, T, g, d_x, dps));
+      float o0, o1, o2, o3;
+      obj32n::pe32_x2_pair_fb(pe, 2 * T, g, d_x[0], d_x[1], dps[2 * T], o0, o1);
+      obj32n::pe32_x2_pair_fb(pe, 2 * T + 1, g, d_x[2], d_x[3], dps[2 * T + 1], o2, o3);
+      store16_b(stg_lane, 32 + 16 * T, f32x4{o0, o1, o2, o3});
     }
     const bf16x8 d_h4_b = pack32(d_h4);
     T32 d_h3 = zero32();
@@ -832,55 +863,14 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
       f32x4 d_x = zero4();
       bwd_tile(d_x, t_cat, 32 + 16 * T, d_h3_b);
       bwd_tile(d_x, t_in, 16 * T, d_h1_b);
-      store16_b(stg_lane, 32 + 16 * T, pe_x1_tile_fb(pe, T, g, d_x, dps));
+      store16_b(stg_lane, 32 + 16 * T, obj32n::pe32_x1_tile_fb(pe, T, g, d_x, dps[T]));
     }
-    {
-      // cross-group sum of d ps on the matrix core (see objnerf_train.hip), then rows j of the fp32 table;
-      // eight registers per bf16 MFMA: k-slot (g, e) = register 8 blk + e of lane group g, A = 0/1/2 selection
-      T32 dpj = zero32();
+    // d B[j][x] += d proj_j * t_x (embedding.py:48); j = 4 i + g lives in this lane only
 #pragma unroll
-      for (int blk = 0; blk < 3; ++blk) {
-        bf16x8 bv, a0, a1;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int i = 8 * blk + e;
-          if (i < OBJ_NDIR) {
-            const int m = 4 * g + i;
-            const bool wrap = (i > 8) && (m >= OBJ_NDIR);
-            const int j = wrap ? m - OBJ_NDIR : m;
-            const float f = wrap ? 2.0f : 1.0f;
-            bv[e] = (__bf16)dps[i];
-            a0[e] = (__bf16)((j == c) ? f : 0.0f);
-            a1[e] = (__bf16)((j - 16 == c) ? f : 0.0f);
-          } else {
-            bv[e] = (__bf16)0.0f; a0[e] = (__bf16)0.0f; a1[e] = (__bf16)0.0f;
-          }
-        }
-        dpj.t[0] = MFMA_BF16(a0, bv, dpj.t[0]);
-        dpj.t[1] = MFMA_BF16(a1, bv, dpj.t[1]);
-      }
-      float* trow = tbuf + (4 * g) * TB_LD + 16 * w + c;
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) trow[(16 * tt + r) * TB_LD] = dpj.t[tt][r];
-      if (g == 0) {
-        trow[32 * TB_LD] = pe.t[0];
-        trow[33 * TB_LD] = pe.t[1];
-        trow[34 * TB_LD] = pe.t[2];
-      }
-      // d B[j][x] += sum over THIS wave's 16 samples of dproj[j][s] t[x][s] (embedding.py:48): the wave re-reads
-      // its own columns as MFMA operands (A = table rows, B = the three t rows), no barrier, no strided reduce
-      __builtin_amdgcn_wave_barrier();
-      asm volatile("" ::: "memory");
-      const float* ta = tbuf + c * TB_LD + 16 * w + g;
-      const float* tb = tbuf + (32 + (c < 3 ? c : 2)) * TB_LD + 16 * w + g;
-#pragma unroll
-      for (int st = 0; st < 4; ++st) {
-        const float bv = (c < 3) ? tb[4 * st] : 0.0f;
-        accT0 = OBJ_MFMA(ta[4 * st], bv, accT0);
-        accT1 = OBJ_MFMA(ta[16 * TB_LD + 4 * st], bv, accT1);
-      }
+    for (int i = 0; i < 6; ++i) {
+      dB[i][0] = fmaf(dps[i], pe.t[0], dB[i][0]);
+      dB[i][1] = fmaf(dps[i], pe.t[1], dB[i][1]);
+      dB[i][2] = fmaf(dps[i], pe.t[2], dB[i][2]);
     }
     PT(11);
     __syncthreads();
@@ -929,12 +919,12 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
 
   float* slab = a.slab + ((long)k * a.G + gi) * a.slab_stride;
   const Layout& L = a.L;
-  if (w < 5) write_pair_b(slab, accA0, accA1, c, g, w, L.cl_w, H + OBJ_E2, L.cl_b);
+  if (w < 5) write_pair_b(slab, accA0, accA1, c, g, w, L.cl_w, H + OBJ_E2, L.cl_b, H, true);
   else if (w < 7) write_pair_b(slab, accA0, accA1, c, g, w - 5, L.m2_w, H, -1);
-  write_pair_b(slab, accB0, accB1, c, g, w, L.cat_w, H + OBJ_E1, L.cat_b);
-  if (w < 6) write_pair_b(slab, accC0, accC1, c, g, w, L.in_w, OBJ_E1, L.in_b);
+  write_pair_b(slab, accB0, accB1, c, g, w, L.cat_w, H + OBJ_E1, L.cat_b, H, false);
+  if (w < 6) write_pair_b(slab, accC0, accC1, c, g, w, L.in_w, OBJ_E1, L.in_b, 0, false);
   else write_pair_b(slab, accC0, accC1, c, g, w - 6, L.m1_w, H, -1);
-  if (FEAT && w < 5) write_pair_b(slab, accF0, accF1, c, g, w, L.fl_w, H + OBJ_E2, L.fl_b);
+  if (FEAT && w < 5) write_pair_b(slab, accF0, accF1, c, g, w, L.fl_w, H + OBJ_E2, L.fl_b, H, true);
   float* red = reinterpret_cast<float*>(stg);   // [NWAVE][NRED]
   {
     float* mine = red + w * NRED;
@@ -947,20 +937,20 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
     const float e0 = wave_sum64(l_d), e1 = wave_sum64(l_c), e2 = wave_sum64(l_o);
     const float e3 = wave_sum64(l_f);
     if (lane == 0) { mine[196] = e0; mine[197] = e1; mine[198] = e2; mine[199] = e3; }
-    if (c < 3) {
-      float* dbw = red + NWAVE * NRED + w * 64;            // [NWAVE][21 * 3]
+    float* dbw = red + NWAVE * NRED + w * 72;            // [NWAVE][slot i][g][3] = B's own row-major order
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        dbw[(4 * g + r) * 3 + c] = accT0[r];
-        if (16 + 4 * g + r < OBJ_NDIR) dbw[(16 + 4 * g + r) * 3 + c] = accT1[r];
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int x = 0; x < 3; ++x) {
+        const float v = dpp_rowsum16(dB[i][x]);
+        if (c == 0) dbw[12 * i + 3 * g + x] = v;
       }
-    }
   }
   __syncthreads();
   if (tid < 3 * OBJ_NDIR) {
     float v = 0.f;
 #pragma unroll
-    for (int ww = 0; ww < NWAVE; ++ww) v += red[NWAVE * NRED + ww * 64 + tid];
+    for (int ww = 0; ww < NWAVE; ++ww) v += red[NWAVE * NRED + ww * 72 + tid];
     slab[L.pe_b + tid] = v;
   }
   for (int i = tid; i < NRED; i += NTHR) {
