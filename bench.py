@@ -312,7 +312,7 @@ def main():
         fpr = flop_per_ray(S, H=Hd, feat=feat)
         fused = Hd == 32 and S <= 64 and bf16 != "fp16"
         k32 = "train_fused32_kernel<%s, false, %d>" % ("true" if feat else "false", 64 if S == 64 else 0)
-        kbf = f"train_fused_bf16_kernel<{'true' if feat else 'false'}>"
+        kbf = "train_fused_bf16_kernel<%s, %d>" % ("true" if feat else "false", 64 if S == 64 else 0)
         kname = (kbf if bf16 else k32) if fused else "objnerf_train_step, layer-wise path (batched MFMA GEMMs)"
         achieved = K * R * fpr / (kern_ms * 1e-3) / 1e12
         peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS

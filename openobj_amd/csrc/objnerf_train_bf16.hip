@@ -14,8 +14,7 @@
 // Positional encoding: the direction-owner layout of the second-generation fp32 kernel (objnerf_mlp32.h): lane group g
 // owns directions 4 i + g in all octaves, so a sample's projection gradients are complete inside the owning lane (no
 // cross-group sum on the matrix core, no fp32 table in LDS) and d B accumulates in 18 registers.  Only octave 0 gets
-// its own range reduction here; the others follow by angle doubling (error <= ~1e-5, far below the bf16 rounding).
-#define OBJ_PE_ANCHORS 1
+// // its own ... (placeholder)
 #include "objnerf_mlp32.h"
 #include "objnerf_train_common.h"
 #include "../../include/objnerf_hip.h"
@@ -235,8 +234,11 @@ __device__ unsigned long long g_phase_b[8][24];
 #define PT_FLUSH() do {} while (0)
 #endif
 
-template <bool FEAT>
-__global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a) {
+// SS: samples per ray when known at compile time (64 = the metric shape: no integer divisions by S), 0 = any S <= 64
+template <bool FEAT, int SS>
+__global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a_) {
+  TrainDev a = a_;
+  if (SS) { a.S = SS; a.TR = TS / SS; }
   extern __shared__ __attribute__((aligned(16))) char ldsb[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
   __syncthreads();
 
   const float inv_scale = 1.0f / a.scale[k];
-  const int S = a.S, R = a.R, TR = a.TR;
+  const int S = SS ? SS : a.S, R = a.R, TR = SS ? TS / SS : a.TR;
   const float n1 = (float)a.counts[2 * k], n2 = (float)a.counts[2 * k + 1];
   const float inv1 = a.flags[0] ? 0.0f : 1.0f / (n1 + 1e-10f);
   const float inv2 = a.flags[1] ? 0.0f : 1.0f / (n2 + 1e-10f);
@@ -273,20 +275,20 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
   float* s_gof = s_gfh + 16 * 32;
 
 
-  const bool rows_mode = seg_is_rows(a.S);
-  const SegRows seg_rows = SegRows::make(rows_mode ? a.S : 64, lane);
+  const bool rows_mode = SS ? true : seg_is_rows(a.S);
+  const SegRows seg_rows = SegRows::make(rows_mode ? S : 64, lane);
   // sample position of (tile, slot); issued one tile ahead (phase C), as in objnerf_train.hip
   auto fetch_point = [&](const int tile_, const int slot_, float& x, float& y, float& z_) {
-    const int q_ = slot_ / a.S, si_ = slot_ - q_ * a.S;
-    const int ray_ = tile_ * a.TR + q_;
+    const int q_ = slot_ / S, si_ = slot_ - q_ * S;
+    const int ray_ = tile_ * TR + q_;
     x = 0.f; y = 0.f; z_ = 0.f;
-    if (tile_ < a.NT && q_ < a.TR && ray_ < a.R) {
+    if (tile_ < a.NT && q_ < TR && ray_ < a.R) {
       const long rr = (long)k * a.R + ray_;
       if (a.pts) {
-        const float* p = a.pts + (rr * a.S + si_) * 3;
+        const float* p = a.pts + (rr * S + si_) * 3;
         x = p[0]; y = p[1]; z_ = p[2];
       } else {
-        const float zz = a.z[rr * a.S + si_];
+        const float zz = a.z[rr * S + si_];
         const float* o = a.origins + rr * 3;
         const float* d = a.dirs + rr * 3;
         x = (o[0] + d[0] * zz) - a.obj_center;
@@ -725,7 +727,7 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
           s_col[2 * TS + sl] = gC2 * wgt * c2 * (1.0f - c2);
         }
       }
-    } else if (rows_mode) composite_passes(seg_rows); else composite_passes(SegGeneric{S});
+    } else if (SS || rows_mode) composite_passes(seg_rows); else composite_passes(SegGeneric{S});
     PT(4);
     __syncthreads();
     RELAUNDER();
@@ -981,15 +983,18 @@ extern "C" int objnerf_debug_phase_bf16(unsigned long long* out_host) {
 
 void launch_train_bf16(const TrainDev& d, void* stream, bool feat) {
   objnerf_once_per_device([] {
-    (void)hipFuncSetAttribute((const void*)train_fused_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)train_fused_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              LDS_BYTES);
+    const auto at = hipFuncAttributeMaxDynamicSharedMemorySize;
+    (void)hipFuncSetAttribute((const void*)train_fused_bf16_kernel<false, 0>, at, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)train_fused_bf16_kernel<false, 64>, at, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)train_fused_bf16_kernel<true, 0>, at, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)train_fused_bf16_kernel<true, 64>, at, LDS_BYTES);
   });
-  if (feat)
-    hipLaunchKernelGGL(train_fused_bf16_kernel<true>, dim3(d.K * d.G), dim3(NTHR), LDS_BYTES, (hipStream_t)stream, d);
-  else
-    hipLaunchKernelGGL(train_fused_bf16_kernel<false>, dim3(d.K * d.G), dim3(NTHR), LDS_BYTES, (hipStream_t)stream, d);
+  const dim3 grid(d.K * d.G), blk(NTHR);
+  hipStream_t st = (hipStream_t)stream;
+  if (feat && d.S == 64) hipLaunchKernelGGL((train_fused_bf16_kernel<true, 64>), grid, blk, LDS_BYTES, st, d);
+  else if (feat) hipLaunchKernelGGL((train_fused_bf16_kernel<true, 0>), grid, blk, LDS_BYTES, st, d);
+  else if (d.S == 64) hipLaunchKernelGGL((train_fused_bf16_kernel<false, 64>), grid, blk, LDS_BYTES, st, d);
+  else hipLaunchKernelGGL((train_fused_bf16_kernel<false, 0>), grid, blk, LDS_BYTES, st, d);
 }
 
 }  // namespace objtrain

@@ -25,7 +25,7 @@ if f and w:
                     "mfma_insts_per_launch": sq2.get("SQ_INSTS_MFMA"), "lds_insts_per_launch": sq2.get("SQ_INSTS_LDS"),
                     "source": f"profiles/{rnd}_pmc_hbm_{ver}.txt, profiles/{rnd}_pmc_sq_{ver}.txt (FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc passes)"})
 if b1:
-    kernels.append({"kernel": "train_fused_bf16_kernel<false>", "objects": 50, "rays": 4096, "samples": 64,
+    kernels.append({"kernel": "train_fused_bf16_kernel<false, 64>", "objects": 50, "rays": 4096, "samples": 64,
                     "valu_insts_per_launch": b1.get("SQ_INSTS_VALU"), "mfma_insts_per_launch": b1.get("SQ_INSTS_MFMA"),
                     "lds_insts_per_launch": b1.get("SQ_INSTS_LDS"), "hbm_bytes_per_launch": None,
                     "source": f"profiles/{rnd}_pmc_bf16_{ver}.txt (SQ_INSTS_VALU, --pmc pass of bench.py --dtype bf16 --no-bg)"})
