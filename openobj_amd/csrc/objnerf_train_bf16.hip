@@ -262,7 +262,18 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
   const float inv2 = a.flags[1] ? 0.0f : 1.0f / (n2 + 1e-10f);
 
   f32x4 accA0 = zero4(), accA1 = zero4(), accB0 = zero4(), accB1 = zero4(), accC0 = zero4(), accC1 = zero4();
+  // Row sums over the samples (head weights, mid1 / mid2 biases): transposing DPP butterflies into slot registers per
+  // tile, or -- where the registers allow (LAZY_*) -- per-lane partial sums reduced once at the end of the sweep
+  // (the butterflies are ~150 select / DPP instructions per tile in a VALU-bound kernel).
+#ifdef OBJ_BF16_BUTTERFLY
+  constexpr bool LAZY_H = false, LAZY_B = false;
+#else
+  constexpr bool LAZY_H = !FEAT || SS != 0, LAZY_B = !FEAT;     // (the any-S feature build has no registers to spare)
+#endif
   float gS0 = 0.f, gS1 = 0.f, gS2 = 0.f;
+  float hW[4][8], bS[2][8];
+#pragma unroll
+  for (int s_ = 0; s_ < 8; ++s_) hW[0][s_] = hW[1][s_] = hW[2][s_] = hW[3][s_] = bS[0][s_] = bS[1][s_] = 0.f;
   float g_ba = 0.f, g_boc0 = 0.f, g_boc1 = 0.f, g_boc2 = 0.f;
   float dB[6][3];                           // d B[4 i + g][x], summed over this lane's samples
 #pragma unroll
@@ -765,17 +776,26 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
         const int row = 16 * tt + 4 * g + r;
         const int s = 4 * tt + r;
         const float hv = hc.t[tt][r];
-        pa_[s] = da * h4.t[tt][r];
-        pb_[s] = dc0 * hv;
-        pc_[s] = dc1 * hv;
-        pd_[s] = dc2 * hv;
+        if (LAZY_H) {
+          hW[0][s] = fmaf(da, h4.t[tt][r], hW[0][s]);
+          hW[1][s] = fmaf(dc0, hv, hW[1][s]);
+          hW[2][s] = fmaf(dc1, hv, hW[2][s]);
+          hW[3][s] = fmaf(dc2, hv, hW[3][s]);
+        } else {
+          pa_[s] = da * h4.t[tt][r];
+          pb_[s] = dc0 * hv;
+          pc_[s] = dc1 * hv;
+          pd_[s] = dc2 * hv;
+        }
         const float dv = fmaf(sm[S_WOC + 2 * H + row], dc2, fmaf(sm[S_WOC + H + row], dc1, sm[S_WOC + row] * dc0));
         d_hc.t[tt][r] = hv > 0.0f ? dv : 0.0f;
         d_h4.t[tt][r] = sm[S_WA + row] * da;
       }
-    gS0 += slot_sums16(pa_, pb_, c);
-    gS1 += slot_sums16(pc_, pd_, c);
-    asm volatile("" : "+v"(gS0), "+v"(gS1));
+    if (!LAZY_H) {
+      gS0 += slot_sums16(pa_, pb_, c);
+      gS1 += slot_sums16(pc_, pd_, c);
+      asm volatile("" : "+v"(gS0), "+v"(gS1));
+    }
     store32_b(stg_lane, 0, h4);
     store32_b(stg_lane, 96, h3);
     store32_b(stg_lane, 128, d_hc);
@@ -788,11 +808,16 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
       bwd_tile(d_h4.t[1], t_fl, 16, d_hf_b);
     }
     d_h4 = relu_mask32(d_h4, h4);
+    if (LAZY_B) {
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
+      for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) pa_[4 * tt + r] = d_h4.t[tt][r];
-    {
+        for (int r = 0; r < 4; ++r) bS[1][4 * tt + r] += d_h4.t[tt][r];
+    } else {
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pa_[4 * tt + r] = d_h4.t[tt][r];
       const float sv = slot_sums8(pa_, c);
       gS2 += (c >= 8) ? sv : 0.0f;
       asm volatile("" : "+v"(gS2));
@@ -844,12 +869,17 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
     bwd_tile(d_h2.t[0], t_cat, 0, d_h3_b);
     bwd_tile(d_h2.t[1], t_cat, 16, d_h3_b);
     d_h2 = relu_mask32(d_h2, h2);
-    float pa2_[8];
+    if (LAZY_B) {
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
+      for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) pa2_[4 * tt + r] = d_h2.t[tt][r];
-    {
+        for (int r = 0; r < 4; ++r) bS[0][4 * tt + r] += d_h2.t[tt][r];
+    } else {
+      float pa2_[8];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pa2_[4 * tt + r] = d_h2.t[tt][r];
       const float sv = slot_sums8(pa2_, c);
       gS2 += (c < 8) ? sv : 0.0f;
       asm volatile("" : "+v"(gS2));
@@ -932,8 +962,28 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
     float* mine = red + w * NRED;
     const int s = c & 7;
     const int row = 16 * (s >> 2) + 4 * g + (s & 3);
-    if (c < 8) { mine[64 + row] = gS0; mine[128 + row] = gS1; mine[row] = gS2; }
-    else { mine[96 + row] = gS0; mine[160 + row] = gS1; mine[32 + row] = gS2; }
+    if (LAZY_H) {
+#pragma unroll
+      for (int s_ = 0; s_ < 8; ++s_) {
+        const int rw = 16 * (s_ >> 2) + 4 * g + (s_ & 3);
+        const float v2 = dpp_rowsum16(hW[0][s_]), v3 = dpp_rowsum16(hW[1][s_]);
+        const float v4 = dpp_rowsum16(hW[2][s_]), v5 = dpp_rowsum16(hW[3][s_]);
+        if (c == 0) { mine[64 + rw] = v2; mine[96 + rw] = v3; mine[128 + rw] = v4; mine[160 + rw] = v5; }
+      }
+    } else {
+      if (c < 8) { mine[64 + row] = gS0; mine[128 + row] = gS1; }
+      else { mine[96 + row] = gS0; mine[160 + row] = gS1; }
+    }
+    if (LAZY_B) {
+#pragma unroll
+      for (int s_ = 0; s_ < 8; ++s_) {
+        const int rw = 16 * (s_ >> 2) + 4 * g + (s_ & 3);
+        const float v0 = dpp_rowsum16(bS[0][s_]), v1 = dpp_rowsum16(bS[1][s_]);
+        if (c == 0) { mine[rw] = v0; mine[32 + rw] = v1; }
+      }
+    } else {
+      mine[(c < 8 ? 0 : 32) + row] = gS2;
+    }
     const float s0 = wave_sum64(g_ba), s1 = wave_sum64(g_boc0), s2 = wave_sum64(g_boc1), s3 = wave_sum64(g_boc2);
     if (lane == 0) { mine[192] = s0; mine[193] = s1; mine[194] = s2; mine[195] = s3; }
     const float e0 = wave_sum64(l_d), e1 = wave_sum64(l_c), e2 = wave_sum64(l_o);
