@@ -1314,8 +1314,8 @@ static WS carve(char* base, int H, int C, long n, long R, int K, bool feat) {
       add(H, H, n, true); add(H, OBJ_E2, n, false);        // feature layer
       add(C, (int)XC, R, false); add((int)XC, (int)XC, R, false);   // 512-d head moments
     }
-    // (+ the block partials of the head weight gradients and of d B: at most 512 + 1024 blocks of 4 H + 4 / 63 floats)
-    w.parts_floats = tot + (size_t)(512 + K) * (4 * Hs + 68) + (size_t)K * 1024 * 64;
+    // (+ the block partials of the head weight gradients and of d B: at most 2048 + 1024 blocks of 4 H + 4 / 63 floats)
+    w.parts_floats = tot + (size_t)(2048 + K) * (4 * Hs + 68) + (size_t)K * 1024 * 64;
     w.parts = take(w.parts_floats);
     w.loss_part = take((size_t)K * R * 4);
   }
@@ -1563,8 +1563,10 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
     wgrad(ss, K, 1, H, n, w.dhead, 1, 4, n * 4, w.h4, H, 1, nH, G + off[8], H, ps, G + off[9]);
     wgrad(ss, K, 3, H, n, w.dhead + 1, 1, 4, n * 4, w.hc, H, 1, nH, G + off[12], H, ps, G + off[13]);
   } else {
-    int hb = (int)((n + 511) / 512);                      // >= 512 samples per block, about two blocks per CU in all
-    const int cap = (512 + K - 1) / K;
+    // 64 samples per block (32 iterations of a 2-row pass at H = 128): the loop is a chain of load latencies, so the
+    // reduction wants many short blocks (512 samples per block: 183 us for the background batch; now ~25 us)
+    int hb = (int)((n + 63) / 64);
+    const int cap = (2048 + K - 1) / K;
     if (hb > cap) hb = cap;
     // block partials + an ordered reduction (reduce_parts_kernel: "GEMMs" of M = 1 / 3 rows with hb slices)
     float* pA = parts_alloc((size_t)K * hb * H), *pW = parts_alloc((size_t)K * hb * 3 * H);

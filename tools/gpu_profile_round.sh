@@ -19,6 +19,12 @@ rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmc_bf16b -o p -- python3 $R/bench.py --dtype bf16 $P > /dev/null 2> $OUT/pmc_bf16b.err
 python3 $R/bench.py --no-bg --steps 10 --warmup 3 $Q > $OUT/bench_nobg.json 2>/dev/null
 python3 $R/bench.py > $OUT/bench_full.json 2>$OUT/bench_full.err
+python3 $R/bench.py --config c3 --steps 10 --warmup 3 $Q > $OUT/bench_c3.json 2>/dev/null
+python3 $R/bench.py --config c4 --steps 5 --warmup 2 $Q > $OUT/bench_c4.json 2>/dev/null
+python3 $R/bench.py --config c5 --steps 2 --warmup 1 $Q --no-bf16-line > $OUT/bench_c5.json 2>/dev/null
+python3 $R/bench.py --config c5 --dtype fp16 --steps 2 --warmup 1 $Q > $OUT/bench_c5_fp16.json 2>/dev/null
+# the two-collective iteration over RCCL with one rank (the multi-GPU code path on the one GPU there is)
+OBJNERF_DIST_SELFTEST=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 $R/bench.py --gpus 1 --steps 10 --warmup 3 $Q 2>/dev/null | tail -1 > $OUT/bench_dist_selftest.json
 for d in pmc_fetch pmc_write pmc_sq pmc_sq2; do
   f=$(ls $OUT/$d/*counter_collection.csv 2>/dev/null | head -1)
   [ -n "$f" ] && python3 $R/tools/pmc_summary.py $f train_fused32 > $OUT/$d.txt
