@@ -522,7 +522,16 @@ struct FwdSmall {
 constexpr int FS_H = 128, FS_P = 132;
 template <int RT> constexpr size_t fs_lds_bytes() { return (size_t)(FS_H + 2 * 16 * RT) * FS_P * sizeof(float); }
 
-template <int RT>
+// BF: OBJNERF_TRAIN_BF16 -- the same kernel with the contraction on v_mfma_f32_16x16x32_bf16: operands stay fp32 in
+// LDS, a lane reads its 8 consecutive k of a 32-block (two ds_read_b128) and rounds them to bf16 on the fly; one MFMA
+// replaces eight (the fp32 kernel spends ~60 % of its time in the MFMA loop).
+__device__ __forceinline__ bf16x8 cvt_bf16x8(const f32x4& lo, const f32x4& hi) {
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { o[e] = (__bf16)lo[e]; o[4 + e] = (__bf16)hi[e]; }
+  return o;
+}
+template <int RT, bool BF>
 __global__ __launch_bounds__(512) void mlp_fwd_small_kernel(const FwdSmall a) {
   constexpr int BM = 16 * RT, H = FS_H, PT = FS_P;
   extern __shared__ __attribute__((aligned(16))) float fs_lds[];
@@ -548,8 +557,8 @@ __global__ __launch_bounds__(512) void mlp_fwd_small_kernel(const FwdSmall a) {
     er1[i] = (in && kk < OBJ_E1) ? emb[(m0 + m) * OBJ_EMB + kk] : 0.f;
     er2[i] = (in && kk < OBJ_E2) ? emb[(m0 + m) * OBJ_EMB + OBJ_E1 + kk] : 0.f;
   }
-  auto put_emb = [&](float* X, const float (&er)[ER], const int KC) {      // zero-padded to a multiple of 16 columns
-    const int KC16 = (KC + 15) & ~15;
+  auto put_emb = [&](float* X, const float (&er)[ER], const int KC) {      // zero-padded to a multiple of 16 (32) columns
+    const int KC16 = BF ? ((KC + 31) & ~31) : ((KC + 15) & ~15);
     if (kk < KC16) {
 #pragma unroll
       for (int i = 0; i < ER; ++i) {
@@ -579,6 +588,20 @@ __global__ __launch_bounds__(512) void mlp_fwd_small_kernel(const FwdSmall a) {
   // four steps of an operand with ONE ds_read_b128 (conflict-free with the 132-float pitch); the next block's
   // operands are requested before the current block's 4 RT MFMAs are issued.
   auto mma = [&](const float* X, const int KC) {
+    if (BF) {          // KC a multiple of 32 (the callers round up; the padding columns hold zeros on both sides)
+      const float* bp = Wb + (16 * w + c) * PT + 8 * gg;
+      const float* ap = X + c * PT + 8 * gg;
+      for (int kb = 0; kb < KC; kb += 32) {
+        const bf16x8 b = cvt_bf16x8(*reinterpret_cast<const f32x4*>(bp + kb), *reinterpret_cast<const f32x4*>(bp + kb + 4));
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+          const float* r = ap + 16 * i * PT + kb;
+          const bf16x8 av = cvt_bf16x8(*reinterpret_cast<const f32x4*>(r), *reinterpret_cast<const f32x4*>(r + 4));
+          acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b, acc[i], 0, 0, 0);
+        }
+      }
+      return;
+    }
     const float* bp = Wb + (16 * w + c) * PT + 4 * gg;
     const float* ap = X + c * PT + 4 * gg;
     f32x4 bc = *reinterpret_cast<const f32x4*>(bp), ac[RT];
@@ -616,7 +639,7 @@ __global__ __launch_bounds__(512) void mlp_fwd_small_kernel(const FwdSmall a) {
         if (m0 + m < n) out[(m0 + m) * H + f] = v;
       }
   };
-  constexpr int E1P = (OBJ_E1 + 15) & ~15, E2P = (OBJ_E2 + 15) & ~15;
+  constexpr int E1P = BF ? ((OBJ_E1 + 31) & ~31) : ((OBJ_E1 + 15) & ~15), E2P = BF ? ((OBJ_E2 + 31) & ~31) : ((OBJ_E2 + 15) & ~15);
   // biases and head weights of this lane, fetched before anything waits on them
   const int fb = 16 * w + c;
   const float b_in = P[a.o_in_b + fb], b_m1 = P[a.o_m1_b + fb], b_cat = P[a.o_cat_b + fb], b_m2 = P[a.o_m2_b + fb];
@@ -742,7 +765,7 @@ struct BwdSmall {
 constexpr int BS_PW = 130;
 template <int RT> constexpr size_t bs_lds_bytes() { return (size_t)(FS_H * BS_PW + 2 * 16 * RT * FS_P) * sizeof(float); }
 
-template <int RT>
+template <int RT, bool BF>
 __global__ __launch_bounds__(512) void mlp_bwd_small_kernel(const BwdSmall a) {
   constexpr int BM = 16 * RT, H = FS_H, PT = FS_P, PW = BS_PW;
   extern __shared__ __attribute__((aligned(16))) float fs_lds[];
@@ -782,6 +805,23 @@ __global__ __launch_bounds__(512) void mlp_bwd_small_kernel(const BwdSmall a) {
   // forward kernel (step j of a 16-block takes k = 16 blk + 4 gg + j): D rows by ds_read_b128, the four weight rows
   // by ds_read_b32 (bank = 8 gg + 2 j + n: two lanes per bank, the minimum for 64 lanes).
   auto mma = [&](const float* D, f32x4 (&v)[RT]) {
+    if (BF) {          // bf16 MFMA: k-slot (block, gg, e) = output feature 32 block + 8 gg + e; eight weight rows per lane
+      const float* bp = Wb + 8 * gg * PW + 16 * w + c;       // (bank = 16 gg + 2 e + c: conflict-free)
+      const float* ap = D + c * PT + 8 * gg;
+#pragma unroll
+      for (int kb = 0; kb < H; kb += 32) {
+        bf16x8 b;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) b[e] = (__bf16)bp[(kb + e) * PW];
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+          const float* r = ap + 16 * i * PT + kb;
+          const bf16x8 av = cvt_bf16x8(*reinterpret_cast<const f32x4*>(r), *reinterpret_cast<const f32x4*>(r + 4));
+          v[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b, v[i], 0, 0, 0);
+        }
+      }
+      return;
+    }
     const float* bp = Wb + 4 * gg * PW + 16 * w + c;
     const float* ap = D + c * PT + 4 * gg;
     f32x4 bc, ac[RT];
@@ -937,23 +977,29 @@ __global__ __launch_bounds__(512) void mlp_bwd_small_kernel(const BwdSmall a) {
 }
 
 template <int RT>
-static void launch_bwd_small(hipStream_t st, const BwdSmall& f, int K) {
+static void launch_bwd_small(hipStream_t st, const BwdSmall& f, int K, bool bf) {
   objnerf_once_per_device([] {
-    (void)hipFuncSetAttribute((const void*)mlp_bwd_small_kernel<RT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void*)mlp_bwd_small_kernel<RT, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)bs_lds_bytes<RT>());
+    (void)hipFuncSetAttribute((const void*)mlp_bwd_small_kernel<RT, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)bs_lds_bytes<RT>());
   });
   dim3 grid((unsigned)((f.n + 16 * RT - 1) / (16 * RT)), (unsigned)K);
-  hipLaunchKernelGGL(mlp_bwd_small_kernel<RT>, grid, dim3(512), bs_lds_bytes<RT>(), st, f);
+  if (bf) hipLaunchKernelGGL((mlp_bwd_small_kernel<RT, true>), grid, dim3(512), bs_lds_bytes<RT>(), st, f);
+  else hipLaunchKernelGGL((mlp_bwd_small_kernel<RT, false>), grid, dim3(512), bs_lds_bytes<RT>(), st, f);
 }
 
 template <int RT>
-static void launch_fwd_small(hipStream_t st, const FwdSmall& f, int K) {
+static void launch_fwd_small(hipStream_t st, const FwdSmall& f, int K, bool bf) {
   objnerf_once_per_device([] {
-    (void)hipFuncSetAttribute((const void*)mlp_fwd_small_kernel<RT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void*)mlp_fwd_small_kernel<RT, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)fs_lds_bytes<RT>());
+    (void)hipFuncSetAttribute((const void*)mlp_fwd_small_kernel<RT, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)fs_lds_bytes<RT>());
   });
   dim3 grid((unsigned)((f.n + 16 * RT - 1) / (16 * RT)), (unsigned)K);
-  hipLaunchKernelGGL(mlp_fwd_small_kernel<RT>, grid, dim3(512), fs_lds_bytes<RT>(), st, f);
+  if (bf) hipLaunchKernelGGL((mlp_fwd_small_kernel<RT, true>), grid, dim3(512), fs_lds_bytes<RT>(), st, f);
+  else hipLaunchKernelGGL((mlp_fwd_small_kernel<RT, false>), grid, dim3(512), fs_lds_bytes<RT>(), st, f);
 }
 
 // row tiles per workgroup: the smallest RT for which K * ceil(n / (16 RT)) workgroups fit the chip in one round;
@@ -964,8 +1010,8 @@ static int small_batch_rt(int H, long n, int K) {
     if ((long)K * ((n + 16 * rt - 1) / (16 * rt)) <= 256) return rt;
   // up to four rounds of 80-sample workgroups the one-launch kernels still win (76 800 samples: 1.02 vs 1.07 ms per
   // step, 38 400: 0.53 vs 0.65); beyond that the GEMM path runs near the MFMA peak
-  // (fp32 mode only: with bf16 operands the GEMMs are ahead again from two rounds on)
-  if (!t_bf16_operands && (long)K * ((n + 79) / 80) <= 1024) return 5;
+  // (fp32 and bf16 modes: the one-launch kernels exist for both; fp16 keeps the GEMM path from two rounds on)
+  if (t_bf16_operands != 2 && (long)K * ((n + 79) / 80) <= 1024) return 5;
   return 0;
 }
 
@@ -1475,8 +1521,9 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
   dim3 eg((unsigned)((n + 15) / 16), (unsigned)K);      // 16 lanes per sample row
   const size_t head_lds = (size_t)4 * H * sizeof(float);
   const int small_rt = small_batch_rt(H, n, K);
-  // (the small-batch kernels are fp32: in that latency-bound regime they beat the bf16-operand GEMMs as well, so
-  // OBJNERF_TRAIN_BF16 is a no-op there)
+  // the small-batch kernels come in fp32 and bf16-MFMA form (fp16 mode: fp32 there); their weight-gradient GEMMs stay
+  // fp32 (one grouped launch)
+  const bool small_bf = small_rt && t_bf16_operands == 1;
   if (small_rt) t_bf16_operands = 0;
   if (small_rt) {
     FwdSmall f;
@@ -1488,11 +1535,11 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
     f.o_a_w = (int)off[8]; f.o_a_b = (int)off[9]; f.o_cl_w = (int)off[10]; f.o_cl_b = (int)off[11];
     f.o_oc_w = (int)off[12]; f.o_oc_b = (int)off[13]; f.o_fl_w = (int)off[14]; f.o_fl_b = (int)off[15];
     switch (small_rt) {
-      case 1: launch_fwd_small<1>(st, f, K); break;
-      case 2: launch_fwd_small<2>(st, f, K); break;
-      case 3: launch_fwd_small<3>(st, f, K); break;
-      case 4: launch_fwd_small<4>(st, f, K); break;
-      default: launch_fwd_small<5>(st, f, K); break;
+      case 1: launch_fwd_small<1>(st, f, K, small_bf); break;
+      case 2: launch_fwd_small<2>(st, f, K, small_bf); break;
+      case 3: launch_fwd_small<3>(st, f, K, small_bf); break;
+      case 4: launch_fwd_small<4>(st, f, K, small_bf); break;
+      default: launch_fwd_small<5>(st, f, K, small_bf); break;
     }
   } else {
   // h1 = relu(x1 W_in^T + b)
@@ -1628,11 +1675,11 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
     b.o_in_w = (int)off[0]; b.o_m1_w = (int)off[2]; b.o_cat_w = (int)off[4]; b.o_m2_w = (int)off[6];
     b.o_cl_w = (int)off[10]; b.o_fl_w = (int)off[14];
     switch (small_rt) {
-      case 1: launch_bwd_small<1>(st, b, K); break;
-      case 2: launch_bwd_small<2>(st, b, K); break;
-      case 3: launch_bwd_small<3>(st, b, K); break;
-      case 4: launch_bwd_small<4>(st, b, K); break;
-      default: launch_bwd_small<5>(st, b, K); break;
+      case 1: launch_bwd_small<1>(st, b, K, small_bf); break;
+      case 2: launch_bwd_small<2>(st, b, K, small_bf); break;
+      case 3: launch_bwd_small<3>(st, b, K, small_bf); break;
+      case 4: launch_bwd_small<4>(st, b, K, small_bf); break;
+      default: launch_bwd_small<5>(st, b, K, small_bf); break;
     }
     fork();
     GemmGroup group;
