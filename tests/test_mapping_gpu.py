@@ -340,3 +340,40 @@ def test_mapping_bf16_mode(dev, tmp_path):
     assert m.loop.bf16 and m.bg_loop.bf16
     first, last = _total(hist[0]["obj"]), _total(hist[-1]["obj"])
     assert torch.isfinite(last).all() and float(last[-10:].mean()) < 0.5 * float(first[:10].mean())
+
+
+def test_mapping_scannet_camera_15_objects_part_features(dev, tmp_path):
+    """BASELINE configs[3]'s per-GPU shape end to end: ScanNet-format files, a 640 x 480 camera, 15 foreground objects
+    (120 objects over 8 GPUs) + the background, part-level features (512-d distillation loss), the reference's ScanNet
+    sampling numbers.  Files -> dataset adapter -> batched ingestion -> seeded sampler (origins / dirs / recorded
+    pixels for the feature lookup) -> fused feature-loss iterations -> checkpoints."""
+    root = tmp_path / "scene"
+    cam = SF.write_grid_scene(str(root), "ScanNet", n_obj=15, n_frames=20, part_dim=512, part_down=10, stored_down=5)
+    c = ocfg.Config(ocfg.replica_room0_config(train_device=str(dev), **{
+        "dataset.path": str(root), "dataset.format": "ScanNet", "trainer.part_mode": 1, "trainer.part_down": 10,
+        "camera.w": cam["W"], "camera.h": cam["H"], "camera.fx": cam["fx"], "camera.fy": cam["fy"], "camera.cx": cam["cx"],
+        "camera.cy": cam["cy"], "render.iters_per_frame": 20, "render.depth_range": [0.0, 8.0]}))
+    m = mapping.IncrementalMapper(c)
+    hist = []
+    m.run(ods.init_loader(c, multi_worker=False), on_frame=lambda f, l: hist.append(l))
+    assert len(hist) == 2 and list(m.obj_dict) == cam["ids"] and sorted(m.vis_dict) == [0] + cam["ids"]
+    # (the ScanNet adapter halves the stored 128 x 96 part map when part_down is 10: dataset.py:305-309)
+    assert m.loop.arena.K == 15 and m.loop.with_feat and m.global_partfeat.shape[1:] == (64, 48, 512)
+    t0, t1 = torch.stack(hist[0]["obj"]), torch.stack(hist[-1]["obj"])             # [iterations, 15, 4]
+    assert t0.shape == (20, 15, 4) and bool(torch.isfinite(t1).all())
+    assert bool((t0[:, :, 3] > 0).all())                                            # every object has a feature term
+    first, last = _total(hist[0]["obj"]), _total(hist[-1]["obj"])
+    assert float(last[-5:].mean()) < 0.6 * float(first[:5].mean()), (first[:5], last[-5:])
+    # depth along the central ray of three objects after 40 iterations: within 0.35 m of their surfaces
+    for k in (0, 7, 14):
+        so = m.obj_dict[cam["ids"][k]]
+        r, cc = divmod(k, 5)
+        u, v = cc * 128 + 128 // 6 + 42, r * 160 + 160 // 6 + 53                    # centre of the rectangle
+        d = torch.tensor([(u - cam["cx"]) / cam["fx"], (v - cam["cy"]) / cam["fy"], 1.0], device=dev)
+        z = torch.linspace(0.3, 4.0, 128, device=dev)
+        occ, _, _ = so.trainer.eval_points((z[:, None] * d[None]).reshape(-1, 3))
+        w_ = occ * torch.cumprod(torch.cat([torch.ones(1, device=dev), 1 - occ[:-1] + 1e-10]), 0)
+        depth = float((w_ * z).sum() / w_.sum().clamp(min=1e-6))
+        assert abs(depth - (1.2 + 0.1 * k)) < 0.35, (k, depth)
+    m.save_checkpoints(str(tmp_path / "log"))
+    assert os.path.exists(tmp_path / "log" / "ckpt" / str(cam["ids"][14]) / ("obj_%d.pth" % cam["ids"][14]))
