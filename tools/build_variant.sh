@@ -7,7 +7,7 @@ name=$1; shift
 mkdir -p abl
 make -s
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off"
-SCHED32=${SCHED32--mllvm -amdgpu-sched-strategy=max-ilp}
+SCHED32=${SCHED32--mllvm -amdgpu-sched-strategy=iterative-ilp}
 /opt/rocm/bin/hipcc $FLAGS -mllvm -amdgpu-sched-strategy=max-ilp "$@" -c objnerf_train.hip -o abl/train_$name.o &
 /opt/rocm/bin/hipcc $FLAGS $SCHED32 "$@" -c objnerf_train32.hip -o abl/train32_$name.o &
 /opt/rocm/bin/hipcc $FLAGS "$@" -c objnerf_train_bf16.hip -o abl/train_bf16_$name.o &
