@@ -217,16 +217,19 @@ template <> struct Op16<_Float16> {
 // BKB: k-stage depth (OBJ_G16_BK / OBJ_G16_BK_WIDE).  Measured on MI355X (tools/gemm16_ab.sh): deeper stages LOSE --
 // background step in bf16 mode 0.92 ms at 32, 1.19 ms at 64, 2.2 ms at 128; configs[4] share in fp16 2.18 / 2.37 /
 // 2.60 s -- the prefetch registers and the larger LDS tiles cost more occupancy than the saved barriers return.
-template <int TM, int TN, typename OT, int BKB>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(const Gemm g) {
-  constexpr int BM = 32 * TM, BN = 32 * TN, LDK = BKB + 8;
+// WM x WN waves per workgroup, TM x TN MFMA tiles per wave.  The 128 x 128 tile runs on 8 waves (4 x 2, 32 x 64 per wave:
+// 32 accumulator and 16 staging registers): as 4 waves of 64 x 64 it needed 197 registers, ONE wave per SIMD, and ran
+// the hidden-256 layer GEMMs at 28 TFLOP/s -- slower than the fp32 kernel.
+template <int TM, int TN, typename OT, int BKB, int WM = 2, int WN = 2>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(const Gemm g) {
+  constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN, LDK = BKB + 8, NTH = 64 * WM * WN;
   typedef typename Op16<OT>::V OV;
   __shared__ __attribute__((aligned(16))) OT As[BM][LDK];
   __shared__ __attribute__((aligned(16))) OT Bs[BN][LDK];
   const float a_scale = g.a_scale, inv_scale = 1.0f / g.a_scale;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int c = lane & 15, gg = lane >> 4;
-  const int wm = w >> 1, wn = w & 1;
+  const int wm = w / WN, wn = w % WN;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int sk = g.splitk > 1 ? g.splitk : 1;
   const long z = blockIdx.z / sk;
@@ -241,12 +244,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const Gemm g) {
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  constexpr int NA = BM * BKB / 256, NB = BN * BKB / 256;
+  constexpr int NA = BM * BKB / NTH, NB = BN * BKB / NTH;
   float ra[NA], rb[NB];
   auto load_tiles = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const int e = tid + 256 * i;
+      const int e = tid + NTH * i;
       int am, ak;
       if (g.sak == 1) { ak = e % BKB; am = e / BKB; } else { am = e % BM; ak = e / BM; }
       const int gm = m0 + am, gk = k0 + ak;
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const Gemm g) {
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      const int e = tid + 256 * i;
+      const int e = tid + NTH * i;
       int bn, bk;
       if (g.sbk == 1) { bk = e % BKB; bn = e / BKB; } else { bn = e % BN; bk = e / BN; }
       const int gn = n0 + bn, gk2 = k0 + bk;
@@ -264,14 +267,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const Gemm g) {
   auto store_tiles = [&]() {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const int e = tid + 256 * i;
+      const int e = tid + NTH * i;
       int am, ak;
       if (g.sak == 1) { ak = e % BKB; am = e / BKB; } else { am = e % BM; ak = e / BM; }
       As[am][ak] = Op16<OT>::cvt(ra[i] * a_scale);
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      const int e = tid + 256 * i;
+      const int e = tid + NTH * i;
       int bn, bk;
       if (g.sbk == 1) { bk = e % BKB; bn = e / BKB; } else { bn = e % BN; bk = e / BN; }
       Bs[bn][bk] = Op16<OT>::cvt(rb[i]);
@@ -447,8 +450,8 @@ static void gemm(hipStream_t st, int batch, int M, int N, int Kd, const float* A
   if (t_bf16_operands) {
     const bool wide = M >= 256 && N >= 192, f16 = t_bf16_operands == 2;
     const dim3 grid(wide ? (N + 127) / 128 : (N + 63) / 64, wide ? (M + 127) / 128 : (M + 63) / 64, nz);
-    if (wide && f16) hipLaunchKernelGGL((gemm_bf16_kernel<4, 4, _Float16, OBJ_G16_BK_WIDE>), grid, dim3(256), 0, st, g);
-    else if (wide) hipLaunchKernelGGL((gemm_bf16_kernel<4, 4, __bf16, OBJ_G16_BK_WIDE>), grid, dim3(256), 0, st, g);
+    if (wide && f16) hipLaunchKernelGGL((gemm_bf16_kernel<2, 4, _Float16, OBJ_G16_BK_WIDE, 4, 2>), grid, dim3(512), 0, st, g);
+    else if (wide) hipLaunchKernelGGL((gemm_bf16_kernel<2, 4, __bf16, OBJ_G16_BK_WIDE, 4, 2>), grid, dim3(512), 0, st, g);
     else if (f16) hipLaunchKernelGGL((gemm_bf16_kernel<2, 2, _Float16, OBJ_G16_BK>), grid, dim3(256), 0, st, g);
     else hipLaunchKernelGGL((gemm_bf16_kernel<2, 2, __bf16, OBJ_G16_BK>), grid, dim3(256), 0, st, g);
     return;
