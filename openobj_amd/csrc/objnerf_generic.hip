@@ -220,12 +220,37 @@ template <> struct Op16<_Float16> {
 // WM x WN waves per workgroup, TM x TN MFMA tiles per wave.  The 128 x 128 tile runs on 8 waves (4 x 2, 32 x 64 per wave:
 // 32 accumulator and 16 staging registers): as 4 waves of 64 x 64 it needed 197 registers, ONE wave per SIMD, and ran
 // the hidden-256 layer GEMMs at 28 TFLOP/s -- slower than the fp32 kernel.
-template <int TM, int TN, typename OT, int BKB, int WM = 2, int WN = 2>
+//
+// AKM / BKM: the operand's ROWS (m / n) are the contiguous dimension in memory (weight gradients: A = d_out^T, B =
+// activations; input gradients: B = W as stored).  Such a tile is staged K-MAJOR -- four consecutive rows per thread,
+// one 8-byte LDS store, coalesced -- and the MFMA operand (8 consecutive k of one row) is gathered by two
+// ds_read_b64_tr_b16 (gfx950's transposing LDS read: a 16-lane group reads a 4 k x 16 rows block column-wise;
+// tools/ubench_tr.hip checks the lane map).  Before, those tiles went to the [row][k] image as 2-byte stores with a
+// 4-way bank conflict and the hidden-256 weight gradients ran at 18 TFLOP/s.
+// (the read is issued without a wait; lds_tr16_wait ties the results of a batch of reads to ONE s_waitcnt, so the reads
+// of a k-step are in flight together instead of one LDS round trip each)
+__device__ __forceinline__ uint2 lds_tr16(const void* p) {
+  uint2 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"((uint32_t)(uintptr_t)p) : "memory");
+  return r;
+}
+// (the results must not be touched -- not even copied -- before the wait: the hardware does not interlock on LDS
+// returns, so the wait is tied to the very registers the reads write)
+template <int N>
+__device__ __forceinline__ void lds_tr16_wait(uint2 (&lo)[N], uint2 (&hi)[N]) {
+  static_assert(N == 2 || N == 4, "batch size");
+#define OBJ_T2(i) "+v"(lo[i]), "+v"(hi[i])
+  if constexpr (N == 2) asm volatile("s_waitcnt lgkmcnt(0)" : OBJ_T2(0), OBJ_T2(1)::"memory");
+  else asm volatile("s_waitcnt lgkmcnt(0)" : OBJ_T2(0), OBJ_T2(1), OBJ_T2(2), OBJ_T2(3)::"memory");
+#undef OBJ_T2
+}
+template <int TM, int TN, typename OT, int BKB, int WM = 2, int WN = 2, bool AKM = false, bool BKM = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(const Gemm g) {
   constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN, LDK = BKB + 8, NTH = 64 * WM * WN;
+  constexpr int PA = BM + 8, PB = BN + 8;                 // k-major row pitches (elements; 8-byte aligned rows)
   typedef typename Op16<OT>::V OV;
-  __shared__ __attribute__((aligned(16))) OT As[BM][LDK];
-  __shared__ __attribute__((aligned(16))) OT Bs[BN][LDK];
+  __shared__ __attribute__((aligned(16))) OT Asm[AKM ? BKB * PA : BM * LDK];
+  __shared__ __attribute__((aligned(16))) OT Bsm[BKM ? BKB * PB : BN * LDK];
   const float a_scale = g.a_scale, inv_scale = 1.0f / g.a_scale;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int c = lane & 15, gg = lane >> 4;
@@ -246,39 +271,79 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(const Gemm g) {
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   constexpr int NA = BM * BKB / NTH, NB = BN * BKB / NTH;
   float ra[NA], rb[NB];
+  static_assert(NA % 4 == 0 && NB % 4 == 0, "k-major staging takes four rows per thread");
+  typedef OT ot4 __attribute__((ext_vector_type(4)));
+  // element e of a thread's share -> (row, k).  Row-major image: lanes along k.  K-major image: quad q = 4 rows at one k.
   auto load_tiles = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const int e = tid + NTH * i;
       int am, ak;
-      if (g.sak == 1) { ak = e % BKB; am = e / BKB; } else { am = e % BM; ak = e / BM; }
+      if (AKM) { const int q = tid + NTH * (i >> 2); am = 4 * (q % (BM / 4)) + (i & 3); ak = q / (BM / 4); }
+      else { const int e = tid + NTH * i; ak = e % BKB; am = e / BKB; }
       const int gm = m0 + am, gk = k0 + ak;
       ra[i] = (gm < g.M && gk < kend) ? A[gm * g.sam + gk * g.sak] : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      const int e = tid + NTH * i;
       int bn, bk;
-      if (g.sbk == 1) { bk = e % BKB; bn = e / BKB; } else { bn = e % BN; bk = e / BN; }
+      if (BKM) { const int q = tid + NTH * (i >> 2); bn = 4 * (q % (BN / 4)) + (i & 3); bk = q / (BN / 4); }
+      else { const int e = tid + NTH * i; bk = e % BKB; bn = e / BKB; }
       const int gn = n0 + bn, gk2 = k0 + bk;
       rb[i] = (gn < g.N && gk2 < kend) ? B[gk2 * g.sbk + gn * g.sbn] : 0.f;
     }
   };
   auto store_tiles = [&]() {
+    if (AKM) {
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const int e = tid + NTH * i;
-      int am, ak;
-      if (g.sak == 1) { ak = e % BKB; am = e / BKB; } else { am = e % BM; ak = e / BM; }
-      As[am][ak] = Op16<OT>::cvt(ra[i] * a_scale);
-    }
+      for (int i = 0; i < NA; i += 4) {
+        const int q = tid + NTH * (i >> 2);
+        ot4 v;
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int e = tid + NTH * i;
-      int bn, bk;
-      if (g.sbk == 1) { bk = e % BKB; bn = e / BKB; } else { bn = e % BN; bk = e / BN; }
-      Bs[bn][bk] = Op16<OT>::cvt(rb[i]);
+        for (int j = 0; j < 4; ++j) v[j] = Op16<OT>::cvt(ra[i + j] * a_scale);
+        *reinterpret_cast<ot4*>(&Asm[(q / (BM / 4)) * PA + 4 * (q % (BM / 4))]) = v;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const int e = tid + NTH * i;
+        Asm[(e / BKB) * LDK + e % BKB] = Op16<OT>::cvt(ra[i] * a_scale);
+      }
     }
+    if (BKM) {
+#pragma unroll
+      for (int i = 0; i < NB; i += 4) {
+        const int q = tid + NTH * (i >> 2);
+        ot4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = Op16<OT>::cvt(rb[i + j]);
+        *reinterpret_cast<ot4*>(&Bsm[(q / (BN / 4)) * PB + 4 * (q % (BN / 4))]) = v;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int e = tid + NTH * i;
+        Bsm[(e / BKB) * LDK + e % BKB] = Op16<OT>::cvt(rb[i]);
+      }
+    }
+  };
+  // MFMA operands of the wave's T row tiles (first tile-local row row0), k-slots ks + 8 gg .. + 7
+  auto operands_km = [&](auto& out, const OT* img, const int pitch, const int row0, const int ks) {
+    constexpr int T = sizeof(out) / sizeof(out[0]);
+    uint2 lo[T], hi[T];
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+      const OT* p = img + (ks + 8 * gg + (c >> 2)) * pitch + row0 + 16 * i + 4 * (c & 3);
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo[i]) : "v"((uint32_t)(uintptr_t)p) : "memory");
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi[i]) : "v"((uint32_t)(uintptr_t)(p + 4 * pitch)) : "memory");
+    }
+    lds_tr16_wait(lo, hi);
+#pragma unroll
+    for (int i = 0; i < T; ++i) out[i] = __builtin_bit_cast(OV, uint4{lo[i].x, lo[i].y, hi[i].x, hi[i].y});
+  };
+  auto operands_rm = [&](auto& out, const OT* img, const int row0, const int ks) {
+    constexpr int T = sizeof(out) / sizeof(out[0]);
+#pragma unroll
+    for (int i = 0; i < T; ++i) out[i] = *reinterpret_cast<const OV*>(img + (row0 + 16 * i + c) * LDK + ks + 8 * gg);
   };
   float rs = 0.f;
   const bool do_rs = g.rowsum != nullptr && blockIdx.x == 0 && tid < BM;
@@ -289,15 +354,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(const Gemm g) {
     if (k0 + BKB < kend) load_tiles(k0 + BKB);
     if (do_rs) {
 #pragma unroll
-      for (int kk = 0; kk < BKB; ++kk) rs += (float)As[tid][kk];
+      for (int kk = 0; kk < BKB; ++kk) rs += (float)(AKM ? Asm[kk * PA + tid] : Asm[tid * LDK + kk]);
     }
 #pragma unroll
     for (int ks = 0; ks < BKB; ks += 32) {
       OV a[TM], b[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const OV*>(&As[16 * TM * wm + 16 * i + c][ks + 8 * gg]);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const OV*>(&Bs[16 * TN * wn + 16 * j + c][ks + 8 * gg]);
+      if (AKM) operands_km(a, Asm, PA, 16 * TM * wm, ks); else operands_rm(a, Asm, 16 * TM * wm, ks);
+      if (BKM) operands_km(b, Bsm, PB, 16 * TN * wn, ks); else operands_rm(b, Bsm, 16 * TN * wn, ks);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -450,10 +513,24 @@ static void gemm(hipStream_t st, int batch, int M, int N, int Kd, const float* A
   if (t_bf16_operands) {
     const bool wide = M >= 256 && N >= 192, f16 = t_bf16_operands == 2;
     const dim3 grid(wide ? (N + 127) / 128 : (N + 63) / 64, wide ? (M + 127) / 128 : (M + 63) / 64, nz);
-    if (wide && f16) hipLaunchKernelGGL((gemm_bf16_kernel<2, 4, _Float16, OBJ_G16_BK_WIDE, 4, 2>), grid, dim3(512), 0, st, g);
-    else if (wide) hipLaunchKernelGGL((gemm_bf16_kernel<2, 4, __bf16, OBJ_G16_BK_WIDE, 4, 2>), grid, dim3(512), 0, st, g);
-    else if (f16) hipLaunchKernelGGL((gemm_bf16_kernel<2, 2, _Float16, OBJ_G16_BK>), grid, dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<2, 2, __bf16, OBJ_G16_BK>), grid, dim3(256), 0, st, g);
+    // operands whose rows are the contiguous dimension are staged k-major (exec is full at the transposing reads:
+    // out-of-range elements are zero-filled, never masked)
+    const bool akm = sak != 1 && sam == 1, bkm = sbk != 1 && sbn == 1;
+#define OBJ_G16_LAUNCH(OT_, AK_, BK_)                                                                                   \
+    do {                                                                                                                \
+      if (wide) hipLaunchKernelGGL((gemm_bf16_kernel<2, 4, OT_, OBJ_G16_BK_WIDE, 4, 2, AK_, BK_>), grid, dim3(512), 0, st, g); \
+      else hipLaunchKernelGGL((gemm_bf16_kernel<2, 2, OT_, OBJ_G16_BK, 2, 2, AK_, BK_>), grid, dim3(256), 0, st, g);    \
+    } while (0)
+#define OBJ_G16_LAUNCH_T(OT_)                                                                                           \
+    do {                                                                                                                \
+      if (akm && bkm) OBJ_G16_LAUNCH(OT_, true, true);                                                                  \
+      else if (bkm) OBJ_G16_LAUNCH(OT_, false, true);                                                                   \
+      else if (akm) OBJ_G16_LAUNCH(OT_, true, false);                                                                   \
+      else OBJ_G16_LAUNCH(OT_, false, false);                                                                           \
+    } while (0)
+    if (f16) OBJ_G16_LAUNCH_T(_Float16); else OBJ_G16_LAUNCH_T(__bf16);
+#undef OBJ_G16_LAUNCH_T
+#undef OBJ_G16_LAUNCH
     return;
   }
   if (M >= 256 && N >= 192) {         // wide layer GEMMs (hidden 256): 128 x 128 tiles on 8 waves (3.5 % faster than the
