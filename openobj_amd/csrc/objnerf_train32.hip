@@ -63,6 +63,19 @@ __device__ __forceinline__ void wg_half(f32x4& acc0, const float* dT, const floa
   }
 }
 
+// a quarter: one 16-output half over half of the staged samples (steps st0 .. st0 + 15 of every lane group's 32)
+__device__ __forceinline__ void wg_quarter(f32x4& acc0, const float* dT, const float* aT, const int st0) {
+  dT = (const float*)__builtin_assume_aligned(dT, 8);
+  aT = (const float*)__builtin_assume_aligned(aT, 8);
+#pragma unroll 8
+  for (int st = st0; st < st0 + 16; st += 2) {
+    const f32x2 b = *reinterpret_cast<const f32x2*>(aT + st);
+    const f32x2 a0 = *reinterpret_cast<const f32x2*>(dT + st);
+    acc0 = OBJ_MFMA(a0[0], b[0], acc0);
+    acc0 = OBJ_MFMA(a0[1], b[1], acc0);
+  }
+}
+
 // one weight-gradient tile pair -> slab.  col: reference column of this lane's staged input row (>= 0), BIAS_COL
 // (-> b_off) or ZERO_COL (padding: nothing to write)
 __device__ __forceinline__ void wr_pair(float* slab, const f32x4& a0, const f32x4& a1, const int g, const int col,
@@ -113,7 +126,7 @@ __device__ unsigned long long g_phase32[8][24];
 //                    A2 h3 0.., x2 48..79 (stays), d_h4 80.., d_hf (stays)     feature 2 + mid2 2 pairs, as 8 halves
 //                    B  as above                                               cat 8
 //                    C  x1 (stays), d_h1 128..                                 in 6
-//                    C2 h1 0.., d_h2 128..                                     mid1 2 pairs as 4 halves
+//                    C2 h1 0.., d_h2 128..                                     mid1 2 pairs as 8 quarters (halves x sample halves)
 template <bool FEAT>
 struct Lay {
   static constexpr int IMG = img_floats(FEAT);
@@ -771,12 +784,15 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
     __syncthreads();
     PT(15);
     if (FEAT) {
-      // round C: the six in-layer tiles; round C2: d_h2 over the d_h1 rows, the two mid1 tiles as four halves
+      // round C: the six in-layer tiles; round C2: d_h2 over the d_h1 rows, the two mid1 tiles as eight quarters
       if (w < 6) wg_pair(accC0, accC1, lane_rd + 128 * STG_LD, lane_rd + (32 + 16 * w) * STG_LD);
       __syncthreads();
       st_T32(stg_lane, LY::C_DH2, d_h2);
       __syncthreads();
-      if (w < 4) wg_half(accC2, lane_rd + (LY::C_DH2 + 16 * (w & 1)) * STG_LD, lane_rd + (16 * (w >> 1)) * STG_LD);
+      // all eight waves: wave w takes half (w >> 1) & 1 of tile w >> 2 over the sample half w & 1; the two partial
+      // sums of a half meet once, after the sweep
+      wg_quarter(accC2, lane_rd + (LY::C_DH2 + 16 * ((w >> 1) & 1)) * STG_LD, lane_rd + (16 * (w >> 2)) * STG_LD,
+                 16 * (w & 1));
       // the next tile's forward pass writes its hidden-feature buffer into rows this round is reading
       __syncthreads();
     } else {
@@ -825,7 +841,16 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
     } else if (!FEAT) {
       wr_pair(slab, accC0, accC1, g, 16 * (w - 6) + c, L.m1_w, H, -1);
     }
-    if (FEAT && w < 4) wr_half(slab, accC2, w & 1, g, 16 * (w >> 1) + c, L.m1_w, H, -1);
+  }
+  if (FEAT) {        // round C2's sample halves: odd waves hand their partial sums to their even partners
+    __syncthreads();                                  // (the last round's staging reads are done)
+    float* xch = stg + (w >> 1) * 256 + 4 * lane;
+    if (w & 1) *reinterpret_cast<f32x4*>(xch) = accC2;
+    __syncthreads();
+    if (!(w & 1)) {
+      accC2 += *reinterpret_cast<const f32x4*>(xch);
+      wr_half(slab, accC2, (w >> 1) & 1, g, 16 * (w >> 2) + c, L.m1_w, H, -1);
+    }
   }
   // slot registers -> LDS (per wave), then sum the 8 waves
   __syncthreads();    // the last tile's weight-gradient reads of the staging area are done
