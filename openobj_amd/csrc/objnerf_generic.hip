@@ -164,8 +164,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Gemm g) {
   gemm_tile<TM, TN, BKT>(g, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 // 128 x 128 tile on 8 waves (4 x 2 waves of 32 x 64)
+#ifndef OBJ_GEMM_BK_WIDE
+#define OBJ_GEMM_BK_WIDE 8      // measured on the hidden-256 layer GEMMs (configs[4] share): 8 -> 422 ms, 16 -> 452, 32 -> 457
+#endif
 __global__ __launch_bounds__(512) void gemm_kernel8(const Gemm g) {
-  gemm_tile<2, 4, BK, 4, 2>(g, blockIdx.x, blockIdx.y, blockIdx.z);
+  gemm_tile<2, 4, OBJ_GEMM_BK_WIDE, 4, 2>(g, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // Several independent GEMMs in ONE launch (the weight-gradient GEMMs of a small-batch step: each alone is ~260
