@@ -332,12 +332,14 @@ int objnerf_adamw_step(int32_t K, int64_t P, int64_t p_stride, float* params, co
  * feature terms were constants this iteration: the colour branch [colour_lo, feature_lo) and the feature branch
  * [feature_lo, feature_hi) of every object had .grad = None in the reference, and torch.optim.AdamW skips such
  * parameters entirely (no decay, no moment update, no step increment); both flags set = nothing is updated.
- * group_steps: device int32[3] per-group step counters (trunk + density head + B | colour | feature), zero-initialised by
- * the caller, advanced here.  has_grad still masks what a configuration never differentiates. */
+ * group_steps: device int32[2][3]: two banks of per-group step counters (trunk + density head + B | colour | feature),
+ * zero-initialised by the caller.  The call reads bank `bank` (0 / 1) and writes the advanced counters to the other
+ * one: the caller alternates `bank` from call to call, starting with 0 (one launch, no counter is read after it moved).
+ * has_grad still masks what a configuration never differentiates. */
 int objnerf_adamw_step_flags(int32_t K, int64_t P, int64_t p_stride, float* params, const float* grads, float* exp_avg,
                              float* exp_avg_sq, const uint8_t* has_grad, const int32_t* flags, int32_t* group_steps,
-                             int64_t colour_lo, int64_t feature_lo, int64_t feature_hi, float lr, float beta1, float beta2,
-                             float eps, float weight_decay, void* stream);
+                             int32_t bank, int64_t colour_lo, int64_t feature_lo, int64_t feature_hi, float lr,
+                             float beta1, float beta2, float eps, float weight_decay, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Helper functions of the reference's call surface that a caller may use outside the fused iteration

@@ -144,8 +144,8 @@ SIGNATURES = {
                                      C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float,
                                      C.c_float, C.c_float, C.c_void_p]),
     "objnerf_adamw_step_flags": (C.c_int, [C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_float,
-                                           C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int64,
+                                           C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
 }
 
 _lib: Optional[C.CDLL] = None

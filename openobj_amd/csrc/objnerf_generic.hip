@@ -432,7 +432,7 @@ struct RedItem {
   long scm, bsc, bsrs;
 };
 struct RedGroup {
-  static constexpr int MAXG = GemmGroup::MAXG;
+  static constexpr int MAXG = 16;        // (>= the GEMM group's capacity + head sums + d B: a step's reductions in ONE launch)
   int count;
   int beg[MAXG + 1];      // first block of each item
   RedItem it[MAXG];
@@ -471,6 +471,16 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(const RedGroup gr) {
 }
 static int red_blocks(const RedItem& r) {
   return (int)(((long)r.batch * ((long)r.M * r.N + (r.rs_part ? r.M : 0)) + 255) / 256);
+}
+static void red_append(RedGroup& rg, const RedItem& r) {
+  if (rg.count == 0) rg.beg[0] = 0;
+  rg.it[rg.count] = r;
+  rg.beg[rg.count + 1] = rg.beg[rg.count] + red_blocks(r);
+  ++rg.count;
+}
+static void launch_reductions(hipStream_t st, RedGroup& rg) {
+  if (rg.count) hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)rg.beg[rg.count]), dim3(256), 0, st, rg);
+  rg.count = 0;
 }
 // bump allocator over the caller's workspace region for the partial slabs of ONE train_step (the weight-gradient GEMMs
 // of a step run side by side, so each has its own slab); exhausted or absent -> atomics
@@ -568,11 +578,7 @@ static void wgrad(hipStream_t st, int batch, int M, int N, long n, const float* 
     r.part = part; r.rs_part = rs_part; r.C = C; r.rowsum = bias_grad;
     r.M = M; r.N = N; r.sk = skd; r.batch = batch; r.scm = scm; r.bsc = bsc; r.bsrs = bsc;
     if (t_red_group && t_red_group->count < RedGroup::MAXG) {
-      RedGroup& rg = *t_red_group;
-      if (rg.count == 0) rg.beg[0] = 0;
-      rg.it[rg.count] = r;
-      rg.beg[rg.count + 1] = rg.beg[rg.count] + red_blocks(r);
-      ++rg.count;
+      red_append(*t_red_group, r);
     } else {
       RedGroup rg;
       rg.count = 1; rg.beg[0] = 0; rg.beg[1] = red_blocks(r); rg.it[0] = r;
@@ -1108,13 +1114,9 @@ static void flush_group(hipStream_t st, GemmGroup& gr) {
   }
   hipLaunchKernelGGL(gemm_group_kernel, dim3((mx + 1) / 2, (my + 1) / 2, gr.zbeg[gr.count]), dim3(512), 0, st, gr);
   gr.count = 0;
-  if (t_red_group) {                     // the ordered reductions of the group's split-K GEMMs, one launch
-    RedGroup& rg = *t_red_group;
-    t_red_group = nullptr;
-    if (rg.count) hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)rg.beg[rg.count]), dim3(256), 0, st, rg);
-    rg.count = 0;
-  }
+  t_red_group = nullptr;                 // (the caller launches the collected reductions: launch_reductions)
 }
+
 
 // heads forward: alpha = 10 (h4 . wa + ba), color = sigmoid(hc Woc^T + boc)        (model.py:81-96)
 // 16 lanes per sample row (float4 each, coalesced), the four dot products meet by DPP row sums.
@@ -1549,6 +1551,8 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
   WS w = carve((char*)a->workspace, H, C, n, (long)a->R, K, feat);
   if (a->workspace_bytes < w.bytes) return OBJNERF_EINVAL;
   t_parts = w.parts; t_parts_cap = w.parts_floats; t_parts_off = 0;
+  RedGroup step_red;                 // small-batch path: every ordered reduction of the step in ONE launch, after the join
+  step_red.count = 0;
   struct PartsScope { ~PartsScope() { t_parts = nullptr; t_parts_cap = t_parts_off = 0; t_red_group = nullptr; } } parts_scope;
   if (!a->pts) {
     const long total = (long)K * n;
@@ -1714,7 +1718,8 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
       a1.part = pW; a1.rs_part = rW; a1.C = G + off[12]; a1.rowsum = G + off[13];
       a1.M = 3; a1.N = H; a1.sk = hb; a1.batch = K; a1.scm = H; a1.bsc = ps; a1.bsrs = ps;
       rg.beg[1] = red_blocks(a0); rg.beg[2] = rg.beg[1] + red_blocks(a1);
-      hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)rg.beg[2]), dim3(256), 0, ss, rg);
+      if (small_rt) { red_append(step_red, a0); red_append(step_red, a1); }
+      else hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)rg.beg[2]), dim3(256), 0, ss, rg);
     }
   }
   // d_emb needs no zero fill: the first dgrad into each column block overwrites (x2: feature layer if
@@ -1768,9 +1773,7 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
     GemmGroup group;
     group.count = 0;
     t_group = &group;
-    RedGroup red_group;
-    red_group.count = 0;
-    t_red_group = &red_group;
+    t_red_group = &step_red;
     if (feat) {
       wgrad(side(), K, H, H, n, w.d_hf, 1, H, nH, w.h4, H, 1, nH, G + off[14], H + E2, ps, G + off[15]);
       wgrad(side(), K, H, E2, n, w.d_hf, 1, H, nH, w.emb + E1, EM, 1, n * EM, G + off[14] + H, H + E2, ps);
@@ -1825,7 +1828,8 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
     r.part = pe_part; r.rs_part = nullptr; r.C = G + off[18]; r.rowsum = nullptr;
     r.M = 1; r.N = 63; r.sk = pg; r.batch = K; r.scm = 63; r.bsc = ps; r.bsrs = 0;
     rg.beg[1] = red_blocks(r);
-    hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)rg.beg[1]), dim3(256), 0, st, rg);
+    if (small_rt) red_append(step_red, r);
+    else hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)rg.beg[1]), dim3(256), 0, st, rg);
   } else {
     hipLaunchKernelGGL(copy_cols_kernel, dim3((unsigned)((K * 63 + 255) / 256)), dim3(256), 0, st, (long)K, 63, w.dBpe, 63L,
                        G + off[18], ps);
@@ -1834,6 +1838,7 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
     (void)hipEventRecord(sd.done_all[i], sd.all[i]);
     (void)hipStreamWaitEvent(st, sd.done_all[i], 0);
   }
+  launch_reductions(st, step_red);
   if (hipGetLastError() != hipSuccess) return OBJNERF_ELAUNCH;
   return OBJNERF_OK;
 }

@@ -417,17 +417,21 @@ __global__ void adamw_kernel(long P, long p_stride, float* params, const float* 
 // Three groups with their own step counters (device int32[3]): 0 = trunk + density head + B, 1 = colour branch
 // [lo1, lo2), 2 = feature branch [lo2, hi2).
 __global__ void adamw_dyn_kernel(long P, long p_stride, float* params, const float* grads, float* m, float* v,
-                                 const uint8_t* has_grad, const int* flags, const int* steps, long lo1, long lo2, long hi2,
-                                 double lr, double b1, double b2, float eps, double wd) {
+                                 const uint8_t* has_grad, const int* flags, int* steps, int bank, long lo1, long lo2,
+                                 long hi2, double lr, double b1, double b2, float eps, double wd) {
+  // step counters: two banks of three; this call READS bank `bank` and its first block WRITES the advanced counters to
+  // the other one -- no second launch, and no block can see a counter of its own call already advanced
   __shared__ float s_step_size[3], s_bc2_sqrt[3];
   __shared__ int s_active[3];
   if (threadIdx.x < 3) {
     const int g = threadIdx.x;
     const bool f0 = flags[0] != 0, f1 = flags[1] != 0;
     s_active[g] = g == 0 ? !(f0 && f1) : !f0;
-    const double st = (double)(steps[g] + 1);
+    const int old = steps[3 * bank + g];
+    const double st = (double)(old + 1);
     s_step_size[g] = (float)(lr / (1.0 - pow(b1, st)));
     s_bc2_sqrt[g] = (float)sqrt(1.0 - pow(b2, st));
+    if (blockIdx.x == 0 && blockIdx.y == 0) steps[3 * (1 - bank) + g] = old + (s_active[g] ? 1 : 0);
   }
   __syncthreads();
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -446,11 +450,6 @@ __global__ void adamw_dyn_kernel(long P, long p_stride, float* params, const flo
   params[idx] = p;
   m[idx] = mn;
   v[idx] = vn;
-}
-__global__ void adamw_bump_kernel(const int* flags, int* steps) {
-  const bool f0 = flags[0] != 0, f1 = flags[1] != 0;
-  if (!(f0 && f1)) steps[0] += 1;
-  if (!f0) { steps[1] += 1; steps[2] += 1; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -869,17 +868,17 @@ int objnerf_adamw_step(int32_t K, int64_t P, int64_t p_stride, float* params, co
 
 int objnerf_adamw_step_flags(int32_t K, int64_t P, int64_t p_stride, float* params, const float* grads, float* exp_avg,
                              float* exp_avg_sq, const uint8_t* has_grad, const int32_t* flags, int32_t* group_steps,
-                             int64_t colour_lo, int64_t feature_lo, int64_t feature_hi, float lr, float beta1, float beta2,
-                             float eps, float weight_decay, void* stream) {
+                             int32_t bank, int64_t colour_lo, int64_t feature_lo, int64_t feature_hi, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, void* stream) {
   CLEAR_STALE();
   if (K <= 0 || P <= 0 || p_stride < P || !params || !grads || !exp_avg || !exp_avg_sq || !flags || !group_steps ||
+      (bank != 0 && bank != 1) ||
       colour_lo > feature_lo || feature_lo > feature_hi || feature_hi > P)
     return OBJNERF_EINVAL;
   dim3 grid((unsigned)((P + 255) / 256), (unsigned)K);
   hipLaunchKernelGGL(adamw_dyn_kernel, grid, dim3(256), 0, (hipStream_t)stream, (long)P, (long)p_stride, params, grads,
-                     exp_avg, exp_avg_sq, has_grad, flags, group_steps, (long)colour_lo, (long)feature_lo, (long)feature_hi,
-                     (double)lr, (double)beta1, (double)beta2, eps, (double)weight_decay);
-  hipLaunchKernelGGL(adamw_bump_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, flags, group_steps);
+                     exp_avg, exp_avg_sq, has_grad, flags, group_steps, (int)bank, (long)colour_lo, (long)feature_lo,
+                     (long)feature_hi, (double)lr, (double)beta1, (double)beta2, eps, (double)weight_decay);
   CHECK_LAUNCH();
   return OBJNERF_OK;
 }

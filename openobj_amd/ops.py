@@ -427,17 +427,21 @@ def adamw_step(arena: ParamArena, grads: torch.Tensor, exp_avg: torch.Tensor, ex
 
 
 def adamw_step_flags(arena: ParamArena, grads: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor,
-                     has_grad: Optional[torch.Tensor], flags: torch.Tensor, group_steps: torch.Tensor, lr: float,
-                     weight_decay: float, beta1=0.9, beta2=0.999, eps=1e-8, params: Optional[torch.Tensor] = None) -> None:
+                     has_grad: Optional[torch.Tensor], flags: torch.Tensor, group_steps: torch.Tensor, bank: int,
+                     lr: float, weight_decay: float, beta1=0.9, beta2=0.999, eps=1e-8,
+                     params: Optional[torch.Tensor] = None) -> None:
     """AdamW with the iteration's early-return flags deciding on the device which tensor groups received a gradient
-    (objnerf_adamw_step_flags); group_steps: int32[3] device counters owned by the caller."""
+    (objnerf_adamw_step_flags); group_steps: int32[2, 3] device counters owned by the caller, `bank` the bank to read
+    (the other one receives the advanced counters: alternate it from call to call)."""
     p = arena.params if params is None else params
     flags = _req(flags, torch.int32, "flags")
     group_steps = _req(group_steps, torch.int32, "group_steps")
+    if group_steps.numel() != 6 or bank not in (0, 1):
+        raise ObjnerfError("adamw_step_flags: group_steps must be int32[2, 3], bank 0 or 1")
     o = arena.offsets
     check(lib().objnerf_adamw_step_flags(arena.K, arena.P, arena.p_stride, _ptr(p), _ptr(grads), _ptr(exp_avg),
-                                         _ptr(exp_avg_sq), _ptr(has_grad), _ptr(flags), _ptr(group_steps), int(o[10]),
-                                         int(o[14]), int(o[18]), lr, beta1, beta2, eps, weight_decay, _stream()),
+                                         _ptr(exp_avg_sq), _ptr(has_grad), _ptr(flags), _ptr(group_steps), int(bank),
+                                         int(o[10]), int(o[14]), int(o[18]), lr, beta1, beta2, eps, weight_decay, _stream()),
           "objnerf_adamw_step_flags")
 
 

@@ -19,7 +19,9 @@ class ArenaAdamW:
         self.exp_avg_sq = torch.zeros_like(self.arena.params)
         self.step_count = 0
         # per-group step counters of the flag-aware step (trunk + density head + B | colour branch | feature branch)
-        self.group_steps = torch.zeros(3, dtype=torch.int32, device=self.arena.params.device)
+        # (two banks: a step reads one and writes the advanced counters to the other, objnerf_adamw_step_flags)
+        self._banks = torch.zeros(2, 3, dtype=torch.int32, device=self.arena.params.device)
+        self._bank = 0
 
     def step(self, grads: torch.Tensor, has_grad: Optional[torch.Tensor] = None, flags: Optional[torch.Tensor] = None):
         """flags: the iteration's early-return flag pair (device int32[2]).  With it, tensors whose loss terms were
@@ -27,12 +29,18 @@ class ArenaAdamW:
         update, their own step count) -- decided on the device, no host sync.  Without it every tensor of `has_grad`
         is stepped with one global step count."""
         if flags is not None:
-            ops.adamw_step_flags(self.arena, grads, self.exp_avg, self.exp_avg_sq, has_grad, flags, self.group_steps,
+            ops.adamw_step_flags(self.arena, grads, self.exp_avg, self.exp_avg_sq, has_grad, flags, self._banks, self._bank,
                                  self.lr, self.weight_decay, self.betas[0], self.betas[1], self.eps)
+            self._bank ^= 1
             return
         self.step_count += 1
         ops.adamw_step(self.arena, grads, self.exp_avg, self.exp_avg_sq, has_grad, self.step_count, self.lr,
                        self.weight_decay, self.betas[0], self.betas[1], self.eps)
+
+    @property
+    def group_steps(self) -> torch.Tensor:
+        """int32[3]: steps taken so far by (trunk + density head + B | colour branch | feature branch)."""
+        return self._banks[self._bank]
 
     def zero_grad(self, set_to_none=True):
         pass        # gradients are written (not accumulated) by objnerf_train_step
