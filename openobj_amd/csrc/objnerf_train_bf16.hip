@@ -43,11 +43,8 @@ constexpr int T_FL = B_FL + 32 * RS_CL;       // feature layer, transposed image
 constexpr int B_SMALL = T_FL + 80 * RST;      // fp32: bm1[32] bm2[32] wa[32] woc[96] hb[4] peb[99]
 constexpr int S_BM1 = 0, S_BM2 = 32, S_WA = 64, S_WOC = 96, S_HB = 192, S_PEB = 196;
 constexpr int B_SM = B_SMALL + 1280;          // s_alpha | s_col[3]  (fp32, 2 KB)
-constexpr int TB_LD = 130;
-constexpr int TB_ROWS = 35;
-constexpr int B_TBUF = B_SM + 2048;           // fp32 [35][130]: d proj rows 0..20 (..31 zero), t rows 32..34
 constexpr int STG_PITCH = 288;                // bf16 staging row: 128 samples + pad
-constexpr int B_STG = (B_TBUF + TB_ROWS * TB_LD * 4 + 15) / 16 * 16;
+constexpr int B_STG = (B_SM + 2048 + 15) / 16 * 16;
 constexpr int STG_ROWS_B = 192;
 // feature branch, fp32: s_w [128] | gfh [16][32] | gof [32]  (live from the compositing into phase A)
 constexpr int B_FEAT = B_STG + STG_ROWS_B * STG_PITCH;
