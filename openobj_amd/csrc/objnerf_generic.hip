@@ -409,6 +409,9 @@ static thread_local const float* t_biasrow = nullptr;
 static thread_local long t_bsbr = 0;
 
 // ---- deterministic split-K: partial-tile slabs + an ordered reduction (instead of float atomics)
+#ifndef OBJ_WGRAD_TARGET
+#define OBJ_WGRAD_TARGET 512         // 64 x 64 output tiles x slices a weight-gradient GEMM should at least have
+#endif
 #ifndef OBJ_WGRAD_MAXSLICES
 #define OBJ_WGRAD_MAXSLICES 128      // (32 was measured: the background step in bf16 mode 0.92 -> 1.4 ms, too few workgroups)
 #endif
@@ -417,7 +420,7 @@ static thread_local long t_bsbr = 0;
 static int wgrad_slices(int batch, int M, int N, long n) {
   const long tiles = (long)batch * ((M + 63) / 64) * ((N + 63) / 64);
   long per = 512;
-  while (per > OBJ_WGRAD_MINPER && tiles * ((n + per - 1) / per) < 512) per >>= 1;
+  while (per > OBJ_WGRAD_MINPER && tiles * ((n + per - 1) / per) < OBJ_WGRAD_TARGET) per >>= 1;
   int sk = (int)((n + per - 1) / per);
   if (sk < 2) sk = 2;
   if (sk > 256) sk = 256;
@@ -439,38 +442,48 @@ struct RedGroup {
 };
 // one thread per output (m, n) of a batch entry (+ one per row sum): adds the sk slices in slice order
 __global__ __launch_bounds__(256) void reduce_parts_kernel(const RedGroup gr) {
+  // a block = 64 consecutive outputs x 4 waves; wave w adds slices [w sk / 4, (w + 1) sk / 4) of its outputs in order
+  // (coalesced: lanes along the outputs; 16 loads in flight), the four quarter sums meet in LDS and are added in wave
+  // order -- a fixed association, so the result is bit-reproducible
+  __shared__ float quarter[4][64];
   int i = 0;
   while (i + 1 < gr.count && (int)blockIdx.x >= gr.beg[i + 1]) ++i;
   const RedItem& r = gr.it[i];
   const long per = (long)r.M * r.N, nrs = r.rs_part ? r.M : 0;
-  const long e = ((long)blockIdx.x - gr.beg[i]) * 256 + threadIdx.x;
-  if (e >= (long)r.batch * (per + nrs)) return;
-  const long z = e / (per + nrs), q = e - z * (per + nrs);
-  // slices are added in slice order; 16 loads are in flight at a time (a plain loop is one HBM latency per slice)
-  auto ordered_sum = [&](const float* p, const long stride) {
-    float v = 0.f;
-    int s = 0;
-    for (; s + 16 <= r.sk; s += 16) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long e = ((long)blockIdx.x - gr.beg[i]) * 64 + lane;
+  const bool live = e < (long)r.batch * (per + nrs);
+  const long z = live ? e / (per + nrs) : 0, q = live ? e - z * (per + nrs) : 0;
+  const bool is_c = q < per;
+  const float* p = is_c ? r.part + z * r.sk * per + q : r.rs_part + z * r.sk * r.M + (q - per);
+  const long stride = is_c ? per : r.M;
+  const int s0 = (int)((long)r.sk * w / 4), s1 = (int)((long)r.sk * (w + 1) / 4);
+  float v = 0.f;
+  if (live) {
+    int s = s0;
+    for (; s + 16 <= s1; s += 16) {
       float t[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) t[j] = p[(s + j) * stride];
 #pragma unroll
       for (int j = 0; j < 16; ++j) v += t[j];
     }
-    for (; s < r.sk; ++s) v += p[s * stride];
-    return v;
-  };
-  if (q < per) {
-    const float v = ordered_sum(r.part + z * r.sk * per + q, per);
-    const long m = q / r.N, n = q - m * r.N;
-    r.C[z * r.bsc + m * r.scm + n] = v;
-  } else {
-    const long m = q - per;
-    r.rowsum[z * r.bsrs + m] = ordered_sum(r.rs_part + z * r.sk * r.M + m, r.M);
+    for (; s < s1; ++s) v += p[s * stride];
+  }
+  quarter[w][lane] = v;
+  __syncthreads();
+  if (w == 0 && live) {
+    const float sum = ((quarter[0][lane] + quarter[1][lane]) + quarter[2][lane]) + quarter[3][lane];
+    if (is_c) {
+      const long m = q / r.N, n = q - m * r.N;
+      r.C[z * r.bsc + m * r.scm + n] = sum;
+    } else {
+      r.rowsum[z * r.bsrs + (q - per)] = sum;
+    }
   }
 }
 static int red_blocks(const RedItem& r) {
-  return (int)(((long)r.batch * ((long)r.M * r.N + (r.rs_part ? r.M : 0)) + 255) / 256);
+  return (int)(((long)r.batch * ((long)r.M * r.N + (r.rs_part ? r.M : 0)) + 63) / 64);
 }
 static void red_append(RedGroup& rg, const RedItem& r) {
   if (rg.count == 0) rg.beg[0] = 0;
