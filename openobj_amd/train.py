@@ -45,6 +45,10 @@ class BackgroundLoop:
         """n(label == 1), n(label != 2) of this rank's ray slice (int32 [1,2], device)."""
         return ops.label_counts(batch["labels"])[0]
 
+    def local_counts_flags(self, batch):
+        """(counts, early-return flags) of the rays at hand (objnerf_label_counts: both from one launch)."""
+        return ops.label_counts(batch["labels"])
+
     def begin(self, batch: Dict[str, torch.Tensor], counts: torch.Tensor, flags: torch.Tensor):
         """Launch the step with the GLOBAL mask counts / flags and start the gradient all-reduce; returns its handle."""
         ws = self._workspace(batch)
@@ -61,9 +65,10 @@ class BackgroundLoop:
 
     def step(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
         """batch: THIS rank's slice of the background rays, tensors shaped [1, R_local, ...]."""
-        counts = self.local_counts(batch)
-        odist.allreduce_sum_(counts, self.group)                  # global n(label==1), n(label!=2)
-        flags = ((counts.reshape(-1, 2) == 0).any(dim=0)).to(torch.int32)
+        counts, flags = self.local_counts_flags(batch)
+        if odist._active(self.group):
+            odist.allreduce_sum_(counts, self.group)              # global n(label==1), n(label!=2)
+            flags = ((counts.reshape(-1, 2) == 0).any(dim=0)).to(torch.int32)
         return self.finish(self.begin(batch, counts, flags))
 
 
@@ -89,16 +94,18 @@ class ShardedIteration:
         obj_flags = bg_counts = None
         if obj_batch is not None and self.obj_loop is not None and sharded:
             obj_flags = ops.label_counts(obj_batch["labels"])[1]
+        bg_flags = None
         if bg_batch is not None and self.bg_loop is not None:
-            bg_counts = self.bg_loop.local_counts(bg_batch)
+            if sharded:
+                bg_counts = self.bg_loop.local_counts(bg_batch)
+            else:                                   # one object, one rank: the kernel's own flag pair is the batch's
+                bg_counts, bg_flags = self.bg_loop.local_counts_flags(bg_batch)
         gflags = None
         work = None
         if sharded:
             pre = odist.pack_pre(obj_flags, bg_counts, dev)
             odist.allreduce_sum_(pre, self.group)                  # collective 1
             gflags, bg_counts, bg_flags = odist.unpack_pre(pre)
-        elif bg_counts is not None:
-            bg_flags = (bg_counts.reshape(-1, 2) == 0).any(dim=0).to(torch.int32)
         if bg_batch is not None and self.bg_loop is not None:
             work = self.bg_loop.begin(bg_batch, bg_counts, bg_flags)      # collective 2 starts here
         obj_terms = bg_terms = None
