@@ -208,6 +208,9 @@ class IncrementalMapper:
             # as [n_iter, K, npo, ...] so that each iteration's batch is a contiguous view (no per-iteration copies)
             pool = {k: v.reshape(v.shape[0], cfg.n_iter_per_frame, npo, *v.shape[2:]).transpose(0, 1).contiguous()
                     for k, v in pool.items()}
+        if bg_pool is not None:                   # the same for the background rays ([1, n_iter * npo_bg, ...] -> views)
+            bg_pool = {k: v.reshape(v.shape[0], cfg.n_iter_per_frame, npo_bg, *v.shape[2:]).transpose(0, 1).contiguous()
+                       for k, v in bg_pool.items()}
         sharded = odist._active(self.group)
         # The object stack and the background network are independent chains (own parameters, optimiser state and
         # batches).  On one GPU the background steps run on a second stream beside the fused object kernel; under
@@ -222,8 +225,7 @@ class IncrementalMapper:
         sharded_it = otrain.ShardedIteration(self.loop if pool is not None else None, self.bg_loop, self.group) if sharded else None
         for it in range(cfg.n_iter_per_frame):
             batch = {k: v[it] for k, v in pool.items()} if pool is not None else None
-            bs = slice(it * npo_bg, (it + 1) * npo_bg)
-            bg_slice = (lambda: {k: v[:, bs].contiguous() for k, v in bg_pool.items()}) if bg_pool is not None else None
+            bg_slice = (lambda: {k: v[it] for k, v in bg_pool.items()}) if bg_pool is not None else None
             if sharded:
                 ot, bt = sharded_it.step(batch, bg_slice() if bg_slice is not None else None)
                 if ot is not None:
