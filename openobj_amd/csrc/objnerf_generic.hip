@@ -167,8 +167,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Gemm g) {
 #ifndef OBJ_GEMM_BK_WIDE
 #define OBJ_GEMM_BK_WIDE 8      // measured on the hidden-256 layer GEMMs (configs[4] share): 8 -> 422 ms, 16 -> 452, 32 -> 457
 #endif
+#ifndef OBJ_GEMM_WIDE_TM
+#define OBJ_GEMM_WIDE_TM 2      // row tiles per wave of the wide kernel: workgroup tile (64 TM) x 128
+#endif
 __global__ __launch_bounds__(512) void gemm_kernel8(const Gemm g) {
-  gemm_tile<2, 4, OBJ_GEMM_BK_WIDE, 4, 2>(g, blockIdx.x, blockIdx.y, blockIdx.z);
+  gemm_tile<OBJ_GEMM_WIDE_TM, 4, OBJ_GEMM_BK_WIDE, 4, 2>(g, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // Several independent GEMMs in ONE launch (the weight-gradient GEMMs of a small-batch step: each alone is ~260
@@ -563,7 +566,7 @@ static void gemm(hipStream_t st, int batch, int M, int N, int Kd, const float* A
                                       // same tile on 4 waves with 64 accumulator registers each).  Up to N = 128 the
                                       // 64 x 64 tiles win (measured, hidden 128): 4x the workgroups, 16 instead
                                       // of 64 accumulator registers -> occupancy hides the operand latency
-    dim3 grid((N + 127) / 128, (M + 127) / 128, nz);
+    dim3 grid((N + 127) / 128, (M + 64 * OBJ_GEMM_WIDE_TM - 1) / (64 * OBJ_GEMM_WIDE_TM), nz);
     hipLaunchKernelGGL(gemm_kernel8, grid, dim3(512), 0, st, g);
   } else {
     dim3 grid((N + 63) / 64, (M + 63) / 64, nz);
