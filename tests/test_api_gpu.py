@@ -432,3 +432,40 @@ def test_training_step_is_bit_reproducible(dev, shape):
     assert bool(torch.isfinite(g0).all())
     for g, l in outs[1:]:
         assert torch.equal(g[:, :arena.P][:, mask], g0) and torch.equal(l, outs[0][1])
+
+
+def test_round2_entry_points_reject_bad_arguments(dev):
+    """EINVAL (-22) / ENOTSUP (-95) instead of undefined behaviour: the entry points added in ABI 3."""
+    import ctypes as C
+    from openobj_amd import _lib
+    lib = _lib.lib()
+    x = torch.zeros(64, device=dev)
+    p = x.data_ptr()
+    assert lib.objnerf_context_create(None) == -22 and lib.objnerf_context_destroy(None) == 0
+    assert lib.objnerf_render(0, 4, 1, p, p, p, None) == -22 and lib.objnerf_render(4, 4, 1, None, p, p, None) == -22
+    # AdamW with flags: the bank must be 0 or 1, the group bounds ordered
+    assert lib.objnerf_adamw_step_flags(1, 16, 16, p, p, p, p, None, p, p, 2, 4, 8, 12, 1e-3, 0.9, 0.999, 1e-8, 0.0, None) == -22
+    assert lib.objnerf_adamw_step_flags(1, 16, 16, p, p, p, p, None, p, p, 0, 8, 4, 12, 1e-3, 0.9, 0.999, 1e-8, 0.0, None) == -22
+    # sampler: injected draws come all together; seeded keyframes need kf_meta; points or origins + directions
+    a = _lib.SampleArgs()
+    a.F, a.W, a.H, a.n_frames, a.n_px, a.n_cam2surf, a.n_bins = 2, 4, 4, 2, 2, 1, 3
+    for f in ("rgbs", "depth", "t_wc", "bbox", "rays_dir_cache", "out_rgb", "out_depth", "out_valid", "out_labels", "out_z",
+              "out_pts", "max_depth_ws", "kf_ids"):
+        setattr(a, f, p)
+    a.u_w = p                                                    # only one of the four injected arrays
+    assert lib.objnerf_sample_rays(C.byref(a), None) == -22
+    a.u_w = None
+    a.kf_ids = None                                              # seeded keyframes without kf_meta
+    assert lib.objnerf_sample_rays(C.byref(a), None) == -22
+    a.kf_ids = p
+    a.out_pts = None                                             # neither points nor origins / directions
+    assert lib.objnerf_sample_rays(C.byref(a), None) == -22
+    a.out_origins = p                                            # origins without directions
+    assert lib.objnerf_sample_rays(C.byref(a), None) == -22
+    # training step: fp16 and bf16 together, pts and origins both missing
+    arena = ops.ParamArena(1, ops.NetShape(), dev)
+    t = _lib.TrainArgs()
+    net = arena.net.c()
+    assert lib.objnerf_train_step(C.byref(net), C.byref(t), None) == -22
+    with pytest.raises(ValueError):
+        ops.precision_bits("int8")
