@@ -250,8 +250,9 @@ __device__ __forceinline__ void lds_tr16_wait(uint2 (&lo)[N], uint2 (&hi)[N]) {
   else asm volatile("s_waitcnt lgkmcnt(0)" : OBJ_T2(0), OBJ_T2(1), OBJ_T2(2), OBJ_T2(3)::"memory");
 #undef OBJ_T2
 }
+// (the 8-wave tile is held to 128 registers -- two workgroups per CU: at 130 the fp16 forward variant lost one)
 template <int TM, int TN, typename OT, int BKB, int WM = 2, int WN = 2, bool AKM = false, bool BKM = false>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(const Gemm g) {
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 4 : 1) void gemm_bf16_kernel(const Gemm g) {
   constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN, LDK = BKB + 8, NTH = 64 * WM * WN;
   constexpr int PA = BM + 8, PB = BN + 8;                 // k-major row pitches (elements; 8-byte aligned rows)
   typedef typename Op16<OT>::V OV;
@@ -379,28 +380,43 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(const Gemm g) {
     if (g.rs_part) g.rs_part[(z * sk + slice) * g.M + m0 + tid] = rs * inv_scale;
     else atomicAdd(g.rowsum + z * g.bsrs + m0 + tid, rs * inv_scale);
   }
+  // Epilogue through LDS: the accumulator layout gives a lane ONE column of four rows, i.e. 64-byte runs per output row
+  // (and the same for the mask / accumulate reads) -- each wave turns a 16-row strip of its tile around in its own LDS
+  // patch so that the lanes run ALONG a row: 256-byte (128-byte for the 64-wide tile) coalesced rows for every global
+  // access of the epilogue.
+  constexpr int EC = 16 * TN, EP = EC + 4, RPI = 64 / EC;            // strip columns, pitch, rows per pass
+  __shared__ float Ep[WM * WN][16][EP];
+  const int ecol = lane % EC, erow0 = lane / EC;
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int i = 0; i < TM; ++i) {
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + 16 * TM * wm + 16 * i + 4 * gg + r, n = n0 + 16 * TN * wn + 16 * j + c;
-        if (m < g.M && n < g.N) {
-          float* cp = C + m * g.scm + n * g.scn;
-          float v = acc[i][j][r] * inv_scale;
-          if (sk > 1) {
-            if (g.part) g.part[((z * sk + slice) * g.M + m) * g.N + n] = v;
-            else atomicAdd(cp, v);
-            continue;
-          }
-          if (g.accumulate) v += *cp;
-          if (g.bias) v += g.bias[z * g.bsbias + n] * (g.biasrow ? g.biasrow[z * g.bsbr + m] : 1.0f);
-          if (g.relu) v = fmaxf(v, 0.f);
-          if (g.mask) v = g.mask[z * g.bsm + m * g.smm + n * g.smn] > 0.f ? v : 0.f;
-          *cp = v;
+      for (int r = 0; r < 4; ++r) Ep[w][4 * gg + r][16 * j + c] = acc[i][j][r] * inv_scale;
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int n = n0 + EC * wn + ecol;
+#pragma unroll
+    for (int rr = 0; rr < 16; rr += RPI) {
+      const int m = m0 + 16 * TM * wm + 16 * i + rr + erow0;
+      float v = Ep[w][rr + erow0][ecol];
+      if (m < g.M && n < g.N) {
+        float* cp = C + m * g.scm + n * g.scn;
+        if (sk > 1) {
+          if (g.part) g.part[((z * sk + slice) * g.M + m) * g.N + n] = v;
+          else atomicAdd(cp, v);
+          continue;
         }
+        if (g.accumulate) v += *cp;
+        if (g.bias) v += g.bias[z * g.bsbias + n] * (g.biasrow ? g.biasrow[z * g.bsbr + m] : 1.0f);
+        if (g.relu) v = fmaxf(v, 0.f);
+        if (g.mask) v = g.mask[z * g.bsm + m * g.smm + n * g.smn] > 0.f ? v : 0.f;
+        *cp = v;
       }
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+  }
 }
 
 // selected for the duration of one train_step call (single host thread per device)
