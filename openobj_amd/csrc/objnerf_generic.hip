@@ -1132,7 +1132,11 @@ static int small_batch_rt(int H, long n, int K) {
   // up to four rounds of 80-sample workgroups the one-launch kernels still win (76 800 samples: 1.02 vs 1.07 ms per
   // step, 38 400: 0.53 vs 0.65); beyond that the GEMM path runs near the MFMA peak
   // (fp32 and bf16 modes: the one-launch kernels exist for both; fp16 keeps the GEMM path from two rounds on)
+#ifdef OBJ_NO_SMALL_BF16        // diagnostic: the bf16 mode on the GEMM path from two rounds on (tools/bg_ab.py)
+  if (t_bf16_operands == 0 && (long)K * ((n + 79) / 80) <= 1024) return 5;
+#else
   if (t_bf16_operands != 2 && (long)K * ((n + 79) / 80) <= 1024) return 5;
+#endif
   return 0;
 }
 
