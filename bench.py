@@ -181,6 +181,8 @@ def main():
                          "operands rounded to bf16, fp32 accumulation / master weights / compositing / AdamW")
     ap.add_argument("--no-bf16-line", dest="bf16_line", action="store_false",
                     help="do not also time the bf16 mode (reported as the `bf16_mode` object of the fp32 line)")
+    ap.add_argument("--no-overlap", dest="overlap", action="store_false",
+                    help="diagnostic: background chain on the object kernel's stream instead of beside it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-psnr", action="store_true")
     ap.add_argument("--psnr-seeds", type=int, default=128)
@@ -259,7 +261,7 @@ def main():
         for i in range(2):
             b = synthetic.random_batch(1, c.n_per_optim_bg, n1, n2, seed=777 + i, feat_dim=512 if feat else 0)
             bg_batches.append({k: torch.from_numpy(b[k][:, lo:hi]).contiguous().to(dev) for k in keys})
-    iteration = otrain.ShardedIteration(obj_loop, bg_loop)
+    iteration = otrain.ShardedIteration(obj_loop, bg_loop, overlap=args.overlap, resident=True)   # (batches made above)
 
     def step(i, use_bf16):
         obj_loop.bf16 = use_bf16

@@ -30,6 +30,8 @@ struct Gemm {
   float* part; float* rs_part;   // split-K with these set: slice s of batch z STORES its partial tile at part[((z sk + s) M + m)
                                  // N + n] (row sums: rs_part[(z sk + s) M + m]) and reduce_parts_kernel adds the slices in
                                  // order -- bit-reproducible; NULL: float atomics into C / rowsum
+  int vec4;        // AFULL panel loads as dwordx4 (rows 16-byte aligned, Kd % 4 == 0)
+  const void* Bp;  // AFULL: B packed as 16-bit MFMA operands, [z][k / 32][n / 16][lane][8] (pack_b_kernel)
   float a_scale;   // 16-bit operand kernels: A is multiplied by this power of two before it is rounded and the result
                    // divided by it (keeps back-propagated gradients out of fp16's subnormal range); 1 elsewhere
 };
@@ -204,6 +206,15 @@ __global__ __launch_bounds__(512) void gemm_group_kernel(const GemmGroup gr) {
 #ifndef OBJ_G16_BK
 #define OBJ_G16_BK 32
 #endif
+#ifndef OBJ_G16_AFULL
+#define OBJ_G16_AFULL 1
+#endif
+#ifndef OBJ_G16_AFULL_NARROW
+#define OBJ_G16_AFULL_NARROW 0      // (the narrow input-gradient GEMMs, N = 87 / 42: measured no gain)
+#endif
+#ifndef OBJ_G16_XCD
+#define OBJ_G16_XCD 1
+#endif
 #ifndef OBJ_G16_BK_WIDE
 #define OBJ_G16_BK_WIDE 32
 #endif
@@ -251,18 +262,46 @@ __device__ __forceinline__ void lds_tr16_wait(uint2 (&lo)[N], uint2 (&hi)[N]) {
 #undef OBJ_T2
 }
 // (the 8-wave tile is held to 128 registers -- two workgroups per CU: at 130 the fp16 forward variant lost one)
-template <int TM, int TN, typename OT, int BKB, int WM = 2, int WN = 2, bool AKM = false, bool BKM = false>
+//
+// AFULL (layer GEMMs over the sample axis: M = 10^6 rows, contraction <= 256, A rows k-contiguous): the workgroup's A
+// panel -- BM rows x the WHOLE contraction -- is fetched with one burst of loads before the k-loop (64 KB in flight
+// per workgroup) and stays in LDS.  B -- the layer's weights -- is NOT staged by the workgroup at all: pack_b_kernel
+// rounds it ONCE per GEMM into a 16-bit image laid out as MFMA operands ([k / 32][n / 16][lane][8], 128 KB for 256 x
+// 256, L2-resident) and every lane fetches its operand with one 16-byte load.  No barrier and no conversion in the
+// k-loop.  (The plain kernel re-read and re-rounded the fp32 weights in every workgroup: rocprof counted 36 VALU
+// instructions per MFMA on the hidden-256 layer GEMMs, which ran at ~2 TB/s of HBM traffic with the matrix core 90 %
+// idle.)  With BN = 256 the panel is read exactly once.  The epilogue's LDS patch aliases the panel.
+template <int TM, int TN, typename OT, int BKB, int WM = 2, int WN = 2, bool AKM = false, bool BKM = false,
+          bool AFULL = false>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 4 : 1) void gemm_bf16_kernel(const Gemm g) {
   constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN, LDK = BKB + 8, NTH = 64 * WM * WN;
   constexpr int PA = BM + 8, PB = BN + 8;                 // k-major row pitches (elements; 8-byte aligned rows)
+  constexpr int KMAX = 256, LDA = AFULL ? KMAX + 8 : LDK; // AFULL: panel row pitch (conflict-free b128 reads: 132 dwords)
+  static_assert(!(AFULL && AKM), "the resident panel is row-major");
   typedef typename Op16<OT>::V OV;
-  __shared__ __attribute__((aligned(16))) OT Asm[AKM ? BKB * PA : BM * LDK];
-  __shared__ __attribute__((aligned(16))) OT Bsm[BKM ? BKB * PB : BN * LDK];
+  constexpr int EC_ = 16 * TN, EP_ = EC_ + 4;
+  constexpr size_t a_bytes = sizeof(OT) * (AFULL ? BM * LDA : (AKM ? BKB * PA : BM * LDK));
+  constexpr size_t ep_bytes = sizeof(float) * WM * WN * 16 * EP_;
+  __shared__ __attribute__((aligned(16))) char a_raw[AFULL ? (a_bytes > ep_bytes ? a_bytes : ep_bytes) : a_bytes];
+  OT* const Asm = reinterpret_cast<OT*>(a_raw);
+  __shared__ __attribute__((aligned(16))) OT Bsm[AFULL ? 8 : (BKM ? BKB * PB : BN * LDK)];
   const float a_scale = g.a_scale, inv_scale = 1.0f / g.a_scale;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int c = lane & 15, gg = lane >> 4;
   const int wm = w / WN, wn = w % WN;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // Workgroups are handed to the 8 XCDs round-robin in launch order (x fastest), so the column tiles of one row
+  // block -- which read the same A rows -- would land on different L2s.  Re-map: consecutive workgroups OF ONE XCD
+  // take the column tiles of one row block (rows beyond the last multiple of 8 row blocks keep the plain order).
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (OBJ_G16_XCD && gridDim.x > 1) {
+    const unsigned gx = gridDim.x, L = blockIdx.x + gx * blockIdx.y, full = (gridDim.y / 8) * 8 * gx;
+    if (L < full) {
+      const unsigned xcd = L % 8, s = L / 8;
+      bx = (int)(s % gx);
+      by = (int)((s / gx) * 8 + xcd);
+    }
+  }
+  const int m0 = by * BM, n0 = bx * BN;
   const int sk = g.splitk > 1 ? g.splitk : 1;
   const long z = blockIdx.z / sk;
   const int slice = blockIdx.z % sk;
@@ -276,16 +315,52 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 4 : 1) void gemm_bf1
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  constexpr int NA = BM * BKB / NTH, NB = BN * BKB / NTH;
-  float ra[NA], rb[NB];
-  static_assert(NA % 4 == 0 && NB % 4 == 0, "k-major staging takes four rows per thread");
-  typedef OT ot4 __attribute__((ext_vector_type(4)));
-  // element e of a thread's share -> (row, k).  Row-major image: lanes along k.  K-major image: quad q = 4 rows at one k.
+  constexpr int NA = AFULL ? 0 : BM * BKB / NTH, NB = AFULL ? 0 : BN * BKB / NTH;
+  float ra[NA ? NA : 1], rb[NB ? NB : 1];
+  if constexpr (AFULL) {
+    // the panel: BM x KMAX floats, lanes along k.  g.vec4: rows 16-byte aligned and Kd % 4 == 0 -> dwordx4 loads
+    constexpr int NV = BM * KMAX / 4 / NTH;
+    if (g.vec4) {
+      f32x4 pv[NV];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int q = tid + NTH * i, am = q / (KMAX / 4), ak = 4 * (q % (KMAX / 4));
+        const int gm = m0 + am;
+        pv[i] = (gm < g.M && ak < g.Kd) ? *reinterpret_cast<const f32x4*>(A + gm * g.sam + ak) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int q = tid + NTH * i, am = q / (KMAX / 4), ak = 4 * (q % (KMAX / 4));
+        typedef OT ot4 __attribute__((ext_vector_type(4)));
+        ot4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = Op16<OT>::cvt(sizeof(OT) && a_scale != 1.0f ? pv[i][j] * a_scale : pv[i][j]);
+        *reinterpret_cast<ot4*>(&Asm[am * LDA + ak]) = v;
+      }
+    } else {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {          // two bursts of 2 NV scalar loads
+        float ps[2 * NV];
+#pragma unroll
+        for (int i = 0; i < 2 * NV; ++i) {
+          const int e = tid + NTH * (2 * NV * h + i), am = e / KMAX, ak = e % KMAX;
+          const int gm = m0 + am;
+          ps[i] = (gm < g.M && ak < g.Kd) ? A[gm * g.sam + ak] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * NV; ++i) {
+          const int e = tid + NTH * (2 * NV * h + i), am = e / KMAX, ak = e % KMAX;
+          Asm[am * LDA + ak] = Op16<OT>::cvt(ps[i] * a_scale);
+        }
+      }
+    }
+  }
+  // element e of a thread's share -> (row, k): lanes along the operand's contiguous dimension
   auto load_tiles = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       int am, ak;
-      if (AKM) { const int q = tid + NTH * (i >> 2); am = 4 * (q % (BM / 4)) + (i & 3); ak = q / (BM / 4); }
+      if (AKM) { const int e = tid + NTH * i; am = e % BM; ak = e / BM; }
       else { const int e = tid + NTH * i; ak = e % BKB; am = e / BKB; }
       const int gm = m0 + am, gk = k0 + ak;
       ra[i] = (gm < g.M && gk < kend) ? A[gm * g.sam + gk * g.sak] : 0.f;
@@ -293,21 +368,19 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 4 : 1) void gemm_bf1
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       int bn, bk;
-      if (BKM) { const int q = tid + NTH * (i >> 2); bn = 4 * (q % (BN / 4)) + (i & 3); bk = q / (BN / 4); }
+      if (BKM) { const int e = tid + NTH * i; bn = e % BN; bk = e / BN; }
       else { const int e = tid + NTH * i; bk = e % BKB; bn = e / BKB; }
       const int gn = n0 + bn, gk2 = k0 + bk;
       rb[i] = (gn < g.N && gk2 < kend) ? B[gk2 * g.sbk + gn * g.sbn] : 0.f;
     }
   };
   auto store_tiles = [&]() {
-    if (AKM) {
+    if (AFULL) {
+    } else if (AKM) {
 #pragma unroll
-      for (int i = 0; i < NA; i += 4) {
-        const int q = tid + NTH * (i >> 2);
-        ot4 v;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = Op16<OT>::cvt(ra[i + j] * a_scale);
-        *reinterpret_cast<ot4*>(&Asm[(q / (BM / 4)) * PA + 4 * (q % (BM / 4))]) = v;
+      for (int i = 0; i < NA; ++i) {
+        const int e = tid + NTH * i;
+        Asm[(e / BM) * PA + e % BM] = Op16<OT>::cvt(ra[i] * a_scale);
       }
     } else {
 #pragma unroll
@@ -318,12 +391,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 4 : 1) void gemm_bf1
     }
     if (BKM) {
 #pragma unroll
-      for (int i = 0; i < NB; i += 4) {
-        const int q = tid + NTH * (i >> 2);
-        ot4 v;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = Op16<OT>::cvt(rb[i + j]);
-        *reinterpret_cast<ot4*>(&Bsm[(q / (BN / 4)) * PB + 4 * (q % (BN / 4))]) = v;
+      for (int i = 0; i < NB; ++i) {
+        const int e = tid + NTH * i;
+        Bsm[(e / BN) * PB + e % BN] = Op16<OT>::cvt(rb[i]);
       }
     } else {
 #pragma unroll
@@ -347,15 +417,38 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 4 : 1) void gemm_bf1
 #pragma unroll
     for (int i = 0; i < T; ++i) out[i] = __builtin_bit_cast(OV, uint4{lo[i].x, lo[i].y, hi[i].x, hi[i].y});
   };
-  auto operands_rm = [&](auto& out, const OT* img, const int row0, const int ks) {
+  auto operands_rm = [&](auto& out, const OT* img, const int pitch, const int row0, const int ks) {
     constexpr int T = sizeof(out) / sizeof(out[0]);
 #pragma unroll
-    for (int i = 0; i < T; ++i) out[i] = *reinterpret_cast<const OV*>(img + (row0 + 16 * i + c) * LDK + ks + 8 * gg);
+    for (int i = 0; i < T; ++i) out[i] = *reinterpret_cast<const OV*>(img + (row0 + 16 * i + c) * pitch + ks + 8 * gg);
   };
   float rs = 0.f;
-  const bool do_rs = g.rowsum != nullptr && blockIdx.x == 0 && tid < BM;
-  if (kbeg < kend) load_tiles(kbeg);
-  for (int k0 = kbeg; k0 < kend; k0 += BKB) {
+  const bool do_rs = !AFULL && g.rowsum != nullptr && bx == 0 && tid < BM;
+  if constexpr (AFULL) {
+    __syncthreads();                     // the panel is complete
+    const int nks = (g.Kd + 31) / 32;
+    const uint4* bp = reinterpret_cast<const uint4*>(g.Bp) + ((z * (KMAX / 32)) * (BN / 16) + TN * wn) * 64 + lane;
+    OV bcur[TN], bnext[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bcur[j] = __builtin_bit_cast(OV, bp[j * 64]);
+    for (int ks = 0; ks < nks; ++ks) {
+      if (ks + 1 < nks) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bnext[j] = __builtin_bit_cast(OV, bp[((ks + 1) * (BN / 16) + j) * 64]);
+      }
+      OV a[TM];
+      operands_rm(a, Asm, LDA, 16 * TM * wm, 32 * ks);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = Op16<OT>::mfma(a[i], bcur[j], acc[i][j]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bcur[j] = bnext[j];
+    }
+    __syncthreads();                     // every wave is done with the panel: the epilogue patch may overwrite it
+  }
+  if (!AFULL && kbeg < kend) load_tiles(kbeg);
+  for (int k0 = kbeg; !AFULL && k0 < kend; k0 += BKB) {
     store_tiles();
     __syncthreads();
     if (k0 + BKB < kend) load_tiles(k0 + BKB);
@@ -366,8 +459,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 4 : 1) void gemm_bf1
 #pragma unroll
     for (int ks = 0; ks < BKB; ks += 32) {
       OV a[TM], b[TN];
-      if (AKM) operands_km(a, Asm, PA, 16 * TM * wm, ks); else operands_rm(a, Asm, 16 * TM * wm, ks);
-      if (BKM) operands_km(b, Bsm, PB, 16 * TN * wn, ks); else operands_rm(b, Bsm, 16 * TN * wn, ks);
+      if (AKM) operands_km(a, Asm, PA, 16 * TM * wm, ks); else operands_rm(a, Asm, LDA, 16 * TM * wm, ks);
+      if (BKM) operands_km(b, Bsm, PB, 16 * TN * wn, ks); else operands_rm(b, Bsm, LDK, 16 * TN * wn, ks);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -385,7 +478,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 4 : 1) void gemm_bf1
   // patch so that the lanes run ALONG a row: 256-byte (128-byte for the 64-wide tile) coalesced rows for every global
   // access of the epilogue.
   constexpr int EC = 16 * TN, EP = EC + 4, RPI = 64 / EC;            // strip columns, pitch, rows per pass
-  __shared__ float Ep[WM * WN][16][EP];
+  __shared__ float Ep_own[AFULL ? 1 : WM * WN][AFULL ? 1 : 16][AFULL ? 1 : EP];
+  float (*const Ep)[16][EP] = AFULL ? reinterpret_cast<float (*)[16][EP]>(a_raw) : reinterpret_cast<float (*)[16][EP]>(Ep_own);
   const int ecol = lane % EC, erow0 = lane / EC;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -417,6 +511,25 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 4 : 1) void gemm_bf1
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");
   }
+}
+
+// B (generic strides, fp32) -> the AFULL kernel's operand image: thread (ks, jt, lane) writes the 8 values
+// B[32 ks + 8 (lane >> 4) + e][16 jt + (lane & 15)], e = 0..7, rounded to OT; zero beyond Kd / N.
+template <typename OT>
+__global__ __launch_bounds__(256) void pack_b_kernel(const Gemm g, OT* __restrict__ out) {
+  typedef typename Op16<OT>::V OV;
+  const int t = blockIdx.x * 256 + threadIdx.x;              // (ks, jt, lane), 8 * 16 * 64 per batch entry
+  const int lane = t & 63, jt = (t >> 6) & 15, ks = t >> 10;
+  const long z = blockIdx.y;
+  const float* B = g.B + z * g.bsb;
+  const int n = 16 * jt + (lane & 15);
+  OV v;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = 32 * ks + 8 * (lane >> 4) + e;
+    v[e] = Op16<OT>::cvt((k < g.Kd && n < g.N) ? B[k * g.sbk + n * g.sbn] : 0.f);
+  }
+  reinterpret_cast<OV*>(out)[z * 8192 + t] = v;
 }
 
 // selected for the duration of one train_step call (single host thread per device)
@@ -516,6 +629,8 @@ static void launch_reductions(hipStream_t st, RedGroup& rg) {
 }
 // bump allocator over the caller's workspace region for the partial slabs of ONE train_step (the weight-gradient GEMMs
 // of a step run side by side, so each has its own slab); exhausted or absent -> atomics
+static thread_local void* t_packb = nullptr;          // scratch of the AFULL GEMMs' packed B images (128 KB per batch entry)
+static thread_local long t_packb_entries = 0;
 static thread_local float* t_parts = nullptr;
 static thread_local size_t t_parts_cap = 0, t_parts_off = 0;
 static thread_local float* t_next_part = nullptr;       // Gemm::part / rs_part of the next gemm() call
@@ -543,6 +658,7 @@ static void gemm(hipStream_t st, int batch, int M, int N, int Kd, const float* A
   g.accumulate = accumulate; g.relu = relu; g.splitk = splitk;
   g.rowsum = rowsum; g.bsrs = bsrs;
   g.biasrow = t_biasrow; g.bsbr = t_bsbr;
+  g.vec4 = 0; g.Bp = nullptr;
   g.a_scale = t_bf16_operands == 2 ? t_a_scale : 1.0f;
   g.part = t_next_part; g.rs_part = t_next_rs_part;
   t_next_part = t_next_rs_part = nullptr;
@@ -561,6 +677,22 @@ static void gemm(hipStream_t st, int batch, int M, int N, int Kd, const float* A
     // operands whose rows are the contiguous dimension are staged k-major (exec is full at the transposing reads:
     // out-of-range elements are zero-filled, never masked)
     const bool akm = sak != 1 && sam == 1, bkm = sbk != 1 && sbn == 1;
+    // layer GEMMs over the sample axis: resident A panel (64 rows x the whole contraction), 64 x 256 tiles
+    const bool afull = OBJ_G16_AFULL && (wide || (OBJ_G16_AFULL_NARROW && Kd >= 128)) && sak == 1 && Kd <= 256 && N <= 256 && splitk <= 1 && M >= 4096 && !rowsum &&
+                       t_packb && nz <= t_packb_entries;
+    if (afull) {
+      g.vec4 = (Kd % 4 == 0 && sam % 4 == 0 && bsa % 4 == 0 && ((uintptr_t)A & 15) == 0) ? 1 : 0;
+      g.Bp = t_packb;
+      const dim3 pgrid(1, (M + 63) / 64, nz);
+      if (f16) {
+        hipLaunchKernelGGL(pack_b_kernel<_Float16>, dim3(32, nz), dim3(256), 0, st, g, (_Float16*)t_packb);
+        hipLaunchKernelGGL((gemm_bf16_kernel<2, 4, _Float16, 32, 2, 4, false, false, true>), pgrid, dim3(512), 0, st, g);
+      } else {
+        hipLaunchKernelGGL(pack_b_kernel<__bf16>, dim3(32, nz), dim3(256), 0, st, g, (__bf16*)t_packb);
+        hipLaunchKernelGGL((gemm_bf16_kernel<2, 4, __bf16, 32, 2, 4, false, false, true>), pgrid, dim3(512), 0, st, g);
+      }
+      return;
+    }
 #define OBJ_G16_LAUNCH(OT_, AK_, BK_)                                                                                   \
     do {                                                                                                                \
       if (wide) hipLaunchKernelGGL((gemm_bf16_kernel<2, 4, OT_, OBJ_G16_BK_WIDE, 4, 2, AK_, BK_>), grid, dim3(512), 0, st, g); \
@@ -1436,6 +1568,7 @@ struct WS {
   float *dA, *dB_, *dC, *dD, *dE, *d_emb, *dBpe, *pts;
   float* parts; size_t parts_floats;      // split-K partial slabs of the step's weight-gradient GEMMs (wgrad())
   float* loss_part;                       // [K R][4] block partials of the loss terms
+  float* packb;                           // [K][65536] 16-bit: packed B image of the AFULL layer GEMM in flight
   int* counts;
   size_t bytes;
 };
@@ -1485,6 +1618,7 @@ static WS carve(char* base, int H, int C, long n, long R, int K, bool feat) {
     w.parts_floats = tot + (size_t)(2048 + K) * (4 * Hs + 68) + (size_t)K * 1024 * 64;
     w.parts = take(w.parts_floats);
     w.loss_part = take((size_t)K * R * 4);
+    w.packb = H > 128 ? take((size_t)K * 32768) : nullptr;
   }
   w.counts = (int*)take((size_t)2 * K + 2);
   w.bytes = (size_t)(p - base);
@@ -1587,9 +1721,12 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
   WS w = carve((char*)a->workspace, H, C, n, (long)a->R, K, feat);
   if (a->workspace_bytes < w.bytes) return OBJNERF_EINVAL;
   t_parts = w.parts; t_parts_cap = w.parts_floats; t_parts_off = 0;
+  t_packb = w.packb; t_packb_entries = w.packb ? K : 0;
   RedGroup step_red;                 // small-batch path: every ordered reduction of the step in ONE launch, after the join
   step_red.count = 0;
-  struct PartsScope { ~PartsScope() { t_parts = nullptr; t_parts_cap = t_parts_off = 0; t_red_group = nullptr; } } parts_scope;
+  struct PartsScope {
+    ~PartsScope() { t_parts = nullptr; t_parts_cap = t_parts_off = 0; t_red_group = nullptr; t_packb = nullptr; t_packb_entries = 0; }
+  } parts_scope;
   if (!a->pts) {
     const long total = (long)K * n;
     hipLaunchKernelGGL(form_points_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, a->S, a->origins,

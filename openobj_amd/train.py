@@ -2,6 +2,7 @@
 stack the object networks into the arena, run n_iter_per_frame fused iterations over slices of the
 per-frame sample pool, copy the stacked parameters back.  Object creation, dataset reading, labelling
 and visualisation (the rest of train.py) stay with the caller."""
+import contextlib
 from typing import Dict, List, Optional
 
 import torch
@@ -83,36 +84,63 @@ class ShardedIteration:
 
     obj_loop / bg_loop may be None (a rank without foreground objects, do_bg = 0)."""
 
-    def __init__(self, obj_loop=None, bg_loop=None, group=None):
+    def __init__(self, obj_loop=None, bg_loop=None, group=None, overlap: bool = True, resident: bool = False):
+        """overlap: the pre-step exchange and the whole background chain (its kernels, its collective's wait, its AdamW)
+        run on a second HIP stream beside the object kernel -- the two are independent (own parameters, moments and
+        batches; the reference only adds their losses before ONE backward, train.py:463).  The object stream waits
+        for that stream twice: for the global flags before its kernel, and before step() returns.
+        resident: the caller guarantees that the batches handed to step() are complete before the call (resident
+        pools, as in bench.py / mapping.IncrementalMapper); the second stream then never waits for the object
+        stream, so the background chain of iteration i + 1 fills the tail of object kernel i.  Otherwise it waits
+        for the work queued on the caller's stream at every step()."""
         self.obj_loop, self.bg_loop, self.group = obj_loop, bg_loop, group
+        self.overlap, self.resident = overlap, resident
+        self._side = None
+
+    def _bg_stream(self, dev):
+        if not self.overlap or dev.type != "cuda":
+            return None
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=dev)
+        return self._side
 
     def step(self, obj_batch=None, bg_batch=None):
         """-> (object loss terms [K,4] | None, background loss terms [1,4] | None)"""
         ref = obj_batch if obj_batch is not None else bg_batch
         dev = ref["z"].device
         sharded = odist._active(self.group)
-        obj_flags = bg_counts = None
-        if obj_batch is not None and self.obj_loop is not None and sharded:
-            obj_flags = ops.label_counts(obj_batch["labels"])[1]
-        bg_flags = None
-        if bg_batch is not None and self.bg_loop is not None:
+        do_obj = obj_batch is not None and self.obj_loop is not None
+        do_bg = bg_batch is not None and self.bg_loop is not None
+        side = self._bg_stream(dev) if do_obj and do_bg else None
+        main = torch.cuda.current_stream(dev) if side is not None else None
+        on_side = (lambda: torch.cuda.stream(side)) if side is not None else contextlib.nullcontext
+        if side is not None and not self.resident:
+            side.wait_stream(main)
+        obj_flags = bg_counts = bg_flags = gflags = work = None
+        with on_side():
+            if do_obj and sharded:
+                obj_flags = ops.label_counts(obj_batch["labels"])[1]
+            if do_bg:
+                if sharded:
+                    bg_counts = self.bg_loop.local_counts(bg_batch)
+                else:                               # one object, one rank: the kernel's own flag pair is the batch's
+                    bg_counts, bg_flags = self.bg_loop.local_counts_flags(bg_batch)
             if sharded:
-                bg_counts = self.bg_loop.local_counts(bg_batch)
-            else:                                   # one object, one rank: the kernel's own flag pair is the batch's
-                bg_counts, bg_flags = self.bg_loop.local_counts_flags(bg_batch)
-        gflags = None
-        work = None
-        if sharded:
-            pre = odist.pack_pre(obj_flags, bg_counts, dev)
-            odist.allreduce_sum_(pre, self.group)                  # collective 1
-            gflags, bg_counts, bg_flags = odist.unpack_pre(pre)
-        if bg_batch is not None and self.bg_loop is not None:
-            work = self.bg_loop.begin(bg_batch, bg_counts, bg_flags)      # collective 2 starts here
+                pre = odist.pack_pre(obj_flags, bg_counts, dev)
+                odist.allreduce_sum_(pre, self.group)              # collective 1
+                gflags, bg_counts, bg_flags = odist.unpack_pre(pre)
+                if side is not None:
+                    main.wait_stream(side)                         # (the object kernel needs the global flags)
+            if do_bg:
+                work = self.bg_loop.begin(bg_batch, bg_counts, bg_flags)      # collective 2 starts here
         obj_terms = bg_terms = None
-        if obj_batch is not None and self.obj_loop is not None:
-            obj_terms = self.obj_loop.step(obj_batch, global_flags=gflags)     # overlaps the transfer
-        if bg_batch is not None and self.bg_loop is not None:
-            bg_terms = self.bg_loop.finish(work)
+        if do_obj:
+            obj_terms = self.obj_loop.step(obj_batch, global_flags=gflags)     # beside the background chain
+        if do_bg:
+            with on_side():
+                bg_terms = self.bg_loop.finish(work)
+        if side is not None:
+            main.wait_stream(side)
         return obj_terms, bg_terms
 
 
