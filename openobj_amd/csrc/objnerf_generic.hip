@@ -32,6 +32,8 @@ struct Gemm {
                                  // order -- bit-reproducible; NULL: float atomics into C / rowsum
   int vec4;        // AFULL panel loads as dwordx4 (rows 16-byte aligned, Kd % 4 == 0)
   const void* Bp;  // AFULL: B packed as 16-bit MFMA operands, [z][k / 32][n / 16][lane][8] (pack_b_kernel)
+  const float* A2; long sam2, bsa2; int k2;   // AFULL: columns k >= k2 of A come from A2[m sam2 + (k - k2)] (the
+                                              // concatenated layers [h | x] as ONE contraction); k2 >= Kd: none
   float a_scale;   // 16-bit operand kernels: A is multiplied by this power of two before it is rounded and the result
                    // divided by it (keeps back-propagated gradients out of fp16's subnormal range); 1 elsewhere
 };
@@ -272,11 +274,11 @@ __device__ __forceinline__ void lds_tr16_wait(uint2 (&lo)[N], uint2 (&hi)[N]) {
 // instructions per MFMA on the hidden-256 layer GEMMs, which ran at ~2 TB/s of HBM traffic with the matrix core 90 %
 // idle.)  With BN = 256 the panel is read exactly once.  The epilogue's LDS patch aliases the panel.
 template <int TM, int TN, typename OT, int BKB, int WM = 2, int WN = 2, bool AKM = false, bool BKM = false,
-          bool AFULL = false>
+          bool AFULL = false, int KMAX = 256>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 4 : 1) void gemm_bf16_kernel(const Gemm g) {
   constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN, LDK = BKB + 8, NTH = 64 * WM * WN;
   constexpr int PA = BM + 8, PB = BN + 8;                 // k-major row pitches (elements; 8-byte aligned rows)
-  constexpr int KMAX = 256, LDA = AFULL ? KMAX + 8 : LDK; // AFULL: panel row pitch (conflict-free b128 reads: 132 dwords)
+  constexpr int LDA = AFULL ? KMAX + 8 : LDK;   // AFULL: panel row pitch (conflict-free b128 reads: 132 / 180 dwords)
   static_assert(!(AFULL && AKM), "the resident panel is row-major");
   typedef typename Op16<OT>::V OV;
   constexpr int EC_ = 16 * TN, EP_ = EC_ + 4;
@@ -318,15 +320,26 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 4 : 1) void gemm_bf1
   constexpr int NA = AFULL ? 0 : BM * BKB / NTH, NB = AFULL ? 0 : BN * BKB / NTH;
   float ra[NA ? NA : 1], rb[NB ? NB : 1];
   if constexpr (AFULL) {
-    // the panel: BM x KMAX floats, lanes along k.  g.vec4: rows 16-byte aligned and Kd % 4 == 0 -> dwordx4 loads
+    // the panel: BM x KMAX floats, lanes along k.  g.vec4: rows of A 16-byte aligned and its column count a multiple
+    // of 4 -> dwordx4 loads (the second source, x1 / x2 inside the 129-float embedding rows, is read with scalars)
     constexpr int NV = BM * KMAX / 4 / NTH;
+    static_assert(BM * KMAX % (4 * NTH) == 0, "panel share");
+    const int ka = min(g.k2, g.Kd);                     // columns [0, ka) from A, [ka, Kd) from A2
+    const float* A2 = g.A2 + z * g.bsa2;
     if (g.vec4) {
       f32x4 pv[NV];
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         const int q = tid + NTH * i, am = q / (KMAX / 4), ak = 4 * (q % (KMAX / 4));
         const int gm = m0 + am;
-        pv[i] = (gm < g.M && ak < g.Kd) ? *reinterpret_cast<const f32x4*>(A + gm * g.sam + ak) : f32x4{0.f, 0.f, 0.f, 0.f};
+        pv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (gm < g.M) {
+          if (ak < ka) pv[i] = *reinterpret_cast<const f32x4*>(A + gm * g.sam + ak);
+          else if (ak < g.Kd) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pv[i][j] = (ak + j < g.Kd) ? A2[gm * g.sam2 + (ak + j - ka)] : 0.f;
+          }
+        }
       }
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
@@ -334,7 +347,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 4 : 1) void gemm_bf1
         typedef OT ot4 __attribute__((ext_vector_type(4)));
         ot4 v;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = Op16<OT>::cvt(sizeof(OT) && a_scale != 1.0f ? pv[i][j] * a_scale : pv[i][j]);
+        for (int j = 0; j < 4; ++j) v[j] = Op16<OT>::cvt(a_scale != 1.0f ? pv[i][j] * a_scale : pv[i][j]);
         *reinterpret_cast<ot4*>(&Asm[am * LDA + ak]) = v;
       }
     } else {
@@ -345,7 +358,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 4 : 1) void gemm_bf1
         for (int i = 0; i < 2 * NV; ++i) {
           const int e = tid + NTH * (2 * NV * h + i), am = e / KMAX, ak = e % KMAX;
           const int gm = m0 + am;
-          ps[i] = (gm < g.M && ak < g.Kd) ? A[gm * g.sam + ak] : 0.f;
+          ps[i] = (gm < g.M && ak < ka) ? A[gm * g.sam + ak] : (gm < g.M && ak < g.Kd) ? A2[gm * g.sam2 + (ak - ka)] : 0.f;
         }
 #pragma unroll
         for (int i = 0; i < 2 * NV; ++i) {
@@ -515,10 +528,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 4 : 1) void gemm_bf1
 
 // B (generic strides, fp32) -> the AFULL kernel's operand image: thread (ks, jt, lane) writes the 8 values
 // B[32 ks + 8 (lane >> 4) + e][16 jt + (lane & 15)], e = 0..7, rounded to OT; zero beyond Kd / N.
-template <typename OT>
+template <typename OT, int KS>
 __global__ __launch_bounds__(256) void pack_b_kernel(const Gemm g, OT* __restrict__ out) {
   typedef typename Op16<OT>::V OV;
-  const int t = blockIdx.x * 256 + threadIdx.x;              // (ks, jt, lane), 8 * 16 * 64 per batch entry
+  const int t = blockIdx.x * 256 + threadIdx.x;              // (ks, jt, lane), KS * 16 * 64 per batch entry
   const int lane = t & 63, jt = (t >> 6) & 15, ks = t >> 10;
   const long z = blockIdx.y;
   const float* B = g.B + z * g.bsb;
@@ -529,7 +542,7 @@ __global__ __launch_bounds__(256) void pack_b_kernel(const Gemm g, OT* __restric
     const int k = 32 * ks + 8 * (lane >> 4) + e;
     v[e] = Op16<OT>::cvt((k < g.Kd && n < g.N) ? B[k * g.sbk + n * g.sbn] : 0.f);
   }
-  reinterpret_cast<OV*>(out)[z * 8192 + t] = v;
+  reinterpret_cast<OV*>(out)[z * (KS * 1024) + t] = v;
 }
 
 // selected for the duration of one train_step call (single host thread per device)
@@ -629,8 +642,15 @@ static void launch_reductions(hipStream_t st, RedGroup& rg) {
 }
 // bump allocator over the caller's workspace region for the partial slabs of ONE train_step (the weight-gradient GEMMs
 // of a step run side by side, so each has its own slab); exhausted or absent -> atomics
-static thread_local void* t_packb = nullptr;          // scratch of the AFULL GEMMs' packed B images (128 KB per batch entry)
+static thread_local void* t_packb = nullptr;          // scratch of the AFULL GEMMs' packed B images (176 KB per batch entry)
 static thread_local long t_packb_entries = 0;
+struct A2Src { const float* A2; long sam2, bsa2; int k2; };
+static thread_local A2Src t_a2 = {nullptr, 0, 0, 0};  // second A source of the NEXT gemm() call (Gemm::A2), panel path only
+// the layer GEMMs the resident-panel kernel takes (16-bit modes, rows k-contiguous, contraction <= 352, N <= 256)
+static bool panel_ok(int M, int N, int Kd, long sak, int splitk, bool rowsum, int nz) {
+  return OBJ_G16_AFULL && t_bf16_operands && sak == 1 && Kd <= 352 && N <= 256 && splitk <= 1 && M >= 4096 && !rowsum &&
+         t_packb && nz <= t_packb_entries;
+}
 static thread_local float* t_parts = nullptr;
 static thread_local size_t t_parts_cap = 0, t_parts_off = 0;
 static thread_local float* t_next_part = nullptr;       // Gemm::part / rs_part of the next gemm() call
@@ -658,7 +678,7 @@ static void gemm(hipStream_t st, int batch, int M, int N, int Kd, const float* A
   g.accumulate = accumulate; g.relu = relu; g.splitk = splitk;
   g.rowsum = rowsum; g.bsrs = bsrs;
   g.biasrow = t_biasrow; g.bsbr = t_bsbr;
-  g.vec4 = 0; g.Bp = nullptr;
+  g.vec4 = 0; g.Bp = nullptr; g.A2 = nullptr; g.sam2 = g.bsa2 = 0; g.k2 = Kd;
   g.a_scale = t_bf16_operands == 2 ? t_a_scale : 1.0f;
   g.part = t_next_part; g.rs_part = t_next_rs_part;
   t_next_part = t_next_rs_part = nullptr;
@@ -678,21 +698,24 @@ static void gemm(hipStream_t st, int batch, int M, int N, int Kd, const float* A
     // out-of-range elements are zero-filled, never masked)
     const bool akm = sak != 1 && sam == 1, bkm = sbk != 1 && sbn == 1;
     // layer GEMMs over the sample axis: resident A panel (64 rows x the whole contraction), 64 x 256 tiles
-    const bool afull = OBJ_G16_AFULL && (wide || (OBJ_G16_AFULL_NARROW && Kd >= 128)) && sak == 1 && Kd <= 256 && N <= 256 && splitk <= 1 && M >= 4096 && !rowsum &&
-                       t_packb && nz <= t_packb_entries;
-    if (afull) {
-      g.vec4 = (Kd % 4 == 0 && sam % 4 == 0 && bsa % 4 == 0 && ((uintptr_t)A & 15) == 0) ? 1 : 0;
+    if (panel_ok(M, N, Kd, sak, splitk, rowsum != nullptr, nz) && (wide || (OBJ_G16_AFULL_NARROW && Kd >= 128))) {
+      const int ka = t_a2.A2 ? t_a2.k2 : Kd;
+      g.A2 = t_a2.A2 ? t_a2.A2 : A; g.sam2 = t_a2.sam2; g.bsa2 = t_a2.bsa2; g.k2 = ka;
+      t_a2.A2 = nullptr;
+      g.vec4 = (ka % 4 == 0 && sam % 4 == 0 && bsa % 4 == 0 && ((uintptr_t)A & 15) == 0) ? 1 : 0;
       g.Bp = t_packb;
       const dim3 pgrid(1, (M + 63) / 64, nz);
-      if (f16) {
-        hipLaunchKernelGGL(pack_b_kernel<_Float16>, dim3(32, nz), dim3(256), 0, st, g, (_Float16*)t_packb);
-        hipLaunchKernelGGL((gemm_bf16_kernel<2, 4, _Float16, 32, 2, 4, false, false, true>), pgrid, dim3(512), 0, st, g);
-      } else {
-        hipLaunchKernelGGL(pack_b_kernel<__bf16>, dim3(32, nz), dim3(256), 0, st, g, (__bf16*)t_packb);
-        hipLaunchKernelGGL((gemm_bf16_kernel<2, 4, __bf16, 32, 2, 4, false, false, true>), pgrid, dim3(512), 0, st, g);
-      }
+#define OBJ_G16_PANEL(OT_, KM_)                                                                                         \
+      do {                                                                                                              \
+        hipLaunchKernelGGL((pack_b_kernel<OT_, KM_ / 32>), dim3(KM_ / 8, nz), dim3(256), 0, st, g, (OT_*)t_packb);      \
+        hipLaunchKernelGGL((gemm_bf16_kernel<2, 4, OT_, 32, 2, 4, false, false, true, KM_>), pgrid, dim3(512), 0, st, g); \
+      } while (0)
+      if (Kd <= 256) { if (f16) OBJ_G16_PANEL(_Float16, 256); else OBJ_G16_PANEL(__bf16, 256); }
+      else { if (f16) OBJ_G16_PANEL(_Float16, 352); else OBJ_G16_PANEL(__bf16, 352); }
+#undef OBJ_G16_PANEL
       return;
     }
+    t_a2.A2 = nullptr;
 #define OBJ_G16_LAUNCH(OT_, AK_, BK_)                                                                                   \
     do {                                                                                                                \
       if (wide) hipLaunchKernelGGL((gemm_bf16_kernel<2, 4, OT_, OBJ_G16_BK_WIDE, 4, 2, AK_, BK_>), grid, dim3(512), 0, st, g); \
@@ -1618,7 +1641,7 @@ static WS carve(char* base, int H, int C, long n, long R, int K, bool feat) {
     w.parts_floats = tot + (size_t)(2048 + K) * (4 * Hs + 68) + (size_t)K * 1024 * 64;
     w.parts = take(w.parts_floats);
     w.loss_part = take((size_t)K * R * 4);
-    w.packb = H > 128 ? take((size_t)K * 32768) : nullptr;
+    w.packb = H > 128 ? take((size_t)K * 45056) : nullptr;
   }
   w.counts = (int*)take((size_t)2 * K + 2);
   w.bytes = (size_t)(p - base);
@@ -1806,13 +1829,25 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
   gemm(st, K, n, H, E1, w.emb, EM, 1, n * EM, P + off[0], 1, E1, ps, w.h1, H, 1, nH, false, P + off[1], ps, true);
   gemm(st, K, n, H, H, w.h1, H, 1, nH, P + off[2], 1, H, ps, w.h2, H, 1, nH, false, P + off[3], ps, true);
   // h3 = relu([h2 | x1] W_cat^T + b)
+  // ([h2 | x1] as ONE contraction when the resident-panel kernel takes it: no round trip of the partial result)
+  const bool fuse2 = panel_ok((int)n, H, H + E1, 1, 1, false, K) && H >= 192;
+  if (fuse2) {
+    t_a2 = A2Src{w.emb, EM, n * EM, H};
+    gemm(st, K, n, H, H + E1, w.h2, H, 1, nH, P + off[4], 1, H + E1, ps, w.h3, H, 1, nH, false, P + off[5], ps, true);
+  } else {
   gemm(st, K, n, H, H, w.h2, H, 1, nH, P + off[4], 1, H + E1, ps, w.h3, H, 1, nH);
   gemm(st, K, n, H, E1, w.emb, EM, 1, n * EM, P + off[4] + H, 1, H + E1, ps, w.h3, H, 1, nH, true, P + off[5], ps, true);
+  }
   gemm(st, K, n, H, H, w.h3, H, 1, nH, P + off[6], 1, H, ps, w.h4, H, 1, nH, false, P + off[7], ps, true);
   // hc = relu([h4 | x2] W_cl^T + b)
+  if (fuse2) {
+    t_a2 = A2Src{w.emb + E1, EM, n * EM, H};
+    gemm(st, K, n, H, H + E2, w.h4, H, 1, nH, P + off[10], 1, H + E2, ps, w.hc, H, 1, nH, false, P + off[11], ps, true);
+  } else {
   gemm(st, K, n, H, H, w.h4, H, 1, nH, P + off[10], 1, H + E2, ps, w.hc, H, 1, nH);
   gemm(st, K, n, H, E2, w.emb + E1, EM, 1, n * EM, P + off[10] + H, 1, H + E2, ps, w.hc, H, 1, nH, true, P + off[11], ps,
        true);
+  }
   hipLaunchKernelGGL(heads_fwd_kernel, eg, dim3(256), head_lds, st, H, n, w.h4, w.hc, P, ps, (int)off[8], (int)off[9],
                      (int)off[12], (int)off[13], w.alpha, w.color);
   if (feat) {
