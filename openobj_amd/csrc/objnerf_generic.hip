@@ -294,19 +294,30 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 4 : 1) void gemm_bf1
   // Workgroups are handed to the 8 XCDs round-robin in launch order (x fastest), so the column tiles of one row
   // block -- which read the same A rows -- would land on different L2s.  Re-map: consecutive workgroups OF ONE XCD
   // take the column tiles of one row block (rows beyond the last multiple of 8 row blocks keep the plain order).
-  int bx = blockIdx.x, by = blockIdx.y;
-  if (OBJ_G16_XCD && gridDim.x > 1) {
+  // Split-K weight gradients (few output tiles, hundreds of slices): the tiles of ONE slice read the same operand slabs,
+  // so they go to one XCD the same way.
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (OBJ_G16_XCD && gridDim.x > 1 && gridDim.y >= 8) {
     const unsigned gx = gridDim.x, L = blockIdx.x + gx * blockIdx.y, full = (gridDim.y / 8) * 8 * gx;
     if (L < full) {
       const unsigned xcd = L % 8, s = L / 8;
       bx = (int)(s % gx);
       by = (int)((s / gx) * 8 + xcd);
     }
+  } else if (OBJ_G16_XCD && gridDim.x * gridDim.y > 1 && gridDim.z >= 8) {
+    const unsigned gx = gridDim.x, T = gx * gridDim.y, L = blockIdx.x + gx * blockIdx.y + T * blockIdx.z;
+    const unsigned full = (gridDim.z / 8) * 8 * T;
+    if (L < full) {
+      const unsigned xcd = L % 8, s = L / 8, tile = s % T;
+      bx = (int)(tile % gx);
+      by = (int)(tile / gx);
+      bz = (int)((s / T) * 8 + xcd);
+    }
   }
   const int m0 = by * BM, n0 = bx * BN;
   const int sk = g.splitk > 1 ? g.splitk : 1;
-  const long z = blockIdx.z / sk;
-  const int slice = blockIdx.z % sk;
+  const long z = bz / sk;
+  const int slice = bz % sk;
   const float* A = g.A + z * g.bsa;
   const float* B = g.B + z * g.bsb;
   float* C = g.C + z * g.bsc;
