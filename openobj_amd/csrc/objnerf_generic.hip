@@ -30,8 +30,10 @@ struct Gemm {
   float* part; float* rs_part;   // split-K with these set: slice s of batch z STORES its partial tile at part[((z sk + s) M + m)
                                  // N + n] (row sums: rs_part[(z sk + s) M + m]) and reduce_parts_kernel adds the slices in
                                  // order -- bit-reproducible; NULL: float atomics into C / rowsum
-  int vec4;        // AFULL panel loads as dwordx4 (rows 16-byte aligned, Kd % 4 == 0)
+  int vec4;        // A is read with dwordx4 loads: AFULL panel rows / k-major A rows are 16-byte aligned
   const void* Bp;  // AFULL: B packed as 16-bit MFMA operands, [z][k / 32][n / 16][lane][8] (pack_b_kernel)
+  int a16, b16, m16, c16;   // 16-bit kernels: A / B / mask / C are arrays of the kernel's operand type (the layer-wise
+                            // path keeps h1 .. hc in 16 bit in the 16-bit modes); element strides as for floats
   const float* A2; long sam2, bsa2; int k2;   // AFULL: columns k >= k2 of A come from A2[m sam2 + (k - k2)] (the
                                               // concatenated layers [h | x] as ONE contraction); k2 >= Kd: none
   float a_scale;   // 16-bit operand kernels: A is multiplied by this power of two before it is rounded and the result
@@ -211,6 +213,9 @@ __global__ __launch_bounds__(512) void gemm_group_kernel(const GemmGroup gr) {
 #ifndef OBJ_G16_AFULL
 #define OBJ_G16_AFULL 1
 #endif
+#ifndef OBJ_ACT16
+#define OBJ_ACT16 1
+#endif
 #ifndef OBJ_G16_AFULL_NARROW
 #define OBJ_G16_AFULL_NARROW 0      // (the narrow input-gradient GEMMs, N = 87 / 42: measured no gain)
 #endif
@@ -331,30 +336,38 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 4 : 1) void gemm_bf1
   constexpr int NA = AFULL ? 0 : BM * BKB / NTH, NB = AFULL ? 0 : BN * BKB / NTH;
   float ra[NA ? NA : 1], rb[NB ? NB : 1];
   if constexpr (AFULL) {
-    // the panel: BM x KMAX floats, lanes along k.  g.vec4: rows of A 16-byte aligned and its column count a multiple
-    // of 4 -> dwordx4 loads (the second source, x1 / x2 inside the 129-float embedding rows, is read with scalars)
-    constexpr int NV = BM * KMAX / 4 / NTH;
-    static_assert(BM * KMAX % (4 * NTH) == 0, "panel share");
-    const int ka = min(g.k2, g.Kd);                     // columns [0, ka) from A, [ka, Kd) from A2
-    const float* A2 = g.A2 + z * g.bsa2;
-    if (g.vec4) {
+    // the panel: columns [0, ka) from A (lanes along k; 16-byte loads when g.vec4: rows 16-byte aligned, ka a multiple
+    // of 8), then, for the 352-deep variant, columns [256, 352) from the second source (x1 / x2 inside the 129-float
+    // embedding rows: scalars).  Everything else of the panel is zero.
+    constexpr int KA = 256;
+    const int ka = min(g.k2, g.Kd);                     // columns [0, ka) from A, [ka, Kd) from A2 (then ka == KA)
+    if (g.a16) {
+      constexpr int N8 = BM * KA / 8 / NTH;
+      const OT* A16 = reinterpret_cast<const OT*>(g.A) + z * g.bsa;
+      uint4 pv[N8];
+#pragma unroll
+      for (int i = 0; i < N8; ++i) {
+        const int q = tid + NTH * i, am = q / (KA / 8), ak = 8 * (q % (KA / 8));
+        const int gm = m0 + am;
+        pv[i] = (gm < g.M && ak < ka) ? *reinterpret_cast<const uint4*>(A16 + gm * g.sam + ak) : uint4{0u, 0u, 0u, 0u};
+      }
+#pragma unroll
+      for (int i = 0; i < N8; ++i) {
+        const int q = tid + NTH * i, am = q / (KA / 8), ak = 8 * (q % (KA / 8));
+        *reinterpret_cast<uint4*>(&Asm[am * LDA + ak]) = pv[i];
+      }
+    } else if (g.vec4) {
+      constexpr int NV = BM * KA / 4 / NTH;
       f32x4 pv[NV];
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
-        const int q = tid + NTH * i, am = q / (KMAX / 4), ak = 4 * (q % (KMAX / 4));
+        const int q = tid + NTH * i, am = q / (KA / 4), ak = 4 * (q % (KA / 4));
         const int gm = m0 + am;
-        pv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (gm < g.M) {
-          if (ak < ka) pv[i] = *reinterpret_cast<const f32x4*>(A + gm * g.sam + ak);
-          else if (ak < g.Kd) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) pv[i][j] = (ak + j < g.Kd) ? A2[gm * g.sam2 + (ak + j - ka)] : 0.f;
-          }
-        }
+        pv[i] = (gm < g.M && ak < ka) ? *reinterpret_cast<const f32x4*>(A + gm * g.sam + ak) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
-        const int q = tid + NTH * i, am = q / (KMAX / 4), ak = 4 * (q % (KMAX / 4));
+        const int q = tid + NTH * i, am = q / (KA / 4), ak = 4 * (q % (KA / 4));
         typedef OT ot4 __attribute__((ext_vector_type(4)));
         ot4 v;
 #pragma unroll
@@ -362,25 +375,54 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 4 : 1) void gemm_bf1
         *reinterpret_cast<ot4*>(&Asm[am * LDA + ak]) = v;
       }
     } else {
+      constexpr int NS = BM * KA / NTH / 2;
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {          // two bursts of 2 NV scalar loads
-        float ps[2 * NV];
+      for (int h = 0; h < 2; ++h) {          // two bursts of scalar loads
+        float ps[NS];
 #pragma unroll
-        for (int i = 0; i < 2 * NV; ++i) {
-          const int e = tid + NTH * (2 * NV * h + i), am = e / KMAX, ak = e % KMAX;
+        for (int i = 0; i < NS; ++i) {
+          const int e = tid + NTH * (NS * h + i), am = e / KA, ak = e % KA;
           const int gm = m0 + am;
-          ps[i] = (gm < g.M && ak < ka) ? A[gm * g.sam + ak] : (gm < g.M && ak < g.Kd) ? A2[gm * g.sam2 + (ak - ka)] : 0.f;
+          ps[i] = (gm < g.M && ak < ka) ? A[gm * g.sam + ak] : 0.f;
         }
 #pragma unroll
-        for (int i = 0; i < 2 * NV; ++i) {
-          const int e = tid + NTH * (2 * NV * h + i), am = e / KMAX, ak = e % KMAX;
+        for (int i = 0; i < NS; ++i) {
+          const int e = tid + NTH * (NS * h + i), am = e / KA, ak = e % KA;
           Asm[am * LDA + ak] = Op16<OT>::cvt(ps[i] * a_scale);
         }
+      }
+    }
+    if constexpr (KMAX > KA) {
+      constexpr int K2 = KMAX - KA, N2 = BM * K2 / NTH;
+      static_assert(BM * K2 % NTH == 0, "second-source share");
+      const float* A2 = g.A2 + z * g.bsa2;
+      float ps[N2];
+#pragma unroll
+      for (int i = 0; i < N2; ++i) {
+        const int e = tid + NTH * i, am = e / K2, ak = KA + e % K2;
+        const int gm = m0 + am;
+        ps[i] = (gm < g.M && ak >= ka && ak < g.Kd) ? A2[gm * g.sam2 + (ak - ka)] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < N2; ++i) {
+        const int e = tid + NTH * i, am = e / K2, ak = KA + e % K2;
+        Asm[am * LDA + ak] = Op16<OT>::cvt(ps[i] * a_scale);
       }
     }
   }
   // element e of a thread's share -> (row, k): lanes along the operand's contiguous dimension
   auto load_tiles = [&](int k0) {
+    if (AKM && g.vec4) {
+      // rows contiguous and 16-byte aligned (weight gradients: A = d_out^T): four consecutive m per lane, one dwordx4
+#pragma unroll
+      for (int i = 0; i < NA / 4; ++i) {
+        const int q = tid + NTH * i, am = 4 * (q % (BM / 4)), ak = q / (BM / 4);
+        const int gm = m0 + am, gk = k0 + ak;
+        const f32x4 v = (gm < g.M && gk < kend) ? *reinterpret_cast<const f32x4*>(A + gk * g.sak + gm) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ra[4 * i + j] = v[j];
+      }
+    } else
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       int am, ak;
@@ -388,6 +430,19 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 4 : 1) void gemm_bf1
       else { const int e = tid + NTH * i; ak = e % BKB; am = e / BKB; }
       const int gm = m0 + am, gk = k0 + ak;
       ra[i] = (gm < g.M && gk < kend) ? A[gm * g.sam + gk * g.sak] : 0.f;
+    }
+    if (BKM && g.b16) {
+      // B is a 16-bit activation array (weight gradients in the 16-bit modes): four consecutive n per lane, one 8-byte
+      // load, passed through to the k-major image unchanged (host-checked: sbn == 1, sbk and N multiples of 4)
+      const OT* B16 = reinterpret_cast<const OT*>(g.B) + z * g.bsb;
+#pragma unroll
+      for (int i = 0; i < NB / 4; ++i) {
+        const int q = tid + NTH * i, bn = 4 * (q % (BN / 4)), bk = q / (BN / 4);
+        const int gn = n0 + bn, gk2 = k0 + bk;
+        const uint2 u = (gn < g.N && gk2 < kend) ? *reinterpret_cast<const uint2*>(B16 + gk2 * g.sbk + gn) : uint2{0u, 0u};
+        rb[2 * i] = __builtin_bit_cast(float, u.x); rb[2 * i + 1] = __builtin_bit_cast(float, u.y);
+      }
+      return;
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -400,6 +455,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 4 : 1) void gemm_bf1
   };
   auto store_tiles = [&]() {
     if (AFULL) {
+    } else if (AKM && g.vec4) {
+#pragma unroll
+      for (int i = 0; i < NA / 4; ++i) {
+        const int q = tid + NTH * i;
+        typedef OT ot4 __attribute__((ext_vector_type(4)));
+        ot4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = Op16<OT>::cvt(ra[4 * i + j] * a_scale);
+        *reinterpret_cast<ot4*>(&Asm[(q / (BM / 4)) * PA + 4 * (q % (BM / 4))]) = v;
+      }
     } else if (AKM) {
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
@@ -413,7 +478,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 4 : 1) void gemm_bf1
         Asm[(e / BKB) * LDK + e % BKB] = Op16<OT>::cvt(ra[i] * a_scale);
       }
     }
-    if (BKM) {
+    if (BKM && g.b16) {
+#pragma unroll
+      for (int i = 0; i < NB / 4; ++i) {
+        const int q = tid + NTH * i;
+        *reinterpret_cast<uint2*>(&Bsm[(q / (BN / 4)) * PB + 4 * (q % (BN / 4))]) =
+            uint2{__builtin_bit_cast(uint32_t, rb[2 * i]), __builtin_bit_cast(uint32_t, rb[2 * i + 1])};
+      }
+    } else if (BKM) {
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         const int e = tid + NTH * i;
@@ -528,8 +600,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 4 : 1) void gemm_bf1
         if (g.accumulate) v += *cp;
         if (g.bias) v += g.bias[z * g.bsbias + n] * (g.biasrow ? g.biasrow[z * g.bsbr + m] : 1.0f);
         if (g.relu) v = fmaxf(v, 0.f);
-        if (g.mask) v = g.mask[z * g.bsm + m * g.smm + n * g.smn] > 0.f ? v : 0.f;
-        *cp = v;
+        if (g.mask) {
+          const long mi = z * g.bsm + m * g.smm + n * g.smn;
+          const bool on = g.m16 ? (float)reinterpret_cast<const OT*>(g.mask)[mi] > 0.f : g.mask[mi] > 0.f;
+          v = on ? v : 0.f;
+        }
+        if (g.c16) reinterpret_cast<OT*>(g.C)[z * g.bsc + m * g.scm + n * g.scn] = Op16<OT>::cvt(v);
+        else *cp = v;
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -655,6 +732,11 @@ static void launch_reductions(hipStream_t st, RedGroup& rg) {
 // of a step run side by side, so each has its own slab); exhausted or absent -> atomics
 static thread_local void* t_packb = nullptr;          // scratch of the AFULL GEMMs' packed B images (176 KB per batch entry)
 static thread_local long t_packb_entries = 0;
+// [lo, hi): the step's 16-bit activation buffers (h1 .. hc stored in the operand type); gemm() marks every operand that
+// lies inside (Gemm::a16 / b16 / m16 / c16)
+static thread_local const char* t_act16_lo = nullptr;
+static thread_local const char* t_act16_hi = nullptr;
+static bool in_act16(const void* p) { return t_act16_lo && (const char*)p >= t_act16_lo && (const char*)p < t_act16_hi; }
 struct A2Src { const float* A2; long sam2, bsa2; int k2; };
 static thread_local A2Src t_a2 = {nullptr, 0, 0, 0};  // second A source of the NEXT gemm() call (Gemm::A2), panel path only
 // the layer GEMMs the resident-panel kernel takes (16-bit modes, rows k-contiguous, contraction <= 352, N <= 256)
@@ -690,6 +772,7 @@ static void gemm(hipStream_t st, int batch, int M, int N, int Kd, const float* A
   g.rowsum = rowsum; g.bsrs = bsrs;
   g.biasrow = t_biasrow; g.bsbr = t_bsbr;
   g.vec4 = 0; g.Bp = nullptr; g.A2 = nullptr; g.sam2 = g.bsa2 = 0; g.k2 = Kd;
+  g.a16 = in_act16(A); g.b16 = in_act16(B); g.m16 = mask && in_act16(mask); g.c16 = in_act16(C);
   g.a_scale = t_bf16_operands == 2 ? t_a_scale : 1.0f;
   g.part = t_next_part; g.rs_part = t_next_rs_part;
   t_next_part = t_next_rs_part = nullptr;
@@ -713,7 +796,9 @@ static void gemm(hipStream_t st, int batch, int M, int N, int Kd, const float* A
       const int ka = t_a2.A2 ? t_a2.k2 : Kd;
       g.A2 = t_a2.A2 ? t_a2.A2 : A; g.sam2 = t_a2.sam2; g.bsa2 = t_a2.bsa2; g.k2 = ka;
       t_a2.A2 = nullptr;
-      g.vec4 = (ka % 4 == 0 && sam % 4 == 0 && bsa % 4 == 0 && ((uintptr_t)A & 15) == 0) ? 1 : 0;
+      g.vec4 = (ka % 8 == 0 && sam % 8 == 0 && bsa % 8 == 0 && ((uintptr_t)A & 15) == 0) ? 1 : 0;
+      if (g.a16 && !g.vec4) { fprintf(stderr, "objnerf: 16-bit activation panel needs aligned rows\n"); abort(); }
+      if (g.c16 && (accumulate || g.b16)) { fprintf(stderr, "objnerf: unsupported 16-bit GEMM operands\n"); abort(); }
       g.Bp = t_packb;
       const dim3 pgrid(1, (M + 63) / 64, nz);
 #define OBJ_G16_PANEL(OT_, KM_)                                                                                         \
@@ -727,6 +812,11 @@ static void gemm(hipStream_t st, int batch, int M, int N, int Kd, const float* A
       return;
     }
     t_a2.A2 = nullptr;
+    g.vec4 = (akm && sak % 4 == 0 && bsa % 4 == 0 && M % 4 == 0 && ((uintptr_t)A & 15) == 0) ? 1 : 0;
+    if (g.a16 || g.c16 || (g.b16 && !(bkm && sbk % 4 == 0 && N % 4 == 0 && bsb % 4 == 0))) {
+      fprintf(stderr, "objnerf: 16-bit activations in a GEMM shape that does not take them\n");
+      abort();
+    }
 #define OBJ_G16_LAUNCH(OT_, AK_, BK_)                                                                                   \
     do {                                                                                                                \
       if (wide) hipLaunchKernelGGL((gemm_bf16_kernel<2, 4, OT_, OBJ_G16_BK_WIDE, 4, 2, AK_, BK_>), grid, dim3(512), 0, st, g); \
@@ -1320,11 +1410,29 @@ static void flush_group(hipStream_t st, GemmGroup& gr) {
 }
 
 
+// Activation loads of the kernels around the GEMMs: act = 0 fp32 storage, 1 bf16, 2 fp16 (the 16-bit modes keep
+// h1 .. hc in the operand type at hidden 256: half the traffic of the HBM-bound layer GEMMs).
+__device__ __forceinline__ float act_ld(const float* p, long i, int act) {
+  if (act == 0) return p[i];
+  if (act == 1) return (float)reinterpret_cast<const __bf16*>(p)[i];
+  return (float)reinterpret_cast<const _Float16*>(p)[i];
+}
+__device__ __forceinline__ float4 act_ld4(const float* p, long i, int act) {       // i % 4 == 0
+  if (act == 0) return *reinterpret_cast<const float4*>(p + i);
+  const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(p) + i);
+  if (act == 1)
+    return make_float4(__builtin_bit_cast(float, r.x << 16), __builtin_bit_cast(float, r.x & 0xffff0000u),
+                       __builtin_bit_cast(float, r.y << 16), __builtin_bit_cast(float, r.y & 0xffff0000u));
+  typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+  const h4_t h = __builtin_bit_cast(h4_t, r);
+  return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+}
+
 // heads forward: alpha = 10 (h4 . wa + ba), color = sigmoid(hc Woc^T + boc)        (model.py:81-96)
 // 16 lanes per sample row (float4 each, coalesced), the four dot products meet by DPP row sums.
 __global__ __launch_bounds__(256) void heads_fwd_kernel(int Hh, long n, const float* h4, const float* hc,
                                                         const float* params, long p_stride, int off_wa, int off_ba,
-                                                        int off_woc, int off_boc, float* alpha, float* color) {
+                                                        int off_woc, int off_boc, float* alpha, float* color, int act) {
   extern __shared__ float sw[];            // wa | woc[3]  (4 Hh floats)
   const long z = blockIdx.y;
   const float* P = params + z * p_stride;
@@ -1335,11 +1443,10 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(int Hh, long n, const fl
   const long i = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
   float sa = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
   if (i < n) {
-    const float* a = h4 + (z * n + i) * Hh;
-    const float* cc = hc + (z * n + i) * Hh;
+    const long ro = (z * n + i) * Hh;
     for (int h = 4 * l16; h < Hh; h += 64) {
-      const float4 av = *reinterpret_cast<const float4*>(a + h);
-      const float4 cv = *reinterpret_cast<const float4*>(cc + h);
+      const float4 av = act_ld4(h4, ro + h, act);
+      const float4 cv = act_ld4(hc, ro + h, act);
       const float* w0 = sw + h;
       sa = fmaf(w0[3], av.w, fmaf(w0[2], av.z, fmaf(w0[1], av.y, fmaf(w0[0], av.x, sa))));
       s0 = fmaf(w0[Hh + 3], cv.w, fmaf(w0[Hh + 2], cv.z, fmaf(w0[Hh + 1], cv.y, fmaf(w0[Hh], cv.x, s0))));
@@ -1361,7 +1468,7 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(int Hh, long n, const fl
 __global__ __launch_bounds__(256) void heads_bwd_kernel(int Hh, long n, const float* hc, const float* color,
                                                         const float* d_alpha, const float* d_color, const float* params,
                                                         long p_stride, int off_wa, int off_woc, float* dhead, float* d_hc,
-                                                        float* d_h4) {
+                                                        float* d_h4, int act) {
   extern __shared__ float sw[];            // wa | woc[3]
   const long z = blockIdx.y;
   const float* P = params + z * p_stride;
@@ -1380,7 +1487,7 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(int Hh, long n, const fl
   }
   if (l16 == 0) *reinterpret_cast<float4*>(dhead + o * 4) = make_float4(da, dc[0], dc[1], dc[2]);
   for (int h = 4 * l16; h < Hh; h += 64) {
-    const float4 hv = *reinterpret_cast<const float4*>(hc + o * Hh + h);
+    const float4 hv = act_ld4(hc, o * Hh + h, act);
     const float* w0 = sw + h;
     float4 v, u;
     v.x = fmaf(w0[3 * Hh], dc[2], fmaf(w0[2 * Hh], dc[1], w0[Hh] * dc[0]));
@@ -1399,7 +1506,8 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(int Hh, long n, const fl
 // samples (reads h4 and hc once, coalesced along f); one atomic per block and entry into the pre-zeroed gradient.
 __global__ __launch_bounds__(256) void head_wgrad_kernel(int Hh, long n, const float* dhead, const float* h4, const float* hc,
                                                          float* grads, long p_stride, int off_wa, int off_ba, int off_woc,
-                                                         int off_boc, float* partA, float* partW, float* rsA, float* rsW) {
+                                                         int off_boc, float* partA, float* partW, float* rsA, float* rsW,
+                                                         int act) {
   __shared__ float red[4][256];
   const long z = blockIdx.y;
   const int rows = 256 / Hh > 0 ? 256 / Hh : 1;            // sample rows per pass (H <= 256)
@@ -1412,7 +1520,7 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(int Hh, long n, const f
     for (long i = i0 + row; i < i1; i += rows) {
       const long o = z * n + i;
       const float4 d = *reinterpret_cast<const float4*>(dhead + o * 4);
-      const float hv = h4[o * Hh + f], cv = hc[o * Hh + f];
+      const float hv = act_ld(h4, o * Hh + f, act), cv = act_ld(hc, o * Hh + f, act);
       a = fmaf(d.x, hv, a); c0 = fmaf(d.y, cv, c0); c1 = fmaf(d.z, cv, c1); c2 = fmaf(d.w, cv, c2);
     }
   red[0][threadIdx.x] = a; red[1][threadIdx.x] = c0; red[2][threadIdx.x] = c1; red[3][threadIdx.x] = c2;
@@ -1716,15 +1824,14 @@ struct Bf16Scope {
 
 // test hook (objnerf_train_args.relu_masks): one thread per (object, sample, byte of 8 features)
 __global__ void relu_mask_kernel(long nb, int H, const float* act /* [K n][H] */, uint8_t* masks /* [K n][6][H/8] */,
-                                 int layer) {
+                                 int layer, int act_mode) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nb) return;
   const int hb = H / 8;
   const long s = i / hb;
   const int b = (int)(i - s * hb);
-  const float* p = act + s * H + 8 * b;
   unsigned m = 0;
-  for (int j = 0; j < 8; ++j) m |= (p[j] > 0.0f ? 1u : 0u) << j;
+  for (int j = 0; j < 8; ++j) m |= (act_ld(act, s * H + 8 * b + j, act_mode) > 0.0f ? 1u : 0u) << j;
   masks[(s * 6 + layer) * hb + b] = (uint8_t)m;
 }
 
@@ -1759,7 +1866,10 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
   RedGroup step_red;                 // small-batch path: every ordered reduction of the step in ONE launch, after the join
   step_red.count = 0;
   struct PartsScope {
-    ~PartsScope() { t_parts = nullptr; t_parts_cap = t_parts_off = 0; t_red_group = nullptr; t_packb = nullptr; t_packb_entries = 0; }
+    ~PartsScope() {
+      t_parts = nullptr; t_parts_cap = t_parts_off = 0; t_red_group = nullptr; t_packb = nullptr; t_packb_entries = 0;
+      t_act16_lo = t_act16_hi = nullptr;
+    }
   } parts_scope;
   if (!a->pts) {
     const long total = (long)K * n;
@@ -1819,6 +1929,11 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
   // fp32 (one grouped launch)
   const bool small_bf = small_rt && t_bf16_operands == 1;
   if (small_rt) t_bf16_operands = 0;
+  // 16-bit modes at hidden 256 (configs[4]): h1 .. hc live in the operand type -- written by the forward GEMMs'
+  // epilogues, read as panels / masks / weight-gradient operands and by the head kernels (act_ld).  Their buffers keep
+  // the fp32 spacing in the workspace; gemm() recognises them by address.
+  const int act16 = (t_bf16_operands != 0 && H == 256 && OBJ_ACT16 && panel_ok((int)n, H, H + E1, 1, 1, false, K)) ? t_bf16_operands : 0;
+  if (act16) { t_act16_lo = (const char*)w.h1; t_act16_hi = (const char*)(w.hc + (size_t)K * n * H); }
   if (small_rt) {
     FwdSmall f;
     f.n = n; f.feat = feat ? 1 : 0; f.params = P; f.ps = ps; f.emb = w.emb;
@@ -1841,7 +1956,7 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
   gemm(st, K, n, H, H, w.h1, H, 1, nH, P + off[2], 1, H, ps, w.h2, H, 1, nH, false, P + off[3], ps, true);
   // h3 = relu([h2 | x1] W_cat^T + b)
   // ([h2 | x1] as ONE contraction when the resident-panel kernel takes it: no round trip of the partial result)
-  const bool fuse2 = panel_ok((int)n, H, H + E1, 1, 1, false, K) && H >= 192;
+  const bool fuse2 = panel_ok((int)n, H, H + E1, 1, 1, false, K) && H == 256;
   if (fuse2) {
     t_a2 = A2Src{w.emb, EM, n * EM, H};
     gemm(st, K, n, H, H + E1, w.h2, H, 1, nH, P + off[4], 1, H + E1, ps, w.h3, H, 1, nH, false, P + off[5], ps, true);
@@ -1860,7 +1975,7 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
        true);
   }
   hipLaunchKernelGGL(heads_fwd_kernel, eg, dim3(256), head_lds, st, H, n, w.h4, w.hc, P, ps, (int)off[8], (int)off[9],
-                     (int)off[12], (int)off[13], w.alpha, w.color);
+                     (int)off[12], (int)off[13], w.alpha, w.color, act16);
   if (feat) {
     gemm(st, K, n, H, H, w.h4, H, 1, nH, P + off[14], 1, H + E2, ps, w.hf, H, 1, nH);
     gemm(st, K, n, H, E2, w.emb + E1, EM, 1, n * EM, P + off[14] + H, 1, H + E2, ps, w.hf, H, 1, nH, true, P + off[15],
@@ -1873,7 +1988,7 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
     for (int l = 0; l < 6; ++l)
       if (acts[l])
         hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, nb, H, acts[l],
-                           a->relu_masks, l);
+                           a->relu_masks, l, l < 5 ? act16 : 0);
   }
   if (feat && multi) (void)hipStreamWaitEvent(st, sd.done, 0);      // the feature preparation (side stream) is needed from here
   // ---- loss + d(alpha, color, clip)      (loss.py:5-103)
@@ -1908,7 +2023,7 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
   float* d_hc = w.dA;      // [n][H]
   float* d_h4 = w.dB_;
   hipLaunchKernelGGL(heads_bwd_kernel, eg, dim3(256), head_lds, st, H, n, w.hc, w.color, w.d_alpha, w.d_color, P, ps,
-                     (int)off[8], (int)off[12], w.dhead, d_hc, d_h4);
+                     (int)off[8], (int)off[12], w.dhead, d_hc, d_h4, act16);
   // head weight grads: d wa = dhead[:,0]^T h4, d Woc = dhead[:,1:4]^T hc; biases = column sums of dhead
   // (every bias gradient rides on its layer's weight-gradient GEMM: row sums of the d-output operand tile)
   fork();
@@ -1926,7 +2041,7 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
     float* rA = parts_alloc((size_t)K * hb), *rW = parts_alloc((size_t)K * hb * 3);
     if (!(pA && pW && rA && rW)) pA = pW = rA = rW = nullptr;        // no scratch: float atomics
     hipLaunchKernelGGL(head_wgrad_kernel, dim3((unsigned)hb, (unsigned)K), dim3(256), 0, ss, H, n, w.dhead, w.h4, w.hc, G, ps,
-                       (int)off[8], (int)off[9], (int)off[12], (int)off[13], pA, pW, rA, rW);
+                       (int)off[8], (int)off[9], (int)off[12], (int)off[13], pA, pW, rA, rW, act16);
     if (pA) {
       RedGroup rg;
       rg.count = 2; rg.beg[0] = 0;
@@ -2103,7 +2218,7 @@ int eval_points(const objnerf_net* net, int K, long N, const float* params, long
        true);
   dim3 eg((unsigned)((n + 15) / 16), (unsigned)K);
   hipLaunchKernelGGL(heads_fwd_kernel, eg, dim3(256), (size_t)4 * H * sizeof(float), st, H, n, h4, hc, P, ps,
-                     (int)off[8], (int)off[9], (int)off[12], (int)off[13], out_alpha, out_color);
+                     (int)off[8], (int)off[9], (int)off[12], (int)off[13], out_alpha, out_color, 0);
   if (out_hfeat || out_clip) {
     float* hf = out_hfeat ? out_hfeat : bC;
     gemm(st, K, n, H, H, h4, H, 1, nH, P + off[14], 1, H + E2, ps, hf, H, 1, nH);
