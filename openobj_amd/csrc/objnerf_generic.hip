@@ -26,7 +26,8 @@ struct Gemm {
   int accumulate, relu;
   int splitk;      // > 1: blockIdx.z = batch * splitk + slice; each slice atomically adds its partial into C
   float* rowsum; long bsrs;   // optional: rowsum[m] += sum_k A(m,k)  (bias gradient riding on the weight-gradient GEMM)
-  const float* biasrow; long bsbr;   // optional per-row factor of the bias: + bias[n] * biasrow[m]
+  const float* biasrow; long bsbr;   // optional per-row factor of the bias: + bias[n] * biasrow[m sbr]
+  int sbr;
   float* part; float* rs_part;   // split-K with these set: slice s of batch z STORES its partial tile at part[((z sk + s) M + m)
                                  // N + n] (row sums: rs_part[(z sk + s) M + m]) and reduce_parts_kernel adds the slices in
                                  // order -- bit-reproducible; NULL: float atomics into C / rowsum
@@ -156,7 +157,7 @@ __device__ __forceinline__ void gemm_tile(const Gemm& g, const int bx, const int
             continue;
           }
           if (g.accumulate) v += *cp;
-          if (g.bias) v += g.bias[z * g.bsbias + n] * (g.biasrow ? g.biasrow[z * g.bsbr + m] : 1.0f);
+          if (g.bias) v += g.bias[z * g.bsbias + n] * (g.biasrow ? g.biasrow[z * g.bsbr + (long)m * g.sbr] : 1.0f);
           if (g.relu) v = fmaxf(v, 0.f);
           if (g.mask) v = g.mask[z * g.bsm + m * g.smm + n * g.smn] > 0.f ? v : 0.f;
           *cp = v;
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(512) void gemm_group_kernel(const GemmGroup gr) {
 #define OBJ_ACT16 1
 #endif
 #ifndef OBJ_G16_AFULL_NARROW
-#define OBJ_G16_AFULL_NARROW 0      // (the narrow input-gradient GEMMs, N = 87 / 42: measured no gain)
+#define OBJ_G16_AFULL_NARROW 1
 #endif
 #ifndef OBJ_G16_XCD
 #define OBJ_G16_XCD 1
@@ -598,7 +599,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 4 : 1) void gemm_bf1
           continue;
         }
         if (g.accumulate) v += *cp;
-        if (g.bias) v += g.bias[z * g.bsbias + n] * (g.biasrow ? g.biasrow[z * g.bsbr + m] : 1.0f);
+        if (g.bias) v += g.bias[z * g.bsbias + n] * (g.biasrow ? g.biasrow[z * g.bsbr + (long)m * g.sbr] : 1.0f);
         if (g.relu) v = fmaxf(v, 0.f);
         if (g.mask) {
           const long mi = z * g.bsm + m * g.smm + n * g.smn;
@@ -640,6 +641,7 @@ static thread_local float t_a_scale = 1.0f;       // Gemm::a_scale of the next g
 static thread_local GemmGroup* t_group = nullptr;     // non-null: gemm() collects descriptors instead of launching
 static thread_local const float* t_biasrow = nullptr;
 static thread_local long t_bsbr = 0;
+static thread_local int t_sbr = 1;
 
 // ---- deterministic split-K: partial-tile slabs + an ordered reduction (instead of float atomics)
 #ifndef OBJ_WGRAD_TARGET
@@ -770,7 +772,7 @@ static void gemm(hipStream_t st, int batch, int M, int N, int Kd, const float* A
   g.bias = bias; g.bsbias = bsbias; g.mask = mask; g.smm = smm; g.smn = smn; g.bsm = bsm;
   g.accumulate = accumulate; g.relu = relu; g.splitk = splitk;
   g.rowsum = rowsum; g.bsrs = bsrs;
-  g.biasrow = t_biasrow; g.bsbr = t_bsbr;
+  g.biasrow = t_biasrow; g.bsbr = t_bsbr; g.sbr = t_sbr;
   g.vec4 = 0; g.Bp = nullptr; g.A2 = nullptr; g.sam2 = g.bsa2 = 0; g.k2 = Kd;
   g.a16 = in_act16(A); g.b16 = in_act16(B); g.m16 = mask && in_act16(mask); g.c16 = in_act16(C);
   g.a_scale = t_bf16_operands == 2 ? t_a_scale : 1.0f;
@@ -1464,7 +1466,8 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(int Hh, long n, const fl
 }
 
 // heads backward: dhead[n][4] = (10 d_alpha, d_color * color (1 - color)); d_hc = relu'(hc) Woc^T d_craw;
-// d_h4 = wa * d_araw  (the colour-layer contribution is accumulated by a GEMM afterwards)
+// d_h4 = wa * d_araw  (the colour-layer contribution is accumulated by a GEMM afterwards; d_h4 == NULL: that GEMM adds
+// this rank-1 term itself -- bias = wa, per-row factor = dhead[:, 0] -- and the 2 x n x H round trip is saved)
 __global__ __launch_bounds__(256) void heads_bwd_kernel(int Hh, long n, const float* hc, const float* color,
                                                         const float* d_alpha, const float* d_color, const float* params,
                                                         long p_stride, int off_wa, int off_woc, float* dhead, float* d_hc,
@@ -1497,7 +1500,7 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(int Hh, long n, const fl
     v.x = hv.x > 0.f ? v.x : 0.f; v.y = hv.y > 0.f ? v.y : 0.f; v.z = hv.z > 0.f ? v.z : 0.f; v.w = hv.w > 0.f ? v.w : 0.f;
     u.x = w0[0] * da; u.y = w0[1] * da; u.z = w0[2] * da; u.w = w0[3] * da;
     *reinterpret_cast<float4*>(d_hc + o * Hh + h) = v;
-    *reinterpret_cast<float4*>(d_h4 + o * Hh + h) = u;
+    if (d_h4) *reinterpret_cast<float4*>(d_h4 + o * Hh + h) = u;
   }
 }
 
@@ -2022,8 +2025,11 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
   };
   float* d_hc = w.dA;      // [n][H]
   float* d_h4 = w.dB_;
+  // (layer-wise chain without the feature branch: the colour layer's input-gradient GEMM adds the alpha head's rank-1
+  // term wa x dhead[:, 0] in its epilogue, so d_h4 is written once instead of written, read and written)
+  const bool fold_a = !feat && !small_rt;
   hipLaunchKernelGGL(heads_bwd_kernel, eg, dim3(256), head_lds, st, H, n, w.hc, w.color, w.d_alpha, w.d_color, P, ps,
-                     (int)off[8], (int)off[12], w.dhead, d_hc, d_h4, act16);
+                     (int)off[8], (int)off[12], w.dhead, d_hc, fold_a ? nullptr : d_h4, act16);
   // head weight grads: d wa = dhead[:,0]^T h4, d Woc = dhead[:,1:4]^T hc; biases = column sums of dhead
   // (every bias gradient rides on its layer's weight-gradient GEMM: row sums of the d-output operand tile)
   fork();
@@ -2125,7 +2131,14 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
   fork();
   wgrad(ss, K, H, H, n, d_hc, 1, H, nH, w.h4, H, 1, nH, G + off[10], H + E2, ps, G + off[11]);
   wgrad(ss, K, H, E2, n, d_hc, 1, H, nH, w.emb + E1, EM, 1, n * EM, G + off[10] + H, H + E2, ps);
-  gemm(st, K, n, H, H, d_hc, H, 1, nH, P + off[10], H + E2, 1, ps, d_h4, H, 1, nH, true, nullptr, 0, false, w.h4, H, 1, nH);
+  if (fold_a) {
+    t_biasrow = w.dhead; t_bsbr = n * 4; t_sbr = 4;
+    gemm(st, K, n, H, H, d_hc, H, 1, nH, P + off[10], H + E2, 1, ps, d_h4, H, 1, nH, false, P + off[8], ps, false, w.h4, H, 1,
+         nH);
+    t_biasrow = nullptr; t_bsbr = 0; t_sbr = 1;
+  } else {
+    gemm(st, K, n, H, H, d_hc, H, 1, nH, P + off[10], H + E2, 1, ps, d_h4, H, 1, nH, true, nullptr, 0, false, w.h4, H, 1, nH);
+  }
   gemm(st, K, n, E2, H, d_hc, H, 1, nH, P + off[10] + H, H + E2, 1, ps, w.d_emb + E1, EM, 1, n * EM, feat);
   // mid2:  d_h4 (masked above) -> grads, d_h3
   fork();
