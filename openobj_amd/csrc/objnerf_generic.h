@@ -14,7 +14,7 @@ int step_batch_loss_impl(const objnerf_loss_args* a, const LossHoisted* hz, void
 }  // namespace objmisc
 
 namespace objgen {
-size_t train_workspace_bytes(const objnerf_net* net, int K, int R, int S, int feat);
+size_t train_workspace_bytes(const objnerf_net* net, int K, int R, int S, int feat, int sixteen = 0);
 int train_step(const objnerf_net* net, const objnerf_train_args* a, void* stream);
 // the batched fp32 MFMA GEMM of this path, for the feature-head kernels of objnerf_train.hip:
 //   C[z][m][n] (+)= sum_k A(z; m,k) B(z; k,n), element strides (sam, sak), (sbk, sbn), (scm, scn), batch strides bs*

@@ -1713,18 +1713,23 @@ struct WS {
   float *dA, *dB_, *dC, *dD, *dE, *d_emb, *dBpe, *pts;
   float* parts; size_t parts_floats;      // split-K partial slabs of the step's weight-gradient GEMMs (wgrad())
   float* loss_part;                       // [K R][4] block partials of the loss terms
-  float* packb;                           // [K][65536] 16-bit: packed B image of the AFULL layer GEMM in flight
+  float* packb;                           // [K][90112] 16-bit: packed B image of the AFULL layer GEMM in flight
+  size_t act_floats;                      // room of each of h1 .. hc (floats)
   int* counts;
   size_t bytes;
 };
 
-static WS carve(char* base, int H, int C, long n, long R, int K, bool feat) {
+// the 16-bit modes keep h1 .. hc in the operand type when the resident-panel GEMMs serve the shape (hidden 256, >= 4096
+// samples per object): those five buffers then take half the room
+static bool acts16_shape(int H, long n) { return OBJ_ACT16 && OBJ_G16_AFULL && H == 256 && n >= 4096; }
+static WS carve(char* base, int H, int C, long n, long R, int K, bool feat, bool half_acts = false) {
   WS w;
   char* p = base;
   auto take = [&](size_t floats) { float* r = (float*)p; p += al(floats * 4); return r; };
   w.emb = take((size_t)K * n * OBJ_EMB);
-  w.h1 = take((size_t)K * n * H); w.h2 = take((size_t)K * n * H); w.h3 = take((size_t)K * n * H);
-  w.h4 = take((size_t)K * n * H); w.hc = take((size_t)K * n * H);
+  const size_t act = half_acts ? (size_t)K * n * H / 2 : (size_t)K * n * H;
+  w.h1 = take(act); w.h2 = take(act); w.h3 = take(act); w.h4 = take(act); w.hc = take(act);
+  w.act_floats = act;
   w.hf = feat ? take((size_t)K * n * H) : nullptr;
   w.d_hf = feat ? take((size_t)K * n * H) : nullptr;
   w.rayin = feat ? take((size_t)K * R * (H + 2)) : nullptr;
@@ -1770,8 +1775,9 @@ static WS carve(char* base, int H, int C, long n, long R, int K, bool feat) {
   return w;
 }
 
-size_t train_workspace_bytes(const objnerf_net* net, int K, int R, int S, int feat) {
-  WS w = carve(nullptr, net->hidden, net->feat_dim, (long)R * S, (long)R, K, feat != 0);
+size_t train_workspace_bytes(const objnerf_net* net, int K, int R, int S, int feat, int sixteen) {
+  WS w = carve(nullptr, net->hidden, net->feat_dim, (long)R * S, (long)R, K, feat != 0,
+               sixteen && acts16_shape(net->hidden, (long)R * S));
   return w.bytes + 256;
 }
 
@@ -1862,7 +1868,8 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
   objnerf_param_layout(net, off);
   const long ps = a->p_stride;
   hipStream_t st = (hipStream_t)stream;
-  WS w = carve((char*)a->workspace, H, C, n, (long)a->R, K, feat);
+  const bool half_acts = (a->mode & (OBJNERF_TRAIN_FP16 | OBJNERF_TRAIN_BF16)) != 0 && acts16_shape(H, n);
+  WS w = carve((char*)a->workspace, H, C, n, (long)a->R, K, feat, half_acts);
   if (a->workspace_bytes < w.bytes) return OBJNERF_EINVAL;
   t_parts = w.parts; t_parts_cap = w.parts_floats; t_parts_off = 0;
   t_packb = w.packb; t_packb_entries = w.packb ? K : 0;
@@ -1935,8 +1942,9 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
   // 16-bit modes at hidden 256 (configs[4]): h1 .. hc live in the operand type -- written by the forward GEMMs'
   // epilogues, read as panels / masks / weight-gradient operands and by the head kernels (act_ld).  Their buffers keep
   // the fp32 spacing in the workspace; gemm() recognises them by address.
-  const int act16 = (t_bf16_operands != 0 && H == 256 && OBJ_ACT16 && panel_ok((int)n, H, H + E1, 1, 1, false, K)) ? t_bf16_operands : 0;
-  if (act16) { t_act16_lo = (const char*)w.h1; t_act16_hi = (const char*)(w.hc + (size_t)K * n * H); }
+  const int act16 = half_acts ? t_bf16_operands : 0;
+  if (act16 && !panel_ok((int)n, H, H + E1, 1, 1, false, K)) return OBJNERF_EINVAL;      // (cannot happen: same conditions)
+  if (act16) { t_act16_lo = (const char*)w.h1; t_act16_hi = (const char*)(w.hc + w.act_floats); }
   if (small_rt) {
     FwdSmall f;
     f.n = n; f.feat = feat ? 1 : 0; f.params = P; f.ps = ps; f.emb = w.emb;

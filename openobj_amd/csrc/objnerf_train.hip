@@ -1023,7 +1023,7 @@ static int train_grid(int K, int NT) {
 size_t objnerf_train_workspace_bytes(const objnerf_net* net, int32_t K, int32_t R, int32_t S, int32_t with_feat) {
   if (!net || K <= 0 || R <= 0 || S <= 0) return 0;
   // bit 1 of with_feat (value 2): size for the layer-wise path (OBJNERF_TRAIN_LAYERWISE)
-  if (net->hidden != 32 || S > 64 || (with_feat & 2)) return objgen::train_workspace_bytes(net, K, R, S, with_feat & 1);
+  if (net->hidden != 32 || S > 64 || (with_feat & 2)) return objgen::train_workspace_bytes(net, K, R, S, with_feat & 1, (with_feat & 4) != 0);
   with_feat &= 1;
   int64_t offs[OBJNERF_N_TENSORS + 1];
   const int64_t ps = objnerf_param_layout(net, offs);
@@ -1049,7 +1049,8 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
   if ((a->mode & OBJNERF_TRAIN_FP16) && (a->mode & OBJNERF_TRAIN_BF16)) return OBJNERF_EINVAL;
   if (net->hidden != 32 || a->S > 64 || (a->mode & (OBJNERF_TRAIN_LAYERWISE | OBJNERF_TRAIN_FP16))) {
     // wider networks (background: hidden 128) and long rays: layer-wise path, activations in the workspace
-    if (a->workspace_bytes < objgen::train_workspace_bytes(net, a->K, a->R, a->S, a->gt_feat != nullptr))
+    if (a->workspace_bytes < objgen::train_workspace_bytes(net, a->K, a->R, a->S, a->gt_feat != nullptr,
+                                                           (a->mode & (OBJNERF_TRAIN_FP16 | OBJNERF_TRAIN_BF16)) != 0))
       return OBJNERF_EINVAL;
     (void)hipMemsetAsync(a->status, 0, sizeof(int), (hipStream_t)stream);
     return objgen::train_step(net, a, stream);

@@ -327,7 +327,7 @@ class TrainWorkspace:
         layerwise = layerwise or precision_bits(precision) == 4          # the fp16 mode lives on the layer-wise path
         dev = arena.params.device
         net = arena.net.c()
-        wf = int(with_feat) | (2 if layerwise else 0)
+        wf = int(with_feat) | (2 if layerwise else 0) | (4 if precision_bits(precision) in (1, 4) else 0)   # bit 2: 16-bit modes only
         budget = LAYERWISE_WORKSPACE_BUDGET if budget is None else budget
         self.k_chunk = K
         nbytes = lib().objnerf_train_workspace_bytes(C.byref(net), K, R, S, wf)
