@@ -87,10 +87,14 @@ def test_bf16_psnr_matches_reference_ensemble(dev):
 
 
 @pytest.mark.parametrize("feat", [False, True])
-def test_bf16_background_step_close_to_fp32(dev, feat):
-    """The layer-wise path (hidden 128, the background network) with bf16 GEMM operands against its fp32 self."""
+@pytest.mark.parametrize("net", [(1, 600, 128), (2, 96, 256)])
+def test_bf16_background_step_close_to_fp32(dev, feat, net):
+    """The layer-wise path with bf16 GEMM operands against its fp32 self: hidden 128 (the background network) and
+    hidden 256 with >= 4096 samples per object (configs[4]: resident-panel GEMMs, the concatenated layers as one
+    contraction, activations stored in bf16 -- sized with the 16-bit bit of objnerf_train_workspace_bytes)."""
     from openobj_amd import init as obj_init
-    K, R, n1, n2, H = 1, 600, 16, 48, 128
+    K, R, H = net
+    n1, n2 = 16, 48
     arena = ops.ParamArena(K, ops.NetShape(H, 512, 6), dev)
     arena.load_stacked(obj_init.init_stacked(K, H, 512, seed=3))
     arena.scale.fill_(5.0)
@@ -98,10 +102,13 @@ def test_bf16_background_step_close_to_fp32(dev, feat):
     keys = ["pts", "z", "gt_depth", "gt_rgb", "labels"] + (["gt_feat"] if feat else [])
     batch = {k: T(b[k]).to(dev) for k in keys}
     ws32 = ops.TrainWorkspace(arena, K, R, n1 + n2, feat)
-    ws16 = ops.TrainWorkspace(arena, K, R, n1 + n2, feat)
+    ws16 = ops.TrainWorkspace(arena, K, R, n1 + n2, feat, precision="bf16")
+    if H == 256:
+        assert ws16.nbytes < 0.9 * ws32.nbytes           # h1 .. hc in 16 bit (-15 %)
     ops.train_step(arena, ws32, batch, with_feat=feat)
     ops.train_step(arena, ws16, batch, with_feat=feat, bf16=True)
     torch.cuda.synchronize()
+    assert int(ws16.status.item()) == 0 and bool(torch.isfinite(ws16.grads).all())
     np.testing.assert_allclose(ws16.loss_terms.cpu(), ws32.loss_terms.cpu(), rtol=3e-2, atol=3e-3)
     g32, g16 = arena.views(ws32.grads), arena.views(ws16.grads)
     for i in range(19):
