@@ -273,7 +273,7 @@ int objnerf_label_counts(int32_t K, int32_t R, const uint8_t* labels, int32_t* c
  * left untouched), loss_terms [K][4], status [1].
  * workspace: objnerf_train_workspace_bytes() bytes, 256-byte aligned (its with_feat argument: bit 0 = feature
  * loss, bit 1 = size for OBJNERF_TRAIN_LAYERWISE, bit 2 = size for the 16-bit modes only -- at hidden 256 they keep
- * the five activation buffers in the operand type, 15 % less; a workspace sized without bit 2 serves every mode).
+ * the five activation and five gradient buffers in the operand type, a third less; a workspace sized without bit 2 serves every mode).
  */
 #define OBJNERF_TRAIN_BF16 1   /* mode bit: MFMA operands rounded to bf16 (fp32 accumulate, fp32 master weights,
                                 * fp32 embedding/compositing/losses).  NOT the reference's arithmetic (fp32,

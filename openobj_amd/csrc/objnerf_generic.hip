@@ -413,7 +413,18 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 4 : 1) void gemm_bf1
   }
   // element e of a thread's share -> (row, k): lanes along the operand's contiguous dimension
   auto load_tiles = [&](int k0) {
-    if (AKM && g.vec4) {
+    if (AKM && g.a16) {
+      // A is a 16-bit gradient array (stored already scaled by a_scale): four consecutive m per lane, one 8-byte load,
+      // passed through to the k-major image (host-checked alignment)
+      const OT* A16 = reinterpret_cast<const OT*>(g.A) + z * g.bsa;
+#pragma unroll
+      for (int i = 0; i < NA / 4; ++i) {
+        const int q = tid + NTH * i, am = 4 * (q % (BM / 4)), ak = q / (BM / 4);
+        const int gm = m0 + am, gk = k0 + ak;
+        const uint2 u = (gm < g.M && gk < kend) ? *reinterpret_cast<const uint2*>(A16 + gk * g.sak + gm) : uint2{0u, 0u};
+        ra[2 * i] = __builtin_bit_cast(float, u.x); ra[2 * i + 1] = __builtin_bit_cast(float, u.y);
+      }
+    } else if (AKM && g.vec4) {
       // rows contiguous and 16-byte aligned (weight gradients: A = d_out^T): four consecutive m per lane, one dwordx4
 #pragma unroll
       for (int i = 0; i < NA / 4; ++i) {
@@ -456,6 +467,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 4 : 1) void gemm_bf1
   };
   auto store_tiles = [&]() {
     if (AFULL) {
+    } else if (AKM && g.a16) {
+#pragma unroll
+      for (int i = 0; i < NA / 4; ++i) {
+        const int q = tid + NTH * i;
+        *reinterpret_cast<uint2*>(&Asm[(q / (BM / 4)) * PA + 4 * (q % (BM / 4))]) =
+            uint2{__builtin_bit_cast(uint32_t, ra[2 * i]), __builtin_bit_cast(uint32_t, ra[2 * i + 1])};
+      }
     } else if (AKM && g.vec4) {
 #pragma unroll
       for (int i = 0; i < NA / 4; ++i) {
@@ -598,7 +616,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 4 : 1) void gemm_bf1
           else atomicAdd(cp, v);
           continue;
         }
-        if (g.accumulate) v += *cp;
+        if (g.accumulate) v += g.c16 ? (float)reinterpret_cast<const OT*>(g.C)[z * g.bsc + m * g.scm + n * g.scn] * inv_scale : *cp;
         if (g.bias) v += g.bias[z * g.bsbias + n] * (g.biasrow ? g.biasrow[z * g.bsbr + (long)m * g.sbr] : 1.0f);
         if (g.relu) v = fmaxf(v, 0.f);
         if (g.mask) {
@@ -606,7 +624,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 4 : 1) void gemm_bf1
           const bool on = g.m16 ? (float)reinterpret_cast<const OT*>(g.mask)[mi] > 0.f : g.mask[mi] > 0.f;
           v = on ? v : 0.f;
         }
-        if (g.c16) reinterpret_cast<OT*>(g.C)[z * g.bsc + m * g.scm + n * g.scn] = Op16<OT>::cvt(v);
+        // (16-bit outputs are stored as the NEXT GEMM's operand: gradients already scaled by a_scale -- 1 in the forward)
+        if (g.c16) reinterpret_cast<OT*>(g.C)[z * g.bsc + m * g.scm + n * g.scn] = Op16<OT>::cvt(v * a_scale);
         else *cp = v;
       }
     }
@@ -738,7 +757,12 @@ static thread_local long t_packb_entries = 0;
 // lies inside (Gemm::a16 / b16 / m16 / c16)
 static thread_local const char* t_act16_lo = nullptr;
 static thread_local const char* t_act16_hi = nullptr;
-static bool in_act16(const void* p) { return t_act16_lo && (const char*)p >= t_act16_lo && (const char*)p < t_act16_hi; }
+static thread_local const char* t_grad16_lo = nullptr;   // the same for d_hc, d_h4 .. d_h1 (stored scaled by a_scale)
+static thread_local const char* t_grad16_hi = nullptr;
+static bool in_act16(const void* p) {
+  return (t_act16_lo && (const char*)p >= t_act16_lo && (const char*)p < t_act16_hi) ||
+         (t_grad16_lo && (const char*)p >= t_grad16_lo && (const char*)p < t_grad16_hi);
+}
 struct A2Src { const float* A2; long sam2, bsa2; int k2; };
 static thread_local A2Src t_a2 = {nullptr, 0, 0, 0};  // second A source of the NEXT gemm() call (Gemm::A2), panel path only
 // the layer GEMMs the resident-panel kernel takes (16-bit modes, rows k-contiguous, contraction <= 352, N <= 256)
@@ -800,7 +824,7 @@ static void gemm(hipStream_t st, int batch, int M, int N, int Kd, const float* A
       t_a2.A2 = nullptr;
       g.vec4 = (ka % 8 == 0 && sam % 8 == 0 && bsa % 8 == 0 && ((uintptr_t)A & 15) == 0) ? 1 : 0;
       if (g.a16 && !g.vec4) { fprintf(stderr, "objnerf: 16-bit activation panel needs aligned rows\n"); abort(); }
-      if (g.c16 && (accumulate || g.b16)) { fprintf(stderr, "objnerf: unsupported 16-bit GEMM operands\n"); abort(); }
+      if (g.c16 && g.b16) { fprintf(stderr, "objnerf: unsupported 16-bit GEMM operands\n"); abort(); }
       g.Bp = t_packb;
       const dim3 pgrid(1, (M + 63) / 64, nz);
 #define OBJ_G16_PANEL(OT_, KM_)                                                                                         \
@@ -815,7 +839,7 @@ static void gemm(hipStream_t st, int batch, int M, int N, int Kd, const float* A
     }
     t_a2.A2 = nullptr;
     g.vec4 = (akm && sak % 4 == 0 && bsa % 4 == 0 && M % 4 == 0 && ((uintptr_t)A & 15) == 0) ? 1 : 0;
-    if (g.a16 || g.c16 || (g.b16 && !(bkm && sbk % 4 == 0 && N % 4 == 0 && bsb % 4 == 0))) {
+    if ((g.a16 && !(akm && g.vec4)) || g.c16 || (g.b16 && !(bkm && sbk % 4 == 0 && N % 4 == 0 && bsb % 4 == 0))) {
       fprintf(stderr, "objnerf: 16-bit activations in a GEMM shape that does not take them\n");
       abort();
     }
@@ -1430,6 +1454,22 @@ __device__ __forceinline__ float4 act_ld4(const float* p, long i, int act) {    
   return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
 }
 
+__device__ __forceinline__ void act_st4(float* p, long i, float4 v, int act, float scale) {     // i % 4 == 0
+  if (act == 0) { *reinterpret_cast<float4*>(p + i) = v; return; }
+  uint2 r;
+  if (act == 1) {
+    typedef __bf16 b4_t __attribute__((ext_vector_type(4)));
+    const b4_t b = {(__bf16)(v.x * scale), (__bf16)(v.y * scale), (__bf16)(v.z * scale), (__bf16)(v.w * scale)};
+    r = __builtin_bit_cast(uint2, b);
+  } else {
+    typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+    const h4_t h = {Op16<_Float16>::cvt(v.x * scale), Op16<_Float16>::cvt(v.y * scale), Op16<_Float16>::cvt(v.z * scale),
+                    Op16<_Float16>::cvt(v.w * scale)};
+    r = __builtin_bit_cast(uint2, h);
+  }
+  *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p) + i) = r;
+}
+
 // heads forward: alpha = 10 (h4 . wa + ba), color = sigmoid(hc Woc^T + boc)        (model.py:81-96)
 // 16 lanes per sample row (float4 each, coalesced), the four dot products meet by DPP row sums.
 __global__ __launch_bounds__(256) void heads_fwd_kernel(int Hh, long n, const float* h4, const float* hc,
@@ -1471,7 +1511,7 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(int Hh, long n, const fl
 __global__ __launch_bounds__(256) void heads_bwd_kernel(int Hh, long n, const float* hc, const float* color,
                                                         const float* d_alpha, const float* d_color, const float* params,
                                                         long p_stride, int off_wa, int off_woc, float* dhead, float* d_hc,
-                                                        float* d_h4, int act) {
+                                                        float* d_h4, int act, float gscale) {
   extern __shared__ float sw[];            // wa | woc[3]
   const long z = blockIdx.y;
   const float* P = params + z * p_stride;
@@ -1499,8 +1539,9 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(int Hh, long n, const fl
     v.w = fmaf(w0[3 * Hh + 3], dc[2], fmaf(w0[2 * Hh + 3], dc[1], w0[Hh + 3] * dc[0]));
     v.x = hv.x > 0.f ? v.x : 0.f; v.y = hv.y > 0.f ? v.y : 0.f; v.z = hv.z > 0.f ? v.z : 0.f; v.w = hv.w > 0.f ? v.w : 0.f;
     u.x = w0[0] * da; u.y = w0[1] * da; u.z = w0[2] * da; u.w = w0[3] * da;
-    *reinterpret_cast<float4*>(d_hc + o * Hh + h) = v;
-    if (d_h4) *reinterpret_cast<float4*>(d_h4 + o * Hh + h) = u;
+    // (act != 0: the gradient buffers are 16-bit too, stored as the next GEMM's operand -- scaled by gscale)
+    act_st4(d_hc, o * Hh + h, v, act, gscale);
+    if (d_h4) act_st4(d_h4, o * Hh + h, u, act, gscale);
   }
 }
 
@@ -1742,8 +1783,7 @@ static WS carve(char* base, int H, int C, long n, long R, int K, bool feat, bool
   w.alpha = take((size_t)K * n); w.color = take((size_t)K * n * 3);
   w.d_alpha = take((size_t)K * n); w.d_color = take((size_t)K * n * 3);
   w.dhead = take((size_t)K * n * 4);
-  w.dA = take((size_t)K * n * H); w.dB_ = take((size_t)K * n * H);
-  w.dC = take((size_t)K * n * H); w.dD = take((size_t)K * n * H); w.dE = take((size_t)K * n * H);
+  w.dA = take(act); w.dB_ = take(act); w.dC = take(act); w.dD = take(act); w.dE = take(act);
   w.d_emb = take((size_t)K * n * OBJ_EMB);
   w.dBpe = take((size_t)K * 64);
   w.pts = take((size_t)K * n * 3);          // sample positions of the origins / directions form of the batch
@@ -1878,7 +1918,7 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
   struct PartsScope {
     ~PartsScope() {
       t_parts = nullptr; t_parts_cap = t_parts_off = 0; t_red_group = nullptr; t_packb = nullptr; t_packb_entries = 0;
-      t_act16_lo = t_act16_hi = nullptr;
+      t_act16_lo = t_act16_hi = t_grad16_lo = t_grad16_hi = nullptr;
     }
   } parts_scope;
   if (!a->pts) {
@@ -1944,7 +1984,10 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
   // the fp32 spacing in the workspace; gemm() recognises them by address.
   const int act16 = half_acts ? t_bf16_operands : 0;
   if (act16 && !panel_ok((int)n, H, H + E1, 1, 1, false, K)) return OBJNERF_EINVAL;      // (cannot happen: same conditions)
-  if (act16) { t_act16_lo = (const char*)w.h1; t_act16_hi = (const char*)(w.hc + w.act_floats); }
+  if (act16) {
+    t_act16_lo = (const char*)w.h1; t_act16_hi = (const char*)(w.hc + w.act_floats);
+    t_grad16_lo = (const char*)w.dA; t_grad16_hi = (const char*)(w.dE + w.act_floats);
+  }
   if (small_rt) {
     FwdSmall f;
     f.n = n; f.feat = feat ? 1 : 0; f.params = P; f.ps = ps; f.emb = w.emb;
@@ -2037,7 +2080,8 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
   // term wa x dhead[:, 0] in its epilogue, so d_h4 is written once instead of written, read and written)
   const bool fold_a = !feat && !small_rt;
   hipLaunchKernelGGL(heads_bwd_kernel, eg, dim3(256), head_lds, st, H, n, w.hc, w.color, w.d_alpha, w.d_color, P, ps,
-                     (int)off[8], (int)off[12], w.dhead, d_hc, fold_a ? nullptr : d_h4, act16);
+                     (int)off[8], (int)off[12], w.dhead, d_hc, fold_a ? nullptr : d_h4, act16,
+                     act16 == 2 ? grad_scale : 1.0f);
   // head weight grads: d wa = dhead[:,0]^T h4, d Woc = dhead[:,1:4]^T hc; biases = column sums of dhead
   // (every bias gradient rides on its layer's weight-gradient GEMM: row sums of the d-output operand tile)
   fork();
