@@ -241,7 +241,9 @@ template <> struct Op16<_Float16> {
 };
 // BKB: k-stage depth (OBJ_G16_BK / OBJ_G16_BK_WIDE).  Measured on MI355X (tools/gemm16_ab.sh): deeper stages LOSE --
 // background step in bf16 mode 0.92 ms at 32, 1.19 ms at 64, 2.2 ms at 128; configs[4] share in fp16 2.18 / 2.37 /
-// 2.60 s -- the prefetch registers and the larger LDS tiles cost more occupancy than the saved barriers return.
+// 2.60 s -- the prefetch registers and the larger LDS tiles cost more occupancy than the saved barriers return.  (Again
+// with both weight-gradient operands 16-bit pass-through, 8 registers per stage: share per 8 objects 83 ms at 32,
+// 104 at 64, 85 at 128.)
 // WM x WN waves per workgroup, TM x TN MFMA tiles per wave.  The 128 x 128 tile runs on 8 waves (4 x 2, 32 x 64 per wave:
 // 32 accumulator and 16 staging registers): as 4 waves of 64 x 64 it needed 197 registers, ONE wave per SIMD, and ran
 // the hidden-256 layer GEMMs at 28 TFLOP/s -- slower than the fp32 kernel.

@@ -104,7 +104,7 @@ def test_bf16_background_step_close_to_fp32(dev, feat, net):
     ws32 = ops.TrainWorkspace(arena, K, R, n1 + n2, feat)
     ws16 = ops.TrainWorkspace(arena, K, R, n1 + n2, feat, precision="bf16")
     if H == 256:
-        assert ws16.nbytes < 0.75 * ws32.nbytes          # h1 .. hc and d_hc .. d_h1 in 16 bit
+        assert ws16.nbytes < (0.8 if feat else 0.75) * ws32.nbytes          # h1 .. hc and d_hc .. d_h1 in 16 bit
     ops.train_step(arena, ws32, batch, with_feat=feat)
     ops.train_step(arena, ws16, batch, with_feat=feat, bf16=True)
     torch.cuda.synchronize()
