@@ -43,6 +43,7 @@ from openobj_amd import ops, synthetic    # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA
+PEAK_HBM_GBS = 8000.0             # HBM3E, MI355X_MICROARCH.md
 VALU_SIMDS = 256 * 4              # SIMDs of the chip
 VALU_CYCLES_PER_INST = 2.0        # a wave64 VALU instruction occupies its SIMD-32 for 2 cycles (cycle-constants table)
 CLOCK_HZ = 2.4e9
@@ -325,10 +326,21 @@ def main():
                                 "no recorded PMC pass for this workload",
                 "kernel": kname, "kernel_ms": kern_ms, "flop_per_ray": fpr,
                 "algorithmic_bytes_per_launch": K * R * (S * 16 + 17 + (2048 * 2 if feat else 0))}
+        if not fused and bf16 and Hd == 256 and not feat:
+            # configs[4] in the 16-bit modes: every kernel of the layer-wise chain streams its operands once and is
+            # HBM-bound.  Algorithmic bytes per sample: activations and back-propagated
+            # gradients 2 H bytes each per pass, the fp32 embedding rows / their gradient as stored.
+            bps = (1408 + 22 * Hd) + (2604 + 60 * Hd)
+            gbs = K * R * S * bps / (kern_ms * 1e-3) / 1e9
+            roof.update({"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                         "algorithmic_bytes_per_launch": K * R * S * bps, "bytes_per_sample": bps,
+                         "mfma_tflops": achieved, "frac_of_bf16_mfma_peak": achieved / peak,
+                         "note": "layer-wise chain, 16-bit activations and gradients; bytes per sample = forward "
+                                 "1408 + 22 H, backward 2604 + 60 H (each buffer counted once per kernel that streams it)"})
         if not args.no_peak:
             pm = measured_mfma_peak(dev, 1 if bf16 else 0)
             roof["peak_measured"] = pm
-            roof["frac_of_measured_peak"] = achieved / pm
+            roof["frac_of_measured_peak"] = achieved / pm          # (of the measured MFMA peak)
         out = {
             "metric": "training rays/sec/GPU @64 samples/ray, 50 obj; PSNR delta vs ref",
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -23,6 +23,11 @@ python3 $R/bench.py --config c3 --steps 10 --warmup 3 $Q > $OUT/bench_c3.json 2>
 python3 $R/bench.py --config c4 --steps 5 --warmup 2 $Q > $OUT/bench_c4.json 2>/dev/null
 python3 $R/bench.py --config c5 --steps 2 --warmup 1 $Q --no-bf16-line > $OUT/bench_c5.json 2>/dev/null
 python3 $R/bench.py --config c5 --dtype fp16 --steps 2 --warmup 1 $Q > $OUT/bench_c5_fp16.json 2>/dev/null
+python3 $R/bench.py --config c5 --dtype bf16 --steps 2 --warmup 1 $Q > $OUT/bench_c5_bf16.json 2>/dev/null
+# the layer-wise kernels of the configs[4] share in bf16 mode (resident-panel GEMMs, split-K weight gradients)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c5_bf16 -o s -- python3 $R/bench.py --config c5 --dtype bf16 --objects 8 --steps 2 --warmup 1 --no-bg $Q > /dev/null 2> $OUT/stats_c5_bf16.err
+# fp32 layer chain against its three-bf16-piece emulation (tools/ubench_x3.hip, built in-tree before the call)
+[ -x $R/openobj_amd/csrc/abl/ubench_x3 ] && $R/openobj_amd/csrc/abl/ubench_x3 > $OUT/ubench_x3.txt 2>&1
 # the two-collective iteration over RCCL with one rank (the multi-GPU code path on the one GPU there is)
 OBJNERF_DIST_SELFTEST=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 $R/bench.py --gpus 1 --steps 10 --warmup 3 $Q 2>/dev/null | tail -1 > $OUT/bench_dist_selftest.json
 for d in pmc_fetch pmc_write pmc_sq pmc_sq2; do
