@@ -49,6 +49,25 @@ def test_param_layout_matches_reference_counts(H, P):
     assert sizes[18] == 63
 
 
+def test_train_workspace_sizes():
+    """objnerf_train_workspace_bytes is pure host arithmetic: its with_feat bit field (bit 0 feature loss, bit 1
+    layer-wise sizing, bit 2 sizing for the 16-bit modes) -- bit 2 only changes the hidden-256 / >= 4096-sample shape,
+    where activations and back-propagated gradients live in the operand type."""
+    import ctypes as C
+    from openobj_amd import ops
+    l = _lib.lib()
+    def size(H, K, R, S, wf):
+        net = ops.NetShape(H, 512, 6).c()
+        return int(l.objnerf_train_workspace_bytes(C.byref(net), K, R, S, wf))
+    full, half = size(256, 2, 64, 64, 0), size(256, 2, 64, 64, 4)
+    assert 0 < half < 0.75 * full
+    assert size(256, 2, 64, 64, 1) > full and size(256, 2, 64, 64, 5) < size(256, 2, 64, 64, 1)
+    assert size(256, 2, 32, 64, 4) == size(256, 2, 32, 64, 0)          # 2048 samples per object: fp32 storage
+    assert size(128, 1, 1200, 64, 4) == size(128, 1, 1200, 64, 0)      # hidden 128: fp32 storage
+    assert size(32, 50, 4096, 64, 4) == size(32, 50, 4096, 64, 0)      # fused kernel: slabs only
+    assert size(32, 50, 4096, 64, 2) > size(32, 50, 4096, 64, 0)       # bit 1: the layer-wise path's activations
+
+
 def test_missing_library_is_loud(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "_lib", None)
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
