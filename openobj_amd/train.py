@@ -131,6 +131,7 @@ class ShardedIteration:
                 gflags, bg_counts, bg_flags = odist.unpack_pre(pre)
                 if side is not None:
                     main.wait_stream(side)                         # (the object kernel needs the global flags)
+                    gflags.record_stream(main)                     # (allocated on the second stream, read on this one)
             if do_bg:
                 work = self.bg_loop.begin(bg_batch, bg_counts, bg_flags)      # collective 2 starts here
         obj_terms = bg_terms = None
