@@ -328,7 +328,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 4 : 1) void gemm_bf1
   const int slice = bz % sk;
   const float* A = g.A + z * g.bsa;
   const float* B = g.B + z * g.bsb;
-  float* C = g.C + z * g.bsc;
   const int kper = ((g.Kd + sk - 1) / sk + BKB - 1) / BKB * BKB;
   const int kbeg = slice * kper, kend = min(g.Kd, kbeg + kper);
   f32x4 acc[TM][TN];
@@ -607,28 +606,34 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 4 : 1) void gemm_bf1
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const int n = n0 + EC * wn + ecol;
+    // (element offsets of the strip's first row, advanced by one row pass each: the per-row 64-bit products of the
+    // generic strides were most of this kernel's VALU work -- 15 instructions per MFMA on the hidden-256 layer GEMMs)
+    const int mfirst = m0 + 16 * TM * wm + 16 * i + erow0;
+    long coff = z * g.bsc + (long)mfirst * g.scm + (long)n * g.scn;             // into g.C (float or 16-bit elements)
+    long moff = z * g.bsm + (long)mfirst * g.smm + (long)n * g.smn;             // into g.mask
+    long roff = z * g.bsbr + (long)mfirst * g.sbr;                              // into g.biasrow
+    const long cstep = (long)RPI * g.scm, mstep = (long)RPI * g.smm, rstep = (long)RPI * g.sbr;
+    const float bn_ = (g.bias && n < g.N) ? g.bias[z * g.bsbias + n] : 0.f;
 #pragma unroll
-    for (int rr = 0; rr < 16; rr += RPI) {
-      const int m = m0 + 16 * TM * wm + 16 * i + rr + erow0;
+    for (int rr = 0; rr < 16; rr += RPI, coff += cstep, moff += mstep, roff += rstep) {
+      const int m = mfirst + rr;
       float v = Ep[w][rr + erow0][ecol];
       if (m < g.M && n < g.N) {
-        float* cp = C + m * g.scm + n * g.scn;
         if (sk > 1) {
           if (g.part) g.part[((z * sk + slice) * g.M + m) * g.N + n] = v;
-          else atomicAdd(cp, v);
+          else atomicAdd(g.C + coff, v);
           continue;
         }
-        if (g.accumulate) v += g.c16 ? (float)reinterpret_cast<const OT*>(g.C)[z * g.bsc + m * g.scm + n * g.scn] * inv_scale : *cp;
-        if (g.bias) v += g.bias[z * g.bsbias + n] * (g.biasrow ? g.biasrow[z * g.bsbr + (long)m * g.sbr] : 1.0f);
+        if (g.accumulate) v += g.c16 ? (float)reinterpret_cast<const OT*>(g.C)[coff] * inv_scale : g.C[coff];
+        if (g.bias) v += bn_ * (g.biasrow ? g.biasrow[roff] : 1.0f);
         if (g.relu) v = fmaxf(v, 0.f);
         if (g.mask) {
-          const long mi = z * g.bsm + m * g.smm + n * g.smn;
-          const bool on = g.m16 ? (float)reinterpret_cast<const OT*>(g.mask)[mi] > 0.f : g.mask[mi] > 0.f;
+          const bool on = g.m16 ? (float)reinterpret_cast<const OT*>(g.mask)[moff] > 0.f : g.mask[moff] > 0.f;
           v = on ? v : 0.f;
         }
         // (16-bit outputs are stored as the NEXT GEMM's operand: gradients already scaled by a_scale -- 1 in the forward)
-        if (g.c16) reinterpret_cast<OT*>(g.C)[z * g.bsc + m * g.scm + n * g.scn] = Op16<OT>::cvt(v * a_scale);
-        else *cp = v;
+        if (g.c16) reinterpret_cast<OT*>(g.C)[coff] = Op16<OT>::cvt(v * a_scale);
+        else g.C[coff] = v;
       }
     }
     __builtin_amdgcn_wave_barrier();
