@@ -140,29 +140,40 @@ __device__ __forceinline__ void gemm_tile(const Gemm& g, const int bx, const int
     if (g.rs_part) g.rs_part[(z * sk + slice) * g.M + m0 + tid] = rs;
     else atomicAdd(g.rowsum + z * g.bsrs + m0 + tid, rs);
   }
-  // epilogue: D layout: col n = lane & 15, row m = 4 * (lane >> 4) + r
+  // epilogue: D layout: col n = lane & 15, row m = 4 * (lane >> 4) + r.  Offsets are advanced incrementally (the 64-bit
+  // stride products per element were ~15 VALU instructions each, and VALU time adds to fp32 MFMA time on this part).
+  const int mb = m0 + 16 * TM * wm + 4 * gg, nb = n0 + 16 * TN * wn + c;
+  long ci = (long)mb * g.scm + (long)nb * g.scn;                        // into C (this batch entry)
+  long mi = z * g.bsm + (long)mb * g.smm + (long)nb * g.smn;            // into g.mask
+  long ri = z * g.bsbr + (long)mb * g.sbr;                              // into g.biasrow
+  const long c16m = 16 * g.scm, c16n = 16 * g.scn, m16m = 16 * g.smm, m16n = 16 * g.smn, r16 = 16 * (long)g.sbr;
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int i = 0; i < TM; ++i, ci += c16m, mi += m16m, ri += r16) {
+    long cj = ci, mj = mi;
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int j = 0; j < TN; ++j, cj += c16n, mj += m16n) {
+      const int n = nb + 16 * j;
+      const float bn_ = (g.bias && n < g.N && sk <= 1) ? g.bias[z * g.bsbias + n] : 0.f;
+      long co = cj, mo = mj, ro = ri;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + 16 * TM * wm + 16 * i + 4 * gg + r, n = n0 + 16 * TN * wn + 16 * j + c;
+      for (int r = 0; r < 4; ++r, co += g.scm, mo += g.smm, ro += g.sbr) {
+        const int m = mb + 16 * i + r;
         if (m < g.M && n < g.N) {
-          float* cp = C + m * g.scm + n * g.scn;
           float v = acc[i][j][r];
           if (sk > 1) {
             if (g.part) g.part[((z * sk + slice) * g.M + m) * g.N + n] = v;
-            else atomicAdd(cp, v);
+            else atomicAdd(C + co, v);
             continue;
           }
-          if (g.accumulate) v += *cp;
-          if (g.bias) v += g.bias[z * g.bsbias + n] * (g.biasrow ? g.biasrow[z * g.bsbr + (long)m * g.sbr] : 1.0f);
+          if (g.accumulate) v += C[co];
+          if (g.bias) v += bn_ * (g.biasrow ? g.biasrow[ro] : 1.0f);
           if (g.relu) v = fmaxf(v, 0.f);
-          if (g.mask) v = g.mask[z * g.bsm + m * g.smm + n * g.smn] > 0.f ? v : 0.f;
-          *cp = v;
+          if (g.mask) v = g.mask[mo] > 0.f ? v : 0.f;
+          C[co] = v;
         }
       }
+    }
+  }
 }
 
 
