@@ -255,6 +255,41 @@ def test_background_loop_matches_single_shot(dev):
     assert t.shape == (1, 4) and float((bg.arena.params - before).abs().max()) > 0
 
 
+def test_iteration_streams_do_not_change_results(dev):
+    """train.ShardedIteration runs the background chain on a second HIP stream beside the object kernel (overlap,
+    resident batches: the two streams only meet at the end of a step).  Four iterations give the SAME parameters,
+    moments and loss terms bit for bit as the single-stream order -- the chains are independent and every kernel is
+    deterministic."""
+    def run(overlap, resident):
+        ts = make_trainers(3, dev, seed=21)
+        c = make_cfg(dev)
+        c.hidden_feature_size, c.obj_scale, c.obj_id = 128, 5.0, 0
+        torch.manual_seed(22)
+        bg = trainer.Trainer(c)
+        obj_loop = otrain.HipTrainLoop(make_cfg(dev), ts, with_feat=False)
+        bg_loop = otrain.BackgroundLoop(c, bg)
+        it = otrain.ShardedIteration(obj_loop, bg_loop, overlap=overlap, resident=resident)
+        keys = ["pts", "z", "gt_depth", "gt_rgb", "labels"]
+        out = []
+        batches = []
+        for i in range(4):
+            bo = synthetic.random_batch(3, 96, 16, 48, seed=30 + i)
+            bb = synthetic.random_batch(1, 200, 5, 9, seed=40 + i)
+            batches.append(({k: T(bo[k]).to(dev) for k in keys}, {k: T(bb[k]).to(dev) for k in keys}))
+        torch.cuda.synchronize()
+        for ob, bgb in batches:
+            ot, bt = it.step(ob, bgb)
+            out.append((ot.clone(), bt.clone()))
+        torch.cuda.synchronize()
+        return obj_loop.arena.params.clone(), bg.arena.params.clone(), out
+    p0, b0, o0 = run(False, False)
+    for overlap, resident in ((True, False), (True, True)):
+        p1, b1, o1 = run(overlap, resident)
+        assert torch.equal(p0, p1) and torch.equal(b0, b1)
+        for (a, b), (c_, d) in zip(o0, o1):
+            assert torch.equal(a, c_) and torch.equal(b, d)
+
+
 @pytest.mark.parametrize("H", [32, 128])
 def test_render_2d_syn_g11(golden, dev, H):
     """Novel-view rendering of one object inside its oriented box (Trainer.sample_points_bbox +
