@@ -312,7 +312,7 @@ __device__ __forceinline__ void lds_tr16_wait(uint2 (&lo)[N], uint2 (&hi)[N]) {
 // idle.)  With BN = 256 the panel is read exactly once.  The epilogue's LDS patch aliases the panel.
 template <int TM, int TN, typename OT, int BKB, int WM = 2, int WN = 2, bool AKM = false, bool BKM = false,
           bool AFULL = false, int KMAX = 256>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 4 : 1) void gemm_bf16_kernel(const Gemm g) {
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? ((AFULL && KMAX == 256) ? 8 : 4) : 1) void gemm_bf16_kernel(const Gemm g) {
   constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN, LDK = BKB + 8, NTH = 64 * WM * WN;
   constexpr int PA = BM + 8, PB = BN + 8;                 // k-major row pitches (elements; 8-byte aligned rows)
   constexpr int LDA = AFULL ? KMAX + 8 : LDK;   // AFULL: panel row pitch (conflict-free b128 reads: 132 / 180 dwords)
@@ -573,22 +573,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 4 : 1) void gemm_bf1
     __syncthreads();                     // the panel is complete
     const int nks = (g.Kd + 31) / 32;
     const uint4* bp = reinterpret_cast<const uint4*>(g.Bp) + ((z * (KMAX / 32)) * (BN / 16) + TN * wn) * 64 + lane;
-    OV bcur[TN], bnext[TN];
+    for (int ks = 0; ks < nks; ++ks) {     // (no operand prefetch: 64 registers -> four workgroups per CU hide the round trip)
+      OV bcur[TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) bcur[j] = __builtin_bit_cast(OV, bp[j * 64]);
-    for (int ks = 0; ks < nks; ++ks) {
-      if (ks + 1 < nks) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bnext[j] = __builtin_bit_cast(OV, bp[((ks + 1) * (BN / 16) + j) * 64]);
-      }
+      for (int j = 0; j < TN; ++j) bcur[j] = __builtin_bit_cast(OV, bp[(ks * (BN / 16) + j) * 64]);
       OV a[TM];
       operands_rm(a, Asm, LDA, 16 * TM * wm, 32 * ks);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = Op16<OT>::mfma(a[i], bcur[j], acc[i][j]);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bcur[j] = bnext[j];
     }
     __syncthreads();                     // every wave is done with the panel: the epilogue patch may overwrite it
   }
