@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Gemm g) {
 #ifndef OBJ_GEMM_WIDE_TM
 #define OBJ_GEMM_WIDE_TM 2      // row tiles per wave of the wide kernel: workgroup tile (64 TM) x 128
 #endif
-__global__ __launch_bounds__(512) void gemm_kernel8(const Gemm g) {
+__global__ __launch_bounds__(512, 8) void gemm_kernel8(const Gemm g) {
   gemm_tile<OBJ_GEMM_WIDE_TM, 4, OBJ_GEMM_BK_WIDE, 4, 2>(g, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
