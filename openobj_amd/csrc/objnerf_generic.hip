@@ -243,6 +243,9 @@ __global__ __launch_bounds__(512) void gemm_group_kernel(const GemmGroup gr) {
 #ifndef OBJ_G16_AFULL
 #define OBJ_G16_AFULL 1
 #endif
+#ifndef OBJ_G16_WIDE_NARROW
+#define OBJ_G16_WIDE_NARROW 1
+#endif
 #ifndef OBJ_ACT16
 #define OBJ_ACT16 1
 #endif
@@ -842,11 +845,13 @@ static void gemm(hipStream_t st, int batch, int M, int N, int Kd, const float* A
     return;
   }
   if (t_bf16_operands) {
-    const bool wide = M >= 256 && N >= 192, f16 = t_bf16_operands == 2;
-    const dim3 grid(wide ? (N + 127) / 128 : (N + 63) / 64, wide ? (M + 127) / 128 : (M + 63) / 64, nz);
     // operands whose rows are the contiguous dimension are staged k-major (exec is full at the transposing reads:
     // out-of-range elements are zero-filled, never masked)
     const bool akm = sak != 1 && sam == 1, bkm = sbk != 1 && sbn == 1;
+    // (split-K weight gradients with a narrow output -- the x1 / x2 columns of the concatenated layers, N = 87 / 42 --
+    // take the 128-row tile too: the streamed d_out^T operand is then read once instead of once per 64-row tile)
+    const bool wide = M >= 256 && (N >= 192 || (OBJ_G16_WIDE_NARROW && akm && splitk > 1 && N >= 40)), f16 = t_bf16_operands == 2;
+    const dim3 grid(wide ? (N + 127) / 128 : (N + 63) / 64, wide ? (M + 127) / 128 : (M + 63) / 64, nz);
     // layer GEMMs over the sample axis: resident A panel (64 rows x the whole contraction), 64 x 256 tiles
     if (panel_ok(M, N, Kd, sak, splitk, rowsum != nullptr, nz) && (wide || (OBJ_G16_AFULL_NARROW && Kd >= 128))) {
       const int ka = t_a2.A2 ? t_a2.k2 : Kd;
