@@ -17,137 +17,43 @@ Objects shard across ranks with no data-path collective.  An iteration has exact
 and one fp32 SUM of the replicated background network's gradient (182 339 floats + 4 loss terms) that is in flight
 under the object kernel.
 
+Ranks.  `--gpus N` with N > 1 and no WORLD_SIZE in the environment makes THIS process a launcher: before anything
+touches the GPU it starts N fresh `bench.py` processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in
+their environment, one per GPU, RCCL between them), relays rank 0's single JSON line and exits non-zero if any rank
+did.  Under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` the environment already names the
+ranks and the process is one of them.  `--dry-launch` is the CPU form of the same launch (gloo, no kernels): the test
+of the launcher and of the collectives' host path (tests/test_bench_launcher.py).
+
 dtype: the headline line is fp32 -- the reference's arithmetic (train.py:74, AMP off) and the only mode held to the
 1e-4 parity bar.  BASELINE.json's configs name bf16: the opt-in bf16-operand mode of the same step (fp32 accumulation,
 master weights, compositing and AdamW; PSNR-gated) is timed in the same run and reported as the `bf16_mode` object
 (or as the headline with --dtype bf16).
 
-Prints ONE JSON line (rank 0): `roofline` = the dominant kernel against the dense fp32 MFMA peak (spec and measured),
-`cpu_baseline` = the oracle (the reference's op sequence in PyTorch on the host cores) at BASELINE.md section 3's
-shapes, `psnr` = the reconstruction quality of the same kernels on the G9 scene against the reference's ensemble.
+Prints ONE JSON line (rank 0): `roofline` = the dominant kernel against the dense MFMA peak of its operand type (spec
+and measured), `cpu_baseline` = the oracle (the reference's op sequence in PyTorch on the host cores) at BASELINE.md
+section 3's shapes, `psnr` = the reconstruction quality of the same kernels on the G9 scene against the reference's
+ensemble, `other_configs` = the other BASELINE configurations (c3, configs[3]'s per-GPU share, configs[4]'s per-GPU
+share in fp16) timed by the same run.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from openobj_amd import init as obj_init  # noqa: E402
-from openobj_amd import ops, synthetic    # noqa: E402
-
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (matrix)"
-PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 / fp16 MFMA
 PEAK_HBM_GBS = 8000.0             # HBM3E, MI355X_MICROARCH.md
 VALU_SIMDS = 256 * 4              # SIMDs of the chip
 VALU_CYCLES_PER_INST = 2.0        # a wave64 VALU instruction occupies its SIMD-32 for 2 cycles (cycle-constants table)
 CLOCK_HZ = 2.4e9
-RECORDED = os.path.join(ROOT, "profiles", "r02_counters.json")
-
-
-def flop_per_ray(S: int, H: int = 32, feat: bool = False) -> float:
-    """Algorithmic training FLOP per ray, SURVEY.md section 8(d): 3 * 2 * (S * M_s [+ 512 H])."""
-    ms = 63 + (5 * H * H + 262 * H if feat else 4 * H * H + 220 * H)
-    return 3.0 * 2.0 * (S * ms + (512 * H if feat else 0))
-
-
-def recorded_counters(kernel: str, K, R, S):
-    """PMC figures of `kernel` for this workload from the profile passes committed under profiles/ (rocprofv3 --pmc in
-    separate runs, gfx950 FETCH_SIZE correction applied: tools/gpu_profile_round.sh).  Hardware counters cannot be
-    read from inside this process: these are RECORDED values of the same launch, None when the workload differs."""
-    try:
-        with open(RECORDED) as f:
-            for e in json.load(f)["kernels"]:
-                if e["kernel"] == kernel and (e["objects"], e["rays"], e["samples"]) == (K, R, S):
-                    return e
-    except (OSError, KeyError, ValueError):
-        pass
-    return None
-
-
-def measured_mfma_peak(dev, dtype_id):
-    """TFLOP/s of a saturated MFMA loop (objnerf_mfma_peak: one wave per SIMD, four independent accumulators, operands
-    in registers, non-trivial data) on THIS device -- the denominator a kernel can actually reach."""
-    from openobj_amd import _lib
-    n_wg, iters = 1024, 20000
-    sink = torch.empty(n_wg * 256, device=dev)
-    st = torch.cuda.current_stream().cuda_stream
-    for it in (2000, iters):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        _lib.check(_lib.lib().objnerf_mfma_peak(dtype_id, it, n_wg, sink.data_ptr(), st), "objnerf_mfma_peak")
-        e1.record()
-        torch.cuda.synchronize()
-    flop = (2048.0 if dtype_id == 0 else 16384.0) * 4 * iters * 4 * n_wg
-    return flop / (e0.elapsed_time(e1) * 1e-3) / 1e12
-
-
-def cpu_step_time(K, R, n1, n2, seed, steps, feat):
-    """ms per step of the oracle = the reference's op sequence (vmap(pe) -> vmap(fc) -> step_batch_loss -> backward
-    -> AdamW), fp32, on the host cores: 1 warm-up + `steps` timed, median."""
-    from oracle import objnerf_oracle as O
-    stacked = obj_init.init_stacked(K, 32, 512, seed=0)
-    fc = [p.clone().requires_grad_(True) for p in stacked[:18]]
-    B = stacked[18].clone().requires_grad_(True)
-    params = fc + [B]
-    m = [torch.zeros_like(p) for p in params]
-    v = [torch.zeros_like(p) for p in params]
-    b = synthetic.random_batch(K, R, n1, n2, seed=seed, feat_dim=512 if feat else 0)
-    tb = {k: torch.from_numpy(b[k]) for k in ["pts", "gt_depth", "gt_rgb", "labels", "z"] + (["gt_feat"] if feat else [])}
-    scale = torch.full((K,), 2.0)
-    times = []
-    for it in range(steps + 1):
-        t0 = time.perf_counter()
-        loss, _ = O.train_forward_loss(fc, B, scale, tb["pts"], tb["gt_depth"], tb["gt_rgb"], tb["labels"], tb["z"],
-                                       gt_feat=tb["gt_feat"] if feat else None)
-        grads = torch.autograd.grad(loss, params, allow_unused=True)
-        with torch.no_grad():
-            for p, g, mm, vv in zip(params, grads, m, v):
-                if g is not None:
-                    O.adamw_step(p, g, mm, vv, it + 1, 1e-3, 0.013)
-        times.append(time.perf_counter() - t0)
-    return float(np.median(times[1:])) * 1e3
-
-
-def cpu_baseline(feat, seed=4242):
-    """BASELINE.md section 3: c1 (K=1, R=256, S=32) in full; the 50-object stack at the reference-native R=120, S=10
-    and at R=1024, S=64 (the metric's sample count); >= 3 timed steps after one warm-up.  `value` is the S=64 shape."""
-    shapes = [("c1", 1, 256, 8, 24, 5), ("c2/c3 native", 50, 120, 1, 9, 3), ("c2/c3 metric", 50, 1024, 16, 48, 3)]
-    rows = []
-    for name, K, R, n1, n2, steps in shapes:
-        f = feat and K > 1
-        ms = cpu_step_time(K, R, n1, n2, seed, steps, f)
-        rows.append({"shape": f"{name}: K={K} R={R} S={n1 + n2}{' +feat' if f else ''}", "ms_per_step": ms,
-                     "rays_per_s": K * R / (ms * 1e-3), "timed_steps": steps})
-    return dict(value=rows[-1]["rays_per_s"], unit="rays/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{rows[-1]['shape']}, hidden 32, {rows[-1]['timed_steps']} timed steps after 1 warm-up, "
-                       f"{rows[-1]['ms_per_step']:.0f} ms/step (oracle/objnerf_oracle.py, torch {torch.__version__} CPU fp32)",
-                shapes=rows)
-
-
-def psnr_block(dev, n_seeds, with_bf16):
-    """PSNR of the G9 scene after 300 fused iterations, ensemble over weight seeds, against the reference's own
-    ensemble for the same seeds (tests/golden/g9_ensemble.npz)."""
-    from openobj_amd import psnr_scene
-    ref = psnr_scene.reference_ensemble()
-    if ref is None:
-        return None
-    n = min(n_seeds, len(ref["seeds"]))
-    seeds = [int(s) for s in ref["seeds"][:n]]
-    sc = psnr_scene.PsnrScene(dev)
-    out = {"scene": "G9: 4 analytic ellipsoids, 96 rays x 16 samples per object and iteration, 300 iterations, "
-                    "PSNR of the rendered colour on 256 held-out rays per object",
-           "reference": "the reference's own modules, same seeds (tests/golden/g9_ensemble.npz)"}
-    out["f32"] = psnr_scene.delta_report(sc.ensemble(seeds, bf16=False), ref["psnr"][:n])
-    if with_bf16:
-        out["bf16"] = psnr_scene.delta_report(sc.ensemble(seeds, bf16=True), ref["psnr"][:n])
-    return out
-
+RECORDED = os.path.join(ROOT, "profiles", "r03_counters.json")
+BG_GRAD_FLOATS = 182339 + 4       # the replicated background network's gradient + its four loss terms (collective 2)
 
 CONFIGS = {
     "c2": dict(objects=50, rays=4096, n1=16, n2=48, hidden=32, feat=False, scaling="weak"),
@@ -157,7 +63,7 @@ CONFIGS = {
 }
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
@@ -188,14 +94,415 @@ def main():
     ap.add_argument("--no-psnr", action="store_true")
     ap.add_argument("--psnr-seeds", type=int, default=128)
     ap.add_argument("--no-peak", action="store_true", help="skip the saturated-MFMA measurement")
-    args = ap.parse_args()
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="default line only: do not also time c3, configs[3]'s share and configs[4]'s share")
+    ap.add_argument("--other-steps", type=int, default=10, help="timed steps of each `other_configs` entry")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="CPU form of the N-rank launch: gloo instead of RCCL, the iteration's two collectives on host "
+                         "buffers, no kernels; the line carries \"dry_launch\": true and value 0")
+    return ap.parse_args(argv)
 
-    cfgname = args.config or "c2"
-    wl = dict(CONFIGS[cfgname])
-    for k_arg, k_wl in (("objects", "objects"), ("rays", "rays"), ("n_cam2surf", "n1"), ("n_bins", "n2"),
-                        ("hidden", "hidden"), ("feat", "feat")):
-        if getattr(args, k_arg) is not None:
-            wl[k_wl] = getattr(args, k_arg)
+
+# ----------------------------------------------------------------------------------------------------------------------
+# launcher: `--gpus N` without an outer torchrun.  Runs before torch / the package are imported: nothing here may
+# initialise the GPU (a process that has must not be the parent of the ranks' rendezvous, and is never re-exec'd).
+# ----------------------------------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _device_count_in_child() -> int:
+    """torch.cuda.device_count() read in a CHILD process (the launcher itself never asks the GPU runtime anything)."""
+    r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    try:
+        return int(r.stdout.strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        sys.stderr.write("bench.py: cannot count GPUs: " + r.stderr[-2000:] + "\n")
+        return 0
+
+
+def launch_ranks(args, argv) -> int:
+    n = args.gpus
+    if not args.dry_launch:
+        have = _device_count_in_child()
+        if n > have:
+            sys.stderr.write(f"bench.py: --gpus {n} but this node shows {have} GPU(s); refusing to oversubscribe\n")
+            return 2
+    env0 = dict(os.environ)
+    env0.update({"WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1",
+                 "MASTER_PORT": str(_free_port()), "OBJNERF_BENCH_LAUNCHED": "1"})
+    env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL across processes needs it on this pool
+    cmd = [sys.executable, os.path.abspath(__file__)] + list(argv)
+    procs = []
+    for r in range(n):
+        env = dict(env0)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r)})
+        # rank 0's stdout carries the line; the other ranks print nothing there (their stdout goes to our stderr)
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno()))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode]
+    deadline = time.time() + 600
+    for p in procs[1:]:
+        try:
+            codes.append(p.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:
+            p.kill()                                          # (the exact child we started)
+            codes.append(-9)
+    lines = [ln for ln in out0.decode(errors="replace").splitlines() if ln.strip().startswith("{")]
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad or len(lines) != 1:
+        sys.stderr.write(f"bench.py: launch of {n} ranks failed: exit codes {codes}, {len(lines)} JSON line(s) from rank 0\n")
+        return 1
+    sys.stdout.write(lines[0] + "\n")
+    sys.stdout.flush()
+    return 0
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def flop_per_ray(S: int, H: int = 32, feat: bool = False) -> float:
+    """Algorithmic training FLOP per ray, SURVEY.md section 8(d): 3 * 2 * (S * M_s [+ 512 H])."""
+    ms = 63 + (5 * H * H + 262 * H if feat else 4 * H * H + 220 * H)
+    return 3.0 * 2.0 * (S * ms + (512 * H if feat else 0))
+
+
+def algorithmic_bytes(K, R, S, feat):
+    """SURVEY.md 8(d), points / z supplied: 16 B per sample + 17 B per ray (+ the fp32 target feature read once)."""
+    return K * R * (S * 16 + 17 + (2048 if feat else 0))
+
+
+def recorded_counters(kernel: str, K, R, S):
+    """PMC figures of `kernel` for this workload from the profile passes committed under profiles/ (rocprofv3 --pmc in
+    separate runs, gfx950 FETCH_SIZE correction applied: tools/gpu_profile_round.sh).  Hardware counters cannot be
+    read from inside this process: these are RECORDED values of the same launch, None when the workload differs."""
+    for path in (RECORDED, RECORDED.replace("r03_", "r02_")):
+        try:
+            with open(path) as f:
+                for e in json.load(f)["kernels"]:
+                    if e["kernel"] == kernel and (e["objects"], e["rays"], e["samples"]) == (K, R, S):
+                        return e
+        except (OSError, KeyError, ValueError):
+            pass
+    return None
+
+
+def measured_mfma_peak(dev, dtype_id):
+    """TFLOP/s of a saturated MFMA loop (objnerf_mfma_peak: one wave per SIMD, four independent accumulators, operands
+    in registers, non-trivial data) on THIS device -- the denominator a kernel can actually reach."""
+    import torch
+    from openobj_amd import _lib
+    n_wg, iters = 1024, 20000
+    sink = torch.empty(n_wg * 256, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    for it in (2000, iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(_lib.lib().objnerf_mfma_peak(dtype_id, it, n_wg, sink.data_ptr(), st), "objnerf_mfma_peak")
+        e1.record()
+        torch.cuda.synchronize()
+    flop = (2048.0 if dtype_id == 0 else 16384.0) * 4 * iters * 4 * n_wg
+    return flop / (e0.elapsed_time(e1) * 1e-3) / 1e12
+
+
+def cpu_step_time(K, R, n1, n2, seed, steps, feat):
+    """ms per step of the oracle = the reference's op sequence (vmap(pe) -> vmap(fc) -> step_batch_loss -> backward
+    -> AdamW), fp32, on the host cores: 1 warm-up + `steps` timed, median."""
+    import numpy as np
+    import torch
+    from openobj_amd import init as obj_init, synthetic
+    from oracle import objnerf_oracle as O
+    stacked = obj_init.init_stacked(K, 32, 512, seed=0)
+    fc = [p.clone().requires_grad_(True) for p in stacked[:18]]
+    B = stacked[18].clone().requires_grad_(True)
+    params = fc + [B]
+    m = [torch.zeros_like(p) for p in params]
+    v = [torch.zeros_like(p) for p in params]
+    b = synthetic.random_batch(K, R, n1, n2, seed=seed, feat_dim=512 if feat else 0)
+    tb = {k: torch.from_numpy(b[k]) for k in ["pts", "gt_depth", "gt_rgb", "labels", "z"] + (["gt_feat"] if feat else [])}
+    scale = torch.full((K,), 2.0)
+    times = []
+    for it in range(steps + 1):
+        t0 = time.perf_counter()
+        loss, _ = O.train_forward_loss(fc, B, scale, tb["pts"], tb["gt_depth"], tb["gt_rgb"], tb["labels"], tb["z"],
+                                       gt_feat=tb["gt_feat"] if feat else None)
+        grads = torch.autograd.grad(loss, params, allow_unused=True)
+        with torch.no_grad():
+            for p, g, mm, vv in zip(params, grads, m, v):
+                if g is not None:
+                    O.adamw_step(p, g, mm, vv, it + 1, 1e-3, 0.013)
+        times.append(time.perf_counter() - t0)
+    return float(np.median(times[1:])) * 1e3
+
+
+def cpu_baseline(feat, seed=4242):
+    """BASELINE.md section 3: c1 (K=1, R=256, S=32) in full; the 50-object stack at the reference-native R=120, S=10
+    and at R=1024, S=64 (the metric's sample count); >= 3 timed steps after one warm-up.  `value` is the S=64 shape."""
+    import torch
+    shapes = [("c1", 1, 256, 8, 24, 5), ("c2/c3 native", 50, 120, 1, 9, 3), ("c2/c3 metric", 50, 1024, 16, 48, 3)]
+    rows = []
+    for name, K, R, n1, n2, steps in shapes:
+        f = feat and K > 1
+        ms = cpu_step_time(K, R, n1, n2, seed, steps, f)
+        rows.append({"shape": f"{name}: K={K} R={R} S={n1 + n2}{' +feat' if f else ''}", "ms_per_step": ms,
+                     "rays_per_s": K * R / (ms * 1e-3), "timed_steps": steps})
+    return dict(value=rows[-1]["rays_per_s"], unit="rays/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{rows[-1]['shape']}, hidden 32, {rows[-1]['timed_steps']} timed steps after 1 warm-up, "
+                       f"{rows[-1]['ms_per_step']:.0f} ms/step (oracle/objnerf_oracle.py, torch {torch.__version__} CPU fp32)",
+                shapes=rows)
+
+
+def psnr_block(dev, n_seeds, with_bf16):
+    """PSNR half of the metric on the same kernels (openobj_amd.psnr_scene): the well-posed per-seed comparison after
+    50 iterations and the ensemble comparison after 300, both against the reference's own modules on the same seeds
+    (tests/golden/g9_ensemble*.npz)."""
+    from openobj_amd import psnr_scene
+    return psnr_scene.report(dev, n_seeds, modes=["f32"] + (["bf16"] if with_bf16 else []))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+class Workload:
+    """One BASELINE configuration resident on this rank's GPU: arena, alternating batches, the object loop, the
+    background loop and the sharded iteration around them."""
+
+    def __init__(self, cfgname, wl, args, dev, world, rank, precision):
+        import torch
+        from openobj_amd import cfg as ocfg, dist as odist, init as obj_init, ops, optim as ooptim, synthetic
+        from openobj_amd import trainer as otrainer, train as otrain
+        self.name, self.wl, self.args, self.dev, self.world, self.rank = cfgname, wl, args, dev, world, rank
+        R, n1, n2, Hd, feat = wl["rays"], wl["n1"], wl["n2"], wl["hidden"], bool(wl["feat"])
+        self.R, self.n1, self.n2, self.Hd, self.feat, self.S = R, n1, n2, Hd, feat, n1 + n2
+        if wl["scaling"] == "strong":                       # a fixed population of objects dealt to the ranks
+            lo, hi = odist.shard_objects(wl["objects"], world, rank)
+            K, K_total = hi - lo, wl["objects"]
+        else:
+            K, K_total = wl["objects"], wl["objects"] * world
+        self.K, self.K_total = K, K_total
+        self.precision = precision                            # ops.precision_bits: False / True ("bf16") / "fp16"
+        self.ops = ops
+        arena = self.arena = ops.ParamArena(K, ops.NetShape(Hd, 512, 6), dev)
+        arena.load_stacked(obj_init.init_stacked(K, Hd, 512, seed=1000 + rank))
+        keys = ["pts", "z", "gt_depth", "gt_rgb", "labels"] + (["gt_feat"] if feat else [])
+        self.nb = 2 if Hd == 32 else 1  # resident batches, alternated so no step re-reads its own outputs
+        self.distinct = K if Hd == 32 else min(K, 8)     # (the stress shape re-uses 8 objects' rays for its 64 networks)
+        self.batches = []
+        for i in range(self.nb):
+            b = synthetic.random_batch(self.distinct, R, n1, n2, seed=4242 + 17 * rank + i, feat_dim=512 if feat else 0)
+            reps = (K + self.distinct - 1) // self.distinct
+            self.batches.append({k: torch.from_numpy(b[k]).to(dev).repeat(reps, *([1] * (b[k].ndim - 1)))[:K].contiguous()
+                                 for k in keys})
+        S = self.S
+
+        class ObjLoop:                  # the object stack of this rank: fused step + AdamW over the arena
+            def __init__(self):
+                self.ws = ops.TrainWorkspace(arena, K, R, S, feat, precision=precision)
+                self.opt = ooptim.ArenaAdamW(arena, lr=1e-3, weight_decay=0.013)
+                self.mask = arena.has_grad_mask(feat)
+                self.bf16 = False
+
+            def step(self, batch, global_flags=None):
+                ops.train_step(arena, self.ws, batch, global_flags=global_flags, with_feat=feat, bf16=self.bf16)
+                self.opt.step(self.ws.grads, self.mask, flags=global_flags if global_flags is not None else self.ws.flags)
+                return self.ws.loss_terms
+
+        self.obj_loop = ObjLoop()
+        self.bg_loop, self.bg_batches = None, [None, None]
+        if args.bg and wl.get("bg", True):
+            c = ocfg.Config(ocfg.replica_room0_config(train_device=str(dev)))
+            c.obj_id, c.hidden_feature_size, c.obj_scale = 0, c.hidden_feature_size_bg, c.bg_scale
+            torch.manual_seed(7)                               # identical replica on every rank
+            self.bg_loop = otrain.BackgroundLoop(c, otrainer.Trainer(c), with_feat=feat)
+            lo, hi = odist.shard_rays(c.n_per_optim_bg, world, rank)
+            self.bg_batches = []
+            for i in range(2):
+                b = synthetic.random_batch(1, c.n_per_optim_bg, n1, n2, seed=777 + i, feat_dim=512 if feat else 0)
+                self.bg_batches.append({k: torch.from_numpy(b[k][:, lo:hi]).contiguous().to(dev) for k in keys})
+        self.iteration = otrain.ShardedIteration(self.obj_loop, self.bg_loop, overlap=args.overlap, resident=True,
+                                                 device=dev)
+
+    def step(self, i, mode):
+        self.obj_loop.bf16 = mode
+        if self.bg_loop is not None:
+            self.bg_loop.bf16 = mode             # the mode applies to the whole step
+        self.iteration.step(self.batches[i % self.nb], self.bg_batches[i & 1])
+
+    def timed(self, mode, steps, warmup, dist=None):
+        """W warm-up steps, then exactly K steps between barrier + synchronize; max over ranks.  Then the dominant
+        kernel alone: HIP events on the launch stream (torch's current stream, which the C ABI is handed) around
+        objnerf_train_step = fused kernel + its slab reduction (the reduction is < 1 % of it)."""
+        import torch
+        for i in range(warmup):
+            self.step(i, mode)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            self.step(i, mode)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt_ = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([dt_], device=self.dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt_ = float(tt.item())
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=True)
+        nk = max(3, min(steps, 20))
+        ev0.record()
+        for i in range(nk):
+            self.ops.train_step(self.arena, self.obj_loop.ws, self.batches[i % self.nb], with_feat=self.feat, bf16=mode)
+        ev1.record()
+        torch.cuda.synchronize()
+        return dt_, ev0.elapsed_time(ev1) / nk
+
+    # ---- reporting -----------------------------------------------------------------------------------------------
+    def rays_per_step(self):
+        return self.K_total * self.R if self.wl["scaling"] == "strong" else self.K * self.R * self.world
+
+    def kernel_name(self, mode):
+        feat, S, Hd = self.feat, self.S, self.Hd
+        if Hd == 32 and S <= 64 and mode != "fp16":
+            if mode:
+                return "train_fused_bf16_kernel<%s, %d>" % ("true" if feat else "false", 64 if S == 64 else 0)
+            return "train_fused32_kernel<%s, false, %d>" % ("true" if feat else "false", 64 if S == 64 else 0)
+        return "objnerf_train_step, layer-wise path (batched MFMA GEMMs)"
+
+    def roofline(self, mode, kern_ms, with_peak=False):
+        """The dominant launch (objnerf_train_step) against the dense MFMA peak of its operand type: the path is a
+        dense contraction with everything else on chip; `traffic` = RECORDED PMC bytes of the same
+        launch, `traffic_ratio` against the algorithmic bytes."""
+        K, R, S = self.K, self.R, self.S
+        fpr = flop_per_ray(S, H=self.Hd, feat=self.feat)
+        kname = self.kernel_name(mode)
+        achieved = K * R * fpr / (kern_ms * 1e-3) / 1e12
+        peak = PEAK_BF16_MFMA_TFLOPS if mode else PEAK_F32_MFMA_TFLOPS
+        rec = recorded_counters(kname, K, R, S)
+        alg = algorithmic_bytes(K, R, S, self.feat)
+        roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                "traffic": rec.get("hbm_bytes_per_launch") if rec else None,
+                "traffic_note": ("RECORDED, not measured by this run: " + rec["source"]) if rec else
+                                "no recorded PMC pass for this workload",
+                "kernel": kname, "kernel_ms": kern_ms, "flop_per_ray": fpr, "algorithmic_bytes_per_launch": alg}
+        if rec:
+            if rec.get("hbm_bytes_per_launch"):
+                roof["traffic_ratio"] = rec["hbm_bytes_per_launch"] / alg
+            if mode and rec.get("valu_insts_per_launch"):
+                floor_ms = rec["valu_insts_per_launch"] * VALU_CYCLES_PER_INST / (VALU_SIMDS * CLOCK_HZ) * 1e3
+                roof.update({"valu_insts_per_launch": rec["valu_insts_per_launch"], "valu_floor_ms": floor_ms,
+                             "frac_of_valu_floor": floor_ms / kern_ms})
+        if with_peak:
+            pm = measured_mfma_peak(self.dev, 1 if mode else 0)
+            roof["peak_measured"] = pm
+            roof["frac_of_measured_peak"] = achieved / pm
+        return roof
+
+    def describe(self):
+        wl = self.wl
+        return {"workload": f"{self.name}: Replica room_0-shaped, {self.K} object MLPs on this GPU"
+                            f"{' of %d in total' % self.K_total if wl['scaling'] == 'strong' else ''} (hidden {self.Hd}), "
+                            f"{self.R} rays/object/step, {self.S} samples/ray ({self.n1}+{self.n2}), RGB+depth+opacity"
+                            f"{'+512-d feature' if self.feat else ''} loss, fused fwd+loss+bwd+AdamW",
+                "objects_per_gpu": self.K, "objects_total": self.K_total, "rays_per_object": self.R,
+                "samples_per_ray": self.S, "hidden": self.Hd, "feature_head": self.feat,
+                "background_mlp": self.bg_loop is not None, "distinct_ray_sets": self.distinct}
+
+    def free(self):
+        import torch
+        self.iteration = self.obj_loop = self.bg_loop = self.batches = self.bg_batches = self.arena = None
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+
+
+OTHER_CONFIGS = [   # (key, base config, overrides, operand modes) -- timed after the headline by the default run
+    ("c3", "c3", {}, [False, True]),
+    ("c4_share", "c4", {"objects": 15, "scaling": "weak"}, [False, True]),
+    ("c5_share_fp16", "c5", {"bg": False}, ["fp16"]),
+]
+
+
+def other_configs(args, dev):
+    """The BASELINE configurations the headline line is not quoted on, each timed by the same procedure (`--other-steps`
+    timed steps): c3, configs[3]'s per-GPU share (15 objects with the feature loss) and configs[4]'s per-GPU share
+    (64 objects, hidden 256, 8192 x 128) in fp16."""
+    out = {}
+    names = {False: "f32", True: "bf16", "fp16": "fp16"}
+    for key, base, over, modes in OTHER_CONFIGS:
+        wl = dict(CONFIGS[base])
+        wl.update(over)
+        try:
+            w = Workload(key, wl, args, dev, 1, 0, modes[0] if modes[0] == "fp16" else False)
+            entry = {"config": w.describe()}
+            for mode in modes:
+                steps = args.other_steps
+                dt, kms = w.timed(mode, steps, 2)
+                entry[names[mode]] = {"value": w.rays_per_step() * steps / dt, "unit": "rays/s", "steps": steps,
+                                      "ms_per_step": dt / steps * 1e3, "roofline": w.roofline(mode, kms),
+                                      "loss_status": int(w.obj_loop.ws.status.item())}
+            w.free()
+            out[key] = entry
+        except Exception as e:      # a failing extra must not cost the headline line; it is reported, not hidden
+            out[key] = {"error": f"{type(e).__name__}: {e}"}
+    return out
+
+
+def dry_launch(args, world, rank, json_fd):
+    """The N-rank launch on CPU: gloo, the iteration's two collectives on host buffers of the real sizes, the bench's
+    barrier / max-over-ranks timing; no kernels (value 0)."""
+    import torch
+    import torch.distributed as dist
+    from openobj_amd import dist as odist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo")
+    wl = dict(CONFIGS[args.config or "c2"])
+    if wl["scaling"] == "strong":
+        lo, hi = odist.shard_objects(wl["objects"], world, rank)
+        K = hi - lo
+    else:
+        K = wl["objects"]
+    per_rank = torch.zeros(world, dtype=torch.int64)
+    per_rank[rank] = K
+    dist.all_reduce(per_rank)
+    flat = torch.zeros(BG_GRAD_FLOATS)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pre = odist.pack_pre(torch.tensor([0, 1 if rank == 0 else 0], dtype=torch.int32),
+                             torch.tensor([[600, 500]], dtype=torch.int32), "cpu")
+        odist.allreduce_sum_(pre)                                  # collective 1
+        gflags, bg_counts, _ = odist.unpack_pre(pre)
+        flat.fill_(1.0)
+        work = odist.allreduce_sum_async(flat)                     # collective 2
+        work.wait()
+    dist.barrier()
+    tt = torch.tensor([time.perf_counter() - t0])
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    ok = gflags.tolist() == [0, 1] and bg_counts.tolist() == [[600 * world, 500 * world]] and float(flat[0]) == world
+    if rank == 0:
+        out = {"metric": "training rays/sec/GPU @64 samples/ray, 50 obj; PSNR delta vs ref", "value": 0.0,
+               "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": float(tt.item()) / max(1, args.steps) * 1e3, "higher_is_better": True,
+               "scaling": wl["scaling"], "vs_baseline": None, "dtype": args.dtype, "data": "none", "dry_launch": True,
+               "config": {"workload": "dry launch: collectives only (gloo, host buffers), no kernels",
+                          "rccl_ranks": dist.get_world_size(), "backend": "gloo",
+                          "objects_per_rank": per_rank.tolist(), "collectives_per_step": 2,
+                          "collectives_ok": bool(ok)}}
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    dist.destroy_process_group()
+    if os.environ.get("OBJNERF_BENCH_FAIL_RANK") == str(rank):     # test hook: a rank that fails after the run
+        return 3
+    return 0 if ok else 1
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, argv))
 
     # stdout carries exactly ONE line (the JSON, rank 0).  Libraries print there too (RCCL's version banner at the
     # first collective): file descriptor 1 is pointed at stderr for the run and the line goes to the saved descriptor.
@@ -206,8 +513,25 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dry_launch:
+        sys.exit(dry_launch(args, world, rank, json_fd))
+
+    import torch
+    cfgname = args.config or "c2"
+    wl = dict(CONFIGS[cfgname])
+    for k_arg, k_wl in (("objects", "objects"), ("rays", "rays"), ("n_cam2surf", "n1"), ("n_bins", "n2"),
+                        ("hidden", "hidden"), ("feat", "feat")):
+        if getattr(args, k_arg) is not None:
+            wl[k_wl] = getattr(args, k_arg)
+    default_line = (args.config is None and args.dtype == "f32" and args.bg and
+                    all(getattr(args, k) is None for k in ("objects", "rays", "n_cam2surf", "n_bins", "hidden", "feat")))
+
     dist = None
     use_dist = world > 1 or (os.environ.get("OBJNERF_DIST_SELFTEST") == "1" and "RANK" in os.environ)
+    if local_rank >= torch.cuda.device_count():
+        sys.stderr.write(f"bench.py: rank {rank} wants cuda:{local_rank} but the node shows "
+                         f"{torch.cuda.device_count()} GPU(s)\n")
+        sys.exit(2)
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -216,177 +540,64 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    from openobj_amd import cfg as ocfg, dist as odist, optim as ooptim, trainer as otrainer, train as otrain
-    R, n1, n2, Hd, feat = wl["rays"], wl["n1"], wl["n2"], wl["hidden"], bool(wl["feat"])
-    S = n1 + n2
-    if wl["scaling"] == "strong":                       # a fixed population of objects dealt to the ranks
-        lo, hi = odist.shard_objects(wl["objects"], world, rank)
-        K, K_total = hi - lo, wl["objects"]
-    else:
-        K, K_total = wl["objects"], wl["objects"] * world
-    bf16 = {"f32": False, "bf16": True, "fp16": "fp16"}[args.dtype]      # ops.precision_bits
-
-    arena = ops.ParamArena(K, ops.NetShape(Hd, 512, 6), dev)
-    arena.load_stacked(obj_init.init_stacked(K, Hd, 512, seed=1000 + rank))
-    keys = ["pts", "z", "gt_depth", "gt_rgb", "labels"] + (["gt_feat"] if feat else [])
-    nb = 2 if Hd == 32 else 1       # resident batches, alternated so no step re-reads its own outputs
-    batches = []
-    for i in range(nb):
-        src_k = K if Hd == 32 else min(K, 8)            # (the stress shape re-uses 8 objects' rays for its 64 networks)
-        b = synthetic.random_batch(src_k, R, n1, n2, seed=4242 + 17 * rank + i, feat_dim=512 if feat else 0)
-        reps = (K + src_k - 1) // src_k
-        batches.append({k: torch.from_numpy(b[k]).to(dev).repeat(reps, *([1] * (b[k].ndim - 1)))[:K].contiguous()
-                        for k in keys})
-
-    class ObjLoop:                  # the object stack of this rank: fused step + AdamW over the arena
-        def __init__(self):
-            self.ws = ops.TrainWorkspace(arena, K, R, S, feat, precision=bf16)
-            self.opt = ooptim.ArenaAdamW(arena, lr=1e-3, weight_decay=0.013)
-            self.mask = arena.has_grad_mask(feat)
-            self.bf16 = False
-
-        def step(self, batch, global_flags=None):
-            ops.train_step(arena, self.ws, batch, global_flags=global_flags, with_feat=feat, bf16=self.bf16)
-            self.opt.step(self.ws.grads, self.mask, flags=global_flags if global_flags is not None else self.ws.flags)
-            return self.ws.loss_terms
-
-    obj_loop = ObjLoop()
-    bg_loop, bg_batches = None, [None, None]
-    if args.bg:
-        c = ocfg.Config(ocfg.replica_room0_config(train_device=str(dev)))
-        c.obj_id, c.hidden_feature_size, c.obj_scale = 0, c.hidden_feature_size_bg, c.bg_scale
-        torch.manual_seed(7)                               # identical replica on every rank
-        bg_loop = otrain.BackgroundLoop(c, otrainer.Trainer(c), with_feat=feat)
-        lo, hi = odist.shard_rays(c.n_per_optim_bg, world, rank)
-        bg_batches = []
-        for i in range(2):
-            b = synthetic.random_batch(1, c.n_per_optim_bg, n1, n2, seed=777 + i, feat_dim=512 if feat else 0)
-            bg_batches.append({k: torch.from_numpy(b[k][:, lo:hi]).contiguous().to(dev) for k in keys})
-    iteration = otrain.ShardedIteration(obj_loop, bg_loop, overlap=args.overlap, resident=True)   # (batches made above)
-
-    def step(i, use_bf16):
-        obj_loop.bf16 = use_bf16
-        if bg_loop is not None:
-            bg_loop.bf16 = use_bf16              # the mode applies to the whole step
-        iteration.step(batches[i % nb], bg_batches[i & 1])
-
-    def timed(use_bf16):
-        """W warm-up steps, then exactly K steps between barrier + synchronize; max over ranks.  Then the dominant
-        kernel alone: HIP events on the launch stream (torch's current stream, which the C ABI is handed) around
-        objnerf_train_step = fused kernel + its slab reduction (the reduction is < 1 % of it)."""
-        for i in range(args.warmup):
-            step(i, use_bf16)
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            step(i, use_bf16)
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        dt_ = time.perf_counter() - t0
-        if use_dist:
-            tt = torch.tensor([dt_], device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt_ = float(tt.item())
-        ev0 = torch.cuda.Event(enable_timing=True)
-        ev1 = torch.cuda.Event(enable_timing=True)
-        nk = max(3, min(args.steps, 20))
-        ev0.record()
-        for i in range(nk):
-            ops.train_step(arena, obj_loop.ws, batches[i % nb], with_feat=feat, bf16=use_bf16)
-        ev1.record()
-        torch.cuda.synchronize()
-        return dt_, ev0.elapsed_time(ev1) / nk
-
-    dt, kern_ms = timed(bf16)
-    status = int(obj_loop.ws.status.item())
+    mode = {"f32": False, "bf16": True, "fp16": "fp16"}[args.dtype]      # ops.precision_bits
+    w = Workload(cfgname, wl, args, dev, world, rank, mode)
+    dt, kern_ms = w.timed(mode, args.steps, args.warmup, dist if use_dist else None)
+    status = int(w.obj_loop.ws.status.item())
     # the opt-in bf16-operand mode beside the fp32 headline (same step, same batches)
     bf16_extra = None
-    if not bf16 and args.bf16_line:
-        bf16_extra = timed(True)
+    if not mode and args.bf16_line:
+        bf16_extra = w.timed(True, args.steps, args.warmup, dist if use_dist else None)
+    per_rank = [w.K]
+    if use_dist:
+        pr = torch.zeros(world, dtype=torch.int64, device=dev)
+        pr[rank] = w.K
+        dist.all_reduce(pr)
+        per_rank = pr.tolist()
 
     if rank == 0:
-        rays_per_step = K_total * R if wl["scaling"] == "strong" else K * R * world
+        rays_per_step = w.rays_per_step()
         value = rays_per_step * args.steps / dt
-        fpr = flop_per_ray(S, H=Hd, feat=feat)
-        fused = Hd == 32 and S <= 64 and bf16 != "fp16"
-        k32 = "train_fused32_kernel<%s, false, %d>" % ("true" if feat else "false", 64 if S == 64 else 0)
-        kbf = "train_fused_bf16_kernel<%s, %d>" % ("true" if feat else "false", 64 if S == 64 else 0)
-        kname = (kbf if bf16 else k32) if fused else "objnerf_train_step, layer-wise path (batched MFMA GEMMs)"
-        achieved = K * R * fpr / (kern_ms * 1e-3) / 1e12
-        peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
-        rec = recorded_counters(kname, K, R, S)
-        roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                "traffic": rec["hbm_bytes_per_launch"] if rec else None,
-                "traffic_note": ("RECORDED, not measured by this run: " + rec["source"]) if rec else
-                                "no recorded PMC pass for this workload",
-                "kernel": kname, "kernel_ms": kern_ms, "flop_per_ray": fpr,
-                "algorithmic_bytes_per_launch": K * R * (S * 16 + 17 + (2048 * 2 if feat else 0))}
-        if not fused and bf16 and Hd == 256 and not feat:
-            # configs[4] in the 16-bit modes: every kernel of the layer-wise chain streams its operands once and is
-            # HBM-bound (DESIGN.md section 4.8).  Algorithmic bytes per sample: activations and back-propagated
-            # gradients 2 H bytes each per pass, the fp32 embedding rows / their gradient as stored.
-            bps = (1408 + 22 * Hd) + (2604 + 60 * Hd)
-            gbs = K * R * S * bps / (kern_ms * 1e-3) / 1e9
-            roof.update({"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-                         "algorithmic_bytes_per_launch": K * R * S * bps, "bytes_per_sample": bps,
-                         "mfma_tflops": achieved, "frac_of_bf16_mfma_peak": achieved / peak,
-                         "note": "layer-wise chain, 16-bit activations and gradients; bytes per sample = forward "
-                                 "1408 + 22 H, backward 2604 + 60 H (each buffer counted once per kernel that streams it)"})
-        if not args.no_peak:
-            pm = measured_mfma_peak(dev, 1 if bf16 else 0)
-            roof["peak_measured"] = pm
-            roof["frac_of_measured_peak"] = achieved / pm          # (of the measured MFMA peak)
+        cfg_block = w.describe()
+        cfg_block.update({"parallelism": f"objects sharded x{world}", "collectives_per_step": 2 if use_dist else 0,
+                          "rccl_ranks": dist.get_world_size() if use_dist else 1, "objects_per_rank": per_rank,
+                          "launched_by": "bench.py --gpus" if os.environ.get("OBJNERF_BENCH_LAUNCHED") else
+                                         ("torchrun" if "RANK" in os.environ else "single process"),
+                          "loss_status": status})
         out = {
             "metric": "training rays/sec/GPU @64 samples/ray, 50 obj; PSNR delta vs ref",
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": wl["scaling"],
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{cfgname}: Replica room_0-shaped, {K} object MLPs on this GPU"
-                                   f"{' of %d in total' % K_total if wl['scaling'] == 'strong' else ''} (hidden {Hd}), "
-                                   f"{R} rays/object/step, {S} samples/ray ({n1}+{n2}), RGB+depth+opacity"
-                                   f"{'+512-d feature' if feat else ''} loss, fused fwd+loss+bwd+AdamW",
-                       "objects_per_gpu": K, "objects_total": K_total, "rays_per_object": R, "samples_per_ray": S,
-                       "hidden": Hd, "feature_head": feat, "background_mlp": bool(args.bg),
-                       "parallelism": f"objects sharded x{world}", "collectives_per_step": 2 if use_dist else 0,
-                       "loss_status": status},
+            "config": cfg_block,
             "rays_per_sec_per_gpu": value / world,
-            "roofline": roof,
+            "roofline": w.roofline(mode, kern_ms, with_peak=not args.no_peak),
         }
         if bf16_extra is not None:
             bdt, bk = bf16_extra
-            bkname = kbf if fused else "layer-wise path, bf16-operand GEMMs"
-            mf = K * R * fpr / (bk * 1e-3) / 1e12
-            brec = recorded_counters(bkname, K, R, S)
-            broof = {"bound": "valu", "unit": "wave instructions", "kernel": bkname, "kernel_ms": bk,
-                     "mfma_tflops": mf, "frac_of_bf16_mfma_peak": mf / PEAK_BF16_MFMA_TFLOPS}
-            if brec:
-                floor_ms = brec["valu_insts_per_launch"] * VALU_CYCLES_PER_INST / (VALU_SIMDS * CLOCK_HZ) * 1e3
-                broof.update({"valu_insts_per_launch": brec["valu_insts_per_launch"],
-                              "valu_insts_per_sample": brec["valu_insts_per_launch"] * 64.0 / (K * R * S),
-                              "valu_floor_ms": floor_ms, "frac": floor_ms / bk,
-                              "note": "VALU issue floor = wave instructions x 2 cycles / (1024 SIMDs x 2.4 GHz); "
-                                      "instruction count RECORDED: " + brec["source"]})
             out["bf16_mode"] = {"value": rays_per_step * args.steps / bdt, "unit": "rays/s",
-                                "ms_per_step": bdt / args.steps * 1e3, "roofline": broof,
+                                "ms_per_step": bdt / args.steps * 1e3,
+                                "roofline": w.roofline(True, bk, with_peak=not args.no_peak),
                                 "note": "OBJNERF_TRAIN_BF16: bf16 MFMA operands, fp32 accumulate / master weights / "
                                         "compositing / AdamW; PSNR-gated (tests/test_bf16_gpu.py), not 1e-4 parity"}
+    Hd, feat = w.Hd, w.feat
+    w.free()
+    if rank == 0:
+        if world == 1 and default_line and not args.no_other_configs:
+            out["other_configs"] = other_configs(args, dev)
         if world == 1 and not args.no_psnr and Hd == 32:
-            ps = psnr_block(dev, args.psnr_seeds, with_bf16=args.bf16_line or bf16)
+            ps = psnr_block(dev, args.psnr_seeds, with_bf16=args.bf16_line or bool(mode))
             if ps is not None:
                 out["psnr"] = ps
-                key = "bf16" if bf16 else "f32"
-                out["psnr_delta_db"] = ps[key]["delta_db"]
-                out["psnr_delta_ci95_db"] = ps[key]["ci95_db"]
+                key = "bf16" if mode else "f32"
+                out["psnr_delta_db"] = ps["iter50"][key]["mean_delta_db"]
+                out["psnr_delta_ci95_db"] = ps["iter50"][key]["ci95_db"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(feat)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define OBJNERF_ABI_VERSION 3
+#define OBJNERF_ABI_VERSION 4
 
 #define OBJNERF_OK 0
 #define OBJNERF_EINVAL (-22)       /* bad shape / null pointer / unsupported size        */
@@ -313,6 +313,12 @@ typedef struct objnerf_train_args {
   struct objnerf_context* context;   /* NULL: everything on `stream`.  Else the layer-wise path (hidden != 32,
                                       * S > 64, OBJNERF_TRAIN_LAYERWISE) forks its weight-gradient GEMMs and the feature
                                       * preparation onto the context's streams; one context serves one call at a time. */
+  /* ABI 4 */
+  float* emb_debug;      /* NULL in production.  Test hook, [K][R][S][129]: the fused fp32 kernel (hidden 32, S <= 64)
+                          * writes the embedding rows its tiles computed IN REGISTERS (embedding.py:46-55 in the
+                          * reference's column order) -- the kernel never materialises them otherwise, so this is the
+                          * only way to compare its positional encoding with fixture G1.  Every other path refuses it
+                          * (OBJNERF_ENOTSUP): their embedding is objnerf_embed's output. */
 } objnerf_train_args;
 size_t objnerf_train_workspace_bytes(const objnerf_net* net, int32_t K, int32_t R, int32_t S,
                                      int32_t with_feat);

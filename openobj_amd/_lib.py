@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OBJNERF_LIB") or os.path.join(_HERE, "csrc", "libobjnerf_hip.so")   # OBJNERF_LIB: diagnostic builds
 
 OBJNERF_N_TENSORS = 19
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class ObjnerfError(RuntimeError):
@@ -80,7 +80,7 @@ class TrainArgs(C.Structure):
                 ("counts", C.c_void_p), ("flags", C.c_void_p),
                 ("grads", C.c_void_p), ("loss_terms", C.c_void_p), ("status", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
-                ("relu_masks", C.c_void_p), ("context", C.c_void_p)]
+                ("relu_masks", C.c_void_p), ("context", C.c_void_p), ("emb_debug", C.c_void_p)]
 
 
 # name -> (restype, argtypes); every symbol include/objnerf_hip.h declares

@@ -1052,13 +1052,14 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
     if (a->workspace_bytes < objgen::train_workspace_bytes(net, a->K, a->R, a->S, a->gt_feat != nullptr,
                                                            (a->mode & (OBJNERF_TRAIN_FP16 | OBJNERF_TRAIN_BF16)) != 0))
       return OBJNERF_EINVAL;
+    if (a->emb_debug) return OBJNERF_ENOTSUP;
     (void)hipMemsetAsync(a->status, 0, sizeof(int), (hipStream_t)stream);
     return objgen::train_step(net, a, stream);
   }
   const bool feat = a->gt_feat != nullptr;
   if (feat && (TS / a->S) > 16) return OBJNERF_ENOTSUP;
   const bool bf16 = (a->mode & OBJNERF_TRAIN_BF16) != 0;
-  if (bf16 && a->relu_masks) return OBJNERF_ENOTSUP;
+  if (bf16 && (a->relu_masks || a->emb_debug)) return OBJNERF_ENOTSUP;
   if (a->workspace_bytes < objnerf_train_workspace_bytes(net, a->K, a->R, a->S, a->gt_feat != nullptr))
     return OBJNERF_EINVAL;
   int64_t offs[OBJNERF_N_TENSORS + 1];
@@ -1103,6 +1104,7 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
   }
   d.rayin = rayin; d.gram = gram; d.rayfeat = rayfeat;
   d.relu_masks = a->relu_masks;
+  d.emb_debug = a->emb_debug;
 
   hipStream_t st = (hipStream_t)stream;
   // slab-reduced entries: everything except what this launch does not differentiate.  Without gt_feat the

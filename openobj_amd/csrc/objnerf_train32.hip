@@ -257,9 +257,26 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
       Emb32 e;                        // forward-only: the backward re-creates the embedding tile by tile
       embed32(e, pe, g);
       PT(1);
+      if (MASKS && a.emb_debug && valid) {     // test hook: this lane's share of its sample's embedding row
+        float* er = a.emb_debug + (((long)k * R + ray) * S + (slot - q * S)) * (OBJ_E1 + OBJ_E2);
+#pragma unroll
+        for (int T_ = 0; T_ < 6; ++T_)
+#pragma unroll
+          for (int r_ = 0; r_ < 4; ++r_) {
+            const int col = x1_col(4 * T_ + r_, g);
+            if (col >= 0) er[col] = e.x1[T_][r_];
+          }
+#pragma unroll
+        for (int T_ = 0; T_ < 3; ++T_)
+#pragma unroll
+          for (int r_ = 0; r_ < 4; ++r_) {
+            const int col = x2_col(4 * T_ + r_, g);
+            if (col >= 0) er[OBJ_E1 + col] = e.x2[T_][r_];
+          }
+      }
       s_alpha[g * TS + slot] = mlp32_forward<FEAT>(wf, sv, g, e, act);
     }
-    if (MASKS) {                      // test hook: ReLU branch bits of this lane's sample
+    if (MASKS && a.relu_masks) {      // test hook: ReLU branch bits of this lane's sample
       uint8_t* dst = a.relu_masks + (((long)k * R + (valid ? ray : 0)) * S + (slot - q * S)) * 24;
       write_relu_mask(dst, 0, g, act.h1, valid);
       write_relu_mask(dst, 1, g, act.h2, valid);
@@ -932,10 +949,10 @@ void launch_train32(const TrainDev& d, void* stream, bool feat) {
   const dim3 grid(d.K * d.G), blk(NTHR);
   hipStream_t st = (hipStream_t)stream;
   if (feat) {
-    if (d.relu_masks) hipLaunchKernelGGL((train_fused32_kernel<true, true, 0>), grid, blk, n1, st, d);
+    if (d.relu_masks || d.emb_debug) hipLaunchKernelGGL((train_fused32_kernel<true, true, 0>), grid, blk, n1, st, d);
     else if (d.S == 64) hipLaunchKernelGGL((train_fused32_kernel<true, false, 64>), grid, blk, n1, st, d);
     else hipLaunchKernelGGL((train_fused32_kernel<true, false, 0>), grid, blk, n1, st, d);
-  } else if (d.relu_masks) hipLaunchKernelGGL((train_fused32_kernel<false, true, 0>), grid, blk, n0, st, d);
+  } else if (d.relu_masks || d.emb_debug) hipLaunchKernelGGL((train_fused32_kernel<false, true, 0>), grid, blk, n0, st, d);
   else if (d.S == 64) hipLaunchKernelGGL((train_fused32_kernel<false, false, 64>), grid, blk, n0, st, d);
   else hipLaunchKernelGGL((train_fused32_kernel<false, false, 0>), grid, blk, n0, st, d);
 }

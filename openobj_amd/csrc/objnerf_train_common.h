@@ -28,6 +28,7 @@ struct TrainDev {
   const float* gram;    // [K][GRAM]      G = W_of^T W_of (32x32), wb = W_of^T b_of (32), b_of . b_of
   float* rayfeat;       // [K][R][RAYFEAT] composited hidden fh (32), a, c, opacity   (-> feat_post kernels)
   uint8_t* relu_masks;  // objnerf_train_args.relu_masks (test hook) or NULL
+  float* emb_debug;     // objnerf_train_args.emb_debug (test hook) or NULL
   Layout L;
 };
 constexpr int RAYIN = 34, GRAM = 1088, RAYFEAT = 36;

@@ -222,7 +222,8 @@ class IncrementalMapper:
                 self._side = torch.cuda.Stream(device=cfg.training_device)
             side = self._side
             side.wait_stream(torch.cuda.current_stream(cfg.training_device))
-        sharded_it = otrain.ShardedIteration(self.loop if pool is not None else None, self.bg_loop, self.group) if sharded else None
+        sharded_it = otrain.ShardedIteration(self.loop if pool is not None else None, self.bg_loop, self.group,
+                                             device=cfg.training_device) if sharded else None
         for it in range(cfg.n_iter_per_frame):
             batch = {k: v[it] for k, v in pool.items()} if pool is not None else None
             bg_slice = (lambda: {k: v[it] for k, v in bg_pool.items()}) if bg_pool is not None else None

@@ -353,7 +353,8 @@ class TrainWorkspace:
 def train_step(arena: ParamArena, ws: TrainWorkspace, batch: Dict[str, torch.Tensor], color_scaling=5.0,
                opacity_scaling=10.0, feat_scaling=5.0, with_feat=False, obj_center=0.0,
                global_flags: Optional[torch.Tensor] = None, global_counts: Optional[torch.Tensor] = None,
-               bf16: bool = False, layerwise: bool = False, relu_masks: Optional[torch.Tensor] = None) -> None:
+               bf16: bool = False, layerwise: bool = False, relu_masks: Optional[torch.Tensor] = None,
+               emb_debug: Optional[torch.Tensor] = None) -> None:
     """One fused iteration (train.py:424-472): fills ws.grads, ws.loss_terms, ws.status.
 
     layerwise: OBJNERF_TRAIN_LAYERWISE -- run the layer-wise (any width) implementation even where the fused
@@ -365,6 +366,8 @@ def train_step(arena: ParamArena, ws: TrainWorkspace, batch: Dict[str, torch.Ten
 
     relu_masks: test hook -- uint8 [K,R,S,6,hidden/8] receiving the ReLU branch bits of the iteration
     (objnerf_train_args.relu_masks); None in production.
+    emb_debug: test hook -- float32 [K,R,S,129] receiving the embedding rows the fused fp32 kernel formed in registers
+    (objnerf_train_args.emb_debug; hidden 32, S <= 64, fp32 only); None in production.
 
     batch: pts [K,R,S,3] (or origins+dirs), z, gt_depth, gt_rgb, labels u8 (+ gt_feat when with_feat).
     global_flags: optional [2] int32 tensor already max-reduced over all ranks (object sharding)."""
@@ -394,13 +397,17 @@ def train_step(arena: ParamArena, ws: TrainWorkspace, batch: Dict[str, torch.Ten
         relu_masks = _req(relu_masks, torch.uint8, "relu_masks")
         if tuple(relu_masks.shape) != (K, R, S, 6, arena.net.hidden // 8):
             raise ObjnerfError("relu_masks must be uint8 [K,R,S,6,hidden/8]")
+    if emb_debug is not None:
+        emb_debug = _req(emb_debug, torch.float32, "emb_debug")
+        if tuple(emb_debug.shape) != (K, R, S, EMB1 + EMB2):
+            raise ObjnerfError("emb_debug must be float32 [K,R,S,129]")
     kc = getattr(ws, "k_chunk", K)
     ctx = ws.context.handle if getattr(ws, "context", None) is not None else None
     if kc >= K:
         a = TrainArgs(K, R, S, mode, color_scaling, opacity_scaling, feat_scaling, obj_center, _ptr(arena.params),
                       arena.p_stride, _ptr(arena.scale), _ptr(pts), _ptr(origins), _ptr(dirs), _ptr(z), _ptr(gt_depth),
                       _ptr(gt_rgb), _ptr(labels), _ptr(gt_feat), _ptr(counts), _ptr(flags), _ptr(ws.grads),
-                      _ptr(ws.loss_terms), _ptr(ws.status), _ptr(ws.buf), ws.nbytes, _ptr(relu_masks), ctx)
+                      _ptr(ws.loss_terms), _ptr(ws.status), _ptr(ws.buf), ws.nbytes, _ptr(relu_masks), ctx, _ptr(emb_debug))
         check(lib().objnerf_train_step(C.byref(net), C.byref(a), st), "objnerf_train_step")
         return
     # layer-wise path, chunk of objects at a time (leading-dimension slices are contiguous views)
@@ -412,7 +419,7 @@ def train_step(arena: ParamArena, ws: TrainWorkspace, batch: Dict[str, torch.Ten
                       _ptr(sl(origins, k0, k1)), _ptr(sl(dirs, k0, k1)), _ptr(z[k0:k1]), _ptr(gt_depth[k0:k1]),
                       _ptr(gt_rgb[k0:k1]), _ptr(labels[k0:k1]), _ptr(sl(gt_feat, k0, k1)), _ptr(counts[k0:k1]),
                       _ptr(flags), _ptr(ws.grads[k0:k1]), _ptr(ws.loss_terms[k0:k1]), _ptr(ws.status_chunks[ci:ci + 1]),
-                      _ptr(ws.buf), ws.nbytes, _ptr(sl(relu_masks, k0, k1)), ctx)
+                      _ptr(ws.buf), ws.nbytes, _ptr(sl(relu_masks, k0, k1)), ctx, _ptr(sl(emb_debug, k0, k1)))
         check(lib().objnerf_train_step(C.byref(net), C.byref(a), st), "objnerf_train_step")
     torch.amax(ws.status_chunks, dim=0, keepdim=True, out=ws.status)
 

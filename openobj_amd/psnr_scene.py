@@ -1,26 +1,39 @@
-"""The PSNR scene of BASELINE.json's metric ("... PSNR delta vs ref"; SURVEY.md 8(d), fixture G9): K analytic
-ellipsoids (synthetic.EllipsoidScene), the reference's initial weights for a seed, the seeded batches of
-tests/golden/make_golden.py g9, `steps` fused iterations, PSNR of the rendered colour on held-out rays.
+"""The PSNR scene of BASELINE.json's metric ("... PSNR delta vs ref"; SURVEY.md 8(d), fixtures G9 / G9b): K analytic
+ellipsoids (synthetic.EllipsoidScene), the reference's initial weights for a seed, seeded batches, `steps` fused
+iterations, PSNR of the rendered colour on held-out rays.
 
-The reference computes no PSNR anywhere; the reference side of the comparison is the ensemble its own modules
-produced for the same seeds (tests/golden/g9_ensemble.npz, written by tests/golden/make_g9_ensemble.py).  Training is
-chaotic -- a 1e-7 relative perturbation of the initial weights moves the reference's own 300-iteration PSNR by
-~0.5 dB -- so the delta is a difference of ENSEMBLE MEANS with a confidence interval, never a single run.
+The reference computes no PSNR anywhere; the reference side of every comparison is what its own modules produced for
+the same weight seeds in the build container (tests/golden/make_g9_ensemble.py, make_g9b_ensemble.py).  Two
+comparisons, because training is chaotic -- a 1e-7 relative perturbation of the initial weights moves the reference's
+own 300-iteration PSNR by ~0.5 dB:
+
+  * after 50 iterations two correct implementations have not diverged yet: the difference is taken PER SEED (paired);
+  * after 300 iterations only ENSEMBLE MEANS compare: difference of means with a Welch confidence interval.
+
+G9  (round 1/2): K = 4, 256 held-out rays per object, 128 reference seeds, colour loss only.
+G9B (SURVEY.md 8(d)'s definition): K = 8, 4096 held-out label-1 rays per object, 320 reference seeds without and 128
+    with the 512-d feature loss; `EnsembleRun` trains ALL seeds side by side -- n_seeds x K independent object
+    networks stacked into one arena, one fused launch per iteration (the objects of different seeds never interact:
+    the early-return flags of render_rays.py:89-94 span the stacked batch, and no object of this scene ever has an
+    empty mask).
 """
 import math
 import os
-from typing import Dict, List, Optional
+from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 import torch
 
 from . import cfg as ocfg
-from . import ops, synthetic, trainer
+from . import ops, optim, synthetic, trainer
 from . import train as otrain
 
+GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 G9 = dict(K=4, R=96, N=4, M=12, steps=300, eval_R=256, eval_S=32, scene_seed=7, weight_seed=90)
-ENSEMBLE_FIXTURE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
-                                "g9_ensemble.npz")
+G9B = dict(K=8, R=96, N=4, M=12, steps=300, early=50, eval_R=4096, eval_S=32, feat_R=256, scene_seed=7,
+           weight_seed=9000, batch_seed=9000)
+ENSEMBLE_FIXTURE = os.path.join(GOLDEN, "g9_ensemble.npz")
+MODES = {"f32": False, "bf16": True, "fp16": "fp16"}
 
 
 def _psnr(pred: torch.Tensor, gt: torch.Tensor) -> float:
@@ -29,6 +42,8 @@ def _psnr(pred: torch.Tensor, gt: torch.Tensor) -> float:
 
 
 class PsnrScene:
+    """The round-1 scene (G9), one weight seed per run."""
+
     def __init__(self, device, steps: Optional[int] = None):
         self.dev = torch.device(device)
         self.steps = steps or G9["steps"]
@@ -62,10 +77,19 @@ class PsnrScene:
 
 
 def reference_ensemble() -> Optional[Dict[str, np.ndarray]]:
-    """seeds / psnr arrays of the reference's own runs (None when the fixture is absent)."""
+    """seeds / psnr arrays of the reference's own G9 runs (None when the fixture is absent)."""
     try:
         d = np.load(ENSEMBLE_FIXTURE)
         return {"seeds": d["seeds"], "psnr": d["psnr"]}
+    except OSError:
+        return None
+
+
+def reference_ensemble_b(with_feat: bool = False) -> Optional[Dict[str, np.ndarray]]:
+    """The reference's G9b runs: seeds, psnr50, psnr300 (+ featcos300 with the feature loss); None when absent."""
+    try:
+        d = np.load(os.path.join(GOLDEN, "g9b_ensemble_%s.npz" % ("feat" if with_feat else "nofeat")))
+        return {k: d[k] for k in d.files}
     except OSError:
         return None
 
@@ -76,3 +100,130 @@ def delta_report(hip: np.ndarray, ref: np.ndarray) -> Dict[str, float]:
     return {"delta_db": float(hip.mean() - ref.mean()), "ci95_db": 1.96 * se, "hip_mean_db": float(hip.mean()),
             "ref_mean_db": float(ref.mean()), "hip_std_db": float(hip.std(ddof=1)), "ref_std_db": float(ref.std(ddof=1)),
             "n_hip": int(len(hip)), "n_ref": int(len(ref))}
+
+
+def paired_report(hip: np.ndarray, ref: np.ndarray) -> Dict[str, float]:
+    """Per-seed differences (same seed, same batches, before the trajectories diverge): mean, its 95 % half-width,
+    the largest single difference."""
+    d = np.asarray(hip, np.float64) - np.asarray(ref, np.float64)
+    return {"mean_delta_db": float(d.mean()), "ci95_db": float(1.96 * d.std(ddof=1) / math.sqrt(len(d))),
+            "max_abs_delta_db": float(np.abs(d).max()), "std_delta_db": float(d.std(ddof=1)), "n": int(len(d)),
+            "hip_mean_db": float(np.mean(hip)), "ref_mean_db": float(np.mean(ref))}
+
+
+class EnsembleRun:
+    """G9b: all weight seeds trained side by side in one arena (see the module docstring)."""
+
+    def __init__(self, device, with_feat: bool = False, spec: Optional[dict] = None):
+        self.dev = torch.device(device)
+        self.spec = dict(G9B if spec is None else spec)
+        self.with_feat = with_feat
+        s = self.spec
+        self.scene = synthetic.EllipsoidScene.make(s["K"], 512, seed=s["scene_seed"])
+        ev = self.scene.eval_rays(s["eval_R"], s["eval_S"])
+        self.ev = {k: torch.from_numpy(ev[k]).to(self.dev) for k in ("pts", "z", "gt_rgb")}
+        self.keys = ["pts", "z", "gt_depth", "gt_rgb", "labels"] + (["gt_feat"] if with_feat else [])
+        self.batches = []
+        for it in range(s["steps"]):                      # the same seeded batches for every weight seed
+            b = self.scene.batch(s["R"], s["N"], s["M"], seed=s["batch_seed"] + it, with_feat=with_feat)
+            self.batches.append({k: torch.from_numpy(b[k]).to(self.dev) for k in self.keys})
+        c = ocfg.Config(ocfg.replica_room0_config(train_device="cpu"))      # initial weights are drawn on the host
+        c.obj_id = 1
+        self.cfg = c
+        self.feat_gt = torch.from_numpy(self.scene.feat).to(self.dev)
+
+    def initial_arena(self, seeds: Sequence[int]) -> ops.ParamArena:
+        """n x K networks, object n * K + k = object k of seed n, each with the reference's initial weights for that
+        seed (torch.manual_seed(seed), then K Trainer constructions in order: trainer.py:36-44)."""
+        K = self.spec["K"]
+        blocks = []
+        for seed in seeds:
+            torch.manual_seed(int(seed))
+            blocks += [trainer.Trainer(self.cfg).arena.params[0] for _ in range(K)]
+        arena = ops.ParamArena(len(blocks), ops.NetShape(self.cfg.hidden_feature_size, self.cfg.clip_point_feature_size,
+                                                         self.cfg.n_unidir_funcs + 1), self.dev)
+        arena.params.copy_(torch.stack(blocks))
+        arena.scale.fill_(float(self.cfg.obj_scale))
+        return arena
+
+    def _evaluate(self, arena, n) -> Dict[str, np.ndarray]:
+        s, K = self.spec, self.spec["K"]
+        R, S = s["eval_R"], s["eval_S"]
+        psnr, fcos = [], []
+        sub = ops.ParamArena(K, arena.net, self.dev)
+        sub.scale.copy_(arena.scale[:K])
+        for i in range(n):                                # one seed (K objects, K x R x S points) at a time
+            sub.params.copy_(arena.params[i * K:(i + 1) * K])
+            a, c, _, _ = ops.eval_points(sub, self.ev["pts"].reshape(K, -1, 3))
+            out = ops.composite(a.reshape(-1, S), c.reshape(-1, S, 3), self.ev["z"].reshape(-1, S))
+            psnr.append(_psnr(out["rgb"].reshape(K, R, 3), self.ev["gt_rgb"]))
+            if self.with_feat:
+                Rf = s["feat_R"]
+                pts = self.ev["pts"][:, :Rf].reshape(K, -1, 3).contiguous()
+                a, c, hf, _ = ops.eval_points(sub, pts, want_hfeat=True)
+                H = hf.shape[-1]
+                o2 = ops.composite(a.reshape(-1, S), None, None, vals=hf.reshape(-1, S, H))
+                F = ops.feature_head(sub, o2["vals"].reshape(K, Rf, H), o2["opacity"].reshape(K, Rf))
+                fcos.append(torch.nn.functional.cosine_similarity(F, self.feat_gt[:, None, :], dim=-1).mean().item())
+        return {"psnr": np.array(psnr), "featcos": np.array(fcos) if self.with_feat else None}
+
+    def run(self, seeds: Sequence[int], mode=False) -> Dict[str, np.ndarray]:
+        """mode: ops.precision_bits (False / True = "bf16" / "fp16").  -> psnr50 [n], psnr300 [n] (+ featcos300)."""
+        s, n = self.spec, len(seeds)
+        arena = self.initial_arena(seeds)
+        nK = arena.K
+        S = s["N"] + s["M"]
+        ws = ops.TrainWorkspace(arena, nK, s["R"], S, self.with_feat, precision=mode)
+        opt = optim.ArenaAdamW(arena, lr=self.cfg.learning_rate, weight_decay=self.cfg.weight_decay)
+        mask = arena.has_grad_mask(self.with_feat)
+        early = None
+        for it, b in enumerate(self.batches):
+            batch = {k: v.repeat(n, *([1] * (v.dim() - 1))) for k, v in b.items()}
+            ops.train_step(arena, ws, batch, with_feat=self.with_feat, bf16=mode)
+            opt.step(ws.grads, mask, flags=ws.flags)
+            if it + 1 == s["early"]:
+                early = self._evaluate(arena, n)
+        if int(ws.status.item()) != 0:
+            raise RuntimeError("loss explode in the PSNR scene")
+        final = self._evaluate(arena, n)
+        out = {"psnr50": early["psnr"], "psnr300": final["psnr"]}
+        if self.with_feat:
+            out["featcos300"] = final["featcos"]
+        return out
+
+
+def compare(run: Dict[str, np.ndarray], ref: Dict[str, np.ndarray], n: int) -> Dict[str, dict]:
+    out = {"iter50": paired_report(run["psnr50"], ref["psnr50"][:n]),
+           "iter300": delta_report(run["psnr300"], ref["psnr300"][:n])}
+    if "featcos300" in run:
+        out["featcos300"] = {"hip_mean": float(run["featcos300"].mean()), "ref_mean": float(ref["featcos300"][:n].mean())}
+    return out
+
+
+def report(dev, n_seeds: int, modes: Sequence[str] = ("f32", "bf16"), feat_seeds: Optional[int] = None):
+    """The `psnr` block of bench.py: G9b without the feature loss for every mode in `modes`, with it for fp32 (and bf16
+    when asked); None when the reference fixtures are absent."""
+    ref = reference_ensemble_b(False)
+    if ref is None:
+        return None
+    s = G9B
+    out = {"scene": "G9b (SURVEY.md 8(d)): %d analytic ellipsoids, %d rays x %d samples per object and iteration, PSNR of "
+                    "the rendered colour on %d held-out label-1 rays per object after %d (per seed) and %d (ensemble) "
+                    "iterations; all seeds trained side by side in one arena"
+                    % (s["K"], s["R"], s["N"] + s["M"], s["eval_R"], s["early"], s["steps"]),
+           "reference": "the reference's own modules, same weight seeds and batches (tests/golden/g9b_ensemble_*.npz)",
+           "iter50": {}, "iter300": {}}
+    n = min(n_seeds, len(ref["seeds"]))
+    seeds = [int(x) for x in ref["seeds"][:n]]
+    er = EnsembleRun(dev, with_feat=False)
+    for m in modes:
+        c = compare(er.run(seeds, MODES[m]), ref, n)
+        out["iter50"][m], out["iter300"][m] = c["iter50"], c["iter300"]
+    del er
+    reff = reference_ensemble_b(True)
+    if reff is not None:
+        nf = min(feat_seeds or n_seeds, len(reff["seeds"]))
+        fseeds = [int(x) for x in reff["seeds"][:nf]]
+        er = EnsembleRun(dev, with_feat=True)
+        out["with_feature_loss"] = {m: compare(er.run(fseeds, MODES[m]), reff, nf) for m in modes if m != "fp16"}
+    return out

@@ -26,9 +26,16 @@ def occupancy_to_termination(occupancy, is_batch=False):
 
 def render(termination, vals, dim=-1):
     """Weighted sum of per-sample values along a ray (reference render_rays.py:56-63; the reference multiplies tensors
-    of equal shape and sums over `dim`): objnerf_render.  vals may also carry a trailing channel axis [..., S, C]."""
+    of equal shape and sums over `dim`): objnerf_render.  Two call forms:
+      render(term [..., S], vals [..., S])            dim = -1  (loss.py:28 depth, vmap.py:664)
+      render(term [..., S, 1], vals [..., S, C], -2)  the reference's vector form (loss.py:34,82, vmap.py:670,678)
+    and, beyond the reference, vals with a trailing channel axis next to an un-expanded termination [..., S]."""
+    if dim in (-2, termination.dim() - 2) and termination.dim() >= 2 and termination.shape[-1] == 1 \
+            and vals.dim() == termination.dim():
+        return ops.render(termination[..., 0].contiguous(), vals.contiguous())
     if dim not in (-1, termination.dim() - 1):
-        raise ValueError("render: the sample axis must be termination's last axis")
+        raise ValueError("render: the sample axis must be termination's last axis (or dim=-2 with a trailing "
+                         "singleton axis on termination, the reference's vector form)")
     return ops.render(termination.contiguous(), vals.expand_as(termination).contiguous()
                       if vals.dim() == termination.dim() else vals.contiguous())
 

@@ -84,8 +84,12 @@ class ShardedIteration:
 
     obj_loop / bg_loop may be None (a rank without foreground objects, do_bg = 0)."""
 
-    def __init__(self, obj_loop=None, bg_loop=None, group=None, overlap: bool = True, resident: bool = False):
-        """overlap: the pre-step exchange and the whole background chain (its kernels, its collective's wait, its AdamW)
+    def __init__(self, obj_loop=None, bg_loop=None, group=None, overlap: bool = True, resident: bool = False,
+                 device=None):
+        """device: where this rank's collectives' buffers live (cfg.training_device).  Needed by a rank that is handed
+        NO batch in some iteration (no foreground object yet, do_bg = 0): it still has to join both exchanges, or the
+        other ranks block in them.  Defaults to the device of the first batch seen.
+        overlap: the pre-step exchange and the whole background chain (its kernels, its collective's wait, its AdamW)
         run on a second HIP stream beside the object kernel -- the two are independent (own parameters, moments and
         batches; the reference only adds their losses before ONE backward, train.py:463).  The object stream waits
         for that stream twice: for the global flags before its kernel, and before step() returns.
@@ -95,6 +99,7 @@ class ShardedIteration:
         for the work queued on the caller's stream at every step()."""
         self.obj_loop, self.bg_loop, self.group = obj_loop, bg_loop, group
         self.overlap, self.resident = overlap, resident
+        self.device = torch.device(device) if device is not None else None
         self._side = None
 
     def _bg_stream(self, dev):
@@ -107,8 +112,20 @@ class ShardedIteration:
     def step(self, obj_batch=None, bg_batch=None):
         """-> (object loss terms [K,4] | None, background loss terms [1,4] | None)"""
         ref = obj_batch if obj_batch is not None else bg_batch
-        dev = ref["z"].device
+        if ref is not None and self.device is None:
+            self.device = ref["z"].device
+        dev = self.device
         sharded = odist._active(self.group)
+        if ref is None:
+            # nothing to train on this rank in this iteration (no foreground object yet and no background batch).
+            # Unsharded that is a no-op; sharded, the rank still joins collective 1 with zeros (flags and counts are
+            # SUMs, so the other ranks' values pass through) -- otherwise they would block in it.  Collective 2 is
+            # issued by the ranks that were handed background rays: every rank or none (the caller splits ONE
+            # replicated batch over all ranks).
+            if not sharded:
+                return None, None
+            if dev is None:
+                raise ValueError("ShardedIteration.step(None, None) under sharding needs device= at construction")
         do_obj = obj_batch is not None and self.obj_loop is not None
         do_bg = bg_batch is not None and self.bg_loop is not None
         side = self._bg_stream(dev) if do_obj and do_bg else None

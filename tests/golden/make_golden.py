@@ -214,9 +214,10 @@ def g4():
 
 
 # ---------------------------------------------------------------------------------------- G5/G6
-def run_reference_steps(ts, batches, feat_on, n_steps, lr=1e-3, wd=0.013, record_grads=True):
+def run_reference_steps(ts, batches, feat_on, n_steps, lr=1e-3, wd=0.013, record_grads=True, on_step=None):
     """train.py:78,272-276,424-474 on CPU: update_vmap -> vmap(pe)/vmap(fc) -> step_batch_loss
-    -> backward -> AdamW.step -> zero_grad."""
+    -> backward -> AdamW.step -> zero_grad.  on_step(n_done, fc_param, pe_param): optional observer called after
+    every optimiser step (the G9b ensembles read the PSNR after 50 iterations of the SAME run that goes on to 300)."""
     optimiser = torch.optim.AdamW([torch.autograd.Variable(torch.tensor(0))], lr=lr, weight_decay=wd)
     fc_models = [t.fc_occ_map for t in ts]
     pe_models = [t.pe for t in ts]
@@ -243,6 +244,8 @@ def run_reference_steps(ts, batches, feat_on, n_steps, lr=1e-3, wd=0.013, record
                                  for p in list(fc_param) + list(pe_param)])
         optimiser.step()
         optimiser.zero_grad(set_to_none=True)
+        if on_step is not None:
+            on_step(it + 1, fc_param, pe_param)
         if record_grads:
             rec["params"].append([p.detach().clone() for p in list(fc_param) + list(pe_param)])
     rec["final_fc"] = [p.detach().clone() for p in fc_param]

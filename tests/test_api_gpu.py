@@ -85,6 +85,12 @@ def test_render_rays_helpers_g3(golden, dev):
     assert maxerr(render_rays.render(term, T(g["z"]).to(dev)), g["depth"]) < 1e-5
     col = torch.rand(*term.shape, 3, generator=torch.Generator().manual_seed(1)).to(dev)      # [.., S, C] values
     assert maxerr(render_rays.render(term, col), (term[..., None] * col).sum(dim=-2)) < 1e-5
+    # the reference's own vector call form (loss.py:34,82, vmap.py:670,678): render(termination[..., None], color, dim=-2)
+    assert maxerr(render_rays.render(term[..., None], col, dim=-2), (term[..., None] * col).sum(dim=-2)) < 1e-5
+    color = T(g["color"]).to(dev)
+    assert maxerr(render_rays.render(term[..., None], color, dim=-2), g["rgb"]) < 1e-5
+    with pytest.raises(ValueError):
+        render_rays.render(term, col, dim=0)
 
 
 @pytest.mark.parametrize("feat_on", [False, True])

@@ -129,11 +129,17 @@ def _worker(rank, world, port, q):
         ol, bl = ObjLoop(), BgLoop()
         ot, bt = otrain.ShardedIteration(ol, bl).step({"z": torch.zeros(2, 3, 4), "labels": None},
                                                       {"z": torch.zeros(1, 3, 4), "labels": None})
+        # one foreground object in the whole job and do_bg = 0 (mapping.train_frame on a rank that owns nothing):
+        # rank 1 is handed NO batch and must still join collective 1, or rank 0 blocks in it
+        ol2 = ObjLoop()
+        it2 = otrain.ShardedIteration(ol2 if rank == 0 else None, None, device="cpu")
+        r2 = it2.step({"z": torch.zeros(1, 3, 4), "labels": None} if rank == 0 else None, None)
+        lone = (r2[0].tolist() if r2[0] is not None else None, r2[1], getattr(ol2, "seen_flags", None))
     finally:
         oops.label_counts = _lc
     q.put((rank, flags.tolist(), float(tot), counts.tolist(), grads[0, 0].item(), odist.rank_world(), w[0, 0].item(),
            (gflags.tolist(), bg_counts.tolist(), bg_flags.tolist(), flat.tolist()),
-           (ol.seen_flags, bl.seen, bt.tolist())))
+           (ol.seen_flags, bl.seen, bt.tolist()), lone))
     dist.destroy_process_group()
 
 
@@ -150,7 +156,7 @@ def test_two_rank_flags_and_loss_gloo():
         p.join(60)
     expect = 2 * (1 + 5 + 10 + 5) * 1.0 + 2 * (1 + 5 + 10 + 5) * 2.0
     assert odist.rank_world() == (0, 1)              # no process group in this process
-    for rank, flags, tot, counts, g0, rw, w0, packed, orch in res:
+    for rank, flags, tot, counts, g0, rw, w0, packed, orch, lone in res:
         assert rw == (rank, 2) and w0 == 10.0
         assert flags == [1, 0]
         assert abs(tot - expect) < 1e-4
@@ -160,6 +166,13 @@ def test_two_rank_flags_and_loss_gloo():
         assert packed[3] == [3.0] * 8 + [1.5] * 4                      # gradient and loss terms in ONE all-reduce
         # orchestration: both ranks see rank 0's empty mask, the background's GLOBAL counts, and the summed buffer
         assert orch[0] == [0, 1] and orch[1] == ([[1200, 5]], [0, 0]) and orch[2] == [[3.0, 3.0, 3.0, 3.0]]
+        # the rank without a batch returned (None, None) after joining the exchange; the owner saw ITS flags only
+        assert lone == (([[0.0] * 4] * 2, None, [0, 1]) if rank == 0 else (None, None, None))
+
+
+def test_sharded_iteration_without_batches_unsharded_is_a_noop():
+    from openobj_amd import train as otrain
+    assert otrain.ShardedIteration(None, None).step(None, None) == (None, None)
 
 
 def test_view_buffers_zbuffer_merge():
