@@ -36,3 +36,10 @@ int eval_points(const objnerf_net* net, int K, long N, const float* params, long
                 const float* pts, float* out_alpha, float* out_color, float* out_hfeat, float* out_clip,
                 void* workspace, size_t workspace_bytes, void* stream, const float* emb_in = nullptr);
 }
+
+// hidden 256 in the 16-bit operand modes without the feature loss (BASELINE configs[4]): objnerf_train256.hip
+namespace obj256 {
+bool applicable(const objnerf_net* net, const objnerf_train_args* a);
+size_t workspace_bytes(int K, int R, int S);
+int train_step(const objnerf_net* net, const objnerf_train_args* a, void* stream);
+}

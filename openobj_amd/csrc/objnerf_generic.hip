@@ -1853,7 +1853,12 @@ static WS carve(char* base, int H, int C, long n, long R, int K, bool feat, bool
 size_t train_workspace_bytes(const objnerf_net* net, int K, int R, int S, int feat, int sixteen) {
   WS w = carve(nullptr, net->hidden, net->feat_dim, (long)R * S, (long)R, K, feat != 0,
                sixteen && acts16_shape(net->hidden, (long)R * S));
-  return w.bytes + 256;
+  size_t need = w.bytes + 256;
+  if (net->hidden == 256 && (S == 32 || S == 64 || S == 128)) {      // the fused hidden-256 path (16-bit modes)
+    const size_t n256 = obj256::workspace_bytes(K, R, S);
+    if (n256 > need) need = n256;
+  }
+  return need;
 }
 
 }  // namespace objgen

@@ -1053,6 +1053,9 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
                                                            (a->mode & (OBJNERF_TRAIN_FP16 | OBJNERF_TRAIN_BF16)) != 0))
       return OBJNERF_EINVAL;
     if (a->emb_debug) return OBJNERF_ENOTSUP;
+#ifndef OBJ_NO_TRAIN256
+    if (!(a->mode & OBJNERF_TRAIN_LAYERWISE) && obj256::applicable(net, a)) return obj256::train_step(net, a, stream);
+#endif
     (void)hipMemsetAsync(a->status, 0, sizeof(int), (hipStream_t)stream);
     return objgen::train_step(net, a, stream);
   }

@@ -116,7 +116,7 @@ def oracle_step(fc, B, scale, b, feat, dtype=None, device="cpu", k_chunk=None, d
 
 
 def oracle_step_16(fc, B, scale, b, feat, operand_dtype, act16, grad_scale=1.0, round_head_weights=False,
-                   device="cpu"):
+                   device="cpu", round_head_grads=False):
     """One iteration through the SPECIFICATION of the opt-in 16-bit modes (oracle.mlp_forward_stacked_16: operands of
     every hidden nn.Linear rounded to the operand type, fp32 accumulation).  Same result dict as oracle_step."""
     K = B.shape[0]
@@ -129,7 +129,7 @@ def oracle_step_16(fc, B, scale, b, feat, operand_dtype, act16, grad_scale=1.0, 
     loss, t = O.train_forward_loss(fcr, Br, sc, tb["pts"], tb["gt_depth"], tb["gt_rgb"], tb["labels"], tb["z"],
                                    gt_feat=tb["gt_feat"] if feat else None, return_terms=True, do_clip=bool(feat),
                                    operand_dtype=operand_dtype, act16=act16, grad_scale=grad_scale,
-                                   round_head_weights=round_head_weights)
+                                   round_head_weights=round_head_weights, round_head_grads=round_head_grads)
     loss.backward()
     terms = torch.zeros(K, 4, dtype=torch.float64)
     for j, name in enumerate(["depth", "color", "opacity", "feat"]):

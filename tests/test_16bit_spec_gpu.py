@@ -23,8 +23,10 @@ pytestmark = pytest.mark.gpu
 
 DT = {"bf16": torch.bfloat16, "fp16": torch.float16}
 # relative-norm bounds per gradient tensor: an order below the former "within 15 % / 2 % of the fp32 kernel" ones
-# (measured, profiles/r03_16bit_spec.txt: bf16 <= 3.3e-3, fp16 <= 1.6e-3; most tensors 1e-5 .. 5e-4)
-BOUND = {"bf16": 0.01, "fp16": 0.003}
+# (measured, profiles/r03_16bit_spec.txt: bf16 <= 3.3e-3, fp16 <= 7.1e-3 -- the colour layer of a 9000-sample batch,
+# where a handful of units whose pre-activation sits within one 16-bit rounding step of zero take the other ReLU branch
+# in any two implementations of the same specification; most tensors 1e-5 .. 1e-3)
+BOUND = {"bf16": 0.01, "fp16": 0.01}
 
 
 def _run(dev, K, R, n1, n2, H, feat, mode, seed=7):
@@ -53,10 +55,12 @@ def test_layerwise_16bit_step_matches_its_specification(dev, mode, shape):
         pytest.skip("small hidden-128 batches run the one-launch fp32 kernels in fp16 mode (objnerf_generic.hip "
                     "small_batch_rt): nothing is rounded, test_hip_parity.py covers that path")
     arena, st, b, ws, _ = _run(dev, K, R, n1, n2, H, False, mode)
-    n = R * (n1 + n2)
-    act16 = H == 256 and n >= 4096
+    # hidden 256 with S a power of two in 32..256: the fused objnerf_train256.hip path -- activations ARE the next MFMA's
+    # 16-bit operands, the heads and their gradients run on the matrix core too
+    fused256 = H == 256 and (n1 + n2) in (32, 64, 128, 256)
     gs = 2.0 ** (math.floor(math.log2(R)) + 3) if mode == "fp16" else 1.0
-    o = oracle_step_16(list(st[:18]), st[18], 2.0, b, False, DT[mode], act16, gs, device=dev)
+    o = oracle_step_16(list(st[:18]), st[18], 2.0, b, False, DT[mode], fused256, gs, device=dev,
+                       round_head_weights=fused256, round_head_grads=fused256)
     np.testing.assert_allclose(ws.loss_terms.double().cpu()[:, :3], o["terms"][:, :3], rtol=2e-4 if mode == "fp16" else 2e-3,
                                atol=1e-5)
     gv = arena.views(ws.grads)
