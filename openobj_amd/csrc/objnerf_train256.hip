@@ -653,16 +653,17 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
       return [&](auto ks_tag) __attribute__((always_inline)) {
         constexpr int CD = decltype(cd_tag)::value, NK = decltype(nk_tag)::value, KS = decltype(ks_tag)::value;
         if constexpr (KS == 0) flush_pending();
-        // transfer i after MFMA i (as early as possible: it has until the end of the NEXT stage to land); whatever has
-        // no such slot after the last MFMA
+        // one wave issues one instruction per ~4 cycles: the side work is spread, a transfer behind every other MFMA
+        // (transfer i after MFMA 2 i + 1), so that no gap between two MFMAs holds more than the MFMA's own 32 cycles;
+        // whatever has no such slot goes after the last MFMA
         if constexpr (KS == NK - 1) {
-          if constexpr (0 >= NK - 1 && 0 < CD) ring.template issue<0>();
-          if constexpr (1 >= NK - 1 && 1 < CD) ring.template issue<1>();
-          if constexpr (2 >= NK - 1 && 2 < CD) ring.template issue<2>();
-          if constexpr (3 >= NK - 1 && 3 < CD) ring.template issue<3>();
-          if constexpr (4 >= NK - 1 && 4 < CD) ring.template issue<4>();
-          if constexpr (5 >= NK - 1 && 5 < CD) ring.template issue<5>();
-        } else if constexpr (KS < CD) ring.template issue<KS>();
+          if constexpr (1 >= NK - 1 && 0 < CD) ring.template issue<0>();
+          if constexpr (3 >= NK - 1 && 1 < CD) ring.template issue<1>();
+          if constexpr (5 >= NK - 1 && 2 < CD) ring.template issue<2>();
+          if constexpr (7 >= NK - 1 && 3 < CD) ring.template issue<3>();
+          if constexpr (9 >= NK - 1 && 4 < CD) ring.template issue<4>();
+          if constexpr (11 >= NK - 1 && 5 < CD) ring.template issue<5>();
+        } else if constexpr ((KS & 1) && KS / 2 < CD) ring.template issue<KS / 2>();
       };
     };
     auto reload = [&]() __attribute__((always_inline)) {          // hin <- the fragments the layer just produced
@@ -980,19 +981,20 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // kernel B: weight gradients.  Task types (A rows x B columns, both read back from kernel A's fragments):
-//   0 L2   d_pre2 x h1      1 L3h  d_pre3 x h2     2 L4  d_pre4 x h3      3 L5h  d_pre5 x h4          (8 x 8 blocks)
-//   4 L1   d_pre1 x x1      5 L3x  d_pre3 x x1                                                          (8 x 3)
-//   6 L5x  d_pre5 x x2                                                                                  (8 x 2)
-//   7 col  d_head x hc      8 alp  d_head x h4                                                          (1 x 8)
+//   0 L2   d_pre2 x h1                 2 L4  d_pre4 x h3                                   (8 x 8 blocks)
+//   1 L3   d_pre3 x [h2 | x1]                                                              (8 x 11: one pass over d_pre3)
+//   3 L5   [d_pre5 ; d_head] x [h4 | x2]      (8 x 10, + the head row block x h4: one pass over d_pre5 and h4)
+//   4 L1   d_pre1 x x1                                                                     (8 x 3)
+//   5 col  d_head x hc                                                                     (1 x 8)
 // Every task also yields the row sums of its A operand (bias gradients).  A workgroup takes one (object, type, part)
-// = a range of sample groups, and writes its partial tiles [RB][CB][32][32] + row sums [RB][32] into its slab.
+// = a range of sample groups, and writes its partial tiles [.][32][32] + row sums into its slab.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int NTYPE = 9;
-__host__ __device__ constexpr int type_rb(int t) { return t >= 7 ? 1 : 8; }
-__host__ __device__ constexpr int type_cb(int t) { return t < 4 ? 8 : (t < 6 ? 3 : (t == 6 ? 2 : 8)); }
-__host__ __device__ constexpr int type_slab(int t) { return type_rb(t) * type_cb(t) * 1024 + type_rb(t) * 32; }
+constexpr int NTYPE = 6;
+__host__ __device__ constexpr int type_tiles(int t) { return t == 1 ? 88 : t == 3 ? 88 : t == 4 ? 24 : t == 5 ? 8 : 64; }
+__host__ __device__ constexpr int type_rows(int t) { return t == 3 ? 9 * 32 : t == 5 ? 32 : 8 * 32; }      // row sums
+__host__ __device__ constexpr int type_slab(int t) { return type_tiles(t) * 1024 + type_rows(t); }
 __host__ __device__ constexpr int type_pieces(int t) {      // 1-KB pieces per sample group
-  return (t >= 7 ? 1 : 16) + (t < 4 || t >= 7 ? 16 : (t < 6 ? KS_X1 : KS_X2));
+  return t == 1 ? 16 + 16 + KS_X1 : t == 3 ? 16 + 1 + 16 + KS_X2 : t == 4 ? 16 + KS_X1 : t == 5 ? 1 + 16 : 32;
 }
 struct WgArgs {
   int K;
@@ -1161,6 +1163,162 @@ __device__ __forceinline__ void wgrad_task(const WgArgs& a, const char* Asrc, co
   }
 }
 
+// The concatenated layers in ONE pass over their d_pre: rows = the 8 blocks of d_pre (wave w owns block w), columns =
+// [hidden input (8 blocks) | x slots (CBX blocks)]; HEAD: the d_head row block x the hidden input on top (wave w: its
+// column block w) -- the density head's weight gradient shares the read of h4.  One sample group per chunk.
+template <typename OT, int KSX, bool HEAD>
+__device__ __forceinline__ void wgrad_cat(const char* Asrc, const char* Hsrc, const char* Bsrc, const char* Xsrc, const long sg0,
+                                          const long sg1, float* slab, char* lds) {
+  typedef typename Op<OT>::V V;
+  constexpr int CBX = (KSX + 1) / 2, CB = 8 + CBX;
+  constexpr int NA = 8 + (HEAD ? 1 : 0);                       // block images of the A side
+  constexpr int NP = 16 + (HEAD ? 1 : 0) + 16 + KSX;           // pieces per sample group
+  constexpr int PPW = (NP + NWAVE - 1) / NWAVE;
+  constexpr int BUF = (NA + CB) * IMG_BLK;
+  static_assert(2 * BUF <= 163840, "LDS");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int s = lane & 31, h = lane >> 5;
+  f32x16 acc[CB], hacc = zero16();
+#pragma unroll
+  for (int j = 0; j < CB; ++j) acc[j] = zero16();
+  float rs = 0.f, rsh = 0.f;
+
+  uint4 stg[PPW];
+  auto load_chunk = [&](const long sg) {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int p = w + NWAVE * i;
+      stg[i] = make_uint4(0, 0, 0, 0);
+      if (p < NP && sg < sg1) {
+        const char* src;
+        if (p < 16) src = Asrc + ((sg * 16 + p) * 64 + lane) * 16;
+        else if (HEAD && p == 16) src = Hsrc + (sg * 64 + lane) * 16;
+        else if (p < NP - KSX) src = Bsrc + ((sg * 16 + (p - (NP - KSX - 16))) * 64 + lane) * 16;
+        else src = Xsrc + ((sg * KSX + (p - (NP - KSX))) * 64 + lane) * 16;
+        stg[i] = *reinterpret_cast<const uint4*>(src);
+      }
+    }
+  };
+  auto store_chunk = [&](char* buf) {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int p = w + NWAVE * i;
+      if (p < NP) {
+        const uint2 lo = make_uint2(stg[i].x, stg[i].y), hi = make_uint2(stg[i].z, stg[i].w);
+        int blk, ks; bool hidden;
+        if (p < 16) { blk = p >> 1; ks = p; hidden = true; }
+        else if (HEAD && p == 16) { blk = 8; ks = 0; hidden = false; }
+        else if (p < NP - KSX) { ks = p - (NP - KSX - 16); blk = NA + (ks >> 1); hidden = true; }
+        else { ks = p - (NP - KSX); blk = NA + 8 + (ks >> 1); hidden = false; }
+        char* base = buf + blk * IMG_BLK + s * IMG_PITCH;
+        if (hidden) {
+          char* d = base + (16 * (ks & 1) + 4 * h) * 2;
+          *reinterpret_cast<uint2*>(d) = lo;
+          *reinterpret_cast<uint2*>(d + 16) = hi;
+        } else {
+          char* d = base + (16 * (ks & 1) + 8 * h) * 2;
+          *reinterpret_cast<uint2*>(d) = lo;
+          *reinterpret_cast<uint2*>(d + 8) = hi;
+        }
+      }
+    }
+  };
+  const uint32_t lds0 = (uint32_t)(uintptr_t)lds;
+  const int grp = (lane >> 4) & 1, li = lane & 15;
+  const uint32_t tr_lane = (uint32_t)(((li >> 2) + 8 * h) * IMG_PITCH + (16 * grp + 4 * (li & 3)) * 2);
+  auto frag = [&](const uint32_t ad) __attribute__((always_inline)) -> V {
+    uint2 lo = lds_tr16(ad), hi = lds_tr16(ad + 4 * IMG_PITCH);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo), "+v"(hi)::"memory");
+    const uint4 u = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    return *reinterpret_cast<const V*>(&u);
+  };
+
+  load_chunk(sg0);
+  store_chunk(lds);
+  __syncthreads();
+  int cur = 0;
+  for (long sg = sg0; sg < sg1; ++sg) {
+    const bool more = sg + 1 < sg1;
+    if (more) load_chunk(sg + 1);
+    const uint32_t buf = lds0 + cur * BUF;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const uint32_t rowoff = buf + kk * 16 * IMG_PITCH + tr_lane;
+      // the A operand (and the head rows), then the columns four at a time (the tr reads of a batch share one wait;
+      // all eleven at once do not fit the 256 registers next to 176 accumulators)
+      uint2 alo = lds_tr16(rowoff + w * IMG_BLK), ahi = lds_tr16(rowoff + w * IMG_BLK + 4 * IMG_PITCH);
+      uint2 hlo = alo, hhi = ahi;
+      if (HEAD) { hlo = lds_tr16(rowoff + 8 * IMG_BLK); hhi = lds_tr16(rowoff + 8 * IMG_BLK + 4 * IMG_PITCH); }
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(alo), "+v"(ahi), "+v"(hlo), "+v"(hhi)::"memory");
+      const uint4 ua = make_uint4(alo.x, alo.y, ahi.x, ahi.y);
+      const V af = *reinterpret_cast<const V*>(&ua);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) rs += (float)af[j];
+#pragma unroll
+      for (int j0 = 0; j0 < CB; j0 += 4) {
+        uint2 blo[4], bhi[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (j0 + j < CB) { blo[j] = lds_tr16(rowoff + (NA + j0 + j) * IMG_BLK); bhi[j] = lds_tr16(rowoff + (NA + j0 + j) * IMG_BLK + 4 * IMG_PITCH); }
+          else { blo[j] = blo[0]; bhi[j] = bhi[0]; }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(blo[0]), "+v"(bhi[0]), "+v"(blo[1]), "+v"(bhi[1]), "+v"(blo[2]), "+v"(bhi[2]),
+                     "+v"(blo[3]), "+v"(bhi[3])::"memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (j0 + j < CB) {
+            const uint4 ub = make_uint4(blo[j].x, blo[j].y, bhi[j].x, bhi[j].y);
+            acc[j0 + j] = Op<OT>::mfma(af, *reinterpret_cast<const V*>(&ub), acc[j0 + j]);
+          }
+      }
+      if (HEAD) {
+        const uint4 uh = make_uint4(hlo.x, hlo.y, hhi.x, hhi.y);
+        const V hf = *reinterpret_cast<const V*>(&uh);
+        if (w == 0) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) rsh += (float)hf[j];
+        }
+        // this wave's column block w of the hidden input
+        V bw;
+        {
+          const uint32_t ad = rowoff + (NA + w) * IMG_BLK;
+          uint2 lo = lds_tr16(ad), hi = lds_tr16(ad + 4 * IMG_PITCH);
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo), "+v"(hi)::"memory");
+          const uint4 u = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          bw = *reinterpret_cast<const V*>(&u);
+        }
+        hacc = Op<OT>::mfma(hf, bw, hacc);
+      }
+    }
+    (void)frag;
+    if (more) store_chunk(lds + (cur ^ 1) * BUF);
+    __syncthreads();
+    cur ^= 1;
+  }
+  // slab: tiles (rb = wave, cb) at (w * CB + cb) * 1024; HEAD: head tiles at (8 * CB + w) * 1024; row sums behind the tiles
+#pragma unroll
+  for (int j = 0; j < CB; ++j) {
+    float* t = slab + (w * CB + j) * 1024;
+#pragma unroll
+    for (int n = 0; n < 16; ++n) t[acc_row(n, h) * 32 + s] = acc[j][n];
+  }
+  constexpr int NT = 8 * CB + (HEAD ? 8 : 0);
+  if (HEAD) {
+    float* t = slab + (8 * CB + w) * 1024;
+#pragma unroll
+    for (int n = 0; n < 16; ++n) t[acc_row(n, h) * 32 + s] = hacc[n];
+  }
+  {
+    const float v = rs + __shfl_xor(rs, 32, 64);
+    if (h == 0) slab[NT * 1024 + w * 32 + s] = v;
+    if (HEAD && w == 0) {
+      const float vh = rsh + __shfl_xor(rsh, 32, 64);
+      if (h == 0) slab[NT * 1024 + 256 + s] = vh;
+    }
+  }
+}
+
 template <typename OT>
 __global__ __launch_bounds__(NTHR) void wgrad256_kernel(const WgArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -1176,14 +1334,11 @@ __global__ __launch_bounds__(NTHR) void wgrad256_kernel(const WgArgs a) {
   const char* x1 = ws + a.wl.off_x1; const char* x2 = ws + a.wl.off_x2; const char* dh = ws + a.wl.off_dhead;
   switch (t) {
     case 0: wgrad_task<OT, 8, 8, 4, 2, 0, 0, 0>(a, act(6), act(0), sg0, sg1, slab, lds); break;
-    case 1: wgrad_task<OT, 8, 8, 4, 2, 0, 0, 0>(a, act(7), act(1), sg0, sg1, slab, lds); break;
+    case 1: wgrad_cat<OT, KS_X1, false>(act(7), dh, act(1), x1, sg0, sg1, slab, lds); break;
     case 2: wgrad_task<OT, 8, 8, 4, 2, 0, 0, 0>(a, act(8), act(2), sg0, sg1, slab, lds); break;
-    case 3: wgrad_task<OT, 8, 8, 4, 2, 0, 0, 0>(a, act(9), act(3), sg0, sg1, slab, lds); break;
+    case 3: wgrad_cat<OT, KS_X2, true>(act(9), dh, act(3), x2, sg0, sg1, slab, lds); break;
     case 4: wgrad_task<OT, 8, 3, 8, 1, 0, 2, KS_X1>(a, act(5), x1, sg0, sg1, slab, lds); break;
-    case 5: wgrad_task<OT, 8, 3, 8, 1, 0, 2, KS_X1>(a, act(7), x1, sg0, sg1, slab, lds); break;
-    case 6: wgrad_task<OT, 8, 2, 8, 1, 0, 2, KS_X2>(a, act(9), x2, sg0, sg1, slab, lds); break;
-    case 7: wgrad_task<OT, 1, 8, 1, 8, 1, 0, 0>(a, dh, act(4), sg0, sg1, slab, lds); break;
-    default: wgrad_task<OT, 1, 8, 1, 8, 1, 0, 0>(a, dh, act(3), sg0, sg1, slab, lds); break;
+    default: wgrad_task<OT, 1, 8, 1, 8, 1, 0, 0>(a, dh, act(4), sg0, sg1, slab, lds); break;
   }
 }
 
@@ -1226,31 +1381,28 @@ __global__ __launch_bounds__(256) void finalize256_kernel(const FinArgs a) {
   if (i < a.P) {
     float v = 0.f;
     bool has = true;
-    // tile element (rb, cb, row, col) of a task with CB column blocks: (rb * CB + cb) * 1024 + row * 32 + col
-    auto wide = [&](int t, int o, int c) { return slab_sum(a, k, t, (long)((o >> 5) * 8 + (c >> 5)) * 1024 + (o & 31) * 32 + (c & 31)); };
-    auto rowsum = [&](int t, int o) { return slab_sum(a, k, t, (long)type_rb(t) * type_cb(t) * 1024 + o); };
+    // tile element: tile * 1024 + row * 32 + col; row sums behind a task's tiles
+    auto tile = [&](int t, int tl, int row, int col) { return slab_sum(a, k, t, (long)tl * 1024 + row * 32 + col); };
+    auto rowsum = [&](int t, int o) { return slab_sum(a, k, t, (long)type_tiles(t) * 1024 + o); };
     if (i < L.in_b) { const int o = (int)(i - L.in_w) / E1, c = (int)(i - L.in_w) % E1; const int pos = x1_col_pos(c);
-                      v = slab_sum(a, k, 4, (long)((o >> 5) * 3 + (pos >> 10)) * 1024 + (o & 31) * 32 + (pos & 1023)); }
+                      v = tile(4, (o >> 5) * 3 + (pos >> 10), o & 31, pos & 1023); }
     else if (i < L.m1_w) v = rowsum(4, (int)(i - L.in_b));
-    else if (i < L.m1_b) { const int e = (int)(i - L.m1_w); v = wide(0, e / HID, e % HID); }
+    else if (i < L.m1_b) { const int e = (int)(i - L.m1_w), o = e / HID, c = e % HID; v = tile(0, (o >> 5) * 8 + (c >> 5), o & 31, c & 31); }
     else if (i < L.cat_w) v = rowsum(0, (int)(i - L.m1_b));
     else if (i < L.cat_b) { const int e = (int)(i - L.cat_w), o = e / (HID + E1), c = e % (HID + E1);
-                            if (c < HID) v = wide(1, o, c);
-                            else { const int pos = x1_col_pos(c - HID);
-                                   v = slab_sum(a, k, 5, (long)((o >> 5) * 3 + (pos >> 10)) * 1024 + (o & 31) * 32 + (pos & 1023)); } }
+                            if (c < HID) v = tile(1, (o >> 5) * 11 + (c >> 5), o & 31, c & 31);
+                            else { const int pos = x1_col_pos(c - HID); v = tile(1, (o >> 5) * 11 + 8 + (pos >> 10), o & 31, pos & 1023); } }
     else if (i < L.m2_w) v = rowsum(1, (int)(i - L.cat_b));
-    else if (i < L.m2_b) { const int e = (int)(i - L.m2_w); v = wide(2, e / HID, e % HID); }
+    else if (i < L.m2_b) { const int e = (int)(i - L.m2_w), o = e / HID, c = e % HID; v = tile(2, (o >> 5) * 8 + (c >> 5), o & 31, c & 31); }
     else if (i < L.a_w) v = rowsum(2, (int)(i - L.m2_b));
-    else if (i < L.a_b) { const int c = (int)(i - L.a_w); v = slab_sum(a, k, 8, (long)(c >> 5) * 1024 + 0 * 32 + (c & 31)); }
-    else if (i < L.cl_w) v = rowsum(8, 0);
+    else if (i < L.a_b) { const int c = (int)(i - L.a_w); v = tile(3, 80 + (c >> 5), 0, c & 31); }
+    else if (i < L.cl_w) v = rowsum(3, 256);
     else if (i < L.cl_b) { const int e = (int)(i - L.cl_w), o = e / (HID + E2), c = e % (HID + E2);
-                           if (c < HID) v = wide(3, o, c);
-                           else { const int pos = x2_col_pos(c - HID);
-                                  v = slab_sum(a, k, 6, (long)((o >> 5) * 2 + (pos >> 10)) * 1024 + (o & 31) * 32 + (pos & 1023)); } }
+                           if (c < HID) v = tile(3, (o >> 5) * 10 + (c >> 5), o & 31, c & 31);
+                           else { const int pos = x2_col_pos(c - HID); v = tile(3, (o >> 5) * 10 + 8 + (pos >> 10), o & 31, pos & 1023); } }
     else if (i < L.oc_w) v = rowsum(3, (int)(i - L.cl_b));
-    else if (i < L.oc_b) { const int e = (int)(i - L.oc_w), ch = e / HID, c = e % HID;
-                           v = slab_sum(a, k, 7, (long)(c >> 5) * 1024 + (1 + ch) * 32 + (c & 31)); }
-    else if (i < L.oc_b + 3) v = rowsum(7, 1 + (int)(i - L.oc_b));
+    else if (i < L.oc_b) { const int e = (int)(i - L.oc_w), ch = e / HID, c = e % HID; v = tile(5, c >> 5, 1 + ch, c & 31); }
+    else if (i < L.oc_b + 3) v = rowsum(5, 1 + (int)(i - L.oc_b));
     else if (i >= L.pe_b && i < L.pe_b + 63) {
       float sdb = 0.f;
       for (int g = 0; g < NWG_A; ++g) sdb += a.part[((long)k * NWG_A + g) * PART_FLOATS + (i - L.pe_b)];
