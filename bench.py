@@ -92,7 +92,7 @@ def parse_args(argv=None):
                     help="diagnostic: background chain on the object kernel's stream instead of beside it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-psnr", action="store_true")
-    ap.add_argument("--psnr-seeds", type=int, default=128)
+    ap.add_argument("--psnr-seeds", type=int, default=320)
     ap.add_argument("--no-peak", action="store_true", help="skip the saturated-MFMA measurement")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="default line only: do not also time c3, configs[3]'s share and configs[4]'s share")
@@ -175,13 +175,22 @@ def algorithmic_bytes(K, R, S, feat):
 
 def recorded_counters(kernel: str, K, R, S):
     """PMC figures of `kernel` for this workload from the profile passes committed under profiles/ (rocprofv3 --pmc in
-    separate runs, gfx950 FETCH_SIZE correction applied: tools/gpu_profile_round.sh).  Hardware counters cannot be
-    read from inside this process: these are RECORDED values of the same launch, None when the workload differs."""
+    separate runs, gfx950 FETCH_SIZE correction applied: tools/gpu_profile_round3.sh).  Hardware counters cannot be
+    read from inside this process: these are RECORDED values of the same launch, None when the workload differs.
+    Entries recorded per object (the hidden-256 path runs its objects in workspace chunks) are scaled to K objects."""
     for path in (RECORDED, RECORDED.replace("r03_", "r02_")):
         try:
             with open(path) as f:
                 for e in json.load(f)["kernels"]:
-                    if e["kernel"] == kernel and (e["objects"], e["rays"], e["samples"]) == (K, R, S):
+                    if e["kernel"] != kernel or (e["rays"], e["samples"]) != (R, S):
+                        continue
+                    if e.get("per_object"):
+                        e = dict(e)
+                        for k in ("hbm_bytes_per_launch", "valu_insts_per_launch", "mfma_insts_per_launch"):
+                            if e.get(k) is not None:
+                                e[k] = e[k] * K
+                        return e
+                    if e["objects"] == K:
                         return e
         except (OSError, KeyError, ValueError):
             pass
@@ -370,6 +379,8 @@ class Workload:
             if mode:
                 return "train_fused_bf16_kernel<%s, %d>" % ("true" if feat else "false", 64 if S == 64 else 0)
             return "train_fused32_kernel<%s, false, %d>" % ("true" if feat else "false", 64 if S == 64 else 0)
+        if Hd == 256 and mode and not feat and S in (32, 64, 128):
+            return "objnerf_train_step, fused hidden-256 path (fwd256_kernel + wgrad256_kernel)"
         return "objnerf_train_step, layer-wise path (batched MFMA GEMMs)"
 
     def roofline(self, mode, kern_ms, with_peak=False):

@@ -219,16 +219,8 @@ def test_train_loop_psnr_g9(golden, dev):
     np.testing.assert_allclose(losses[:10], g["loss"][:10], rtol=2e-4)
     np.testing.assert_allclose(losses[:50], g["loss"][:50], rtol=2e-2)
     assert abs(p50 - float(g["psnr50"])) < 0.1, (p50, float(g["psnr50"]))
-    # 300 iterations: difference of ENSEMBLE MEANS against the reference's own 128-seed ensemble (fixture
-    # g9_ensemble.npz, sigma 0.60 dB), the same 128 weight seeds here: standard error of the difference 0.075 dB;
-    # the gate is its 99.9 % interval -- a systematic quality loss of 0.25 dB or more fails.
+    # (300 iterations: ensemble means on the SURVEY 8(d) scene, tests/test_psnr_gpu.py)
     assert psnr_scene.G9["K"] == K and psnr_scene.G9["steps"] == steps
-    ref = psnr_scene.reference_ensemble()
-    ens = psnr_scene.PsnrScene(dev).ensemble([int(x) for x in ref["seeds"]])
-    rep = psnr_scene.delta_report(ens, ref["psnr"])
-    print("PSNR delta vs reference ensemble:", rep)
-    assert abs(rep["delta_db"]) < 3.29 * rep["ci95_db"] / 1.96 < 0.26, rep
-    assert abs(rep["hip_std_db"] - rep["ref_std_db"]) < 0.2 and ens.min() > ref["psnr"].min() - 1.0, rep
 
 
 def test_background_loop_matches_single_shot(dev):

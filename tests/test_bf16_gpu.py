@@ -72,18 +72,7 @@ def test_bf16_feature_step_close_to_fp32(golden, dev, shape):
         assert rel < 0.15, (i, ops.TENSOR_NAMES[i], rel)
 
 
-def test_bf16_psnr_matches_reference_ensemble(dev):
-    """The bf16-operand mode is gated by reconstruction quality, not by 1e-4 parity: 300 iterations of the G9 scene from
-    the reference's initial weights, 128 weight seeds, against the reference's own 128-seed ensemble (fixture
-    g9_ensemble.npz).  Training is chaotic (sigma 0.6 dB over seeds), so the gate is the 99.9 % interval of the
-    difference of ensemble means (standard error 0.075 dB): a systematic loss of 0.25 dB or more fails."""
-    from openobj_amd import psnr_scene
-    ref = psnr_scene.reference_ensemble()
-    ens = psnr_scene.PsnrScene(dev).ensemble([int(x) for x in ref["seeds"]], bf16=True)
-    rep = psnr_scene.delta_report(ens, ref["psnr"])
-    print("bf16 PSNR delta vs reference ensemble:", rep)
-    assert abs(rep["delta_db"]) < 3.29 * rep["ci95_db"] / 1.96 < 0.26, rep
-    assert abs(rep["hip_std_db"] - rep["ref_std_db"]) < 0.2 and ens.min() > ref["psnr"].min() - 1.0, rep
+# (the mode's quality gate: tests/test_psnr_gpu.py -- 320 seeds on the SURVEY 8(d) scene, with and without the feature loss)
 
 
 @pytest.mark.parametrize("feat", [False, True])

@@ -241,3 +241,35 @@ def test_g11_render_2d_syn(golden, H):
     np.testing.assert_allclose(r["depth"], g[f"{tag}_depth"], rtol=1e-5, atol=1e-6)
     assert np.abs(r["color"].numpy().astype(int) - g[f"{tag}_color"].astype(int)).max() <= 1
     np.testing.assert_allclose(r["feat"].detach(), g[f"{tag}_feat"], rtol=1e-4, atol=1e-5)
+
+
+def test_g9b_oracle_reproduces_reference_psnr50():
+    """G9b (the PSNR scene of SURVEY.md 8(d), tests/golden/make_g9b_ensemble.py): the oracle, started from the
+    reference's initial weights for the first fixture seed (the host mirror of trainer.py:36-44 draws them), reproduces
+    the reference's PSNR after 50 iterations -- the fixture the GPU ensembles are held to is what the reference
+    computes, and the oracle agrees with it."""
+    from openobj_amd import psnr_scene
+    ref = psnr_scene.reference_ensemble_b(False)
+    assert ref is not None and len(ref["seeds"]) >= 300
+    s = psnr_scene.G9B
+    assert [int(x) for x in ref["meta"][:8]] == [s["K"], s["R"], s["N"], s["M"], s["steps"], s["early"], s["eval_R"], s["eval_S"]]
+    er = psnr_scene.EnsembleRun("cpu", with_feat=False)
+    seed = int(ref["seeds"][0])
+    arena = er.initial_arena([seed])
+    params = [p.clone().requires_grad_(True) for p in arena.views()]
+    m = [torch.zeros_like(p) for p in params]
+    v = [torch.zeros_like(p) for p in params]
+    scale = torch.full((s["K"],), float(er.cfg.obj_scale))
+    for it in range(s["early"]):
+        b = er.batches[it]
+        loss, _ = O.train_forward_loss(params[:18], params[18], scale, b["pts"], b["gt_depth"], b["gt_rgb"], b["labels"], b["z"])
+        grads = torch.autograd.grad(loss, params, allow_unused=True)
+        with torch.no_grad():
+            for p, g, mm, vv in zip(params, grads, m, v):
+                if g is not None:
+                    O.adamw_step(p, g, mm, vv, it + 1, er.cfg.learning_rate, er.cfg.weight_decay)
+    with torch.no_grad():
+        out = O.render_forward([p.detach() for p in params[:18]], params[18].detach(), scale, er.ev["pts"], er.ev["z"],
+                               with_feat=False)
+    p50 = O.psnr(out["rgb"], er.ev["gt_rgb"])
+    assert abs(p50 - float(ref["psnr50"][0])) < 0.02, (p50, float(ref["psnr50"][0]))
