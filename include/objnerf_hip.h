@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define OBJNERF_ABI_VERSION 4
+#define OBJNERF_ABI_VERSION 5
 
 #define OBJNERF_OK 0
 #define OBJNERF_EINVAL (-22)       /* bad shape / null pointer / unsupported size        */
@@ -195,6 +195,30 @@ int objnerf_mlp_forward_ws(const objnerf_net* net, int32_t K, int64_t N, const f
                            int64_t p_stride, const float* emb, float* out_alpha, float* out_color,
                            float* out_hfeat, float* out_clip, void* workspace, size_t workspace_bytes,
                            void* stream);
+
+/* ABI 5 -- the BACKWARD halves of the two mirrored modules, for a caller that keeps the reference's loop body
+ * (train.py:424-436: vmap(pe_model) -> vmap(fc_model) -> step_batch_loss -> loss.backward()) instead of the fused
+ * objnerf_train_step: what autograd runs through model.py:61-103 and embedding.py:46-55.  fp32, any hidden width that
+ * is a multiple of 32.
+ *   emb      [K][N][129]  the embedding the forward entry was given (activations are recomputed from it),
+ *   d_alpha  [K][N]       dL / d alpha   (alpha = the 10x-scaled occupancy logit objnerf_mlp_forward returns),
+ *   d_color  [K][N][3]    dL / d color   (post-sigmoid),
+ *   d_clip   [K][N][C]    dL / d out_clip, or NULL: the feature branch (tensors 14..17) then receives no gradient
+ *                         and its slots of `grads` are left untouched,
+ *   grads    [K][p_stride]  gradient arena in objnerf_param_layout order, tensors 0..13 (0..17 with d_clip) overwritten,
+ *   d_emb    [K][N][129]  dL / d emb, overwritten (feed it to objnerf_embed_bwd).
+ * workspace: objnerf_mlp_backward_workspace_bytes(net, K, N, d_clip != NULL) bytes, 256-byte aligned. */
+size_t objnerf_mlp_backward_workspace_bytes(const objnerf_net* net, int32_t K, int64_t N, int32_t with_clip);
+int objnerf_mlp_backward_ws(const objnerf_net* net, int32_t K, int64_t N, const float* params,
+                            int64_t p_stride, const float* emb, const float* d_alpha, const float* d_color,
+                            const float* d_clip, float* grads, float* d_emb, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
+/* d B [K][21][3] of UniDirsEmbed.B_layer.weight (embedding.py:36-38) from d_emb [K][N][129] and the inputs of
+ * objnerf_embed; scratch: K * 64 floats.  (The reference differentiates neither the points nor the scale.) */
+int objnerf_embed_bwd(const objnerf_net* net, int32_t K, int64_t N, const float* params, int64_t p_stride,
+                      const float* scale, const float* pts, const float* d_emb, float* d_B, float* scratch,
+                      void* stream);
 
 /* A6 alone: emb [K][N][3+21*n_freqs]. */
 int objnerf_embed(const objnerf_net* net, int32_t K, int64_t N, const float* params,

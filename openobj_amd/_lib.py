@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OBJNERF_LIB") or os.path.join(_HERE, "csrc", "libobjnerf_hip.so")   # OBJNERF_LIB: diagnostic builds
 
 OBJNERF_N_TENSORS = 19
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class ObjnerfError(RuntimeError):
@@ -114,6 +114,12 @@ SIGNATURES = {
                                          C.c_void_p, C.c_size_t, C.c_void_p]),
     "objnerf_embed": (C.c_int, [C.POINTER(Net), C.c_int32, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                 C.c_void_p, C.c_void_p, C.c_void_p]),
+    "objnerf_mlp_backward_workspace_bytes": (C.c_size_t, [C.POINTER(Net), C.c_int32, C.c_int64, C.c_int32]),
+    "objnerf_mlp_backward_ws": (C.c_int, [C.POINTER(Net), C.c_int32, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_size_t, C.c_void_p]),
+    "objnerf_embed_bwd": (C.c_int, [C.POINTER(Net), C.c_int32, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "objnerf_occupancy": (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "objnerf_render": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "objnerf_render_loss": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,

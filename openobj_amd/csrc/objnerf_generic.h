@@ -35,6 +35,13 @@ size_t eval_workspace_bytes(const objnerf_net* net, int K, long N);
 int eval_points(const objnerf_net* net, int K, long N, const float* params, long p_stride, const float* scale,
                 const float* pts, float* out_alpha, float* out_color, float* out_hfeat, float* out_clip,
                 void* workspace, size_t workspace_bytes, void* stream, const float* emb_in = nullptr);
+// backward halves of the mirrored modules (objnerf_mlp_backward_ws / objnerf_embed_bwd)
+size_t mlp_backward_workspace_bytes(const objnerf_net* net, int K, long N, int with_clip);
+int mlp_backward(const objnerf_net* net, int K, long N, const float* params, long p_stride, const float* emb,
+                 const float* d_alpha, const float* d_color, const float* d_clip, float* grads, float* d_emb,
+                 void* workspace, size_t workspace_bytes, void* stream);
+int embed_backward(const objnerf_net* net, int K, long N, const float* params, long p_stride, const float* scale,
+                   const float* pts, const float* d_emb, float* d_B, float* scratch, void* stream);
 }
 
 // hidden 256 in the 16-bit operand modes without the feature loss (BASELINE configs[4]): objnerf_train256.hip

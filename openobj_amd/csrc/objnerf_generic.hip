@@ -2336,6 +2336,115 @@ int eval_points(const objnerf_net* net, int K, long N, const float* params, long
   return OBJNERF_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Backward of model.py:61-103 alone (objnerf_mlp_backward_ws): what loss.backward() runs through the stacked networks
+// when a caller keeps the reference's loop body (train.py:424-436) instead of the fused step.  fp32.  The activations
+// are recomputed from `emb` (the forward entry keeps none), then the same dgrad / weight-gradient GEMMs as train_step's
+// layer-wise chain; with d_clip the 512-d head is differentiated directly (no hoisting: the loss is the caller's).
+size_t mlp_backward_workspace_bytes(const objnerf_net* net, int K, long N, int with_clip) {
+  WS w = carve(nullptr, net->hidden, net->feat_dim, N, 1, K, with_clip != 0);
+  size_t extra = 0;
+  if (with_clip) {
+    const size_t M = (size_t)net->feat_dim, Hn = (size_t)net->hidden;
+    extra = al(((size_t)K * wgrad_slices(K, (int)M, (int)Hn, N) * (M * Hn + M) + 256) * 4);
+  }
+  return w.bytes + extra + 256;
+}
+
+int mlp_backward(const objnerf_net* net, int K, long N, const float* params, long p_stride, const float* emb,
+                 const float* d_alpha, const float* d_color, const float* d_clip, float* grads, float* d_emb,
+                 void* workspace, size_t workspace_bytes, void* stream) {
+  const int H = net->hidden, C = net->feat_dim;
+  if (H % 32 != 0 || net->n_freqs != 6) return OBJNERF_ENOTSUP;
+  const bool feat = d_clip != nullptr;
+  const long n = N, ps = p_stride, nH = n * H;
+  if (!workspace || workspace_bytes + 256 < mlp_backward_workspace_bytes(net, K, N, feat)) return OBJNERF_EINVAL;
+  int64_t off[OBJNERF_N_TENSORS + 1];
+  objnerf_param_layout(net, off);
+  hipStream_t st = (hipStream_t)stream;
+  const Bf16Scope fp32_scope(0);
+  WS w = carve((char*)workspace, H, C, n, 1, K, feat);
+  t_parts = w.parts; t_parts_cap = w.parts_floats; t_parts_off = 0;
+  struct PartsScope {
+    ~PartsScope() { t_parts = nullptr; t_parts_cap = t_parts_off = 0; }
+  } parts_scope;
+  const float* P = params;
+  float* G = grads;
+  const int E1 = OBJ_E1, E2 = OBJ_E2, EM = OBJ_EMB;
+  for (int k = 0; k < K; ++k)      // feature-branch entries only when they receive a gradient ("no gradient" = untouched)
+    (void)hipMemsetAsync(G + (long)k * ps, 0, (size_t)(feat ? off[18] : off[14]) * 4, st);
+  // ---- forward (recompute)
+  gemm(st, K, n, H, E1, emb, EM, 1, n * EM, P + off[0], 1, E1, ps, w.h1, H, 1, nH, false, P + off[1], ps, true);
+  gemm(st, K, n, H, H, w.h1, H, 1, nH, P + off[2], 1, H, ps, w.h2, H, 1, nH, false, P + off[3], ps, true);
+  gemm(st, K, n, H, H, w.h2, H, 1, nH, P + off[4], 1, H + E1, ps, w.h3, H, 1, nH);
+  gemm(st, K, n, H, E1, emb, EM, 1, n * EM, P + off[4] + H, 1, H + E1, ps, w.h3, H, 1, nH, true, P + off[5], ps, true);
+  gemm(st, K, n, H, H, w.h3, H, 1, nH, P + off[6], 1, H, ps, w.h4, H, 1, nH, false, P + off[7], ps, true);
+  gemm(st, K, n, H, H, w.h4, H, 1, nH, P + off[10], 1, H + E2, ps, w.hc, H, 1, nH);
+  gemm(st, K, n, H, E2, emb + E1, EM, 1, n * EM, P + off[10] + H, 1, H + E2, ps, w.hc, H, 1, nH, true, P + off[11], ps, true);
+  dim3 eg((unsigned)((n + 15) / 16), (unsigned)K);
+  const size_t head_lds = (size_t)4 * H * sizeof(float);
+  hipLaunchKernelGGL(heads_fwd_kernel, eg, dim3(256), head_lds, st, H, n, w.h4, w.hc, P, ps, (int)off[8], (int)off[9],
+                     (int)off[12], (int)off[13], w.alpha, w.color, 0);
+  if (feat) {
+    gemm(st, K, n, H, H, w.h4, H, 1, nH, P + off[14], 1, H + E2, ps, w.hf, H, 1, nH);
+    gemm(st, K, n, H, E2, emb + E1, EM, 1, n * EM, P + off[14] + H, 1, H + E2, ps, w.hf, H, 1, nH, true, P + off[15], ps, true);
+  }
+  // ---- backward
+  float *d_hc = w.dA, *d_h4 = w.dB_, *d_h3 = w.dC, *d_h2 = w.dD, *d_h1 = w.dE;
+  hipLaunchKernelGGL(heads_bwd_kernel, eg, dim3(256), head_lds, st, H, n, w.hc, w.color, d_alpha, d_color, P, ps, (int)off[8],
+                     (int)off[12], w.dhead, d_hc, d_h4, 0, 1.0f);
+  wgrad(st, K, 1, H, n, w.dhead, 1, 4, n * 4, w.h4, H, 1, nH, G + off[8], H, ps, G + off[9]);
+  wgrad(st, K, 3, H, n, w.dhead + 1, 1, 4, n * 4, w.hc, H, 1, nH, G + off[12], H, ps, G + off[13]);
+  if (feat) {
+    // 512-d head: d W_of = d_clip^T hf, d b_of = column sums, d_hf = (d_clip W_of) o [hf > 0]
+    float* extra = (float*)((char*)workspace + w.bytes);
+    float* keep = t_parts; const size_t keep_cap = t_parts_cap, keep_off = t_parts_off;
+    t_parts = extra; t_parts_cap = (size_t)K * wgrad_slices(K, C, H, n) * ((size_t)C * H + C) + 256; t_parts_off = 0;
+    wgrad(st, K, C, H, n, d_clip, 1, C, n * C, w.hf, H, 1, nH, G + off[16], H, ps, G + off[17]);
+    t_parts = keep; t_parts_cap = keep_cap; t_parts_off = keep_off;
+    gemm(st, K, n, H, C, d_clip, C, 1, n * C, P + off[16], H, 1, ps, w.d_hf, H, 1, nH, false, nullptr, 0, false, w.hf, H, 1, nH);
+    wgrad(st, K, H, H, n, w.d_hf, 1, H, nH, w.h4, H, 1, nH, G + off[14], H + E2, ps, G + off[15]);
+    wgrad(st, K, H, E2, n, w.d_hf, 1, H, nH, emb + E1, EM, 1, n * EM, G + off[14] + H, H + E2, ps);
+    gemm(st, K, n, H, H, w.d_hf, H, 1, nH, P + off[14], H + E2, 1, ps, d_h4, H, 1, nH, true);
+    gemm(st, K, n, E2, H, w.d_hf, H, 1, nH, P + off[14] + H, H + E2, 1, ps, d_emb + E1, EM, 1, n * EM, false);
+  }
+  wgrad(st, K, H, H, n, d_hc, 1, H, nH, w.h4, H, 1, nH, G + off[10], H + E2, ps, G + off[11]);
+  wgrad(st, K, H, E2, n, d_hc, 1, H, nH, emb + E1, EM, 1, n * EM, G + off[10] + H, H + E2, ps);
+  gemm(st, K, n, H, H, d_hc, H, 1, nH, P + off[10], H + E2, 1, ps, d_h4, H, 1, nH, true, nullptr, 0, false, w.h4, H, 1, nH);
+  gemm(st, K, n, E2, H, d_hc, H, 1, nH, P + off[10] + H, H + E2, 1, ps, d_emb + E1, EM, 1, n * EM, feat);
+  wgrad(st, K, H, H, n, d_h4, 1, H, nH, w.h3, H, 1, nH, G + off[6], H, ps, G + off[7]);
+  gemm(st, K, n, H, H, d_h4, H, 1, nH, P + off[6], H, 1, ps, d_h3, H, 1, nH, false, nullptr, 0, false, w.h3, H, 1, nH);
+  wgrad(st, K, H, H, n, d_h3, 1, H, nH, w.h2, H, 1, nH, G + off[4], H + E1, ps, G + off[5]);
+  wgrad(st, K, H, E1, n, d_h3, 1, H, nH, emb, EM, 1, n * EM, G + off[4] + H, H + E1, ps);
+  gemm(st, K, n, H, H, d_h3, H, 1, nH, P + off[4], H + E1, 1, ps, d_h2, H, 1, nH, false, nullptr, 0, false, w.h2, H, 1, nH);
+  gemm(st, K, n, E1, H, d_h3, H, 1, nH, P + off[4] + H, H + E1, 1, ps, d_emb, EM, 1, n * EM, false);
+  wgrad(st, K, H, H, n, d_h2, 1, H, nH, w.h1, H, 1, nH, G + off[2], H, ps, G + off[3]);
+  gemm(st, K, n, H, H, d_h2, H, 1, nH, P + off[2], H, 1, ps, d_h1, H, 1, nH, false, nullptr, 0, false, w.h1, H, 1, nH);
+  wgrad(st, K, H, E1, n, d_h1, 1, H, nH, emb, EM, 1, n * EM, G + off[0], E1, ps, G + off[1]);
+  gemm(st, K, n, E1, H, d_h1, H, 1, nH, P + off[0], E1, 1, ps, d_emb, EM, 1, n * EM, true);
+  if (hipGetLastError() != hipSuccess) return OBJNERF_ELAUNCH;
+  return OBJNERF_OK;
+}
+
+// Backward of embedding.py:46-55 alone (objnerf_embed_bwd): d B [K][21][3] from d_emb [K][N][129]; scratch [K][64] floats
+int embed_backward(const objnerf_net* net, int K, long N, const float* params, long p_stride, const float* scale,
+                   const float* pts, const float* d_emb, float* d_B, float* scratch, void* stream) {
+  if (net->n_freqs != 6) return OBJNERF_ENOTSUP;
+  int64_t off[OBJNERF_N_TENSORS + 1];
+  objnerf_param_layout(net, off);
+  hipStream_t st = (hipStream_t)stream;
+  int pg = (int)((N + 47) / 48);
+  if (pg > 1024) pg = 1024;
+  if (pg < 1) pg = 1;
+  (void)hipMemsetAsync(scratch, 0, (size_t)K * 64 * 4, st);
+  hipLaunchKernelGGL(pe_bwd_kernel, dim3(pg, K), dim3(256), 0, st, N, params, p_stride, (int)off[18], scale, pts, d_emb, scratch,
+                     (float*)nullptr);
+  hipLaunchKernelGGL(copy_cols_kernel, dim3((unsigned)((K * 63 + 255) / 256)), dim3(256), 0, st, (long)K, 63, scratch, 63L, d_B,
+                     63L);
+  if (hipGetLastError() != hipSuccess) return OBJNERF_ELAUNCH;
+  return OBJNERF_OK;
+}
+
 // G = W_of^T W_of, wb = W_of^T b_of, bb = b_of . b_of of K objects: gram[k][Hh * Hh | Hh | 1], batch stride gstride
 void feat_gram(void* stream, int K, const float* params, long p_stride, int off_w, int off_b, int C, int Hh, float* gram,
                long gstride) {

@@ -1223,4 +1223,25 @@ int objnerf_mlp_forward_ws(const objnerf_net* net, int32_t K, int64_t N, const f
                              out_clip, workspace, workspace_bytes, stream, emb);
 }
 
+size_t objnerf_mlp_backward_workspace_bytes(const objnerf_net* net, int32_t K, int64_t N, int32_t with_clip) {
+  if (!net || K <= 0 || N <= 0) return 0;
+  return objgen::mlp_backward_workspace_bytes(net, K, (long)N, with_clip);
+}
+
+int objnerf_mlp_backward_ws(const objnerf_net* net, int32_t K, int64_t N, const float* params, int64_t p_stride,
+                            const float* emb, const float* d_alpha, const float* d_color, const float* d_clip,
+                            float* grads, float* d_emb, void* workspace, size_t workspace_bytes, void* stream) {
+  (void)hipGetLastError();
+  if (!net || !params || !emb || !d_alpha || !d_color || !grads || !d_emb || K <= 0 || N <= 0) return OBJNERF_EINVAL;
+  return objgen::mlp_backward(net, K, (long)N, params, (long)p_stride, emb, d_alpha, d_color, d_clip, grads, d_emb, workspace,
+                              workspace_bytes, stream);
+}
+
+int objnerf_embed_bwd(const objnerf_net* net, int32_t K, int64_t N, const float* params, int64_t p_stride,
+                      const float* scale, const float* pts, const float* d_emb, float* d_B, float* scratch, void* stream) {
+  (void)hipGetLastError();
+  if (!net || !params || !scale || !pts || !d_emb || !d_B || !scratch || K <= 0 || N <= 0) return OBJNERF_EINVAL;
+  return objgen::embed_backward(net, K, (long)N, params, (long)p_stride, scale, pts, d_emb, d_B, scratch, stream);
+}
+
 }  // extern "C"

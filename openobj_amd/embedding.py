@@ -4,6 +4,7 @@ the parameter arena; forward runs objnerf_embed."""
 import torch
 
 from . import ops
+from .autograd import EmbedFunction
 from .init import icosa_dirs
 
 
@@ -34,6 +35,5 @@ class UniDirsEmbed(torch.nn.Module):
         """x [...,3] -> [..., 3 + 21 * n_freqs] (embedding.py:46-55)."""
         lead = x.shape[:-1]
         self._arena.scale.fill_(float(self.scale))
-        with torch.no_grad():
-            emb = ops.embed(self._arena, x.reshape(1, -1, 3).contiguous())
+        emb = EmbedFunction.apply(self._arena, False, x.reshape(1, -1, 3).contiguous(), self.B_layer.weight)
         return emb.reshape(*lead, emb.shape[-1])

@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from .autograd import MlpFunction
 
 
 def init_weights(m, init_fn=torch.nn.init.xavier_normal_):
@@ -69,17 +70,17 @@ class OccupancyMap(torch.nn.Module):
 
     def forward(self, x, noise_std=None, do_alpha=True, do_color=True, do_cat=True, do_clip=True):
         """x [..., 129] (an embedding) -> (alpha [...,1], color [...,3], clip [...,C]); model.py:61-103.
-        Inference path (no autograd graph): training goes through training_strategy == "hip"."""
+        Differentiable (autograd.MlpFunction -> objnerf_mlp_backward_ws) w.r.t. the parameters and x; the fast training
+        path is training_strategy == "hip"."""
         if not do_cat:
             raise NotImplementedError("do_cat=False is never used by the reference")
         lead = x.shape[:-1]
         emb = x.reshape(1, -1, x.shape[-1]).contiguous()
         want_clip = self.do_clip and do_clip
-        with torch.no_grad():
-            alpha, color, _, clip = ops.mlp_forward(self._arena, emb, want_clip=want_clip)
-            alpha = alpha.reshape(*lead, 1)
-            if noise_std is not None:                       # model.py:83-85: raw + noise, then * 10
-                alpha = alpha + 10.0 * noise_std * torch.randn(alpha.shape, device=alpha.device)
-            color = color.reshape(*lead, 3)
-            clip = clip.reshape(*lead, -1) if want_clip else None
+        alpha, color, clip = MlpFunction.apply(self._arena, want_clip, False, emb, *self.parameters())
+        alpha = alpha.reshape(*lead, 1)
+        if noise_std is not None:                       # model.py:83-85: raw + noise, then * 10
+            alpha = alpha + 10.0 * noise_std * torch.randn(alpha.shape, device=alpha.device)
+        color = color.reshape(*lead, 3)
+        clip = clip.reshape(*lead, -1) if want_clip else None
         return (alpha if do_alpha else None), (color if (self.do_color and do_color) else None), clip

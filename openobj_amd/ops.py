@@ -188,6 +188,41 @@ def embed(arena: ParamArena, pts: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def mlp_backward(arena: ParamArena, emb: torch.Tensor, d_alpha: torch.Tensor, d_color: torch.Tensor,
+                 d_clip: Optional[torch.Tensor] = None):
+    """Backward of OccupancyMap.forward (model.py:61-103) for the K stacked networks: -> (grads [K,p_stride] in arena
+    layout -- tensors 0..13, 0..17 with d_clip, the rest zero --, d_emb [K,N,129])."""
+    emb = _req(emb, torch.float32, "emb")
+    K, N = emb.shape[0], emb.shape[1]
+    d_alpha = _req(d_alpha.reshape(K, N), torch.float32, "d_alpha")
+    d_color = _req(d_color.reshape(K, N, 3), torch.float32, "d_color")
+    if d_clip is not None:
+        d_clip = _req(d_clip.reshape(K, N, arena.net.feat_dim), torch.float32, "d_clip")
+    dev = emb.device
+    grads = torch.zeros(K, arena.p_stride, device=dev)
+    d_emb = torch.empty_like(emb)
+    net = arena.net.c()
+    nbytes = int(lib().objnerf_mlp_backward_workspace_bytes(C.byref(net), K, N, 1 if d_clip is not None else 0))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    check(lib().objnerf_mlp_backward_ws(C.byref(net), K, N, _ptr(arena.params), arena.p_stride, _ptr(emb), _ptr(d_alpha),
+                                        _ptr(d_color), _ptr(d_clip), _ptr(grads), _ptr(d_emb), _ptr(ws), nbytes, _stream()),
+          "objnerf_mlp_backward_ws")
+    return grads, d_emb
+
+
+def embed_backward(arena: ParamArena, pts: torch.Tensor, d_emb: torch.Tensor) -> torch.Tensor:
+    """Backward of UniDirsEmbed.forward (embedding.py:46-55) w.r.t. B_layer.weight: -> d B [K,21,3]."""
+    pts = _req(pts, torch.float32, "pts")
+    K, N = pts.shape[0], pts.shape[1]
+    d_emb = _req(d_emb.reshape(K, N, -1), torch.float32, "d_emb")
+    d_B = torch.empty(K, N_DIRS, 3, device=pts.device)
+    scratch = torch.empty(K * 64, device=pts.device)
+    net = arena.net.c()
+    check(lib().objnerf_embed_bwd(C.byref(net), K, N, _ptr(arena.params), arena.p_stride, _ptr(arena.scale), _ptr(pts),
+                                  _ptr(d_emb), _ptr(d_B), _ptr(scratch), _stream()), "objnerf_embed_bwd")
+    return d_B
+
+
 def occupancy(alpha: torch.Tensor) -> torch.Tensor:
     alpha = _req(alpha, torch.float32, "alpha")
     out = torch.empty_like(alpha)

@@ -6,6 +6,7 @@ from time import perf_counter_ns
 import torch
 
 from . import ops
+from .autograd import EmbedFunction, MlpFunction
 
 
 class performance_measure:
@@ -39,15 +40,16 @@ class StackedModel:
 def vmap(fmodel: StackedModel):
     """Stand-in for functorch.vmap on a StackedModel (train.py:424-425): one batched HIP launch."""
     def run(params, buffers, x):
+        # differentiable w.r.t. `params` (and, for the networks, the embedding): loss.backward() of the reference's loop
+        # body (train.py:424-436) reaches the stacked tensors through objnerf_mlp_backward_ws / objnerf_embed_bwd
         a = fmodel.arena
         K = a.K
-        with torch.no_grad():
-            if fmodel.kind == "pe":
-                lead = x.shape[1:-1]
-                return ops.embed(a, x.reshape(K, -1, 3).contiguous()).reshape(K, *lead, -1)
-            lead = x.shape[1:-1]
-            alpha, color, _, clip = ops.mlp_forward(a, x.reshape(K, -1, x.shape[-1]).contiguous(), want_clip=True)
-            return alpha.reshape(K, *lead, 1), color.reshape(K, *lead, 3), clip.reshape(K, *lead, -1)
+        lead = x.shape[1:-1]
+        if fmodel.kind == "pe":
+            emb = EmbedFunction.apply(a, True, x.reshape(K, -1, 3).contiguous(), params[0])
+            return emb.reshape(K, *lead, -1)
+        alpha, color, clip = MlpFunction.apply(a, True, True, x.reshape(K, -1, x.shape[-1]).contiguous(), *params)
+        return alpha.reshape(K, *lead, 1), color.reshape(K, *lead, 3), clip.reshape(K, *lead, -1)
     return run
 
 
@@ -76,6 +78,8 @@ def update_vmap(models, optimiser=None, arena=None):
                     views[i][k].copy_(p)
             params = list(views[:18])
             buffers = []
+    for p in params:                       # utils.py:58: [p.requires_grad_() for p in params]
+        p.requires_grad_()
     if optimiser is not None and hasattr(optimiser, "add_param_group"):
         optimiser.add_param_group({"params": params})
     return StackedModel(arena, "pe" if is_pe else "fc"), params, buffers
