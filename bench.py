@@ -198,11 +198,11 @@ def recorded_counters(kernel: str, K, R, S):
 
 
 def measured_mfma_peak(dev, dtype_id):
-    """TFLOP/s of a saturated MFMA loop (objnerf_mfma_peak: one wave per SIMD, four independent accumulators, operands
-    in registers, non-trivial data) on THIS device -- the denominator a kernel can actually reach."""
+    """TFLOP/s of a saturated MFMA loop (objnerf_mfma_peak: one wave per SIMD, two independent 32x32 accumulator chains,
+    operands in registers, non-trivial data) on THIS device -- the denominator a kernel can actually reach."""
     import torch
     from openobj_amd import _lib
-    n_wg, iters = 1024, 20000
+    n_wg, iters = 1024, 10000
     sink = torch.empty(n_wg * 256, device=dev)
     st = torch.cuda.current_stream().cuda_stream
     for it in (2000, iters):
@@ -211,7 +211,7 @@ def measured_mfma_peak(dev, dtype_id):
         _lib.check(_lib.lib().objnerf_mfma_peak(dtype_id, it, n_wg, sink.data_ptr(), st), "objnerf_mfma_peak")
         e1.record()
         torch.cuda.synchronize()
-    flop = (2048.0 if dtype_id == 0 else 16384.0) * 4 * iters * 4 * n_wg
+    flop = (4096.0 if dtype_id == 0 else 32768.0) * 4 * iters * 4 * n_wg
     return flop / (e0.elapsed_time(e1) * 1e-3) / 1e12
 
 

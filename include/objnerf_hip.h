@@ -239,8 +239,9 @@ int objnerf_composite(int64_t n_rays, int32_t S, int32_t flags, const float* alp
                       float* out_vals, void* stream);
 
 /* Measurement support (bench.py `roofline.peak_measured`; nothing in the reference): a saturated-MFMA loop, n_wg
- * workgroups of 4 waves x iters x 4 MFMAs; dtype 0: v_mfma_f32_16x16x4_f32 (2048 FLOP each), 1: v_mfma_f32_16x16x32_bf16
- * (16384 FLOP each).  sink: n_wg * 256 floats. */
+ * workgroups of 4 waves x iters x 4 MFMAs on two accumulator chains per wave; dtype 0: v_mfma_f32_32x32x2_f32 (4096 FLOP
+ * each), 1: v_mfma_f32_32x32x16_bf16 (32768 FLOP each) -- the instructions of the training kernels.  sink: n_wg * 256
+ * floats. */
 int objnerf_mfma_peak(int32_t dtype, int32_t iters, int32_t n_wg, float* sink, void* stream);
 
 /* A8 alone: occupancy_activation(alpha) = sigmoid(alpha), n elements (render_rays.py:6-14). */

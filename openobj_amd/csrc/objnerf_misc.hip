@@ -741,34 +741,39 @@ int step_batch_loss_impl(const objnerf_loss_args* a, const LossHoisted* hz, void
 }
 }  // namespace objmisc
 
-// Saturated-MFMA loop for bench.py's `roofline.peak_measured`: 256-thread workgroups (one wave per SIMD), four
-// independent 16x16 accumulators, operands in registers, lane-dependent non-trivial data (the clock the chip holds
-// depends on the operands: MI355X_MICROARCH.md, DVFS give-back).  DT 0: v_mfma_f32_16x16x4_f32, 1: v_mfma_f32_16x16x32_bf16.
+// Saturated-MFMA loop for bench.py's `roofline.peak_measured`: 256-thread workgroups (one wave per SIMD), TWO
+// independent 32x32 accumulator chains per wave (a 16-pass MFMA issues every 64 cycles per chain: two chains keep
+// the pipe full with nothing else to issue), operands in registers, lane-dependent non-trivial data (the clock the
+// chip holds depends on the operands: MI355X_MICROARCH.md, DVFS give-back).  The instructions are the ones the training
+// kernels use.  DT 0: v_mfma_f32_32x32x2_f32, 1: v_mfma_f32_32x32x16_bf16; four MFMAs per iteration.
 template <int DT>
 __global__ __launch_bounds__(256) void mfma_peak_kernel(int iters, float* sink) {
-  typedef float f4 __attribute__((ext_vector_type(4)));
+  typedef float f16v __attribute__((ext_vector_type(16)));
   typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
   const int lane = threadIdx.x & 63;
-  f4 a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+  f16v a0, a1;
+  for (int i = 0; i < 16; ++i) { a0[i] = 0.f; a1[i] = 0.f; }
   const float av = 0.37f + 0.011f * lane, bv = -0.52f + 0.007f * (lane ^ 21);
   bf8 ab, bb;
   for (int i = 0; i < 8; ++i) { ab[i] = (__bf16)(av + 0.05f * i); bb[i] = (__bf16)(bv - 0.03f * i); }
   for (int i = 0; i < iters; ++i) {
     if (DT == 0) {
-      a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, a0, 0, 0, 0);
-      a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av, a1, 0, 0, 0);
-      a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, av, a2, 0, 0, 0);
-      a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, bv, a3, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, av, a1, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, av, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, bv, a1, 0, 0, 0);
     } else {
-      a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, bb, a0, 0, 0, 0);
-      a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bb, ab, a1, 0, 0, 0);
-      a2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, ab, a2, 0, 0, 0);
-      a3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bb, bb, a3, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, bb, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bb, ab, a1, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, ab, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bb, bb, a1, 0, 0, 0);
     }
     // keep the accumulators bounded without leaving the MFMA-only regime: rescale once in a while
-    if ((i & 63) == 63) { a0 *= 1e-3f; a1 *= 1e-3f; a2 *= 1e-3f; a3 *= 1e-3f; }
+    if ((i & 127) == 127) { a0 *= 1e-3f; a1 *= 1e-3f; }
   }
-  sink[blockIdx.x * 256 + threadIdx.x] = a0[0] + a1[1] + a2[2] + a3[3];
+  float r = 0.f;
+  for (int i = 0; i < 16; ++i) r += a0[i] + a1[i];
+  sink[blockIdx.x * 256 + threadIdx.x] = r;
 }
 
 extern "C" {

@@ -1,16 +1,21 @@
 #!/bin/bash
-# Diagnostic builds of the library with extra -D flags on the fused-kernel translation units:
-#   tools/build_variant.sh NAME -DPHASE_TIMING ...   ->  openobj_amd/csrc/abl/lib_NAME.so   (use with OBJNERF_LIB=...)
+# Diagnostic build of the library with extra -D flags, beside the product one:
+#   tools/build_variant.sh pe63 -DOBJ_PE_ANCHORS=63   ->  openobj_amd/csrc/variants/libobjnerf_hip_pe63.so
+# Use it with OBJNERF_LIB=<that path> (openobj_amd/_lib.py).  Never loaded by default.
 set -e
-cd "$(dirname "$0")/../openobj_amd/csrc"
 name=$1; shift
-mkdir -p abl
-make -s
-FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off"
-SCHED32=${SCHED32--mllvm -amdgpu-sched-strategy=iterative-ilp}
-/opt/rocm/bin/hipcc $FLAGS -mllvm -amdgpu-sched-strategy=max-ilp "$@" -c objnerf_train.hip -o abl/train_$name.o &
-/opt/rocm/bin/hipcc $FLAGS $SCHED32 "$@" -c objnerf_train32.hip -o abl/train32_$name.o &
-/opt/rocm/bin/hipcc $FLAGS "$@" -c objnerf_train_bf16.hip -o abl/train_bf16_$name.o &
-wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o abl/lib_$name.so abl/train_$name.o abl/train32_$name.o abl/train_bf16_$name.o objnerf_misc.o objnerf_generic.o objnerf_helpers.o
-echo built abl/lib_$name.so
+cd "$(dirname "$0")/../openobj_amd/csrc"
+out=variants/$name
+mkdir -p $out
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-function"
+pids=()
+for f in objnerf_train objnerf_train32 objnerf_train_bf16 objnerf_misc objnerf_generic objnerf_helpers objnerf_train256; do
+  extra=""
+  [ $f = objnerf_train ] && extra="-mllvm -amdgpu-sched-strategy=max-ilp"
+  [ $f = objnerf_train32 ] && extra="-mllvm -amdgpu-sched-strategy=iterative-ilp"
+  /opt/rocm/bin/hipcc $FLAGS $extra "$@" -c $f.hip -o $out/$f.o &
+  pids+=($!)
+done
+for p in "${pids[@]}"; do wait $p; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/libobjnerf_hip_$name.so $out/*.o
+echo built openobj_amd/csrc/variants/libobjnerf_hip_$name.so
