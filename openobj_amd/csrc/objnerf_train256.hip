@@ -114,23 +114,39 @@ __host__ __device__ constexpr int seq_off(int q) {       // first piece of the s
   return o;
 }
 constexpr int N_PIECES = seq_off(NSEQ);
-constexpr int N_STAGES = 8 + 8 + 8 + 8 + 9 + 1 + 8 + 8 + 2 + 8 + 8 + 3 + 8 + 3;
-static_assert(N_PIECES == 1323 && N_STAGES == 90, "image size");
+static_assert(N_PIECES == 1323, "image size");
 constexpr long IMG_BYTES = (long)N_PIECES * PIECE;
 constexpr int MAX_NK = 22;
 constexpr int RING_SLOT = MAX_NK * PIECE;            // 22 KB
-// stage -> (first piece, k-steps); one period, read with a wave-uniform index
-struct StageTab { short off[N_STAGES + 2]; signed char nk[N_STAGES + 2]; };
-__host__ __device__ constexpr StageTab make_stage_tab() {
-  StageTab t{};
+// Ring stages: one per block of a sequence -- except B6, whose eight one-piece blocks form ONE stage.  A tile's stage
+// schedule is a compile-time object: every stage site knows how many pieces the stage two ahead of it has, so the
+// transfer set-up is a handful of scalar additions (no table look-ups, no division, no selects).
+__host__ __device__ constexpr int stg_nb(int q) { return q == B6 ? 1 : seq_nb(q); }
+__host__ __device__ constexpr int stg_np(int q) { return q == B6 ? 8 : seq_nk(q); }      // pieces per stage
+__host__ __device__ constexpr int stg_base(int q) {
   int g = 0;
-  for (int q = 0; q < NSEQ; ++q)
-    for (int b = 0; b < seq_nb(q); ++b) { t.off[g] = (short)(seq_off(q) + b * seq_nk(q)); t.nk[g] = (signed char)seq_nk(q); ++g; }
-  t.off[g] = t.off[0]; t.nk[g] = t.nk[0];
-  t.off[g + 1] = t.off[1]; t.nk[g + 1] = t.nk[1];
-  return t;
+  for (int i = 0; i < q; ++i) g += stg_nb(i);
+  return g;
 }
-__device__ __constant__ StageTab c_stage = make_stage_tab();
+constexpr int N_STAGES = stg_base(NSEQ);
+static_assert(N_STAGES == 83, "stage schedule");
+__host__ __device__ constexpr int stage_pieces(int g) {        // pieces of stage g (mod N_STAGES)
+  g %= N_STAGES;
+  for (int q = 0; q < NSEQ; ++q) {
+    if (g < stg_nb(q)) return stg_np(q);
+    g -= stg_nb(q);
+  }
+  return 0;
+}
+// piece-count classes of a stage; a wave moves a CONTIGUOUS share of a stage: quota pieces (the last wave what is left)
+constexpr int NCLS = 6;
+__host__ __device__ constexpr int cls_of(int np) { return np == 6 ? 0 : np == 8 ? 1 : np == 16 ? 2 : np == 17 ? 3 : np == 19 ? 4 : 5; }
+__host__ __device__ constexpr int cls_np(int c) { return c == 0 ? 6 : c == 1 ? 8 : c == 2 ? 16 : c == 3 ? 17 : c == 4 ? 19 : 22; }
+__host__ __device__ constexpr int quota(int np, int nw) { return (np + nw - 1) / nw; }
+__host__ __device__ constexpr int wave_cnt(int np, int nw, int w) {
+  const int q = quota(np, nw), r = np - w * q;
+  return r < 0 ? 0 : (r > q ? q : r);
+}
 
 struct Lay256 { int in_w, in_b, m1_w, m1_b, cat_w, cat_b, m2_w, m2_b, a_w, a_b, cl_w, cl_b, oc_w, oc_b, pe_b; };
 
@@ -229,6 +245,7 @@ struct FwdArgs {
   const int* counts; const int* flags;
   const void* img;                      // packed weight images [K][IMG_BYTES]
   char* ws;                             // activation workspace
+  char* dummy;                          // [NWG_A][8 waves][2 KB]: where a layer's first stage parks its (stale) fragment stores
   float* part;                          // [K][NWG_A][PART_FLOATS]
   Lay256 L;
   WsLay wl;
@@ -264,32 +281,38 @@ __device__ __forceinline__ float rev_sin(const float vh, const float vl, const f
 }
 
 // ---- epilogues on PACKED words (two 16-bit values per register): the ReLU is a packed integer max with zero (a
-// negative value has its sign bit set in either 16-bit format), the branch bit of each half a packed min with 1, and
-// the backward mask a packed integer multiply by those 0 / 1 halves.  ~5 instructions per value pair instead of ~13.
-__device__ __forceinline__ uint32_t pk_relu(uint32_t w) {
-  uint32_t r;
-  asm("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(w));
-  return r;
+// negative value has its sign bit set in either 16-bit format), the branch bit of each half its (inverted) sign bit --
+// a pre-activation that rounds to +0 counts as passed: its activation is 0 either way -- and the backward mask a packed
+// integer multiply by those 0 / 1 halves.  ~6 instructions per value pair instead of ~13, all native (an inline-asm
+// VALU instruction costs an s_nop on either side).
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_relu(uint32_t w) {                             // v_pk_max_i16
+  const s16x2 z = {0, 0};
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, w), z));
 }
 __device__ __forceinline__ uint32_t pk_nonzero(uint32_t w) {                          // 1 per non-zero half (0x00010001-style)
-  uint32_t r;
+  uint32_t r;                                                                         // (the vector min is scalarised by hipcc)
   asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(w), "v"(0x00010001u));
   return r;
 }
 __device__ __forceinline__ uint32_t pk_mask(uint32_t w, uint32_t m01) {               // halves of w times the 0 / 1 halves of m01
-  uint32_t r;
-  asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(w), "v"(m01));
-  return r;
+  return __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, w) * __builtin_bit_cast(u16x2, m01)));
 }
 template <typename OT> __device__ __forceinline__ uint32_t pk_cvt(float a, float b);
 template <> __device__ __forceinline__ uint32_t pk_cvt<__bf16>(float a, float b) {
   typedef __bf16 b2 __attribute__((ext_vector_type(2)));
-  const b2 v = {(__bf16)a, (__bf16)b};
-  return __builtin_bit_cast(uint32_t, v);
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const f2 x = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(x, b2));      // one v_cvt_pk_bf16_f32
 }
 template <> __device__ __forceinline__ uint32_t pk_cvt<_Float16>(float a, float b) {
   typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-  const h2 v = {(_Float16)__builtin_amdgcn_fmed3f(a, -65504.0f, 65504.0f), (_Float16)__builtin_amdgcn_fmed3f(b, -65504.0f, 65504.0f)};
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const f2 x = {a, b};
+  const h2 lim = {(_Float16)65504.0f, (_Float16)65504.0f};
+  h2 v = __builtin_convertvector(x, h2);                       // (round to nearest even; an overflow becomes +-inf ...)
+  v = __builtin_elementwise_max(__builtin_elementwise_min(v, lim), -lim);              // ... and is clamped here
   return __builtin_bit_cast(uint32_t, v);
 }
 
@@ -328,100 +351,87 @@ struct KA {
   }
 
   // -------------------------------------------------------------------------------------------------------------
-  // ring: stage g of this workgroup's stream lives in slot g % 3.  During stage g the waves issue the LDS-DMA
-  // (global_load_lds_dwordx4: 1 KB per wave instruction, no registers) of the pieces of stage g + 2 into the slot that
-  // held stage g - 1, which every wave has left (they all passed the barrier that ended it).  A stage ends with a
-  // COUNTED wait (stage_sync<C>): everything older than this stage's own C transfers has landed -- the pieces of the
-  // stage computed next and the previous stage's fragment stores -- while the newest transfer stays in flight across
-  // the barrier: two stages of latency are hidden.  (The count is wave-uniform and dynamic: the wait is picked by a
-  // scalar switch -- s_waitcnt takes immediates only.)
+  // The weight stream: stage g of this workgroup lives in ring slot g % 3.  During stage g the waves issue the LDS-DMA
+  // (global_load_lds_dwordx4: 1 KB per wave instruction, no registers; its instruction offset moves BOTH the source and
+  // the LDS address -- tools/ubench_glds_off.hip -- so the pieces of a wave's contiguous share need one M0 value and
+  // one source pointer) of the pieces of stage g + 2 into the slot that held stage g - 1, which every wave has left
+  // (they all passed the barrier that ended it).  A stage ends with a COUNTED wait: everything older than the C
+  // vector-memory operations this wave issued during the stage (its transfers and its fragment stores; vmcnt counts
+  // loads, stores and LDS-DMA together, in issue order) has landed -- in particular the pieces of the stage computed
+  // next -- while the stage's own transfers and stores stay in flight across the barrier: two stages of latency are
+  // hidden.  C may under-count (older stragglers are then waited for too), never over-count.  All of it is scalar
+  // arithmetic on a compile-time schedule: the image is consumed front to back, so the source pointer just advances.
   // -------------------------------------------------------------------------------------------------------------
-  struct Ring {
-    const char* img;          // packed images of all objects
-    long tiles_per_obj;
-    long tau_end;             // one past this workgroup's last tile
-    long tau;                 // tile of the stage being computed
-    long obj, tile;           // = tau / tiles_per_obj, tau % tiles_per_obj, kept incrementally (no division per stage)
-    int st;                   // its stage index inside the tile (0 .. 89)
-    int slot;                 // its ring slot
-    int wave, nw;
-    uint32_t lds_ring, voff;                // LDS byte address of the ring; lane * 16
-    // the transfer being issued (scalars): this wave moves pieces wave, wave + nw, ... of the stage: cnt of them
-    unsigned long long src; uint32_t dst; int cnt;
+  template <int NW>
+  struct Stream {
+    unsigned long long srcp;      // (scalar) image address of the first piece of the stage TWO ahead of the one computed
+    uint32_t dst2;                // (scalar) LDS address of that stage's ring slot
+    uint32_t rd;                  // (scalar) LDS address of the slot being computed
+    uint32_t lo;                  // (scalar) LDS address of the ring
+    uint32_t voff[NCLS];          // (vector) lane * 16 + this wave's share offset inside a stage of class c
+    uint32_t woff[NCLS];          // (scalar) this wave's share offset: wave * quota * PIECE
+    int cw[NCLS];                 // (scalar) transfers of this wave per stage of class c
+    bool last;                    // (scalar) the last wave (the one whose share may be short)
 
-    // generic form (prologue): table lookups
-    __device__ __forceinline__ void prepare(const int ahead) {
-      int st2 = __builtin_amdgcn_readfirstlane(st) + ahead;
-      setup(st2 >= N_STAGES, c_stage.off[st2 >= N_STAGES ? st2 - N_STAGES : st2], c_stage.nk[st2 >= N_STAGES ? st2 - N_STAGES : st2], ahead);
-    }
-    // the stage two ahead of block blk of sequence Q, from compile-time tables: no memory access, a few scalar selects
-    template <int Q>
-    __device__ __forceinline__ void prepare2(const int blk) {
-      constexpr int NB = seq_nb(Q), NK = seq_nk(Q), OFF = seq_off(Q);
-      constexpr int Q1 = (Q + 1) % NSEQ, Q2 = (Q + 2) % NSEQ, Q3 = (Q + 3) % NSEQ;
-      // stage index (relative to the first block of Q) -> (sequence, block): at most three sequences ahead
-      constexpr int NB1 = seq_nb(Q1), NB2 = seq_nb(Q2);
-      const int e = blk + 2 - NB;                       // >= 0: past the end of Q
-      int off, nk; bool wrap;
-      if (e < 0) { off = OFF + (blk + 2) * NK; nk = NK; wrap = false; }
-      else if (e < NB1) { off = seq_off(Q1) + e * seq_nk(Q1); nk = seq_nk(Q1); wrap = Q1 < Q; }
-      else if (e - NB1 < NB2) { off = seq_off(Q2) + (e - NB1) * seq_nk(Q2); nk = seq_nk(Q2); wrap = Q2 < Q; }
-      else { off = seq_off(Q3) + (e - NB1 - NB2) * seq_nk(Q3); nk = seq_nk(Q3); wrap = Q3 < Q; }
-      setup(wrap, off, nk, 2);
-    }
-    __device__ __forceinline__ void setup(const bool wrap, const int off, const int nk, const int ahead) {
-      long obj2 = obj;
-      bool live = true;
-      if (wrap) {
-        live = tau + 1 < tau_end;
-        if (live && tile + 1 == tiles_per_obj) obj2 += 1;
+    __device__ __forceinline__ void init(const uint32_t lds_ring, const int wave, const int lane) {
+      lo = lds_ring; dst2 = lds_ring; rd = lds_ring;
+      last = wave == NW - 1;
+#pragma unroll
+      for (int c = 0; c < NCLS; ++c) {
+        const int q = quota(cls_np(c), NW);
+        int r = cls_np(c) - wave * q;
+        r = r < 0 ? 0 : (r > q ? q : r);
+        cw[c] = __builtin_amdgcn_readfirstlane(r);
+        woff[c] = __builtin_amdgcn_readfirstlane(wave * q * PIECE);
+        voff[c] = (uint32_t)lane * 16u + woff[c];
       }
-      int s2 = __builtin_amdgcn_readfirstlane(slot) + ahead; if (s2 >= 3) s2 -= 3;
-      const int npiece = live ? nk : 0;
-      cnt = __builtin_amdgcn_readfirstlane(npiece > wave ? (npiece - wave + nw - 1) / nw : 0);
-      const unsigned long long sa = (unsigned long long)(img + obj2 * IMG_BYTES + ((long)off + wave) * PIECE);
+    }
+    __device__ __forceinline__ void set_source(const char* p) {
+      const unsigned long long sa = (unsigned long long)p;
       // scalar registers, provably (readfirstlane returns int: through uint32_t, or the low half is sign-extended)
-      src = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sa >> 32)) << 32) |
-            (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sa);
-      dst = __builtin_amdgcn_readfirstlane(lds_ring + s2 * RING_SLOT + wave * PIECE);
+      srcp = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sa >> 32)) << 32) |
+             (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sa);
     }
-    template <int I>
-    __device__ __forceinline__ void issue() const {                     // the I-th piece of this wave, if it has one
-      if (I < cnt) {
-        const unsigned long long sa = src + (unsigned long long)I * nw * PIECE;
-        const uint32_t da = dst + I * nw * PIECE;
-        // M0 (the LDS destination) belongs to the compiler: saved and restored inside the statement that uses it.
-        // Operands are scalar-ALU results of values made scalar in prepare(), long before: no VALU-written SGPR reaches
-        // the VMEM instruction inside its 5 wait states (hipcc pads nothing for inline asm).
-        uint32_t keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "s"(da), "v"(voff), "s"(sa) : "memory");
+    // transfer I of this wave's share of a stage of NP pieces (first piece at srcp, slot at dst2); ALLC: every transfer
+    // is conditional on the run-time count `cnt` (the stages that wrap to the next tile)
+    template <int NP, int I, bool ALLC>
+    __device__ __forceinline__ void issue(const int cnt) const {
+      constexpr int Q4 = quota(NP, NW), CMIN = wave_cnt(NP, NW, NW - 1), C = cls_of(NP);
+      if constexpr (I < Q4) {
+        auto go = [&]() __attribute__((always_inline)) {
+          // M0 = the LDS destination; operands are scalar-ALU results of values made scalar long before: no
+          // VALU-written SGPR reaches the VMEM instruction inside its wait states (hipcc pads nothing for inline asm)
+          const uint32_t d = dst2 + woff[C] + (I >= 4 ? 4 * PIECE : 0);
+          const unsigned long long sa = srcp + (I >= 4 ? 4 * PIECE : 0);
+          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3"
+                       :: "s"(d), "v"(voff[C]), "s"(sa), "n"((I & 3) * PIECE) : "memory", "m0");
+        };
+        if constexpr (!ALLC && I < CMIN) go();
+        else if (I < cnt) go();
       }
     }
+    // the stage two ahead has been requested: on to the next one
+    template <int NP>
     __device__ __forceinline__ void advance() {
-      if (++slot == 3) slot = 0;
-      if (++st == N_STAGES) { st = 0; ++tau; if (++tile == tiles_per_obj) { tile = 0; ++obj; } }
+      srcp += (unsigned long long)NP * PIECE;
+      dst2 += RING_SLOT; if (dst2 == lo + 3 * RING_SLOT) dst2 = lo;
+      rd += RING_SLOT; if (rd == lo + 3 * RING_SLOT) rd = lo;
     }
   };
-  // end of a stage in which this wave issued cnt transfers (raw s_barrier: __syncthreads() would drain the DMA)
-  static __device__ __forceinline__ void stage_sync(const int cnt) {
-    switch (cnt) {
-      case 0: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-      case 1: asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-      case 2: asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-      case 3: asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-      case 4: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-      case 5: asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-      default: asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-    }
+  // end of a stage (raw s_barrier: __syncthreads() would drain the DMA): at most N vector-memory operations of this
+  // wave stay in flight
+  template <int N>
+  static __device__ __forceinline__ void sync_imm() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(N < 63 ? N : 63) : "memory");
   }
-  // DMA instructions per wave for a stage issued from sequence q: the stage two ahead lies in q, q + 1 or q + 2
-  static constexpr int dma_count(int q, int nw) {
-    int m = seq_nk(q);
-    const int q1 = (q + 1) % NSEQ, q2 = (q + 2) % NSEQ;
-    if (seq_nk(q1) > m) m = seq_nk(q1);
-    if (seq_nk(q2) > m) m = seq_nk(q2);
-    return (m + nw - 1) / nw;
+  // ... of a stage that requested a stage of NP pieces and issued ST stores of its own
+  template <int NW, int NP, int ST>
+  static __device__ __forceinline__ void stage_sync(const bool last_wave) {
+    constexpr int Q4 = quota(NP, NW), CMIN = wave_cnt(NP, NW, NW - 1);
+    static_assert(NW < 3 || wave_cnt(NP, NW, NW - 2) == Q4, "only the last wave's share is short");
+    if constexpr (Q4 == CMIN) sync_imm<Q4 + ST>();
+    else if (last_wave) sync_imm<CMIN + ST>();
+    else sync_imm<Q4 + ST>();
   }
 
   // one block of a sequence: acc += sum over the stage's k-steps of piece(ks) x bfrag(ks).  The A operands are read
@@ -436,21 +446,39 @@ struct KA {
   }
   template <int N>
   static __device__ __forceinline__ void wait_for(V& x) {       // at most N LDS reads still outstanding
-    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x) : "i"(N));
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x) : "n"(N));
   }
-  template <int NK, int KS, class BF, class SD>
-  static __device__ __forceinline__ void step(f32x16& acc, V (&a)[DEPTH], const uint32_t addr, const BF& bfrag, SD& side) {
+  template <int N>
+  static __device__ __forceinline__ void wait_for2(V& x, V& y) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(x), "+v"(y) : "n"(N));
+  }
+  // TWO accumulator chains (even / odd k-steps): a v_mfma_f32_32x32x16 that depends on the one issued right before it
+  // starts ~110 cycles after it, an independent one after ~34 (tools/ubench_mfma32.hip: 645 against 1708 TFLOP/s on
+  // the whole chip) -- with one wave per SIMD there is no other wave to fill that gap, so the block's contraction is
+  // split over two accumulators that the epilogue adds.  One counted wait serves a PAIR of k-steps (every instruction
+  // of the single wave costs an issue slot).
+  // Z0 / Z1: the chain starts from zero (the MFMA takes the constant as its C operand: no register initialisation).
+  template <int NK, int KS, bool Z0, bool Z1, class BF, class SD>
+  static __device__ __forceinline__ void step(f32x16& acc0, f32x16& acc1, V (&a)[DEPTH], const uint32_t addr, const BF& bfrag, SD& side) {
     if constexpr (KS < NK) {
       constexpr int inflight = (NK - 1 - KS) < (DEPTH - 1) ? (NK - 1 - KS) : (DEPTH - 1);   // reads issued after read KS
-      wait_for<inflight>(a[KS % DEPTH]);
-      acc = O::mfma(a[KS % DEPTH], bfrag(KS), acc);
+      if constexpr ((KS & 1) == 0) {
+        if constexpr (KS + 1 < NK) wait_for2<(inflight > 0 ? inflight - 1 : 0)>(a[KS % DEPTH], a[(KS + 1) % DEPTH]);
+        else wait_for<inflight>(a[KS % DEPTH]);
+        if constexpr (KS == 0 && Z0) acc0 = O::mfma(a[KS % DEPTH], bfrag(KS), zero16());
+        else acc0 = O::mfma(a[KS % DEPTH], bfrag(KS), acc0);
+      } else {
+        if constexpr (KS == 1 && Z1) acc1 = O::mfma(a[KS % DEPTH], bfrag(KS), zero16());
+        else acc1 = O::mfma(a[KS % DEPTH], bfrag(KS), acc1);
+      }
       if constexpr (KS + DEPTH < NK) rd<(KS + DEPTH) * PIECE>(a[KS % DEPTH], addr);
       side(std::integral_constant<int, KS>{});
-      step<NK, KS + 1>(acc, a, addr, bfrag, side);
+      step<NK, KS + 1, Z0, Z1>(acc0, acc1, a, addr, bfrag, side);
     }
   }
-  template <int NK, class BF, class SD>
-  static __device__ __forceinline__ void block_mma(f32x16& acc, const uint32_t addr, const BF& bfrag, SD& side) {
+  template <int NK, bool Z0, bool Z1, class BF, class SD>
+  static __device__ __forceinline__ void block_mma(f32x16& acc0, f32x16& acc1, const uint32_t addr, const BF& bfrag, SD& side) {
+    static_assert(NK >= 2 || !Z1, "chain 1 needs a k-step to start from");
     V a[DEPTH];
     rd<0>(a[0], addr);
     if constexpr (NK > 1) rd<PIECE>(a[1], addr);
@@ -458,7 +486,7 @@ struct KA {
     if constexpr (NK > 3) rd<3 * PIECE>(a[3], addr);
     if constexpr (NK > 4) rd<4 * PIECE>(a[4], addr);
     if constexpr (NK > 5) rd<5 * PIECE>(a[5], addr);
-    step<NK, 0>(acc, a, addr, bfrag, side);
+    step<NK, 0, Z0, Z1>(acc0, acc1, a, addr, bfrag, side);
   }
 };
 
@@ -495,17 +523,24 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
   char* hbuf = lds + L_HBUF + w * (KS_H * PIECE) + lane * 16;       // this lane's 16 bytes of fragment ks at + ks * PIECE
   const uint32_t lds0 = (uint32_t)(uintptr_t)lds;
 
-  typename KT::Ring ring;
-  ring.img = (const char*)a.img; ring.tiles_per_obj = a.ntile; ring.tau_end = tau1; ring.tau = tau0; ring.st = 0; ring.slot = 0;
-  ring.obj = tau0 / a.ntile; ring.tile = tau0 - ring.obj * a.ntile;
-  ring.wave = w; ring.nw = NW; ring.voff = lane * 16;
-  ring.lds_ring = __builtin_amdgcn_readfirstlane(lds0 + L_RING);
-  // prologue: stages 0 and 1
-  ring.prepare(0);
-  ring.template issue<0>(); ring.template issue<1>(); ring.template issue<2>(); ring.template issue<3>(); ring.template issue<4>(); ring.template issue<5>();
-  ring.prepare(1);
-  ring.template issue<0>(); ring.template issue<1>(); ring.template issue<2>(); ring.template issue<3>(); ring.template issue<4>(); ring.template issue<5>();
+  typename KT::template Stream<NW> strm;
+  strm.init(__builtin_amdgcn_readfirstlane(lds0 + L_RING), w, lane);
+  long tile_i; int k_i;
+  {
+    const long obj0 = tau0 / a.ntile;
+    k_i = (int)obj0; tile_i = tau0 - obj0 * a.ntile;
+    strm.set_source((const char*)a.img + obj0 * IMG_BYTES);
+    // prologue: stages 0 and 1 (F1 blocks 0 and 1) into slots 0 and 1; the stream then points at stage 2 / slot 2
+    constexpr int NP0 = stage_pieces(0), NP1 = stage_pieces(1);
+    strm.template issue<NP0, 0, true>(strm.cw[cls_of(NP0)]); strm.template issue<NP0, 1, true>(strm.cw[cls_of(NP0)]);
+    strm.srcp += (unsigned long long)NP0 * PIECE; strm.dst2 += RING_SLOT;
+    strm.template issue<NP1, 0, true>(strm.cw[cls_of(NP1)]); strm.template issue<NP1, 1, true>(strm.cw[cls_of(NP1)]);
+    strm.srcp += (unsigned long long)NP1 * PIECE; strm.dst2 += RING_SLOT;
+    static_assert(quota(NP0, NW) <= 2 && quota(NP1, NW) <= 2, "prologue transfers");
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  typedef __attribute__((address_space(1))) typename Op<OT>::V GVp;
+  GVp* const park = (GVp*)(a.dummy + ((long)wg * 8 + w) * 2048 + lane * 16);
 
   const float gs = a.grad_scale, inv_gs = 1.0f / a.grad_scale;
   T256_DECL;
@@ -543,8 +578,10 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
   };
 
   for (long tau = tau0; tau < tau1; ++tau) {
-    const int k = (int)ring.obj;              // (the ring is at stage 0 of this tile)
-    const long tile = ring.tile;
+    const int k = k_i;                        // (the stream is at stage 0 of this tile)
+    const long tile = tile_i;
+    const bool live = tau + 1 < tau1;         // another tile follows: the last two stages request its first two
+    const long next_obj = (tile + 1 == a.ntile) ? (long)k + 1 : (long)k;
     if (k != cur_obj) {
       if (cur_obj >= 0) flush_object();
       cur_obj = k;
@@ -637,81 +674,113 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
     }
 
     V hin[KS_H];
-    // fragment stores of a block are issued in the shadow of the NEXT block's MFMAs
-    V pend0, pend1;
-    GV* pend_ptr = nullptr;
-    auto flush_pending = [&]() __attribute__((always_inline)) {
-      if (pend_ptr) {      // non-temporal: 5 KB per sample stream through the L2 that also has to keep serving the weight ring
-        __builtin_nontemporal_store(pend0, pend_ptr);
-        __builtin_nontemporal_store(pend1, pend_ptr + 64);
-        pend_ptr = nullptr;
-      }
-    };
-    // the side work of a stage that issues CD transfers: stores after the first MFMA, one transfer every other MFMA,
-    // whatever is left after the last one
-    auto side_work = [&](auto cd_tag, auto nk_tag) __attribute__((always_inline)) {
-      return [&](auto ks_tag) __attribute__((always_inline)) {
-        constexpr int CD = decltype(cd_tag)::value, NK = decltype(nk_tag)::value, KS = decltype(ks_tag)::value;
-        if constexpr (KS == 0) flush_pending();
-        // one wave issues one instruction per ~4 cycles: the side work is spread, a transfer behind every other MFMA
-        // (transfer i after MFMA 2 i + 1), so that no gap between two MFMAs holds more than the MFMA's own 32 cycles;
-        // whatever has no such slot goes after the last MFMA
-        if constexpr (KS == NK - 1) {
-          if constexpr (1 >= NK - 1 && 0 < CD) ring.template issue<0>();
-          if constexpr (3 >= NK - 1 && 1 < CD) ring.template issue<1>();
-          if constexpr (5 >= NK - 1 && 2 < CD) ring.template issue<2>();
-          if constexpr (7 >= NK - 1 && 3 < CD) ring.template issue<3>();
-          if constexpr (9 >= NK - 1 && 4 < CD) ring.template issue<4>();
-          if constexpr (11 >= NK - 1 && 5 < CD) ring.template issue<5>();
-        } else if constexpr ((KS & 1) && KS / 2 < CD) ring.template issue<KS / 2>();
-      };
+    // the transfers of a stage that requests a stage of NP2 pieces, spread behind the MFMAs of its NK k-steps (transfer
+    // i after MFMA 2 i + 1: one wave issues one instruction per ~4 cycles, so no gap between two MFMAs should hold more
+    // than the MFMA's own cycles), whatever has no such slot after the last one
+    auto dma_side = [&](auto np2_tag, auto nk_tag, auto ks_tag, auto allc_tag, const int cnt) __attribute__((always_inline)) {
+      constexpr int NP2 = decltype(np2_tag)::value, NK = decltype(nk_tag)::value, KS = decltype(ks_tag)::value;
+      constexpr bool AC = decltype(allc_tag)::value;
+      constexpr int CD = quota(NP2, NW);
+      static_assert(CD <= 6, "transfers per wave and stage");
+      if constexpr (KS == NK - 1) {
+        if constexpr (1 >= NK - 1 && 0 < CD) strm.template issue<NP2, 0, AC>(cnt);
+        if constexpr (3 >= NK - 1 && 1 < CD) strm.template issue<NP2, 1, AC>(cnt);
+        if constexpr (5 >= NK - 1 && 2 < CD) strm.template issue<NP2, 2, AC>(cnt);
+        if constexpr (7 >= NK - 1 && 3 < CD) strm.template issue<NP2, 3, AC>(cnt);
+        if constexpr (9 >= NK - 1 && 4 < CD) strm.template issue<NP2, 4, AC>(cnt);
+        if constexpr (11 >= NK - 1 && 5 < CD) strm.template issue<NP2, 5, AC>(cnt);
+      } else if constexpr ((KS & 1) && KS / 2 < CD) strm.template issue<NP2, KS / 2, AC>(cnt);
     };
     auto reload = [&]() __attribute__((always_inline)) {          // hin <- the fragments the layer just produced
 #pragma unroll
       for (int ks = 0; ks < KS_H; ++ks) hin[ks] = *reinterpret_cast<const V*>(hbuf + ks * PIECE);
     };
-    auto ring_addr = [&]() __attribute__((always_inline)) -> uint32_t {
-      return lds0 + L_RING + lane * 16 + ring.slot * RING_SLOT;
-    };
-
-    // forward hidden layer: NK k-steps from bsel(ks); blocks 0..7 -> fragments (LDS hand-off buffer + workspace tensor
-    // `layer`), ReLU bits.  The block loop is ROLLED: one body per layer keeps the tile body inside the instruction cache.
-    auto fwd_layer = [&](auto seq_tag, auto nk_tag, const int layer, auto&& bsel) __attribute__((always_inline)) {
+    auto ring_addr = [&]() __attribute__((always_inline)) -> uint32_t { return strm.rd + (uint32_t)lane * 16u; };
+    // a stage without an epilogue of its own: the block's MFMAs (two chains) + the transfers; the caller ends it
+    auto plain_stage = [&](auto np2_tag, auto nk_tag, auto allc_tag, const int cnt, f32x16& acc0, f32x16& acc1, auto&& bsel)
+        __attribute__((always_inline)) {
       constexpr int NK = decltype(nk_tag)::value;
-      constexpr int CD = KT::dma_count(decltype(seq_tag)::value, NW);
+      auto sd = [&](auto ks_tag) __attribute__((always_inline)) { dma_side(np2_tag, nk_tag, ks_tag, allc_tag, cnt); };
+      KT::template block_mma<NK, true, true>(acc0, acc1, ring_addr(), bsel, sd);
+    };
+#define NP2_OF(Q_, BLK_) stage_pieces(stg_base(Q_) + (BLK_) + 2)
+
+    // Hidden layers are SOFTWARE-PIPELINED over their eight blocks on two accumulators: with one wave per SIMD nothing
+    // overlaps an MFMA but this wave's own independent instructions, so the epilogue of block b - 1 (convert, ReLU /
+    // mask, pack, hand-off and fragment stores) runs piecewise in the shadow of block b's MFMAs (one value pair behind
+    // each of the first eight), and so do the scalar set-up of the ring transfer and the bias rows of block b + 1.  Only
+    // the last block's epilogue is exposed.  Stage 0 runs the same code on a stale accumulator: its stores are parked
+    // in hand-off pieces 14 / 15 and mask word 3, which blocks 6 / 7 overwrite later, and its global stores are skipped.
+    // forward hidden layer: NK k-steps from bsel(ks); blocks 0..7 -> fragments (LDS hand-off buffer + workspace tensor
+    // `layer`), ReLU bits.  The block loop is rolled over block PAIRS (the accumulators swap roles) for blocks 0..5,
+    // whose stage two ahead lies in the same sequence; blocks 6 and 7 are peeled (theirs is the next sequence's).
+    auto fwd_layer = [&](auto seq_tag, auto nk_tag, const int layer, auto&& bsel) __attribute__((always_inline)) {
+      constexpr int NK = decltype(nk_tag)::value, Q = decltype(seq_tag)::value;
+      constexpr int SK = NK - 1 < 8 ? NK - 1 : 8;          // the k-step whose shadow finishes the previous block's epilogue
       uint32_t mprev = 0;
-#pragma unroll 1
-      for (int blk = 0; blk < 8; ++blk) {
-        T256(5);
-        ring.template prepare2<decltype(seq_tag)::value>(blk);
-        f32x16 acc;
+      auto load_bias = [&](f32x16& acc, const int blk) __attribute__((always_inline)) {
         const float* bp = s_bias + layer * 256 + blk * 32 + h * 16;
 #pragma unroll
         for (int n4 = 0; n4 < 4; ++n4) {
           const f32x4v b4 = *reinterpret_cast<const f32x4v*>(bp + 4 * n4);
           acc[4 * n4] = b4[0]; acc[4 * n4 + 1] = b4[1]; acc[4 * n4 + 2] = b4[2]; acc[4 * n4 + 3] = b4[3];
         }
-        T256(0);
-        auto sd = side_work(std::integral_constant<int, CD>{}, nk_tag);
-        KT::template block_mma<NK>(acc, ring_addr(), bsel, sd);
-        T256(1);
+      };
+      auto finish = [&](const int pb, const uint32_t (&wd)[8], const uint32_t bits, GV* dst) __attribute__((always_inline)) {
+        const uint4 u0 = make_uint4(wd[0], wd[1], wd[2], wd[3]), u1 = make_uint4(wd[4], wd[5], wd[6], wd[7]);
+        const V f0 = __builtin_bit_cast(V, u0), f1 = __builtin_bit_cast(V, u1);
+        *reinterpret_cast<V*>(hbuf + (2 * pb) * PIECE) = f0;
+        *reinterpret_cast<V*>(hbuf + (2 * pb + 1) * PIECE) = f1;
+        s_mask[(layer * 4 + (pb >> 1)) * NTHR + tid] = (pb & 1) ? (mprev | (bits << 8)) : bits;
+        mprev = bits;
+        // non-temporal: 5 KB per sample stream through the L2 that also has to keep serving the weight ring
+        __builtin_nontemporal_store(f0, dst);
+        __builtin_nontemporal_store(f1, dst + 64);
+      };
+      auto stage = [&](auto np2_tag, const int blk, f32x16& cur, f32x16& cur1, f32x16& prv, f32x16& prv1) __attribute__((always_inline)) {
+        constexpr int NP2 = decltype(np2_tag)::value;
+        uint32_t wd[8], bits = 0;
+        const int pb = (blk + 7) & 7;                      // the block whose epilogue rides along
+        auto piece = [&](const int i) __attribute__((always_inline)) {
+          const uint32_t c = pk_cvt<OT>(prv[2 * i] + prv1[2 * i], prv[2 * i + 1] + prv1[2 * i + 1]);
+          wd[i] = pk_relu(c);
+          bits = ((c >> (15 - i)) & (0x00010001u << i)) | bits;      // SIGN bits: bit i value 2 i, bit 16 + i value 2 i + 1
+        };
+        auto sd = [&](auto ks_tag) __attribute__((always_inline)) {
+          constexpr int KS = decltype(ks_tag)::value;
+          if constexpr (KS < SK) piece(KS);
+          if constexpr (KS == SK) {
+#pragma unroll
+            for (int i = SK; i < 8; ++i) piece(i);
+            finish(pb, wd, ~bits & 0x00ff00ffu, blk > 0 ? act_base(layer, 2 * pb) : (GV*)park);
+            load_bias(prv, (blk + 1) & 7);                 // prv becomes the next block's first chain (the second starts from 0)
+          }
+          dma_side(np2_tag, nk_tag, ks_tag, std::false_type{}, strm.cw[cls_of(NP2)]);
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        KT::template block_mma<NK, false, true>(cur, cur1, ring_addr(), bsel, sd);
+        asm volatile("" : "+v"(prv));                      // (the compiler's wait for the bias rows lands here, not in the next stage)
+        KT::template stage_sync<NW, NP2, 2>(strm.last);
+        strm.template advance<NP2>();
+      };
+      f32x16 accA, accA1 = zero16(), accB = zero16(), accB1 = zero16();
+      load_bias(accA, 0);
+#pragma unroll 1
+      for (int blk = 0; blk < 6; blk += 2) {
+        stage(nk_tag, blk, accA, accA1, accB, accB1);
+        stage(nk_tag, blk + 1, accB, accB1, accA, accA1);
+      }
+      stage(std::integral_constant<int, NP2_OF(Q, 6)>{}, 6, accA, accA1, accB, accB1);
+      stage(std::integral_constant<int, NP2_OF(Q, 7)>{}, 7, accB, accB1, accA, accA1);
+      {   // block 7's epilogue
         uint32_t wd[8], bits = 0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          wd[i] = pk_relu(pk_cvt<OT>(acc[2 * i], acc[2 * i + 1]));
-          bits |= pk_nonzero(wd[i]) << i;            // bit i: value 2 i, bit 16 + i: value 2 i + 1
+          const uint32_t c = pk_cvt<OT>(accB[2 * i] + accB1[2 * i], accB[2 * i + 1] + accB1[2 * i + 1]);
+          wd[i] = pk_relu(c);
+          bits = ((c >> (15 - i)) & (0x00010001u << i)) | bits;
         }
-        const uint4 u0 = make_uint4(wd[0], wd[1], wd[2], wd[3]), u1 = make_uint4(wd[4], wd[5], wd[6], wd[7]);
-        const V f0 = __builtin_bit_cast(V, u0), f1 = __builtin_bit_cast(V, u1);
-        *reinterpret_cast<V*>(hbuf + (2 * blk) * PIECE) = f0;
-        *reinterpret_cast<V*>(hbuf + (2 * blk + 1) * PIECE) = f1;
-        pend0 = f0; pend1 = f1; pend_ptr = act_base(layer, 2 * blk);
-        if (blk & 1) s_mask[(layer * 4 + (blk >> 1)) * NTHR + tid] = mprev | (bits << 8);
-        mprev = bits;
-        T256(2);
-        KT::stage_sync(ring.cnt);
-        T256(3);
-        ring.advance();
+        finish(7, wd, ~bits & 0x00ff00ffu, act_base(layer, 14));
       }
     };
     // ------------------------------------------------------------------ forward
@@ -749,25 +818,26 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
     fwd_layer(std::integral_constant<int, F5>{}, std::integral_constant<int, 19>{}, 4,
               [&](int ks) -> V { return ks < KS_H ? hin[ks] : x2f[ks - KS_H]; });                                              // hc
     {   // F5 block 8: row 0 = w_alpha . h4  (raw density, model.py:81)
-      constexpr int CD = KT::dma_count(F5, NW);
-      ring.template prepare2<F5>(8);
-      f32x16 acc = zero16();
-      auto sd = side_work(std::integral_constant<int, CD>{}, std::integral_constant<int, 19>{});
-      KT::template block_mma<19>(acc, ring_addr(), [&](int ks) -> V { return ks < KS_H ? hin[ks] : x2f[ks - KS_H]; }, sd);
-      if (h == 0) s_raw[st_idx] = acc[0] + ba;
-      KT::stage_sync(ring.cnt);
-      ring.advance();
+      constexpr int NP2 = NP2_OF(F5, 8);
+      f32x16 acc = zero16(), acc1 = zero16();
+      plain_stage(std::integral_constant<int, NP2>{}, std::integral_constant<int, 19>{}, std::false_type{}, strm.cw[cls_of(NP2)], acc, acc1,
+                  [&](int ks) -> V { return ks < KS_H ? hin[ks] : x2f[ks - KS_H]; });
+      if (h == 0) s_raw[st_idx] = (acc[0] + acc1[0]) + ba;
+      KT::template stage_sync<NW, NP2, 0>(strm.last);
+      strm.template advance<NP2>();
     }
     reload();                                  // hin = hc
     {   // F6: colour head on hc (model.py:95)
-      constexpr int CD = KT::dma_count(F6, NW);
-      ring.template prepare2<F6>(0);
-      f32x16 acc = zero16();
-      auto sd = side_work(std::integral_constant<int, CD>{}, std::integral_constant<int, 16>{});
-      KT::template block_mma<16>(acc, ring_addr(), [&](int ks) -> V { return hin[ks]; }, sd);
-      if (h == 0) { s_col[st_idx] = acc[0] + boc0; s_col[TSAMP + st_idx] = acc[1] + boc1; s_col[2 * TSAMP + st_idx] = acc[2] + boc2; }
-      KT::stage_sync(ring.cnt);           // (also publishes the strips to the compositing waves)
-      ring.advance();
+      constexpr int NP2 = NP2_OF(F6, 0);
+      f32x16 acc = zero16(), acc1 = zero16();
+      plain_stage(std::integral_constant<int, NP2>{}, std::integral_constant<int, 16>{}, std::false_type{}, strm.cw[cls_of(NP2)], acc, acc1,
+                  [&](int ks) -> V { return hin[ks]; });
+      if (h == 0) {
+        s_col[st_idx] = (acc[0] + acc1[0]) + boc0; s_col[TSAMP + st_idx] = (acc[1] + acc1[1]) + boc1;
+        s_col[2 * TSAMP + st_idx] = (acc[2] + acc1[2]) + boc2;
+      }
+      KT::template stage_sync<NW, NP2, 0>(strm.last);           // (also publishes the strips to the compositing waves)
+      strm.template advance<NP2>();
     }
     // ------------------------------------------------------------------ compositing + losses (loss.py:27-101)
     {
@@ -872,49 +942,143 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
 
     // ------------------------------------------------------------------ backward
     // hidden input-gradient layer: d(input features) from NK k-steps of bsel, masked by the ReLU bits of the PRODUCING
-    // layer `mlayer`, stored as the weight-gradient operand `5 + mlayer` and handed to the next GEMM through hbuf
+    // layer `mlayer`, stored as the weight-gradient operand `5 + mlayer` and handed to the next GEMM through hbuf;
+    // pipelined like the forward layers (the mask word of a block is fetched one stage before its epilogue)
     auto bwd_layer = [&](auto seq_tag, auto nk_tag, const int mlayer, auto&& bsel) __attribute__((always_inline)) {
-      constexpr int NK = decltype(nk_tag)::value;
-      constexpr int CD = KT::dma_count(decltype(seq_tag)::value, NW);
-#pragma unroll 1
-      for (int blk = 0; blk < 8; ++blk) {
-        T256(5);
-        ring.template prepare2<decltype(seq_tag)::value>(blk);
-        const uint32_t bits = s_mask[(mlayer * 4 + (blk >> 1)) * NTHR + tid] >> (8 * (blk & 1));
-        f32x16 acc = zero16();
-        auto sd = side_work(std::integral_constant<int, CD>{}, nk_tag);
-        KT::template block_mma<NK>(acc, ring_addr(), bsel, sd);
-        uint32_t wd[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) wd[i] = pk_mask(pk_cvt<OT>(acc[2 * i], acc[2 * i + 1]), (bits >> i) & 0x00010001u);
+      constexpr int NK = decltype(nk_tag)::value, Q = decltype(seq_tag)::value;
+      constexpr int SK = NK - 1 < 8 ? NK - 1 : 8;
+      auto mask_bits = [&](const int b) __attribute__((always_inline)) -> uint32_t {
+        return s_mask[(mlayer * 4 + (b >> 1)) * NTHR + tid] >> (8 * (b & 1));
+      };
+      auto finish = [&](const int pb, const uint32_t (&wd)[8], GV* dst) __attribute__((always_inline)) {
         const uint4 u0 = make_uint4(wd[0], wd[1], wd[2], wd[3]), u1 = make_uint4(wd[4], wd[5], wd[6], wd[7]);
         const V f0 = __builtin_bit_cast(V, u0), f1 = __builtin_bit_cast(V, u1);
-        *reinterpret_cast<V*>(hbuf + (2 * blk) * PIECE) = f0;
-        *reinterpret_cast<V*>(hbuf + (2 * blk + 1) * PIECE) = f1;
-        pend0 = f0; pend1 = f1; pend_ptr = act_base(5 + mlayer, 2 * blk);
-        KT::stage_sync(ring.cnt);
-        ring.advance();
-        T256(4);
+        *reinterpret_cast<V*>(hbuf + (2 * pb) * PIECE) = f0;
+        *reinterpret_cast<V*>(hbuf + (2 * pb + 1) * PIECE) = f1;
+        __builtin_nontemporal_store(f0, dst);
+        __builtin_nontemporal_store(f1, dst + 64);
+      };
+      uint32_t mb = 0;                                     // mask bits of the block whose epilogue comes next
+      auto stage = [&](auto np2_tag, const int blk, f32x16& cur, f32x16& cur1, f32x16& prv, f32x16& prv1) __attribute__((always_inline)) {
+        constexpr int NP2 = decltype(np2_tag)::value;
+        uint32_t wd[8];
+        const int pb = (blk + 7) & 7;
+        const uint32_t bits = mb;
+        auto piece = [&](const int i) __attribute__((always_inline)) {
+          wd[i] = pk_mask(pk_cvt<OT>(prv[2 * i] + prv1[2 * i], prv[2 * i + 1] + prv1[2 * i + 1]), (bits >> i) & 0x00010001u);
+        };
+        auto sd = [&](auto ks_tag) __attribute__((always_inline)) {
+          constexpr int KS = decltype(ks_tag)::value;
+          if constexpr (KS < SK) piece(KS);
+          if constexpr (KS == SK) {
+#pragma unroll
+            for (int i = SK; i < 8; ++i) piece(i);
+            finish(pb, wd, blk > 0 ? act_base(5 + mlayer, 2 * pb) : (GV*)park);
+            mb = mask_bits(blk);
+          }
+          dma_side(np2_tag, nk_tag, ks_tag, std::false_type{}, strm.cw[cls_of(NP2)]);
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        KT::template block_mma<NK, true, true>(cur, cur1, ring_addr(), bsel, sd);
+        asm volatile("" : "+v"(mb));
+        KT::template stage_sync<NW, NP2, 2>(strm.last);
+        strm.template advance<NP2>();
+      };
+      f32x16 accA, accA1, accB = zero16(), accB1 = zero16();
+#pragma unroll 1
+      for (int blk = 0; blk < 6; blk += 2) {
+        stage(nk_tag, blk, accA, accA1, accB, accB1);
+        stage(nk_tag, blk + 1, accB, accB1, accA, accA1);
+      }
+      stage(std::integral_constant<int, NP2_OF(Q, 6)>{}, 6, accA, accA1, accB, accB1);
+      stage(std::integral_constant<int, NP2_OF(Q, 7)>{}, 7, accB, accB1, accA, accA1);
+      {
+        uint32_t wd[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          wd[i] = pk_mask(pk_cvt<OT>(accB[2 * i] + accB1[2 * i], accB[2 * i + 1] + accB1[2 * i + 1]), (mb >> i) & 0x00010001u);
+        finish(7, wd, act_base(5 + mlayer, 14));
       }
     };
     // slot-gradient blocks (d x1 / d x2): NB blocks accumulated into xacc[b]
     auto bwd_slots = [&](auto seq_tag, auto nb_tag, f32x16* xacc) __attribute__((always_inline)) {
-      constexpr int NB = decltype(nb_tag)::value;
-      constexpr int CD = KT::dma_count(decltype(seq_tag)::value, NW);
+      constexpr int NB = decltype(nb_tag)::value, Q = decltype(seq_tag)::value;
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
-        ring.template prepare2<decltype(seq_tag)::value>(b);
-        auto sd = side_work(std::integral_constant<int, CD>{}, std::integral_constant<int, 16>{});
-        KT::template block_mma<16>(xacc[b], ring_addr(), [&](int ks) -> V { return hin[ks]; }, sd);
-        KT::stage_sync(ring.cnt);
-        ring.advance();
+        f32x16 odd = zero16();
+        auto bs = [&](int ks) -> V { return hin[ks]; };
+        // (b is a constant after unrolling; the switch only turns it into one the templates can take)
+        auto run = [&](auto b_tag) __attribute__((always_inline)) {
+          constexpr int B = decltype(b_tag)::value;
+          constexpr int G2 = stg_base(Q) + B + 2;           // the stage requested here
+          constexpr int NP2 = stage_pieces(G2);
+          if constexpr (G2 >= N_STAGES) {
+            // the next tile's first stages: nothing after the workgroup's last tile; the image restarts (next object's
+            // image after the object's last tile)
+            if constexpr (G2 == N_STAGES) { if (live) strm.set_source((const char*)a.img + next_obj * IMG_BYTES); }
+            const int cnt = live ? strm.cw[cls_of(NP2)] : 0;
+            plain_stage(std::integral_constant<int, NP2>{}, std::integral_constant<int, 16>{}, std::true_type{}, cnt, xacc[b], odd, bs);
+            xacc[b] += odd;
+            if (live) KT::template stage_sync<NW, NP2, 0>(strm.last);
+            else KT::template sync_imm<0>();
+          } else {
+            plain_stage(std::integral_constant<int, NP2>{}, std::integral_constant<int, 16>{}, std::false_type{}, strm.cw[cls_of(NP2)],
+                        xacc[b], odd, bs);
+            xacc[b] += odd;
+            KT::template stage_sync<NW, NP2, 0>(strm.last);
+          }
+          strm.template advance<NP2>();
+        };
+        if (b == 0) run(std::integral_constant<int, 0>{});
+        else if (b == 1) run(std::integral_constant<int, 1>{});
+        else run(std::integral_constant<int, 2>{});
       }
     };
     float dproj[11];
 #pragma unroll
     for (int dd = 0; dd < 11; ++dd) dproj[dd] = 0.f;
 
-    bwd_layer(std::integral_constant<int, B6>{}, std::integral_constant<int, 1>{}, 4, [&](int) -> V { return dh; });          // d hc
+    {   // B6 (ONE stage, eight one-piece blocks): d hc = W_oc^T d colour, masked by hc's ReLU bits -> hbuf, tensor 9
+      constexpr int NP2 = NP2_OF(B6, 0);
+      constexpr int CD = quota(NP2, NW);
+      const uint32_t addr = ring_addr();
+      V wa[8];
+      KT::template rd<0>(wa[0], addr); KT::template rd<PIECE>(wa[1], addr); KT::template rd<2 * PIECE>(wa[2], addr);
+      KT::template rd<3 * PIECE>(wa[3], addr); KT::template rd<4 * PIECE>(wa[4], addr); KT::template rd<5 * PIECE>(wa[5], addr);
+      KT::template rd<6 * PIECE>(wa[6], addr); KT::template rd<7 * PIECE>(wa[7], addr);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wa[0]), "+v"(wa[1]), "+v"(wa[2]), "+v"(wa[3]), "+v"(wa[4]), "+v"(wa[5]), "+v"(wa[6]), "+v"(wa[7]));
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        f32x16 c[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c[i] = Op<OT>::mfma(wa[4 * half + i], dh, zero16());
+        if (half == 0) {
+          strm.template issue<NP2, 0, false>(strm.cw[cls_of(NP2)]); strm.template issue<NP2, 1, false>(strm.cw[cls_of(NP2)]);
+          strm.template issue<NP2, 2, false>(strm.cw[cls_of(NP2)]);
+        } else {
+          strm.template issue<NP2, 3, false>(strm.cw[cls_of(NP2)]); strm.template issue<NP2, 4, false>(strm.cw[cls_of(NP2)]);
+          strm.template issue<NP2, 5, false>(strm.cw[cls_of(NP2)]);
+        }
+        static_assert(CD <= 6, "transfers of the B6 stage");
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int blk = 4 * half + i;
+          const uint32_t bits = s_mask[(4 * 4 + (blk >> 1)) * NTHR + tid] >> (8 * (blk & 1));
+          uint32_t wd[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) wd[e] = pk_mask(pk_cvt<OT>(c[i][2 * e], c[i][2 * e + 1]), (bits >> e) & 0x00010001u);
+          const uint4 u0 = make_uint4(wd[0], wd[1], wd[2], wd[3]), u1 = make_uint4(wd[4], wd[5], wd[6], wd[7]);
+          const V f0 = __builtin_bit_cast(V, u0), f1 = __builtin_bit_cast(V, u1);
+          *reinterpret_cast<V*>(hbuf + (2 * blk) * PIECE) = f0;
+          *reinterpret_cast<V*>(hbuf + (2 * blk + 1) * PIECE) = f1;
+          GV* dst = act_base(9, 2 * blk);
+          __builtin_nontemporal_store(f0, dst);
+          __builtin_nontemporal_store(f1, dst + 64);
+        }
+      }
+      KT::template stage_sync<NW, NP2, 16>(strm.last);
+      strm.template advance<NP2>();
+    }
     reload();                                                                                                                  // hin = d hc
     bwd_layer(std::integral_constant<int, B5H>{}, std::integral_constant<int, 17>{}, 3,
               [&](int ks) -> V { return ks < KS_H ? hin[ks] : dh; });                                                          // d h4
@@ -959,7 +1123,6 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
       bwd_slots(std::integral_constant<int, B1>{}, std::integral_constant<int, 3>{}, x1a);
       pe_bwd_x1(x1a);
     }
-    flush_pending();
     // d B[j][c] += d proj_j * t_c: per-lane sums, reduced over the lanes once per object (flush_object)
 #pragma unroll
     for (int dd = 0; dd < 11; ++dd) {
@@ -969,6 +1132,7 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
       dbacc[dd][1] = fmaf(dp, t1, dbacc[dd][1]);
       dbacc[dd][2] = fmaf(dp, t2, dbacc[dd][2]);
     }
+    if (++tile_i == a.ntile) { tile_i = 0; ++k_i; }
   }
   flush_object();
 #ifdef OBJ256_TIMING
@@ -1428,7 +1592,7 @@ static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 struct Plan {
   WsLay wl;
   int parts[NTYPE]; int prefix[NTYPE + 1]; long slab_prefix[NTYPE + 1];
-  size_t off_img, off_part, off_slabs, off_ws, bytes;
+  size_t off_img, off_part, off_slabs, off_ws, off_dummy, bytes;
 };
 #ifndef OBJ256_NW
 #define OBJ256_NW 4          // waves per workgroup of kernel A where the ray length allows (S <= 32 NW)
@@ -1453,6 +1617,7 @@ static Plan make_plan(int K, long n, int S) {
   p.off_part = o; o += al256((size_t)K * NWG_A * PART_FLOATS * 4);
   p.off_slabs = o; o += al256((size_t)K * p.slab_prefix[NTYPE] * 4);
   p.off_ws = o; o += al256((size_t)K * p.wl.obj_bytes);
+  p.off_dummy = o; o += al256((size_t)NWG_A * 8 * 2048);      // kernel A: parking area of the stale stores of a layer's first stage
   p.bytes = o;
   return p;
 }
@@ -1510,7 +1675,7 @@ static int run(const objnerf_net* net, const objnerf_train_args* a, hipStream_t 
   fa.pts = a->pts; fa.origins = a->origins; fa.dirs = a->dirs; fa.z = a->z;
   fa.gt_depth = a->gt_depth; fa.gt_rgb = a->gt_rgb; fa.labels = a->labels;
   fa.counts = a->counts; fa.flags = a->flags;
-  fa.img = img; fa.ws = ws; fa.part = part; fa.L = L; fa.wl = p.wl;
+  fa.img = img; fa.ws = ws; fa.dummy = base + p.off_dummy; fa.part = part; fa.L = L; fa.wl = p.wl;
 #ifdef OBJ256_ONE          // diagnostic builds: one instantiation (compile time)
   launch_fwd<OT, 128, OBJ256_NW>(fa, st);
 #else

@@ -358,7 +358,9 @@ class TrainWorkspace:
     the objects chunk by chunk -- they are independent networks, only the early-return flags span the batch."""
 
     def __init__(self, arena: ParamArena, K: int, R: int, S: int, with_feat: bool, layerwise: bool = False,
-                 budget: Optional[int] = None, precision=None):
+                 budget: Optional[int] = None, precision=None, context: Optional["StreamContext"] = None):
+        """context: a StreamContext to share (the K one-object workspaces of the forloop strategy run one after the other
+        on one stream, so one set of helper streams serves them all); None = this workspace owns one when its path uses it."""
         layerwise = layerwise or precision_bits(precision) == 4          # the fp16 mode lives on the layer-wise path
         dev = arena.params.device
         net = arena.net.c()
@@ -374,7 +376,8 @@ class TrainWorkspace:
             raise _lib.ObjnerfError("objnerf_train_workspace_bytes returned 0")
         self.nbytes = int(nbytes)
         # the layer-wise path runs independent GEMMs side by side on the context's streams
-        self.context = StreamContext(dev) if (arena.net.hidden != 32 or S > 64 or layerwise) and dev.type == "cuda" else None
+        uses_context = (arena.net.hidden != 32 or S > 64 or layerwise) and dev.type == "cuda"
+        self.context = (context if context is not None else StreamContext(dev)) if uses_context else None
         self.buf = torch.empty(self.nbytes, dtype=torch.uint8, device=dev)
         self.grads = torch.zeros_like(arena.params)
         self.loss_terms = torch.zeros(K, 4, device=dev)
@@ -382,7 +385,12 @@ class TrainWorkspace:
         self.status_chunks = torch.zeros((K + self.k_chunk - 1) // self.k_chunk, dtype=torch.int32, device=dev)
         self.counts = torch.zeros(K, 2, dtype=torch.int32, device=dev)
         self.flags = torch.zeros(2, dtype=torch.int32, device=dev)
-        self.key = (K, R, S, with_feat)
+        # (the workspace size depends on the operand precision: a loop whose precision is toggled must re-allocate)
+        self.key = self.make_key(K, R, S, with_feat, precision)
+
+    @staticmethod
+    def make_key(K, R, S, with_feat, precision=None):
+        return (K, R, S, bool(with_feat), precision_bits(precision))
 
 
 def train_step(arena: ParamArena, ws: TrainWorkspace, batch: Dict[str, torch.Tensor], color_scaling=5.0,

@@ -34,7 +34,7 @@ class BackgroundLoop:
 
     def _workspace(self, batch):
         K, R, S = batch["z"].shape
-        if self.ws is None or self.ws.key != (K, R, S, self.with_feat):
+        if self.ws is None or self.ws.key != ops.TrainWorkspace.make_key(K, R, S, self.with_feat, self.bf16):
             self.ws = ops.TrainWorkspace(self.arena, K, R, S, self.with_feat, precision=self.bf16)
             # gradient and loss terms in ONE buffer: one collective moves both
             self.flat = torch.zeros(self.arena.p_stride + 4, device=self.arena.params.device)
@@ -185,13 +185,20 @@ class HipTrainLoop:
 
     def rebuild(self):
         """utils.update_vmap for both model lists (train.py:272-276): gather the K per-object arena
-        blocks; Adam moments restart because the reference adds a fresh param group."""
+        blocks; on the vmap path the Adam moments restart because the reference adds a fresh param group of the freshly
+        stacked tensors."""
         K = len(self.trainers)
         t0 = self.trainers[0]
-        if self.strategy == "forloop":          # per-object param groups (train.py:240-251): own moments, trained in place
+        if self.strategy == "forloop":
+            # per-object param groups (train.py:240-251): each object's parameters enter the optimiser ONCE, when the
+            # object is created, and keep their Adam moments and step count when later objects arrive -- the optimiser
+            # state therefore lives on the Trainer, not on this (rebuilt) loop
             self.arena = None
-            self.opts = [optim.ArenaAdamW(t.arena, lr=self.cfg.learning_rate, weight_decay=self.cfg.weight_decay)
-                         for t in self.trainers]
+            self.opts = []
+            for t in self.trainers:
+                if getattr(t, "hip_opt", None) is None:
+                    t.hip_opt = optim.ArenaAdamW(t.arena, lr=self.cfg.learning_rate, weight_decay=self.cfg.weight_decay)
+                self.opts.append(t.hip_opt)
             for t in self.trainers:
                 t.arena.scale.fill_(float(t.obj_scale))
             self.mask = t0.arena.has_grad_mask(self.with_feat)
@@ -209,8 +216,11 @@ class HipTrainLoop:
 
     def _step_forloop(self, batch, global_flags):
         K, R, S = batch["z"].shape
-        if self.wss is None or self.wss[0].key != (1, R, S, self.with_feat):
-            self.wss = [ops.TrainWorkspace(t.arena, 1, R, S, self.with_feat, precision=self.bf16) for t in self.trainers]
+        if self.wss is None or self.wss[0].key != ops.TrainWorkspace.make_key(1, R, S, self.with_feat, self.bf16):
+            self.wss = []
+            for t in self.trainers:             # one set of helper streams for the K one-object workspaces
+                self.wss.append(ops.TrainWorkspace(t.arena, 1, R, S, self.with_feat, precision=self.bf16,
+                                                   context=self.wss[0].context if self.wss else None))
             self.loss_terms = torch.zeros(K, 4, device=batch["z"].device)
             self.status = torch.zeros(1, dtype=torch.int32, device=batch["z"].device)
             self.ws = self                      # (status holder for train_frame)
@@ -232,7 +242,7 @@ class HipTrainLoop:
         if self.strategy == "forloop":
             return self._step_forloop(batch, global_flags)
         K, R, S = batch["z"].shape
-        if self.ws is None or self.ws.key != (K, R, S, self.with_feat):
+        if self.ws is None or self.ws.key != ops.TrainWorkspace.make_key(K, R, S, self.with_feat, self.bf16):
             self.ws = ops.TrainWorkspace(self.arena, K, R, S, self.with_feat, precision=self.bf16)
         ops.train_step(self.arena, self.ws, batch, with_feat=self.with_feat, global_flags=global_flags,
                        bf16=self.bf16)

@@ -356,6 +356,45 @@ def test_forloop_strategy_equals_vmap(dev):
         assert maxerr(tv.arena.params, tf.arena.params) < 2e-6
 
 
+def test_forloop_keeps_adam_state_across_rebuilds(dev):
+    """train.py:250-251: under "forloop" an object's parameters enter the optimiser once; a rebuild of the loop (a new
+    object arrived) must not restart the existing objects' moments / step counts."""
+    c = make_cfg(dev)
+    c.training_strategy = "forloop"
+    ts = make_trainers(2, dev, 77)
+    loop = otrain.HipTrainLoop(c, ts[:1], with_feat=False)
+    b = synthetic.random_batch(2, 40, 1, 9, seed=5)
+    one = {k: T(b[k][:1]).to(dev) for k in ["pts", "z", "gt_depth", "gt_rgb", "labels"]}
+    loop.step(one)
+    loop.step(one)
+    opt0 = ts[0].hip_opt
+    assert int(opt0.group_steps[0].item()) == 2
+    loop2 = otrain.HipTrainLoop(c, ts, with_feat=False)              # the mapper restacks when object 2 appears
+    assert ts[0].hip_opt is opt0 and int(opt0.group_steps[0].item()) == 2 and float(opt0.exp_avg.abs().max()) > 0
+    both = {k: T(b[k]).to(dev) for k in ["pts", "z", "gt_depth", "gt_rgb", "labels"]}
+    loop2.step(both)
+    assert int(ts[0].hip_opt.group_steps[0].item()) == 3 and int(ts[1].hip_opt.group_steps[0].item()) == 1
+    assert loop2.wss[0].context is loop2.wss[1].context              # one set of helper streams (None on the fused path)
+
+
+def test_precision_toggle_reallocates_workspace(dev):
+    """The workspace size depends on the operand precision (hidden 256): toggling .bf16 on a live loop re-allocates
+    instead of failing with EINVAL."""
+    c = make_cfg(dev)
+    c.hidden_feature_size = 256
+    ts = make_trainers(1, dev, 9)
+    loop = otrain.HipTrainLoop(c, ts, with_feat=False, bf16="bf16")
+    b = synthetic.random_batch(1, 4096, 8, 24, seed=5)
+    batch = {k: T(b[k]).to(dev) for k in ["pts", "z", "gt_depth", "gt_rgb", "labels"]}
+    t16 = loop.step(batch).clone()
+    ws16 = loop.ws
+    loop.bf16 = False
+    t32 = loop.step(batch).clone()
+    assert loop.ws is not ws16 and loop.ws.nbytes >= ws16.nbytes
+    assert maxerr(t16, t32) < 0.05 * float(t32.abs().max())
+    torch.cuda.synchronize()
+
+
 def test_unknown_training_strategy_is_refused(dev):
     c = make_cfg(dev)
     c.training_strategy = "jit"
