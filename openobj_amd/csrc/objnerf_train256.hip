@@ -257,7 +257,7 @@ constexpr int L_HBUF = L_RING + 3 * RING_SLOT;              // per wave 16 KB: t
 __host__ __device__ constexpr int l_mask(int NW) { return L_HBUF + NW * KS_H * PIECE; }            // [5 layers][4 block pairs][threads] ReLU bits
 __host__ __device__ constexpr int l_bias(int NW) { return l_mask(NW) + 5 * 4 * NW * 64 * 4; }      // [5][8 blk][2 h][16] fp32
 __host__ __device__ constexpr int l_strip(int NW) { return l_bias(NW) + 5 * 256 * 4; }             // raw alpha | colour pre [3] per sample
-__host__ __device__ constexpr int l_small(int NW) { return l_strip(NW) + 4 * NW * 32 * 4; }        // B rows, ba, boc[3] (96 floats)
+__host__ __device__ constexpr int l_small(int NW) { return l_strip(NW) + 5 * NW * 32 * 4 + 8 * 8 * 4; }   // (+ z per sample, 8 floats per ray) B rows, ba, boc[3] (96 floats)
 __host__ __device__ constexpr int l_db(int NW) { return l_small(NW) + 96 * 4; }                    // per-wave d B [64] + loss [4]
 __host__ __device__ constexpr int l_total(int NW) { return (l_db(NW) + NW * 68 * 4 + 15) & ~15; }
 static_assert(l_total(4) <= 163840, "LDS budget");
@@ -518,6 +518,8 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
   float* s_bias = reinterpret_cast<float*>(lds + L_BIAS);
   float* s_raw = reinterpret_cast<float*>(lds + L_STRIP);
   float* s_col = s_raw + TSAMP;
+  float* s_z = s_raw + 4 * TSAMP;              // depth of every sample of the tile, staged early (compositing reads it)
+  float* s_ray = s_z + TSAMP;                  // per ray of the tile: gt depth, gt rgb, label (8 floats)
   float* s_small = reinterpret_cast<float*>(lds + L_SMALL);
   float* s_db = reinterpret_cast<float*>(lds + L_DB);
   char* hbuf = lds + L_HBUF + w * (KS_H * PIECE) + lane * 16;       // this lane's 16 bytes of fragment ks at + ks * PIECE
@@ -577,6 +579,29 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
     __syncthreads();
   };
 
+  // the sample point (and depth) of this lane in tile (k_, tile_): requested one tile ahead
+  auto load_point = [&](const int k_, const long tile_, float& px, float& py, float& pz, float& zv) __attribute__((always_inline)) {
+    const int sidx = 32 * w + s, q_ = sidx / S, si_ = sidx - q_ * S;
+    const long ray_ = tile_ * TR + q_;
+    px = py = pz = zv = 0.f;
+    if (ray_ < a.R) {
+      const long rr = (long)k_ * a.R + ray_;
+      zv = a.z[rr * S + si_];
+      if (a.pts) {
+        const float* p = a.pts + (rr * S + si_) * 3;
+        px = p[0]; py = p[1]; pz = p[2];
+      } else {
+        const float* o = a.origins + rr * 3;
+        const float* d = a.dirs + rr * 3;
+        px = (o[0] + d[0] * zv) - a.obj_center;
+        py = (o[1] + d[1] * zv) - a.obj_center;
+        pz = (o[2] + d[2] * zv) - a.obj_center;
+      }
+    }
+  };
+  float npx, npy, npz, nzv;
+  load_point(k_i, tile_i, npx, npy, npz, nzv);
+
   for (long tau = tau0; tau < tau1; ++tau) {
     const int k = k_i;                        // (the stream is at stage 0 of this tile)
     const long tile = tile_i;
@@ -618,20 +643,12 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
     const int q = st_idx / S, si = st_idx - q * S;
     const long ray = tile * TR + q;
     const bool valid = ray < a.R;
-    float px = 0.f, py = 0.f, pz = 0.f;
-    if (valid) {
+    const float px = npx, py = npy, pz = npz, z_own = nzv;      // (requested during the previous tile)
+    // per-ray targets of the tile: one lane per ray requests them now and parks them in LDS after the first layer
+    float rg0 = 0.f, rg1 = 0.f, rg2 = 0.f, rg3 = 0.f; int rlab = 2;
+    if (valid && si == 0) {
       const long rr = (long)k * a.R + ray;
-      if (a.pts) {
-        const float* p = a.pts + (rr * S + si) * 3;
-        px = p[0]; py = p[1]; pz = p[2];
-      } else {
-        const float zz = a.z[rr * S + si];
-        const float* o = a.origins + rr * 3;
-        const float* d = a.dirs + rr * 3;
-        px = (o[0] + d[0] * zz) - a.obj_center;
-        py = (o[1] + d[1] * zz) - a.obj_center;
-        pz = (o[2] + d[2] * zz) - a.obj_center;
-      }
+      rg0 = a.gt_depth[rr]; rg1 = a.gt_rgb[rr * 3]; rg2 = a.gt_rgb[rr * 3 + 1]; rg3 = a.gt_rgb[rr * 3 + 2]; rlab = a.labels[rr];
     }
     const float t0 = px / scale, t1 = py / scale, t2 = pz / scale;       // embedding.py:47
     // projections of this half's directions as revolutions (hi + lo); recomputed where needed (22 registers otherwise)
@@ -697,11 +714,11 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
     };
     auto ring_addr = [&]() __attribute__((always_inline)) -> uint32_t { return strm.rd + (uint32_t)lane * 16u; };
     // a stage without an epilogue of its own: the block's MFMAs (two chains) + the transfers; the caller ends it
-    auto plain_stage = [&](auto np2_tag, auto nk_tag, auto allc_tag, const int cnt, f32x16& acc0, f32x16& acc1, auto&& bsel)
+    auto plain_stage = [&](auto np2_tag, auto nk_tag, auto allc_tag, auto keep_tag, const int cnt, f32x16& acc0, f32x16& acc1, auto&& bsel)
         __attribute__((always_inline)) {
       constexpr int NK = decltype(nk_tag)::value;
       auto sd = [&](auto ks_tag) __attribute__((always_inline)) { dma_side(np2_tag, nk_tag, ks_tag, allc_tag, cnt); };
-      KT::template block_mma<NK, true, true>(acc0, acc1, ring_addr(), bsel, sd);
+      KT::template block_mma<NK, !decltype(keep_tag)::value, true>(acc0, acc1, ring_addr(), bsel, sd);
     };
 #define NP2_OF(Q_, BLK_) stage_pieces(stg_base(Q_) + (BLK_) + 2)
 
@@ -758,9 +775,12 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
           dma_side(np2_tag, nk_tag, ks_tag, std::false_type{}, strm.cw[cls_of(NP2)]);
           __builtin_amdgcn_sched_barrier(0);
         };
+        T256(0);
         KT::template block_mma<NK, false, true>(cur, cur1, ring_addr(), bsel, sd);
         asm volatile("" : "+v"(prv));                      // (the compiler's wait for the bias rows lands here, not in the next stage)
+        T256(1);
         KT::template stage_sync<NW, NP2, 2>(strm.last);
+        T256(2);
         strm.template advance<NP2>();
       };
       f32x16 accA, accA1 = zero16(), accB = zero16(), accB1 = zero16();
@@ -785,6 +805,11 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
     };
     // ------------------------------------------------------------------ forward
     fwd_layer(std::integral_constant<int, F1>{}, std::integral_constant<int, 6>{}, 0, [&](int ks) -> V { return x1f[ks]; });   // h1
+    {   // the loads requested at the top of the tile have landed under the first layer: park them for the compositing
+      s_z[st_idx] = z_own;
+      if (si == 0) { float* rp = s_ray + 8 * q; rp[0] = rg0; rp[1] = rg1; rp[2] = rg2; rp[3] = rg3; rp[4] = __int_as_float(rlab); }
+      if (live) load_point((int)next_obj, next_obj != k ? 0 : tile + 1, npx, npy, npz, nzv);      // the next tile's sample
+    }
     reload();
     fwd_layer(std::integral_constant<int, F2>{}, std::integral_constant<int, 16>{}, 1, [&](int ks) -> V { return hin[ks]; });  // h2
     reload();
@@ -820,7 +845,7 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
     {   // F5 block 8: row 0 = w_alpha . h4  (raw density, model.py:81)
       constexpr int NP2 = NP2_OF(F5, 8);
       f32x16 acc = zero16(), acc1 = zero16();
-      plain_stage(std::integral_constant<int, NP2>{}, std::integral_constant<int, 19>{}, std::false_type{}, strm.cw[cls_of(NP2)], acc, acc1,
+      plain_stage(std::integral_constant<int, NP2>{}, std::integral_constant<int, 19>{}, std::false_type{}, std::false_type{}, strm.cw[cls_of(NP2)], acc, acc1,
                   [&](int ks) -> V { return ks < KS_H ? hin[ks] : x2f[ks - KS_H]; });
       if (h == 0) s_raw[st_idx] = (acc[0] + acc1[0]) + ba;
       KT::template stage_sync<NW, NP2, 0>(strm.last);
@@ -830,7 +855,7 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
     {   // F6: colour head on hc (model.py:95)
       constexpr int NP2 = NP2_OF(F6, 0);
       f32x16 acc = zero16(), acc1 = zero16();
-      plain_stage(std::integral_constant<int, NP2>{}, std::integral_constant<int, 16>{}, std::false_type{}, strm.cw[cls_of(NP2)], acc, acc1,
+      plain_stage(std::integral_constant<int, NP2>{}, std::integral_constant<int, 16>{}, std::false_type{}, std::false_type{}, strm.cw[cls_of(NP2)], acc, acc1,
                   [&](int ks) -> V { return hin[ks]; });
       if (h == 0) {
         s_col[st_idx] = (acc[0] + acc1[0]) + boc0; s_col[TSAMP + st_idx] = (acc[1] + acc1[1]) + boc1;
@@ -853,7 +878,7 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
         const long rr = (long)k * a.R + (on ? rayq : 0);
         float gtd = 0.f, gr = 0.f, gg = 0.f, gb = 0.f;
         int lab = 2;
-        if (on) { gtd = a.gt_depth[rr]; gr = a.gt_rgb[rr * 3]; gg = a.gt_rgb[rr * 3 + 1]; gb = a.gt_rgb[rr * 3 + 2]; lab = a.labels[rr]; }
+        if (on) { const float* rp = s_ray + 8 * qq; gtd = rp[0]; gr = rp[1]; gg = rp[2]; gb = rp[3]; lab = __float_as_int(rp[4]); }
         float occ[SPL], fr[SPL], zz[SPL], c0[SPL], c1[SPL], c2[SPL], Tn[SPL], wgt[SPL];
         float lp = 1.0f;
 #pragma unroll
@@ -864,7 +889,7 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
           if (on) {
             al = 10.0f * s_raw[sl];                                     // model.py:88
             c0[e] = sigmoid_acc(s_col[sl]); c1[e] = sigmoid_acc(s_col[TSAMP + sl]); c2[e] = sigmoid_acc(s_col[2 * TSAMP + sl]);
-            zz[e] = a.z[rr * S + li * SPL + e];
+            zz[e] = s_z[sl];
           }
           occ[e] = on ? sigmoid_acc(al) : 0.0f;                         // render_rays.py:13
           fr[e] = on ? (1.0f - occ[e]) + 1e-10f : 1.0f;                 // :38
@@ -979,8 +1004,10 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
           dma_side(np2_tag, nk_tag, ks_tag, std::false_type{}, strm.cw[cls_of(NP2)]);
           __builtin_amdgcn_sched_barrier(0);
         };
+        T256(0);
         KT::template block_mma<NK, true, true>(cur, cur1, ring_addr(), bsel, sd);
         asm volatile("" : "+v"(mb));
+        T256(3);
         KT::template stage_sync<NW, NP2, 2>(strm.last);
         strm.template advance<NP2>();
       };
@@ -1001,7 +1028,8 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
       }
     };
     // slot-gradient blocks (d x1 / d x2): NB blocks accumulated into xacc[b]
-    auto bwd_slots = [&](auto seq_tag, auto nb_tag, f32x16* xacc) __attribute__((always_inline)) {
+    auto bwd_slots = [&](auto seq_tag, auto nb_tag, auto keep_tag, f32x16* xacc) __attribute__((always_inline)) {
+      constexpr bool KEEP = decltype(keep_tag)::value;      // the chains continue from xacc (B1 adds to B3X's d x1)
       constexpr int NB = decltype(nb_tag)::value, Q = decltype(seq_tag)::value;
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
@@ -1017,13 +1045,13 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
             // image after the object's last tile)
             if constexpr (G2 == N_STAGES) { if (live) strm.set_source((const char*)a.img + next_obj * IMG_BYTES); }
             const int cnt = live ? strm.cw[cls_of(NP2)] : 0;
-            plain_stage(std::integral_constant<int, NP2>{}, std::integral_constant<int, 16>{}, std::true_type{}, cnt, xacc[b], odd, bs);
+            plain_stage(std::integral_constant<int, NP2>{}, std::integral_constant<int, 16>{}, std::true_type{}, keep_tag, cnt, xacc[b], odd, bs);
             xacc[b] += odd;
             if (live) KT::template stage_sync<NW, NP2, 0>(strm.last);
             else KT::template sync_imm<0>();
           } else {
-            plain_stage(std::integral_constant<int, NP2>{}, std::integral_constant<int, 16>{}, std::false_type{}, strm.cw[cls_of(NP2)],
-                        xacc[b], odd, bs);
+            plain_stage(std::integral_constant<int, NP2>{}, std::integral_constant<int, 16>{}, std::false_type{}, keep_tag,
+                        strm.cw[cls_of(NP2)], xacc[b], odd, bs);
             xacc[b] += odd;
             KT::template stage_sync<NW, NP2, 0>(strm.last);
           }
@@ -1083,8 +1111,8 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
     bwd_layer(std::integral_constant<int, B5H>{}, std::integral_constant<int, 17>{}, 3,
               [&](int ks) -> V { return ks < KS_H ? hin[ks] : dh; });                                                          // d h4
     {                                                                                                                          // B5X: d x2
-      f32x16 xa[2] = {zero16(), zero16()};
-      bwd_slots(std::integral_constant<int, B5X>{}, std::integral_constant<int, 2>{}, xa);
+      f32x16 xa[2];
+      bwd_slots(std::integral_constant<int, B5X>{}, std::integral_constant<int, 2>{}, std::false_type{}, xa);
       float vh[11], vl[11];
       project(vh, vl);
 #pragma unroll
@@ -1111,16 +1139,16 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
       }
     };
     {                                                                                                                          // B3X: d x1
-      f32x16 x1a[3] = {zero16(), zero16(), zero16()};
-      bwd_slots(std::integral_constant<int, B3X>{}, std::integral_constant<int, 3>{}, x1a);
+      f32x16 x1a[3];
+      bwd_slots(std::integral_constant<int, B3X>{}, std::integral_constant<int, 3>{}, std::false_type{}, x1a);
       pe_bwd_x1(x1a);          // (the chain rule is linear in d x1: applied per contribution)
     }
     reload();                                                                                                                  // hin = d h2
     bwd_layer(std::integral_constant<int, B2>{}, std::integral_constant<int, 16>{}, 0, [&](int ks) -> V { return hin[ks]; });  // d h1
     reload();
     {                                                                                                                          // B1: d x1 +=
-      f32x16 x1a[3] = {zero16(), zero16(), zero16()};
-      bwd_slots(std::integral_constant<int, B1>{}, std::integral_constant<int, 3>{}, x1a);
+      f32x16 x1a[3];
+      bwd_slots(std::integral_constant<int, B1>{}, std::integral_constant<int, 3>{}, std::false_type{}, x1a);
       pe_bwd_x1(x1a);
     }
     // d B[j][c] += d proj_j * t_c: per-lane sums, reduced over the lanes once per object (flush_object)
@@ -1138,8 +1166,8 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
 #ifdef OBJ256_TIMING
   T256(5);
   if (blockIdx.x == 0 && tid == 0)
-    printf("t256 fwd-layer stages: issue %llu  mma %llu  epilogue %llu  sync %llu  | bwd-layer stages %llu | everything else %llu\n",
-           tm_[0], tm_[1], tm_[2], tm_[3], tm_[4], tm_[5]);
+    printf("t256 (ticks of workgroup 0, wave 0): outside layer stages %llu | fwd-layer block_mma %llu  sync %llu | bwd-layer block_mma %llu | tail %llu\n",
+           tm_[0], tm_[1], tm_[2], tm_[3], tm_[5]);
 #endif
 }
 

@@ -12,7 +12,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define S1(x) asm volatile("s_add_u32 %0, %0, 3" : "+s"(x) : : "scc")
 
 template <int MODE>
-__global__ __launch_bounds__(256) void k(int iters, float* out, unsigned long long* cyc) {
+__global__ __launch_bounds__(256) void k(int iters, float* out, unsigned long long* cyc, const char* wsrc) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x & 63;
   bf16x8 a, b;
@@ -25,7 +25,23 @@ __global__ __launch_bounds__(256) void k(int iters, float* out, unsigned long lo
   for (int i = threadIdx.x; i < 4096; i += 256) lds[i] = i;
   __syncthreads();
   const uint32_t la = (uint32_t)(uintptr_t)lds + lane * 16;
-  bf16x8 r0 = a, r1 = a;
+  bf16x8 r0 = a, r1 = a, r2 = a, r3 = a;
+  // (modes 10-13) a 1 KB piece per wave and transfer, from a 4 MB L2-resident table, like the weight ring of fwd256_kernel
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned long long sa0 = (unsigned long long)(wsrc + ((blockIdx.x * 4 + wv) & 1023) * 4096);
+  const unsigned long long sbase = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sa0 >> 32)) << 32) |
+                                   (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sa0);
+  const uint32_t dbase = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds + 32768 + wv * 4096);
+  const uint32_t vo = lane * 16;
+  typedef __attribute__((address_space(1))) const bf16x8 GV;
+  bf16x8 g0 = a;
+#define RDW(reg, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(reg) : "v"(la))
+#define WT2(x, y, n) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(x), "+v"(y))
+#define GLDS(off) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:" #off :: "s"(dbase), "v"(vo), "s"(sbase) : "memory", "m0")
+#define QUAD() do { WT2(r0, r1, 2); c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, b, c0, 0, 0, 0); RDW(r0, 0); \
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r1, b, c1, 0, 0, 0); RDW(r1, 1024); \
+                    WT2(r2, r3, 2); c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r2, b, c0, 0, 0, 0); RDW(r2, 2048); \
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r3, b, c1, 0, 0, 0); RDW(r3, 3072); } while (0)
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   for (int i = 0; i < iters; ++i) {
     if (MODE == 0) { MF(c0); MF(c0); MF(c0); MF(c0); }
@@ -49,6 +65,15 @@ __global__ __launch_bounds__(256) void k(int iters, float* out, unsigned long lo
     if (MODE == 8) { MF(c0); V1(x0); V1(x1); V1(x2); V1(x3); MF(c1); V1(x4); V1(x5); V1(x6); V1(x7); MF(c0); V1(x0); V1(x1); V1(x2); V1(x3); MF(c1); V1(x4); V1(x5); V1(x6); V1(x7); }   // 2 chains + 4 VALU
     if (MODE == 9) { MF(c0); V1(x0); V1(x1); V1(x2); V1(x3); V1(x4); V1(x5); V1(x6); V1(x7); MF(c1); V1(x0); V1(x1); V1(x2); V1(x3); V1(x4); V1(x5); V1(x6); V1(x7);
                      MF(c0); V1(x0); V1(x1); V1(x2); V1(x3); V1(x4); V1(x5); V1(x6); V1(x7); MF(c1); V1(x0); V1(x1); V1(x2); V1(x3); V1(x4); V1(x5); V1(x6); V1(x7); }                    // 2 chains + 8 VALU
+    if (MODE == 10) { QUAD(); }                                            // two chains, one ds_read_b128 per MFMA, a wait per pair
+    if (MODE == 11) { QUAD(); GLDS(0); }                                   // + one LDS-DMA piece per 4 MFMAs
+    if (MODE == 12) { QUAD(); GLDS(0); QUAD(); }                           // + one per 8 MFMAs (counted as 4 MFMAs per iteration: see main)
+    if (MODE == 13) {                                                      // + one register-staged piece per 4 MFMAs
+      QUAD();
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(g0));
+      asm volatile("ds_write_b128 %0, %1 offset:32768" :: "v"(la), "v"(g0) : "memory");
+      g0 = *(GV*)(wsrc + ((blockIdx.x * 4 + wv + i) & 1023) * 4096 + vo);
+    }
     if ((i & 255) == 255) { c0 *= 1e-3f; c1 *= 1e-3f; c2 *= 1e-3f; c3 *= 1e-3f; }
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -58,21 +83,22 @@ __global__ __launch_bounds__(256) void k(int iters, float* out, unsigned long lo
   if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
-template <int MODE> void run(const char* name, float* out, unsigned long long* cyc) {
+static char* wsrc;
+template <int MODE> void run(const char* name, float* out, unsigned long long* cyc, double mfma_per_iter = 4.0) {
   const int iters = 20000, nwg = 256;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipFuncSetAttribute((const void*)k<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
   for (int rep = 0; rep < 2; ++rep) {
     hipEventRecord(e0);
-    hipLaunchKernelGGL(k<MODE>, dim3(nwg), dim3(256), 100 * 1024, 0, iters, out, cyc);
+    hipLaunchKernelGGL(k<MODE>, dim3(nwg), dim3(256), 100 * 1024, 0, iters, out, cyc, (const char*)wsrc);
     hipEventRecord(e1); hipEventSynchronize(e1);
   }
   float ms; hipEventElapsedTime(&ms, e0, e1);
   unsigned long long h[256]; hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
   double s = 0; for (int i = 0; i < nwg; ++i) s += (double)h[i];
-  const double per = s / nwg / (4.0 * iters);
-  const double tf = 32768.0 * 4 * iters * 4 * nwg / (ms * 1e-3) / 1e12;
-  printf("%-44s %7.1f ticks / MFMA   %8.3f ms   %7.1f TFLOP/s   %6.2f ns / MFMA\n", name, per, ms, tf, ms * 1e6 / (4.0 * iters));
+  const double per = s / nwg / (mfma_per_iter * iters);
+  const double tf = 32768.0 * mfma_per_iter * iters * 4 * nwg / (ms * 1e-3) / 1e12;
+  printf("%-44s %7.1f ticks / MFMA   %8.3f ms   %7.1f TFLOP/s   %6.2f ns / MFMA\n", name, per, ms, tf, ms * 1e6 / (mfma_per_iter * iters));
   fflush(stdout);
 }
 
@@ -81,6 +107,7 @@ int main() {
   printf("start\n");
   float* out; unsigned long long* cyc;
   hipMalloc(&out, 256 * 256 * 4); hipMalloc(&cyc, 256 * 8);
+  hipMalloc(&wsrc, 4 << 20); hipMemset(wsrc, 0x11, 4 << 20);
   run<0>("one dependent chain", out, cyc);
   run<1>("two chains", out, cyc);
   run<2>("four chains", out, cyc);
@@ -91,5 +118,9 @@ int main() {
   run<7>("one chain + ds_read_b128 + counted wait", out, cyc);
   run<8>("two chains + 4 VALU per MFMA", out, cyc);
   run<9>("two chains + 8 VALU per MFMA", out, cyc);
+  run<10>("two chains + ds_read_b128 per MFMA (paired waits)", out, cyc);
+  run<11>("  + one LDS-DMA piece per 4 MFMAs", out, cyc);
+  run<12>("  + one LDS-DMA piece per 8 MFMAs", out, cyc, 8.0);
+  run<13>("  + one register-staged piece per 4 MFMAs", out, cyc);
   return 0;
 }
