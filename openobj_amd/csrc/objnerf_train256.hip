@@ -39,6 +39,7 @@ namespace obj256 {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
 
 constexpr int HID = 256, NWAVE = 8, NTHR = 512;     // (kernel B and the widest kernel A; kernel A: NW waves x 32 samples)
 constexpr int KS_H = 16, KS_X1 = 6, KS_X2 = 3;       // k-steps (16 features each) of a hidden vector, of x1, of x2
@@ -1241,7 +1242,7 @@ __device__ __forceinline__ void wgrad_task(const WgArgs& a, const char* Asrc, co
         const long sg = sgc + sgi;
         if (sg < sg1) {
           const char* src = pp < NPA ? Asrc + ((sg * NPA + pp) * 64 + lane) * 16 : Bsrc + ((sg * NPB + (pp - NPA)) * 64 + lane) * 16;
-          stg[i] = *reinterpret_cast<const uint4*>(src);
+          { const u32x4v t_ = __builtin_nontemporal_load(reinterpret_cast<const u32x4v*>(src)); stg[i] = make_uint4(t_[0], t_[1], t_[2], t_[3]); }   // streamed once
         }
       }
     }
@@ -1388,7 +1389,7 @@ __device__ __forceinline__ void wgrad_cat(const char* Asrc, const char* Hsrc, co
         else if (HEAD && p == 16) src = Hsrc + (sg * 64 + lane) * 16;
         else if (p < NP - KSX) src = Bsrc + ((sg * 16 + (p - (NP - KSX - 16))) * 64 + lane) * 16;
         else src = Xsrc + ((sg * KSX + (p - (NP - KSX))) * 64 + lane) * 16;
-        stg[i] = *reinterpret_cast<const uint4*>(src);
+        { const u32x4v t_ = __builtin_nontemporal_load(reinterpret_cast<const u32x4v*>(src)); stg[i] = make_uint4(t_[0], t_[1], t_[2], t_[3]); }   // streamed once
       }
     }
   };
