@@ -7,13 +7,13 @@ name=$1; shift
 cd "$(dirname "$0")/../openobj_amd/csrc"
 out=variants/$name
 mkdir -p $out
-FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-function"
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -Wall -Wno-unused-function"
 pids=()
 for f in objnerf_train objnerf_train32 objnerf_train_bf16 objnerf_misc objnerf_generic objnerf_helpers objnerf_train256; do
   extra=""
   [ $f = objnerf_train ] && extra="-mllvm -amdgpu-sched-strategy=max-ilp"
   [ $f = objnerf_train32 ] && extra="-mllvm -amdgpu-sched-strategy=iterative-ilp"
-  [ $f = objnerf_train256 ] && extra="-mllvm -amdgpu-mfma-vgpr-form -fno-slp-vectorize -Wno-inline-asm"
+  [ $f = objnerf_train256 ] && extra="-mllvm -amdgpu-mfma-vgpr-form -Wno-inline-asm"
   /opt/rocm/bin/hipcc $FLAGS $extra "$@" -c $f.hip -o $out/$f.o &
   pids+=($!)
 done
