@@ -687,13 +687,44 @@ __global__ __launch_bounds__(256) void pack_b_kernel(const Gemm g, OT* __restric
 }
 
 // selected for the duration of one train_step call (single host thread per device)
-static thread_local int t_bf16_operands = 0;      // 0: fp32 GEMMs, 1: bf16 operands, 2: fp16 operands
-static thread_local float t_a_scale = 1.0f;       // Gemm::a_scale of the next gemm() calls (fp16 backward)
-// per-row bias factor of the NEXT gemm() call (feature_head), reset by the caller
-static thread_local GemmGroup* t_group = nullptr;     // non-null: gemm() collects descriptors instead of launching
-static thread_local const float* t_biasrow = nullptr;
-static thread_local long t_bsbr = 0;
-static thread_local int t_sbr = 1;
+struct A2Src { const float* A2; long sam2, bsa2; int k2; };
+struct RedGroup;
+// What a GEMM call needs beyond its operands: the operand precision of the step, the step's scratch regions and the
+// one-shot modifiers of the NEXT call.  One instance per C-ABI call, on that call's stack, passed explicitly -- the
+// library keeps no state between (or beside) calls.
+struct GemmEnv {
+  int operands = 0;                 // 0: fp32 GEMMs, 1: bf16 operands, 2: fp16 operands
+  float a_scale = 1.0f;             // Gemm::a_scale of the next gemm(E, ) calls (fp16 backward)
+  GemmGroup* group = nullptr;       // non-null: gemm(E, ) collects descriptors instead of launching
+  const float* biasrow = nullptr;   // Gemm::biasrow / bsbr / sbr of the next calls
+  long bsbr = 0;
+  int sbr = 1;
+  void* packb = nullptr;            // scratch of the AFULL GEMMs' packed B images (176 KB per batch entry)
+  long packb_entries = 0;
+  // [lo, hi): the step's 16-bit activation buffers (h1 .. hc stored in the operand type) and the same for d_hc,
+  // d_h4 .. d_h1 (stored scaled by a_scale); gemm(E, ) marks every operand that lies inside (Gemm::a16 / b16 / m16 / c16)
+  const char *act16_lo = nullptr, *act16_hi = nullptr, *grad16_lo = nullptr, *grad16_hi = nullptr;
+  A2Src a2 = {nullptr, 0, 0, 0};    // second A source of the NEXT gemm(E, ) call (Gemm::A2), panel path only
+  // bump allocator over the caller's workspace region for the partial slabs of ONE step (the weight-gradient GEMMs of
+  // a step run side by side, so each has its own slab); exhausted or absent -> atomics
+  float* parts = nullptr;
+  size_t parts_cap = 0, parts_off = 0;
+  float* next_part = nullptr;       // Gemm::part / rs_part of the next gemm(E, ) call
+  float* next_rs_part = nullptr;
+  RedGroup* red_group = nullptr;    // non-null: reductions are collected (grouped launch)
+  bool in_act16(const void* p) const {
+    return (act16_lo && (const char*)p >= act16_lo && (const char*)p < act16_hi) ||
+           (grad16_lo && (const char*)p >= grad16_lo && (const char*)p < grad16_hi);
+  }
+  float* parts_alloc(size_t floats) {
+    floats = (floats + 63) / 64 * 64;
+    if (!parts || parts_off + floats > parts_cap) return nullptr;
+    float* p = parts + parts_off;
+    parts_off += floats;
+    return p;
+  }
+};
+// per-row bias factor of the NEXT gemm(E, ) call (feature_head), reset by the caller
 
 // ---- deterministic split-K: partial-tile slabs + an ordered reduction (instead of float atomics)
 #ifndef OBJ_WGRAD_TARGET
@@ -782,41 +813,13 @@ static void launch_reductions(hipStream_t st, RedGroup& rg) {
   if (rg.count) hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)rg.beg[rg.count]), dim3(256), 0, st, rg);
   rg.count = 0;
 }
-// bump allocator over the caller's workspace region for the partial slabs of ONE train_step (the weight-gradient GEMMs
-// of a step run side by side, so each has its own slab); exhausted or absent -> atomics
-static thread_local void* t_packb = nullptr;          // scratch of the AFULL GEMMs' packed B images (176 KB per batch entry)
-static thread_local long t_packb_entries = 0;
-// [lo, hi): the step's 16-bit activation buffers (h1 .. hc stored in the operand type); gemm() marks every operand that
-// lies inside (Gemm::a16 / b16 / m16 / c16)
-static thread_local const char* t_act16_lo = nullptr;
-static thread_local const char* t_act16_hi = nullptr;
-static thread_local const char* t_grad16_lo = nullptr;   // the same for d_hc, d_h4 .. d_h1 (stored scaled by a_scale)
-static thread_local const char* t_grad16_hi = nullptr;
-static bool in_act16(const void* p) {
-  return (t_act16_lo && (const char*)p >= t_act16_lo && (const char*)p < t_act16_hi) ||
-         (t_grad16_lo && (const char*)p >= t_grad16_lo && (const char*)p < t_grad16_hi);
-}
-struct A2Src { const float* A2; long sam2, bsa2; int k2; };
-static thread_local A2Src t_a2 = {nullptr, 0, 0, 0};  // second A source of the NEXT gemm() call (Gemm::A2), panel path only
 // the layer GEMMs the resident-panel kernel takes (16-bit modes, rows k-contiguous, contraction <= 352, N <= 256)
-static bool panel_ok(int M, int N, int Kd, long sak, int splitk, bool rowsum, int nz) {
-  return OBJ_G16_AFULL && t_bf16_operands && sak == 1 && Kd <= 352 && N <= 256 && splitk <= 1 && M >= 4096 && !rowsum &&
-         t_packb && nz <= t_packb_entries;
-}
-static thread_local float* t_parts = nullptr;
-static thread_local size_t t_parts_cap = 0, t_parts_off = 0;
-static thread_local float* t_next_part = nullptr;       // Gemm::part / rs_part of the next gemm() call
-static thread_local float* t_next_rs_part = nullptr;
-static thread_local RedGroup* t_red_group = nullptr;    // non-null: reductions are collected (grouped launch)
-static float* parts_alloc(size_t floats) {
-  floats = (floats + 63) / 64 * 64;
-  if (!t_parts || t_parts_off + floats > t_parts_cap) return nullptr;
-  float* p = t_parts + t_parts_off;
-  t_parts_off += floats;
-  return p;
+static bool panel_ok(const GemmEnv& E, int M, int N, int Kd, long sak, int splitk, bool rowsum, int nz) {
+  return OBJ_G16_AFULL && E.operands && sak == 1 && Kd <= 352 && N <= 256 && splitk <= 1 && M >= 4096 && !rowsum &&
+         E.packb && nz <= E.packb_entries;
 }
 
-static void gemm(hipStream_t st, int batch, int M, int N, int Kd, const float* A, long sam, long sak, long bsa,
+static void gemm(GemmEnv& E, hipStream_t st, int batch, int M, int N, int Kd, const float* A, long sam, long sak, long bsa,
                  const float* B, long sbk, long sbn, long bsb, float* C, long scm, long scn, long bsc,
                  bool accumulate = false, const float* bias = nullptr, long bsbias = 0, bool relu = false,
                  const float* mask = nullptr, long smm = 0, long smn = 0, long bsm = 0, int splitk = 1,
@@ -829,42 +832,42 @@ static void gemm(hipStream_t st, int batch, int M, int N, int Kd, const float* A
   g.bias = bias; g.bsbias = bsbias; g.mask = mask; g.smm = smm; g.smn = smn; g.bsm = bsm;
   g.accumulate = accumulate; g.relu = relu; g.splitk = splitk;
   g.rowsum = rowsum; g.bsrs = bsrs;
-  g.biasrow = t_biasrow; g.bsbr = t_bsbr; g.sbr = t_sbr;
+  g.biasrow = E.biasrow; g.bsbr = E.bsbr; g.sbr = E.sbr;
   g.vec4 = 0; g.Bp = nullptr; g.A2 = nullptr; g.sam2 = g.bsa2 = 0; g.k2 = Kd;
-  g.a16 = in_act16(A); g.b16 = in_act16(B); g.m16 = mask && in_act16(mask); g.c16 = in_act16(C);
-  g.a_scale = t_bf16_operands == 2 ? t_a_scale : 1.0f;
-  g.part = t_next_part; g.rs_part = t_next_rs_part;
-  t_next_part = t_next_rs_part = nullptr;
+  g.a16 = E.in_act16(A); g.b16 = E.in_act16(B); g.m16 = mask && E.in_act16(mask); g.c16 = E.in_act16(C);
+  g.a_scale = E.operands == 2 ? E.a_scale : 1.0f;
+  g.part = E.next_part; g.rs_part = E.next_rs_part;
+  E.next_part = E.next_rs_part = nullptr;
   const int nz = batch * (splitk > 1 ? splitk : 1);
-  if (t_group && !t_bf16_operands && !(M >= 256 && N >= 192) && t_group->count < GemmGroup::MAXG) {
-    GemmGroup& gr = *t_group;               // collected; launched by flush_group()
+  if (E.group && !E.operands && !(M >= 256 && N >= 192) && E.group->count < GemmGroup::MAXG) {
+    GemmGroup& gr = *E.group;               // collected; launched by flush_group(E, )
     if (gr.count == 0) gr.zbeg[0] = 0;
     gr.g[gr.count] = g;
     gr.zbeg[gr.count + 1] = gr.zbeg[gr.count] + nz;
     ++gr.count;
     return;
   }
-  if (t_bf16_operands) {
+  if (E.operands) {
     // operands whose rows are the contiguous dimension are staged k-major (exec is full at the transposing reads:
     // out-of-range elements are zero-filled, never masked)
     const bool akm = sak != 1 && sam == 1, bkm = sbk != 1 && sbn == 1;
     // (split-K weight gradients with a narrow output -- the x1 / x2 columns of the concatenated layers, N = 87 / 42 --
     // take the 128-row tile too: the streamed d_out^T operand is then read once instead of once per 64-row tile)
-    const bool wide = M >= 256 && (N >= 192 || (OBJ_G16_WIDE_NARROW && akm && splitk > 1 && N >= 40)), f16 = t_bf16_operands == 2;
+    const bool wide = M >= 256 && (N >= 192 || (OBJ_G16_WIDE_NARROW && akm && splitk > 1 && N >= 40)), f16 = E.operands == 2;
     const dim3 grid(wide ? (N + 127) / 128 : (N + 63) / 64, wide ? (M + 127) / 128 : (M + 63) / 64, nz);
     // layer GEMMs over the sample axis: resident A panel (64 rows x the whole contraction), 64 x 256 tiles
-    if (panel_ok(M, N, Kd, sak, splitk, rowsum != nullptr, nz) && (wide || (OBJ_G16_AFULL_NARROW && Kd >= 128))) {
-      const int ka = t_a2.A2 ? t_a2.k2 : Kd;
-      g.A2 = t_a2.A2 ? t_a2.A2 : A; g.sam2 = t_a2.sam2; g.bsa2 = t_a2.bsa2; g.k2 = ka;
-      t_a2.A2 = nullptr;
+    if (panel_ok(E, M, N, Kd, sak, splitk, rowsum != nullptr, nz) && (wide || (OBJ_G16_AFULL_NARROW && Kd >= 128))) {
+      const int ka = E.a2.A2 ? E.a2.k2 : Kd;
+      g.A2 = E.a2.A2 ? E.a2.A2 : A; g.sam2 = E.a2.sam2; g.bsa2 = E.a2.bsa2; g.k2 = ka;
+      E.a2.A2 = nullptr;
       g.vec4 = (ka % 8 == 0 && sam % 8 == 0 && bsa % 8 == 0 && ((uintptr_t)A & 15) == 0) ? 1 : 0;
       if (g.a16 && !g.vec4) { fprintf(stderr, "objnerf: 16-bit activation panel needs aligned rows\n"); abort(); }
       if (g.c16 && g.b16) { fprintf(stderr, "objnerf: unsupported 16-bit GEMM operands\n"); abort(); }
-      g.Bp = t_packb;
+      g.Bp = E.packb;
       const dim3 pgrid(1, (M + 63) / 64, nz);
 #define OBJ_G16_PANEL(OT_, KM_)                                                                                         \
       do {                                                                                                              \
-        hipLaunchKernelGGL((pack_b_kernel<OT_, KM_ / 32>), dim3(KM_ / 8, nz), dim3(256), 0, st, g, (OT_*)t_packb);      \
+        hipLaunchKernelGGL((pack_b_kernel<OT_, KM_ / 32>), dim3(KM_ / 8, nz), dim3(256), 0, st, g, (OT_*)E.packb);      \
         hipLaunchKernelGGL((gemm_bf16_kernel<2, 4, OT_, 32, 2, 4, false, false, true, KM_>), pgrid, dim3(512), 0, st, g); \
       } while (0)
       if (Kd <= 256) { if (f16) OBJ_G16_PANEL(_Float16, 256); else OBJ_G16_PANEL(__bf16, 256); }
@@ -872,7 +875,7 @@ static void gemm(hipStream_t st, int batch, int M, int N, int Kd, const float* A
 #undef OBJ_G16_PANEL
       return;
     }
-    t_a2.A2 = nullptr;
+    E.a2.A2 = nullptr;
     g.vec4 = (akm && sak % 4 == 0 && bsa % 4 == 0 && M % 4 == 0 && ((uintptr_t)A & 15) == 0) ? 1 : 0;
     if ((g.a16 && !(akm && g.vec4)) || g.c16 || (g.b16 && !(bkm && sbk % 4 == 0 && N % 4 == 0 && bsb % 4 == 0))) {
       fprintf(stderr, "objnerf: 16-bit activations in a GEMM shape that does not take them\n");
@@ -910,24 +913,24 @@ static void gemm(hipStream_t st, int batch, int M, int N, int Kd, const float* A
 
 // weight gradient: C[M][N] += sum over the n samples; few output tiles, long contraction -> split-K + atomics.
 // bias_grad (optional, pre-zeroed like C): [M] column sums of the output-gradient operand, same pass.
-static void wgrad(hipStream_t st, int batch, int M, int N, long n, const float* A, long sam, long sak, long bsa,
+static void wgrad(GemmEnv& E, hipStream_t st, int batch, int M, int N, long n, const float* A, long sam, long sak, long bsa,
                   const float* B, long sbk, long sbn, long bsb, float* C, long scm, long bsc,
                   float* bias_grad = nullptr) {
   const int sk = wgrad_slices(batch, M, N, n);
 #ifndef OBJ_WGRAD_ATOMICS
   // deterministic form: every slice stores its partial tile; an ordered reduction follows
   const int skd = sk;
-  float* part = parts_alloc((size_t)batch * skd * M * N);
-  float* rs_part = (part && bias_grad) ? parts_alloc((size_t)batch * skd * M) : nullptr;
+  float* part = E.parts_alloc((size_t)batch * skd * M * N);
+  float* rs_part = (part && bias_grad) ? E.parts_alloc((size_t)batch * skd * M) : nullptr;
   if (part && (!bias_grad || rs_part)) {
-    t_next_part = part; t_next_rs_part = rs_part;
-    gemm(st, batch, M, N, (int)n, A, sam, sak, bsa, B, sbk, sbn, bsb, C, scm, 1, bsc, false, nullptr, 0, false, nullptr, 0,
+    E.next_part = part; E.next_rs_part = rs_part;
+    gemm(E, st, batch, M, N, (int)n, A, sam, sak, bsa, B, sbk, sbn, bsb, C, scm, 1, bsc, false, nullptr, 0, false, nullptr, 0,
          0, 0, skd, bias_grad, bsc);
     RedItem r;
     r.part = part; r.rs_part = rs_part; r.C = C; r.rowsum = bias_grad;
     r.M = M; r.N = N; r.sk = skd; r.batch = batch; r.scm = scm; r.bsc = bsc; r.bsrs = bsc;
-    if (t_red_group && t_red_group->count < RedGroup::MAXG) {
-      red_append(*t_red_group, r);
+    if (E.red_group && E.red_group->count < RedGroup::MAXG) {
+      red_append(*E.red_group, r);
     } else {
       RedGroup rg;
       rg.count = 1; rg.beg[0] = 0; rg.beg[1] = red_blocks(r); rg.it[0] = r;
@@ -936,7 +939,7 @@ static void wgrad(hipStream_t st, int batch, int M, int N, long n, const float* 
     return;
   }
 #endif
-  gemm(st, batch, M, N, (int)n, A, sam, sak, bsa, B, sbk, sbn, bsb, C, scm, 1, bsc, false, nullptr, 0, false, nullptr, 0,
+  gemm(E, st, batch, M, N, (int)n, A, sam, sak, bsa, B, sbk, sbn, bsb, C, scm, 1, bsc, false, nullptr, 0, false, nullptr, 0,
        0, 0, sk, bias_grad, bsc);
 }
 
@@ -1442,7 +1445,7 @@ static void launch_fwd_small(hipStream_t st, const FwdSmall& f, int K, bool bf) 
 
 // row tiles per workgroup: the smallest RT for which K * ceil(n / (16 RT)) workgroups fit the chip in one round;
 // 0 = not a small batch
-static int small_batch_rt(int H, long n, int K) {
+static int small_batch_rt(const GemmEnv& E, int H, long n, int K) {
   if (H != FS_H) return 0;
   for (int rt = 1; rt <= 5; ++rt)
     if ((long)K * ((n + 16 * rt - 1) / (16 * rt)) <= 256) return rt;
@@ -1450,15 +1453,15 @@ static int small_batch_rt(int H, long n, int K) {
   // step, 38 400: 0.53 vs 0.65); beyond that the GEMM path runs near the MFMA peak
   // (fp32 and bf16 modes: the one-launch kernels exist for both; fp16 keeps the GEMM path from two rounds on)
 #ifdef OBJ_NO_SMALL_BF16        // diagnostic: the bf16 mode on the GEMM path from two rounds on (tools/bg_ab.py)
-  if (t_bf16_operands == 0 && (long)K * ((n + 79) / 80) <= 1024) return 5;
+  if (E.operands == 0 && (long)K * ((n + 79) / 80) <= 1024) return 5;
 #else
-  if (t_bf16_operands != 2 && (long)K * ((n + 79) / 80) <= 1024) return 5;
+  if (E.operands != 2 && (long)K * ((n + 79) / 80) <= 1024) return 5;
 #endif
   return 0;
 }
 
-static void flush_group(hipStream_t st, GemmGroup& gr) {
-  t_group = nullptr;
+static void flush_group(GemmEnv& E, hipStream_t st, GemmGroup& gr) {
+  E.group = nullptr;
   if (gr.count == 0) return;
   int mx = 1, my = 1;
   for (int i = 0; i < gr.count; ++i) {
@@ -1467,7 +1470,7 @@ static void flush_group(hipStream_t st, GemmGroup& gr) {
   }
   hipLaunchKernelGGL(gemm_group_kernel, dim3((mx + 1) / 2, (my + 1) / 2, gr.zbeg[gr.count]), dim3(512), 0, st, gr);
   gr.count = 0;
-  t_red_group = nullptr;                 // (the caller launches the collected reductions: launch_reductions)
+  E.red_group = nullptr;                 // (the caller launches the collected reductions: launch_reductions)
 }
 
 
@@ -1787,7 +1790,7 @@ struct WS {
   float *emb, *h1, *h2, *h3, *h4, *hc, *hf, *alpha, *color, *d_alpha, *d_color, *dhead;
   float *d_hf, *rayin, *gram, *rayfeat, *X1, *X2, *Tm, *mom;      // feature branch (hoisted head)
   float *dA, *dB_, *dC, *dD, *dE, *d_emb, *dBpe, *pts;
-  float* parts; size_t parts_floats;      // split-K partial slabs of the step's weight-gradient GEMMs (wgrad())
+  float* parts; size_t parts_floats;      // split-K partial slabs of the step's weight-gradient GEMMs (wgrad(E, ))
   float* loss_part;                       // [K R][4] block partials of the loss terms
   float* packb;                           // [K][90112] 16-bit: packed B image of the AFULL layer GEMM in flight
   size_t act_floats;                      // room of each of h1 .. hc (floats)
@@ -1823,7 +1826,7 @@ static WS carve(char* base, int H, int C, long n, long R, int K, bool feat, bool
   w.dBpe = take((size_t)K * 64);
   w.pts = take((size_t)K * n * 3);          // sample positions of the origins / directions form of the batch
   {
-    // every weight-gradient GEMM of the step with its own slice count (wgrad()): (M, N, samples, has bias)
+    // every weight-gradient GEMM of the step with its own slice count (wgrad(E, )): (M, N, samples, has bias)
     const size_t XC = (size_t)H + 1, Hs = (size_t)H;
     size_t tot = 0;
     auto add = [&](int M, int N, long ns, bool bias) {
@@ -1905,10 +1908,6 @@ extern "C" int objnerf_context_destroy(objnerf_context* c) {
 namespace objgen {
 namespace {
 typedef objnerf_context Side;
-struct Bf16Scope {
-  explicit Bf16Scope(int operands) { t_bf16_operands = operands; t_a_scale = 1.0f; }
-  ~Bf16Scope() { t_bf16_operands = 0; t_a_scale = 1.0f; }
-};
 }  // namespace
 
 // test hook (objnerf_train_args.relu_masks): one thread per (object, sample, byte of 8 features)
@@ -1939,7 +1938,8 @@ __global__ void form_points_kernel(long total, int S, const float* origins, cons
 int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* stream) {
   objnerf_train_args a_local = *a_in;
   const objnerf_train_args* a = &a_local;
-  const Bf16Scope bf16_scope((a->mode & OBJNERF_TRAIN_FP16) ? 2 : (a->mode & OBJNERF_TRAIN_BF16) ? 1 : 0);
+  GemmEnv E;                                   // this call's GEMM environment (nothing outlives the call)
+  E.operands = (a->mode & OBJNERF_TRAIN_FP16) ? 2 : (a->mode & OBJNERF_TRAIN_BF16) ? 1 : 0;
   const int H = net->hidden, C = net->feat_dim, K = a->K;
   if (H % 32 != 0 || net->n_freqs != 6) return OBJNERF_ENOTSUP;
   const bool feat = a->gt_feat != nullptr;
@@ -1951,16 +1951,10 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
   const bool half_acts = (a->mode & (OBJNERF_TRAIN_FP16 | OBJNERF_TRAIN_BF16)) != 0 && acts16_shape(H, n);
   WS w = carve((char*)a->workspace, H, C, n, (long)a->R, K, feat, half_acts);
   if (a->workspace_bytes < w.bytes) return OBJNERF_EINVAL;
-  t_parts = w.parts; t_parts_cap = w.parts_floats; t_parts_off = 0;
-  t_packb = w.packb; t_packb_entries = w.packb ? K : 0;
+  E.parts = w.parts; E.parts_cap = w.parts_floats; E.parts_off = 0;
+  E.packb = w.packb; E.packb_entries = w.packb ? K : 0;
   RedGroup step_red;                 // small-batch path: every ordered reduction of the step in ONE launch, after the join
   step_red.count = 0;
-  struct PartsScope {
-    ~PartsScope() {
-      t_parts = nullptr; t_parts_cap = t_parts_off = 0; t_red_group = nullptr; t_packb = nullptr; t_packb_entries = 0;
-      t_act16_lo = t_act16_hi = t_grad16_lo = t_grad16_hi = nullptr;
-    }
-  } parts_scope;
   if (!a->pts) {
     const long total = (long)K * n;
     hipLaunchKernelGGL(form_points_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, a->S, a->origins,
@@ -2001,9 +1995,9 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
     // None of it depends on the forward pass: side stream, joined before the loss.
     const long R = a->R;
     const long gst = (long)H * H + H + 1;
-    gemm(ss, K, H, H, C, P + off[16], 1, H, ps, P + off[16], H, 1, ps, w.gram, H, 1, gst);
+    gemm(E, ss, K, H, H, C, P + off[16], 1, H, ps, P + off[16], H, 1, ps, w.gram, H, 1, gst);
     hipLaunchKernelGGL(featg_wb_kernel, dim3(H + 1, K), dim3(64), 0, ss, P, ps, (int)off[16], (int)off[17], C, H, w.gram, gst);
-    gemm(ss, K, (int)R, H, C, a->gt_feat, C, 1, R * C, P + off[16], H, 1, ps, w.rayin, H + 2, 1, R * (H + 2));
+    gemm(E, ss, K, (int)R, H, C, a->gt_feat, C, 1, R * C, P + off[16], H, 1, ps, w.rayin, H + 2, 1, R * (H + 2));
     hipLaunchKernelGGL(featg_rowstats_kernel, dim3((unsigned)((R + 15) / 16), K), dim3(256), 0, ss, P, ps, (int)off[17], C,
                        (int)R, H + 2, a->gt_feat, w.rayin);
     if (multi) (void)hipEventRecord(sd.done, ss);
@@ -2014,19 +2008,19 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
   if (rc) return rc;
   dim3 eg((unsigned)((n + 15) / 16), (unsigned)K);      // 16 lanes per sample row
   const size_t head_lds = (size_t)4 * H * sizeof(float);
-  const int small_rt = small_batch_rt(H, n, K);
+  const int small_rt = small_batch_rt(E, H, n, K);
   // the small-batch kernels come in fp32 and bf16-MFMA form (fp16 mode: fp32 there); their weight-gradient GEMMs stay
   // fp32 (one grouped launch)
-  const bool small_bf = small_rt && t_bf16_operands == 1;
-  if (small_rt) t_bf16_operands = 0;
+  const bool small_bf = small_rt && E.operands == 1;
+  if (small_rt) E.operands = 0;
   // 16-bit modes at hidden 256 (configs[4]): h1 .. hc live in the operand type -- written by the forward GEMMs'
   // epilogues, read as panels / masks / weight-gradient operands and by the head kernels (act_ld).  Their buffers keep
-  // the fp32 spacing in the workspace; gemm() recognises them by address.
-  const int act16 = half_acts ? t_bf16_operands : 0;
-  if (act16 && !panel_ok((int)n, H, H + E1, 1, 1, false, K)) return OBJNERF_EINVAL;      // (cannot happen: same conditions)
+  // the fp32 spacing in the workspace; gemm(E, ) recognises them by address.
+  const int act16 = half_acts ? E.operands : 0;
+  if (act16 && !panel_ok(E, (int)n, H, H + E1, 1, 1, false, K)) return OBJNERF_EINVAL;      // (cannot happen: same conditions)
   if (act16) {
-    t_act16_lo = (const char*)w.h1; t_act16_hi = (const char*)(w.hc + w.act_floats);
-    t_grad16_lo = (const char*)w.dA; t_grad16_hi = (const char*)(w.dE + w.act_floats);
+    E.act16_lo = (const char*)w.h1; E.act16_hi = (const char*)(w.hc + w.act_floats);
+    E.grad16_lo = (const char*)w.dA; E.grad16_hi = (const char*)(w.dE + w.act_floats);
   }
   if (small_rt) {
     FwdSmall f;
@@ -2046,33 +2040,33 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
     }
   } else {
   // h1 = relu(x1 W_in^T + b)
-  gemm(st, K, n, H, E1, w.emb, EM, 1, n * EM, P + off[0], 1, E1, ps, w.h1, H, 1, nH, false, P + off[1], ps, true);
-  gemm(st, K, n, H, H, w.h1, H, 1, nH, P + off[2], 1, H, ps, w.h2, H, 1, nH, false, P + off[3], ps, true);
+  gemm(E, st, K, n, H, E1, w.emb, EM, 1, n * EM, P + off[0], 1, E1, ps, w.h1, H, 1, nH, false, P + off[1], ps, true);
+  gemm(E, st, K, n, H, H, w.h1, H, 1, nH, P + off[2], 1, H, ps, w.h2, H, 1, nH, false, P + off[3], ps, true);
   // h3 = relu([h2 | x1] W_cat^T + b)
   // ([h2 | x1] as ONE contraction when the resident-panel kernel takes it: no round trip of the partial result)
-  const bool fuse2 = panel_ok((int)n, H, H + E1, 1, 1, false, K) && H == 256;
+  const bool fuse2 = panel_ok(E, (int)n, H, H + E1, 1, 1, false, K) && H == 256;
   if (fuse2) {
-    t_a2 = A2Src{w.emb, EM, n * EM, H};
-    gemm(st, K, n, H, H + E1, w.h2, H, 1, nH, P + off[4], 1, H + E1, ps, w.h3, H, 1, nH, false, P + off[5], ps, true);
+    E.a2 = A2Src{w.emb, EM, n * EM, H};
+    gemm(E, st, K, n, H, H + E1, w.h2, H, 1, nH, P + off[4], 1, H + E1, ps, w.h3, H, 1, nH, false, P + off[5], ps, true);
   } else {
-  gemm(st, K, n, H, H, w.h2, H, 1, nH, P + off[4], 1, H + E1, ps, w.h3, H, 1, nH);
-  gemm(st, K, n, H, E1, w.emb, EM, 1, n * EM, P + off[4] + H, 1, H + E1, ps, w.h3, H, 1, nH, true, P + off[5], ps, true);
+  gemm(E, st, K, n, H, H, w.h2, H, 1, nH, P + off[4], 1, H + E1, ps, w.h3, H, 1, nH);
+  gemm(E, st, K, n, H, E1, w.emb, EM, 1, n * EM, P + off[4] + H, 1, H + E1, ps, w.h3, H, 1, nH, true, P + off[5], ps, true);
   }
-  gemm(st, K, n, H, H, w.h3, H, 1, nH, P + off[6], 1, H, ps, w.h4, H, 1, nH, false, P + off[7], ps, true);
+  gemm(E, st, K, n, H, H, w.h3, H, 1, nH, P + off[6], 1, H, ps, w.h4, H, 1, nH, false, P + off[7], ps, true);
   // hc = relu([h4 | x2] W_cl^T + b)
   if (fuse2) {
-    t_a2 = A2Src{w.emb + E1, EM, n * EM, H};
-    gemm(st, K, n, H, H + E2, w.h4, H, 1, nH, P + off[10], 1, H + E2, ps, w.hc, H, 1, nH, false, P + off[11], ps, true);
+    E.a2 = A2Src{w.emb + E1, EM, n * EM, H};
+    gemm(E, st, K, n, H, H + E2, w.h4, H, 1, nH, P + off[10], 1, H + E2, ps, w.hc, H, 1, nH, false, P + off[11], ps, true);
   } else {
-  gemm(st, K, n, H, H, w.h4, H, 1, nH, P + off[10], 1, H + E2, ps, w.hc, H, 1, nH);
-  gemm(st, K, n, H, E2, w.emb + E1, EM, 1, n * EM, P + off[10] + H, 1, H + E2, ps, w.hc, H, 1, nH, true, P + off[11], ps,
+  gemm(E, st, K, n, H, H, w.h4, H, 1, nH, P + off[10], 1, H + E2, ps, w.hc, H, 1, nH);
+  gemm(E, st, K, n, H, E2, w.emb + E1, EM, 1, n * EM, P + off[10] + H, 1, H + E2, ps, w.hc, H, 1, nH, true, P + off[11], ps,
        true);
   }
   hipLaunchKernelGGL(heads_fwd_kernel, eg, dim3(256), head_lds, st, H, n, w.h4, w.hc, P, ps, (int)off[8], (int)off[9],
                      (int)off[12], (int)off[13], w.alpha, w.color, act16);
   if (feat) {
-    gemm(st, K, n, H, H, w.h4, H, 1, nH, P + off[14], 1, H + E2, ps, w.hf, H, 1, nH);
-    gemm(st, K, n, H, E2, w.emb + E1, EM, 1, n * EM, P + off[14] + H, 1, H + E2, ps, w.hf, H, 1, nH, true, P + off[15],
+    gemm(E, st, K, n, H, H, w.h4, H, 1, nH, P + off[14], 1, H + E2, ps, w.hf, H, 1, nH);
+    gemm(E, st, K, n, H, E2, w.emb + E1, EM, 1, n * EM, P + off[14] + H, 1, H + E2, ps, w.hf, H, 1, nH, true, P + off[15],
          ps, true);
   }
   }
@@ -2107,7 +2101,7 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
   // (loss scale) / R per ray times a per-sample weight -- mostly below fp16's smallest normal number (6.1e-5) -- so A is
   // scaled by ~8 R (a power of two: exact) before rounding and the product scaled back (Gemm::a_scale).
   const float grad_scale = exp2f(floorf(log2f((float)a->R)) + 3.0f);
-  t_a_scale = grad_scale;
+  E.a_scale = grad_scale;
   int rr = 0;
   auto side = [&]() -> hipStream_t {        // stream of the next independent weight-gradient GEMM
     hipStream_t r = sd.all[rr];
@@ -2126,8 +2120,8 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
   // (every bias gradient rides on its layer's weight-gradient GEMM: row sums of the d-output operand tile)
   fork();
   if (H > 256) {
-    wgrad(ss, K, 1, H, n, w.dhead, 1, 4, n * 4, w.h4, H, 1, nH, G + off[8], H, ps, G + off[9]);
-    wgrad(ss, K, 3, H, n, w.dhead + 1, 1, 4, n * 4, w.hc, H, 1, nH, G + off[12], H, ps, G + off[13]);
+    wgrad(E, ss, K, 1, H, n, w.dhead, 1, 4, n * 4, w.h4, H, 1, nH, G + off[8], H, ps, G + off[9]);
+    wgrad(E, ss, K, 3, H, n, w.dhead + 1, 1, 4, n * 4, w.hc, H, 1, nH, G + off[12], H, ps, G + off[13]);
   } else {
     // 64 samples per block (32 iterations of a 2-row pass at H = 128): the loop is a chain of load latencies, so the
     // reduction wants many short blocks (512 samples per block: 183 us for the background batch; now ~25 us)
@@ -2135,8 +2129,8 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
     const int cap = (2048 + K - 1) / K;
     if (hb > cap) hb = cap;
     // block partials + an ordered reduction (reduce_parts_kernel: "GEMMs" of M = 1 / 3 rows with hb slices)
-    float* pA = parts_alloc((size_t)K * hb * H), *pW = parts_alloc((size_t)K * hb * 3 * H);
-    float* rA = parts_alloc((size_t)K * hb), *rW = parts_alloc((size_t)K * hb * 3);
+    float* pA = E.parts_alloc((size_t)K * hb * H), *pW = E.parts_alloc((size_t)K * hb * 3 * H);
+    float* rA = E.parts_alloc((size_t)K * hb), *rW = E.parts_alloc((size_t)K * hb * 3);
     if (!(pA && pW && rA && rW)) pA = pW = rA = rW = nullptr;        // no scratch: float atomics
     hipLaunchKernelGGL(head_wgrad_kernel, dim3((unsigned)hb, (unsigned)K), dim3(256), 0, ss, H, n, w.dhead, w.h4, w.hc, G, ps,
                        (int)off[8], (int)off[9], (int)off[12], (int)off[13], pA, pW, rA, rW, act16);
@@ -2168,18 +2162,18 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
     hipLaunchKernelGGL(featg_scale_kernel, dim3((unsigned)((nr * XC + 255) / 256)), dim3(256), 0, ss, nr, H, w.rayfeat, w.X1,
                        w.X2);
     (void)hipMemsetAsync(w.Tm, 0, ((size_t)K * C * XC + (size_t)K * XC * XC) * 4, ss);
-    t_a_scale = 1.0f;                       // (targets and moments of the feature head: not gradients)
-    wgrad(ss, K, C, XC, R, a->gt_feat, 1, C, R * C, w.X1, XC, 1, R * XC, w.Tm, XC, (long)C * XC);
-    wgrad(ss, K, XC, XC, R, w.X2, 1, XC, R * XC, w.rayfeat, H + 3, 1, R * (H + 3), w.mom, XC, (long)XC * XC);
-    t_a_scale = grad_scale;
+    E.a_scale = 1.0f;                       // (targets and moments of the feature head: not gradients)
+    wgrad(E, ss, K, C, XC, R, a->gt_feat, 1, C, R * C, w.X1, XC, 1, R * XC, w.Tm, XC, (long)C * XC);
+    wgrad(E, ss, K, XC, XC, R, w.X2, 1, XC, R * XC, w.rayfeat, H + 3, 1, R * (H + 3), w.mom, XC, (long)XC * XC);
+    E.a_scale = grad_scale;
     hipLaunchKernelGGL(featg_finish_kernel, dim3((unsigned)(((long)C * XC + 255) / 256), K), dim3(256), 0, ss, P, ps,
                        (int)off[16], (int)off[17], C, H, w.Tm, w.mom, G);
     // feature layer: grads + contributions to d_h4 / d_x2
     if (!small_rt) {
-      wgrad(ss, K, H, H, n, d_hf, 1, H, nH, w.h4, H, 1, nH, G + off[14], H + E2, ps, G + off[15]);
-      wgrad(ss, K, H, E2, n, d_hf, 1, H, nH, w.emb + E1, EM, 1, n * EM, G + off[14] + H, H + E2, ps);
-      gemm(st, K, n, H, H, d_hf, H, 1, nH, P + off[14], H + E2, 1, ps, d_h4, H, 1, nH, true);
-      gemm(st, K, n, E2, H, d_hf, H, 1, nH, P + off[14] + H, H + E2, 1, ps, w.d_emb + E1, EM, 1, n * EM, false);
+      wgrad(E, ss, K, H, H, n, d_hf, 1, H, nH, w.h4, H, 1, nH, G + off[14], H + E2, ps, G + off[15]);
+      wgrad(E, ss, K, H, E2, n, d_hf, 1, H, nH, w.emb + E1, EM, 1, n * EM, G + off[14] + H, H + E2, ps);
+      gemm(E, st, K, n, H, H, d_hf, H, 1, nH, P + off[14], H + E2, 1, ps, d_h4, H, 1, nH, true);
+      gemm(E, st, K, n, E2, H, d_hf, H, 1, nH, P + off[14] + H, H + E2, 1, ps, w.d_emb + E1, EM, 1, n * EM, false);
     }
   }
   float* d_h3 = w.dC;
@@ -2204,59 +2198,59 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
     fork();
     GemmGroup group;
     group.count = 0;
-    t_group = &group;
-    t_red_group = &step_red;
+    E.group = &group;
+    E.red_group = &step_red;
     if (feat) {
-      wgrad(side(), K, H, H, n, w.d_hf, 1, H, nH, w.h4, H, 1, nH, G + off[14], H + E2, ps, G + off[15]);
-      wgrad(side(), K, H, E2, n, w.d_hf, 1, H, nH, w.emb + E1, EM, 1, n * EM, G + off[14] + H, H + E2, ps);
+      wgrad(E, side(), K, H, H, n, w.d_hf, 1, H, nH, w.h4, H, 1, nH, G + off[14], H + E2, ps, G + off[15]);
+      wgrad(E, side(), K, H, E2, n, w.d_hf, 1, H, nH, w.emb + E1, EM, 1, n * EM, G + off[14] + H, H + E2, ps);
     }
-    wgrad(side(), K, H, H, n, d_hc, 1, H, nH, w.h4, H, 1, nH, G + off[10], H + E2, ps, G + off[11]);
-    wgrad(side(), K, H, E2, n, d_hc, 1, H, nH, w.emb + E1, EM, 1, n * EM, G + off[10] + H, H + E2, ps);
-    wgrad(side(), K, H, H, n, d_h4, 1, H, nH, w.h3, H, 1, nH, G + off[6], H, ps, G + off[7]);
-    wgrad(side(), K, H, H, n, d_h3, 1, H, nH, w.h2, H, 1, nH, G + off[4], H + E1, ps, G + off[5]);
-    wgrad(side(), K, H, E1, n, d_h3, 1, H, nH, w.emb, EM, 1, n * EM, G + off[4] + H, H + E1, ps);
-    wgrad(side(), K, H, H, n, d_h2, 1, H, nH, w.h1, H, 1, nH, G + off[2], H, ps, G + off[3]);
-    wgrad(side(), K, H, E1, n, d_h1, 1, H, nH, w.emb, EM, 1, n * EM, G + off[0], E1, ps, G + off[1]);
-    flush_group(ss, group);
+    wgrad(E, side(), K, H, H, n, d_hc, 1, H, nH, w.h4, H, 1, nH, G + off[10], H + E2, ps, G + off[11]);
+    wgrad(E, side(), K, H, E2, n, d_hc, 1, H, nH, w.emb + E1, EM, 1, n * EM, G + off[10] + H, H + E2, ps);
+    wgrad(E, side(), K, H, H, n, d_h4, 1, H, nH, w.h3, H, 1, nH, G + off[6], H, ps, G + off[7]);
+    wgrad(E, side(), K, H, H, n, d_h3, 1, H, nH, w.h2, H, 1, nH, G + off[4], H + E1, ps, G + off[5]);
+    wgrad(E, side(), K, H, E1, n, d_h3, 1, H, nH, w.emb, EM, 1, n * EM, G + off[4] + H, H + E1, ps);
+    wgrad(E, side(), K, H, H, n, d_h2, 1, H, nH, w.h1, H, 1, nH, G + off[2], H, ps, G + off[3]);
+    wgrad(E, side(), K, H, E1, n, d_h1, 1, H, nH, w.emb, EM, 1, n * EM, G + off[0], E1, ps, G + off[1]);
+    flush_group(E, ss, group);
   } else {
   // colour layer
   fork();
-  wgrad(ss, K, H, H, n, d_hc, 1, H, nH, w.h4, H, 1, nH, G + off[10], H + E2, ps, G + off[11]);
-  wgrad(ss, K, H, E2, n, d_hc, 1, H, nH, w.emb + E1, EM, 1, n * EM, G + off[10] + H, H + E2, ps);
+  wgrad(E, ss, K, H, H, n, d_hc, 1, H, nH, w.h4, H, 1, nH, G + off[10], H + E2, ps, G + off[11]);
+  wgrad(E, ss, K, H, E2, n, d_hc, 1, H, nH, w.emb + E1, EM, 1, n * EM, G + off[10] + H, H + E2, ps);
   if (fold_a) {
-    t_biasrow = w.dhead; t_bsbr = n * 4; t_sbr = 4;
-    gemm(st, K, n, H, H, d_hc, H, 1, nH, P + off[10], H + E2, 1, ps, d_h4, H, 1, nH, false, P + off[8], ps, false, w.h4, H, 1,
+    E.biasrow = w.dhead; E.bsbr = n * 4; E.sbr = 4;
+    gemm(E, st, K, n, H, H, d_hc, H, 1, nH, P + off[10], H + E2, 1, ps, d_h4, H, 1, nH, false, P + off[8], ps, false, w.h4, H, 1,
          nH);
-    t_biasrow = nullptr; t_bsbr = 0; t_sbr = 1;
+    E.biasrow = nullptr; E.bsbr = 0; E.sbr = 1;
   } else {
-    gemm(st, K, n, H, H, d_hc, H, 1, nH, P + off[10], H + E2, 1, ps, d_h4, H, 1, nH, true, nullptr, 0, false, w.h4, H, 1, nH);
+    gemm(E, st, K, n, H, H, d_hc, H, 1, nH, P + off[10], H + E2, 1, ps, d_h4, H, 1, nH, true, nullptr, 0, false, w.h4, H, 1, nH);
   }
-  gemm(st, K, n, E2, H, d_hc, H, 1, nH, P + off[10] + H, H + E2, 1, ps, w.d_emb + E1, EM, 1, n * EM, feat);
+  gemm(E, st, K, n, E2, H, d_hc, H, 1, nH, P + off[10] + H, H + E2, 1, ps, w.d_emb + E1, EM, 1, n * EM, feat);
   // mid2:  d_h4 (masked above) -> grads, d_h3
   fork();
-  wgrad(ss, K, H, H, n, d_h4, 1, H, nH, w.h3, H, 1, nH, G + off[6], H, ps, G + off[7]);
-  gemm(st, K, n, H, H, d_h4, H, 1, nH, P + off[6], H, 1, ps, d_h3, H, 1, nH, false, nullptr, 0, false, w.h3, H, 1, nH);
+  wgrad(E, ss, K, H, H, n, d_h4, 1, H, nH, w.h3, H, 1, nH, G + off[6], H, ps, G + off[7]);
+  gemm(E, st, K, n, H, H, d_h4, H, 1, nH, P + off[6], H, 1, ps, d_h3, H, 1, nH, false, nullptr, 0, false, w.h3, H, 1, nH);
   // cat layer
   fork();
-  wgrad(ss, K, H, H, n, d_h3, 1, H, nH, w.h2, H, 1, nH, G + off[4], H + E1, ps, G + off[5]);
-  wgrad(ss, K, H, E1, n, d_h3, 1, H, nH, w.emb, EM, 1, n * EM, G + off[4] + H, H + E1, ps);
-  gemm(st, K, n, H, H, d_h3, H, 1, nH, P + off[4], H + E1, 1, ps, d_h2, H, 1, nH, false, nullptr, 0, false, w.h2, H, 1, nH);
-  gemm(st, K, n, E1, H, d_h3, H, 1, nH, P + off[4] + H, H + E1, 1, ps, w.d_emb, EM, 1, n * EM, false);
+  wgrad(E, ss, K, H, H, n, d_h3, 1, H, nH, w.h2, H, 1, nH, G + off[4], H + E1, ps, G + off[5]);
+  wgrad(E, ss, K, H, E1, n, d_h3, 1, H, nH, w.emb, EM, 1, n * EM, G + off[4] + H, H + E1, ps);
+  gemm(E, st, K, n, H, H, d_h3, H, 1, nH, P + off[4], H + E1, 1, ps, d_h2, H, 1, nH, false, nullptr, 0, false, w.h2, H, 1, nH);
+  gemm(E, st, K, n, E1, H, d_h3, H, 1, nH, P + off[4] + H, H + E1, 1, ps, w.d_emb, EM, 1, n * EM, false);
   // mid1
   fork();
-  wgrad(ss, K, H, H, n, d_h2, 1, H, nH, w.h1, H, 1, nH, G + off[2], H, ps, G + off[3]);
-  gemm(st, K, n, H, H, d_h2, H, 1, nH, P + off[2], H, 1, ps, d_h1, H, 1, nH, false, nullptr, 0, false, w.h1, H, 1, nH);
+  wgrad(E, ss, K, H, H, n, d_h2, 1, H, nH, w.h1, H, 1, nH, G + off[2], H, ps, G + off[3]);
+  gemm(E, st, K, n, H, H, d_h2, H, 1, nH, P + off[2], H, 1, ps, d_h1, H, 1, nH, false, nullptr, 0, false, w.h1, H, 1, nH);
   // in layer
   fork();
-  wgrad(ss, K, H, E1, n, d_h1, 1, H, nH, w.emb, EM, 1, n * EM, G + off[0], E1, ps, G + off[1]);
-  gemm(st, K, n, E1, H, d_h1, H, 1, nH, P + off[0], E1, 1, ps, w.d_emb, EM, 1, n * EM, true);
+  wgrad(E, ss, K, H, E1, n, d_h1, 1, H, nH, w.emb, EM, 1, n * EM, G + off[0], E1, ps, G + off[1]);
+  gemm(E, st, K, n, E1, H, d_h1, H, 1, nH, P + off[0], E1, 1, ps, w.d_emb, EM, 1, n * EM, true);
   }
   // embedding directions: block partials + ordered reduction straight into the gradient arena (float atomics into dBpe
   // and a copy when the scratch is exhausted)
   int pg = (int)((n + 47) / 48);           // 12 samples per block and pass: at least 4 passes per block
   if (pg > 1024) pg = 1024;
   if (pg < 1) pg = 1;
-  float* pe_part = parts_alloc((size_t)K * pg * 63);
+  float* pe_part = E.parts_alloc((size_t)K * pg * 63);
   if (!pe_part) (void)hipMemsetAsync(w.dBpe, 0, (size_t)K * 64 * 4, st);
   hipLaunchKernelGGL(pe_bwd_kernel, dim3(pg, K), dim3(256), 0, st, n, P, ps, (int)off[18], a->scale, a->pts, w.d_emb,
                      w.dBpe, pe_part);
@@ -2295,6 +2289,7 @@ int eval_points(const objnerf_net* net, int K, long N, const float* params, long
   const int H = net->hidden, C = net->feat_dim;
   if (H % 32 != 0 || net->n_freqs != 6) return OBJNERF_ENOTSUP;
   if (!workspace || workspace_bytes < eval_workspace_bytes(net, K, N) - 256) return OBJNERF_EINVAL;
+  GemmEnv E;                                   // fp32
   int64_t off[OBJNERF_N_TENSORS + 1];
   objnerf_param_layout(net, off);
   hipStream_t st = (hipStream_t)stream;
@@ -2313,24 +2308,24 @@ int eval_points(const objnerf_net* net, int K, long N, const float* params, long
     emb = emb_ws;
   }
   float *h1 = bA, *h2 = bB, *h3 = bA, *h4 = bB, *hc = bA;
-  gemm(st, K, n, H, E1, emb, EM, 1, n * EM, P + off[0], 1, E1, ps, h1, H, 1, nH, false, P + off[1], ps, true);
-  gemm(st, K, n, H, H, h1, H, 1, nH, P + off[2], 1, H, ps, h2, H, 1, nH, false, P + off[3], ps, true);
-  gemm(st, K, n, H, H, h2, H, 1, nH, P + off[4], 1, H + E1, ps, h3, H, 1, nH);
-  gemm(st, K, n, H, E1, emb, EM, 1, n * EM, P + off[4] + H, 1, H + E1, ps, h3, H, 1, nH, true, P + off[5], ps, true);
-  gemm(st, K, n, H, H, h3, H, 1, nH, P + off[6], 1, H, ps, h4, H, 1, nH, false, P + off[7], ps, true);
-  gemm(st, K, n, H, H, h4, H, 1, nH, P + off[10], 1, H + E2, ps, hc, H, 1, nH);
-  gemm(st, K, n, H, E2, emb + E1, EM, 1, n * EM, P + off[10] + H, 1, H + E2, ps, hc, H, 1, nH, true, P + off[11], ps,
+  gemm(E, st, K, n, H, E1, emb, EM, 1, n * EM, P + off[0], 1, E1, ps, h1, H, 1, nH, false, P + off[1], ps, true);
+  gemm(E, st, K, n, H, H, h1, H, 1, nH, P + off[2], 1, H, ps, h2, H, 1, nH, false, P + off[3], ps, true);
+  gemm(E, st, K, n, H, H, h2, H, 1, nH, P + off[4], 1, H + E1, ps, h3, H, 1, nH);
+  gemm(E, st, K, n, H, E1, emb, EM, 1, n * EM, P + off[4] + H, 1, H + E1, ps, h3, H, 1, nH, true, P + off[5], ps, true);
+  gemm(E, st, K, n, H, H, h3, H, 1, nH, P + off[6], 1, H, ps, h4, H, 1, nH, false, P + off[7], ps, true);
+  gemm(E, st, K, n, H, H, h4, H, 1, nH, P + off[10], 1, H + E2, ps, hc, H, 1, nH);
+  gemm(E, st, K, n, H, E2, emb + E1, EM, 1, n * EM, P + off[10] + H, 1, H + E2, ps, hc, H, 1, nH, true, P + off[11], ps,
        true);
   dim3 eg((unsigned)((n + 15) / 16), (unsigned)K);
   hipLaunchKernelGGL(heads_fwd_kernel, eg, dim3(256), (size_t)4 * H * sizeof(float), st, H, n, h4, hc, P, ps,
                      (int)off[8], (int)off[9], (int)off[12], (int)off[13], out_alpha, out_color, 0);
   if (out_hfeat || out_clip) {
     float* hf = out_hfeat ? out_hfeat : bC;
-    gemm(st, K, n, H, H, h4, H, 1, nH, P + off[14], 1, H + E2, ps, hf, H, 1, nH);
-    gemm(st, K, n, H, E2, emb + E1, EM, 1, n * EM, P + off[14] + H, 1, H + E2, ps, hf, H, 1, nH, true, P + off[15], ps,
+    gemm(E, st, K, n, H, H, h4, H, 1, nH, P + off[14], 1, H + E2, ps, hf, H, 1, nH);
+    gemm(E, st, K, n, H, E2, emb + E1, EM, 1, n * EM, P + off[14] + H, 1, H + E2, ps, hf, H, 1, nH, true, P + off[15], ps,
          true);
     if (out_clip)
-      gemm(st, K, n, C, H, hf, H, 1, nH, P + off[16], 1, H, ps, out_clip, C, 1, n * C, false, P + off[17], ps, false);
+      gemm(E, st, K, n, C, H, hf, H, 1, nH, P + off[16], 1, H, ps, out_clip, C, 1, n * C, false, P + off[17], ps, false);
   }
   if (hipGetLastError() != hipSuccess) return OBJNERF_ELAUNCH;
   return OBJNERF_OK;
@@ -2362,66 +2357,63 @@ int mlp_backward(const objnerf_net* net, int K, long N, const float* params, lon
   int64_t off[OBJNERF_N_TENSORS + 1];
   objnerf_param_layout(net, off);
   hipStream_t st = (hipStream_t)stream;
-  const Bf16Scope fp32_scope(0);
+  GemmEnv E;
   WS w = carve((char*)workspace, H, C, n, 1, K, feat);
-  t_parts = w.parts; t_parts_cap = w.parts_floats; t_parts_off = 0;
-  struct PartsScope {
-    ~PartsScope() { t_parts = nullptr; t_parts_cap = t_parts_off = 0; }
-  } parts_scope;
+  E.parts = w.parts; E.parts_cap = w.parts_floats; E.parts_off = 0;
   const float* P = params;
   float* G = grads;
   const int E1 = OBJ_E1, E2 = OBJ_E2, EM = OBJ_EMB;
   for (int k = 0; k < K; ++k)      // feature-branch entries only when they receive a gradient ("no gradient" = untouched)
     (void)hipMemsetAsync(G + (long)k * ps, 0, (size_t)(feat ? off[18] : off[14]) * 4, st);
   // ---- forward (recompute)
-  gemm(st, K, n, H, E1, emb, EM, 1, n * EM, P + off[0], 1, E1, ps, w.h1, H, 1, nH, false, P + off[1], ps, true);
-  gemm(st, K, n, H, H, w.h1, H, 1, nH, P + off[2], 1, H, ps, w.h2, H, 1, nH, false, P + off[3], ps, true);
-  gemm(st, K, n, H, H, w.h2, H, 1, nH, P + off[4], 1, H + E1, ps, w.h3, H, 1, nH);
-  gemm(st, K, n, H, E1, emb, EM, 1, n * EM, P + off[4] + H, 1, H + E1, ps, w.h3, H, 1, nH, true, P + off[5], ps, true);
-  gemm(st, K, n, H, H, w.h3, H, 1, nH, P + off[6], 1, H, ps, w.h4, H, 1, nH, false, P + off[7], ps, true);
-  gemm(st, K, n, H, H, w.h4, H, 1, nH, P + off[10], 1, H + E2, ps, w.hc, H, 1, nH);
-  gemm(st, K, n, H, E2, emb + E1, EM, 1, n * EM, P + off[10] + H, 1, H + E2, ps, w.hc, H, 1, nH, true, P + off[11], ps, true);
+  gemm(E, st, K, n, H, E1, emb, EM, 1, n * EM, P + off[0], 1, E1, ps, w.h1, H, 1, nH, false, P + off[1], ps, true);
+  gemm(E, st, K, n, H, H, w.h1, H, 1, nH, P + off[2], 1, H, ps, w.h2, H, 1, nH, false, P + off[3], ps, true);
+  gemm(E, st, K, n, H, H, w.h2, H, 1, nH, P + off[4], 1, H + E1, ps, w.h3, H, 1, nH);
+  gemm(E, st, K, n, H, E1, emb, EM, 1, n * EM, P + off[4] + H, 1, H + E1, ps, w.h3, H, 1, nH, true, P + off[5], ps, true);
+  gemm(E, st, K, n, H, H, w.h3, H, 1, nH, P + off[6], 1, H, ps, w.h4, H, 1, nH, false, P + off[7], ps, true);
+  gemm(E, st, K, n, H, H, w.h4, H, 1, nH, P + off[10], 1, H + E2, ps, w.hc, H, 1, nH);
+  gemm(E, st, K, n, H, E2, emb + E1, EM, 1, n * EM, P + off[10] + H, 1, H + E2, ps, w.hc, H, 1, nH, true, P + off[11], ps, true);
   dim3 eg((unsigned)((n + 15) / 16), (unsigned)K);
   const size_t head_lds = (size_t)4 * H * sizeof(float);
   hipLaunchKernelGGL(heads_fwd_kernel, eg, dim3(256), head_lds, st, H, n, w.h4, w.hc, P, ps, (int)off[8], (int)off[9],
                      (int)off[12], (int)off[13], w.alpha, w.color, 0);
   if (feat) {
-    gemm(st, K, n, H, H, w.h4, H, 1, nH, P + off[14], 1, H + E2, ps, w.hf, H, 1, nH);
-    gemm(st, K, n, H, E2, emb + E1, EM, 1, n * EM, P + off[14] + H, 1, H + E2, ps, w.hf, H, 1, nH, true, P + off[15], ps, true);
+    gemm(E, st, K, n, H, H, w.h4, H, 1, nH, P + off[14], 1, H + E2, ps, w.hf, H, 1, nH);
+    gemm(E, st, K, n, H, E2, emb + E1, EM, 1, n * EM, P + off[14] + H, 1, H + E2, ps, w.hf, H, 1, nH, true, P + off[15], ps, true);
   }
   // ---- backward
   float *d_hc = w.dA, *d_h4 = w.dB_, *d_h3 = w.dC, *d_h2 = w.dD, *d_h1 = w.dE;
   hipLaunchKernelGGL(heads_bwd_kernel, eg, dim3(256), head_lds, st, H, n, w.hc, w.color, d_alpha, d_color, P, ps, (int)off[8],
                      (int)off[12], w.dhead, d_hc, d_h4, 0, 1.0f);
-  wgrad(st, K, 1, H, n, w.dhead, 1, 4, n * 4, w.h4, H, 1, nH, G + off[8], H, ps, G + off[9]);
-  wgrad(st, K, 3, H, n, w.dhead + 1, 1, 4, n * 4, w.hc, H, 1, nH, G + off[12], H, ps, G + off[13]);
+  wgrad(E, st, K, 1, H, n, w.dhead, 1, 4, n * 4, w.h4, H, 1, nH, G + off[8], H, ps, G + off[9]);
+  wgrad(E, st, K, 3, H, n, w.dhead + 1, 1, 4, n * 4, w.hc, H, 1, nH, G + off[12], H, ps, G + off[13]);
   if (feat) {
     // 512-d head: d W_of = d_clip^T hf, d b_of = column sums, d_hf = (d_clip W_of) o [hf > 0]
     float* extra = (float*)((char*)workspace + w.bytes);
-    float* keep = t_parts; const size_t keep_cap = t_parts_cap, keep_off = t_parts_off;
-    t_parts = extra; t_parts_cap = (size_t)K * wgrad_slices(K, C, H, n) * ((size_t)C * H + C) + 256; t_parts_off = 0;
-    wgrad(st, K, C, H, n, d_clip, 1, C, n * C, w.hf, H, 1, nH, G + off[16], H, ps, G + off[17]);
-    t_parts = keep; t_parts_cap = keep_cap; t_parts_off = keep_off;
-    gemm(st, K, n, H, C, d_clip, C, 1, n * C, P + off[16], H, 1, ps, w.d_hf, H, 1, nH, false, nullptr, 0, false, w.hf, H, 1, nH);
-    wgrad(st, K, H, H, n, w.d_hf, 1, H, nH, w.h4, H, 1, nH, G + off[14], H + E2, ps, G + off[15]);
-    wgrad(st, K, H, E2, n, w.d_hf, 1, H, nH, emb + E1, EM, 1, n * EM, G + off[14] + H, H + E2, ps);
-    gemm(st, K, n, H, H, w.d_hf, H, 1, nH, P + off[14], H + E2, 1, ps, d_h4, H, 1, nH, true);
-    gemm(st, K, n, E2, H, w.d_hf, H, 1, nH, P + off[14] + H, H + E2, 1, ps, d_emb + E1, EM, 1, n * EM, false);
+    float* keep = E.parts; const size_t keep_cap = E.parts_cap, keep_off = E.parts_off;
+    E.parts = extra; E.parts_cap = (size_t)K * wgrad_slices(K, C, H, n) * ((size_t)C * H + C) + 256; E.parts_off = 0;
+    wgrad(E, st, K, C, H, n, d_clip, 1, C, n * C, w.hf, H, 1, nH, G + off[16], H, ps, G + off[17]);
+    E.parts = keep; E.parts_cap = keep_cap; E.parts_off = keep_off;
+    gemm(E, st, K, n, H, C, d_clip, C, 1, n * C, P + off[16], H, 1, ps, w.d_hf, H, 1, nH, false, nullptr, 0, false, w.hf, H, 1, nH);
+    wgrad(E, st, K, H, H, n, w.d_hf, 1, H, nH, w.h4, H, 1, nH, G + off[14], H + E2, ps, G + off[15]);
+    wgrad(E, st, K, H, E2, n, w.d_hf, 1, H, nH, emb + E1, EM, 1, n * EM, G + off[14] + H, H + E2, ps);
+    gemm(E, st, K, n, H, H, w.d_hf, H, 1, nH, P + off[14], H + E2, 1, ps, d_h4, H, 1, nH, true);
+    gemm(E, st, K, n, E2, H, w.d_hf, H, 1, nH, P + off[14] + H, H + E2, 1, ps, d_emb + E1, EM, 1, n * EM, false);
   }
-  wgrad(st, K, H, H, n, d_hc, 1, H, nH, w.h4, H, 1, nH, G + off[10], H + E2, ps, G + off[11]);
-  wgrad(st, K, H, E2, n, d_hc, 1, H, nH, emb + E1, EM, 1, n * EM, G + off[10] + H, H + E2, ps);
-  gemm(st, K, n, H, H, d_hc, H, 1, nH, P + off[10], H + E2, 1, ps, d_h4, H, 1, nH, true, nullptr, 0, false, w.h4, H, 1, nH);
-  gemm(st, K, n, E2, H, d_hc, H, 1, nH, P + off[10] + H, H + E2, 1, ps, d_emb + E1, EM, 1, n * EM, feat);
-  wgrad(st, K, H, H, n, d_h4, 1, H, nH, w.h3, H, 1, nH, G + off[6], H, ps, G + off[7]);
-  gemm(st, K, n, H, H, d_h4, H, 1, nH, P + off[6], H, 1, ps, d_h3, H, 1, nH, false, nullptr, 0, false, w.h3, H, 1, nH);
-  wgrad(st, K, H, H, n, d_h3, 1, H, nH, w.h2, H, 1, nH, G + off[4], H + E1, ps, G + off[5]);
-  wgrad(st, K, H, E1, n, d_h3, 1, H, nH, emb, EM, 1, n * EM, G + off[4] + H, H + E1, ps);
-  gemm(st, K, n, H, H, d_h3, H, 1, nH, P + off[4], H + E1, 1, ps, d_h2, H, 1, nH, false, nullptr, 0, false, w.h2, H, 1, nH);
-  gemm(st, K, n, E1, H, d_h3, H, 1, nH, P + off[4] + H, H + E1, 1, ps, d_emb, EM, 1, n * EM, false);
-  wgrad(st, K, H, H, n, d_h2, 1, H, nH, w.h1, H, 1, nH, G + off[2], H, ps, G + off[3]);
-  gemm(st, K, n, H, H, d_h2, H, 1, nH, P + off[2], H, 1, ps, d_h1, H, 1, nH, false, nullptr, 0, false, w.h1, H, 1, nH);
-  wgrad(st, K, H, E1, n, d_h1, 1, H, nH, emb, EM, 1, n * EM, G + off[0], E1, ps, G + off[1]);
-  gemm(st, K, n, E1, H, d_h1, H, 1, nH, P + off[0], E1, 1, ps, d_emb, EM, 1, n * EM, true);
+  wgrad(E, st, K, H, H, n, d_hc, 1, H, nH, w.h4, H, 1, nH, G + off[10], H + E2, ps, G + off[11]);
+  wgrad(E, st, K, H, E2, n, d_hc, 1, H, nH, emb + E1, EM, 1, n * EM, G + off[10] + H, H + E2, ps);
+  gemm(E, st, K, n, H, H, d_hc, H, 1, nH, P + off[10], H + E2, 1, ps, d_h4, H, 1, nH, true, nullptr, 0, false, w.h4, H, 1, nH);
+  gemm(E, st, K, n, E2, H, d_hc, H, 1, nH, P + off[10] + H, H + E2, 1, ps, d_emb + E1, EM, 1, n * EM, feat);
+  wgrad(E, st, K, H, H, n, d_h4, 1, H, nH, w.h3, H, 1, nH, G + off[6], H, ps, G + off[7]);
+  gemm(E, st, K, n, H, H, d_h4, H, 1, nH, P + off[6], H, 1, ps, d_h3, H, 1, nH, false, nullptr, 0, false, w.h3, H, 1, nH);
+  wgrad(E, st, K, H, H, n, d_h3, 1, H, nH, w.h2, H, 1, nH, G + off[4], H + E1, ps, G + off[5]);
+  wgrad(E, st, K, H, E1, n, d_h3, 1, H, nH, emb, EM, 1, n * EM, G + off[4] + H, H + E1, ps);
+  gemm(E, st, K, n, H, H, d_h3, H, 1, nH, P + off[4], H + E1, 1, ps, d_h2, H, 1, nH, false, nullptr, 0, false, w.h2, H, 1, nH);
+  gemm(E, st, K, n, E1, H, d_h3, H, 1, nH, P + off[4] + H, H + E1, 1, ps, d_emb, EM, 1, n * EM, false);
+  wgrad(E, st, K, H, H, n, d_h2, 1, H, nH, w.h1, H, 1, nH, G + off[2], H, ps, G + off[3]);
+  gemm(E, st, K, n, H, H, d_h2, H, 1, nH, P + off[2], H, 1, ps, d_h1, H, 1, nH, false, nullptr, 0, false, w.h1, H, 1, nH);
+  wgrad(E, st, K, H, E1, n, d_h1, 1, H, nH, emb, EM, 1, n * EM, G + off[0], E1, ps, G + off[1]);
+  gemm(E, st, K, n, E1, H, d_h1, H, 1, nH, P + off[0], E1, 1, ps, d_emb, EM, 1, n * EM, true);
   if (hipGetLastError() != hipSuccess) return OBJNERF_ELAUNCH;
   return OBJNERF_OK;
 }
@@ -2448,7 +2440,8 @@ int embed_backward(const objnerf_net* net, int K, long N, const float* params, l
 // G = W_of^T W_of, wb = W_of^T b_of, bb = b_of . b_of of K objects: gram[k][Hh * Hh | Hh | 1], batch stride gstride
 void feat_gram(void* stream, int K, const float* params, long p_stride, int off_w, int off_b, int C, int Hh, float* gram,
                long gstride) {
-  gemm((hipStream_t)stream, K, Hh, Hh, C, params + off_w, 1, Hh, p_stride, params + off_w, Hh, 1, p_stride, gram, Hh, 1,
+  GemmEnv E;
+  gemm(E, (hipStream_t)stream, K, Hh, Hh, C, params + off_w, 1, Hh, p_stride, params + off_w, Hh, 1, p_stride, gram, Hh, 1,
        gstride);
   hipLaunchKernelGGL(featg_wb_kernel, dim3(Hh + 1, K), dim3(64), 0, (hipStream_t)stream, params, p_stride, off_w, off_b, C,
                      Hh, gram, gstride);
@@ -2456,23 +2449,24 @@ void feat_gram(void* stream, int K, const float* params, long p_stride, int off_
 // out[k][m][:] = W_of[k] hfeat[k][m] + b_of[k] * weight[k][m]   (model.py:101 applied after compositing; weight NULL = 1)
 void feature_head(void* stream, int K, long n, int Hh, int C, const float* params, long p_stride, long off_w, long off_b,
                   const float* hfeat, const float* weight, float* out) {
-  t_biasrow = weight; t_bsbr = n;
-  gemm((hipStream_t)stream, K, (int)n, C, Hh, hfeat, Hh, 1, n * Hh, params + off_w, 1, Hh, p_stride, out, C, 1, n * C, false,
+  GemmEnv E;
+  E.biasrow = weight; E.bsbr = n;
+  gemm(E, (hipStream_t)stream, K, (int)n, C, Hh, hfeat, Hh, 1, n * Hh, params + off_w, 1, Hh, p_stride, out, C, 1, n * C, false,
        params + off_b, p_stride, false);
-  t_biasrow = nullptr; t_bsbr = 0;
 }
 void gemm_f32(void* stream, int batch, int M, int N, int Kd, const float* A, long sam, long sak, long bsa, const float* B,
               long sbk, long sbn, long bsb, float* C, long scm, long scn, long bsc, bool accumulate) {
-  gemm((hipStream_t)stream, batch, M, N, Kd, A, sam, sak, bsa, B, sbk, sbn, bsb, C, scm, scn, bsc, accumulate);
+  GemmEnv E;
+  gemm(E, (hipStream_t)stream, batch, M, N, Kd, A, sam, sak, bsa, B, sbk, sbn, bsb, C, scm, scn, bsc, accumulate);
 }
 size_t wgrad_parts_floats(int batch, int M, int N, long n) {
   return (size_t)batch * wgrad_slices(batch, M, N, n) * M * N + 64;
 }
 void wgrad_f32(void* stream, int batch, int M, int N, long n, const float* A, long sam, long sak, long bsa, const float* B,
                long sbk, long sbn, long bsb, float* C, long scm, long bsc, float* parts, size_t parts_floats) {
-  t_parts = parts; t_parts_cap = parts ? parts_floats : 0; t_parts_off = 0;
-  wgrad((hipStream_t)stream, batch, M, N, n, A, sam, sak, bsa, B, sbk, sbn, bsb, C, scm, bsc);
-  t_parts = nullptr; t_parts_cap = t_parts_off = 0;
+  GemmEnv E;
+  E.parts = parts; E.parts_cap = parts ? parts_floats : 0; E.parts_off = 0;
+  wgrad(E, (hipStream_t)stream, batch, M, N, n, A, sam, sak, bsa, B, sbk, sbn, bsb, C, scm, bsc);
 }
 
 }  // namespace objgen

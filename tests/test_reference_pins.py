@@ -169,7 +169,7 @@ def test_reference_written_checkpoint_renders_like_reference_g13(golden, dev):
     emb = so.trainer.pe(pts)
     alpha, color, clip = so.trainer.fc_occ_map(emb)
     assert float((emb.detach().cpu() - T(g["emb"])).abs().max()) < 2e-5
-    assert float((alpha.cpu() - T(g["alpha"])).abs().max()) < 1e-4
+    assert float((alpha.detach().cpu() - T(g["alpha"])).abs().max()) < 1e-4
     assert float((color.cpu() - T(g["color"])).abs().max()) < 1e-5
     assert float((clip.cpu() - T(g["clip"])).abs().max()) < 1e-4
 
