@@ -281,6 +281,23 @@ __device__ __forceinline__ float rev_sin(const float vh, const float vl, const f
   return __builtin_amdgcn_sinf(fmaf(vl, sc, r));
 }
 
+// sin / cos of octaves F0 .. F0 + N - 1 of one direction: the lowest octave from its own exact reduction, the others by
+// angle doubling (sin 2x = 2 sin x cos x, cos 2x = 1 - 2 sin^2 x: 3 instructions instead of a reduction + two
+// transcendentals).  The error grows ~4x per octave (v_sin: ~1e-6 -> ~1e-4 at the third doubling): used for the
+// BACKWARD factors only (cos times a 16-bit-rounded gradient); the forward embedding values are MFMA operands and keep
+// their own reductions (measured: the ladder there moved the mid-layer weight gradients from 2e-4 to 1e-3 of the
+// specification).
+template <int F0, int N>
+__device__ __forceinline__ void rev_ladder(const float vh, const float vl, float (&sv)[N], float (&cv)[N]) {
+  rev_sincos(vh, vl, (float)(1 << F0), sv[0], cv[0]);
+#pragma unroll
+  for (int i = 1; i < N; ++i) {
+    const float t = sv[i - 1] + sv[i - 1];
+    sv[i] = t * cv[i - 1];
+    cv[i] = fmaf(-t, sv[i - 1], 1.0f);
+  }
+}
+
 // ---- epilogues on PACKED words (two 16-bit values per register): the ReLU is a packed integer max with zero (a
 // negative value has its sign bit set in either 16-bit format), the branch bit of each half its (inverted) sign bit --
 // a pre-activation that rounds to +0 counts as passed: its activation is 0 either way -- and the backward mask a packed
@@ -670,8 +687,8 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
       float vh[11], vl[11];
       project(vh, vl);
 #pragma unroll
-      for (int t = 0; t < KS_X1; ++t) {
-#pragma unroll
+      for (int t = 0; t < KS_X1; ++t) {        // (every octave from its own exact reduction: these values ARE operands --
+#pragma unroll                               //  a doubling ladder's 1e-4 moves 2 % of their bf16 roundings)
         for (int j = 0; j < 8; ++j) {
           const int u = 8 * t + j, dd = u >> 2, f = u & 3;
           float v = 0.0f;
@@ -1117,11 +1134,14 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
       float vh[11], vl[11];
       project(vh, vl);
 #pragma unroll
-      for (int u = 0; u < 22; ++u) {                        // slot u = 2 dd + (f - 4)
-        const int dd = u >> 1, f = 4 + (u & 1);
-        float sv, cv;
-        rev_sincos(vh[dd], vl[dd], (float)(1 << f), sv, cv);
-        dproj[dd] = fmaf(xa[u >> 4][u & 15], (cv * OBJ_PI_F) * (float)(1 << f), dproj[dd]);     // embedding.py:49-52
+      for (int dd = 0; dd < 11; ++dd) {                     // slot u = 2 dd + (f - 4)
+        float sv[2], cv[2];
+        rev_ladder<4, 2>(vh[dd], vl[dd], sv, cv);
+#pragma unroll
+        for (int f = 4; f < 6; ++f) {
+          const int u = 2 * dd + (f - 4);
+          dproj[dd] = fmaf(xa[u >> 4][u & 15], cv[f - 4] * (OBJ_PI_F * (float)(1 << f)), dproj[dd]);     // embedding.py:49-52
+        }
       }
     }
     reload();                                                                                                                  // hin = d h4
@@ -1132,11 +1152,14 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
       float vh[11], vl[11];
       project(vh, vl);
 #pragma unroll
-      for (int u = 0; u < 44; ++u) {                          // slot u = 4 dd + f
-        const int dd = u >> 2, f = u & 3;
-        float sv, cv;
-        rev_sincos(vh[dd], vl[dd], (float)(1 << f), sv, cv);
-        dproj[dd] = fmaf(x1a[u >> 4][u & 15], (cv * OBJ_PI_F) * (float)(1 << f), dproj[dd]);
+      for (int dd = 0; dd < 11; ++dd) {                       // slot u = 4 dd + f
+        float sv[4], cv[4];
+        rev_ladder<0, 4>(vh[dd], vl[dd], sv, cv);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          const int u = 4 * dd + f;
+          dproj[dd] = fmaf(x1a[u >> 4][u & 15], cv[f] * (OBJ_PI_F * (float)(1 << f)), dproj[dd]);
+        }
       }
     };
     {                                                                                                                          // B3X: d x1
