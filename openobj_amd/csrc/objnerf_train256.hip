@@ -335,7 +335,7 @@ template <> __device__ __forceinline__ uint32_t pk_cvt<_Float16>(float a, float 
 }
 
 #ifdef OBJ256_TIMING      // diagnostic build: cycles per part of a stage (s_memtime), printed by workgroup 0 / wave 0
-#define T256_DECL unsigned long long tm_[6] = {0, 0, 0, 0, 0, 0}; unsigned long long tm_t = __builtin_amdgcn_s_memtime()
+#define T256_DECL unsigned long long tm_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tm_t = __builtin_amdgcn_s_memtime()
 #define T256(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tm_[i] += t_ - tm_t; tm_t = t_; } while (0)
 #else
 #define T256_DECL do {} while (0)
@@ -822,6 +822,7 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
       }
     };
     // ------------------------------------------------------------------ forward
+    T256(6);
     fwd_layer(std::integral_constant<int, F1>{}, std::integral_constant<int, 6>{}, 0, [&](int ks) -> V { return x1f[ks]; });   // h1
     {   // the loads requested at the top of the tile have landed under the first layer: park them for the compositing
       s_z[st_idx] = z_own;
@@ -860,6 +861,7 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
     }
     fwd_layer(std::integral_constant<int, F5>{}, std::integral_constant<int, 19>{}, 4,
               [&](int ks) -> V { return ks < KS_H ? hin[ks] : x2f[ks - KS_H]; });                                              // hc
+    T256(7);
     {   // F5 block 8: row 0 = w_alpha . h4  (raw density, model.py:81)
       constexpr int NP2 = NP2_OF(F5, 8);
       f32x16 acc = zero16(), acc1 = zero16();
@@ -882,6 +884,7 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
       KT::template stage_sync<NW, NP2, 0>(strm.last);           // (also publishes the strips to the compositing waves)
       strm.template advance<NP2>();
     }
+    T256(8);
     // ------------------------------------------------------------------ compositing + losses (loss.py:27-101)
     {
       constexpr int LPR = S < 64 ? S : 64;               // lanes per ray
@@ -973,6 +976,7 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
       }
     }
     __syncthreads();
+    T256(9);
     // head gradient fragment: slot (0, 0) = d raw, (0, 1 + c) = d colour pre-activation; everything times the scale
     V dh = KT::zero_frag();
     if (h == 0 && valid) {
@@ -1028,6 +1032,7 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
         T256(3);
         KT::template stage_sync<NW, NP2, 2>(strm.last);
         strm.template advance<NP2>();
+        T256(4);
       };
       f32x16 accA, accA1, accB = zero16(), accB1 = zero16();
 #pragma unroll 1
@@ -1126,8 +1131,10 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
       strm.template advance<NP2>();
     }
     reload();                                                                                                                  // hin = d hc
+    T256(10);
     bwd_layer(std::integral_constant<int, B5H>{}, std::integral_constant<int, 17>{}, 3,
               [&](int ks) -> V { return ks < KS_H ? hin[ks] : dh; });                                                          // d h4
+    T256(7);
     {                                                                                                                          // B5X: d x2
       f32x16 xa[2];
       bwd_slots(std::integral_constant<int, B5X>{}, std::integral_constant<int, 2>{}, std::false_type{}, xa);
@@ -1144,6 +1151,7 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
         }
       }
     }
+    T256(11);
     reload();                                                                                                                  // hin = d h4
     bwd_layer(std::integral_constant<int, B4>{}, std::integral_constant<int, 16>{}, 2, [&](int ks) -> V { return hin[ks]; });  // d h3
     reload();
@@ -1162,19 +1170,23 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
         }
       }
     };
+    T256(7);
     {                                                                                                                          // B3X: d x1
       f32x16 x1a[3];
       bwd_slots(std::integral_constant<int, B3X>{}, std::integral_constant<int, 3>{}, std::false_type{}, x1a);
       pe_bwd_x1(x1a);          // (the chain rule is linear in d x1: applied per contribution)
     }
+    T256(12);
     reload();                                                                                                                  // hin = d h2
     bwd_layer(std::integral_constant<int, B2>{}, std::integral_constant<int, 16>{}, 0, [&](int ks) -> V { return hin[ks]; });  // d h1
     reload();
+    T256(7);
     {                                                                                                                          // B1: d x1 +=
       f32x16 x1a[3];
       bwd_slots(std::integral_constant<int, B1>{}, std::integral_constant<int, 3>{}, std::false_type{}, x1a);
       pe_bwd_x1(x1a);
     }
+    T256(13);
     // d B[j][c] += d proj_j * t_c: per-lane sums, reduced over the lanes once per object (flush_object)
 #pragma unroll
     for (int dd = 0; dd < 11; ++dd) {
@@ -1185,13 +1197,15 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
       dbacc[dd][2] = fmaf(dp, t2, dbacc[dd][2]);
     }
     if (++tile_i == a.ntile) { tile_i = 0; ++k_i; }
+    T256(14);
   }
   flush_object();
 #ifdef OBJ256_TIMING
   T256(5);
   if (blockIdx.x == 0 && tid == 0)
-    printf("t256 (ticks of workgroup 0, wave 0): outside layer stages %llu | fwd-layer block_mma %llu  sync %llu | bwd-layer block_mma %llu | tail %llu\n",
-           tm_[0], tm_[1], tm_[2], tm_[3], tm_[5]);
+    printf("t256 (ticks of workgroup 0, wave 0): tile head %llu | fwd-layer mma %llu sync %llu | bwd-layer mma %llu sync %llu | layer tails (last epilogue, reload) %llu | "
+           "alpha + colour stages %llu | compositing %llu | dh + B6 %llu | B5X + pe %llu | B3X + pe %llu | B1 + pe %llu | tile tail %llu | rest %llu %llu\n",
+           tm_[6], tm_[1], tm_[2], tm_[3], tm_[4], tm_[7], tm_[8], tm_[9], tm_[10], tm_[11], tm_[12], tm_[13], tm_[14], tm_[0], tm_[5]);
 #endif
 }
 
@@ -1220,6 +1234,9 @@ struct WgArgs {
   const char* ws; float* slabs;
   WsLay wl;
 };
+#ifndef OBJ256_WG_CH
+#define OBJ256_WG_CH 2      // sample groups per chunk of the plain weight-gradient tasks (1: half the bytes in flight)
+#endif
 constexpr int IMG_PITCH = 72;                       // bytes per sample row of a 32-feature block image
 constexpr int IMG_BLK = 32 * IMG_PITCH;             // 2304
 
@@ -1236,7 +1253,7 @@ __device__ __forceinline__ void wgrad_task(const WgArgs& a, const char* Asrc, co
   typedef typename Op<OT>::V V;
   constexpr int RBW = RB / NRG, CBW = CB / NCG;
   constexpr int NPA = AK == 0 ? 2 * RB : 1, NPB = BK == 0 ? 2 * CB : KSB;
-  constexpr int CH = 2;                                        // sample groups per chunk
+  constexpr int CH = OBJ256_WG_CH;                             // sample groups per chunk
   constexpr int NP = CH * (NPA + NPB);
   constexpr int PPW = (NP + NWAVE - 1) / NWAVE;                // pieces per wave and chunk
   constexpr int BUF = CH * (RB + CB) * IMG_BLK;
