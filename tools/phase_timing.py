@@ -1,9 +1,9 @@
 """Diagnostic: per-phase s_memtime breakdown of the fused fp32 training kernel (workgroup 0, every wave).
-Build first:  tools/build_variant.sh PHASE -DPHASE_TIMING ;  run on the GPU box."""
+Build first:  tools/build_variant.sh PHASE -DPHASE_TIMING ;  run on the GPU box (--bf16: the bf16 kernel, --feat)."""
 import ctypes as C, os, sys
 import numpy as np
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["OBJNERF_LIB"] = os.path.join(root, "openobj_amd/csrc/abl/lib_PHASE.so")
+os.environ.setdefault("OBJNERF_LIB", os.path.join(root, "openobj_amd/csrc/variants/libobjnerf_hip_PHASE.so"))
 sys.path.insert(0, root)
 import torch
 from openobj_amd import _lib, ops, synthetic, init as obj_init
