@@ -896,7 +896,6 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
         const int qq = ps * RPP + ql;
         const long rayq = tile * TR + qq;
         const bool on = (qq < TR) && (rayq < a.R);
-        const long rr = (long)k * a.R + (on ? rayq : 0);
         float gtd = 0.f, gr = 0.f, gg = 0.f, gb = 0.f;
         int lab = 2;
         if (on) { const float* rp = s_ray + 8 * qq; gtd = rp[0]; gr = rp[1]; gg = rp[2]; gb = rp[3]; lab = __float_as_int(rp[4]); }
@@ -1052,7 +1051,7 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
     };
     // slot-gradient blocks (d x1 / d x2): NB blocks accumulated into xacc[b]
     auto bwd_slots = [&](auto seq_tag, auto nb_tag, auto keep_tag, f32x16* xacc) __attribute__((always_inline)) {
-      constexpr bool KEEP = decltype(keep_tag)::value;      // the chains continue from xacc (B1 adds to B3X's d x1)
+      // keep_tag: the chains continue from xacc instead of starting at zero
       constexpr int NB = decltype(nb_tag)::value, Q = decltype(seq_tag)::value;
 #pragma unroll
       for (int b = 0; b < NB; ++b) {

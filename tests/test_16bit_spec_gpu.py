@@ -49,7 +49,7 @@ def _run(dev, K, R, n1, n2, H, feat, mode, seed=7):
                                    (1, 4096, 16, 48, 64),
                                    # fused hidden-256 path: S = 32 with a ragged ray count, workgroups that cross from one
                                    # object's tiles (and weight image) to the next one's
-                                   (3, 700, 8, 24, 256), (2, 300, 16, 48, 256)])
+                                   (3, 700, 8, 24, 256), (2, 300, 16, 48, 256), (2, 101, 8, 24, 256), (1, 33, 16, 48, 256)])
 def test_layerwise_16bit_step_matches_its_specification(dev, mode, shape):
     """Layer-wise path (any width), no feature loss -- configs[4]'s arithmetic: hidden 256 with R x S >= 4096 samples
     per object runs the resident-panel GEMMs with activations stored in the operand type (act16)."""
