@@ -1,7 +1,7 @@
 # Diagnostic (GPU box): kernel sequence with durations of the last launches of a bench.py run -> gpurun_out/seq/seq.txt
 #   bash tools/kernel_seq.sh --config c5 --dtype bf16 --objects 4 --steps 1 --warmup 1
 R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out/seq; mkdir -p $OUT; cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $OUT -o s -- python3 $R/bench.py "$@" --no-psnr --no-cpu-baseline --no-peak > $OUT/bench.json 2> $OUT/err.txt
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT -o s -- python3 $R/bench.py "$@" --no-psnr --no-cpu-baseline --no-peak > $OUT/bench.json 2> $OUT/err.txt
 python3 - <<'PY'
 import csv, glob, os
 R=os.environ.get('GRAFT_REPO_ROOT','/root/repo')
