@@ -313,29 +313,45 @@ __device__ __forceinline__ void embed32_load(Emb32& e, const float* __restrict__
 // Forward chain of one 16-sample block.  wf: forward base of this lane, sv: small vectors.  Heads: every lane group
 // ends with ONE of the four outputs of its sample -- group 0: 10 * raw alpha (model.py:88), groups 1..3: the colour
 // channel g - 1 after the sigmoid (model.py:96) -- so only one sigmoid per lane is evaluated.
+// Experiment (-DOBJ_PRIO_TOGGLE): the two waves of a SIMD alternate issue priority layer by layer.  The arbiter serves
+// the older wave first, so waves 0..3 run ahead and then wait at the phase's barrier while waves 4..7 finish alone.
+#ifdef OBJ_PRIO_TOGGLE
+__device__ __forceinline__ void prio_layer(const int layer) {
+  const int grp = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) & 1;
+  if (layer >= 0 && ((layer ^ grp) & 1)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+}
+#else
+__device__ __forceinline__ void prio_layer(const int) {}
+#endif
+
 template <bool FEAT>
 __device__ __forceinline__ float mlp32_forward(const float* wf, const float* sv, const int g, const Emb32& e, Acts& a) {
   T32 acc = zero32();
+  prio_layer(1);
 #pragma unroll
   for (int T = 0; T < 6; ++T) mma_f16(acc, wf, R_IN + 16 * T, e.x1[T]);
   a.h1 = relu32(acc);
+  prio_layer(2);
 #pragma unroll
   for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc.t[tt][r] = sv[SV_BM1 + 16 * tt + 4 * g + r];
   mma_f32(acc, wf, R_M1, a.h1);
   a.h2 = relu32(acc);
+  prio_layer(3);
   acc = zero32();
   mma_f32(acc, wf, R_CAT, a.h2);
 #pragma unroll
   for (int T = 0; T < 6; ++T) mma_f16(acc, wf, R_CAT + 32 + 16 * T, e.x1[T]);
   a.h3 = relu32(acc);
+  prio_layer(4);
 #pragma unroll
   for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc.t[tt][r] = sv[SV_BM2 + 16 * tt + 4 * g + r];
   mma_f32(acc, wf, R_M2, a.h3);
   a.h4 = relu32(acc);
+  prio_layer(5);
   acc = zero32();
   mma_f32(acc, wf, R_CL, a.h4);
 #pragma unroll
@@ -348,6 +364,7 @@ __device__ __forceinline__ float mlp32_forward(const float* wf, const float* sv,
     for (int T = 0; T < 3; ++T) mma_f16(acc, wf, R_FL + 32 + 16 * T, e.x2[T]);
     a.hf = relu32(acc);
   }
+  prio_layer(-1);
   float pa = 0.f, pc0 = 0.f, pc1 = 0.f, pc2 = 0.f;
 #pragma unroll
   for (int tt = 0; tt < 2; ++tt)

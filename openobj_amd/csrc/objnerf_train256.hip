@@ -30,6 +30,7 @@
 // round_head_weights, round_head_grads): fp32 accumulation, biases, compositing, losses and master weights; operands
 // (weights, embedding, stored activations, stored pre-activation gradients -- fp16 pre-scaled by 2^(floor(log2 R)+3))
 // rounded to the operand type.  Not the reference's fp32 arithmetic: opt-in, PSNR-gated.
+#include <cstdlib>
 #include <type_traits>
 #include "objnerf_device.h"
 #include "objnerf_generic.h"
@@ -1669,7 +1670,8 @@ static int waves_for(int) { return OBJ256_NW; }
 static Plan make_plan(int K, long n, int S) {
   Plan p;
   p.wl = WsLay::make(n, 32 * waves_for(S));
-  const long target = 48L << 20;                      // bytes one weight-gradient workgroup streams
+  static const long target_mb = [] { const char* e = getenv("OBJ256_WG_TARGET_MB"); return e ? atol(e) : 48L; }();   // (diagnostic override)
+  const long target = target_mb << 20;                // bytes one weight-gradient workgroup streams
   p.prefix[0] = 0; p.slab_prefix[0] = 0;
   for (int t = 0; t < NTYPE; ++t) {
     const long bytes = p.wl.nsg * type_pieces(t) * PIECE;
