@@ -13,7 +13,7 @@ for f in objnerf_train objnerf_train32 objnerf_train_bf16 objnerf_misc objnerf_g
   extra=""
   [ $f = objnerf_train ] && extra="-mllvm -amdgpu-sched-strategy=max-ilp"
   [ $f = objnerf_train32 ] && extra="-mllvm -amdgpu-sched-strategy=iterative-ilp"
-  [ $f = objnerf_train256 ] && extra="-mllvm -amdgpu-mfma-vgpr-form -Wno-inline-asm"
+  [ $f = objnerf_train256 ] && extra="-mllvm -amdgpu-mfma-vgpr-form -Wno-inline-asm $T256_EXTRA"   # T256_EXTRA: flags for that unit only
   /opt/rocm/bin/hipcc $FLAGS $extra "$@" -c $f.hip -o $out/$f.o &
   pids+=($!)
 done
