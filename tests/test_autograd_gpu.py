@@ -70,6 +70,33 @@ def test_single_module_autograd_vs_oracle(dev, hidden):
         assert maxerr(m, r.grad) < 1e-4 * scale, (i, maxerr(m, r.grad), scale)
 
 
+@pytest.mark.parametrize("hidden", [128, 256])
+def test_stacked_autograd_wide_networks_vs_oracle(dev, hidden):
+    """vmap(pe) -> vmap(fc) -> weighted sums -> backward() for K = 2 stacked networks of the background / stress widths
+    (the layer-wise backward entry), against torch autograd over the stacked oracle."""
+    from openobj_amd import init as obj_init
+    K, N = 2, 300
+    st = obj_init.init_stacked(K, hidden, 512, seed=21)
+    arena = ops.ParamArena(K, ops.NetShape(hidden, 512, 6), dev)
+    arena.load_stacked(st)
+    arena.scale.fill_(2.0)
+    views = arena.views()
+    fc_param, pe_param = [v.requires_grad_() for v in views[:18]], [views[18].requires_grad_()]
+    rs = np.random.RandomState(8)
+    pts = torch.from_numpy(rs.uniform(-2, 2, (K, N, 3)).astype(np.float32))
+    wa, wc, wf = [torch.from_numpy(rs.standard_normal(s).astype(np.float32)) for s in ((K, N, 1), (K, N, 3), (K, N, 512))]
+    emb = utils.vmap(utils.StackedModel(arena, "pe"))(pe_param, [], pts.to(dev))
+    alpha, color, clip = utils.vmap(utils.StackedModel(arena, "fc"))(fc_param, [], emb)
+    ((alpha * wa.to(dev)).sum() + (color * wc.to(dev)).sum() + 0.01 * (clip * wf.to(dev)).sum()).backward()
+    ref = [t.clone().requires_grad_() for t in st]
+    e = O.embed_stacked(ref[18], torch.full((K,), 2.0), pts)
+    a, c, f = O.mlp_forward_stacked(ref[:18], e, True)
+    ((a * wa).sum() + (c * wc).sum() + 0.01 * (f * wf).sum()).backward()
+    for i, (m, r) in enumerate(zip(fc_param + pe_param, ref)):
+        scale = max(1e-3, float(r.grad.abs().max()))
+        assert maxerr(m.grad, r.grad) < 1e-4 * scale, (i, ops.TENSOR_NAMES[i], maxerr(m.grad, r.grad), scale)
+
+
 def test_inference_calls_build_no_graph(dev):
     t = make_trainers(1, dev, 5)[0]
     with torch.no_grad():
