@@ -803,18 +803,26 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
 
 // ------------------------------------------------------------------------------------------------
 // grads[k][i] = sum_g slab[k][g][i] for entries with has_grad; loss_terms[k][:] = sum_g loss_part.
+// flat_nwg > 0 (objnerf_train_common.h): object k's partial slabs are those of the workgroups whose share touches it,
+// slot 0 .. cnt - 1 of its Gs
 __global__ void finalize_kernel(const float* slab, const float* loss_part, int K, int G, long P, long slab_stride,
-                                long p_stride, const uint8_t* has_grad, float* grads, float* loss_terms, int* status) {
+                                long p_stride, const uint8_t* has_grad, float* grads, float* loss_terms, int* status,
+                                int flat_nwg, int NT, int Gs) {
   const int k = blockIdx.y;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (flat_nwg) {
+    const long T = (long)K * NT;
+    G = flat_wg_of(T, flat_nwg, (long)(k + 1) * NT - 1) - flat_wg_of(T, flat_nwg, (long)k * NT) + 1;
+  }
+  const int stride = flat_nwg ? Gs : G;
   if (i < P && has_grad[i]) {
     float s = 0.f;
-    for (int g = 0; g < G; ++g) s += slab[((long)k * G + g) * slab_stride + i];
+    for (int g = 0; g < G; ++g) s += slab[((long)k * stride + g) * slab_stride + i];
     grads[(long)k * p_stride + i] = s;
   }
   if (blockIdx.x == 0 && threadIdx.x < 4) {
     float s = 0.f;
-    for (int g = 0; g < G; ++g) s += loss_part[((long)k * G + g) * 4 + threadIdx.x];
+    for (int g = 0; g < G; ++g) s += loss_part[((long)k * stride + g) * 4 + threadIdx.x];
     loss_terms[k * 4 + threadIdx.x] = s;
     if (s > 100000.0f) atomicOr(status, 1);       // render_rays.py:109-111
   }
@@ -1020,6 +1028,23 @@ static int train_grid(int K, int NT) {
   return best;
 }
 
+// Flat mode of the second-generation fp32 kernel (objnerf_train_common.h): one workgroup per CU, equal shares of the flat
+// (object, tile) space.  Taken when its longest workgroup (tiles + a fixed cost per segment) beats the strided grid's and
+// an object's partial slabs fit the workspace (grid_cap(K) slots).
+static void choose_flat(TrainDev& d, int K) {
+  constexpr long TILE_EQUIV = 4;
+  const int cu = num_cu();
+  const long T = (long)K * d.NT;
+  if (T < cu) return;
+  const long share = (T + cu - 1) / cu;
+  const long segs = 1 + (share + d.NT - 1) / d.NT;                    // segments a share can be cut into
+  const long cost_flat = share + segs * TILE_EQUIV;
+  const long rounds = ((long)K * d.G + cu - 1) / cu;
+  const long cost_strided = rounds * ((d.NT + d.G - 1) / d.G + TILE_EQUIV);
+  const long gs = ((long)d.NT * cu + T - 1) / T + 1;                  // workgroups that can touch one object
+  if (cost_flat < cost_strided && gs <= grid_cap(K)) { d.flat_nwg = cu; d.Gs = (int)gs; }
+}
+
 size_t objnerf_train_workspace_bytes(const objnerf_net* net, int32_t K, int32_t R, int32_t S, int32_t with_feat) {
   if (!net || K <= 0 || R <= 0 || S <= 0) return 0;
   // bit 1 of with_feat (value 2): size for the layer-wise path (OBJNERF_TRAIN_LAYERWISE)
@@ -1074,6 +1099,7 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
   d.TR = TS / a->S;
   d.NT = (a->R + d.TR - 1) / d.TR;
   d.G = train_grid(a->K, d.NT);
+  d.flat_nwg = 0; d.Gs = 0;
   d.color_scaling = a->color_scaling; d.opacity_scaling = a->opacity_scaling; d.feat_scaling = a->feat_scaling;
   d.obj_center = a->obj_center;
   d.params = a->params; d.p_stride = a->p_stride; d.scale = a->scale;
@@ -1137,7 +1163,7 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
     else if (d.relu_masks) hipLaunchKernelGGL((train_fused_kernel<true, true>), dim3(a->K * d.G), dim3(NTHR), lds_bytes, st, d);
     else hipLaunchKernelGGL((train_fused_kernel<true, false>), dim3(a->K * d.G), dim3(NTHR), lds_bytes, st, d);
 #else
-    else launch_train32(d, stream, true);
+    else { choose_flat(d, a->K); launch_train32(d, stream, true); }
     (void)lds_bytes;
 #endif
     if (hipGetLastError() != hipSuccess) return OBJNERF_ELAUNCH;
@@ -1155,13 +1181,14 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
   } else if (bf16) {
     launch_train_bf16(d, stream, false);
   } else {
+    choose_flat(d, a->K);
     launch_train32(d, stream, false);
   }
   if (hipGetLastError() != hipSuccess) return OBJNERF_ELAUNCH;
   const long P = offs[OBJNERF_N_TENSORS];
   dim3 fg((unsigned)((P + 255) / 256), (unsigned)a->K);
   hipLaunchKernelGGL(finalize_kernel, fg, dim3(256), 0, st, d.slab, d.loss_part, a->K, d.G, P, (long)ps,
-                     (long)a->p_stride, has_grad, a->grads, a->loss_terms, a->status);
+                     (long)a->p_stride, has_grad, a->grads, a->loss_terms, a->status, d.flat_nwg, d.NT, d.Gs);
   if (hipGetLastError() != hipSuccess) return OBJNERF_ELAUNCH;
   return OBJNERF_OK;
 }

@@ -157,11 +157,34 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, g = lane >> 4;
-  const int k = blockIdx.x / a.G, gi = blockIdx.x % a.G;
   float* sv = lds + sv_base(FEAT);
   float* s_alpha = lds + IMG;            // [4][TS]: 10 * raw alpha | colour[3]; overwritten in place by their gradients
   float* s_col = s_alpha + TS;
   float* stg = lds + IMG + SM_FLOATS;
+
+  // this workgroup's segments (objnerf_train_common.h): one (k, gi, NT, step G) in strided mode; in flat mode the
+  // pieces of its share of the flat (object, tile) space, each with its own weight staging and partial slab
+  const long T_flat = (long)a.K * a.NT;
+  long cur = a.flat_nwg ? T_flat * blockIdx.x / a.flat_nwg : 0;
+  const long cur_end = a.flat_nwg ? T_flat * (blockIdx.x + 1) / a.flat_nwg : 1;
+  bool first_seg = true;
+  while (cur < cur_end) {
+  int k, t0, t1, tstep, sslot;
+  if (a.flat_nwg) {
+    k = (int)(cur / a.NT);
+    t0 = (int)(cur - (long)k * a.NT);
+    const long rem = cur_end - cur;
+    t1 = (long)t0 + rem < (long)a.NT ? (int)(t0 + rem) : a.NT;
+    tstep = 1;
+    sslot = (int)blockIdx.x - flat_wg_of(T_flat, a.flat_nwg, (long)k * a.NT);
+    cur += t1 - t0;
+  } else {
+    k = blockIdx.x / a.G; t0 = blockIdx.x % a.G; t1 = a.NT; tstep = a.G; sslot = t0;
+    cur = cur_end;
+  }
+  const int n_slots = a.flat_nwg ? a.Gs : a.G;
+  if (!first_seg) __syncthreads();       // (the previous segment's reduction has read the staging area)
+  first_seg = false;
 
   stage_weights32(lds, a.params + (long)k * a.p_stride, a.L, FEAT, tid, NTHR);
   for (int i = tid; i < LY::ROWS * STG_LD; i += NTHR) stg[i] = 0.0f;
@@ -221,7 +244,7 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
     const int q_ = slot_ / S, si_ = slot_ - q_ * S;
     const int ray_ = tile_ * TR + q_;
     x = 0.f; y = 0.f; z_ = 0.f;
-    if (tile_ < a.NT && q_ < TR && ray_ < a.R) {
+    if (tile_ < t1 && q_ < TR && ray_ < a.R) {
       const long rr = (long)k * a.R + ray_;
       if (a.pts) {
         const float* p = a.pts + (rr * S + si_) * 3;
@@ -240,9 +263,9 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
   const SegRows seg_rows = SegRows::make(rows_mode ? S : 64, lane);
   const int slot = 16 * w + c;
   float nx, ny, nz;
-  fetch_point(gi, slot, nx, ny, nz);
+  fetch_point(t0, slot, nx, ny, nz);
   PT_INIT();
-  for (int tile = gi; tile < a.NT; tile += a.G) {
+  for (int tile = t0; tile < t1; tile += tstep) {
     asm volatile("" ::: "memory");   // keep the LDS weight reads inside the loop (no LICM into registers)
     const int ray0 = tile * TR;
     // ---------------------------------------------------------------- 1. forward
@@ -793,7 +816,7 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
     PT(13);
     __syncthreads();
     // ---- phase C: in layer (x1 stays at rows 32..127) + mid1.  h1 rows 0.., d_h1pre 128.., d_h2pre 160..
-    fetch_point(tile + a.G, slot, nx, ny, nz);
+    fetch_point(tile + tstep, slot, nx, ny, nz);
     st_T32(stg_lane, 0, act.h1);
     st_T32(stg_lane, 128, d_h1);
     if (!FEAT) st_T32(stg_lane, LY::C_DH2, d_h2);
@@ -824,7 +847,7 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
   PT_FLUSH();
 
   // ------------------------------------------------------------------ write this workgroup's slab
-  float* slab = a.slab + ((long)k * a.G + gi) * a.slab_stride;
+  float* slab = a.slab + ((long)k * n_slots + sslot) * a.slab_stride;
   const Layout& L = a.L;
   {
     // reference column of the staged input row this lane's accumulator column stands for
@@ -925,9 +948,10 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
     else if (i < 192) slab[L.oc_w + i - 96] = v;
     else if (i == 192) slab[L.a_b] = v;
     else if (i < 196) slab[L.oc_b + i - 193] = v;
-    else if (i < 200) a.loss_part[((long)k * a.G + gi) * 4 + (i - 196)] = v;
+    else if (i < 200) a.loss_part[((long)k * n_slots + sslot) * 4 + (i - 196)] = v;
     else if (i - 200 < 3 * OBJ_NDIR) slab[L.pe_b + (i - 200)] = v;       // [4 i + g][x] = B's own row-major order
   }
+  }      // segments
 }
 
 }  // namespace
@@ -946,7 +970,7 @@ void launch_train32(const TrainDev& d, void* stream, bool feat) {
     (void)hipFuncSetAttribute((const void*)train_fused32_kernel<true, false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, n1);
     (void)hipFuncSetAttribute((const void*)train_fused32_kernel<true, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, n1);
   });
-  const dim3 grid(d.K * d.G), blk(NTHR);
+  const dim3 grid(d.flat_nwg ? d.flat_nwg : d.K * d.G), blk(NTHR);
   hipStream_t st = (hipStream_t)stream;
   if (feat) {
     if (d.relu_masks || d.emb_debug) hipLaunchKernelGGL((train_fused32_kernel<true, true, 0>), grid, blk, n1, st, d);

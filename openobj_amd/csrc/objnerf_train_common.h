@@ -20,9 +20,14 @@ struct TrainDev {
   const float* pts; const float* origins; const float* dirs; const float* z;
   const float* gt_depth; const float* gt_rgb; const uint8_t* labels; const float* gt_feat;
   const int* counts; const int* flags;
-  float* slab;        // [K][G][slab_stride]
+  float* slab;        // [K][G][slab_stride]  (flat mode: [K][Gs][slab_stride])
   long slab_stride;
   float* loss_part;   // [K][G][4]
+  // Work distribution.  flat_nwg == 0: workgroup (k, gi) sweeps tiles gi, gi + G, ... of object k.  flat_nwg > 0 (the
+  // second-generation fp32 kernel): workgroup b of flat_nwg takes the b-th share of the flat (object, tile) space --
+  // one to a few segments (object, [t0, t1)) -- so that every CU carries the same number of tiles whatever K is
+  // (K = 50 on 256 CUs: 400 tiles each instead of 410 on 250 of them); an object has at most Gs partial slabs.
+  int flat_nwg, Gs;
   // feature-distillation branch (gt_feat != NULL)
   const float* rayin;   // [K][R][RAYIN]  u = W_of^T g (32), beta = b_of . g, |g|     (feat_pre_kernel)
   const float* gram;    // [K][GRAM]      G = W_of^T W_of (32x32), wb = W_of^T b_of (32), b_of . b_of
@@ -32,6 +37,8 @@ struct TrainDev {
   Layout L;
 };
 constexpr int RAYIN = 34, GRAM = 1088, RAYFEAT = 36;
+// flat mode: the workgroup whose share [T b / nwg, T (b + 1) / nwg) holds flat tile x
+__host__ __device__ inline int flat_wg_of(const long T, const int nwg, const long x) { return (int)(((x + 1) * nwg - 1) / T); }
 // LDS aliases inside the staging area, valid from the forward pass until phase B of the backward pass
 constexpr int HF_LD = 33;                       // hfbuf [128][33] at stg + 0
 constexpr int OFF_GBUF = TS * HF_LD;            // G [32][33], wb [32], bb          (4224 ..)
