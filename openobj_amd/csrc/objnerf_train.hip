@@ -1031,8 +1031,10 @@ static int train_grid(int K, int NT) {
 // Flat mode of the second-generation fp32 kernel (objnerf_train_common.h): one workgroup per CU, equal shares of the flat
 // (object, tile) space.  Taken when its longest workgroup (tiles + a fixed cost per segment) beats the strided grid's and
 // an object's partial slabs fit the workspace (grid_cap(K) slots).
-static void choose_flat(TrainDev& d, int K) {
-  constexpr long TILE_EQUIV = 4;
+// tile_equiv: the fixed cost of a segment (LDS clear, weight staging, slab write + reduction) in tiles: ~4 for the fp32
+// kernel (22 us per tile).  The bf16 kernel stays on the strided grid: its segment costs ~10 of its 7-us tiles, and
+// wrapping its body in the segment loop alone cost 3.5 % (measured: 2.74 -> 2.83 ms strided, 2.79 flat).
+static void choose_flat(TrainDev& d, int K, const long TILE_EQUIV) {
   const int cu = num_cu();
   const long T = (long)K * d.NT;
   if (T < cu) return;
@@ -1163,7 +1165,7 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
     else if (d.relu_masks) hipLaunchKernelGGL((train_fused_kernel<true, true>), dim3(a->K * d.G), dim3(NTHR), lds_bytes, st, d);
     else hipLaunchKernelGGL((train_fused_kernel<true, false>), dim3(a->K * d.G), dim3(NTHR), lds_bytes, st, d);
 #else
-    else { choose_flat(d, a->K); launch_train32(d, stream, true); }
+    else { choose_flat(d, a->K, 4); launch_train32(d, stream, true); }
     (void)lds_bytes;
 #endif
     if (hipGetLastError() != hipSuccess) return OBJNERF_ELAUNCH;
@@ -1181,7 +1183,7 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
   } else if (bf16) {
     launch_train_bf16(d, stream, false);
   } else {
-    choose_flat(d, a->K);
+    choose_flat(d, a->K, 4);
     launch_train32(d, stream, false);
   }
   if (hipGetLastError() != hipSuccess) return OBJNERF_ELAUNCH;
