@@ -900,6 +900,80 @@ __global__ __launch_bounds__(256) void feat_rowstats_kernel(const float* params,
     o[33] = sqrtf(gs);
   }
 }
+// The same three quantities in ONE pass over gt_feat (round 3): rayin[r] = [u (32) | beta | |g|] with u = W_of^T g[r],
+// beta = b_of . g[r].  A workgroup of 8 waves takes 128 rays; [W_of | b_of] sits in LDS as the B operand of
+// v_mfma_f32_16x16x4_f32 (three 16-column tiles: u, u, beta + padding); a lane streams ITS ray's features as float4 --
+// k-step j of block s uses feature 16 s + 4 q + j, a permutation of the contraction both operands share -- and squares
+// them on the way for |g|.  gt_feat is read once instead of twice (GEMM + feat_rowstats_kernel: 240 + 101 us at
+// K = 50, R = 4096 -> ~100 us).  C <= 512, C % 16 == 0.
+constexpr int FEAT_PRE_MAXC = 512;
+__global__ __launch_bounds__(512) void feat_pre_kernel(const float* __restrict__ params, long p_stride, int off_w, int off_b,
+                                                       int C, int R, const float* __restrict__ gt_feat,
+                                                       float* __restrict__ rayin) {
+  extern __shared__ __attribute__((aligned(16))) float fp_lds[];       // [C / 16][3][64][4]
+  const int k = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int n = lane & 15, q = lane >> 4;
+  const float* W = params + (long)k * p_stride + off_w;
+  const float* Bv = params + (long)k * p_stride + off_b;
+  const int nblk = C / 16;
+  // B image: W_of row-major [c][h] read coalesced, scattered into (block c >> 4, tile h >> 4, lane (h & 15) + 16 ((c >> 2) & 3),
+  // element c & 3); tile 2 = [b_of | 0 ...]
+  for (int i = tid; i < C * 32; i += 512) {
+    const int c = i >> 5, hc = i & 31;
+    fp_lds[(((c >> 4) * 3 + (hc >> 4)) * 64 + (hc & 15) + 16 * ((c >> 2) & 3)) * 4 + (c & 3)] = W[i];
+  }
+  for (int i = tid; i < C * 16; i += 512) {
+    const int c = i >> 4, nn = i & 15;
+    fp_lds[(((c >> 4) * 3 + 2) * 64 + nn + 16 * ((c >> 2) & 3)) * 4 + (c & 3)] = nn == 0 ? Bv[c] : 0.0f;
+  }
+  __syncthreads();
+  const f32x4* bl = reinterpret_cast<const f32x4*>(fp_lds) + lane;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  constexpr int PF = 8;                                                 // float4 loads in flight per lane: 8 blocks ahead
+  for (long t0 = (long)blockIdx.x * 128; t0 < R; t0 += (long)gridDim.x * 128) {
+    const long r = t0 + 16 * w + n;                                     // this lane's ray (as A row)
+    const bool on = r < R;
+    const float* gp = gt_feat + ((long)k * R + (on ? r : 0)) * C + 4 * q;
+    f32x4 acc0 = zero, acc1 = zero, acc2 = zero;
+    float gs = 0.f;
+    f32x4 buf[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) buf[i] = (on && i < nblk) ? *reinterpret_cast<const f32x4*>(gp + 16 * i) : zero;
+    for (int s0 = 0; s0 < nblk; s0 += PF) {
+#pragma unroll
+      for (int i = 0; i < PF; ++i) {
+        const int sblk = s0 + i;
+        const f32x4 av = buf[i];
+        buf[i] = (on && sblk + PF < nblk) ? *reinterpret_cast<const f32x4*>(gp + 16 * (sblk + PF)) : zero;
+        if (sblk < nblk) {
+          const f32x4 b0 = bl[(sblk * 3 + 0) * 64], b1 = bl[(sblk * 3 + 1) * 64], b2 = bl[(sblk * 3 + 2) * 64];
+          gs = fmaf(av[3], av[3], fmaf(av[2], av[2], fmaf(av[1], av[1], fmaf(av[0], av[0], gs))));
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], b0[j], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], b1[j], acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], b2[j], acc2, 0, 0, 0);
+          }
+        }
+      }
+    }
+    // |g|^2: the four lanes (q) of a ray
+    gs += __shfl_xor(gs, 16, 64);
+    gs += __shfl_xor(gs, 32, 64);
+    if (on && q == 0) rayin[((long)k * R + r) * RAYIN + 33] = sqrtf(gs);
+    // D: lane (n, q) register rr = row 4 q + rr (ray), column n
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const long ro = t0 + 16 * w + 4 * q + rr;
+      if (ro < R) {
+        float* o = rayin + ((long)k * R + ro) * RAYIN;
+        o[n] = acc0[rr];
+        o[16 + n] = acc1[rr];
+        if (n == 0) o[32] = acc2[rr];
+      }
+    }
+  }
+}
 // post: the fused kernel left (fh[32], O, a, c) per ray.  d W_of = sum_r (a_r g_r + c_r F_r) fh_r^T with
 // F_r = W_of fh_r + b_of O_r, so  d W_of = gt_feat^T [a fh] + W_of M2 + b_of m1^T  and
 // d b_of = gt_feat^T [a O] + W_of m1 + b_of s2  with the moments  [M2 m1; . s2] = [c fh | c O]^T [fh | O].
@@ -1156,10 +1230,24 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
   if (feat) {
     objgen::feat_gram(stream, a->K, a->params, (long)a->p_stride, d.L.of_w, d.L.of_b, C, 32, gram, GRAM);
     // u = gt_feat W_of  ([R x C] [C x 32] per object) on the batched MFMA GEMM; beta, |g| beside it
-    objgen::gemm_f32(stream, a->K, a->R, 32, C, a->gt_feat, C, 1, (long)a->R * C, a->params + d.L.of_w, 32, 1,
-                     (long)a->p_stride, rayin, RAYIN, 1, (long)a->R * RAYIN, false);
-    hipLaunchKernelGGL(feat_rowstats_kernel, dim3((a->R + 15) / 16, a->K), dim3(256), 0, st, a->params,
-                       (long)a->p_stride, d.L.of_b, C, a->R, a->gt_feat, rayin);
+    if (C <= FEAT_PRE_MAXC && C % 16 == 0) {
+      // u, beta, |g| in one pass over gt_feat (feat_pre_kernel)
+      const size_t pre_lds = (size_t)(C / 16) * 3 * 64 * 4 * sizeof(float);
+      objnerf_once_per_device([] {
+        (void)hipFuncSetAttribute((const void*)feat_pre_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)((FEAT_PRE_MAXC / 16) * 3 * 64 * 4 * sizeof(float)));
+      });
+      int gpo = num_cu() / a->K;                  // workgroups per object: one round of the chip, each sweeping ray tiles
+      if (gpo < 1) gpo = 1;
+      if (gpo > (a->R + 127) / 128) gpo = (a->R + 127) / 128;
+      hipLaunchKernelGGL(feat_pre_kernel, dim3(gpo, a->K), dim3(512), pre_lds, st, a->params, (long)a->p_stride,
+                         d.L.of_w, d.L.of_b, C, a->R, a->gt_feat, rayin);
+    } else {
+      objgen::gemm_f32(stream, a->K, a->R, 32, C, a->gt_feat, C, 1, (long)a->R * C, a->params + d.L.of_w, 32, 1,
+                       (long)a->p_stride, rayin, RAYIN, 1, (long)a->R * RAYIN, false);
+      hipLaunchKernelGGL(feat_rowstats_kernel, dim3((a->R + 15) / 16, a->K), dim3(256), 0, st, a->params,
+                         (long)a->p_stride, d.L.of_b, C, a->R, a->gt_feat, rayin);
+    }
     if (bf16) launch_train_bf16(d, stream, true);
 #ifdef OBJ_FEAT_GEN1      // diagnostic builds: the first-generation feature kernel (tools/build_variant.sh)
     else if (d.relu_masks) hipLaunchKernelGGL((train_fused_kernel<true, true>), dim3(a->K * d.G), dim3(NTHR), lds_bytes, st, d);
