@@ -989,20 +989,128 @@ __global__ void feat_scale_kernel(long n, const float* rayfeat, float* X1, float
   X1[i] = rf[33] * v;
   X2[i] = rf[34] * v;
 }
+// post, round 3: the same sums in ONE pass over gt_feat, straight from the fused kernel's per-ray record (fh[32], O, a, c)
+// -- no X1 / X2 copies, no split-K GEMM launches, no zero fills.  Workgroup (g, k) takes the g-th chunk of object k's
+// rays; wave w owns target-feature block [64 w, 64 w + 64).  v_mfma_f32_16x16x4_f32 with the RAY as contraction index:
+// A lane (i, q) streams gt_feat[ray 4 s + q][64 w + 4 i + j] as float4 (element j = the A operand of MFMA j, whose
+// output rows are the features 64 w + 4 m + j), B lane (n, q) = a_r [fh | O][16 t + n] for the three column tiles ->
+// T = gt_feat^T [a fh | a O].  The moments M = [c fh | c O]^T [fh | O] ride along: the B values of a lane are also its A
+// values (same lane index), each wave takes every eighth ray quad, the partial tiles meet in LDS.  Partials
+// Tpart [K][G][C][33], Mpart [K][G][33][33] are summed by feat_finish_kernel.  C == 512.
+__global__ __launch_bounds__(512) void feat_post_kernel(int C, int R, const float* __restrict__ gt_feat,
+                                                        const float* __restrict__ rayfeat, float* __restrict__ Tpart,
+                                                        float* __restrict__ Mpart) {
+  __shared__ float s_m[8][9][64][4];                   // per wave: 3 x 3 moment tiles as D fragments
+  const int k = blockIdx.y, g = blockIdx.x, G = gridDim.x;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const long r_lo = (long)R * g / G, r_hi = (long)R * (g + 1) / G;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[4][3], macc[3][3];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int t = 0; t < 3; ++t) acc[j][t] = zero;
+#pragma unroll
+  for (int a_ = 0; a_ < 3; ++a_)
+#pragma unroll
+    for (int b_ = 0; b_ < 3; ++b_) macc[a_][b_] = zero;
+  const float* gbase = gt_feat + (long)k * R * C + 64 * w + 4 * i;
+  const float* fbase = rayfeat + (long)k * R * RAYFEAT;
+  const long nq = (r_hi - r_lo + 3) / 4;               // ray quads of this chunk
+  constexpr int PF = 6;
+  f32x4 abuf[PF];
+  float fb[PF][5];                                     // fh[i], fh[16 + i], O, a, c of this lane's ray
+  auto fetch = [&](const long sq, f32x4& av, float (&f)[5]) {
+    const long r = r_lo + 4 * sq + q;
+    if (sq < nq && r < r_hi) {
+      av = *reinterpret_cast<const f32x4*>(gbase + r * C);
+      const float* rf = fbase + r * RAYFEAT;
+      f[0] = rf[i]; f[1] = rf[16 + i]; f[2] = rf[32]; f[3] = rf[33]; f[4] = rf[34];
+    } else {
+      av = zero; f[0] = f[1] = f[2] = f[3] = f[4] = 0.f;
+    }
+  };
+#pragma unroll
+  for (int p = 0; p < PF; ++p) fetch(p, abuf[p], fb[p]);
+  for (long s0 = 0; s0 < nq; s0 += PF) {
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+      const long sq = s0 + p;
+      const f32x4 av = abuf[p];
+      const float f0 = fb[p][0], f1 = fb[p][1], f2 = i == 0 ? fb[p][2] : 0.0f, ar = fb[p][3], cr = fb[p][4];
+      fetch(sq + PF, abuf[p], fb[p]);
+      if (sq < nq) {
+        const float x0 = ar * f0, x1 = ar * f1, x2 = ar * f2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], x0, acc[j][0], 0, 0, 0);
+          acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], x1, acc[j][1], 0, 0, 0);
+          acc[j][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], x2, acc[j][2], 0, 0, 0);
+        }
+        if ((int)(sq & 7) == w) {                      // (wave-uniform) this wave's share of the moments
+          const float y0 = cr * f0, y1 = cr * f1, y2 = cr * f2;
+          macc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(y0, f0, macc[0][0], 0, 0, 0);
+          macc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(y0, f1, macc[0][1], 0, 0, 0);
+          macc[0][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(y0, f2, macc[0][2], 0, 0, 0);
+          macc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(y1, f0, macc[1][0], 0, 0, 0);
+          macc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(y1, f1, macc[1][1], 0, 0, 0);
+          macc[1][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(y1, f2, macc[1][2], 0, 0, 0);
+          macc[2][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(y2, f0, macc[2][0], 0, 0, 0);
+          macc[2][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(y2, f1, macc[2][1], 0, 0, 0);
+          macc[2][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(y2, f2, macc[2][2], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // T partial: D lane (n = i, q) register rr of MFMA j = T[c = 64 w + 4 (4 q + rr) + j][16 t + n]
+  float* Tp = Tpart + ((long)k * G + g) * C * XCOLS;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      float* row = Tp + (long)(64 * w + 4 * (4 * q + rr) + j) * XCOLS;
+      row[i] = acc[j][0][rr];
+      row[16 + i] = acc[j][1][rr];
+      if (i == 0) row[32] = acc[j][2][rr];
+    }
+  // moments: sum the eight waves' partial tiles
+#pragma unroll
+  for (int a_ = 0; a_ < 3; ++a_)
+#pragma unroll
+    for (int b_ = 0; b_ < 3; ++b_)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) s_m[w][3 * a_ + b_][lane][rr] = macc[a_][b_][rr];
+  __syncthreads();
+  float* Mp = Mpart + ((long)k * G + g) * XCOLS * XCOLS;
+  for (int e = tid; e < 9 * 64 * 4; e += 512) {
+    const int rr = e & 3, ln = (e >> 2) & 63, tile = e >> 8;
+    float v = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < 8; ++ww) v += s_m[ww][tile][ln][rr];
+    const int m = 16 * (tile / 3) + 4 * (ln >> 4) + rr, nn = 16 * (tile % 3) + (ln & 15);
+    if (m < XCOLS && nn < XCOLS) Mp[m * XCOLS + nn] = v;
+  }
+}
 // d W_of[c][h] = T[c][h] + sum_j W_of[c][j] M2[j][h] + b_of[c] m1[h];  d b_of[c] = T[c][32] + W_of[c] . m1 + b_of[c] s2
 __global__ __launch_bounds__(256) void feat_finish_kernel(const float* params, long p_stride, int off_w, int off_b, int C,
-                                                          const float* Tm /* [K][C][33] */,
-                                                          const float* mom /* [K][33][33] */, float* grads) {
+                                                          const float* Tm /* [K][G][C][33] */,
+                                                          const float* mom /* [K][G][33][33] */, float* grads, int G) {
   __shared__ float M[XCOLS][XCOLS];
   const int k = blockIdx.y;
-  for (int i = threadIdx.x; i < XCOLS * XCOLS; i += 256) M[i / XCOLS][i % XCOLS] = mom[(long)k * XCOLS * XCOLS + i];
+  for (int i = threadIdx.x; i < XCOLS * XCOLS; i += 256) {
+    float v = 0.f;
+    for (int g = 0; g < G; ++g) v += mom[((long)k * G + g) * XCOLS * XCOLS + i];
+    M[i / XCOLS][i % XCOLS] = v;
+  }
   __syncthreads();
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= C * XCOLS) return;
   const int cc = i / XCOLS, hh = i - cc * XCOLS;
   const float* W = params + (long)k * p_stride + off_w + cc * 32;
   const float bc = params[(long)k * p_stride + off_b + cc];
-  float v = Tm[(long)k * C * XCOLS + i];
+  float v = 0.f;
+  for (int g = 0; g < G; ++g) v += Tm[((long)k * G + g) * C * XCOLS + i];
   if (hh < 32) {
     for (int j = 0; j < 32; ++j) v = fmaf(W[j], M[j][hh], v);              // M2[j][h]  (c fh_j . fh_h)
     grads[(long)k * p_stride + off_w + cc * 32 + hh] = fmaf(bc, M[32][hh], v);   // m1[h] = (c O) . fh_h
@@ -1259,15 +1367,29 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
     if (hipGetLastError() != hipSuccess) return OBJNERF_ELAUNCH;
     // 512-d head gradient from the per-ray (fh, O, a, c): two split-K GEMMs over the rays + a small finish
     const long nr = (long)a->K * a->R;
-    hipLaunchKernelGGL(feat_scale_kernel, dim3((unsigned)((nr * XCOLS + 255) / 256)), dim3(256), 0, st, nr, rayfeat, X1, X2);
-    (void)hipMemsetAsync(Tm, 0, ((size_t)a->K * C * XCOLS + (size_t)a->K * XCOLS * XCOLS) * 4, st);
-    objgen::wgrad_f32(stream, a->K, C, XCOLS, a->R, a->gt_feat, 1, C, (long)a->R * C, X1, XCOLS, 1, (long)a->R * XCOLS, Tm,
-                      XCOLS, (long)C * XCOLS, parts_t, objgen::wgrad_parts_floats(a->K, C, XCOLS, a->R));
-    objgen::wgrad_f32(stream, a->K, XCOLS, XCOLS, a->R, X2, 1, XCOLS, (long)a->R * XCOLS, rayfeat, RAYFEAT, 1,
-                      (long)a->R * RAYFEAT, mom, XCOLS, (long)XCOLS * XCOLS, parts_m,
-                      objgen::wgrad_parts_floats(a->K, XCOLS, XCOLS, a->R));
+    int gpo = num_cu() / a->K;                    // ray chunks per object: one round of the chip
+    if (gpo < 1) gpo = 1;
+    if (gpo > 8) gpo = 8;
+    while (gpo > 1 && (size_t)gpo * ((size_t)C * XCOLS + XCOLS * XCOLS) > (size_t)a->R * XCOLS) --gpo;   // partials live in X1's room
+    const bool one_pass = C == 512 && (size_t)gpo * ((size_t)C * XCOLS + XCOLS * XCOLS) <= (size_t)a->R * XCOLS;
+    int Gfin = 1;
+    const float *Tsrc = Tm, *Msrc = mom;
+    if (one_pass) {
+      float* Tpart = X1;
+      float* Mpart = X1 + (size_t)a->K * gpo * C * XCOLS;
+      hipLaunchKernelGGL(feat_post_kernel, dim3(gpo, a->K), dim3(512), 0, st, C, a->R, a->gt_feat, rayfeat, Tpart, Mpart);
+      Gfin = gpo; Tsrc = Tpart; Msrc = Mpart;
+    } else {
+      hipLaunchKernelGGL(feat_scale_kernel, dim3((unsigned)((nr * XCOLS + 255) / 256)), dim3(256), 0, st, nr, rayfeat, X1, X2);
+      (void)hipMemsetAsync(Tm, 0, ((size_t)a->K * C * XCOLS + (size_t)a->K * XCOLS * XCOLS) * 4, st);
+      objgen::wgrad_f32(stream, a->K, C, XCOLS, a->R, a->gt_feat, 1, C, (long)a->R * C, X1, XCOLS, 1, (long)a->R * XCOLS, Tm,
+                        XCOLS, (long)C * XCOLS, parts_t, objgen::wgrad_parts_floats(a->K, C, XCOLS, a->R));
+      objgen::wgrad_f32(stream, a->K, XCOLS, XCOLS, a->R, X2, 1, XCOLS, (long)a->R * XCOLS, rayfeat, RAYFEAT, 1,
+                        (long)a->R * RAYFEAT, mom, XCOLS, (long)XCOLS * XCOLS, parts_m,
+                        objgen::wgrad_parts_floats(a->K, XCOLS, XCOLS, a->R));
+    }
     hipLaunchKernelGGL(feat_finish_kernel, dim3((C * XCOLS + 255) / 256, a->K), dim3(256), 0, st, a->params,
-                       (long)a->p_stride, d.L.of_w, d.L.of_b, C, Tm, mom, a->grads);
+                       (long)a->p_stride, d.L.of_w, d.L.of_b, C, Tsrc, Msrc, a->grads, Gfin);
   } else if (bf16) {
     launch_train_bf16(d, stream, false);
   } else {
