@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define OBJNERF_ABI_VERSION 5
+#define OBJNERF_ABI_VERSION 6
 
 #define OBJNERF_OK 0
 #define OBJNERF_EINVAL (-22)       /* bad shape / null pointer / unsupported size        */
@@ -111,6 +111,15 @@ typedef struct objnerf_sample_args {
   uint64_t seed; uint32_t draw; uint32_t reserved;
   const int32_t* kf_meta; int64_t* out_kf; int32_t* out_px;
   float* out_origins; float* out_dirs;
+  /* ABI 6 -- the part-level feature gather of vmap.py:437-452 inside the same launch (out_partfeat == NULL: off).
+   * global_partfeat [pf_frames][pf_w][pf_h][pf_c] fp32: the scene's part-feature maps (train.py:378), one per used
+   * dataset frame; use_frame [F] int32: dataset frame id of every keyframe slot (vmap.py:108,199-231; stacked call:
+   * [K][F]); the ray's source row is frame trunc(use_frame[kf] / pf_stride) (float64 quotient, :440), pixel
+   * (floor(idx_w / part_down), floor(idx_h / part_down)) with the FLOAT pixel index divided in fp32 (:441-442).
+   * out_partfeat [n][pf_c] (stacked: [K][n][pf_c]) is written once, a wave per ray, 16-byte lanes.  Indices outside
+   * the map are clamped (the reference raises IndexError; the host wrapper checks the frame range). */
+  const float* global_partfeat; const int32_t* use_frame; float* out_partfeat;
+  int32_t pf_frames, pf_w, pf_h, pf_c, pf_stride; float part_down;
 } objnerf_sample_args;
 int objnerf_sample_rays(const objnerf_sample_args* a, void* stream);
 

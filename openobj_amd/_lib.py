@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OBJNERF_LIB") or os.path.join(_HERE, "csrc", "libobjnerf_hip.so")   # OBJNERF_LIB: diagnostic builds
 
 OBJNERF_N_TENSORS = 19
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class ObjnerfError(RuntimeError):
@@ -46,7 +46,11 @@ class SampleArgs(C.Structure):
                 ("max_depth_ws", C.c_void_p),
                 ("seed", C.c_uint64), ("draw", C.c_uint32), ("reserved", C.c_uint32),
                 ("kf_meta", C.c_void_p), ("out_kf", C.c_void_p), ("out_px", C.c_void_p),
-                ("out_origins", C.c_void_p), ("out_dirs", C.c_void_p)]
+                ("out_origins", C.c_void_p), ("out_dirs", C.c_void_p),
+                # ABI 6: the part-feature gather (vmap.py:437-452)
+                ("global_partfeat", C.c_void_p), ("use_frame", C.c_void_p), ("out_partfeat", C.c_void_p),
+                ("pf_frames", C.c_int32), ("pf_w", C.c_int32), ("pf_h", C.c_int32), ("pf_c", C.c_int32),
+                ("pf_stride", C.c_int32), ("part_down", C.c_float)]
 
 
 class IngestItem(C.Structure):

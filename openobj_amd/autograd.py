@@ -10,13 +10,30 @@ import torch
 from . import ops
 
 
+def _check_inputs(arena, params, what):
+    for p in params:
+        if torch.is_tensor(p) and not arena.owns(p):
+            raise ValueError(f"{what}: a parameter tensor is not a view of the arena the kernels read")
+
+
+def _check_unmodified(ctx, what):
+    """backward() recomputes from the LIVE arena (only emb / pts are saved): an optimiser step, a copy-in or a scale
+    change between forward and backward would give silently wrong gradients where torch raises on a modified saved
+    tensor -- so does this."""
+    if ctx.arena.state_version() != ctx.arena_version:
+        raise RuntimeError(f"{what}: one of the variables needed for gradient computation has been modified by an "
+                           "inplace operation (the parameter arena or its scale changed between forward and backward)")
+
+
 class MlpFunction(torch.autograd.Function):
     """OccupancyMap.forward (model.py:61-103) of K stacked networks: emb [K,N,129] -> alpha [K,N], color [K,N,3],
     clip [K,N,C] (or an empty tensor).  `stacked`: params carry the leading K axis (vmap) or not (one module)."""
 
     @staticmethod
     def forward(ctx, arena, want_clip, stacked, emb, *params):
+        _check_inputs(arena, params, "MlpFunction")
         alpha, color, _, clip = ops.mlp_forward(arena, emb, want_clip=want_clip)
+        ctx.arena_version = arena.state_version()
         ctx.arena, ctx.want_clip, ctx.stacked, ctx.n_params = arena, want_clip, stacked, len(params)
         ctx.save_for_backward(emb)
         ctx.set_materialize_grads(False)
@@ -24,6 +41,7 @@ class MlpFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_alpha, d_color, d_clip):
+        _check_unmodified(ctx, "MlpFunction")
         (emb,) = ctx.saved_tensors
         K, N = emb.shape[0], emb.shape[1]
         if d_alpha is None:
@@ -49,7 +67,9 @@ class EmbedFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, arena, stacked, pts, B):
+        _check_inputs(arena, (B,), "EmbedFunction")
         ctx.arena, ctx.stacked = arena, stacked
+        ctx.arena_version = arena.state_version()
         ctx.save_for_backward(pts)
         return ops.embed(arena, pts)
 
@@ -57,6 +77,7 @@ class EmbedFunction(torch.autograd.Function):
     def backward(ctx, d_emb):
         if ctx.needs_input_grad[2]:
             raise NotImplementedError("gradient w.r.t. the sample positions is not part of the training path")
+        _check_unmodified(ctx, "EmbedFunction")
         (pts,) = ctx.saved_tensors
         d_B = ops.embed_backward(ctx.arena, pts, d_emb.contiguous())
         return None, None, None, (d_B if ctx.stacked else d_B[0])

@@ -480,6 +480,7 @@ __device__ __forceinline__ objnerf_sample_args sample_args_of(const objnerf_samp
     if (b.out_kf) b.out_kf += (long)k * a.n_frames;
     if (b.out_px) b.out_px += k * n * 2;
     if (b.out_origins) { b.out_origins += k * n * 3; b.out_dirs += k * n * 3; }
+    if (b.out_partfeat) { b.out_partfeat += k * n * b.pf_c; b.use_frame += (long)k * a.F; }
     if (b.out_pts) b.out_pts += k * n * S * 3;
     b.obj_index = a.obj_index + k;
     b.out_rgb += k * n * 3; b.out_depth += k * n; b.out_valid += k * n; b.out_labels += k * n;
@@ -490,54 +491,81 @@ __device__ __forceinline__ objnerf_sample_args sample_args_of(const objnerf_samp
   return b;
 }
 
-__global__ void sample_gather_kernel(const objnerf_sample_args a_, const objnerf_kf_store* table) {
+__global__ __launch_bounds__(256) void sample_gather_kernel(const objnerf_sample_args a_, const objnerf_kf_store* table) {
   const objnerf_sample_args a = sample_args_of(a_, table, blockIdx.y);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = a.n_frames * a.n_px;
-  if (i >= n) return;
-  float* origins_ws = a.out_origins ? a.out_origins : a.max_depth_ws + 1;
-  float* dirs_ws = a.out_origins ? a.out_dirs : a.max_depth_ws + 1 + (size_t)n * 3;
-  const int f = i / a.n_px;
-  const uint32_t tag = (uint32_t)a.draw << 3;
-  long kf;
-  if (a.kf_ids) {
-    kf = a.kf_ids[f];
-  } else {                                                       // vmap.py:390-401
-    const int nk = a.kf_meta[0];
-    const int tail = f - (a.n_frames - 2);                       // 0 / 1 for the last two frames of the draw
-    if (tail >= 0 && a.kf_meta[1 + tail] >= 0) {
-      kf = a.kf_meta[1 + tail];
-    } else {
-      const float uk = objrng::uniform1(a.seed, objrng::S_KEYFRAME | tag, (uint32_t)a.obj_index, 0u, (uint32_t)f);
-      kf = min((int)(uk * (float)nk), nk - 1);
+  __shared__ long pf_row[256];                                   // source row of every ray of the block (part features)
+  if (i < n) {
+    float* origins_ws = a.out_origins ? a.out_origins : a.max_depth_ws + 1;
+    float* dirs_ws = a.out_origins ? a.out_dirs : a.max_depth_ws + 1 + (size_t)n * 3;
+    const int f = i / a.n_px;
+    const uint32_t tag = (uint32_t)a.draw << 3;
+    long kf;
+    if (a.kf_ids) {
+      kf = a.kf_ids[f];
+    } else {                                                       // vmap.py:390-401
+      const int nk = a.kf_meta[0];
+      const int tail = f - (a.n_frames - 2);                       // 0 / 1 for the last two frames of the draw
+      if (tail >= 0 && a.kf_meta[1 + tail] >= 0) {
+        kf = a.kf_meta[1 + tail];
+      } else {
+        const float uk = objrng::uniform1(a.seed, objrng::S_KEYFRAME | tag, (uint32_t)a.obj_index, 0u, (uint32_t)f);
+        kf = min((int)(uk * (float)nk), nk - 1);
+      }
+      if (a.out_kf && i == f * a.n_px) a.out_kf[f] = kf;
     }
-    if (a.out_kf && i == f * a.n_px) a.out_kf[f] = kf;
+    const float* bb = a.bbox + kf * 4;
+    float uw, uh;
+    if (a.u_w) {
+      uw = a.u_w[i]; uh = a.u_h[i];
+    } else {
+      float r4[4];
+      objrng::uniform4(a.seed, objrng::S_PIXEL_W | tag, (uint32_t)a.obj_index, (uint32_t)i, 0u, r4);
+      uw = r4[0]; uh = r4[1];
+    }
+    const float fw = uw * (bb[1] - bb[0]) + bb[0];
+    const float fh = uh * (bb[3] - bb[2]) + bb[2];
+    const long iw = (long)fw, ih = (long)fh;                       // .long() truncation (vmap.py:418-419)
+    if (a.out_px) { a.out_px[2 * i] = (int)iw; a.out_px[2 * i + 1] = (int)ih; }
+    const long pix = (kf * a.W + iw) * a.H + ih;
+    const uint8_t* px = a.rgbs + pix * 4;
+    a.out_rgb[i * 3] = px[0]; a.out_rgb[i * 3 + 1] = px[1]; a.out_rgb[i * 3 + 2] = px[2];
+    a.out_labels[i] = px[3];
+    const float d = a.depth[pix];
+    a.out_depth[i] = d;
+    atomicMax((int*)a.max_depth_ws, __float_as_int(fmaxf(d, 0.0f)));
+    const float* dc = a.rays_dir_cache + (iw * a.H + ih) * 3;
+    const float* T = a.t_wc + kf * 16;
+    for (int r = 0; r < 3; ++r) {
+      dirs_ws[i * 3 + r] = fmaf(T[r * 4 + 2], dc[2], fmaf(T[r * 4 + 1], dc[1], T[r * 4] * dc[0]));
+      origins_ws[i * 3 + r] = T[r * 4 + 3];
+    }
+    if (a.out_partfeat) {                                          // vmap.py:437-452
+      long fid = (long)((double)a.use_frame[kf] / (double)a.pf_stride);          // :439-440 (float64, truncated)
+      long pw = (long)floorf(fw / a.part_down), ph = (long)floorf(fh / a.part_down);   // :441-442 (fp32 quotient)
+      fid = min(max(fid, 0l), (long)a.pf_frames - 1);
+      pw = min(max(pw, 0l), (long)a.pf_w - 1);
+      ph = min(max(ph, 0l), (long)a.pf_h - 1);
+      pf_row[threadIdx.x] = (fid * a.pf_w + pw) * a.pf_h + ph;
+    }
   }
-  const float* bb = a.bbox + kf * 4;
-  float uw, uh;
-  if (a.u_w) {
-    uw = a.u_w[i]; uh = a.u_h[i];
-  } else {
-    float r4[4];
-    objrng::uniform4(a.seed, objrng::S_PIXEL_W | tag, (uint32_t)a.obj_index, (uint32_t)i, 0u, r4);
-    uw = r4[0]; uh = r4[1];
-  }
-  const float fw = uw * (bb[1] - bb[0]) + bb[0];
-  const float fh = uh * (bb[3] - bb[2]) + bb[2];
-  const long iw = (long)fw, ih = (long)fh;                       // .long() truncation (vmap.py:418-419)
-  if (a.out_px) { a.out_px[2 * i] = (int)iw; a.out_px[2 * i + 1] = (int)ih; }
-  const long pix = (kf * a.W + iw) * a.H + ih;
-  const uint8_t* px = a.rgbs + pix * 4;
-  a.out_rgb[i * 3] = px[0]; a.out_rgb[i * 3 + 1] = px[1]; a.out_rgb[i * 3 + 2] = px[2];
-  a.out_labels[i] = px[3];
-  const float d = a.depth[pix];
-  a.out_depth[i] = d;
-  atomicMax((int*)a.max_depth_ws, __float_as_int(fmaxf(d, 0.0f)));
-  const float* dc = a.rays_dir_cache + (iw * a.H + ih) * 3;
-  const float* T = a.t_wc + kf * 16;
-  for (int r = 0; r < 3; ++r) {
-    dirs_ws[i * 3 + r] = fmaf(T[r * 4 + 2], dc[2], fmaf(T[r * 4 + 1], dc[1], T[r * 4] * dc[0]));
-    origins_ws[i * 3 + r] = T[r * 4 + 3];
+  if (!a.out_partfeat) return;                                     // (uniform over the launch)
+  __syncthreads();
+  // the block's rows, one wave per ray and 16 bytes per lane: global_partfeat[fid, pw, ph, :] -> out_partfeat[i, :]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int C = a.pf_c;
+  const int r_end = min(256, n - (int)(blockIdx.x * blockDim.x));
+  const bool vec = (C & 3) == 0 && (((size_t)a.global_partfeat | (size_t)a.out_partfeat) & 15) == 0;
+  for (int r = wave; r < r_end; r += 4) {
+    const float* src = a.global_partfeat + pf_row[r] * C;
+    float* dst = a.out_partfeat + ((long)blockIdx.x * blockDim.x + r) * C;
+    if (vec) {
+      typedef float f32x4v __attribute__((ext_vector_type(4)));
+      for (int c = lane; c < C / 4; c += 64) ((f32x4v*)dst)[c] = ((const f32x4v*)src)[c];
+    } else {
+      for (int c = lane; c < C; c += 64) dst[c] = src[c];
+    }
   }
 }
 
@@ -928,6 +956,8 @@ static bool sample_args_ok(const objnerf_sample_args* a) {
   if (!a->kf_ids && (n_inj != 0 || !a->kf_meta)) return false;
   if (!a->out_pts && (!a->out_origins || !a->out_dirs)) return false;
   if ((a->out_origins != nullptr) != (a->out_dirs != nullptr)) return false;
+  if (a->out_partfeat && (!a->global_partfeat || !a->use_frame || a->pf_frames <= 0 || a->pf_w <= 0 || a->pf_h <= 0 ||
+                          a->pf_c <= 0 || a->pf_stride <= 0 || !(a->part_down > 0.0f))) return false;
   return a->rays_dir_cache && a->out_rgb && a->out_depth && a->out_valid && a->out_labels && a->out_z &&
          a->max_depth_ws && a->n_frames > 0 && a->n_px > 0 && a->n_cam2surf > 0 && a->n_bins > 0;
 }

@@ -26,7 +26,7 @@ class UniDirsEmbed(torch.nn.Module):
         with torch.no_grad():
             bview.copy_(icosa_dirs())                       # embedding.py:15-40
         self.B_layer.weight = torch.nn.Parameter(bview)
-        self._arena.scale.fill_(float(scale))
+        self._arena.set_scale(float(scale))
         frequency_bands = 2.0 ** torch.linspace(self.min_deg, self.max_deg, self.n_freqs)
         self.register_buffer("frequency_bands", frequency_bands, persistent=False)
         self.register_buffer("scale", self.tensor_scale, persistent=True)
@@ -34,6 +34,6 @@ class UniDirsEmbed(torch.nn.Module):
     def forward(self, x):
         """x [...,3] -> [..., 3 + 21 * n_freqs] (embedding.py:46-55)."""
         lead = x.shape[:-1]
-        self._arena.scale.fill_(float(self.scale))
+        self._arena.set_scale(float(self.scale))
         emb = EmbedFunction.apply(self._arena, False, x.reshape(1, -1, 3).contiguous(), self.B_layer.weight)
         return emb.reshape(*lead, emb.shape[-1])

@@ -222,13 +222,20 @@ class IncrementalMapper:
                 self._side = torch.cuda.Stream(device=cfg.training_device)
             side = self._side
             side.wait_stream(torch.cuda.current_stream(cfg.training_device))
-        sharded_it = otrain.ShardedIteration(self.loop if pool is not None else None, self.bg_loop, self.group,
-                                             device=cfg.training_device) if sharded else None
+        sharded_it = pre = None
+        if sharded:
+            # the frame's pools are resident and complete: ONE pre-step exchange for all n_iter iterations (early-return
+            # flags of render_rays.py:89-94 and the background's global mask counts), then one collective per
+            # iteration (the background gradient), none of them on the object kernel's critical path
+            sharded_it = otrain.ShardedIteration(self.loop if pool is not None else None, self.bg_loop, self.group,
+                                                 device=cfg.training_device, resident=True)
+            pre = sharded_it.frame_pre(pool["labels"] if pool is not None else None,
+                                       bg_pool["labels"] if bg_pool is not None else None, cfg.n_iter_per_frame)
         for it in range(cfg.n_iter_per_frame):
             batch = {k: v[it] for k, v in pool.items()} if pool is not None else None
             bg_slice = (lambda: {k: v[it] for k, v in bg_pool.items()}) if bg_pool is not None else None
             if sharded:
-                ot, bt = sharded_it.step(batch, bg_slice() if bg_slice is not None else None)
+                ot, bt = sharded_it.step(batch, bg_slice() if bg_slice is not None else None, pre=pre[it])
                 if ot is not None:
                     out["obj"].append(ot.clone())
                 if bt is not None:

@@ -9,6 +9,7 @@ import ctypes as C
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -75,6 +76,27 @@ class ParamArena:
         self.shapes = tensor_shapes(net.hidden, net.feat_dim)
         self.params = torch.zeros(K, self.p_stride, dtype=torch.float32, device=device)
         self.scale = torch.full((K,), 2.0, dtype=torch.float32, device=device)
+        self.version = 0            # bumped by every writer that goes around torch (the kernels write raw pointers)
+
+    def set_scale(self, value: float) -> None:
+        """scale[:] = value, skipped when that is what the last set_scale wrote and nobody has touched the tensor since
+        (a module's forward calls this every time; an unconditional fill_ would count as a modification between the
+        forward and the backward of an earlier call)."""
+        key = (float(value), self.scale._version)
+        if getattr(self, "_scale_set", None) == key:
+            return
+        self.scale.fill_(float(value))
+        self._scale_set = (float(value), self.scale._version)
+
+    def state_version(self):
+        """What an autograd node compares between its forward and its backward (autograd.py): the kernels' own write
+        counter plus torch's in-place counters of the two tensors the kernels read."""
+        return (self.version, self.params._version, self.scale._version)
+
+    def owns(self, t: torch.Tensor) -> bool:
+        """t is a view into this arena's parameter block."""
+        lo = self.params.data_ptr()
+        return t.device == self.params.device and lo <= t.data_ptr() < lo + self.params.numel() * 4
 
     def views(self, buf: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
         buf = self.params if buf is None else buf
@@ -90,6 +112,7 @@ class ParamArena:
         """tensors: 19 stacked [K,...] tensors (18 FC in parameters() order + B)."""
         for v, t in zip(self.views(), tensors):
             v.copy_(t.to(v.device))
+        self.version += 1
 
     def has_grad_mask(self, with_feat: bool) -> torch.Tensor:
         m = torch.ones(self.P, dtype=torch.uint8, device=self.params.device)
@@ -544,13 +567,40 @@ def _sample_common(K, n_frames, n_px, n_cam2surf, n_bins, dev, want_pts, record,
     return o
 
 
+def _partfeat_fields(a: SampleArgs, partfeat, K, F, n, dev, stacked):
+    """ABI 6 fields of the part-feature gather (vmap.py:437-452).  partfeat = (global_partfeat [Fn, Wp, Hp, C] fp32,
+    use_frame [F] | [K, F] (dataset frame id of every keyframe slot), stride, part_down) or None.  Returns the output
+    tensor ([n, C] | [K, n, C]) the launch fills; the frame range is checked here (the reference would raise an
+    IndexError from its advanced indexing, the kernel clamps)."""
+    if partfeat is None:
+        return None
+    gpf, use_frame, stride, part_down = partfeat
+    gpf = _req(gpf, torch.float32, "global_partfeat")
+    if gpf.dim() != 4:
+        raise ObjnerfError("global_partfeat must be [frames, W / part_down, H / part_down, C]")
+    uf = torch.as_tensor(np.asarray(use_frame.cpu() if torch.is_tensor(use_frame) else use_frame))   # host bookkeeping
+    if int(stride) != stride or int(stride) <= 0 or bool((uf != uf.round()).any()):
+        raise ObjnerfError("part features: integer frame ids and stride expected")
+    if uf.numel() != K * F:
+        raise ObjnerfError("use_frame must hold one frame id per keyframe slot")
+    if int(uf.min()) < 0 or int(uf.max()) // int(stride) >= gpf.shape[0]:
+        raise IndexError("use_frame / stride outside global_partfeat")
+    uf = uf.to(torch.int32).contiguous().to(dev)
+    out = torch.empty(*((K,) if stacked else ()), n, gpf.shape[3], device=dev)
+    a.global_partfeat, a.use_frame, a.out_partfeat = _ptr(gpf), _ptr(uf), _ptr(out)
+    a.pf_frames, a.pf_w, a.pf_h, a.pf_c = gpf.shape
+    a.pf_stride, a.part_down = int(stride), float(part_down)
+    a._keep = (gpf, uf)
+    return out
+
+
 def _seed_of(seed):
     return (torch.initial_seed() if seed is None else int(seed)) & (2 ** 64 - 1)
 
 
 def sample_rays_stacked(table: torch.Tensor, F: int, W: int, H: int, rays_dir_cache, kf_ids, u_w, u_h, u, g,
                         n_cam2surf: int, n_bins: int, surface_eps: float, stop_eps: float, min_bound: float = 0.0,
-                        obj_center: float = 0.0):
+                        obj_center: float = 0.0, partfeat=None):
     """sample_rays for K objects in one launch chain, INJECTED draws: kf_ids [K, n_frames], u_w / u_h
     [K, n_frames, n_px], u [K, n, N+M], g [K, n, M].  Returns the STACKED batch tensors (rgb u8 [K,n,3], depth [K,n],
     valid [K,n] bool, labels u8 [K,n], pts [K,n,S,3], z [K,n,S])."""
@@ -571,15 +621,17 @@ def sample_rays_stacked(table: torch.Tensor, F: int, W: int, H: int, rays_dir_ca
                    None, None, None, None, _ptr(rays_dir_cache), _ptr(kf_ids), _ptr(u_w), _ptr(u_h), _ptr(u), _ptr(g),
                    _ptr(o["rgb"]), _ptr(o["depth"]), _ptr(o["valid"]), _ptr(o["labels"]), _ptr(o["z"]), _ptr(o["pts"]),
                    _ptr(o["ws"]), 0, 0, 0, None, None, None, None, None)
+    pf = _partfeat_fields(a, partfeat, K, F, n, table.device, True)
     check(lib().objnerf_sample_rays_stacked(C.byref(a), K, _ptr(table), _stream()), "objnerf_sample_rays_stacked")
-    return o["rgb"], o["depth"], o["valid"].bool(), o["labels"], o["pts"], o["z"]
+    r = (o["rgb"], o["depth"], o["valid"].bool(), o["labels"], o["pts"], o["z"])
+    return r if partfeat is None else r + (pf,)
 
 
 def sample_rays_seeded(stores, F: int, W: int, H: int, rays_dir_cache, kf_meta: torch.Tensor, n_frames: int, n_px: int,
                        n_cam2surf: int, n_bins: int, surface_eps: float, stop_eps: float, min_bound: float = 0.0,
                        obj_center: float = 0.0, seed: Optional[int] = None, draw: Optional[int] = None,
                        obj_index: int = 0, want_pts: bool = False, record: bool = False,
-                       kf_ids: Optional[torch.Tensor] = None) -> Dict[str, Optional[torch.Tensor]]:
+                       kf_ids: Optional[torch.Tensor] = None, partfeat=None) -> Dict[str, Optional[torch.Tensor]]:
     """The sampler with its random numbers generated in the kernels (Philox keyed on seed / draw / object / ray / bin;
     nothing random is stored).  stores: a keyframe table [K, 4] (ops.keyframe_table -> stacked call, tensors
     [K, ...]) or the four store tensors of ONE object (tensors without the leading K).  kf_meta int32 [K, 4] | [4]:
@@ -587,6 +639,8 @@ def sample_rays_seeded(stores, F: int, W: int, H: int, rays_dir_cache, kf_meta: 
     (without kf_meta: obj_index (+ k)); kf_ids overrides the seeded
     keyframe choice.  want_pts = False returns origins / dirs / z -- the pts == NULL form of ops.train_step, the
     [.., n, S, 3] point tensor is never written; record = True adds the drawn keyframes `kf` and pixels `px`.
+    partfeat = (global_partfeat, use_frame, stride, part_down): the part-level feature of every ray (vmap.py:437-452)
+    is gathered by the same launch -> key "partfeat" [.., n, C].
     Returns a dict: rgb u8, depth, valid (bool), labels u8, z, pts | origins + dirs, kf, px."""
     stacked = torch.is_tensor(stores)
     rays_dir_cache = _req(rays_dir_cache, torch.float32, "rays_dir_cache")
@@ -611,6 +665,7 @@ def sample_rays_seeded(stores, F: int, W: int, H: int, rays_dir_cache, kf_meta: 
                    _ptr(o["rgb"]), _ptr(o["depth"]), _ptr(o["valid"]), _ptr(o["labels"]), _ptr(o["z"]), _ptr(o["pts"]),
                    _ptr(o["ws"]), _seed_of(seed), (_next_offset() if draw is None else int(draw)) & 0x1FFFFFFF, 0,
                    _ptr(kf_meta), _ptr(o["kf"]), _ptr(o["px"]), _ptr(o["origins"]), _ptr(o["dirs"]))
+    o["partfeat"] = _partfeat_fields(a, partfeat, K, F, n_frames * n_px, dev, stacked)
     if stacked:
         check(lib().objnerf_sample_rays_stacked(C.byref(a), K, _ptr(table), _stream()), "objnerf_sample_rays_stacked")
     else:
@@ -630,8 +685,10 @@ def rays_dirs(W: int, H: int, fx: float, fy: float, cx: float, cy: float, device
 
 def sample_rays(rgbs_batch, depth_batch, t_wc_batch, bbox, rays_dir_cache, kf_ids, u_w, u_h, u, g,
                 n_cam2surf: int, n_bins: int, surface_eps: float, stop_eps: float, min_bound: float = 0.0,
-                obj_center: float = 0.0):
-    """sceneObject.get_training_samples + sample_3d_points with injected draws (vmap.py:386-554)."""
+                obj_center: float = 0.0, partfeat=None):
+    """sceneObject.get_training_samples + sample_3d_points with injected draws (vmap.py:386-554).
+    partfeat = (global_partfeat, use_frame, stride, part_down): also returns sampled_partfeat [n_frames, n_px, C]
+    (vmap.py:437-452), gathered by the same launch."""
     rgbs_batch = _req(rgbs_batch, torch.uint8, "rgbs_batch")
     depth_batch = _req(depth_batch, torch.float32, "depth_batch")
     t_wc_batch = _req(t_wc_batch, torch.float32, "t_wc_batch")
@@ -659,8 +716,10 @@ def sample_rays(rgbs_batch, depth_batch, t_wc_batch, bbox, rays_dir_cache, kf_id
                    _ptr(kf_ids), _ptr(u_w), _ptr(u_h), _ptr(u), _ptr(g), _ptr(out_rgb), _ptr(out_depth),
                    _ptr(out_valid), _ptr(out_labels), _ptr(out_z), _ptr(out_pts), _ptr(ws), 0, 0, 0, None, None, None,
                    None, None)
+    pf = _partfeat_fields(a, partfeat, 1, F, n, dev, False)
     check(lib().objnerf_sample_rays(C.byref(a), _stream()), "objnerf_sample_rays")
-    return out_rgb, out_depth, out_valid.bool(), out_labels, out_pts, out_z
+    r = (out_rgb, out_depth, out_valid.bool(), out_labels, out_pts, out_z)
+    return r if partfeat is None else r + (pf.reshape(n_frames, n_px, -1),)
 
 
 # ------------------------------------------------------------------------------------------------

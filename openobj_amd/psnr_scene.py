@@ -31,7 +31,10 @@ from . import train as otrain
 GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 G9 = dict(K=4, R=96, N=4, M=12, steps=300, eval_R=256, eval_S=32, scene_seed=7, weight_seed=90)
 G9B = dict(K=8, R=96, N=4, M=12, steps=300, early=50, eval_R=4096, eval_S=32, feat_R=256, scene_seed=7,
-           weight_seed=9000, batch_seed=9000)
+           weight_seed=9000, batch_seed=9000, hidden=32)
+# G9C: the same scene for BASELINE configs[4]'s network -- hidden 256, 32 samples per ray, no feature loss: the shape
+# the fused hidden-256 kernels of the 16-bit modes take (objnerf_train256.hip); 33 reference seeds
+G9C = dict(G9B, N=8, M=24, hidden=256)
 ENSEMBLE_FIXTURE = os.path.join(GOLDEN, "g9_ensemble.npz")
 MODES = {"f32": False, "bf16": True, "fp16": "fp16"}
 
@@ -94,6 +97,15 @@ def reference_ensemble_b(with_feat: bool = False) -> Optional[Dict[str, np.ndarr
         return None
 
 
+def reference_ensemble_c() -> Optional[Dict[str, np.ndarray]]:
+    """The reference's G9C runs (hidden 256; tests/golden/make_g9b_ensemble.py h256); None when absent."""
+    try:
+        d = np.load(os.path.join(GOLDEN, "g9c_ensemble_h256.npz"))
+        return {k: d[k] for k in d.files}
+    except OSError:
+        return None
+
+
 def delta_report(hip: np.ndarray, ref: np.ndarray) -> Dict[str, float]:
     """Difference of ensemble means with its 95 % confidence half-width (Welch, normal quantile)."""
     se = math.sqrt(hip.var(ddof=1) / len(hip) + ref.var(ddof=1) / len(ref))
@@ -129,6 +141,7 @@ class EnsembleRun:
             self.batches.append({k: torch.from_numpy(b[k]).to(self.dev) for k in self.keys})
         c = ocfg.Config(ocfg.replica_room0_config(train_device="cpu"))      # initial weights are drawn on the host
         c.obj_id = 1
+        c.hidden_feature_size = int(s.get("hidden", 32))
         self.cfg = c
         self.feat_gt = torch.from_numpy(self.scene.feat).to(self.dev)
 

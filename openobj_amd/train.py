@@ -109,13 +109,51 @@ class ShardedIteration:
             self._side = torch.cuda.Stream(device=dev)
         return self._side
 
-    def step(self, obj_batch=None, bg_batch=None):
-        """-> (object loss terms [K,4] | None, background loss terms [1,4] | None)"""
+    def frame_pre(self, obj_labels=None, bg_labels=None, n_iter: Optional[int] = None) -> Optional[torch.Tensor]:
+        """Collective 1 of ALL iterations of a frame in ONE exchange (train.py:394-404: the sample pool of a frame is
+        complete before its first iteration, so every iteration's labels are known up front).
+        obj_labels u8 [n_iter, K, R] / bg_labels u8 [n_iter, 1, R_bg] (either may be None; n_iter then has to be
+        given): one objnerf_label_counts launch per tensor, ONE int32[n_iter, 4] SUM all-reduce (rows as
+        dist.pack_pre).  Returns None without sharding (the
+        kernels then derive flags and counts from the batch itself).  The result is a list: element `it` is
+        (object flags int32[2], background counts int32[1,2], background flags int32[2]) for step(..., pre=)."""
+        if not odist._active(self.group):
+            return None
+        ref = obj_labels if obj_labels is not None else bg_labels
+        n_iter = ref.shape[0] if ref is not None else int(n_iter)
+        dev = ref.device if ref is not None else self.device
+        if dev is None:
+            raise ValueError("ShardedIteration.frame_pre without labels needs device= at construction")
+        pre = torch.zeros(n_iter, 4, dtype=torch.int32, device=dev)
+        if obj_labels is not None and self.obj_loop is not None:
+            K = obj_labels.shape[1]
+            counts = ops.label_counts(obj_labels.reshape(n_iter * K, -1))[0]            # [n_iter * K, 2]
+            pre[:, 0:2] = (counts.reshape(n_iter, K, 2) == 0).sum(dim=1).to(torch.int32)   # objects with an empty mask
+        if bg_labels is not None and self.bg_loop is not None:
+            pre[:, 2:4] = ops.label_counts(bg_labels.reshape(n_iter, -1))[0]
+        odist.allreduce_sum_(pre, self.group)                     # collective 1, once per frame
+        # unpacked once for every iteration (dist.unpack_pre row-wise): step() only takes views -- no kernel and no
+        # cross-stream hand-over per iteration; the background stream picks the buffers up after this point
+        rows = ((pre[:, 0:2] > 0).to(torch.int32), pre[:, 2:4].reshape(n_iter, 1, 2).contiguous(),
+                (pre[:, 2:4] == 0).to(torch.int32))
+        side = self._bg_stream(dev)
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream(dev))
+            for t in rows:
+                t.record_stream(side)
+        return [tuple(t[it] for t in rows) for it in range(n_iter)]
+
+    def step(self, obj_batch=None, bg_batch=None, pre: Optional[torch.Tensor] = None):
+        """-> (object loss terms [K,4] | None, background loss terms [1,4] | None)
+        pre: this iteration's element of frame_pre() (already reduced over the ranks): the pre-step exchange is skipped
+        and the iteration has ONE collective, the background gradient's."""
         ref = obj_batch if obj_batch is not None else bg_batch
         if ref is not None and self.device is None:
             self.device = ref["z"].device
         dev = self.device
         sharded = odist._active(self.group)
+        if ref is None and pre is not None:
+            return None, None                   # (the exchange this rank would have had to join happened in frame_pre)
         if ref is None:
             # nothing to train on this rank in this iteration (no foreground object yet and no background batch).
             # Unsharded that is a no-op; sharded, the rank still joins collective 1 with zeros (flags and counts are
@@ -135,17 +173,19 @@ class ShardedIteration:
             side.wait_stream(main)
         obj_flags = bg_counts = bg_flags = gflags = work = None
         with on_side():
-            if do_obj and sharded:
+            if pre is not None:                     # reduced for the whole frame by frame_pre()
+                gflags, bg_counts, bg_flags = pre
+            elif do_obj and sharded:
                 obj_flags = ops.label_counts(obj_batch["labels"])[1]
-            if do_bg:
+            if do_bg and pre is None:
                 if sharded:
                     bg_counts = self.bg_loop.local_counts(bg_batch)
                 else:                               # one object, one rank: the kernel's own flag pair is the batch's
                     bg_counts, bg_flags = self.bg_loop.local_counts_flags(bg_batch)
-            if sharded:
-                pre = odist.pack_pre(obj_flags, bg_counts, dev)
-                odist.allreduce_sum_(pre, self.group)              # collective 1
-                gflags, bg_counts, bg_flags = odist.unpack_pre(pre)
+            if sharded and pre is None:
+                pre1 = odist.pack_pre(obj_flags, bg_counts, dev)
+                odist.allreduce_sum_(pre1, self.group)             # collective 1
+                gflags, bg_counts, bg_flags = odist.unpack_pre(pre1)
                 if side is not None:
                     main.wait_stream(side)                         # (the object kernel needs the global flags)
                     gflags.record_stream(main)                     # (allocated on the second stream, read on this one)

@@ -178,15 +178,11 @@ class sceneObject:
         return [self.n_keyframes] + (list(self.lastest_kf_queue[-2:]) if self.n_keyframes > 2 else [-1, -1]) + \
                [int(self.obj_id) & 0x7FFFFFFF]
 
-    def _partfeat(self, kf, px, global_partfeat):
-        """vmap.py:437-452 from the drawn keyframes kf [n_frames] and pixels px [n, 2] (floor(idx / part_down) of the
-        float index equals the integer division of its truncation)."""
-        use_frame = torch.tensor(self.use_frame).to(kf.device)
-        n_px = px.shape[0] // kf.shape[0]
-        fid = (use_frame[kf] / self.stride).long().repeat_interleave(n_px)
-        pd = int(self.part_down)
-        return global_partfeat[fid, torch.div(px[:, 0].long(), pd, rounding_mode="floor"),
-                               torch.div(px[:, 1].long(), pd, rounding_mode="floor")]
+    def _partfeat_args(self, global_partfeat):
+        """The part-feature gather of vmap.py:437-452 as arguments of the sampler launch (ops._partfeat_fields)."""
+        if not (self.part_mode and global_partfeat is not None):
+            return None
+        return (global_partfeat, self.use_frame, self.stride, self.part_down)
 
     def get_training_samples(self, n_frames, n_samples, cached_rays_dir, global_partfeat=None, draws=None, seed=None,
                              compact=False):
@@ -200,32 +196,24 @@ class sceneObject:
         N, M = self.n_bins_cam2surface, self.n_bins
         n = n_frames * n_samples
         if draws is None:
-            want_feat = self.part_mode and global_partfeat is not None
             meta = torch.tensor(self.kf_meta(), dtype=torch.int32).to(dev)
             o = ops.sample_rays_seeded(self.keyframe_store(), self.keyframe_buffer_size, self.frames_width,
                                        self.frames_height, cached_rays_dir, meta, n_frames, n_samples, N, M,
                                        self.surface_eps, self.stop_eps, float(self.min_bound), float(self.obj_center),
-                                       seed=seed, want_pts=not compact, record=want_feat)
-            partfeat = self._partfeat(o["kf"], o["px"], global_partfeat) if want_feat else None
+                                       seed=seed, want_pts=not compact, partfeat=self._partfeat_args(global_partfeat))
+            partfeat = o["partfeat"]
+            if partfeat is not None:
+                partfeat = partfeat.reshape(n_frames, n_samples, -1)
             S = N + M
             pcs = (o["origins"], o["dirs"]) if compact else o["pts"].reshape(n_frames, n_samples, S, 3)
             return (o["rgb"].reshape(n_frames, n_samples, 3), o["depth"].reshape(n_frames, n_samples), o["valid"],
                     o["labels"], pcs, o["z"].reshape(n_frames, n_samples, S), partfeat)
-        rgb, depth, valid, labels, pts, z = ops.sample_rays(
+        pf = self._partfeat_args(global_partfeat)                   # vmap.py:437-452: gathered by the same launch
+        r = ops.sample_rays(
             self.rgbs_batch, self.depth_batch, self.t_wc_batch, self.bbox, cached_rays_dir, draws["kf_ids"],
             draws["u_w"], draws["u_h"], draws["u"], draws["g"], N, M, self.surface_eps, self.stop_eps,
-            float(self.min_bound), float(self.obj_center))
-        partfeat = None
-        if self.part_mode and global_partfeat is not None:          # vmap.py:437-452
-            kf = draws["kf_ids"][:, None]
-            bb = self.bbox[kf]
-            idx_w = draws["u_w"] * (bb[..., 1] - bb[..., 0]) + bb[..., 0]
-            idx_h = draws["u_h"] * (bb[..., 3] - bb[..., 2]) + bb[..., 2]
-            use_frame = torch.tensor(self.use_frame).to(dev)
-            fid = (use_frame[kf] / self.stride).long()
-            partfeat = global_partfeat[fid, torch.floor(idx_w / self.part_down).long(),
-                                       torch.floor(idx_h / self.part_down).long()]
-        return rgb, depth, valid, labels, pts, z, partfeat
+            float(self.min_bound), float(self.obj_center), partfeat=pf)
+        return r if pf is not None else r + (None,)
 
     def keyframe_store(self):
         """The four device tensors the sampler reads (fixed addresses for the life of the object)."""
@@ -381,38 +369,22 @@ class StackedSampler:
         o = self.objs[0]
         if draws is None:
             dev = o.data_device
-            K = len(self.objs)
-            want_feat = o.part_mode and global_partfeat is not None
             meta = torch.tensor([x.kf_meta() for x in self.objs], dtype=torch.int32).to(dev)   # one small H2D copy
             r = ops.sample_rays_seeded(self.table, o.keyframe_buffer_size, o.frames_width, o.frames_height,
                                        cached_rays_dir, meta, n_frames, n_samples, o.n_bins_cam2surface, o.n_bins,
                                        o.surface_eps, o.stop_eps, float(o.min_bound), float(o.obj_center), seed=seed,
-                                       want_pts=not compact, record=want_feat)
-            partfeat = None
-            if want_feat:                                                       # vmap.py:437-452, all objects at once
-                use = torch.tensor(np.stack([x.use_frame for x in self.objs])).to(dev)            # [K, F]
-                fid = (torch.gather(use, 1, r["kf"]) / o.stride).long().repeat_interleave(n_samples, dim=1)   # [K, n]
-                pd = int(o.part_down)
-                partfeat = global_partfeat[fid, torch.div(r["px"][..., 0].long(), pd, rounding_mode="floor"),
-                                           torch.div(r["px"][..., 1].long(), pd, rounding_mode="floor")]
+                                       want_pts=not compact, partfeat=self._partfeat_args(global_partfeat))
             pcs = (r["origins"], r["dirs"]) if compact else r["pts"]
-            return r["rgb"], r["depth"], r["valid"], r["labels"], pcs, r["z"], partfeat
-        rgb, depth, valid, labels, pts, z = ops.sample_rays_stacked(
+            return r["rgb"], r["depth"], r["valid"], r["labels"], pcs, r["z"], r["partfeat"]
+        pf = self._partfeat_args(global_partfeat)                              # vmap.py:437-452, all objects at once
+        r = ops.sample_rays_stacked(
             self.table, o.keyframe_buffer_size, o.frames_width, o.frames_height, cached_rays_dir, draws["kf_ids"],
             draws["u_w"], draws["u_h"], draws["u"], draws["g"], o.n_bins_cam2surface, o.n_bins, o.surface_eps,
-            o.stop_eps, float(o.min_bound), float(o.obj_center))
-        partfeat = None
-        if o.part_mode and global_partfeat is not None:                        # vmap.py:437-452, all objects at once
-            dev = o.data_device
-            K = len(self.objs)
-            kf = draws["kf_ids"]                                                # [K, n_frames]
-            bbox = torch.stack([x.bbox for x in self.objs])                     # [K, F, 4]
-            bb = torch.gather(bbox, 1, kf[:, :, None].expand(-1, -1, 4))[:, :, None, :]      # [K, n_frames, 1, 4]
-            idx_w = draws["u_w"] * (bb[..., 1] - bb[..., 0]) + bb[..., 0]
-            idx_h = draws["u_h"] * (bb[..., 3] - bb[..., 2]) + bb[..., 2]
-            use = torch.tensor(np.stack([x.use_frame for x in self.objs])).to(dev)            # [K, F]
-            fid = (torch.gather(use, 1, kf) / o.stride).long()[:, :, None]
-            partfeat = global_partfeat[fid, torch.floor(idx_w / o.part_down).long(),
-                                       torch.floor(idx_h / o.part_down).long()]
-            partfeat = partfeat.reshape(K, n_frames * n_samples, -1)
-        return rgb, depth, valid, labels, pts, z, partfeat
+            o.stop_eps, float(o.min_bound), float(o.obj_center), partfeat=pf)
+        return r if pf is not None else r + (None,)
+
+    def _partfeat_args(self, global_partfeat):
+        o = self.objs[0]
+        if not (o.part_mode and global_partfeat is not None):
+            return None
+        return (global_partfeat, np.stack([x.use_frame for x in self.objs]), o.stride, o.part_down)

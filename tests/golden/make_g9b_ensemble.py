@@ -7,8 +7,9 @@ well-posed) AND after 300 (chaotic: only ensemble means compare), for every weig
 feature loss (cfg.part_mode).  The feature variant also records the mean cosine between the rendered 512-d feature
 (the reference's composited out_clip tensor) and the target on the first 256 held-out rays of each object.
 
-    python tests/golden/make_g9b_ensemble.py run  nofeat|feat first_seed n_seeds part_file
-    python tests/golden/make_g9b_ensemble.py join nofeat|feat part_file...        -> g9b_ensemble_<variant>.npz
+    python tests/golden/make_g9b_ensemble.py run  nofeat|feat|h256 first_seed n_seeds part_file
+    python tests/golden/make_g9b_ensemble.py join nofeat|feat|h256 part_file...   -> g9b_ensemble_<variant>.npz
+                                                                                     (h256: g9c_ensemble_h256.npz)
     python tests/golden/make_g9b_ensemble.py all  [n_nofeat n_feat n_procs]       (shards over processes, then joins)
 
 Build container only (imports /root/reference through make_golden.py)."""
@@ -23,13 +24,18 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
 G9B = dict(K=8, R=96, N=4, M=12, steps=300, early=50, eval_R=4096, eval_S=32, feat_R=256, scene_seed=7,
-           weight_seed=9000, batch_seed=9000)
+           weight_seed=9000, batch_seed=9000, hidden=32)
+# "h256": the same scene for BASELINE configs[4]'s network (hidden 256) at 32 samples per ray, no feature loss -- the
+# shape the fused hidden-256 kernels of the 16-bit modes take (objnerf_train256.hip); fewer seeds (the reference costs
+# ~60 GFLOP per iteration on the CPU)
+G9C = dict(G9B, N=8, M=24, hidden=256)
 
 
 def run(variant, first, n, out):
     import make_golden as MG
     torch.set_num_threads(int(os.environ.get("THREADS", "2")))
     feat_on = variant == "feat"
+    G9B = G9C if variant == "h256" else globals()["G9B"]
     scene = MG.synthetic.EllipsoidScene.make(G9B["K"], 512, seed=G9B["scene_seed"])
     ev = scene.eval_rays(G9B["eval_R"], G9B["eval_S"])
     cache = {}
@@ -55,7 +61,7 @@ def run(variant, first, n, out):
 
     rows = []
     for seed in range(first, first + n):
-        ts = MG.make_trainers(G9B["K"], seed=seed, perturb_B=False)
+        ts = MG.make_trainers(G9B["K"], seed=seed, perturb_B=False, hidden=G9B["hidden"])
         early = {}
 
         def on_step(done, fc_param, pe_param):
@@ -73,10 +79,11 @@ def run(variant, first, n, out):
 def join(variant, parts):
     rows = np.concatenate([np.load(p) for p in parts])
     rows = rows[np.argsort(rows[:, 0])]
-    np.savez(os.path.join(HERE, f"g9b_ensemble_{variant}.npz"), seeds=rows[:, 0].astype(np.int64), psnr50=rows[:, 1],
+    G9B = G9C if variant == "h256" else globals()["G9B"]
+    np.savez(os.path.join(HERE, ("g9c_ensemble_h256.npz" if variant == "h256" else f"g9b_ensemble_{variant}.npz")), seeds=rows[:, 0].astype(np.int64), psnr50=rows[:, 1],
              psnr300=rows[:, 2], featcos300=rows[:, 3], loss300=rows[:, 4],
              meta=np.array([G9B[k] for k in ["K", "R", "N", "M", "steps", "early", "eval_R", "eval_S", "feat_R",
-                                             "scene_seed", "batch_seed"]], np.int64))
+                                             "scene_seed", "batch_seed", "hidden"]], np.int64))
     print(variant, len(rows), "seeds  PSNR50 mean", rows[:, 1].mean(), " PSNR300 mean", rows[:, 2].mean(), "sigma",
           rows[:, 2].std(ddof=1))
 

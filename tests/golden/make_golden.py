@@ -26,6 +26,9 @@ Fixtures:
   g12_keyframes  sceneObject.__init__ / append_keyframe / prune_keyframe (vmap.py:29-257) driven frame by frame
              with the state maps of train.py:197-205: slot trace (kf_id_dict order, lastest_kf_queue, kf_pointer,
              n_keyframes, use_frame), the recorded random.choice picks and the final keyframe buffers
+  g7b_partfeat  get_training_samples with part_mode on: sampled_partfeat (vmap.py:436-454), part_down 5 and 3
+  g15_forloop   the "forloop" training strategy (train.py:240-251,405-420): per-object modules and param groups,
+             3 iterations incl. one with the cross-object early return: loss, grads, params after every step
   g13_ckpt   sceneObject.save_checkpoints (vmap.py:556-576): the file the reference writes (g13_ref_obj_5.pth)
              + the saved parameters and the reference's outputs for them on a few points
 """
@@ -425,6 +428,136 @@ def g7():
     save("g7_sample", **out)
 
 
+# ------------------------------------------------------------------------------------------- G7b
+def g7b():
+    """sceneObject.get_training_samples with part_mode on (vmap.py:436-454): the 7th output, sampled_partfeat =
+    global_partfeat[use_frame[kf] / stride, floor(idx_w / part_down), floor(idx_h / part_down)].  Two cases: the
+    configured part_down = 5 and an odd part_down = 3 with stride 2 (floor of the FLOAT index divided in fp32 is not
+    always the integer division of the truncated index; the fixture holds whichever the reference produced)."""
+    out = {}
+    for tag, (pd, stride, Cf, seed) in {"pd5": (5, 1, 64, 72), "pd3": (3, 2, 12, 73)}.items():
+        torch.manual_seed(seed)
+        Fk, W, H = 4, 40, 30
+        cfg = types.SimpleNamespace(data_device="cpu", W=W, H=H, fx=30.0, fy=30.0, cx=19.5, cy=14.5)
+        cam = ref_vmap.cameraInfo(cfg)
+        rgbs_batch = torch.randint(0, 256, (Fk, W, H, 4), dtype=torch.uint8)
+        rgbs_batch[..., 3] = torch.randint(0, 3, (Fk, W, H), dtype=torch.uint8)
+        depth_batch = torch.rand(Fk, W, H) * 4 + 0.5
+        depth_batch[torch.rand(Fk, W, H) < 0.1] = 0.0
+        t_wc = torch.eye(4).repeat(Fk, 1, 1)
+        t_wc[:, :3, :3] = torch.from_numpy(synthetic._random_rotations(np.random.RandomState(4), Fk)).float()
+        t_wc[:, :3, 3] = torch.randn(Fk, 3)
+        # boxes with edges ON multiples of part_down (idx / part_down then lands next to an integer)
+        bbox = torch.tensor([[3., 30., 2., 25.], [0., 40., 0., 30.], [10., 15., 5., 27.], [5., 20., 6., 21.]])
+        use_frame = np.zeros(Fk)                                     # float64, as sceneObject.__init__ makes it
+        use_frame[:] = np.array([0, 2, 4, 6]) * stride
+        n_ds = 4                                                     # dataset frames with part features
+        use_frame = np.minimum(use_frame, (n_ds - 1) * stride)
+        global_partfeat = torch.randn(n_ds, -(-W // pd), -(-H // pd), Cf)
+        n_frames, n_samples = 7, 24
+        self_ns = types.SimpleNamespace(n_keyframes=Fk, data_device="cpu", lastest_kf_queue=[2, 3], bbox=bbox,
+                                        rgbs_batch=rgbs_batch, depth_batch=depth_batch, t_wc_batch=t_wc,
+                                        part_mode=True, use_frame=use_frame, stride=stride, part_down=pd,
+                                        n_bins_cam2surface=1, n_bins=9, surface_eps=0.1,
+                                        stop_eps=0.05, min_bound=0.0, this_obj=1, obj_center=torch.tensor(0.0))
+        self_ns.sample_3d_points = lambda *a, _s=self_ns, **k: ref_vmap.sceneObject.sample_3d_points(_s, *a, **k)
+        _randint = torch.randint
+        kf_rec = []
+
+        def randint(*a, **k):
+            r = _randint(*a, **k)
+            kf_rec.append(r.clone())
+            return r
+
+        torch.randint = randint
+        try:
+            with _Recorder() as rec:
+                g_rgb, g_depth, g_valid, g_lab, g_pts, g_z, g_pf = ref_vmap.sceneObject.get_training_samples(
+                    self_ns, n_frames, n_samples, cam.rays_dir_cache, global_partfeat)
+        finally:
+            torch.randint = _randint
+        kf_ids = torch.cat([kf_rec[0], torch.tensor([2, 3])])
+        u_w, u_h = rec.rand[0], rec.rand[1]
+        n = n_frames * n_samples
+        d = g_depth.reshape(-1)
+        invalid = d <= 0
+        valid = ~invalid
+        obj = (g_lab == 1) & valid
+        oth = (g_lab != 1) & valid
+        u = torch.zeros(n, 10)
+        g = torch.zeros(n, 9)
+        ri = 2
+        if invalid.any():
+            u[invalid] = rec.rand[ri]; ri += 1
+        u[valid, :1] = rec.rand[ri]; ri += 1
+        if obj.any():
+            g[obj] = rec.normal[0]
+        if oth.any():
+            u[oth, 1:] = rec.rand[ri]; ri += 1
+        assert ri == len(rec.rand)
+        assert g_pf.shape == (n_frames, n_samples, Cf)
+        out.update({f"{tag}_rgbs_batch": rgbs_batch, f"{tag}_depth_batch": depth_batch, f"{tag}_t_wc": t_wc,
+                    f"{tag}_bbox": bbox, f"{tag}_kf_ids": kf_ids, f"{tag}_u_w": u_w, f"{tag}_u_h": u_h, f"{tag}_u": u,
+                    f"{tag}_g": g, f"{tag}_rgb": g_rgb, f"{tag}_depth": g_depth, f"{tag}_labels": g_lab,
+                    f"{tag}_z": g_z, f"{tag}_use_frame": use_frame, f"{tag}_global_partfeat": global_partfeat,
+                    f"{tag}_partfeat": g_pf, f"{tag}_meta": np.array([pd, stride, Cf, W, H], np.int32)})
+    out["rays_dir_cache"] = cam.rays_dir_cache
+    save("g7b_partfeat", **out)
+
+
+# ------------------------------------------------------------------------------------------- G15
+def g15():
+    """training_strategy == "forloop" (train.py:240-251, 405-420, 435-474): every object's OWN modules in per-object
+    param groups of one AdamW, outputs stacked before ONE step_batch_loss, backward, step, zero_grad -- three
+    iterations; in the second one object has no label-1 ray (the cross-object early return of render_rays.py:89-94
+    then zeroes the depth / colour / feature terms of EVERY object, and those tensors' .grad stays None)."""
+    for tag, (K, R, n1, n2, feat_on) in {"nofeat": (2, 16, 1, 9, False), "feat": (2, 16, 1, 9, True)}.items():
+        ts = make_trainers(K, seed=150)
+        fc0, B0 = stack_params(ts)
+        fc0, B0 = [p.clone() for p in fc0], B0.clone()
+        optimiser = torch.optim.AdamW([torch.autograd.Variable(torch.tensor(0))], lr=1e-3, weight_decay=0.013)
+        for t in ts:                                                  # train.py:250-251
+            optimiser.add_param_group({"params": t.fc_occ_map.parameters(), "lr": 1e-3, "weight_decay": 0.013})
+            optimiser.add_param_group({"params": t.pe.parameters(), "lr": 1e-3, "weight_decay": 0.013})
+        out = {f"fc0_{i}": fc0[i] for i in range(18)}
+        out["B0"] = B0
+        losses, none_grad = [], []
+        for it in range(3):
+            b = synthetic.random_batch(K, R, n1, n2, seed=1500 + it, feat_dim=512)
+            if it == 1:
+                b["labels"][1][b["labels"][1] == 1] = 0
+            pts, gt_depth, gt_rgb, labels, z = to_t(b, ["pts", "gt_depth", "gt_rgb", "labels", "z"])
+            batch_alpha, batch_color, batch_clip = [], [], []
+            for k, t in enumerate(ts):                                # train.py:405-420
+                emb_k = t.pe(pts[k])
+                alpha_k, color_k, clip_k = t.fc_occ_map(emb_k)
+                batch_alpha.append(alpha_k); batch_color.append(color_k); batch_clip.append(clip_k)
+            batch_alpha, batch_color, batch_clip = (torch.stack(batch_alpha), torch.stack(batch_color),
+                                                    torch.stack(batch_clip))
+            dmask = torch.ones_like(gt_depth, dtype=torch.bool)
+            if feat_on:
+                l, _ = ref_loss.step_batch_loss(batch_alpha, batch_color, gt_depth, gt_rgb, labels, dmask, z,
+                                                gt_partfeat=torch.from_numpy(b["gt_feat"]), pred_partfeat=batch_clip)
+            else:
+                l, _ = ref_loss.step_batch_loss(batch_alpha, batch_color, gt_depth, gt_rgb, labels, dmask, z)
+            l.backward()
+            losses.append(l.item())
+            plist = [[p for p in t.fc_occ_map.parameters()] + [t.pe.B_layer.weight] for t in ts]
+            none_grad.append([[int(p.grad is None) for p in pl] for pl in plist])
+            for i in range(19):
+                out[f"grad{it}_{i}"] = torch.stack([(pl[i].grad.clone() if pl[i].grad is not None
+                                                     else torch.zeros_like(pl[i])) for pl in plist])
+            optimiser.step()
+            optimiser.zero_grad(set_to_none=True)
+            if it != 1:                                               # (after the first and the last step)
+                for i in range(19):
+                    out[f"param{it}_{i}"] = torch.stack([pl[i].detach().clone() for pl in plist])
+        out["loss"] = np.array(losses, np.float64)
+        out["none_grad"] = np.array(none_grad, np.int32)
+        out["meta"] = np.array([K, R, n1, n2, int(feat_on)], np.int32)
+        save(f"g15_forloop_{tag}", **out)
+
+
 # ------------------------------------------------------------------------------------------- G8
 def g8():
     torch.manual_seed(8)
@@ -751,7 +884,8 @@ def g10():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g7", "g8", "g9", "g10", "g11", "g12", "g13",
+                               "g7b", "g15"]
     for w in which:
         {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5": g5_g6, "g7": g7, "g8": g8, "g9": g9, "g11": g11,
-         "g10": g10, "g12": g12, "g13": g13}[w]()
+         "g10": g10, "g12": g12, "g13": g13, "g7b": g7b, "g15": g15}[w]()

@@ -356,6 +356,49 @@ def test_forloop_strategy_equals_vmap(dev):
         assert maxerr(tv.arena.params, tf.arena.params) < 2e-6
 
 
+@pytest.mark.parametrize("tag", ["nofeat", "feat"])
+def test_forloop_strategy_g15(golden, dev, tag):
+    """A14 against the REFERENCE's forloop strategy (fixture G15 = train.py:240-251,405-420,435-474 run on the
+    reference's modules: per-object param groups of one AdamW, outputs stacked before ONE step_batch_loss): loss and the
+    19 gradients of every object at 1e-4 in each of three iterations, parameters after the first and the last
+    optimiser step.  In the second iteration one object has no label-1 ray: the cross-object early return
+    (render_rays.py:89-94) leaves the colour / feature tensors of EVERY object without gradient, so AdamW must skip
+    them (no update, no decay, no step count)."""
+    g = golden(f"g15_forloop_{tag}")
+    K, R, n1, n2, feat_on = [int(x) for x in g["meta"]]
+    ts = make_trainers(K, dev, 1)
+    with torch.no_grad():
+        for k, t in enumerate(ts):
+            for i, p in enumerate(t.fc_occ_map.parameters()):
+                p.copy_(T(g[f"fc0_{i}"][k]))
+            t.pe.B_layer.weight.copy_(T(g["B0"][k]))
+    c = make_cfg(dev)
+    c.training_strategy = "forloop"
+    loop = otrain.HipTrainLoop(c, ts, with_feat=bool(feat_on))
+    keys = ["pts", "z", "gt_depth", "gt_rgb", "labels"] + (["gt_feat"] if feat_on else [])
+    for it in range(3):
+        b = synthetic.random_batch(K, R, n1, n2, seed=1500 + it, feat_dim=512)
+        if it == 1:
+            b["labels"][1][b["labels"][1] == 1] = 0
+        before = [t.arena.params.clone() for t in ts]
+        terms = loop.step({k: T(b[k]).to(dev) for k in keys}).cpu()
+        total = (terms[:, 0] + 5 * terms[:, 1] + 10 * terms[:, 2] + 5 * terms[:, 3]).sum().item()
+        assert abs(total - g["loss"][it]) < 1e-4 * abs(g["loss"][it]), (it, total, g["loss"][it])
+        for k, t in enumerate(ts):
+            gv = t.arena.views(loop.wss[k].grads)
+            pv0, pv1 = t.arena.views(before[k]), t.arena.views(t.arena.params)
+            for i in range(19):
+                if g["none_grad"][it][k][i]:                  # .grad is None in the reference: untouched by AdamW
+                    assert torch.equal(pv0[i], pv1[i]), (it, k, ops.TENSOR_NAMES[i])
+                    continue
+                ref = g[f"grad{it}_{i}"][k]
+                scale = max(1e-3, float(np.abs(ref).max()))
+                assert maxerr(gv[i][0], ref) < 1e-4 * scale, (it, k, ops.TENSOR_NAMES[i], maxerr(gv[i][0], ref), scale)
+                if it != 1:
+                    assert maxerr(pv1[i][0], g[f"param{it}_{i}"][k]) < 3e-6, (it, k, ops.TENSOR_NAMES[i])
+    assert int(loop.status.item()) == 0
+
+
 def test_forloop_keeps_adam_state_across_rebuilds(dev):
     """train.py:250-251: under "forloop" an object's parameters enter the optimiser once; a rebuild of the loop (a new
     object arrived) must not restart the existing objects' moments / step counts."""

@@ -102,3 +102,40 @@ def test_inference_calls_build_no_graph(dev):
     with torch.no_grad():
         alpha, color, clip = t.fc_occ_map(t.pe(torch.zeros(4, 3, device=dev)))
     assert alpha.grad_fn is None and not alpha.requires_grad
+
+
+def test_backward_after_the_arena_changed_raises(dev):
+    """backward() recomputes from the live arena: an optimiser step, a copy into a parameter or a scale change between
+    forward and backward must raise (torch does on a modified saved tensor), a repeated forward must not."""
+    from openobj_amd import optim as ooptim
+    torch.manual_seed(5)
+    t = trainer.Trainer(make_cfg(dev))
+    pts = torch.from_numpy(np.random.RandomState(1).uniform(-1, 1, (6, 5, 3)).astype(np.float32)).to(dev)
+
+    def fwd():
+        a, c, _ = t.fc_occ_map(t.pe(pts))
+        return a.sum() + c.sum()
+
+    l1 = fwd()
+    fwd()                                                  # a second forward (same scale) does not invalidate the first
+    l1.backward()
+    assert t.pe.B_layer.weight.grad is not None
+    l2 = fwd()
+    opt = ooptim.ArenaAdamW(t.arena)
+    opt.step(torch.zeros_like(t.arena.params))             # the kernel writes the arena behind torch's back
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        l2.backward()
+    l3 = fwd()
+    with torch.no_grad():
+        list(t.fc_occ_map.parameters())[0].mul_(1.0)       # torch-side in-place write into an arena view
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        l3.backward()
+    l4 = fwd()
+    t.arena.scale.fill_(3.0)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        l4.backward()
+    other = trainer.Trainer(make_cfg(dev))
+    from openobj_amd.autograd import MlpFunction
+    with pytest.raises(ValueError, match="not a view of the arena"):
+        MlpFunction.apply(t.arena, False, False, t.pe(pts).reshape(1, -1, 129).contiguous(),
+                          *list(other.fc_occ_map.parameters()))

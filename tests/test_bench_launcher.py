@@ -51,4 +51,15 @@ def test_a_failing_rank_fails_the_launch():
     """A rank that exits non-zero turns into a non-zero exit of the launcher and NO line (OBJNERF_BENCH_FAIL_RANK is the
     dry launch's test hook: that rank returns 3 after the run)."""
     r = _run("--gpus", "2", "--dry-launch", "--steps", "1", env={"OBJNERF_BENCH_FAIL_RANK": "1"})
-    assert r.returncode != 0 and r.stdout.strip() == "" and "exit codes [0, 3]" in r.stderr
+    # (rank 0 has normally finished by then: [0, 3]; had it not, the launcher would have stopped it: [-15, 3])
+    assert r.returncode != 0 and r.stdout.strip() == "" and ", 3]" in r.stderr and "exit codes [" in r.stderr
+
+
+def test_a_rank_that_dies_before_the_rendezvous_ends_the_launch_quickly():
+    """Rank 1 exits before init_process_group: rank 0 would sit in the rendezvous until torch's timeout (minutes); the
+    launcher supervises every child, stops rank 0 (the child it started) and fails within seconds."""
+    import time
+    t0 = time.time()
+    r = _run("--gpus", "2", "--dry-launch", "--steps", "1", env={"OBJNERF_BENCH_DIE_EARLY": "1"})
+    assert r.returncode != 0 and r.stdout.strip() == "" and ", 4]" in r.stderr
+    assert time.time() - t0 < 90

@@ -44,34 +44,47 @@ def test_fp16_step_close_to_fp32(dev, shape):
         assert rel < bound, (i, ops.TENSOR_NAMES[i], rel)
 
 
-@pytest.mark.parametrize("mode,bound", [("fp16", 0.03), ("bf16", 0.15)])   # (fp16: 2.1 % on d B, the end of the chain)
-def test_config_c5_object_at_full_size_16bit(dev, mode, bound):
-    """BASELINE configs[4] in the dtype it names: one object at its full size (hidden 256, 8192 rays x 128 samples =
-    10^6 rows per layer GEMM) in the 16-bit modes -- resident-panel GEMMs, activations and back-propagated gradients
-    stored in the operand type, split-K weight gradients over 10^6 samples -- against the same step in fp32 (which
-    test_hip_parity.py pins to the oracle at this size); two objects at once give the same gradients as one by one
-    (batched launches) to 1e-5, and the step is bit-reproducible."""
+@pytest.mark.parametrize("mode", ["fp16", "bf16"])
+def test_config_c5_object_at_full_size_16bit(dev, mode):
+    """BASELINE configs[4] in the dtype it names: objects at their full size (hidden 256, 8192 rays x 128 samples =
+    10^6 samples per object) through the two fused hidden-256 kernels (objnerf_train256.hip: fwd256_kernel +
+    wgrad256_kernel) against the SPECIFICATION of the 16-bit modes evaluated at the same size -- parity_util.
+    oracle_step_16 is oracle.train_forward_loss with the operands of every hidden nn.Linear, the stored activations,
+    the head weights and the head gradients rounded to the operand type (fp16: the back-propagated gradient scaled by
+    2^(floor(log2 R) + 3)), fp32 accumulation, run through torch on the device: every gradient tensor within 1 % in
+    norm (tests/test_16bit_spec_gpu.py holds the same kernels to the same bound at <= 4096 x 64), loss terms within
+    2e-3 / 2e-4.  Also: two objects at once give the same gradients as one by one to 1e-5, and the step is
+    bit-reproducible."""
+    import math
+    from parity_util import oracle_step_16, rel_norm
     K, R, n1, n2, H = 2, 8192, 32, 96, 256
     arena = ops.ParamArena(K, ops.NetShape(H, 512, 6), dev)
-    arena.load_stacked(obj_init.init_stacked(K, H, 512, seed=41))
+    st = obj_init.init_stacked(K, H, 512, seed=41)
+    arena.load_stacked(st)
     b = synthetic.random_batch(K, R, n1, n2, seed=17)
     batch = {k: T(b[k]).to(dev) for k in ["pts", "z", "gt_depth", "gt_rgb", "labels"]}
-    ws32 = ops.TrainWorkspace(arena, K, R, n1 + n2, False)
     ws16 = ops.TrainWorkspace(arena, K, R, n1 + n2, False, precision=mode)
-    assert ws16.nbytes < 0.75 * ws32.nbytes
-    ops.train_step(arena, ws32, batch)
+    assert ws16.nbytes < 0.75 * ops.TrainWorkspace(arena, K, R, n1 + n2, False).nbytes
     ops.train_step(arena, ws16, batch, bf16=mode)
     torch.cuda.synchronize()
     assert int(ws16.status.item()) == 0 and bool(torch.isfinite(ws16.grads).all())
-    np.testing.assert_allclose(ws16.loss_terms.cpu(), ws32.loss_terms.cpu(), rtol=3e-2 if mode == "bf16" else 1e-3, atol=3e-3)
-    g32, g16 = arena.views(ws32.grads), arena.views(ws16.grads)
-    for i in range(19):
-        if i in ops.FEAT_TENSORS:
-            assert float(g16[i].abs().max()) == 0.0
-            continue
-        a, r = g16[i].double().cpu(), g32[i].double().cpu()
-        rel = float((a - r).norm() / (r.norm() + 1e-30))
-        assert rel < bound, (i, ops.TENSOR_NAMES[i], rel)
+    gs = 2.0 ** (math.floor(math.log2(R)) + 3) if mode == "fp16" else 1.0
+    dt = {"bf16": torch.bfloat16, "fp16": torch.float16}[mode]
+    g16 = arena.views(ws16.grads)
+    for k in range(K):                          # one object at a time: the autograd graph of 10^6 samples is ~40 GB
+        bk = {key: v[k:k + 1] for key, v in b.items()}
+        o = oracle_step_16([p[k:k + 1] for p in st[:18]], st[18][k:k + 1], 2.0, bk, False, dt, True, gs, device=dev,
+                           round_head_weights=True, round_head_grads=True)
+        np.testing.assert_allclose(ws16.loss_terms.double().cpu()[k, :3], o["terms"][0, :3],
+                                   rtol=2e-4 if mode == "fp16" else 2e-3, atol=1e-5)
+        for i in list(range(14)) + [18]:
+            rel = rel_norm(g16[i][k], o["grads"][i][0])
+            print(f"{mode} c5 object {k} {ops.TENSOR_NAMES[i]:24s} rel {rel:.2e}")
+            assert rel < 0.01, (k, i, ops.TENSOR_NAMES[i], rel)
+        del o
+        torch.cuda.empty_cache()
+    for i in ops.FEAT_TENSORS:
+        assert float(g16[i].abs().max()) == 0.0
     first = ws16.grads.clone()
     ops.train_step(arena, ws16, batch, bf16=mode)                       # bit-reproducible
     torch.cuda.synchronize()

@@ -303,6 +303,39 @@ def test_get_training_samples_g7(golden, dev):
     assert maxerr(pts, g["gts_pts"]) < 4e-6
 
 
+@pytest.mark.parametrize("tag", ["pd5", "pd3"])
+def test_get_training_samples_partfeat_g7b(golden, dev, tag):
+    """A2's 7th output: sampled_partfeat = global_partfeat[use_frame[kf] / stride, floor(idx_w / part_down),
+    floor(idx_h / part_down)] (vmap.py:437-452), gathered inside objnerf_sample_rays -- bit-equal to the reference's
+    own get_training_samples with part_mode on (fixture G7b: part_down 5 / stride 1 and part_down 3 / stride 2), for
+    the single-object and the stacked entry."""
+    g = golden("g7b_partfeat")
+    pd, stride, Cf, W, H = [int(x) for x in g[f"{tag}_meta"]]
+    st = [T(g[f"{tag}_{k}"]).to(dev) for k in ["rgbs_batch", "depth_batch", "t_wc", "bbox"]]
+    cache = T(g["rays_dir_cache"]).to(dev)
+    dr = [T(g[f"{tag}_{k}"]).to(dev) for k in ["kf_ids", "u_w", "u_h", "u", "g"]]
+    gpf = T(g[f"{tag}_global_partfeat"]).to(dev)
+    out = ops.sample_rays(*st, cache, *dr, 1, 9, 0.1, 0.05, partfeat=(gpf, g[f"{tag}_use_frame"], stride, pd))
+    rgb, d, valid, labels, pts, z, pf = out
+    assert torch.equal(rgb.cpu(), T(g[f"{tag}_rgb"])) and torch.equal(d.cpu(), T(g[f"{tag}_depth"]))
+    assert torch.equal(labels.cpu(), T(g[f"{tag}_labels"]))
+    assert maxerr(z, g[f"{tag}_z"]) < 1e-6
+    assert pf.shape == g[f"{tag}_partfeat"].shape
+    assert torch.equal(pf.cpu(), T(g[f"{tag}_partfeat"]))
+    # stacked entry: two objects = the same store twice, the second with its keyframe slots' frames permuted
+    table = ops.keyframe_table([tuple(st), tuple(st)])
+    uf2 = np.stack([g[f"{tag}_use_frame"], g[f"{tag}_use_frame"][::-1].copy()])
+    o2 = ops.sample_rays_stacked(table, st[0].shape[0], W, H, cache, *[torch.stack([x, x]) for x in dr], 1, 9, 0.1, 0.05,
+                                 partfeat=(gpf, uf2, stride, pd))
+    assert torch.equal(o2[6][0].cpu(), T(g[f"{tag}_partfeat"]).reshape(-1, Cf))
+    ref1 = O.sample_partfeat(T(g[f"{tag}_global_partfeat"]), uf2[1], stride, pd, T(g[f"{tag}_kf_ids"]),
+                             *O.get_training_samples(*[x.cpu() for x in st], T(g[f"{tag}_kf_ids"]), T(g[f"{tag}_u_w"]),
+                                                     T(g[f"{tag}_u_h"]), T(g["rays_dir_cache"]))[4:6])
+    assert torch.equal(o2[6][1].cpu(), ref1.reshape(-1, Cf))
+    with pytest.raises(IndexError):                                   # a keyframe of a frame without part features
+        ops.sample_rays(*st, cache, *dr, 1, 9, 0.1, 0.05, partfeat=(gpf[:2], g[f"{tag}_use_frame"], stride, pd))
+
+
 def test_rays_dirs_g7(golden, dev):
     g = golden("g7_sample")
     W, H, fx, fy, cx, cy = [float(x) for x in g["gts_cam"]]

@@ -170,6 +170,104 @@ def test_two_rank_flags_and_loss_gloo():
         assert lone == (([[0.0] * 4] * 2, None, [0, 1]) if rank == 0 else (None, None, None))
 
 
+def _frame_worker(rank, world, port, q):
+    """A frame of n_iter iterations under object sharding: ONE pre-step exchange for the whole frame
+    (ShardedIteration.frame_pre) + one collective per iteration (the background gradient)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from openobj_amd import ops as oops, train as otrain
+    n_calls = [0]
+    _ar = dist.all_reduce
+
+    def counting(*a, **k):
+        n_calls[0] += 1
+        return _ar(*a, **k)
+
+    dist.all_reduce = counting
+
+    def cpu_label_counts(labels):                    # objnerf_label_counts restated (the kernel needs a GPU)
+        c = torch.stack([(labels == 1).sum(1), (labels != 2).sum(1)], dim=1).to(torch.int32)
+        return c, (c == 0).any(dim=0).to(torch.int32)
+
+    _lc = oops.label_counts
+    oops.label_counts = cpu_label_counts
+    n_iter, K, R, Rb = 5, 2, 6, 4
+    gen = torch.Generator().manual_seed(100 + rank)
+    obj_labels = torch.randint(0, 3, (n_iter, K, R), generator=gen, dtype=torch.uint8)
+    obj_labels[:, :, 0] = 1
+    if rank == 1:
+        obj_labels[2, 1] = 0                         # iteration 2: rank 1's second object has no label-1 ray
+        obj_labels[4, 0] = 2                         # iteration 4: all label 2 -> both masks empty
+    bg_labels = torch.randint(0, 3, (n_iter, 1, Rb), generator=gen, dtype=torch.uint8)
+    seen = []
+
+    class ObjLoop:
+        def step(self, batch, global_flags=None):
+            seen.append(("obj", global_flags.tolist()))
+            return torch.zeros(K, 4)
+
+    class BgLoop:
+        def begin(self, batch, counts, flags):
+            seen.append(("bg", counts.tolist(), flags.tolist()))
+            self.flat = torch.full((6,), float(rank + 1))
+            return odist.allreduce_sum_async(self.flat)
+
+        def finish(self, work):
+            work.wait()
+            return self.flat[-4:].view(1, 4)
+
+    try:
+        it = otrain.ShardedIteration(ObjLoop(), BgLoop(), device="cpu", resident=True)
+        pre = it.frame_pre(obj_labels, bg_labels)
+        after_pre = n_calls[0]
+        sums = []
+        for i in range(n_iter):
+            _, bt = it.step({"z": torch.zeros(K, R, 3), "labels": obj_labels[i]},
+                            {"z": torch.zeros(1, Rb, 3), "labels": bg_labels[i]}, pre=pre[i])
+            sums.append(bt[0, 0].item())
+        total = n_calls[0]
+        # a rank that owns nothing in this frame joins the ONE exchange and nothing else
+        it2 = otrain.ShardedIteration(ObjLoop() if rank == 0 else None, None, device="cpu")
+        pre2 = it2.frame_pre(obj_labels if rank == 0 else None, None, n_iter)
+        r2 = [it2.step({"z": torch.zeros(K, R, 3), "labels": obj_labels[i]} if rank == 0 else None, None, pre=pre2[i])
+              for i in range(n_iter)]
+        lone_calls = n_calls[0] - total
+    finally:
+        oops.label_counts = _lc
+        dist.all_reduce = _ar
+    bg_local = torch.stack([(bg_labels[:, 0] == 1).sum(1), (bg_labels[:, 0] != 2).sum(1)], dim=1)
+    q.put((rank, after_pre, total, lone_calls, seen, sums, bg_local.tolist(), [x[0] is None for x in r2]))
+    dist.destroy_process_group()
+
+
+def test_one_pre_step_collective_per_frame_gloo():
+    """mapping.train_frame under sharding: 1 + n_iter collectives per frame (the early-return flags and background mask
+    counts of ALL iterations in one int32[n_iter, 4] all-reduce before the loop -- render_rays.py:89-94,
+    train.py:447-463 -- then the background gradient's all-reduce per iteration), with the flags every rank's object
+    kernel sees equal to the batch-wide ones."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_frame_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    n_iter = 5
+    bg_global = (np.array(res[0][6]) + np.array(res[1][6])).tolist()
+    for rank, after_pre, total, lone_calls, seen, sums, _, lone_none in res:
+        assert after_pre == 1 and total == 1 + n_iter, (after_pre, total)
+        assert lone_calls == 1
+        obj_seen = [s[1] for s in seen if s[0] == "obj"][:n_iter]
+        assert obj_seen == [[0, 0], [0, 0], [1, 0], [0, 0], [1, 1]], obj_seen      # rank 1's empty masks, on BOTH ranks
+        bg_seen = [s for s in seen if s[0] == "bg"]
+        assert [s[1] for s in bg_seen] == [[c] for c in bg_global]                 # the GLOBAL background counts
+        assert [s[2] for s in bg_seen] == [[int(c[0] == 0), int(c[1] == 0)] for c in bg_global]
+        assert sums == [3.0] * n_iter                                               # collective 2 of every iteration
+        assert lone_none == ([False] * n_iter if rank == 0 else [True] * n_iter)
+
+
 def test_sharded_iteration_without_batches_unsharded_is_a_noop():
     from openobj_amd import train as otrain
     assert otrain.ShardedIteration(None, None).step(None, None) == (None, None)

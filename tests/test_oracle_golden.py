@@ -174,6 +174,41 @@ def test_g7_get_training_samples(golden):
     close(O.rays_dirs(int(W), int(H), fx, fy, cx, cy), g["gts_rays_dir_cache"], 0)
 
 
+@pytest.mark.parametrize("tag", ["pd5", "pd3"])
+def test_g7b_partfeat(golden, tag):
+    """get_training_samples with part_mode on: the 7th output (vmap.py:437-452)."""
+    g = golden("g7b_partfeat")
+    pd, stride, Cf, W, H = [int(x) for x in g[f"{tag}_meta"]]
+    rgbs, depth, _, _, idx_w, idx_h = O.get_training_samples(
+        T(g[f"{tag}_rgbs_batch"]), T(g[f"{tag}_depth_batch"]), T(g[f"{tag}_t_wc"]), T(g[f"{tag}_bbox"]),
+        T(g[f"{tag}_kf_ids"]), T(g[f"{tag}_u_w"]), T(g[f"{tag}_u_h"]), T(g["rays_dir_cache"]))
+    assert bool((rgbs[..., :3] == T(g[f"{tag}_rgb"])).all())
+    close(depth, g[f"{tag}_depth"], 0)
+    pf = O.sample_partfeat(T(g[f"{tag}_global_partfeat"]), g[f"{tag}_use_frame"], stride, pd, T(g[f"{tag}_kf_ids"]),
+                           idx_w, idx_h)
+    assert pf.shape == g[f"{tag}_partfeat"].shape
+    assert np.array_equal(pf.numpy(), g[f"{tag}_partfeat"])          # a gather: bit-exact
+
+
+@pytest.mark.parametrize("tag", ["nofeat", "feat"])
+def test_g15_forloop_first_step(golden, tag):
+    """The reference's forloop strategy (fixture G15) equals the stacked oracle step: loss and gradients of the
+    first iteration (the reference's two strategies agree to 1.9e-6)."""
+    g = golden(f"g15_forloop_{tag}")
+    K, R, n1, n2, feat_on = [int(x) for x in g["meta"]]
+    rec = _run_oracle_steps(g, 1, bool(feat_on),
+                            lambda it: synthetic.random_batch(K, R, n1, n2, seed=1500 + it, feat_dim=512))
+    np.testing.assert_allclose(rec["loss"][0], g["loss"][0], rtol=2e-5)
+    for i in range(19):
+        gr = rec["grads"][0][i]
+        if g["none_grad"][0][0][i]:
+            assert gr is None
+        else:
+            scale = max(1e-3, float(np.abs(g[f"grad0_{i}"]).max()))
+            close(gr, g[f"grad0_{i}"], 2e-5 * scale)
+        close(rec["params"][0][i], g[f"param0_{i}"], 2e-6)
+
+
 def test_g8_box(golden):
     g = golden("g8_box")
     near, far, hit = O.ray_box_intersection(T(g["o"]), T(g["d"]), T(g["bmin"]), T(g["bmax"]))

@@ -119,6 +119,49 @@ def test_seeded_equals_injected_philox(golden, dev, N, M):
     assert torch.equal(o["px"][:, 0].long(), iw) and torch.equal(o["px"][:, 1].long(), ih)
 
 
+@pytest.mark.parametrize("pd,stride,C", [(5, 1, 512), (3, 2, 20)])
+def test_seeded_partfeat_equals_injected_philox(golden, dev, pd, stride, C):
+    """The part-feature gather (vmap.py:437-452) of the SEEDED sampler equals that of the injected sampler -- which
+    fixture G7b pins to the reference bit for bit (test_get_training_samples_partfeat_g7b) -- when the injected draws
+    are the same Philox outputs; also through sceneObject.get_training_samples and StackedSampler (part_mode on)."""
+    _, cam, obj = g7_object(golden, dev, part_mode=1)
+    obj.part_down, obj.stride = pd, stride
+    obj.use_frame = np.array([0., 2., 1., 3.]) * stride
+    W, H = obj.frames_width, obj.frames_height
+    gpf = torch.randn(4, -(-W // pd), -(-H // pd), C, generator=torch.Generator().manual_seed(1)).to(dev)
+    seed, draw, nf, npx = 99, 5, 9, 300
+    meta = torch.tensor(obj.kf_meta(), dtype=torch.int32, device=dev)
+    pfa = (gpf, obj.use_frame, stride, pd)
+    o = ops.sample_rays_seeded(obj.keyframe_store(), 4, W, H, cam.rays_dir_cache, meta, nf, npx, 1, 9, obj.surface_eps,
+                               obj.stop_eps, float(obj.min_bound), float(obj.obj_center), seed=seed, draw=draw,
+                               want_pts=True, partfeat=pfa)
+    d = philox_draws(seed, draw, obj.obj_id, 4, [2, 3], nf, npx, 1, 9, obj.surface_eps)
+    dd = {k: T(v).to(dev) for k, v in d.items()}
+    r = ops.sample_rays(obj.rgbs_batch, obj.depth_batch, obj.t_wc_batch, obj.bbox, cam.rays_dir_cache, dd["kf_ids"],
+                        dd["u_w"], dd["u_h"], dd["u"], dd["g"], 1, 9, obj.surface_eps, obj.stop_eps,
+                        float(obj.min_bound), float(obj.obj_center), partfeat=pfa)
+    assert o["partfeat"].shape == (nf * npx, C)
+    assert torch.equal(o["partfeat"], r[6].reshape(-1, C))
+    # the same gather restated with torch indexing from the injected draws (the reference's three lines)
+    bb = obj.bbox[dd["kf_ids"]][:, None, :]
+    iw = dd["u_w"] * (bb[..., 1] - bb[..., 0]) + bb[..., 0]
+    ih = dd["u_h"] * (bb[..., 3] - bb[..., 2]) + bb[..., 2]
+    fid = (torch.tensor(obj.use_frame).to(dev)[dd["kf_ids"]][:, None] / stride).long()
+    ref = gpf[fid, torch.floor(iw / pd).long(), torch.floor(ih / pd).long()]
+    assert torch.equal(r[6], ref)
+    # the mirrored call surface
+    out = obj.get_training_samples(nf, npx, cam.rays_dir_cache, gpf, draws=dd)
+    assert len(out) == 7 and torch.equal(out[6], ref)
+    out = obj.get_training_samples(nf, npx, cam.rays_dir_cache, gpf, seed=seed)
+    assert out[6].shape == (nf, npx, C)
+    ss = ovmap.StackedSampler([obj, obj])
+    so = ss.sample(nf, npx, cam.rays_dir_cache, gpf, draws={k: torch.stack([v, v]) for k, v in dd.items()})
+    assert torch.equal(so[6][0], ref.reshape(-1, C)) and torch.equal(so[6][1], ref.reshape(-1, C))
+    so = ss.sample(nf, npx, cam.rays_dir_cache, gpf, seed=seed, compact=True)
+    assert so[6].shape == (2, nf * npx, C)
+    assert obj.get_training_samples(nf, npx, cam.rays_dir_cache, None, draws=dd)[6] is None
+
+
 def test_seeded_is_reproducible_and_keyed(golden, dev):
     _, cam, obj = g7_object(golden, dev)
     kw = dict(seed=5)
