@@ -509,7 +509,7 @@ def g7b():
 def g15():
     """training_strategy == "forloop" (train.py:240-251, 405-420, 435-474): every object's OWN modules in per-object
     param groups of one AdamW, outputs stacked before ONE step_batch_loss, backward, step, zero_grad -- three
-    iterations; in the second one object has no label-1 ray (the cross-object early return of render_rays.py:89-94
+    iterations, parameters recorded after every step; in the second one object has no label-1 ray (the cross-object early return of render_rays.py:89-94
     then zeroes the depth / colour / feature terms of EVERY object, and those tensors' .grad stays None)."""
     for tag, (K, R, n1, n2, feat_on) in {"nofeat": (2, 16, 1, 9, False), "feat": (2, 16, 1, 9, True)}.items():
         ts = make_trainers(K, seed=150)
@@ -549,9 +549,8 @@ def g15():
                                                      else torch.zeros_like(pl[i])) for pl in plist])
             optimiser.step()
             optimiser.zero_grad(set_to_none=True)
-            if it != 1:                                               # (after the first and the last step)
-                for i in range(19):
-                    out[f"param{it}_{i}"] = torch.stack([pl[i].detach().clone() for pl in plist])
+            for i in range(19):
+                out[f"param{it}_{i}"] = torch.stack([pl[i].detach().clone() for pl in plist])
         out["loss"] = np.array(losses, np.float64)
         out["none_grad"] = np.array(none_grad, np.int32)
         out["meta"] = np.array([K, R, n1, n2, int(feat_on)], np.int32)

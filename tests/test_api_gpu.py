@@ -380,10 +380,22 @@ def test_forloop_strategy_g15(golden, dev, tag):
         b = synthetic.random_batch(K, R, n1, n2, seed=1500 + it, feat_dim=512)
         if it == 1:
             b["labels"][1][b["labels"][1] == 1] = 0
+        if it > 0:
+            # AdamW's m / (sqrt(v) + eps) amplifies the RELATIVE error of an element's gradient, so two correct fp32
+            # implementations drift apart by up to lr per step in elements whose gradient is near zero, and the next
+            # iteration's gradients would be compared at different parameters.  Every iteration therefore starts from the
+            # reference's parameters (the optimiser keeps ITS moments and step counts): gradients are compared at
+            # identical weights, and the update is checked where it is well-conditioned.
+            with torch.no_grad():
+                for k, t in enumerate(ts):
+                    for i, v in enumerate(t.arena.views()):
+                        v[0].copy_(T(g[f"param{it - 1}_{i}"][k]))
         before = [t.arena.params.clone() for t in ts]
         terms = loop.step({k: T(b[k]).to(dev) for k in keys}).cpu()
         total = (terms[:, 0] + 5 * terms[:, 1] + 10 * terms[:, 2] + 5 * terms[:, 3]).sum().item()
         assert abs(total - g["loss"][it]) < 1e-4 * abs(g["loss"][it]), (it, total, g["loss"][it])
+        if it == 1:
+            assert float(terms[:, :2].abs().max()) == 0.0 and float(terms[:, 3].abs().max()) == 0.0
         for k, t in enumerate(ts):
             gv = t.arena.views(loop.wss[k].grads)
             pv0, pv1 = t.arena.views(before[k]), t.arena.views(t.arena.params)
@@ -394,8 +406,16 @@ def test_forloop_strategy_g15(golden, dev, tag):
                 ref = g[f"grad{it}_{i}"][k]
                 scale = max(1e-3, float(np.abs(ref).max()))
                 assert maxerr(gv[i][0], ref) < 1e-4 * scale, (it, k, ops.TENSOR_NAMES[i], maxerr(gv[i][0], ref), scale)
-                if it != 1:
-                    assert maxerr(pv1[i][0], g[f"param{it}_{i}"][k]) < 3e-6, (it, k, ops.TENSOR_NAMES[i])
+                # the optimiser step: strict where every gradient the element has seen so far is at least 1 % of its
+                # tensor's scale (relative gradient error <= 1e-2 there); elsewhere bounded by one step of lr
+                its = [j for j in range(it + 1) if not g["none_grad"][j][k][i]]
+                rel = np.min([np.abs(g[f"grad{j}_{i}"][k]) / max(1e-30, float(np.abs(g[f"grad{j}_{i}"][k]).max()))
+                              for j in its], axis=0)
+                err = (pv1[i][0].double().cpu() - torch.from_numpy(g[f"param{it}_{i}"][k]).double()).abs().numpy()
+                well = rel > 1e-2
+                assert well.sum() >= 1, (it, k, ops.TENSOR_NAMES[i])
+                assert err[well].max() < 3e-6, (it, k, ops.TENSOR_NAMES[i], float(err[well].max()), int(well.sum()))
+                assert err.max() < 1.1e-3 and np.median(err) < 1e-6, (it, k, ops.TENSOR_NAMES[i], float(err.max()))
     assert int(loop.status.item()) == 0
 
 

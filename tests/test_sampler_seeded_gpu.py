@@ -281,9 +281,9 @@ def test_scene_object_and_stacked_sampler_default_to_seeded_draws(golden, dev):
     gp = torch.arange(4 * (W // 2) * (H // 2), dtype=torch.float32, device=dev).reshape(4, W // 2, H // 2, 1).repeat(1, 1, 1, 3)
     rgb, depth, valid, labels, pts, z, pf = obj.get_training_samples(7, 5, cam.rays_dir_cache, gp, seed=9)
     assert rgb.shape == (7, 5, 3) and depth.shape == (7, 5) and pts.shape == (7, 5, 10, 3) and z.shape == (7, 5, 10)
-    assert pf.shape == (35, 3) and valid.shape == (35,) and labels.shape == (35,)
+    assert pf.shape == (7, 5, 3) and valid.shape == (35,) and labels.shape == (35,)
     # the looked-up feature encodes (frame, w / 2, h / 2): it must be the pixel the colour came from
-    code = pf[:, 0].long()
+    code = pf.reshape(-1, 3)[:, 0].long()
     f, rem = code // ((W // 2) * (H // 2)), code % ((W // 2) * (H // 2))
     cw, ch = rem // (H // 2), rem % (H // 2)
     hit = 0
