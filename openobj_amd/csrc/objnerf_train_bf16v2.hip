@@ -21,7 +21,7 @@
 //    layers' bias sums (against the embedding's constant-1 entry) and the head weights (a 4-row operand [d alpha,
 //    d colour] against h4 / hc) -- so no per-lane head / bias partial sums exist any more.
 //
-// Weight-gradient accumulators: 5 tile pairs per wave (40 registers), on waves 2-7.  LDS: forward images 29.0 KB +
+// Weight-gradient accumulators: 4 tile pairs per wave (32 registers); waves 0-1 take 2 pairs after their compositing.  LDS: forward images 29.0 KB +
 // small vectors 1.25 KB + per-sample heads 2 KB + staging 124 KB = 160 000 B.
 #define OBJ_HW_SINCOS 1      // embedding sin / cos on the transcendental unit (see objnerf_device.h)
 #include <utility>
@@ -71,6 +71,14 @@ __device__ __forceinline__ bf16x8 tr_operand(const char* base, const int off) {
 }
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack2(const float lo, const float hi) {
+  bf16x2 v;
+  v[0] = (__bf16)lo; v[1] = (__bf16)hi;
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ float unpack_lo(const unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float unpack_hi(const unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 // d * (h > 0) with h as the packed bf16 operand the forward built (element e = 4 tt + r of the lane's 8): a ReLU output
 // is positive exactly when its bf16 image is non-zero -- every consumer of an activation sees the rounded value
 __device__ __forceinline__ T32 relu_mask_packed(const T32& gr, const bf16x8 hp) {
@@ -90,20 +98,25 @@ __device__ __forceinline__ T32 relu_mask_packed(const T32& gr, const bf16x8 hp) 
 // ---- weight-gradient work list: (d block, activation tile) pairs of a wave; kind 1 = the head operand against two tiles
 struct Slot { int d, a, kind; };
 template <int W> struct WaveSlots;
-template <> struct WaveSlots<2> { static constexpr int n = 5; static constexpr Slot s[5] = {
-  {F_DH1, F_X1 + 0, 0}, {F_DH1, F_X1 + 32, 0}, {F_DH1, F_X1 + 64, 0}, {F_DH1, F_X1 + 96, 0}, {F_DH1, F_X1 + 128, 0}}; };
-template <> struct WaveSlots<3> { static constexpr int n = 4; static constexpr Slot s[5] = {
-  {F_DH1, F_X1 + 160, 0}, {F_DH2, F_H1, 0}, {F_DH2, F_H1 + 32, 0}, {F_DH2, X1_ONE_TILE, 0}, {0, 0, 0}}; };
-template <> struct WaveSlots<4> { static constexpr int n = 5; static constexpr Slot s[5] = {
-  {F_DH3, F_X1 + 0, 0}, {F_DH3, F_X1 + 32, 0}, {F_DH3, F_X1 + 64, 0}, {F_DH3, F_X1 + 96, 0}, {F_DH3, F_X1 + 128, 0}}; };
-template <> struct WaveSlots<5> { static constexpr int n = 5; static constexpr Slot s[5] = {
-  {F_DH3, F_X1 + 160, 0}, {F_DH3, F_H2, 0}, {F_DH3, F_H2 + 32, 0}, {F_DH4, F_H3, 0}, {F_DH4, F_H3 + 32, 0}}; };
-template <> struct WaveSlots<6> { static constexpr int n = 5; static constexpr Slot s[5] = {
-  {F_DHC, F_H4, 0}, {F_DHC, F_H4 + 32, 0}, {F_DHC, F_X2 + 0, 0}, {F_DHC, F_X2 + 32, 0}, {F_DHC, F_X2 + 64, 0}}; };
-template <> struct WaveSlots<7> { static constexpr int n = 4; static constexpr Slot s[5] = {
-  {F_DH4, X1_ONE_TILE, 0}, {F_DHC, F_X2 + 96, 0}, {F_HEAD, F_H4, 1}, {F_HEAD, F_HC, 1}, {0, 0, 0}}; };
+constexpr int NSLOT = 4;     // tile pairs per wave: 28 pairs = 6 waves x 4 + the two compositing waves x 2
+template <> struct WaveSlots<0> { static constexpr int n = 2; static constexpr Slot s[NSLOT] = {
+  {F_DHC, F_X2 + 64, 0}, {F_DHC, F_X2 + 96, 0}, {0, 0, 0}, {0, 0, 0}}; };
+template <> struct WaveSlots<1> { static constexpr int n = 2; static constexpr Slot s[NSLOT] = {
+  {F_HEAD, F_H4, 1}, {F_HEAD, F_HC, 1}, {0, 0, 0}, {0, 0, 0}}; };
+template <> struct WaveSlots<2> { static constexpr int n = 4; static constexpr Slot s[NSLOT] = {
+  {F_DH1, F_X1 + 0, 0}, {F_DH1, F_X1 + 32, 0}, {F_DH1, F_X1 + 64, 0}, {F_DH1, F_X1 + 96, 0}}; };
+template <> struct WaveSlots<3> { static constexpr int n = 4; static constexpr Slot s[NSLOT] = {
+  {F_DH3, F_X1 + 0, 0}, {F_DH3, F_X1 + 32, 0}, {F_DH3, F_X1 + 64, 0}, {F_DH3, F_X1 + 96, 0}}; };
+template <> struct WaveSlots<4> { static constexpr int n = 4; static constexpr Slot s[NSLOT] = {
+  {F_DHC, F_H4, 0}, {F_DHC, F_H4 + 32, 0}, {F_DHC, F_X2 + 0, 0}, {F_DHC, F_X2 + 32, 0}}; };
+template <> struct WaveSlots<5> { static constexpr int n = 4; static constexpr Slot s[NSLOT] = {
+  {F_DH3, F_X1 + 128, 0}, {F_DH3, F_X1 + 160, 0}, {F_DH3, F_H2, 0}, {F_DH3, F_H2 + 32, 0}}; };
+template <> struct WaveSlots<6> { static constexpr int n = 4; static constexpr Slot s[NSLOT] = {
+  {F_DH1, F_X1 + 128, 0}, {F_DH1, F_X1 + 160, 0}, {F_DH2, F_H1, 0}, {F_DH2, F_H1 + 32, 0}}; };
+template <> struct WaveSlots<7> { static constexpr int n = 4; static constexpr Slot s[NSLOT] = {
+  {F_DH4, F_H3, 0}, {F_DH4, F_H3 + 32, 0}, {F_DH4, X1_ONE_TILE, 0}, {F_DH2, X1_ONE_TILE, 0}}; };
 
-struct WAcc { f32x4 a[5][2]; };
+struct WAcc { f32x4 a[NSLOT][2]; };
 
 // one 32-sample k-step of slot J: base = staging + (4 g + q) * PITCH + 8 p + 32 st * PITCH
 template <int W, int J>
@@ -140,7 +153,6 @@ __device__ __forceinline__ void wgrad_wave(WAcc& acc, const char* lane_base) {
     wgrad_slot<W, 1>(acc, base, a0, a1);
     wgrad_slot<W, 2>(acc, base, a0, a1);
     wgrad_slot<W, 3>(acc, base, a0, a1);
-    wgrad_slot<W, 4>(acc, base, a0, a1);
   }
 }
 
@@ -210,7 +222,6 @@ __device__ __forceinline__ void emit_wave(float* slab, const Layout& L, const WA
   emit_slot<W, 1>(slab, L, acc, c, g);
   emit_slot<W, 2>(slab, L, acc, c, g);
   emit_slot<W, 3>(slab, L, acc, c, g);
-  emit_slot<W, 4>(slab, L, acc, c, g);
 }
 
 // Optional scheduling fences (-DV2_FENCES) at the layer boundaries of the forward / backward passes.  (The first build
@@ -262,7 +273,7 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16v2_kernel(const TrainDev
 
   WAcc acc;
 #pragma unroll
-  for (int j = 0; j < 5; ++j) acc.a[j][0] = acc.a[j][1] = zero4();
+  for (int j = 0; j < NSLOT; ++j) acc.a[j][0] = acc.a[j][1] = zero4();
   float g_ba = 0.f, g_boc0 = 0.f, g_boc1 = 0.f, g_boc2 = 0.f;
   float dB[6][3];                           // d B[4 i + g][x], summed over this lane's samples
 #pragma unroll
@@ -334,8 +345,17 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16v2_kernel(const TrainDev
     pe_project_b(sm, g, nx, ny, nz, inv_scale, pe);
     PT(0);
     bf16x8 h1p, h2p, h3p, h4p, hcp;          // the activations as the packed operands every consumer sees
+#ifndef V2_RECOMPUTE_PE
+    // the embedding blocks and the chain-rule factors d sin(2^f a) / d proj = cos(2^f a) pi 2^f of the lane's six
+    // directions (bf16 pairs; zero where the slot holds no direction) stay in registers for the backward pass: it then
+    // needs no transcendental and no range reduction at all (they were ~20 % of the kernel's VALU instructions)
+    bf16x8 xb1[3], xb2[2];
+    unsigned cpk[18];
+#endif
     {
+#ifdef V2_RECOMPUTE_PE
       bf16x8 xb1[3], xb2[2];
+#endif
       {
         // forward-only embedding (the backward re-creates it tile by tile), packed block by block
         f32x4 x2v[3];
@@ -346,7 +366,15 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16v2_kernel(const TrainDev
           for (int u = 0; u < 2; ++u) {
             const int i = 2 * b + u;
             float sn[6], cs[6];
+#ifdef V2_RECOMPUTE_PE
             obj32n::pe32_octaves<0, 5, false>(pe.vh[i], pe.vl[i], sn, cs);
+#else
+            obj32n::pe32_octaves<0, 5, true>(pe.vh[i], pe.vl[i], sn, cs);
+            const float live = (i == 5 && g != 0) ? 0.0f : OBJ_PI_F;      // only group 0 has a sixth direction
+#pragma unroll
+            for (int f = 0; f < 6; f += 2)
+              cpk[3 * i + (f >> 1)] = pack2(cs[f] * (live * (float)(1 << f)), cs[f + 1] * (live * (float)(2 << f)));
+#endif
             xv[u] = obj32n::pe32_x1_tile(pe, i, g, sn);
             float v4, v5;
             obj32n::pe32_x2_pair(i, g, sn, v4, v5);
@@ -471,12 +499,15 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16v2_kernel(const TrainDev
         s_col[TS + sl] = gC1 * wgt * c1 * (1.0f - c1);
         s_col[2 * TS + sl] = gC2 * wgt * c2 * (1.0f - c2);
       }
+    }
 #ifdef V2_NO_WGRAD
-    } else if (have_prev && a.K < 0) {
+    if (have_prev && a.K < 0) {
 #else
-    } else if (have_prev) {
+    if (have_prev) {         // (the compositing waves take two of the 28 tile pairs each, the other six four)
 #endif
       switch (w) {
+        case 0: wgrad_wave<0>(acc, tr_stg); break;
+        case 1: wgrad_wave<1>(acc, tr_stg); break;
         case 2: wgrad_wave<2>(acc, tr_stg); break;
         case 3: wgrad_wave<3>(acc, tr_stg); break;
         case 4: wgrad_wave<4>(acc, tr_stg); break;
@@ -533,14 +564,25 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16v2_kernel(const TrainDev
       for (int T = 0; T < 3; ++T) {
         f32x4 d_x = zero4();
         BWD_TILE(d_x, t_cl, RS_CL, 1 + (T >> 1), T & 1, d_hc_b);
+#ifdef V2_RECOMPUTE_PE
         float o0, o1, o2, o3;
         obj32n::pe32_x2_pair_fb(pe, 2 * T, g, d_x[0], d_x[1], dps[2 * T], o0, o1);
         obj32n::pe32_x2_pair_fb(pe, 2 * T + 1, g, d_x[2], d_x[3], dps[2 * T + 1], o2, o3);
         x2v[T] = f32x4{o0, o1, o2, o3};
+#else
+        dps[2 * T] = fmaf(d_x[1], unpack_hi(cpk[6 * T + 2]), fmaf(d_x[0], unpack_lo(cpk[6 * T + 2]), dps[2 * T]));
+        dps[2 * T + 1] = fmaf(d_x[3], unpack_hi(cpk[6 * T + 5]), fmaf(d_x[2], unpack_lo(cpk[6 * T + 5]), dps[2 * T + 1]));
+#endif
         SCHED_FENCE();
       }
+#ifdef V2_RECOMPUTE_PE
       *reinterpret_cast<bf16x8*>(row_st + F_X2) = pack8(x2v[0], x2v[1]);
       *reinterpret_cast<bf16x8*>(row_st + F_X2 + 64) = pack8(x2v[2], zero4());
+#else
+      (void)x2v;
+      *reinterpret_cast<bf16x8*>(row_st + F_X2) = xb2[0];
+      *reinterpret_cast<bf16x8*>(row_st + F_X2 + 64) = xb2[1];
+#endif
     }
     PT(6);
     SCHED_FENCE();
@@ -578,10 +620,20 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16v2_kernel(const TrainDev
         f32x4 d_x = zero4();
         BWD_TILE(d_x, t_cat, RS_CAT, 1 + b, u, d_h3_b);
         BWD_TILE(d_x, t_in, RS_IN, b, u, d_h1_b);
+#ifdef V2_RECOMPUTE_PE
         xv[u] = obj32n::pe32_x1_tile_fb(pe, T, g, d_x, dps[T]);
+#else
+        dps[T] = fmaf(d_x[3], unpack_hi(cpk[3 * T + 1]), fmaf(d_x[2], unpack_lo(cpk[3 * T + 1]),
+                 fmaf(d_x[1], unpack_hi(cpk[3 * T]), fmaf(d_x[0], unpack_lo(cpk[3 * T]), dps[T]))));
+#endif
         SCHED_FENCE();
       }
+#ifdef V2_RECOMPUTE_PE
       *reinterpret_cast<bf16x8*>(row_st + F_X1 + 64 * b) = pack8(xv[0], xv[1]);
+#else
+      (void)xv;
+      *reinterpret_cast<bf16x8*>(row_st + F_X1 + 64 * b) = xb1[b];
+#endif
     }
     // d B[j][x] += d proj_j * t_x (embedding.py:48); j = 4 i + g lives in this lane only
 #pragma unroll
@@ -597,8 +649,10 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16v2_kernel(const TrainDev
   PT_FLUSH();
   // the last tile's weight gradients
   __syncthreads();
-  if (w >= TR && have_prev) {
+  if (have_prev) {
     switch (w) {
+      case 0: wgrad_wave<0>(acc, tr_stg); break;
+      case 1: wgrad_wave<1>(acc, tr_stg); break;
       case 2: wgrad_wave<2>(acc, tr_stg); break;
       case 3: wgrad_wave<3>(acc, tr_stg); break;
       case 4: wgrad_wave<4>(acc, tr_stg); break;
@@ -631,6 +685,8 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16v2_kernel(const TrainDev
   float* slab = a.slab + ((long)k * a.G + gi) * a.slab_stride;
   const Layout& L = a.L;
   switch (w) {
+    case 0: emit_wave<0>(slab, L, acc, c, g); break;
+    case 1: emit_wave<1>(slab, L, acc, c, g); break;
     case 2: emit_wave<2>(slab, L, acc, c, g); break;
     case 3: emit_wave<3>(slab, L, acc, c, g); break;
     case 4: emit_wave<4>(slab, L, acc, c, g); break;

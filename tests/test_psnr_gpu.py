@@ -73,9 +73,11 @@ def test_hidden_256_network_psnr(dev, mode):
     """16-bit configurations are judged by PSNR.  BASELINE configs[4]'s network (hidden 256) on
     the G9 scene at 32 samples per ray (fixture G9C: the reference's own modules, 33 weight seeds): bf16 / fp16 run the
     two FUSED hidden-256 kernels (objnerf_train256.hip: fwd256_kernel + wgrad256_kernel), fp32 the layer-wise chain.
-    After 50 iterations the per-seed difference is well-posed (fp32: every seed within 0.1 dB; 16-bit: the mean within
-    0.1 dB and no seed beyond 0.5); after 300 the ensemble means compare, within max(0.1 dB, the 95 % interval 33
-    seeds give)."""
+    At this width training is chaotic from the start: the REFERENCE ITSELF moves by 0.3 .. 2.7 dB after 50 iterations
+    when its initial weights are perturbed by 1e-7 (profiles/r04_h256_sensitivity.txt, tools/h256_sensitivity.py), so no
+    per-seed statement is well-posed (at hidden 32 it is: test_fp32_per_seed_after_50_iterations).  Both comparisons
+    are therefore between ensembles: the difference of the 33-seed means after 50 and after 300 iterations within
+    max(0.1 dB, its 95 % interval), the spread of the ensemble like the reference's, and no seed collapsing."""
     ref = psnr_scene.reference_ensemble_c()
     assert ref is not None, "tests/golden/g9c_ensemble_h256.npz missing"
     seeds = [int(x) for x in ref["seeds"]]
@@ -85,10 +87,8 @@ def test_hidden_256_network_psnr(dev, mode):
     c = psnr_scene.compare(run, ref, len(seeds))
     print(mode, "hidden 256:", c)
     assert c["iter50"]["n"] >= 32
-    if mode == "f32":
-        assert c["iter50"]["max_abs_delta_db"] < 0.1, c["iter50"]
-    else:
-        assert c["iter50"]["max_abs_delta_db"] < 0.5, c["iter50"]
-    assert abs(c["iter50"]["mean_delta_db"]) < 0.1, c["iter50"]
+    early = psnr_scene.delta_report(run["psnr50"], ref["psnr50"][:len(seeds)])
+    assert abs(early["delta_db"]) < max(0.1, early["ci95_db"]), early
     assert abs(c["iter300"]["delta_db"]) < max(0.1, c["iter300"]["ci95_db"]), c["iter300"]
-    assert run["psnr300"].min() > ref["psnr300"].min() - 1.5
+    assert abs(c["iter300"]["hip_std_db"] - c["iter300"]["ref_std_db"]) < 0.6, c["iter300"]
+    assert run["psnr300"].min() > ref["psnr300"].min() - 1.5 and run["psnr50"].min() > ref["psnr50"].min() - 1.5
