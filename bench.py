@@ -52,7 +52,8 @@ PEAK_HBM_GBS = 8000.0             # HBM3E, MI355X_MICROARCH.md
 VALU_SIMDS = 256 * 4              # SIMDs of the chip
 VALU_CYCLES_PER_INST = 2.0        # a wave64 VALU instruction occupies its SIMD-32 for 2 cycles (cycle-constants table)
 CLOCK_HZ = 2.4e9
-RECORDED = os.path.join(ROOT, "profiles", "r03_counters.json")
+RECORDED = os.path.join(ROOT, "profiles", "r04_counters.json")
+HBM_SUSTAINED_GBS = 6300.0        # what streaming kernels sustain of the 8 TB/s (MI355X_MICROARCH.md: 6.0-6.3 TB/s)
 BG_GRAD_FLOATS = 182339 + 4       # the replicated background network's gradient + its four loss terms (collective 2)
 
 CONFIGS = {
@@ -202,7 +203,7 @@ def recorded_counters(kernel: str, K, R, S):
     separate runs, gfx950 FETCH_SIZE correction applied: tools/gpu_profile_round3.sh).  Hardware counters cannot be
     read from inside this process: these are RECORDED values of the same launch, None when the workload differs.
     Entries recorded per object (the hidden-256 path runs its objects in workspace chunks) are scaled to K objects."""
-    for path in (RECORDED, RECORDED.replace("r03_", "r02_")):
+    for path in (RECORDED, RECORDED.replace("r04_", "r03_"), RECORDED.replace("r04_", "r02_")):
         try:
             with open(path) as f:
                 for e in json.load(f)["kernels"]:
@@ -403,6 +404,8 @@ class Workload:
     def kernel_name(self, mode):
         feat, S, Hd = self.feat, self.S, self.Hd
         if Hd == 32 and S <= 64 and mode != "fp16":
+            if mode and not feat and S == 64:
+                return "train_fused_bf16v2_kernel"       # second-generation kernel (objnerf_train_bf16v2.hip)
             if mode:
                 return "train_fused_bf16_kernel<%s, %d>" % ("true" if feat else "false", 64 if S == 64 else 0)
             return "train_fused32_kernel<%s, false, %d>" % ("true" if feat else "false", 64 if S == 64 else 0)
@@ -429,6 +432,13 @@ class Workload:
         if rec:
             if rec.get("hbm_bytes_per_launch"):
                 roof["traffic_ratio"] = rec["hbm_bytes_per_launch"] / alg
+                # the same launch against the HBM roof: recorded bytes / kernel time / sustained bandwidth (the
+                # hidden-256 pair moves ~700x its algorithmic bytes: for it THIS is the binding resource, not the MFMA)
+                roof["hbm_gbs"] = rec["hbm_bytes_per_launch"] / (kern_ms * 1e-3) / 1e9
+                roof["hbm_frac"] = roof["hbm_gbs"] / HBM_SUSTAINED_GBS
+                if roof["hbm_frac"] > roof["frac"]:
+                    roof["binding"] = "hbm (frac %.2f of %.0f GB/s sustained) -- `frac` is the MFMA figure SURVEY.md 8(d) asks for" % (
+                        roof["hbm_frac"], HBM_SUSTAINED_GBS)
             if mode and rec.get("valu_insts_per_launch"):
                 floor_ms = rec["valu_insts_per_launch"] * VALU_CYCLES_PER_INST / (VALU_SIMDS * CLOCK_HZ) * 1e3
                 roof.update({"valu_insts_per_launch": rec["valu_insts_per_launch"], "valu_floor_ms": floor_ms,
