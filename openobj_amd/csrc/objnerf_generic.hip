@@ -286,22 +286,14 @@ template <> struct Op16<_Float16> {
 // ds_read_b64_tr_b16 (gfx950's transposing LDS read: a 16-lane group reads a 4 k x 16 rows block column-wise;
 // tools/ubench_tr.hip checks the lane map).  Before, those tiles went to the [row][k] image as 2-byte stores with a
 // 4-way bank conflict and the hidden-256 weight gradients ran at 18 TFLOP/s.
-// (the read is issued without a wait; lds_tr16_wait ties the results of a batch of reads to ONE s_waitcnt, so the reads
-// of a k-step are in flight together instead of one LDS round trip each)
+// The read is the compiler's builtin (__builtin_amdgcn_ds_read_tr16_b64_*): it knows the instruction returns through
+// LGKM, so it places the s_waitcnt itself and a batch of reads stays in flight together.  (Rounds 2-3 issued it as bare
+// inline asm with a hand-written wait tied to the destination registers: correct only as long as the register
+// allocator never copied a destination before that wait.)
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint2 lds_tr16(const void* p) {
-  uint2 r;
-  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"((uint32_t)(uintptr_t)p) : "memory");
-  return r;
-}
-// (the results must not be touched -- not even copied -- before the wait: the hardware does not interlock on LDS
-// returns, so the wait is tied to the very registers the reads write)
-template <int N>
-__device__ __forceinline__ void lds_tr16_wait(uint2 (&lo)[N], uint2 (&hi)[N]) {
-  static_assert(N == 2 || N == 4, "batch size");
-#define OBJ_T2(i) "+v"(lo[i]), "+v"(hi[i])
-  if constexpr (N == 2) asm volatile("s_waitcnt lgkmcnt(0)" : OBJ_T2(0), OBJ_T2(1)::"memory");
-  else asm volatile("s_waitcnt lgkmcnt(0)" : OBJ_T2(0), OBJ_T2(1), OBJ_T2(2), OBJ_T2(3)::"memory");
-#undef OBJ_T2
+  const s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(p));
+  return __builtin_bit_cast(uint2, v);
 }
 // (the 8-wave tile is held to 128 registers -- two workgroups per CU: at 130 the fp16 forward variant lost one)
 //
@@ -558,10 +550,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? ((AFULL && KMAX == 2
 #pragma unroll
     for (int i = 0; i < T; ++i) {
       const OT* p = img + (ks + 8 * gg + (c >> 2)) * pitch + row0 + 16 * i + 4 * (c & 3);
-      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo[i]) : "v"((uint32_t)(uintptr_t)p) : "memory");
-      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi[i]) : "v"((uint32_t)(uintptr_t)(p + 4 * pitch)) : "memory");
+      lo[i] = lds_tr16(p);
+      hi[i] = lds_tr16(p + 4 * pitch);
     }
-    lds_tr16_wait(lo, hi);
 #pragma unroll
     for (int i = 0; i < T; ++i) out[i] = __builtin_bit_cast(OV, uint4{lo[i].x, lo[i].y, hi[i].x, hi[i].y});
   };

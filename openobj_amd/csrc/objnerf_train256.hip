@@ -1247,10 +1247,11 @@ struct WgArgs {
 constexpr int IMG_PITCH = 72;                       // bytes per sample row of a 32-feature block image
 constexpr int IMG_BLK = 32 * IMG_PITCH;             // 2304
 
+// the compiler's builtin: it tracks the LGKM return itself (no hand-counted s_waitcnt behind the reads any more)
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint2 lds_tr16(const uint32_t addr) {
-  uint2 r;
-  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr) : "memory");
-  return r;
+  const s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(uintptr_t)addr);
+  return __builtin_bit_cast(uint2, v);
 }
 
 // RB / CB: row / column blocks of the task; NRG x NCG waves; AK / BK: 0 hidden fragments (2 per block), 1 head, 2 x slots
@@ -1347,17 +1348,7 @@ __device__ __forceinline__ void wgrad_task(const WgArgs& a, const char* Asrc, co
             const uint32_t ad = rowoff + (RB + cg * CBW + j) * IMG_BLK;
             blo[j] = lds_tr16(ad); bhi[j] = lds_tr16(ad + 4 * IMG_PITCH);
           }
-          // one wait for the whole batch, tied to the registers the reads write
-          if constexpr (RBW == 2 && CBW == 4)
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(alo[0]), "+v"(ahi[0]), "+v"(alo[1]), "+v"(ahi[1]), "+v"(blo[0]), "+v"(bhi[0]),
-                         "+v"(blo[1]), "+v"(bhi[1]), "+v"(blo[2]), "+v"(bhi[2]), "+v"(blo[3]), "+v"(bhi[3])::"memory");
-          else if constexpr (CBW == 3)
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(alo[0]), "+v"(ahi[0]), "+v"(blo[0]), "+v"(bhi[0]), "+v"(blo[1]), "+v"(bhi[1]),
-                         "+v"(blo[2]), "+v"(bhi[2])::"memory");
-          else if constexpr (CBW == 2)
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(alo[0]), "+v"(ahi[0]), "+v"(blo[0]), "+v"(bhi[0]), "+v"(blo[1]), "+v"(bhi[1])::"memory");
-          else
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(alo[0]), "+v"(ahi[0]), "+v"(blo[0]), "+v"(bhi[0])::"memory");
+          // (the compiler waits for the batch of reads where their results are first used)
           __builtin_amdgcn_sched_barrier(0);
           V af[RBW], bf[CBW];
 #pragma unroll
@@ -1469,7 +1460,6 @@ __device__ __forceinline__ void wgrad_cat(const char* Asrc, const char* Hsrc, co
   const uint32_t tr_lane = (uint32_t)(((li >> 2) + 8 * h) * IMG_PITCH + (16 * grp + 4 * (li & 3)) * 2);
   auto frag = [&](const uint32_t ad) __attribute__((always_inline)) -> V {
     uint2 lo = lds_tr16(ad), hi = lds_tr16(ad + 4 * IMG_PITCH);
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo), "+v"(hi)::"memory");
     const uint4 u = make_uint4(lo.x, lo.y, hi.x, hi.y);
     return *reinterpret_cast<const V*>(&u);
   };
@@ -1490,7 +1480,6 @@ __device__ __forceinline__ void wgrad_cat(const char* Asrc, const char* Hsrc, co
       uint2 alo = lds_tr16(rowoff + w * IMG_BLK), ahi = lds_tr16(rowoff + w * IMG_BLK + 4 * IMG_PITCH);
       uint2 hlo = alo, hhi = ahi;
       if (HEAD) { hlo = lds_tr16(rowoff + 8 * IMG_BLK); hhi = lds_tr16(rowoff + 8 * IMG_BLK + 4 * IMG_PITCH); }
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(alo), "+v"(ahi), "+v"(hlo), "+v"(hhi)::"memory");
       const uint4 ua = make_uint4(alo.x, alo.y, ahi.x, ahi.y);
       const V af = *reinterpret_cast<const V*>(&ua);
 #pragma unroll
@@ -1502,8 +1491,6 @@ __device__ __forceinline__ void wgrad_cat(const char* Asrc, const char* Hsrc, co
         for (int j = 0; j < 4; ++j)
           if (j0 + j < CB) { blo[j] = lds_tr16(rowoff + (NA + j0 + j) * IMG_BLK); bhi[j] = lds_tr16(rowoff + (NA + j0 + j) * IMG_BLK + 4 * IMG_PITCH); }
           else { blo[j] = blo[0]; bhi[j] = bhi[0]; }
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(blo[0]), "+v"(bhi[0]), "+v"(blo[1]), "+v"(bhi[1]), "+v"(blo[2]), "+v"(bhi[2]),
-                     "+v"(blo[3]), "+v"(bhi[3])::"memory");
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -1524,7 +1511,6 @@ __device__ __forceinline__ void wgrad_cat(const char* Asrc, const char* Hsrc, co
         {
           const uint32_t ad = rowoff + (NA + w) * IMG_BLK;
           uint2 lo = lds_tr16(ad), hi = lds_tr16(ad + 4 * IMG_PITCH);
-          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo), "+v"(hi)::"memory");
           const uint4 u = make_uint4(lo.x, lo.y, hi.x, hi.y);
           bw = *reinterpret_cast<const V*>(&u);
         }
