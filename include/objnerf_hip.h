@@ -169,6 +169,20 @@ int objnerf_box_points(int64_t n, int32_t n_bins, const float* origin /* [3] */,
                        const float* near, const float* far, const float* u, uint64_t seed, uint32_t draw,
                        float* out_z, float* out_pts, void* stream);
 
+/* f-1 in ONE launch (ABI 6): sceneObject.render_2D_syn's per-object chain (vmap.py:644-676) for the n hit rays of
+ * objnerf_box_rays -- the 149 mid-points of Trainer.sample_points_bbox (trainer.py:171-176; u [n][n_bins] injected, or
+ * NULL: the Philox draws of objnerf_box_points under (seed, draw)), UniDirsEmbed + OccupancyMap (embedding.py:46-55,
+ * model.py:61-103), occupancy_activation / occupancy_to_termination / render (render_rays.py:6-63) -- with a lane per
+ * ray and nothing per sample in HBM.  params: ONE object's block, scale [1].  Outputs per ray: depth, opacity, rgb [3]
+ * and (out_hfeat != NULL) the composited hidden of the feature branch [n][H]: the 512-d map is objnerf_feature_head of
+ * it with weight = opacity (exact: that head is linear).  out_z [n][n_bins-1] optional (the z_vals of the call).
+ * Hidden 32 only (OBJNERF_ENOTSUP otherwise: wider networks keep objnerf_box_points -> objnerf_eval_points_ws ->
+ * objnerf_composite). */
+int objnerf_render_fwd(const objnerf_net* net, int64_t n, int32_t n_bins, const float* params, const float* scale,
+                       const float* origin /* [3] */, const float* dirs_W, const float* near, const float* far,
+                       const float* u, uint64_t seed, uint32_t draw, float* out_depth, float* out_opacity,
+                       float* out_rgb, float* out_hfeat, float* out_z, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * A6+A7  UniDirsEmbed.forward + OccupancyMap.forward (embedding.py:46-55, model.py:61-103),
  * inference: K objects x N points each.

@@ -119,6 +119,17 @@ __device__ __forceinline__ float sigmoid_acc(float x) {
 }
 
 
+// utils.stratified_bins (utils.py:342-379): torch.linspace(0, 1, n + 1)[i] in fp32 (the GPU formula: start + step i
+// below the middle, end - step (n - i) above) and bin i of [lo, hi] with the draw u
+__device__ __forceinline__ float lin01(int i, int n) {
+  const float step = 1.0f / (float)n;
+  return (i < (n + 1) / 2) ? step * (float)i : 1.0f - step * (float)(n - i);
+}
+__device__ __forceinline__ float strat(float lo, float hi, int i, int n, float u) {
+  const float rng = hi - lo;
+  return (rng * lin01(i, n) + lo) + u * (rng / (float)n);
+}
+
 // ----------------------------------------------------------------------------------------------
 // wave64 helpers
 // ----------------------------------------------------------------------------------------------

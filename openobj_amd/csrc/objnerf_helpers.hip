@@ -5,6 +5,7 @@
 // training path (the fused kernels carry their own loss and sampler).
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include "objnerf_device.h"
 #include "objnerf_philox.h"
 #include "../../include/objnerf_hip.h"
 
@@ -117,10 +118,6 @@ __global__ void dirs_w_kernel(long F, long P, const float* T_WC, const float* di
   for (int r = 0; r < 3; ++r) dirs_W[i * 3 + r] = (T[4 * r] * d0 + T[4 * r + 1] * d1) + T[4 * r + 2] * d2;
 }
 
-__device__ __forceinline__ float lin01(int i, int n) {           // torch.linspace(0, 1, n + 1)[i], fp32
-  const float step = 1.0f / (float)n;
-  return (i < (n + 1) / 2) ? step * (float)i : 1.0f - step * (float)(n - i);
-}
 // stratified_bins, utils.py:342-379: lo + range * i / n + U(0, 1) * range / n.  lo / hi: per ray, or NULL = the scalar
 __global__ void strat_bins_kernel(long n_rays, int n_bins, const float* lo_p, float lo_s, const float* hi_p, float hi_s,
                                   const float* u, unsigned long long seed, unsigned long long offset, float* out) {

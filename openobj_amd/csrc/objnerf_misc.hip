@@ -590,14 +590,6 @@ __global__ void ingest_frame_kernel(int W, int H, const uint8_t* rgb, const floa
   it.depth[(long)it.slot * npx + p] = depth[p];
 }
 
-__device__ __forceinline__ float lin01(int i, int n) {           // torch.linspace(0,1,n+1)[i], fp32
-  const float step = 1.0f / (float)n;
-  return (i < (n + 1) / 2) ? step * (float)i : 1.0f - step * (float)(n - i);
-}
-__device__ __forceinline__ float strat(float lo, float hi, int i, int n, float u) {   // utils.py:342-379
-  const float rng = hi - lo;
-  return (rng * lin01(i, n) + lo) + u * (rng / (float)n);
-}
 
 // ------------------------------------------------------------------------------------------------
 // Trainer.sample_points_bbox (trainer.py:130-198)

@@ -325,7 +325,7 @@ __device__ __forceinline__ void prio_layer(const int) {}
 #endif
 
 template <bool FEAT>
-__device__ __forceinline__ float mlp32_forward(const float* wf, const float* sv, const int g, const Emb32& e, Acts& a) {
+__device__ __forceinline__ void mlp32_trunk(const float* wf, const float* sv, const int g, const Emb32& e, Acts& a) {
   T32 acc = zero32();
   prio_layer(1);
 #pragma unroll
@@ -365,6 +365,10 @@ __device__ __forceinline__ float mlp32_forward(const float* wf, const float* sv,
     a.hf = relu32(acc);
   }
   prio_layer(-1);
+}
+// the four head pre-activations of the lane's sample, summed over the lane groups (every lane ends with all four)
+__device__ __forceinline__ void mlp32_head_sums(const float* sv, const int g, const Acts& a, float& sa, float& s0, float& s1,
+                                                float& s2) {
   float pa = 0.f, pc0 = 0.f, pc1 = 0.f, pc2 = 0.f;
 #pragma unroll
   for (int tt = 0; tt < 2; ++tt)
@@ -376,10 +380,28 @@ __device__ __forceinline__ float mlp32_forward(const float* wf, const float* sv,
       pc1 = fmaf(sv[SV_WOC + H + row], a.hc.t[tt][r], pc1);
       pc2 = fmaf(sv[SV_WOC + 2 * H + row], a.hc.t[tt][r], pc2);
     }
-  const float sa = xgroup_sum(pa), s0 = xgroup_sum(pc0), s1 = xgroup_sum(pc1), s2 = xgroup_sum(pc2);
+  sa = xgroup_sum(pa); s0 = xgroup_sum(pc0); s1 = xgroup_sum(pc1); s2 = xgroup_sum(pc2);
+}
+template <bool FEAT>
+__device__ __forceinline__ float mlp32_forward(const float* wf, const float* sv, const int g, const Emb32& e, Acts& a) {
+  mlp32_trunk<FEAT>(wf, sv, g, e, a);
+  float sa, s0, s1, s2;
+  mlp32_head_sums(sv, g, a, sa, s0, s1, s2);
   const float mine = (g == 0) ? sa : ((g == 1) ? s0 : ((g == 2) ? s1 : s2));
   const float z = mine + sv[SV_HB + g];
   return (g == 0) ? z * 10.0f : sigmoid_acc(z);
+}
+// the rendering form: EVERY lane group gets the density head (10 * raw alpha, model.py:88) and, groups 1..3, its own
+// colour channel after the sigmoid (group 0: 0)
+template <bool FEAT>
+__device__ __forceinline__ void mlp32_forward_all(const float* wf, const float* sv, const int g, const Emb32& e, Acts& a,
+                                                  float& alpha10, float& colour) {
+  mlp32_trunk<FEAT>(wf, sv, g, e, a);
+  float sa, s0, s1, s2;
+  mlp32_head_sums(sv, g, a, sa, s0, s1, s2);
+  alpha10 = (sa + sv[SV_HB]) * 10.0f;
+  const float mine = (g == 1) ? s0 : ((g == 2) ? s1 : s2);
+  colour = (g == 0) ? 0.0f : sigmoid_acc(mine + sv[SV_HB + g]);
 }
 
 }  // namespace obj32n

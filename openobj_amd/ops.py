@@ -160,7 +160,8 @@ def box_rays(T_WC: torch.Tensor, T_OC: torch.Tensor, half_extent: torch.Tensor, 
 
 
 def box_points(origin: torch.Tensor, dirs_W: torch.Tensor, near: torch.Tensor, far: torch.Tensor,
-               u: Optional[torch.Tensor] = None, n_bins: Optional[int] = None, seed: Optional[int] = None):
+               u: Optional[torch.Tensor] = None, n_bins: Optional[int] = None, seed: Optional[int] = None,
+               draw: Optional[int] = None):
     """Mid-points of the stratified bins of [near, far] (trainer.py:171-176): u [n, n_bins] (injected draws; None:
     generated in the kernel under `seed` and a per-call counter, n_bins required) -> z_vals [n, n_bins-1],
     pts [n, n_bins-1, 3]."""
@@ -177,9 +178,41 @@ def box_points(origin: torch.Tensor, dirs_W: torch.Tensor, near: torch.Tensor, f
     z = torch.empty(n, n_bins - 1, device=dev)
     pts = torch.empty(n, n_bins - 1, 3, device=dev)
     check(lib().objnerf_box_points(n, n_bins, _ptr(origin), _ptr(dirs_W), _ptr(near), _ptr(far), _ptr(u), _seed_of(seed),
-                                   0 if u is not None else _next_offset() & 0x1FFFFFFF, _ptr(z), _ptr(pts), _stream()),
+                                   0 if u is not None else (_next_offset() if draw is None else int(draw)) & 0x1FFFFFFF,
+                                   _ptr(z), _ptr(pts), _stream()),
           "objnerf_box_points")
     return z, pts
+
+
+def render_fwd(arena: ParamArena, origin: torch.Tensor, dirs_W: torch.Tensor, near: torch.Tensor, far: torch.Tensor,
+               u: Optional[torch.Tensor] = None, n_bins: Optional[int] = None, seed: Optional[int] = None,
+               draw: Optional[int] = None, want_hfeat: bool = True, want_z: bool = False):
+    """The per-object chain of sceneObject.render_2D_syn (vmap.py:644-676) in ONE launch (objnerf_render_fwd, hidden 32):
+    mid-points of the stratified bins of [near, far] -> embedding -> network -> compositing, a lane per ray, nothing per
+    sample in HBM.  arena: ONE object (K = 1).  u [n, n_bins]: injected draws; None: the Philox draws of box_points under
+    (seed, draw).  -> dict(depth [n], opacity [n], rgb [n,3], vals [n,H] | None (composited feature hidden), z | None)."""
+    if arena.K != 1 or arena.net.hidden != 32:
+        raise ObjnerfError("render_fwd: one hidden-32 object per call")
+    dirs_W = _req(dirs_W, torch.float32, "dirs_W")
+    near, far = _req(near, torch.float32, "near"), _req(far, torch.float32, "far")
+    dev = dirs_W.device
+    if u is not None:
+        u = _req(u, torch.float32, "u")
+        n, n_bins = u.shape
+    else:
+        n, n_bins = near.shape[0], int(n_bins)
+    origin = origin.to(dev, torch.float32).contiguous()
+    depth, opacity = torch.empty(n, device=dev), torch.empty(n, device=dev)
+    rgb = torch.empty(n, 3, device=dev)
+    hf = torch.empty(n, arena.net.hidden, device=dev) if want_hfeat else None
+    z = torch.empty(n, n_bins - 1, device=dev) if want_z else None
+    net = arena.net.c()
+    check(lib().objnerf_render_fwd(C.byref(net), n, n_bins, _ptr(arena.params), _ptr(arena.scale), _ptr(origin), _ptr(dirs_W),
+                                   _ptr(near), _ptr(far), _ptr(u), _seed_of(seed),
+                                   0 if u is not None else (_next_offset() if draw is None else int(draw)) & 0x1FFFFFFF,
+                                   _ptr(depth), _ptr(opacity), _ptr(rgb), _ptr(hf), _ptr(z), _stream()),
+          "objnerf_render_fwd")
+    return {"depth": depth, "opacity": opacity, "rgb": rgb, "vals": hf, "z": z}
 
 
 def mlp_forward(arena: ParamArena, emb: torch.Tensor, want_hfeat: bool = False, want_clip: bool = False):

@@ -78,8 +78,37 @@ class Trainer:
         self.origins = T_WC[:3, 3].to(dev).expand(n_rays, 3)
         near_h, far_h = near[hit].contiguous(), far[hit].contiguous()
         u = None if draws is None else torch.as_tensor(draws).to(dev)     # None: drawn inside the kernel (seeded)
-        self.z_vals, self.input_pcs = ops.box_points(T_WC[:3, 3], self.dirs_W.contiguous(), near_h, far_h, u, n_bins)
+        # z_vals / input_pcs are formed on first access (properties below): the fused renderer (vmap.render_2D_syn ->
+        # ops.render_fwd) never needs the [n, 149, 3] point tensor; the same (seed, draw) reproduces the same numbers
+        self._bbox_samples = dict(origin=T_WC[:3, 3], dirs_W=self.dirs_W.contiguous(), near=near_h, far=far_h, u=u,
+                                  n_bins=n_bins, seed=ops._seed_of(None), draw=ops._next_offset() & 0x1FFFFFFF)
+        self._z_vals = self._input_pcs = None
         return hit, near_h, far_h
+
+    def _materialise_bbox_samples(self):
+        b = self._bbox_samples
+        self._z_vals, self._input_pcs = ops.box_points(b["origin"], b["dirs_W"], b["near"], b["far"], b["u"], b["n_bins"],
+                                                       seed=b["seed"], draw=b["draw"])
+
+    @property
+    def z_vals(self):                       # trainer.py:175
+        if getattr(self, "_z_vals", None) is None:
+            self._materialise_bbox_samples()
+        return self._z_vals
+
+    @z_vals.setter
+    def z_vals(self, v):
+        self._z_vals = v
+
+    @property
+    def input_pcs(self):                    # trainer.py:176
+        if getattr(self, "_input_pcs", None) is None:
+            self._materialise_bbox_samples()
+        return self._input_pcs
+
+    @input_pcs.setter
+    def input_pcs(self, v):
+        self._input_pcs = v
 
     def meshing(self, *a, **k):
         raise NotImplementedError("marching cubes / open3d meshing (trainer.py:46-103, vis.py) is outside the "

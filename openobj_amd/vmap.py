@@ -252,27 +252,36 @@ class sceneObject:
         obj_hit, obj_near, obj_far = tr.sample_points_bbox(bbox, do_eval=True, draws=draws)
         if obj_hit is None:
             return None, None, None
-        n_pts, S = tr.z_vals.shape
+        b = tr._bbox_samples
+        n_pts, S = int(obj_near.shape[0]), b["n_bins"] - 1
         if n_pts <= 1:
             print("too few hits")
             return None, None, None
         tr.arena.scale.fill_(float(tr.obj_scale))
         with torch.no_grad():
-            # ray chunks bound the live activations (the H-wide feature hidden is 128 B per sample at hidden 32)
-            rays_per_chunk = max(1, RENDER_SAMPLES_PER_CHUNK // S)
-            depth = torch.empty(n_pts, device=dev)
-            opacity = torch.empty(n_pts, device=dev)
-            rgb = torch.empty(n_pts, 3, device=dev)
-            fh = torch.empty(n_pts, tr.hidden_feature_size, device=dev) if render_part else None
-            for r0 in range(0, n_pts, rays_per_chunk):
-                r1 = min(n_pts, r0 + rays_per_chunk)
-                alpha, color, hfeat, _ = ops.eval_points(tr.arena, tr.input_pcs[r0:r1].reshape(1, -1, 3),
-                                                         want_hfeat=render_part)
-                o = ops.composite(alpha.reshape(r1 - r0, S), color.reshape(r1 - r0, S, 3), tr.z_vals[r0:r1],
-                                  vals=hfeat.reshape(r1 - r0, S, -1) if render_part else None)
-                depth[r0:r1], opacity[r0:r1], rgb[r0:r1] = o["depth"], o["opacity"], o["rgb"]
-                if render_part:
-                    fh[r0:r1] = o["vals"]
+            if tr.hidden_feature_size == 32:
+                # ONE launch: mid-points -> embedding -> network -> compositing with a lane per ray (objnerf_render_fwd);
+                # no point tensor, no per-sample alpha / colour / feature tensors
+                o = ops.render_fwd(tr.arena, b["origin"], b["dirs_W"], b["near"], b["far"], b["u"], b["n_bins"],
+                                   seed=b["seed"], draw=b["draw"], want_hfeat=render_part)
+                depth, opacity, rgb, fh = o["depth"], o["opacity"], o["rgb"], o["vals"]
+            else:
+                # wider networks (the background, hidden 128): layer-wise evaluation in ray chunks that bound the live
+                # activations (the H-wide feature hidden is 4 H bytes per sample)
+                rays_per_chunk = max(1, RENDER_SAMPLES_PER_CHUNK // S)
+                depth = torch.empty(n_pts, device=dev)
+                opacity = torch.empty(n_pts, device=dev)
+                rgb = torch.empty(n_pts, 3, device=dev)
+                fh = torch.empty(n_pts, tr.hidden_feature_size, device=dev) if render_part else None
+                for r0 in range(0, n_pts, rays_per_chunk):
+                    r1 = min(n_pts, r0 + rays_per_chunk)
+                    alpha, color, hfeat, _ = ops.eval_points(tr.arena, tr.input_pcs[r0:r1].reshape(1, -1, 3),
+                                                             want_hfeat=render_part)
+                    o = ops.composite(alpha.reshape(r1 - r0, S), color.reshape(r1 - r0, S, 3), tr.z_vals[r0:r1],
+                                      vals=hfeat.reshape(r1 - r0, S, -1) if render_part else None)
+                    depth[r0:r1], opacity[r0:r1], rgb[r0:r1] = o["depth"], o["opacity"], o["rgb"]
+                    if render_part:
+                        fh[r0:r1] = o["vals"]
             out = dict(rgb=rgb, vals=fh)
             bad = (depth < obj_near) | (depth > obj_far) | (opacity < 0.9)          # :665,672
             keep = ~bad

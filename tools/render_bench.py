@@ -25,6 +25,6 @@ for it in range(3):
     res = ovmap.sceneObject.render_2D_syn(ns, T_WC, None, rays, render_part=part)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    n_hit = int(t.z_vals.shape[0])
+    n_hit = int(t._bbox_samples["near"].shape[0])
     print(f"view {W}x{H}: {n_hit} box rays x 149 samples, kept {res[1].shape[0]}, {dt*1e3:.1f} ms, "
           f"{n_hit/dt/1e6:.2f} M rays/s, {n_hit*149/dt/1e9:.2f} G samples/s, peak mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
