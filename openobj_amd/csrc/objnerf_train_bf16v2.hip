@@ -331,6 +331,9 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16v2_kernel(const TrainDev
     }
   };
 
+#ifdef V2_PRIO      // diagnostic: static issue priority for the younger half of the workgroup (waves 4-7)
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(V2_PRIO);
+#endif
   float nx, ny, nz;
   fetch_point(gi, nx, ny, nz);
   bool have_prev = false;

@@ -605,3 +605,38 @@ def test_round2_entry_points_reject_bad_arguments(dev):
     assert lib.objnerf_train_step(C.byref(net), C.byref(t), None) == -22
     with pytest.raises(ValueError):
         ops.precision_bits("int8")
+
+
+@pytest.mark.parametrize("seeded", [False, True])
+def test_render_fwd_equals_the_unfused_chain(dev, seeded):
+    """objnerf_render_fwd (one launch, a lane per ray) against objnerf_box_points -> objnerf_eval_points ->
+    objnerf_composite, which fixture G11 pinned to the reference's render_2D_syn in rounds 1-3 (the fused entry is what
+    test_render_2d_syn_g11 runs now): same mid-points (also for draws generated in the kernel under the same (seed,
+    draw)), depth / opacity / colour / composited feature hidden to 2e-5, a ragged ray count."""
+    torch.manual_seed(21)
+    t = trainer.Trainer(make_cfg(dev))
+    with torch.no_grad():
+        t.fc_occ_map.out_alpha.bias.add_(-0.5)
+    n, n_bins = 1003, 150
+    rs = np.random.RandomState(5)
+    origin = torch.tensor([0.1, -0.2, 0.3])
+    dirs = T(rs.standard_normal((n, 3)).astype(np.float32)).to(dev)
+    dirs = dirs / dirs.norm(dim=1, keepdim=True)
+    near = T(rs.uniform(0.2, 1.0, n).astype(np.float32)).to(dev)
+    far = near + T(rs.uniform(0.5, 2.0, n).astype(np.float32)).to(dev)
+    u = None if seeded else T(rs.uniform(0, 1, (n, n_bins)).astype(np.float32)).to(dev)
+    kw = dict(seed=1234, draw=77) if seeded else {}
+    t.arena.scale.fill_(float(t.obj_scale))
+    o = ops.render_fwd(t.arena, origin, dirs, near, far, u, n_bins, want_hfeat=True, want_z=True, **kw)
+    z, pts = ops.box_points(origin, dirs, near, far, u, n_bins, **kw)
+    assert torch.equal(o["z"], z)
+    S = n_bins - 1
+    a, c, hf, _ = ops.eval_points(t.arena, pts.reshape(1, -1, 3), want_hfeat=True)
+    r = ops.composite(a.reshape(n, S), c.reshape(n, S, 3), z, vals=hf.reshape(n, S, -1))
+    for k in ("depth", "opacity", "rgb", "vals"):
+        assert maxerr(o[k], r[k]) < 2e-5 * max(1.0, float(r[k].abs().max())), k
+    assert float(r["opacity"].max()) > 0.5             # (the rays do accumulate something)
+    with pytest.raises(ops.ObjnerfError):
+        wide = make_cfg(dev)
+        wide.obj_id, wide.hidden_feature_size = 0, 128
+        ops.render_fwd(trainer.Trainer(wide).arena, origin, dirs, near, far, u, n_bins)

@@ -11,7 +11,8 @@ c.hidden_feature_size = c.hidden_feature_size_bg
 c.obj_scale = c.bg_scale
 t = trainer.Trainer(c)
 loop = otrain.BackgroundLoop(c, t, with_feat=False, bf16="--bf16" in sys.argv)
-b = synthetic.random_batch(1, 1200, 5, 9, seed=1)
+N1, N2 = (16, 48) if "--metric" in sys.argv else (5, 9)      # --metric: the bench shape (64 samples per ray)
+b = synthetic.random_batch(1, 1200, N1, N2, seed=1)
 batch = {k: torch.from_numpy(b[k]).to(dev) for k in ["pts", "z", "gt_depth", "gt_rgb", "labels"]}
 N = int(os.environ.get("STEPS", "50"))
 for _ in range(5):
