@@ -177,11 +177,13 @@ int objnerf_box_points(int64_t n, int32_t n_bins, const float* origin /* [3] */,
  * and (out_hfeat != NULL) the composited hidden of the feature branch [n][H]: the 512-d map is objnerf_feature_head of
  * it with weight = opacity (exact: that head is linear).  out_z [n][n_bins-1] optional (the z_vals of the call).
  * Hidden 32 only (OBJNERF_ENOTSUP otherwise: wider networks keep objnerf_box_points -> objnerf_eval_points_ws ->
- * objnerf_composite). */
+ * objnerf_composite).  mode: 0 = the reference's fp32 arithmetic (1e-4 parity, fixture G11); OBJNERF_TRAIN_BF16 = opt-in:
+ * the operands of every hidden nn.Linear rounded to bf16 (v_mfma_f32_16x16x32_bf16, fp32 accumulation), sin / cos /
+ * sigmoid on the transcendental unit -- the arithmetic of the bf16 training mode, fp32 compositing. */
 int objnerf_render_fwd(const objnerf_net* net, int64_t n, int32_t n_bins, const float* params, const float* scale,
                        const float* origin /* [3] */, const float* dirs_W, const float* near, const float* far,
                        const float* u, uint64_t seed, uint32_t draw, float* out_depth, float* out_opacity,
-                       float* out_rgb, float* out_hfeat, float* out_z, void* stream);
+                       float* out_rgb, float* out_hfeat, float* out_z, int32_t mode, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * A6+A7  UniDirsEmbed.forward + OccupancyMap.forward (embedding.py:46-55, model.py:61-103),

@@ -105,7 +105,7 @@ SIGNATURES = {
                                      C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "objnerf_render_fwd": (C.c_int, [C.POINTER(Net), C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
-                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "objnerf_eval_points": (C.c_int, [C.POINTER(Net), C.c_int32, C.c_int64, C.c_void_p, C.c_int64,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p]),

@@ -92,7 +92,7 @@ __device__ __forceinline__ void pe_project_b(const float* sm, const int g, const
 
 // forward images + small vectors of one object (all threads of the workgroup); `small` = the fp32 block
 __device__ __forceinline__ void stage_forward_bf16(char* lds, float* sm, const float* __restrict__ P, const Layout& L,
-                                                   int tid, const bool feat, const int b_fl) {
+                                                   int tid, const bool feat, const int b_fl, const int NTHR = objtrain::NTHR) {
   __bf16* img = reinterpret_cast<__bf16*>(lds);
   // element (i, b, g, e) <- W[i][32 b + phi(g, e)]
   for (int x = tid; x < 32 * 3 * 32; x += NTHR) {

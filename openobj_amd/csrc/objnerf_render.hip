@@ -96,15 +96,25 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const RenderDev a) {
 
 }  // namespace
 
+// objnerf_render_bf16.hip
+int objnerf_render_fwd_bf16(const objnerf_net* net, int64_t n, int32_t n_bins, const float* params, const float* scale,
+                            const float* origin, const float* dirs_W, const float* near, const float* far, const float* u,
+                            uint64_t seed, uint32_t draw, float* out_depth, float* out_opacity, float* out_rgb,
+                            float* out_hfeat, float* out_z, void* stream);
+
 extern "C" int objnerf_render_fwd(const objnerf_net* net, int64_t n, int32_t n_bins, const float* params, const float* scale,
                                   const float* origin, const float* dirs_W, const float* near, const float* far,
                                   const float* u, uint64_t seed, uint32_t draw, float* out_depth, float* out_opacity,
-                                  float* out_rgb, float* out_hfeat, float* out_z, void* stream) {
+                                  float* out_rgb, float* out_hfeat, float* out_z, int32_t mode, void* stream) {
   (void)hipGetLastError();
   if (!net || n <= 0 || n_bins < 2 || !params || !scale || !origin || !dirs_W || !near || !far || !out_depth ||
       !out_opacity || !out_rgb)
     return OBJNERF_EINVAL;
   if (net->hidden != 32 || net->n_freqs != 6) return OBJNERF_ENOTSUP;      // (wider networks: the layer-wise chain)
+  if (mode & ~OBJNERF_TRAIN_BF16) return OBJNERF_ENOTSUP;
+  if (mode & OBJNERF_TRAIN_BF16)
+    return objnerf_render_fwd_bf16(net, n, n_bins, params, scale, origin, dirs_W, near, far, u, seed, draw, out_depth,
+                                   out_opacity, out_rgb, out_hfeat, out_z, stream);
   RenderDev d;
   d.n = n; d.n_bins = n_bins;
   d.params = params; d.scale = scale; d.origin = origin; d.dirs_W = dirs_W; d.near_ = near; d.far_ = far;

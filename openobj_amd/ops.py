@@ -186,11 +186,12 @@ def box_points(origin: torch.Tensor, dirs_W: torch.Tensor, near: torch.Tensor, f
 
 def render_fwd(arena: ParamArena, origin: torch.Tensor, dirs_W: torch.Tensor, near: torch.Tensor, far: torch.Tensor,
                u: Optional[torch.Tensor] = None, n_bins: Optional[int] = None, seed: Optional[int] = None,
-               draw: Optional[int] = None, want_hfeat: bool = True, want_z: bool = False):
+               draw: Optional[int] = None, want_hfeat: bool = True, want_z: bool = False, bf16: bool = False):
     """The per-object chain of sceneObject.render_2D_syn (vmap.py:644-676) in ONE launch (objnerf_render_fwd, hidden 32):
     mid-points of the stratified bins of [near, far] -> embedding -> network -> compositing, a lane per ray, nothing per
     sample in HBM.  arena: ONE object (K = 1).  u [n, n_bins]: injected draws; None: the Philox draws of box_points under
-    (seed, draw).  -> dict(depth [n], opacity [n], rgb [n,3], vals [n,H] | None (composited feature hidden), z | None)."""
+    (seed, draw).  bf16: opt-in OBJNERF_TRAIN_BF16 arithmetic (bf16 MFMA operands, hardware sin / cos / sigmoid; not the
+    reference's fp32).  -> dict(depth [n], opacity [n], rgb [n,3], vals [n,H] | None (composited feature hidden), z | None)."""
     if arena.K != 1 or arena.net.hidden != 32:
         raise ObjnerfError("render_fwd: one hidden-32 object per call")
     dirs_W = _req(dirs_W, torch.float32, "dirs_W")
@@ -210,7 +211,8 @@ def render_fwd(arena: ParamArena, origin: torch.Tensor, dirs_W: torch.Tensor, ne
     check(lib().objnerf_render_fwd(C.byref(net), n, n_bins, _ptr(arena.params), _ptr(arena.scale), _ptr(origin), _ptr(dirs_W),
                                    _ptr(near), _ptr(far), _ptr(u), _seed_of(seed),
                                    0 if u is not None else (_next_offset() if draw is None else int(draw)) & 0x1FFFFFFF,
-                                   _ptr(depth), _ptr(opacity), _ptr(rgb), _ptr(hf), _ptr(z), _stream()),
+                                   _ptr(depth), _ptr(opacity), _ptr(rgb), _ptr(hf), _ptr(z), _lib.TRAIN_BF16 if bf16 else 0,
+                                   _stream()),
           "objnerf_render_fwd")
     return {"depth": depth, "opacity": opacity, "rgb": rgb, "vals": hf, "z": z}
 

@@ -262,8 +262,10 @@ class sceneObject:
             if tr.hidden_feature_size == 32:
                 # ONE launch: mid-points -> embedding -> network -> compositing with a lane per ray (objnerf_render_fwd);
                 # no point tensor, no per-sample alpha / colour / feature tensors
+                # (trainer.render_bf16 = True: the opt-in bf16-operand arithmetic, ~3x faster, not the reference's fp32)
                 o = ops.render_fwd(tr.arena, b["origin"], b["dirs_W"], b["near"], b["far"], b["u"], b["n_bins"],
-                                   seed=b["seed"], draw=b["draw"], want_hfeat=render_part)
+                                   seed=b["seed"], draw=b["draw"], want_hfeat=render_part,
+                                   bf16=bool(getattr(tr, "render_bf16", False)))
                 depth, opacity, rgb, fh = o["depth"], o["opacity"], o["rgb"], o["vals"]
             else:
                 # wider networks (the background, hidden 128): layer-wise evaluation in ray chunks that bound the live

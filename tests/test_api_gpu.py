@@ -640,3 +640,29 @@ def test_render_fwd_equals_the_unfused_chain(dev, seeded):
         wide = make_cfg(dev)
         wide.obj_id, wide.hidden_feature_size = 0, 128
         ops.render_fwd(trainer.Trainer(wide).arena, origin, dirs, near, far, u, n_bins)
+
+
+def test_render_fwd_bf16_mode_close_to_fp32(dev):
+    """The opt-in bf16-operand renderer (objnerf_render_fwd, mode OBJNERF_TRAIN_BF16) against the fp32 one on the same
+    rays and draws: not the reference's arithmetic, so a tolerance of its own -- depth within 2 % of the ray's range,
+    opacity and colour within 0.03, the composited feature hidden within 5 % in norm."""
+    torch.manual_seed(22)
+    t = trainer.Trainer(make_cfg(dev))
+    with torch.no_grad():
+        t.fc_occ_map.out_alpha.bias.add_(-0.5)
+    n, n_bins = 2000, 150
+    rs = np.random.RandomState(6)
+    origin = torch.tensor([0.0, 0.1, -0.2])
+    dirs = T(rs.standard_normal((n, 3)).astype(np.float32)).to(dev)
+    dirs = dirs / dirs.norm(dim=1, keepdim=True)
+    near = T(rs.uniform(0.2, 1.0, n).astype(np.float32)).to(dev)
+    far = near + T(rs.uniform(0.5, 2.0, n).astype(np.float32)).to(dev)
+    u = T(rs.uniform(0, 1, (n, n_bins)).astype(np.float32)).to(dev)
+    t.arena.scale.fill_(float(t.obj_scale))
+    a = ops.render_fwd(t.arena, origin, dirs, near, far, u, n_bins, want_hfeat=True, want_z=True)
+    b = ops.render_fwd(t.arena, origin, dirs, near, far, u, n_bins, want_hfeat=True, want_z=True, bf16=True)
+    assert torch.equal(a["z"], b["z"])
+    assert float(((a["depth"] - b["depth"]).abs() / (far - near)).max()) < 0.02
+    assert maxerr(a["opacity"], b["opacity"]) < 0.03 and maxerr(a["rgb"], b["rgb"]) < 0.03
+    assert float((a["vals"] - b["vals"]).norm() / a["vals"].norm()) < 0.05
+    assert float(a["opacity"].max()) > 0.5

@@ -9,7 +9,7 @@ out=variants/$name
 mkdir -p $out
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -Wall -Wno-unused-function"
 pids=()
-for f in objnerf_train objnerf_train32 objnerf_train_bf16 objnerf_train_bf16v2 objnerf_misc objnerf_generic objnerf_helpers objnerf_train256 objnerf_render; do
+for f in objnerf_train objnerf_train32 objnerf_train_bf16 objnerf_train_bf16v2 objnerf_misc objnerf_generic objnerf_helpers objnerf_train256 objnerf_render objnerf_render_bf16; do
   extra=""
   [ $f = objnerf_train ] && extra="-mllvm -amdgpu-sched-strategy=max-ilp"
   [ $f = objnerf_train32 ] && extra="${T32_SCHED--mllvm -amdgpu-sched-strategy=iterative-ilp}"   # T32_SCHED: override (may be empty)

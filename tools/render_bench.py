@@ -13,6 +13,7 @@ c.obj_id = 1
 c.W, c.H = W, H
 torch.manual_seed(0)
 t = trainer.Trainer(c)
+t.render_bf16 = os.environ.get("BF16", "0") == "1"     # opt-in bf16-operand renderer (objnerf_render_bf16.hip)
 with torch.no_grad():
     t.fc_occ_map.out_alpha.bias.add_(-1.0)
 rays = ops.rays_dirs(W, H, 600.0, 600.0, W / 2 - 0.5, H / 2 - 0.5, dev)
