@@ -98,17 +98,21 @@ def test_layerwise_16bit_feature_step_matches_its_specification(dev, mode, shape
         assert rel < (4 if i in ops.FEAT_TENSORS else 2) * BOUND[mode], (i, ops.TENSOR_NAMES[i], rel)
 
 
-@pytest.mark.parametrize("shape", [(3, 300, 16, 48), (2, 211, 5, 9), (4, 128, 8, 24)])
+@pytest.mark.parametrize("shape", [(3, 300, 16, 48), (2, 211, 5, 9), (4, 128, 8, 24), (2, 333, 16, 48), (300, 9, 16, 48)])
 def test_fused_bf16_kernel_matches_its_specification(dev, shape):
     """The fused hidden-32 kernel in bf16 mode (objnerf_train_bf16.hip, the kernel behind BASELINE configs[1] / [2]'s
     dtype): activations are packed to bf16 as the next MFMA's operand (act16 semantics: every consumer sees the rounded
     value), the heads run in fp32.  Measured (tools/bf16_fused_diag.py, profiles/r03_bf16_fused_diag.txt): this kernel sits
     1 - 4 % from the specification per tensor (the layer-wise bf16 path: 0.1 - 0.3 %), against 4 - 6 % between the
     specification and fp32 -- its transcendental-unit sin / cos / exp and its own rounding points are not modelled.
-    Bound 6 % (10 % below 20 000 samples; the former bound against the fp32 kernel was 15 %)."""
+    Bound 6 % (10 % below 20 000 samples; the former bound against the fp32 kernel was 15 %).
+    Round 4: the 64-sample shapes run the SECOND-generation kernel (objnerf_train_bf16v2.hip: every tensor within 2 % on
+    the first shape, tools/bf16v2_diag.py; its head gradients are rounded as weight-gradient operands: round_head_grads);
+    (2, 333, ..) ends on a half-filled tile, (300, 9, ..) has more objects than CUs and 4.5 tiles per object."""
     K, R, n1, n2 = shape
     arena, st, b, ws, _ = _run(dev, K, R, n1, n2, 32, False, "bf16", seed=11)
-    o = oracle_step_16(list(st[:18]), st[18], 2.0, b, False, torch.bfloat16, True, 1.0, device=dev)
+    o = oracle_step_16(list(st[:18]), st[18], 2.0, b, False, torch.bfloat16, True, 1.0, device=dev,
+                       round_head_grads=(n1 + n2 == 64))
     # (the depth term divides by sqrt(var) + 1e-4: a ray whose weight sits on one sample amplifies a 1e-6 difference)
     np.testing.assert_allclose(ws.loss_terms.double().cpu()[:, 1:3], o["terms"][:, 1:3], rtol=5e-3, atol=1e-4)
     np.testing.assert_allclose(ws.loss_terms.double().cpu()[:, 0], o["terms"][:, 0], rtol=5e-2, atol=1e-3)
