@@ -181,9 +181,20 @@ struct Pe32 {
 
 __device__ __forceinline__ void pe32_project(const float* sv, const int g, const float px, const float py, const float pz,
                                              const float scale, Pe32& pe) {
-  pe.t[0] = px / scale;        // embedding.py:47
-  pe.t[1] = py / scale;
-  pe.t[2] = pz / scale;
+  // embedding.py:47 x / scale.  A power-of-two scale (obj_scale = 2, room_0.json) makes x * (1 / scale) the SAME fp32
+  // value as the IEEE division, which is ~10 instructions per component on this part: the (wave-uniform) test is
+  // made once per call site.
+  const unsigned sb = __float_as_uint(scale);
+  if ((sb & 0x807fffffu) == 0u && sb != 0u && sb < 0x7f000000u) {
+    const float inv = __uint_as_float(0x7f000000u - sb);       // 2^-e, exact
+    pe.t[0] = px * inv;
+    pe.t[1] = py * inv;
+    pe.t[2] = pz * inv;
+  } else {
+    pe.t[0] = px / scale;
+    pe.t[1] = py / scale;
+    pe.t[2] = pz / scale;
+  }
   const float* bl = sv + SV_PEB + 3 * g;
 #pragma unroll
   for (int i = 0; i < 6; ++i) {

@@ -106,3 +106,43 @@ def test_bf16_background_step_close_to_fp32(dev, feat, net):
         a, r = g16[i].double().cpu(), g32[i].double().cpu()
         rel = float((a - r).norm() / (r.norm() + 1e-12))
         assert rel < 0.15, (i, ops.TENSOR_NAMES[i], rel)
+
+
+def test_bf16_second_generation_kernel_edge_cases(golden, dev):
+    """The 64-sample bf16 kernel (objnerf_train_bf16v2.hip) on what the first generation was tested for at other shapes:
+    (a) the cross-object early return (render_rays.py:89-94): an object without a label-1 ray zeroes the depth / colour
+    terms and their gradients of EVERY object -- exact zeros, and the opacity term still flows; (b) the batch given as
+    origins / dirs / z (the seeded sampler's compact form) equals the batch given as points bit for bit; (c) global
+    flags / counts handed in (object sharding) are honoured; (d) the step is bit-reproducible."""
+    K, R, n1, n2 = 3, 130, 16, 48
+    arena = _arena(golden, K, dev)
+    b = synthetic.random_batch(K, R, n1, n2, seed=77)
+    keys = ["pts", "z", "gt_depth", "gt_rgb", "labels"]
+    batch = {k: T(b[k]).to(dev) for k in keys}
+    ws = ops.TrainWorkspace(arena, K, R, n1 + n2, False)
+    ops.train_step(arena, ws, batch, bf16=True)
+    torch.cuda.synchronize()
+    g0, t0 = ws.grads.clone(), ws.loss_terms.clone()
+    ops.train_step(arena, ws, batch, bf16=True)
+    torch.cuda.synchronize()
+    assert torch.equal(ws.grads, g0) and torch.equal(ws.loss_terms, t0)                       # (d)
+    b2 = {k: T(b[k]).to(dev) for k in ["origins", "dirs", "z", "gt_depth", "gt_rgb", "labels"]}
+    ops.train_step(arena, ws, b2, bf16=True)
+    torch.cuda.synchronize()
+    assert torch.equal(ws.grads, g0)                                                          # (b)
+    lab = batch["labels"].clone()
+    lab[1][lab[1] == 1] = 0
+    ops.train_step(arena, ws, dict(batch, labels=lab), bf16=True)
+    torch.cuda.synchronize()
+    t = ws.loss_terms.cpu()
+    assert float(t[:, :2].abs().max()) == 0.0 and float(t[:, 2].min()) > 0.0                  # (a)
+    gv = arena.views(ws.grads)
+    for i in (10, 11, 12, 13):                                     # the colour branch sees no loss term at all
+        assert float(gv[i].abs().max()) == 0.0, ops.TENSOR_NAMES[i]
+    assert float(gv[0].abs().max()) > 0.0
+    flags = torch.tensor([1, 0], dtype=torch.int32, device=dev)    # (c) the same decision handed in from outside
+    counts = ops.label_counts(batch["labels"])[0]
+    ops.train_step(arena, ws, batch, bf16=True, global_flags=flags, global_counts=counts)
+    torch.cuda.synchronize()
+    assert float(ws.loss_terms[:, :2].abs().max()) == 0.0
+    assert float(arena.views(ws.grads)[12].abs().max()) == 0.0
