@@ -59,7 +59,13 @@ def test_feature_loss_variant(runs, mode):
     print(mode, "with the feature loss:", c)
     if mode == "f32":
         # per seed: one seed in 128 can take another ReLU branch inside the first 50 iterations (measured: 127 seeds
-        # within 0.05 dB, one at 0.14); the spread of the differences is what is bounded
+        # within 0.05 dB, one -- seed 9092 -- at 0.136); the spread of the differences is what is bounded.  That seed was
+        # traced (tools/psnr_seed_trace.py: HIP and the oracle agree to 4e-5 in every parameter for four iterations, then
+        # ONE AdamW step moves cat_layer.weight by 0.6 lr) and the REFERENCE ITSELF shows the same discrete jumps on it:
+        # under 1e-6 / 1e-5 relative perturbations of its initial weights its PSNR after 50 iterations is unchanged to
+        # 1e-4 dB in 9 of 16 draws and moves by +0.031, +0.049 (3x), -0.011 (2x), -0.106 dB in the others
+        # (profiles/r04_feat_seed9092_sensitivity.txt, tools/h256_sensitivity.py VARIANT=feat); its neighbour 9091
+        # never moves by more than 5e-4 dB.
         d = np.abs(run["psnr50"] - ref["psnr50"][:len(run["psnr50"])])
         assert (d >= 0.1).sum() <= 1 and d.max() < 0.2 and c["iter50"]["std_delta_db"] < 0.03, c["iter50"]
     assert abs(c["iter50"]["mean_delta_db"]) < 0.1, c["iter50"]
