@@ -461,11 +461,12 @@ struct KA {
   }
 
   // one block of a sequence: acc += sum over the stage's k-steps of piece(ks) x bfrag(ks).  The A operands are read
-  // DEPTH k-steps ahead by hand (inline ds_read_b128 with literal offsets + counted lgkmcnt waits tied to the registers
-  // they release).  side(ks) is called after the MFMA of k-step ks has been issued: work that does not depend on the
+  // DEPTH k-steps ahead by hand (program order of `rd`; round 4: plain LDS loads whose LGKM waits the compiler counts --
+  // rounds 3's inline ds_read_b128 + hand-counted waits remain under -DOBJ256_ASM_LDS_READS).  side(ks) is called after the MFMA of k-step ks has been issued: work that does not depend on the
   // accumulator (the DMA of a later stage, the previous block's fragment stores) goes into the MFMA's shadow there --
   // with one wave per SIMD nothing else would overlap it.
   static constexpr int DEPTH = 6;
+#ifdef OBJ256_ASM_LDS_READS   // rounds 3's form: bare inline asm reads + hand-counted waits tied to the destination registers
   template <int OFF>
   static __device__ __forceinline__ void rd(V& dst, const uint32_t addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
@@ -478,6 +479,18 @@ struct KA {
   static __device__ __forceinline__ void wait_for2(V& x, V& y) {
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(x), "+v"(y) : "n"(N));
   }
+#else
+  // compiler-visible LDS loads: the compiler counts the outstanding LGKM operations itself and waits where a value is
+  // first used (the same counted s_waitcnt, placed by the tool that also places the copies and spills)
+  template <int OFF>
+  static __device__ __forceinline__ void rd(V& dst, const uint32_t addr) {
+    dst = *reinterpret_cast<const __attribute__((address_space(3))) V*>((uintptr_t)(addr + OFF));
+  }
+  template <int N>
+  static __device__ __forceinline__ void wait_for(V&) {}
+  template <int N>
+  static __device__ __forceinline__ void wait_for2(V&, V&) {}
+#endif
   // TWO accumulator chains (even / odd k-steps): a v_mfma_f32_32x32x16 that depends on the one issued right before it
   // starts ~110 cycles after it, an independent one after ~34 (tools/ubench_mfma32.hip: 645 against 1708 TFLOP/s on
   // the whole chip) -- with one wave per SIMD there is no other wave to fill that gap, so the block's contraction is
@@ -1104,7 +1117,9 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
       KT::template rd<0>(wa[0], addr); KT::template rd<PIECE>(wa[1], addr); KT::template rd<2 * PIECE>(wa[2], addr);
       KT::template rd<3 * PIECE>(wa[3], addr); KT::template rd<4 * PIECE>(wa[4], addr); KT::template rd<5 * PIECE>(wa[5], addr);
       KT::template rd<6 * PIECE>(wa[6], addr); KT::template rd<7 * PIECE>(wa[7], addr);
+#ifdef OBJ256_ASM_LDS_READS
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wa[0]), "+v"(wa[1]), "+v"(wa[2]), "+v"(wa[3]), "+v"(wa[4]), "+v"(wa[5]), "+v"(wa[6]), "+v"(wa[7]));
+#endif
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         f32x16 c[4];
