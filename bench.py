@@ -404,8 +404,8 @@ class Workload:
     def kernel_name(self, mode):
         feat, S, Hd = self.feat, self.S, self.Hd
         if Hd == 32 and S <= 64 and mode != "fp16":
-            if mode and not feat and S == 64:
-                return "train_fused_bf16v2_kernel"       # second-generation kernel (objnerf_train_bf16v2.hip)
+            if mode and S == 64:                         # second-generation kernels (objnerf_bf16v2_body.h)
+                return "train_fused_bf16v2f_kernel" if feat else "train_fused_bf16v2_kernel"
             if mode:
                 return "train_fused_bf16_kernel<%s, %d>" % ("true" if feat else "false", 64 if S == 64 else 0)
             return "train_fused32_kernel<%s, false, %d>" % ("true" if feat else "false", 64 if S == 64 else 0)

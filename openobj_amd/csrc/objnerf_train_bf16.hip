@@ -943,7 +943,10 @@ void launch_train_bf16(const TrainDev& d, void* stream, bool feat) {
     (void)hipFuncSetAttribute((const void*)train_fused_bf16_kernel<true, 0>, at, LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)train_fused_bf16_kernel<true, 64>, at, LDS_BYTES);
   });
-  if (!feat && d.S == 64 && !bf16_first_generation()) { launch_train_bf16_v2(d, stream); return; }
+  if (d.S == 64 && !bf16_first_generation()) {
+    if (feat) launch_train_bf16_v2f(d, stream); else launch_train_bf16_v2(d, stream);
+    return;
+  }
   const dim3 grid(d.K * d.G), blk(NTHR);
   hipStream_t st = (hipStream_t)stream;
   if (feat && d.S == 64) hipLaunchKernelGGL((train_fused_bf16_kernel<true, 64>), grid, blk, LDS_BYTES, st, d);

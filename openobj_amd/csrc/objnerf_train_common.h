@@ -74,8 +74,9 @@ void launch_train32(const TrainDev& d, void* stream, bool feat);
 // bf16 MFMA variant (objnerf_train_bf16.hip): same tile structure, bf16 operands, fp32 accumulation
 size_t bf16_lds_bytes();
 void launch_train_bf16(const TrainDev& d, void* stream, bool feat);
-// second generation (objnerf_train_bf16v2.hip): 64 samples per ray, no feature loss
+// second generation (objnerf_bf16v2_body.h): 64 samples per ray; without / with the feature loss
 size_t bf16v2_lds_bytes();
 void launch_train_bf16_v2(const TrainDev& d, void* stream);
+void launch_train_bf16_v2f(const TrainDev& d, void* stream);
 
 }  // namespace objtrain

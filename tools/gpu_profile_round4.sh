@@ -30,9 +30,9 @@ stats c5 --config c5 --dtype fp16 --objects 8 --no-bg --no-bf16-line --steps 2 -
 pmc f32 train_fused32 --no-bg
 pmc bf16 train_fused_bf16 --no-bg --dtype bf16
 pmc c3_f32 "train_fused32_kernel<true" --config c3 --no-bg
-pmc c3_bf16 "train_fused_bf16_kernel<true" --config c3 --no-bg --dtype bf16
+pmc c3_bf16 train_fused_bf16v2f --config c3 --no-bg --dtype bf16
 pmc c4_f32 "train_fused32_kernel<true" --config c4 --objects 15 --no-bg
-pmc c4_bf16 "train_fused_bf16_kernel<true" --config c4 --objects 15 --no-bg --dtype bf16
+pmc c4_bf16 train_fused_bf16v2f --config c4 --objects 15 --no-bg --dtype bf16
 for kk in fwd256_kernel wgrad256_kernel; do :; done
 C5="--config c5 --dtype fp16 --objects 8 --no-bg"
 for pass in fetch write sq sq2; do

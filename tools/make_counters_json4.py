@@ -53,9 +53,9 @@ def entry(tag, outname, kernel, K, R=4096, S=64, **extra):
 entry("f32", "f32", "train_fused32_kernel<false, false, 64>", 50)
 entry("bf16", "bf16", "train_fused_bf16v2_kernel", 50)
 entry("c3_f32", "c3_f32", "train_fused32_kernel<true, false, 64>", 50)
-entry("c3_bf16", "c3_bf16", "train_fused_bf16_kernel<true, 64>", 50)
+entry("c3_bf16", "c3_bf16", "train_fused_bf16v2f_kernel", 50)
 entry("c4_f32", "c4share_f32", "train_fused32_kernel<true, false, 64>", 15)
-entry("c4_bf16", "c4share_bf16", "train_fused_bf16_kernel<true, 64>", 15)
+entry("c4_bf16", "c4share_bf16", "train_fused_bf16v2f_kernel", 15)
 # configs[4]: two kernels per 8-object launch; recorded per object
 fw, wg = {}, {}
 lines = []
