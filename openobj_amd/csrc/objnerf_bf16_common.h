@@ -7,6 +7,7 @@
 // activation block, packed to bf16.  A forward image row is [out][block][g][e] (position 8 g + e of a block <-> feature
 // phi(g, e)); row pitches are 32 B x odd (mod 256 B), which the 16-lane ds_read_b128 groups read conflict-free.
 #pragma once
+#define OBJ_PE_NO_LOW 1      // these kernels' angles have no low part (pe_project_b): the anchors skip its fma
 #include "objnerf_mlp32.h"
 #include "objnerf_train_common.h"
 
@@ -84,8 +85,8 @@ __device__ __forceinline__ void pe_project_b(const float* sm, const int g, const
   const float* bl = sm + S_PEB + 3 * g;
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
-    const float p = fmaf(pe.t[2], bl[12 * i + 2], fmaf(pe.t[1], bl[12 * i + 1], pe.t[0] * bl[12 * i]));
-    pe.vh[i] = p * 0.5f;     // revolutions of a = p pi: a / (2 pi) = p / 2, exact -- no low part needed
+    // revolutions of a = p pi: a / (2 pi) = p / 2 -- the staged directions are B / 2 (exact), no low part needed
+    pe.vh[i] = fmaf(pe.t[2], bl[12 * i + 2], fmaf(pe.t[1], bl[12 * i + 1], pe.t[0] * bl[12 * i]));
     pe.vl[i] = 0.0f;
   }
 }
@@ -121,7 +122,7 @@ __device__ __forceinline__ void stage_forward_bf16(char* lds, float* sm, const f
   if (tid == 0) sm[S_HB] = P[L.a_b];
   if (tid < 3) sm[S_HB + 1 + tid] = P[L.oc_b + tid];
   // B rows in slot order [slot i][group g][3] (= B's own row-major order), zero for j = 4 i + g >= 21
-  for (int i = tid; i < 72; i += NTHR) sm[S_PEB + i] = (i / 3) < OBJ_NDIR ? P[L.pe_b + i] : 0.0f;
+  for (int i = tid; i < 72; i += NTHR) sm[S_PEB + i] = (i / 3) < OBJ_NDIR ? 0.5f * P[L.pe_b + i] : 0.0f;   // (B / 2: see pe_project_b)
 }
 
 }  // namespace bf16k

@@ -34,6 +34,9 @@
 #if V2_FEAT && !defined(V2_RECOMPUTE_PE)
 #define V2_RECOMPUTE_PE 1    // (the feature instantiation has no registers for the cached embedding / cosine factors)
 #endif
+#if !V2_FEAT && !defined(V2_EARLY_FETCH)
+#define V2_LATE_FETCH 1      // next tile's point requested at the tile's end (measured: 2.293 ms against 2.311 a tile ahead;
+#endif                       // the feature instantiation: 3.88 against 3.84 -- so each keeps its better one)
 #if V2_FEAT
 #define V2_KERNEL train_fused_bf16v2f_kernel
 #else
@@ -129,22 +132,63 @@ __device__ __forceinline__ void unpack8(const bf16x8 hp, float (&o)[8]) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) { o[2 * j] = unpack_lo(u[j]); o[2 * j + 1] = unpack_hi(u[j]); }
 }
-// d * (h > 0) with h as the packed bf16 operand the forward built (element e = 4 tt + r of the lane's 8): a ReLU output
-// is positive exactly when its bf16 image is non-zero -- every consumer of an activation sees the rounded value
-__device__ __forceinline__ T32 relu_mask_packed(const T32& gr, const bf16x8 hp) {
-  const u32x4 u = __builtin_bit_cast(u32x4, hp);
-  T32 o;
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// The packed 16-bit integer instructions below are inline assembly on plain dwords: written as <2 x i16> vector
+// operations on elements of a bit-cast bf16x8, this compiler (HIP 7.2.26015) used the FIRST pair's result for all four
+// pairs of a block (tools/bf16v2_diag.py caught it: every gradient off by 10 % - 170 %).  Their inputs are VALU results
+// and their outputs feed VALU / LDS / MFMA-operand reads, none of which needs software wait states on gfx950.
+__device__ __forceinline__ unsigned pk_max_i16_zero(const unsigned v) {
+  unsigned o;
+  asm("v_pk_max_i16 %0, %1, 0" : "=v"(o) : "v"(v));
+  return o;
+}
+// d with the halves zeroed where the bf16 activation h (a ReLU output: >= 0 as an integer) is zero: d * min(h, 1) on
+// the 16-bit halves (op_sel_hi 0 on the constant: its low half serves both)
+__device__ __forceinline__ unsigned pk_keep_where_nonzero(const unsigned d, const unsigned h) {
+  unsigned m, o;
+  asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(m) : "v"(h));
+  asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(o) : "v"(d), "v"(m));
+  return o;
+}
+// ReLU + pack of an activation block nobody reads in fp32: round first, then max(bits, 0) on the 16-bit halves (a
+// negative bf16 is a negative int16): 4 + 4 instructions instead of 8 + 4
+__device__ __forceinline__ bf16x8 relu_pack(const T32& x) {
+  u32x4 u;
 #pragma unroll
   for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int e = 4 * tt + r;
-      const unsigned half = (e & 1) ? (u[e >> 1] >> 16) : (u[e >> 1] & 0xffffu);
-      o.t[tt][r] = half != 0u ? gr.t[tt][r] : 0.0f;
-    }
-  return o;
+    for (int h = 0; h < 2; ++h) u[2 * tt + h] = pk_max_i16_zero(pack2(x.t[tt][2 * h], x.t[tt][2 * h + 1]));
+  return __builtin_bit_cast(bf16x8, u);
 }
-
+// pack(d * (h > 0)) for a pre-activation gradient that is only ever used as an MFMA operand: round first, then the
+// two packed instructions above per pair instead of two compares and two selects.  Rounding commutes with the mask
+// (0 rounds to 0).
+__device__ __forceinline__ bf16x8 mask_pack(const T32& gr, const bf16x8 hp) {
+  const u32x4 h = __builtin_bit_cast(u32x4, hp);
+  u32x4 u;
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+      u[2 * tt + hf] = pk_keep_where_nonzero(pack2(gr.t[tt][2 * hf], gr.t[tt][2 * hf + 1]), h[2 * tt + hf]);
+  return __builtin_bit_cast(bf16x8, u);
+}
+// two chain-rule factors as an fp16 pair (|factor| <= 32 pi): v_fma_mix_f32 takes either half as an operand, so the
+// backward pass needs no unpacking.  Opaque to the compiler on purpose: it saw through a bf16 pack / unpack pair and
+// re-derived every factor (doubling formula, scale, rounding) in the backward pass -- five instructions per factor.
+__device__ __forceinline__ unsigned pack_h2(const float lo, const float hi) {
+  const f32x2 v = {lo, hi};
+  unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+  asm volatile("" : "+v"(u));
+  return u;
+}
+__device__ __forceinline__ float fma_lo(const float x, const unsigned hpair, const float acc) {
+  return fmaf(x, (float)__builtin_bit_cast(f16x2, hpair)[0], acc);
+}
+__device__ __forceinline__ float fma_hi(const float x, const unsigned hpair, const float acc) {
+  return fmaf(x, (float)__builtin_bit_cast(f16x2, hpair)[1], acc);
+}
 // ---- weight-gradient work list: (d block, activation tile) pairs of a wave; kind 1 = the head operand against two tiles
 struct Slot { int d, a, kind; };
 template <int W> struct WaveSlots;
@@ -306,10 +350,10 @@ constexpr int NRED2 = 8;        // per wave: a_b, oc_b[3], loss terms [3], spare
 
 #ifdef PHASE_TIMING
 __device__ unsigned long long g_phase_b2[8][24];
-#define PT_INIT() unsigned long long pt_acc[12]; for (int i_ = 0; i_ < 12; ++i_) pt_acc[i_] = 0; \
+#define PT_INIT() unsigned long long pt_acc[16]; for (int i_ = 0; i_ < 16; ++i_) pt_acc[i_] = 0; \
   unsigned long long pt_t0 = __builtin_amdgcn_s_memtime()
 #define PT(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pt_acc[i] += t_ - pt_t0; pt_t0 = t_; } while (0)
-#define PT_FLUSH() do { if (blockIdx.x == 0 && lane == 0) for (int i_ = 0; i_ < 12; ++i_) g_phase_b2[w][i_] = pt_acc[i_]; } while (0)
+#define PT_FLUSH() do { if (blockIdx.x == 0 && lane == 0) for (int i_ = 0; i_ < 16; ++i_) g_phase_b2[w][i_] = pt_acc[i_]; } while (0)
 #else
 #define PT_INIT() do {} while (0)
 #define PT(i) do {} while (0)
@@ -400,31 +444,42 @@ __global__ __launch_bounds__(NTHR) void V2_KERNEL(const TrainDev a) {
 
   const int q = w >> 2;                                               // ray of the tile this wave's samples belong to
 
-  auto fetch_point = [&](const int tile_, float& x, float& y, float& z_) {
-    const int ray_ = tile_ * TR + q;
-    x = 0.f; y = 0.f; z_ = 0.f;
-    if (tile_ < a.NT && ray_ < R) {
-      const long rr = (long)k * R + ray_;
-      const int si_ = slot & (S - 1);
-      if (a.pts) {
-        const float* p = a.pts + (rr * S + si_) * 3;
-        x = p[0]; y = p[1]; z_ = p[2];
-      } else {
-        const float zz = a.z[rr * S + si_];
-        const float* o = a.origins + rr * 3;
-        const float* d = a.dirs + rr * 3;
-        x = (o[0] + d[0] * zz) - a.obj_center;
-        y = (o[1] + d[1] * zz) - a.obj_center;
-        z_ = (o[2] + d[2] * zz) - a.obj_center;
-      }
-    }
+  // A sample's point in two halves: request_point only ISSUES the loads (the point itself, or z and the ray's origin /
+  // direction), finish_point consumes them -- up to a whole tile later.  (Measured: the latency of these loads is NOT what
+  // the "load + project" phase of tools/phase_timing.py shows; requesting a tile ahead moves the kernels by 1 % either
+  // way.  That phase is the second wave of each SIMD running beside the first one's forward pass.)
+  auto request_point = [&](const int tile_, float (&raw)[7]) {
+    // branch-free (a join of branches made the compiler wait for the loads right there): a tile past the end reads the
+    // object's last ray and finish_point discards it; with points given, the second / third pointers re-read the point
+    const int ray_ = min(tile_ * TR + q, R - 1);
+    const long rr = (long)k * R + ray_;
+    const long sidx = rr * S + (slot & (S - 1));
+    const bool pm = a.pts != nullptr;
+    const float* p0 = pm ? a.pts + sidx * 3 : a.origins + rr * 3;
+    const float* p1 = pm ? p0 : a.dirs + rr * 3;
+    const float* p2 = pm ? p0 : a.z + sidx;
+    raw[0] = p0[0]; raw[1] = p0[1]; raw[2] = p0[2];
+    raw[3] = p1[0]; raw[4] = p1[1]; raw[5] = p1[2];
+    raw[6] = p2[0];
+  };
+  auto finish_point = [&](const int tile_, const float (&raw)[7], float& x, float& y, float& z_) {
+    const bool ok = tile_ < a.NT && tile_ * TR + q < R;
+    const bool pm = a.pts != nullptr;
+    const float px = pm ? raw[0] : (raw[0] + raw[3] * raw[6]) - a.obj_center;
+    const float py = pm ? raw[1] : (raw[1] + raw[4] * raw[6]) - a.obj_center;
+    const float pz = pm ? raw[2] : (raw[2] + raw[5] * raw[6]) - a.obj_center;
+    x = ok ? px : 0.f; y = ok ? py : 0.f; z_ = ok ? pz : 0.f;
   };
 
 #ifdef V2_PRIO      // diagnostic: static issue priority for the younger half of the workgroup (waves 4-7)
   if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(V2_PRIO);
 #endif
   float nx, ny, nz;
-  fetch_point(gi, nx, ny, nz);
+  {
+    float raw0[7];
+    request_point(gi, raw0);
+    finish_point(gi, raw0, nx, ny, nz);
+  }
   bool have_prev = false;
   PT_INIT();
   for (int tile = gi; tile < a.NT; tile += a.G) {
@@ -435,6 +490,10 @@ __global__ __launch_bounds__(NTHR) void V2_KERNEL(const TrainDev a) {
     // ---------------------------------------------------------------- 1. forward (model.py:61-103 on embedding.py:46-55)
     obj32n::Pe32 pe;
     pe_project_b(sm, g, nx, ny, nz, inv_scale, pe);
+    float raw[7];                            // the next tile's point, requested a whole tile ahead
+#ifndef V2_LATE_FETCH
+    request_point(tile + a.G, raw);
+#endif
     PT(0);
     bf16x8 h1p, h2p, h3p, h4p, hcp;          // the activations as the packed operands every consumer sees
 #if V2_FEAT
@@ -442,7 +501,7 @@ __global__ __launch_bounds__(NTHR) void V2_KERNEL(const TrainDev a) {
 #endif
 #ifndef V2_RECOMPUTE_PE
     // the embedding blocks and the chain-rule factors d sin(2^f a) / d proj = cos(2^f a) pi 2^f of the lane's six
-    // directions (bf16 pairs; zero where the slot holds no direction) stay in registers for the backward pass: it then
+    // directions (fp16 pairs; zero where the slot holds no direction) stay in registers for the backward pass: it then
     // needs no transcendental and no range reduction at all (they were ~20 % of the kernel's VALU instructions)
     bf16x8 xb1[3], xb2[2];
     unsigned cpk[18];
@@ -468,7 +527,7 @@ __global__ __launch_bounds__(NTHR) void V2_KERNEL(const TrainDev a) {
             const float live = (i == 5 && g != 0) ? 0.0f : OBJ_PI_F;      // only group 0 has a sixth direction
 #pragma unroll
             for (int f = 0; f < 6; f += 2)
-              cpk[3 * i + (f >> 1)] = pack2(cs[f] * (live * (float)(1 << f)), cs[f + 1] * (live * (float)(2 << f)));
+              cpk[3 * i + (f >> 1)] = pack_h2(cs[f] * (live * (float)(1 << f)), cs[f + 1] * (live * (float)(2 << f)));
 #endif
             xv[u] = obj32n::pe32_x1_tile(pe, i, g, sn);
             float v4, v5;
@@ -485,19 +544,19 @@ __global__ __launch_bounds__(NTHR) void V2_KERNEL(const TrainDev a) {
       T32 av = zero32();
 #pragma unroll
       for (int b = 0; b < 3; ++b) fwd_blk<RS_IN>(av, f_in, b, xb1[b]);
-      h1p = pack32(relu32(av));
+      h1p = relu_pack(av);
       SCHED_FENCE();
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) av.t[tt][r] = sm[S_BM1 + 16 * tt + 4 * g + r];
       fwd_blk<RS_M>(av, f_m1, 0, h1p);
-      h2p = pack32(relu32(av));
+      h2p = relu_pack(av);
       av = zero32();
       fwd_blk<RS_CAT>(av, f_cat, 0, h2p);
 #pragma unroll
       for (int b = 0; b < 3; ++b) fwd_blk<RS_CAT>(av, f_cat, 1 + b, xb1[b]);
-      h3p = pack32(relu32(av));
+      h3p = relu_pack(av);
       SCHED_FENCE();
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt)
@@ -517,7 +576,7 @@ __global__ __launch_bounds__(NTHR) void V2_KERNEL(const TrainDev a) {
       fwd_blk<RS_CL>(av, f_fl, 0, h4p);
       fwd_blk<RS_CL>(av, f_fl, 1, xb2[0]);
       fwd_blk<RS_CL>(av, f_fl, 2, xb2[1]);
-      hfp = pack32(relu32(av));
+      hfp = relu_pack(av);
 #endif
       SCHED_FENCE();
       // the heads read the fp32 activations (model.py:88,96)
@@ -631,6 +690,7 @@ __global__ __launch_bounds__(NTHR) void V2_KERNEL(const TrainDev a) {
         default: wgrad_wave<7>(acc, tr_stg); break;
       }
     }
+    PT(3);
 #else
     // With the feature loss the compositing has four parts: (i) waves 0-1 composite their ray (waves 2-7: weight
     // gradients of tile t - 1); (ii) every wave forms its 16 samples' share of fh = sum_s w_s hf_s; (iii) every wave
@@ -699,8 +759,10 @@ __global__ __launch_bounds__(NTHR) void V2_KERNEL(const TrainDev a) {
       wbh = Gg[32 * 32 + hh];
       bbv = Gg[32 * 32 + 32];
     }
+    PT(3);
     __syncthreads();
     RELAUNDER();
+    PT(9);
     {
       const float wv = valid ? s_w[slot] : 0.0f;
       float v8[8];
@@ -711,6 +773,7 @@ __global__ __launch_bounds__(NTHR) void V2_KERNEL(const TrainDev a) {
     }
     __syncthreads();
     RELAUNDER();
+    PT(10);
     {
       float* s_fhb = fs + FS_FHB + 64 * w;
       const int half = lane_l >> 5, hh = lane_l & 31;
@@ -761,6 +824,7 @@ __global__ __launch_bounds__(NTHR) void V2_KERNEL(const TrainDev a) {
     }
     __syncthreads();
     RELAUNDER();
+    PT(11);
     if (w < TR) {
       const int pos = lane;
       const int sl = w * S + pos;
@@ -779,8 +843,8 @@ __global__ __launch_bounds__(NTHR) void V2_KERNEL(const TrainDev a) {
         if (w == 0) wgrad_wave<0>(acc, tr_stg); else wgrad_wave<1>(acc, tr_stg);
       }
     }
+    PT(12);
 #endif
-    PT(3);
     __syncthreads();
     RELAUNDER();
     PT(4);
@@ -828,12 +892,11 @@ __global__ __launch_bounds__(NTHR) void V2_KERNEL(const TrainDev a) {
         d_hc.t[tt][r] = dv;
         d_h4.t[tt][r] = sm[S_WA + row] * da;
       }
-    d_hc = relu_mask_packed(d_hc, hcp);
     *reinterpret_cast<bf16x8*>(row_st + F_H4) = h4p;
 #if !V2_FEAT
     *reinterpret_cast<bf16x8*>(row_st + F_HC) = hcp;
 #endif
-    const bf16x8 d_hc_b = pack32(d_hc);
+    const bf16x8 d_hc_b = mask_pack(d_hc, hcp);
     *reinterpret_cast<bf16x8*>(row_st + F_DHC) = d_hc_b;
     BWD_TILE(d_h4.t[0], t_cl, RS_CL, 0, 0, d_hc_b);
     BWD_TILE(d_h4.t[1], t_cl, RS_CL, 0, 1, d_hc_b);
@@ -847,17 +910,15 @@ __global__ __launch_bounds__(NTHR) void V2_KERNEL(const TrainDev a) {
       for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) d_hf.t[tt][r] = valid ? wv * s_gfh[q * 32 + 16 * tt + 4 * g + r] : 0.0f;
-      d_hf = relu_mask_packed(d_hf, hfp);
-      d_hf_b = pack32(d_hf);
+      d_hf_b = mask_pack(d_hf, hfp);
     }
     *reinterpret_cast<bf16x8*>(row_st + F_DHF) = d_hf_b;
     BWD_TILE(d_h4.t[0], t_fl, RS_CL, 0, 0, d_hf_b);
     BWD_TILE(d_h4.t[1], t_fl, RS_CL, 0, 1, d_hf_b);
 #endif
-    d_h4 = relu_mask_packed(d_h4, h4p);
     PT(5);
     SCHED_FENCE();
-    const bf16x8 d_h4_b = pack32(d_h4);
+    const bf16x8 d_h4_b = mask_pack(d_h4, h4p);
     *reinterpret_cast<bf16x8*>(row_st + F_DH4) = d_h4_b;
     {
       f32x4 x2v[3];
@@ -874,8 +935,8 @@ __global__ __launch_bounds__(NTHR) void V2_KERNEL(const TrainDev a) {
         obj32n::pe32_x2_pair_fb(pe, 2 * T + 1, g, d_x[2], d_x[3], dps[2 * T + 1], o2, o3);
         x2v[T] = f32x4{o0, o1, o2, o3};
 #else
-        dps[2 * T] = fmaf(d_x[1], unpack_hi(cpk[6 * T + 2]), fmaf(d_x[0], unpack_lo(cpk[6 * T + 2]), dps[2 * T]));
-        dps[2 * T + 1] = fmaf(d_x[3], unpack_hi(cpk[6 * T + 5]), fmaf(d_x[2], unpack_lo(cpk[6 * T + 5]), dps[2 * T + 1]));
+        dps[2 * T] = fma_hi(d_x[1], cpk[6 * T + 2], fma_lo(d_x[0], cpk[6 * T + 2], dps[2 * T]));
+        dps[2 * T + 1] = fma_hi(d_x[3], cpk[6 * T + 5], fma_lo(d_x[2], cpk[6 * T + 5], dps[2 * T + 1]));
 #endif
         SCHED_FENCE();
       }
@@ -901,25 +962,22 @@ __global__ __launch_bounds__(NTHR) void V2_KERNEL(const TrainDev a) {
     T32 d_h3 = zero32();
     BWD_TILE(d_h3.t[0], t_m2, RS_M, 0, 0, d_h4_b);
     BWD_TILE(d_h3.t[1], t_m2, RS_M, 0, 1, d_h4_b);
-    d_h3 = relu_mask_packed(d_h3, h3p);
     *reinterpret_cast<bf16x8*>(row_st + F_H3) = h3p;
-    const bf16x8 d_h3_b = pack32(d_h3);
+    const bf16x8 d_h3_b = mask_pack(d_h3, h3p);
     *reinterpret_cast<bf16x8*>(row_st + F_DH3) = d_h3_b;
     SCHED_FENCE();
     T32 d_h2 = zero32();
     BWD_TILE(d_h2.t[0], t_cat, RS_CAT, 0, 0, d_h3_b);
     BWD_TILE(d_h2.t[1], t_cat, RS_CAT, 0, 1, d_h3_b);
-    d_h2 = relu_mask_packed(d_h2, h2p);
     *reinterpret_cast<bf16x8*>(row_st + F_H2) = h2p;
-    const bf16x8 d_h2_b = pack32(d_h2);
+    const bf16x8 d_h2_b = mask_pack(d_h2, h2p);
     *reinterpret_cast<bf16x8*>(row_st + F_DH2) = d_h2_b;
     SCHED_FENCE();
     T32 d_h1 = zero32();
     BWD_TILE(d_h1.t[0], t_m1, RS_M, 0, 0, d_h2_b);
     BWD_TILE(d_h1.t[1], t_m1, RS_M, 0, 1, d_h2_b);
-    d_h1 = relu_mask_packed(d_h1, h1p);
     *reinterpret_cast<bf16x8*>(row_st + F_H1) = h1p;
-    const bf16x8 d_h1_b = pack32(d_h1);
+    const bf16x8 d_h1_b = mask_pack(d_h1, h1p);
     *reinterpret_cast<bf16x8*>(row_st + F_DH1) = d_h1_b;
     PT(7);
     SCHED_FENCE();
@@ -935,8 +993,8 @@ __global__ __launch_bounds__(NTHR) void V2_KERNEL(const TrainDev a) {
 #ifdef V2_RECOMPUTE_PE
         xv[u] = obj32n::pe32_x1_tile_fb(pe, T, g, d_x, dps[T]);
 #else
-        dps[T] = fmaf(d_x[3], unpack_hi(cpk[3 * T + 1]), fmaf(d_x[2], unpack_lo(cpk[3 * T + 1]),
-                 fmaf(d_x[1], unpack_hi(cpk[3 * T]), fmaf(d_x[0], unpack_lo(cpk[3 * T]), dps[T]))));
+        dps[T] = fma_hi(d_x[3], cpk[3 * T + 1], fma_lo(d_x[2], cpk[3 * T + 1],
+                 fma_hi(d_x[1], cpk[3 * T], fma_lo(d_x[0], cpk[3 * T], dps[T]))));
 #endif
         SCHED_FENCE();
       }
@@ -954,7 +1012,10 @@ __global__ __launch_bounds__(NTHR) void V2_KERNEL(const TrainDev a) {
       dB[i][1] = fmaf(dps[i], pe.t[1], dB[i][1]);
       dB[i][2] = fmaf(dps[i], pe.t[2], dB[i][2]);
     }
-    fetch_point(tile + a.G, nx, ny, nz);
+#ifdef V2_LATE_FETCH
+    request_point(tile + a.G, raw);
+#endif
+    finish_point(tile + a.G, raw, nx, ny, nz);
     have_prev = true;
     PT(8);
   }

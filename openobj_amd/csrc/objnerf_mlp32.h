@@ -230,7 +230,12 @@ __device__ __forceinline__ void pe32_octaves(const float vh, const float vl, flo
       const float sc = (float)(1 << f);
       const float u = vh * sc;                   // exact
       const float r = u - rintf(u);              // exact, |r| <= 1/2
+#ifdef OBJ_PE_NO_LOW
+      const float w = r;
+      (void)vl;
+#else
       const float w = fmaf(vl, sc, r);
+#endif
       sn = __builtin_amdgcn_sinf(w);
       if (need_cos) cn = __builtin_amdgcn_cosf(w);
     } else {

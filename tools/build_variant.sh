@@ -14,8 +14,8 @@ for f in objnerf_train objnerf_train32 objnerf_train_bf16 objnerf_train_bf16v2 o
   [ $f = objnerf_train ] && extra="-mllvm -amdgpu-sched-strategy=max-ilp"
   [ $f = objnerf_train32 ] && extra="${T32_SCHED--mllvm -amdgpu-sched-strategy=iterative-ilp}"   # T32_SCHED: override (may be empty)
   [ $f = objnerf_train_bf16 ] && extra="${T16_SCHED--mllvm -amdgpu-sched-strategy=iterative-ilp}"   # T16_SCHED: override for the bf16 fused kernels
-  [ $f = objnerf_train_bf16v2 ] && extra="${T16V2_SCHED--mllvm -amdgpu-sched-strategy=iterative-ilp}"   # T16V2_SCHED: the second-generation bf16 kernel
-  [ $f = objnerf_train_bf16v2f ] && extra="${T16V2F_SCHED--mllvm -amdgpu-sched-strategy=iterative-ilp}"
+  [ $f = objnerf_train_bf16v2 ] && extra="${T16V2_SCHED--mllvm -amdgpu-sched-strategy=iterative-ilp -fno-honor-nans}"   # T16V2_SCHED: the second-generation bf16 kernel
+  [ $f = objnerf_train_bf16v2f ] && extra="${T16V2F_SCHED--mllvm -amdgpu-sched-strategy=iterative-ilp -fno-honor-nans}"
   [ $f = objnerf_generic ] && extra="$TGEN_SCHED"   # TGEN_SCHED: flags for the layer-wise / small-batch unit only
   [ $f = objnerf_train256 ] && extra="-mllvm -amdgpu-mfma-vgpr-form -Wno-inline-asm $T256_EXTRA"   # T256_EXTRA: flags for that unit only
   /opt/rocm/bin/hipcc $FLAGS $extra "$@" -c $f.hip -o $out/$f.o &

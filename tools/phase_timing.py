@@ -21,6 +21,8 @@ V2 = "--bf16v2" in sys.argv           # second-generation bf16 kernel (objnerf_t
 if V2:
     NAMES = ["load+project", "embed + mlp fwd + heads", "sync1", "composite | wgrad(t-1)", "sync2", "bwd: d_hc, d_h4",
              "bwd: x2 chain rule", "bwd: d_h3 .. d_h1", "bwd: x1 chain rule, dB, next point"]
+    if FEAT:
+        NAMES += ["feat: sync a", "feat: partial fh + sync", "feat: ray term + sync", "feat: composite bwd | wgrad(t-1) w0-1"]
 ws = ops.TrainWorkspace(arena, K, R, n1 + n2, FEAT)
 b = synthetic.random_batch(K, R, n1, n2, seed=4242, feat_dim=512 if FEAT else 0)
 batch = {k: torch.from_numpy(b[k]).to(dev) for k in ["pts", "z", "gt_depth", "gt_rgb", "labels"] + (["gt_feat"] if FEAT else [])}
@@ -28,7 +30,7 @@ for _ in range(3):
     ops.train_step(arena, ws, batch, with_feat=FEAT, bf16=BF16)
 torch.cuda.synchronize()
 out = (C.c_ulonglong * (8 * 24))()
-f = (_lib.lib().objnerf_debug_phase_bf16v2 if V2 else _lib.lib().objnerf_debug_phase_bf16) if BF16 else _lib.lib().objnerf_debug_phase32
+f = ((_lib.lib().objnerf_debug_phase_bf16v2f if FEAT else _lib.lib().objnerf_debug_phase_bf16v2) if V2 else _lib.lib().objnerf_debug_phase_bf16) if BF16 else _lib.lib().objnerf_debug_phase32
 f.restype = C.c_int
 assert f(out) == 0
 a = np.array(list(out), dtype=np.float64).reshape(8, 24)[:, :18]
