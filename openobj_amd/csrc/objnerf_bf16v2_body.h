@@ -180,7 +180,7 @@ __device__ __forceinline__ bf16x8 mask_pack(const T32& gr, const bf16x8 hp) {
 __device__ __forceinline__ unsigned pack_h2(const float lo, const float hi) {
   const f32x2 v = {lo, hi};
   unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
-  asm volatile("" : "+v"(u));
+  asm("" : "+v"(u));
   return u;
 }
 __device__ __forceinline__ float fma_lo(const float x, const unsigned hpair, const float acc) {
@@ -192,7 +192,11 @@ __device__ __forceinline__ float fma_hi(const float x, const unsigned hpair, con
 // ---- weight-gradient work list: (d block, activation tile) pairs of a wave; kind 1 = the head operand against two tiles
 struct Slot { int d, a, kind; };
 template <int W> struct WaveSlots;
-constexpr int NSLOT = 4;     // tile pairs per wave
+#if V2_FEAT
+constexpr int NSLOT = 5;     // tile pairs per wave
+#else
+constexpr int NSLOT = 4;
+#endif
 #if !V2_FEAT
 // 28 pairs = 6 waves x 4 + the two compositing waves x 2
 template <> struct WaveSlots<0> { static constexpr int n = 2; static constexpr Slot s[NSLOT] = {
@@ -202,15 +206,25 @@ template <> struct WaveSlots<1> { static constexpr int n = 2; static constexpr S
 template <> struct WaveSlots<4> { static constexpr int n = 4; static constexpr Slot s[NSLOT] = {
   {F_DHC, F_H4, 0}, {F_DHC, F_H4 + 32, 0}, {F_DHC, F_X2 + 0, 0}, {F_DHC, F_X2 + 32, 0}}; };
 #else
-// 30 pairs: the five layers as above (x2 now three tiles), the feature layer d hf x [h4 | x2] (5), the two bias pairs;
-// the compositing waves take 3 each
-template <> struct WaveSlots<0> { static constexpr int n = 3; static constexpr Slot s[NSLOT] = {
-  {F_DHF, F_H4, 0}, {F_DHF, F_H4 + 32, 0}, {F_DHF, F_X2 + 0, 0}, {0, 0, 0}}; };
-template <> struct WaveSlots<1> { static constexpr int n = 3; static constexpr Slot s[NSLOT] = {
-  {F_DHF, F_X2 + 32, 0}, {F_DHF, F_X2 + 64, 0}, {F_DHC, F_X2 + 64, 0}, {0, 0, 0}}; };
-template <> struct WaveSlots<4> { static constexpr int n = 4; static constexpr Slot s[NSLOT] = {
-  {F_DHC, F_H4, 0}, {F_DHC, F_H4 + 32, 0}, {F_DHC, F_X2 + 0, 0}, {F_DHC, F_X2 + 32, 0}}; };
+// 30 pairs: the five layers as above (x2 now three tiles), the feature layer d hf x [h4 | x2] (5), the two bias pairs --
+// five per wave on waves 2 - 7, in two halves of the contraction: samples 0 - 63 beside the compositing waves' part (i),
+// samples 64 - 127 beside their part (iv) (they have no other work in either)
+template <> struct WaveSlots<0> { static constexpr int n = 0; static constexpr Slot s[NSLOT] = {}; };
+template <> struct WaveSlots<1> { static constexpr int n = 0; static constexpr Slot s[NSLOT] = {}; };
+template <> struct WaveSlots<2> { static constexpr int n = 5; static constexpr Slot s[NSLOT] = {
+  {F_DH1, F_X1 + 0, 0}, {F_DH1, F_X1 + 32, 0}, {F_DH1, F_X1 + 64, 0}, {F_DH1, F_X1 + 96, 0}, {F_DH1, F_X1 + 128, 0}}; };
+template <> struct WaveSlots<3> { static constexpr int n = 5; static constexpr Slot s[NSLOT] = {
+  {F_DH3, F_X1 + 0, 0}, {F_DH3, F_X1 + 32, 0}, {F_DH3, F_X1 + 64, 0}, {F_DH3, F_X1 + 96, 0}, {F_DH3, F_X1 + 128, 0}}; };
+template <> struct WaveSlots<4> { static constexpr int n = 5; static constexpr Slot s[NSLOT] = {
+  {F_DHC, F_H4, 0}, {F_DHC, F_H4 + 32, 0}, {F_DHC, F_X2 + 0, 0}, {F_DHC, F_X2 + 32, 0}, {F_DHC, F_X2 + 64, 0}}; };
+template <> struct WaveSlots<5> { static constexpr int n = 5; static constexpr Slot s[NSLOT] = {
+  {F_DHF, F_H4, 0}, {F_DHF, F_H4 + 32, 0}, {F_DHF, F_X2 + 0, 0}, {F_DHF, F_X2 + 32, 0}, {F_DHF, F_X2 + 64, 0}}; };
+template <> struct WaveSlots<6> { static constexpr int n = 5; static constexpr Slot s[NSLOT] = {
+  {F_DH1, F_X1 + 160, 0}, {F_DH2, F_H1, 0}, {F_DH2, F_H1 + 32, 0}, {F_DH2, X1_ONE_TILE, 0}, {F_DH4, X1_ONE_TILE, 0}}; };
+template <> struct WaveSlots<7> { static constexpr int n = 5; static constexpr Slot s[NSLOT] = {
+  {F_DH3, F_X1 + 160, 0}, {F_DH3, F_H2, 0}, {F_DH3, F_H2 + 32, 0}, {F_DH4, F_H3, 0}, {F_DH4, F_H3 + 32, 0}}; };
 #endif
+#if !V2_FEAT
 template <> struct WaveSlots<2> { static constexpr int n = 4; static constexpr Slot s[NSLOT] = {
   {F_DH1, F_X1 + 0, 0}, {F_DH1, F_X1 + 32, 0}, {F_DH1, F_X1 + 64, 0}, {F_DH1, F_X1 + 96, 0}}; };
 template <> struct WaveSlots<3> { static constexpr int n = 4; static constexpr Slot s[NSLOT] = {
@@ -221,6 +235,7 @@ template <> struct WaveSlots<6> { static constexpr int n = 4; static constexpr S
   {F_DH1, F_X1 + 128, 0}, {F_DH1, F_X1 + 160, 0}, {F_DH2, F_H1, 0}, {F_DH2, F_H1 + 32, 0}}; };
 template <> struct WaveSlots<7> { static constexpr int n = 4; static constexpr Slot s[NSLOT] = {
   {F_DH4, F_H3, 0}, {F_DH4, F_H3 + 32, 0}, {F_DH4, X1_ONE_TILE, 0}, {F_DH2, X1_ONE_TILE, 0}}; };
+#endif
 
 struct WAcc { f32x4 a[NSLOT][2]; };
 
@@ -246,19 +261,20 @@ __device__ __forceinline__ void wgrad_slot(WAcc& acc, const char* base, bf16x8& 
     }
   }
 }
-template <int W>
+template <int W, int ST0 = 0, int ST1 = TS / 32>
 __device__ __forceinline__ void wgrad_wave(WAcc& acc, const char* lane_base) {
 #ifndef V2_WG_UNROLL
 #define V2_WG_UNROLL 4
 #endif
 #pragma unroll V2_WG_UNROLL   // (fully unrolled with all reads hoisted, the first build spilled 200 registers)
-  for (int st = 0; st < TS / 32; ++st) {
+  for (int st = ST0; st < ST1; ++st) {
     const char* base = lane_base + st * 32 * PITCH;
     bf16x8 a0, a1;
     wgrad_slot<W, 0>(acc, base, a0, a1);
     wgrad_slot<W, 1>(acc, base, a0, a1);
     wgrad_slot<W, 2>(acc, base, a0, a1);
     wgrad_slot<W, 3>(acc, base, a0, a1);
+    if constexpr (NSLOT > 4) wgrad_slot<W, 4>(acc, base, a0, a1);
   }
 }
 
@@ -334,8 +350,12 @@ __device__ __forceinline__ void emit_wave(float* slab, const Layout& L, const WA
   emit_slot<W, 1>(slab, L, acc, c, g);
   emit_slot<W, 2>(slab, L, acc, c, g);
   emit_slot<W, 3>(slab, L, acc, c, g);
+  if constexpr (NSLOT > 4) emit_slot<W, 4>(slab, L, acc, c, g);
 }
 
+// Tried on top of this and measured slower or equal (round 4, K = 50, R = 4096; product 2.185 ms): the embedding of tile
+// t + 1 formed at the end of tile t's backward pass (2.30 - 2.35 ms, 256 registers); one weight-gradient pair on each
+// compositing wave and five on waves 2 - 3 (2.190 ms); a single sin / cos anchor per direction (2.177 ms: kept at two).
 // Optional scheduling fences (-DV2_FENCES) at the layer boundaries of the forward / backward passes.  (The first build
 // kept the five activation blocks in fp32 across the compositing: 256 registers + 70 spilled, the weight-gradient
 // accumulators among them, and their scratch round trip cost 8 000 cycles per tile.  Keeping only the packed operands
@@ -739,12 +759,12 @@ __global__ __launch_bounds__(NTHR) void V2_KERNEL(const TrainDev a) {
       if (on) s_w[sl] = cw_wgt;
     } else if (have_prev) {
       switch (w) {
-        case 2: wgrad_wave<2>(acc, tr_stg); break;
-        case 3: wgrad_wave<3>(acc, tr_stg); break;
-        case 4: wgrad_wave<4>(acc, tr_stg); break;
-        case 5: wgrad_wave<5>(acc, tr_stg); break;
-        case 6: wgrad_wave<6>(acc, tr_stg); break;
-        default: wgrad_wave<7>(acc, tr_stg); break;
+        case 2: wgrad_wave<2, 0, 2>(acc, tr_stg); break;
+        case 3: wgrad_wave<3, 0, 2>(acc, tr_stg); break;
+        case 4: wgrad_wave<4, 0, 2>(acc, tr_stg); break;
+        case 5: wgrad_wave<5, 0, 2>(acc, tr_stg); break;
+        case 6: wgrad_wave<6, 0, 2>(acc, tr_stg); break;
+        default: wgrad_wave<7, 0, 2>(acc, tr_stg); break;
       }
     }
     // (ii) -- the Gram row of part (iii) is requested here: its L2 latency hides behind this part and the barrier
@@ -839,8 +859,14 @@ __global__ __launch_bounds__(NTHR) void V2_KERNEL(const TrainDev a) {
         s_col[TS + sl] = cw_g1 * cw_wgt * cw_c1 * (1.0f - cw_c1);
         s_col[2 * TS + sl] = cw_g2 * cw_wgt * cw_c2 * (1.0f - cw_c2);
       }
-      if (have_prev) {
-        if (w == 0) wgrad_wave<0>(acc, tr_stg); else wgrad_wave<1>(acc, tr_stg);
+    } else if (have_prev) {
+      switch (w) {
+        case 2: wgrad_wave<2, 2, 4>(acc, tr_stg); break;
+        case 3: wgrad_wave<3, 2, 4>(acc, tr_stg); break;
+        case 4: wgrad_wave<4, 2, 4>(acc, tr_stg); break;
+        case 5: wgrad_wave<5, 2, 4>(acc, tr_stg); break;
+        case 6: wgrad_wave<6, 2, 4>(acc, tr_stg); break;
+        default: wgrad_wave<7, 2, 4>(acc, tr_stg); break;
       }
     }
     PT(12);

@@ -146,3 +146,49 @@ def test_bf16_second_generation_kernel_edge_cases(golden, dev):
     torch.cuda.synchronize()
     assert float(ws.loss_terms[:, :2].abs().max()) == 0.0
     assert float(arena.views(ws.grads)[12].abs().max()) == 0.0
+
+
+def test_bf16_second_generation_feature_kernel_edge_cases(golden, dev):
+    """The same four properties for the feature-loss instantiation (train_fused_bf16v2f_kernel: configs[2] / [3] in
+    bf16): bit-reproducible, points == origins / dirs / z bit for bit, and the early return (loss.py:81-99 sits behind the
+    same render_rays.py:89-94 decision) zeroes the depth, colour AND feature terms with the feature branch's gradients --
+    exact zeros -- while the opacity term still trains the trunk.  A ragged ray count (130 = 65 tiles, the last one's
+    second ray past the end of nothing: R is even; 131 leaves a half-filled tile) runs too."""
+    for R in (130, 131):
+        K, n1, n2 = 3, 16, 48
+        arena = _arena(golden, K, dev)
+        b = synthetic.random_batch(K, R, n1, n2, seed=77 + R, feat_dim=512)
+        keys = ["pts", "z", "gt_depth", "gt_rgb", "labels", "gt_feat"]
+        batch = {k: T(b[k]).to(dev) for k in keys}
+        ws = ops.TrainWorkspace(arena, K, R, n1 + n2, True)
+        ops.train_step(arena, ws, batch, with_feat=True, bf16=True)
+        torch.cuda.synchronize()
+        assert int(ws.status.item()) == 0 and bool(torch.isfinite(ws.grads).all())
+        g0, t0 = ws.grads.clone(), ws.loss_terms.clone()
+        assert float(t0[:, 3].min()) > 0.0
+        ops.train_step(arena, ws, batch, with_feat=True, bf16=True)
+        torch.cuda.synchronize()
+        assert torch.equal(ws.grads, g0) and torch.equal(ws.loss_terms, t0)
+        b2 = {k: T(b[k]).to(dev) for k in ["origins", "dirs", "z", "gt_depth", "gt_rgb", "labels", "gt_feat"]}
+        ops.train_step(arena, ws, b2, with_feat=True, bf16=True)
+        torch.cuda.synchronize()
+        assert torch.equal(ws.grads, g0)
+        # against the fp32 fused kernel at this ragged shape
+        ws32 = ops.TrainWorkspace(arena, K, R, n1 + n2, True)
+        ops.train_step(arena, ws32, batch, with_feat=True)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(t0.cpu(), ws32.loss_terms.cpu(), rtol=2e-2, atol=2e-3)
+        g32, g16 = arena.views(ws32.grads), arena.views(g0)
+        for i in range(19):
+            a, r = g16[i].double().cpu(), g32[i].double().cpu()
+            assert float((a - r).norm() / (r.norm() + 1e-12)) < 0.15, (R, i, ops.TENSOR_NAMES[i])
+        lab = batch["labels"].clone()
+        lab[1][lab[1] == 1] = 0
+        ops.train_step(arena, ws, dict(batch, labels=lab), with_feat=True, bf16=True)
+        torch.cuda.synchronize()
+        t = ws.loss_terms.cpu()
+        assert float(t[:, :2].abs().max()) == 0.0 and float(t[:, 3].abs().max()) == 0.0 and float(t[:, 2].min()) > 0.0
+        gv = arena.views(ws.grads)
+        for i in (10, 11, 12, 13) + tuple(ops.FEAT_TENSORS):
+            assert float(gv[i].abs().max()) == 0.0, ops.TENSOR_NAMES[i]
+        assert float(gv[0].abs().max()) > 0.0

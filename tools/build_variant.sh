@@ -12,7 +12,7 @@ pids=()
 for f in objnerf_train objnerf_train32 objnerf_train_bf16 objnerf_train_bf16v2 objnerf_train_bf16v2f objnerf_misc objnerf_generic objnerf_helpers objnerf_train256 objnerf_render objnerf_render_bf16; do
   extra=""
   [ $f = objnerf_train ] && extra="-mllvm -amdgpu-sched-strategy=max-ilp"
-  [ $f = objnerf_train32 ] && extra="${T32_SCHED--mllvm -amdgpu-sched-strategy=iterative-ilp}"   # T32_SCHED: override (may be empty)
+  [ $f = objnerf_train32 ] && extra="${T32_SCHED--mllvm -amdgpu-sched-strategy=iterative-ilp -fno-honor-nans}"   # T32_SCHED: override (may be empty)
   [ $f = objnerf_train_bf16 ] && extra="${T16_SCHED--mllvm -amdgpu-sched-strategy=iterative-ilp}"   # T16_SCHED: override for the bf16 fused kernels
   [ $f = objnerf_train_bf16v2 ] && extra="${T16V2_SCHED--mllvm -amdgpu-sched-strategy=iterative-ilp -fno-honor-nans}"   # T16V2_SCHED: the second-generation bf16 kernel
   [ $f = objnerf_train_bf16v2f ] && extra="${T16V2F_SCHED--mllvm -amdgpu-sched-strategy=iterative-ilp -fno-honor-nans}"
