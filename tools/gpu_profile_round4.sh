@@ -23,6 +23,13 @@ pmc() {    # name, kernel substring, bench args: four passes (FETCH_SIZE, WRITE_
     rm -f $OUT/pmc_${n}_$pass/*.csv
   done
 }
+# ONLY=c4full (environment): just the PMC passes of the full configs[3] launch (120 objects), merged into an existing prof4/
+if [ "${ONLY:-all}" = c4full ]; then
+  pmc c4full_f32 "train_fused32_kernel<true" --config c4 --no-bg
+  pmc c4full_bf16 train_fused_bf16v2f --config c4 --no-bg --dtype bf16
+  ls -la $OUT | tail -12
+  exit 0
+fi
 stats default --steps 20 --warmup 5
 stats feat --config c3 --steps 10 --warmup 3
 stats c4share --config c4 --objects 15 --steps 10 --warmup 3
@@ -33,6 +40,8 @@ pmc c3_f32 "train_fused32_kernel<true" --config c3 --no-bg
 pmc c3_bf16 train_fused_bf16v2f --config c3 --no-bg --dtype bf16
 pmc c4_f32 "train_fused32_kernel<true" --config c4 --objects 15 --no-bg
 pmc c4_bf16 train_fused_bf16v2f --config c4 --objects 15 --no-bg --dtype bf16
+pmc c4full_f32 "train_fused32_kernel<true" --config c4 --no-bg
+pmc c4full_bf16 train_fused_bf16v2f --config c4 --no-bg --dtype bf16
 for kk in fwd256_kernel wgrad256_kernel; do :; done
 C5="--config c5 --dtype fp16 --objects 8 --no-bg"
 for pass in fetch write sq sq2; do

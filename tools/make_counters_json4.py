@@ -56,6 +56,8 @@ entry("c3_f32", "c3_f32", "train_fused32_kernel<true, false, 64>", 50)
 entry("c3_bf16", "c3_bf16", "train_fused_bf16v2f_kernel", 50)
 entry("c4_f32", "c4share_f32", "train_fused32_kernel<true, false, 64>", 15)
 entry("c4_bf16", "c4share_bf16", "train_fused_bf16v2f_kernel", 15)
+entry("c4full_f32", "c4_f32", "train_fused32_kernel<true, false, 64>", 120)
+entry("c4full_bf16", "c4_bf16", "train_fused_bf16v2f_kernel", 120)
 # configs[4]: two kernels per 8-object launch; recorded per object
 fw, wg = {}, {}
 lines = []
