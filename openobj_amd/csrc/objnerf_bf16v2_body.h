@@ -356,6 +356,10 @@ __device__ __forceinline__ void emit_wave(float* slab, const Layout& L, const WA
 // Tried on top of this and measured slower or equal (round 4, K = 50, R = 4096; product 2.185 ms): the embedding of tile
 // t + 1 formed at the end of tile t's backward pass (2.30 - 2.35 ms, 256 registers); one weight-gradient pair on each
 // compositing wave and five on waves 2 - 3 (2.190 ms); a single sin / cos anchor per direction (2.177 ms: kept at two).
+// Feature build: the ray term (part iii) on the two compositing waves only, beside the second half of the weight
+// gradients on waves 2-7 (one more barrier): what the compositing waves carry from part (i) to part (iv) becomes live
+// across the weight-gradient code -- 75 spilled registers with one shared path, 156 with role-specialised paths between
+// the tile's barriers.  It needs ~30 registers first (the head weights' per-lane sums as butterfly sums would free them).
 // Optional scheduling fences (-DV2_FENCES) at the layer boundaries of the forward / backward passes.  (The first build
 // kept the five activation blocks in fp32 across the compositing: 256 registers + 70 spilled, the weight-gradient
 // accumulators among them, and their scratch round trip cost 8 000 cycles per tile.  Keeping only the packed operands
