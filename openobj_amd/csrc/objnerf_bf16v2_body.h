@@ -180,7 +180,11 @@ __device__ __forceinline__ bf16x8 mask_pack(const T32& gr, const bf16x8 hp) {
 __device__ __forceinline__ unsigned pack_h2(const float lo, const float hi) {
   const f32x2 v = {lo, hi};
   unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+#ifdef V2_PACK_RELAXED
   asm("" : "+v"(u));
+#else
+  asm volatile("" : "+v"(u));      // (volatile: 2.185 ms; as a plain asm the scheduler moves the packs and the kernel is 1.3 % slower)
+#endif
   return u;
 }
 __device__ __forceinline__ float fma_lo(const float x, const unsigned hpair, const float acc) {
@@ -355,7 +359,9 @@ __device__ __forceinline__ void emit_wave(float* slab, const Layout& L, const WA
 
 // Tried on top of this and measured slower or equal (round 4, K = 50, R = 4096; product 2.185 ms): the embedding of tile
 // t + 1 formed at the end of tile t's backward pass (2.30 - 2.35 ms, 256 registers); one weight-gradient pair on each
-// compositing wave and five on waves 2 - 3 (2.190 ms); a single sin / cos anchor per direction (2.177 ms: kept at two).
+// compositing wave and five on waves 2 - 3 (2.190 ms); a single sin / cos anchor per direction (2.177 ms: kept at two); the embedding's
+// doubling formulas and factor scaling as packed fp32 over direction pairs (74 fewer instructions per tile; 2.19 -> 2.22 ms
+// -- packed fp32 VALU beside the partner wave's MFMAs is the anti-lever MI355X_MICROARCH.md says it is).
 // Feature build: the ray term (part iii) on the two compositing waves only, beside the second half of the weight
 // gradients on waves 2-7 (one more barrier): what the compositing waves carry from part (i) to part (iv) becomes live
 // across the weight-gradient code -- 75 spilled registers with one shared path, 156 with role-specialised paths between
