@@ -123,7 +123,7 @@ def test_fused_bf16_kernel_matches_its_specification(dev, shape):
         assert rel < (0.06 if K * R * (n1 + n2) >= 20000 else 0.10), (i, ops.TENSOR_NAMES[i], rel)
 
 
-@pytest.mark.parametrize("shape", [(3, 300, 16, 48), (2, 333, 16, 48), (60, 40, 16, 48)])
+@pytest.mark.parametrize("shape", [(3, 300, 16, 48), (2, 333, 16, 48), (60, 40, 16, 48), (300, 9, 16, 48)])
 def test_fused_bf16_feature_kernel_matches_its_specification(dev, shape):
     """The feature-loss instantiation of the second-generation kernel (train_fused_bf16v2f_kernel, configs[2] / [3] in
     bf16) against the operand-rounded specification with the 512-d term.  Measured (tools/bf16v2f_diag.py, 57 600

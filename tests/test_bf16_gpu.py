@@ -192,3 +192,20 @@ def test_bf16_second_generation_feature_kernel_edge_cases(golden, dev):
         for i in (10, 11, 12, 13) + tuple(ops.FEAT_TENSORS):
             assert float(gv[i].abs().max()) == 0.0, ops.TENSOR_NAMES[i]
         assert float(gv[0].abs().max()) > 0.0
+        # the same decision handed in from outside (object sharding: global flags / counts)
+        flags = torch.tensor([1, 0], dtype=torch.int32, device=dev)
+        counts = ops.label_counts(batch["labels"])[0]
+        ops.train_step(arena, ws, batch, with_feat=True, bf16=True, global_flags=flags, global_counts=counts)
+        torch.cuda.synchronize()
+        assert float(ws.loss_terms[:, :2].abs().max()) == 0.0 and float(ws.loss_terms[:, 3].abs().max()) == 0.0
+        assert float(arena.views(ws.grads)[16].abs().max()) == 0.0
+        # ... and with nothing empty, the global counts normalise the terms: twice the counts, half the gradient
+        flags0 = torch.zeros(2, dtype=torch.int32, device=dev)
+        ops.train_step(arena, ws, batch, with_feat=True, bf16=True, global_flags=flags0, global_counts=counts)
+        torch.cuda.synchronize()
+        assert torch.equal(ws.grads, g0)
+        ops.train_step(arena, ws, batch, with_feat=True, bf16=True, global_flags=flags0, global_counts=2 * counts)
+        torch.cuda.synchronize()
+        ref0 = arena.views(g0)[0].double()
+        sel = ref0.abs() > 1e-6
+        assert float((arena.views(ws.grads)[0].double()[sel] / ref0[sel] - 0.5).abs().max()) < 1e-3
