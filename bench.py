@@ -72,6 +72,9 @@ def parse_args(argv=None):
     ap.add_argument("--config", choices=sorted(CONFIGS), default=None,
                     help="BASELINE.json configuration (default c2; the explicit shape flags below override it)")
     ap.add_argument("--objects", type=int, default=None, help="object networks per GPU (c4: in total)")
+    ap.add_argument("--bg-ranks", type=int, default=None,
+                    help="per-GPU share runs: this process stands for one of N ranks and takes one rank's slice of the "
+                         "background rays (the default line's c4_share entry uses 8)")
     ap.add_argument("--rays", type=int, default=None, help="rays per object per step")
     ap.add_argument("--n-cam2surf", type=int, default=None)
     ap.add_argument("--n-bins", type=int, default=None)
@@ -354,7 +357,10 @@ class Workload:
             c.obj_id, c.hidden_feature_size, c.obj_scale = 0, c.hidden_feature_size_bg, c.bg_scale
             torch.manual_seed(7)                               # identical replica on every rank
             self.bg_loop = otrain.BackgroundLoop(c, otrainer.Trainer(c), with_feat=feat)
-            lo, hi = odist.shard_rays(c.n_per_optim_bg, world, rank)
+            # `bg_ranks` (the c4_share entry): this process stands for ONE of that many ranks, so it takes one rank's
+            # slice of the background rays as dist.shard_rays deals them (the gradient all-reduce is not simulated)
+            self.bg_ranks = world * int(wl.get("bg_ranks", 1))
+            lo, hi = odist.shard_rays(c.n_per_optim_bg, self.bg_ranks, rank)
             self.bg_batches = []
             for i in range(2):
                 b = synthetic.random_batch(1, c.n_per_optim_bg, n1, n2, seed=777 + i, feat_dim=512 if feat else 0)
@@ -457,7 +463,8 @@ class Workload:
                             f"{'+512-d feature' if self.feat else ''} loss, fused fwd+loss+bwd+AdamW",
                 "objects_per_gpu": self.K, "objects_total": self.K_total, "rays_per_object": self.R,
                 "samples_per_ray": self.S, "hidden": self.Hd, "feature_head": self.feat,
-                "background_mlp": self.bg_loop is not None, "distinct_ray_sets": self.distinct}
+                "background_mlp": self.bg_loop is not None, "distinct_ray_sets": self.distinct,
+                "background_rays_on_this_gpu": (self.bg_batches[0]["labels"].shape[1] if self.bg_loop is not None else 0)}
 
     def free(self):
         import torch
@@ -468,7 +475,7 @@ class Workload:
 
 OTHER_CONFIGS = [   # (key, base config, overrides, operand modes) -- timed after the headline by the default run
     ("c3", "c3", {}, [False, True]),
-    ("c4_share", "c4", {"objects": 15, "scaling": "weak"}, [False, True]),
+    ("c4_share", "c4", {"objects": 15, "scaling": "weak", "bg_ranks": 8}, [False, True]),
     ("c5_share_fp16", "c5", {"bg": False}, ["fp16"]),
 ]
 
@@ -570,7 +577,7 @@ def main():
     cfgname = args.config or "c2"
     wl = dict(CONFIGS[cfgname])
     for k_arg, k_wl in (("objects", "objects"), ("rays", "rays"), ("n_cam2surf", "n1"), ("n_bins", "n2"),
-                        ("hidden", "hidden"), ("feat", "feat")):
+                        ("hidden", "hidden"), ("feat", "feat"), ("bg_ranks", "bg_ranks")):
         if getattr(args, k_arg) is not None:
             wl[k_wl] = getattr(args, k_arg)
     default_line = (args.config is None and args.dtype == "f32" and args.bg and

@@ -32,14 +32,14 @@ if [ "${ONLY:-all}" = c4full ]; then
 fi
 stats default --steps 20 --warmup 5
 stats feat --config c3 --steps 10 --warmup 3
-stats c4share --config c4 --objects 15 --steps 10 --warmup 3
+stats c4share --config c4 --objects 15 --bg-ranks 8 --steps 10 --warmup 3
 stats c5 --config c5 --dtype fp16 --objects 8 --no-bg --no-bf16-line --steps 2 --warmup 1
 pmc f32 train_fused32 --no-bg
 pmc bf16 train_fused_bf16 --no-bg --dtype bf16
 pmc c3_f32 "train_fused32_kernel<true" --config c3 --no-bg
 pmc c3_bf16 train_fused_bf16v2f --config c3 --no-bg --dtype bf16
-pmc c4_f32 "train_fused32_kernel<true" --config c4 --objects 15 --no-bg
-pmc c4_bf16 train_fused_bf16v2f --config c4 --objects 15 --no-bg --dtype bf16
+pmc c4_f32 "train_fused32_kernel<true" --config c4 --objects 15 --bg-ranks 8 --no-bg
+pmc c4_bf16 train_fused_bf16v2f --config c4 --objects 15 --bg-ranks 8 --no-bg --dtype bf16
 pmc c4full_f32 "train_fused32_kernel<true" --config c4 --no-bg
 pmc c4full_bf16 train_fused_bf16v2f --config c4 --no-bg --dtype bf16
 for kk in fwd256_kernel wgrad256_kernel; do :; done
