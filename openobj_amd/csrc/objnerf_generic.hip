@@ -305,9 +305,10 @@ __device__ __forceinline__ uint2 lds_tr16(const void* p) {
 // k-loop.  (The plain kernel re-read and re-rounded the fp32 weights in every workgroup: rocprof counted 36 VALU
 // instructions per MFMA on the hidden-256 layer GEMMs, which ran at ~2 TB/s of HBM traffic with the matrix core 90 %
 // idle.)  With BN = 256 the panel is read exactly once.  The epilogue's LDS patch aliases the panel.
+// (the body takes its block coordinates as arguments: gemm_group16_kernel below runs it for several GEMMs per launch)
 template <int TM, int TN, typename OT, int BKB, int WM = 2, int WN = 2, bool AKM = false, bool BKM = false,
           bool AFULL = false, int KMAX = 256>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? ((AFULL && KMAX == 256) ? 8 : 4) : 1) void gemm_bf16_kernel(const Gemm g) {
+__device__ __forceinline__ void gemm_bf16_body(const Gemm& g, const int bx, const int by, const int bz) {
   constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN, LDK = BKB + 8, NTH = 64 * WM * WN;
   constexpr int PA = BM + 8, PB = BN + 8;                 // k-major row pitches (elements; 8-byte aligned rows)
   constexpr int LDA = AFULL ? KMAX + 8 : LDK;   // AFULL: panel row pitch (conflict-free b128 reads: 132 / 180 dwords)
@@ -323,29 +324,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? ((AFULL && KMAX == 2
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int c = lane & 15, gg = lane >> 4;
   const int wm = w / WN, wn = w % WN;
-  // Workgroups are handed to the 8 XCDs round-robin in launch order (x fastest), so the column tiles of one row
-  // block -- which read the same A rows -- would land on different L2s.  Re-map: consecutive workgroups OF ONE XCD
-  // take the column tiles of one row block (rows beyond the last multiple of 8 row blocks keep the plain order).
-  // Split-K weight gradients (few output tiles, hundreds of slices): the tiles of ONE slice read the same operand slabs,
-  // so they go to one XCD the same way.
-  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-  if (OBJ_G16_XCD && gridDim.x > 1 && gridDim.y >= 8) {
-    const unsigned gx = gridDim.x, L = blockIdx.x + gx * blockIdx.y, full = (gridDim.y / 8) * 8 * gx;
-    if (L < full) {
-      const unsigned xcd = L % 8, s = L / 8;
-      bx = (int)(s % gx);
-      by = (int)((s / gx) * 8 + xcd);
-    }
-  } else if (OBJ_G16_XCD && gridDim.x * gridDim.y > 1 && gridDim.z >= 8) {
-    const unsigned gx = gridDim.x, T = gx * gridDim.y, L = blockIdx.x + gx * blockIdx.y + T * blockIdx.z;
-    const unsigned full = (gridDim.z / 8) * 8 * T;
-    if (L < full) {
-      const unsigned xcd = L % 8, s = L / 8, tile = s % T;
-      bx = (int)(tile % gx);
-      by = (int)(tile / gx);
-      bz = (int)((s / T) * 8 + xcd);
-    }
-  }
   const int m0 = by * BM, n0 = bx * BN;
   const int sk = g.splitk > 1 ? g.splitk : 1;
   const long z = bz / sk;
@@ -658,6 +636,45 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? ((AFULL && KMAX == 2
   }
 }
 
+template <int TM, int TN, typename OT, int BKB, int WM = 2, int WN = 2, bool AKM = false, bool BKM = false,
+          bool AFULL = false, int KMAX = 256>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? ((AFULL && KMAX == 256) ? 8 : 4) : 1) void gemm_bf16_kernel(const Gemm g) {
+  // Workgroups are handed to the 8 XCDs round-robin in launch order (x fastest), so the column tiles of one row
+  // block -- which read the same A rows -- would land on different L2s.  Re-map: consecutive workgroups OF ONE XCD
+  // take the column tiles of one row block (rows beyond the last multiple of 8 row blocks keep the plain order).
+  // Split-K weight gradients (few output tiles, hundreds of slices): the tiles of ONE slice read the same operand slabs,
+  // so they go to one XCD the same way.
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (OBJ_G16_XCD && gridDim.x > 1 && gridDim.y >= 8) {
+    const unsigned gx = gridDim.x, L = blockIdx.x + gx * blockIdx.y, full = (gridDim.y / 8) * 8 * gx;
+    if (L < full) {
+      const unsigned xcd = L % 8, s = L / 8;
+      bx = (int)(s % gx);
+      by = (int)((s / gx) * 8 + xcd);
+    }
+  } else if (OBJ_G16_XCD && gridDim.x * gridDim.y > 1 && gridDim.z >= 8) {
+    const unsigned gx = gridDim.x, T = gx * gridDim.y, L = blockIdx.x + gx * blockIdx.y + T * blockIdx.z;
+    const unsigned full = (gridDim.z / 8) * 8 * T;
+    if (L < full) {
+      const unsigned xcd = L % 8, s = L / 8, tile = s % T;
+      bx = (int)(tile % gx);
+      by = (int)(tile / gx);
+      bz = (int)((s / T) * 8 + xcd);
+    }
+  }
+  gemm_bf16_body<TM, TN, OT, BKB, WM, WN, AKM, BKM, AFULL, KMAX>(g, bx, by, bz);
+}
+
+// The weight-gradient GEMMs of a small-batch step in bf16 mode, in ONE launch (the fp32 twin: gemm_group_kernel): 64 x 64
+// tiles on 4 waves, both operands k-major (d_out^T and the activations as they lie in memory), split-K partial tiles.
+__global__ __launch_bounds__(256) void gemm_group16_kernel(const GemmGroup gr) {
+  int i = 0;
+  while (i + 1 < gr.count && (int)blockIdx.z >= gr.zbeg[i + 1]) ++i;
+  const Gemm& g = gr.g[i];
+  if ((int)blockIdx.x * 64 >= g.N || (int)blockIdx.y * 64 >= g.M) return;
+  gemm_bf16_body<2, 2, __bf16, OBJ_G16_BK, 2, 2, true, true>(g, blockIdx.x, blockIdx.y, blockIdx.z - gr.zbeg[i]);
+}
+
 // B (generic strides, fp32) -> the AFULL kernel's operand image: thread (ks, jt, lane) writes the 8 values
 // B[32 ks + 8 (lane >> 4) + e][16 jt + (lane & 15)], e = 0..7, rounded to OT; zero beyond Kd / N.
 template <typename OT, int KS>
@@ -687,6 +704,7 @@ struct GemmEnv {
   int operands = 0;                 // 0: fp32 GEMMs, 1: bf16 operands, 2: fp16 operands
   float a_scale = 1.0f;             // Gemm::a_scale of the next gemm(E, ) calls (fp16 backward)
   GemmGroup* group = nullptr;       // non-null: gemm(E, ) collects descriptors instead of launching
+  bool group16 = false;             // the collected GEMMs run with bf16 operands (gemm_group16_kernel: small-batch step in bf16 mode)
   const float* biasrow = nullptr;   // Gemm::biasrow / bsbr / sbr of the next calls
   long bsbr = 0;
   int sbr = 1;
@@ -832,6 +850,11 @@ static void gemm(GemmEnv& E, hipStream_t st, int batch, int M, int N, int Kd, co
   const int nz = batch * (splitk > 1 ? splitk : 1);
   if (E.group && !E.operands && !(M >= 256 && N >= 192) && E.group->count < GemmGroup::MAXG) {
     GemmGroup& gr = *E.group;               // collected; launched by flush_group(E, )
+    if (E.group16) {
+      // gemm_group16_kernel stages both operands k-major: rows contiguous in memory (weight gradients are)
+      if (!(sak != 1 && sam == 1 && sbk != 1 && sbn == 1)) { fprintf(stderr, "objnerf: grouped bf16 GEMM needs k-major operands\n"); abort(); }
+      g.vec4 = (sak % 4 == 0 && bsa % 4 == 0 && M % 4 == 0 && ((uintptr_t)A & 15) == 0) ? 1 : 0;
+    }
     if (gr.count == 0) gr.zbeg[0] = 0;
     gr.g[gr.count] = g;
     gr.zbeg[gr.count + 1] = gr.zbeg[gr.count] + nz;
@@ -1224,7 +1247,16 @@ __global__ __launch_bounds__(512) void mlp_bwd_small_kernel(const BwdSmall a) {
 #pragma unroll
     for (int i = 0; i < 32; ++i) wr[i] = kk < NC ? W[(rg + 4 * i) * ld + kk] : 0.f;
   };
+  // bf16 mode: the weight rows go to LDS ROUNDED, [k = out][n = in] with a 288-byte pitch (72 dwords = 8 mod 64: the
+  // eight rows a transposing read's half-wave touches sit on disjoint bank octets)
+  constexpr int PW16 = 288;
   auto put_w = [&]() {
+    if (BF) {
+      __bf16* W16 = reinterpret_cast<__bf16*>(Wb);
+#pragma unroll
+      for (int i = 0; i < 32; ++i) W16[(rg + 4 * i) * (PW16 / 2) + kk] = (__bf16)wr[i];
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 32; ++i) Wb[(rg + 4 * i) * PW + kk] = wr[i];
   };
@@ -1237,18 +1269,21 @@ __global__ __launch_bounds__(512) void mlp_bwd_small_kernel(const BwdSmall a) {
   // forward kernel (step j of a 16-block takes k = 16 blk + 4 gg + j): D rows by ds_read_b128, the four weight rows
   // by ds_read_b32 (bank = 8 gg + 2 j + n: two lanes per bank, the minimum for 64 lanes).
   auto mma = [&](const float* D, f32x4 (&v)[RT]) {
-    if (BF) {          // bf16 MFMA: k-slot (block, gg, e) = output feature 32 block + 8 gg + e; eight weight rows per lane
-      const float* bp = Wb + 8 * gg * PW + 16 * w + c;       // (bank = 16 gg + 2 e + c: conflict-free)
-      const float* ap = D + c * PT + 8 * gg;
+    if (BF) {
+      // bf16 MFMA: the lane's 8 k-slots of a 32-block are output features 4 gg .. 4 gg + 3 and 16 + 4 gg .. + 3.  The
+      // weight operand -- 8 k of ONE input column -- comes out of the row-major bf16 image by two transposing reads
+      // (lane 4 q + p of a 16-lane group supplies row q, 8-byte chunk p); it used to be eight ds_read_b32 of fp32 rows
+      // and four conversions per MFMA.
+      const char* bp = reinterpret_cast<const char*>(Wb) + (4 * gg + (c >> 2)) * PW16 + 32 * w + 8 * (c & 3);
+      const float* ap = D + c * PT + 4 * gg;
 #pragma unroll
       for (int kb = 0; kb < H; kb += 32) {
-        bf16x8 b;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) b[e] = (__bf16)bp[(kb + e) * PW];
+        const uint2 b0 = lds_tr16(bp + kb * PW16), b1 = lds_tr16(bp + (kb + 16) * PW16);
+        const bf16x8 b = __builtin_bit_cast(bf16x8, uint4{b0.x, b0.y, b1.x, b1.y});
 #pragma unroll
         for (int i = 0; i < RT; ++i) {
           const float* r = ap + 16 * i * PT + kb;
-          const bf16x8 av = cvt_bf16x8(*reinterpret_cast<const f32x4*>(r), *reinterpret_cast<const f32x4*>(r + 4));
+          const bf16x8 av = cvt_bf16x8(*reinterpret_cast<const f32x4*>(r), *reinterpret_cast<const f32x4*>(r + 16));
           v[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b, v[i], 0, 0, 0);
         }
       }
@@ -1459,8 +1494,10 @@ static void flush_group(GemmEnv& E, hipStream_t st, GemmGroup& gr) {
     mx = std::max(mx, (gr.g[i].N + 63) / 64);
     my = std::max(my, (gr.g[i].M + 63) / 64);
   }
-  hipLaunchKernelGGL(gemm_group_kernel, dim3((mx + 1) / 2, (my + 1) / 2, gr.zbeg[gr.count]), dim3(512), 0, st, gr);
+  if (E.group16) hipLaunchKernelGGL(gemm_group16_kernel, dim3(mx, my, gr.zbeg[gr.count]), dim3(256), 0, st, gr);
+  else hipLaunchKernelGGL(gemm_group_kernel, dim3((mx + 1) / 2, (my + 1) / 2, gr.zbeg[gr.count]), dim3(512), 0, st, gr);
   gr.count = 0;
+  E.group16 = false;
   E.red_group = nullptr;                 // (the caller launches the collected reductions: launch_reductions)
 }
 
@@ -2190,6 +2227,7 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
     GemmGroup group;
     group.count = 0;
     E.group = &group;
+    E.group16 = small_bf;             // bf16 mode: the weight gradients take bf16 operands like every other GEMM of the mode
     E.red_group = &step_red;
     if (feat) {
       wgrad(E, side(), K, H, H, n, w.d_hf, 1, H, nH, w.h4, H, 1, nH, G + off[14], H + E2, ps, G + off[15]);
