@@ -94,6 +94,8 @@ def parse_args(argv=None):
                     help="do not also time the bf16 mode (reported as the `bf16_mode` object of the fp32 line)")
     ap.add_argument("--no-overlap", dest="overlap", action="store_false",
                     help="diagnostic: background chain on the object kernel's stream instead of beside it")
+    ap.add_argument("--no-pipeline", dest="pipelined", action="store_false",
+                    help="make the object stream wait for the background chain at the end of EVERY step (round 4's form)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-psnr", action="store_true")
     ap.add_argument("--psnr-seeds", type=int, default=320)
@@ -343,11 +345,12 @@ class Workload:
                 if self.events is not None:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                ops.train_step(arena, self.ws, batch, global_flags=global_flags, with_feat=feat, bf16=self.bf16)
+                # (optim=: AdamW runs in the step's last launch -- objnerf_train_args.optim, ABI 7)
+                ops.train_step(arena, self.ws, batch, global_flags=global_flags, with_feat=feat, bf16=self.bf16,
+                               optim=self.opt)
                 if self.events is not None:
                     e1.record()
                     self.events.append((e0, e1))
-                self.opt.step(self.ws.grads, self.mask, flags=global_flags if global_flags is not None else self.ws.flags)
                 return self.ws.loss_terms
 
         self.obj_loop = ObjLoop()
@@ -365,8 +368,10 @@ class Workload:
             for i in range(2):
                 b = synthetic.random_batch(1, c.n_per_optim_bg, n1, n2, seed=777 + i, feat_dim=512 if feat else 0)
                 self.bg_batches.append({k: torch.from_numpy(b[k][:, lo:hi]).contiguous().to(dev) for k in keys})
+        # (pipelined: the background chain of step i may still run under the object kernel of step i + 1 -- both chains stay
+        # in order on their own streams; timed() synchronises the device before it reads the clock)
         self.iteration = otrain.ShardedIteration(self.obj_loop, self.bg_loop, overlap=args.overlap, resident=True,
-                                                 device=dev)
+                                                 device=dev, pipelined=args.pipelined)
 
     def step(self, i, mode):
         self.obj_loop.bf16 = mode

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define OBJNERF_ABI_VERSION 6
+#define OBJNERF_ABI_VERSION 7
 
 #define OBJNERF_OK 0
 #define OBJNERF_EINVAL (-22)       /* bad shape / null pointer / unsupported size        */
@@ -132,6 +132,17 @@ typedef struct objnerf_kf_store {
   const uint8_t* rgbs; const float* depth; const float* t_wc; const float* bbox;
 } objnerf_kf_store;
 int objnerf_sample_rays_stacked(const objnerf_sample_args* a, int32_t K, const objnerf_kf_store* table, void* stream);
+
+/* A4 alone (ABI 7): sceneObject.sample_3d_points(sampled_rgbs, sampled_depth, origins, dirs_w) (vmap.py:456-554) on
+ * pixels the caller has already gathered: sampled_rgbs [n_frames][n_px][4] u8 (rgb + state, vmap.py:421),
+ * sampled_depth [n_frames][n_px], origins [n_frames][3], dirs_w [n_frames][n_px][3] (utils.origin_dirs_W).  Of `a` the
+ * scalars n_frames, n_px, n_cam2surf, n_bins, surface_eps, stop_eps, min_bound, obj_center, obj_index, seed, draw, the
+ * draws u / g (both or neither: neither = the seeded form) and the outputs out_rgb, out_depth, out_valid, out_labels,
+ * out_z, out_pts (or out_origins + out_dirs [n][3]) and max_depth_ws (1 + 6 n floats) are used; everything that
+ * describes the keyframe store is ignored.  sampled_partfeat is passed through by the host (the reference returns its
+ * argument, vmap.py:554). */
+int objnerf_sample_points(const objnerf_sample_args* a, const uint8_t* sampled_rgbs, const float* sampled_depth,
+                          const float* origins, const float* dirs_w, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * f-3  Frame ingestion (train.py:196-256 + sceneObject.__init__ / append_keyframe, vmap.py:29-257): one new frame is
@@ -339,11 +350,29 @@ int objnerf_label_counts(int32_t K, int32_t R, const uint8_t* labels, int32_t* c
 #define OBJNERF_TRAIN_LAYERWISE 2   /* mode bit: take the layer-wise (any width) path even for hidden 32 / S <= 64 --
                                      * a second, independent implementation of the same iteration; the tests use
                                      * it to cross-check the fused kernel at sizes no CPU oracle reaches. */
+#define OBJNERF_TRAIN_SELF_COUNTS 8   /* mode bit (ABI 7): the step derives the label statistics itself -- `counts` [K][2] and
+                                       * `flags` [2] are then OUTPUTS (n(label == 1), n(label != 2) per object; the two
+                                       * early-return flags of render_rays.py:89-94 over the K objects of THIS call), written
+                                       * before anything of the step reads them: no objnerf_label_counts launch by the caller.
+                                       * For an un-sharded batch only (under object sharding the flags span every rank's
+                                       * objects and the background's counts every rank's rays: reduce them and pass them in). */
 /* Helper streams + events for objnerf_train_step (see the preamble): create on the device that will run the steps,
  * destroy when no step using it is in flight.  The only entries of the library that create or free anything. */
 struct objnerf_context;
 int objnerf_context_create(struct objnerf_context** out);
 int objnerf_context_destroy(struct objnerf_context* ctx);
+
+/* ABI 7 -- the optimiser step of the iteration (train.py:472-473: optimiser.step() right after loss.backward()) inside
+ * objnerf_train_step: the launch that reduces the partial gradients applies torch.optim.AdamW to the element it has
+ * just summed (objnerf_adamw_step_flags' arithmetic, the same flag-dependent skipping and per-group step counters), so
+ * an iteration has no separate optimiser launch and the gradient is not read back from HBM.  `grads` is still written.
+ * group_steps / bank as in objnerf_adamw_step_flags (the caller alternates `bank`).  Tensors that receive no gradient
+ * in the call's configuration (the feature branch without gt_feat) are skipped like a None .grad. */
+typedef struct objnerf_adamw_args {
+  float* exp_avg; float* exp_avg_sq;      /* [K][p_stride] like params */
+  int32_t* group_steps; int32_t bank; int32_t reserved;
+  float lr, beta1, beta2, eps, weight_decay, reserved_f;
+} objnerf_adamw_args;
 
 typedef struct objnerf_train_args {
   int32_t K, R, S, mode;
@@ -369,6 +398,9 @@ typedef struct objnerf_train_args {
                           * reference's column order) -- the kernel never materialises them otherwise, so this is the
                           * only way to compare its positional encoding with fixture G1.  Every other path refuses it
                           * (OBJNERF_ENOTSUP): their embedding is objnerf_embed's output. */
+  /* ABI 7 */
+  const objnerf_adamw_args* optim;   /* NULL: gradients only.  Else `params` (declared const for the gradient-only
+                          * form) is UPDATED in place by the step's last launch, after every kernel that reads it. */
 } objnerf_train_args;
 size_t objnerf_train_workspace_bytes(const objnerf_net* net, int32_t K, int32_t R, int32_t S,
                                      int32_t with_feat);

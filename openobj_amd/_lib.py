@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OBJNERF_LIB") or os.path.join(_HERE, "csrc", "libobjnerf_hip.so")   # OBJNERF_LIB: diagnostic builds
 
 OBJNERF_N_TENSORS = 19
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class ObjnerfError(RuntimeError):
@@ -71,6 +71,14 @@ class LossArgs(C.Structure):
 
 
 TRAIN_BF16 = 1       # objnerf_train_args.mode bit (OBJNERF_TRAIN_BF16)
+TRAIN_SELF_COUNTS = 8    # (OBJNERF_TRAIN_SELF_COUNTS)
+
+
+class AdamWArgs(C.Structure):
+    _fields_ = [("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("group_steps", C.c_void_p),
+                ("bank", C.c_int32), ("reserved", C.c_int32),
+                ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("weight_decay", C.c_float), ("reserved_f", C.c_float)]
 
 
 class TrainArgs(C.Structure):
@@ -84,7 +92,8 @@ class TrainArgs(C.Structure):
                 ("counts", C.c_void_p), ("flags", C.c_void_p),
                 ("grads", C.c_void_p), ("loss_terms", C.c_void_p), ("status", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
-                ("relu_masks", C.c_void_p), ("context", C.c_void_p), ("emb_debug", C.c_void_p)]
+                ("relu_masks", C.c_void_p), ("context", C.c_void_p), ("emb_debug", C.c_void_p),
+                ("optim", C.c_void_p)]
 
 
 # name -> (restype, argtypes); every symbol include/objnerf_hip.h declares
@@ -97,6 +106,7 @@ SIGNATURES = {
                                     C.c_void_p, C.c_void_p]),
     "objnerf_sample_rays": (C.c_int, [C.POINTER(SampleArgs), C.c_void_p]),
     "objnerf_sample_rays_stacked": (C.c_int, [C.POINTER(SampleArgs), C.c_int32, C.c_void_p, C.c_void_p]),
+    "objnerf_sample_points": (C.c_int, [C.POINTER(SampleArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "objnerf_ingest_frame": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                        C.c_void_p, C.c_void_p]),
     "objnerf_box_rays": (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -421,8 +421,10 @@ __global__ __launch_bounds__(NTHR) void V2_KERNEL(const TrainDev a) {
   const float inv_scale = 1.0f / a.scale[k];
   const int R = a.R;
   const float n1 = (float)a.counts[2 * k], n2 = (float)a.counts[2 * k + 1];
-  const float inv1 = a.flags[0] ? 0.0f : 1.0f / (n1 + 1e-10f);
-  const float inv2 = a.flags[1] ? 0.0f : 1.0f / (n2 + 1e-10f);
+  int bflag0, bflag1;
+  batch_flags(a, bflag0, bflag1);
+  const float inv1 = bflag0 ? 0.0f : 1.0f / (n1 + 1e-10f);
+  const float inv2 = bflag1 ? 0.0f : 1.0f / (n2 + 1e-10f);
 
   WAcc acc;
 #pragma unroll

@@ -11,11 +11,20 @@ struct LossHoisted {
 };
 // loss_part: NULL or K * R * 4 floats of scratch -> bit-reproducible per-object loss terms (no float atomics)
 int step_batch_loss_impl(const objnerf_loss_args* a, const LossHoisted* hz, void* stream, float* loss_part);
+// objnerf_adamw_step_flags with the entries [ng_lo, ng_hi) skipped like has_grad == 0 (no byte mask needed)
+int adamw_flags_range(int32_t K, int64_t P, int64_t p_stride, float* params, const float* grads, float* exp_avg,
+                      float* exp_avg_sq, const uint8_t* has_grad, const int32_t* flags, int32_t* group_steps, int32_t bank,
+                      int64_t colour_lo, int64_t feature_lo, int64_t feature_hi, int64_t ng_lo, int64_t ng_hi, float lr,
+                      float beta1, float beta2, float eps, float weight_decay, void* stream);
+// counts [K][2] alone (one workgroup per object; no flags, no zero fill)
+int label_counts_only(int32_t K, int32_t R, const uint8_t* labels, int32_t* counts, void* stream);
 }  // namespace objmisc
 
 namespace objgen {
 size_t train_workspace_bytes(const objnerf_net* net, int K, int R, int S, int feat, int sixteen = 0);
-int train_step(const objnerf_net* net, const objnerf_train_args* a, void* stream);
+// done (optional): bit 0 = the call derived counts / flags itself (OBJNERF_TRAIN_SELF_COUNTS), bit 1 = the call applied
+// a->optim; what is not reported is left to the caller (objnerf_train_step)
+int train_step(const objnerf_net* net, const objnerf_train_args* a, void* stream, int* done = nullptr);
 // the batched fp32 MFMA GEMM of this path, for the feature-head kernels of objnerf_train.hip:
 //   C[z][m][n] (+)= sum_k A(z; m,k) B(z; k,n), element strides (sam, sak), (sbk, sbn), (scm, scn), batch strides bs*
 void feat_gram(void* stream, int K, const float* params, long p_stride, int off_w, int off_b, int C, int Hh, float* gram,

@@ -721,6 +721,9 @@ struct GemmEnv {
   float* next_part = nullptr;       // Gemm::part / rs_part of the next gemm(E, ) call
   float* next_rs_part = nullptr;
   RedGroup* red_group = nullptr;    // non-null: reductions are collected (grouped launch)
+  int max_slices = 0;               // > 0: wgrad(E, ) cuts the sample axis into at most this many split-K slices
+  bool need_parts = false;          // wgrad(E, ): the slab form is required (the gradient arena is not zero-filled)
+  bool parts_failed = false;        // ... and the scratch did not hold it
   bool in_act16(const void* p) const {
     return (act16_lo && (const char*)p >= act16_lo && (const char*)p < act16_hi) ||
            (grad16_lo && (const char*)p >= grad16_lo && (const char*)p < grad16_hi);
@@ -761,11 +764,23 @@ struct RedItem {
   int M, N, sk, batch;
   long scm, bsc, bsrs;
 };
+// Optional tail of the step's reduction launch (the one-launch small-batch iteration, objnerf_small_body.h): the block
+// after the last item's sums the per-workgroup loss terms in workgroup order and WRITES the status word
+// (loss_total_kernel's job), and -- with params set -- every thread that has just summed a gradient element applies
+// torch.optim.AdamW to it (adamw_dyn_kernel's arithmetic, objnerf_misc.hip; the flag-dependent skipping and the
+// per-group step counters included), so the iteration has no optimiser launch and the gradient is not read back.
+struct RedTail {
+  const float* loss_part = nullptr; int loss_blocks, K; float* loss_terms; int* status;      // loss_part == NULL: no tail
+  float* params = nullptr; const float* grads; float* m; float* v; const int* flags; int* steps; int bank;   // params == NULL: no AdamW
+  long p_stride, lo1, lo2, hi2;
+  double lr, b1, b2, wd; float eps;
+};
 struct RedGroup {
   static constexpr int MAXG = 16;        // (>= the GEMM group's capacity + head sums + d B: a step's reductions in ONE launch)
   int count;
   int beg[MAXG + 1];      // first block of each item
   RedItem it[MAXG];
+  RedTail tail;
 };
 // one thread per output (m, n) of a batch entry (+ one per row sum): adds the sk slices in slice order
 __global__ __launch_bounds__(256) void reduce_parts_kernel(const RedGroup gr) {
@@ -773,6 +788,46 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(const RedGroup gr) {
   // (coalesced: lanes along the outputs; 16 loads in flight), the four quarter sums meet in LDS and are added in wave
   // order -- a fixed association, so the result is bit-reproducible
   __shared__ float quarter[4][64];
+  __shared__ float s_step_size[3], s_bc2_sqrt[3];
+  __shared__ int s_active[3];
+  const RedTail& tl = gr.tail;
+  const bool tail_block = (int)blockIdx.x == gr.beg[gr.count];      // (only launched when the tail is set)
+  if (tl.params && threadIdx.x < 3) {
+    const int g = threadIdx.x;
+    const bool f0 = tl.flags[0] != 0, f1 = tl.flags[1] != 0;
+    s_active[g] = g == 0 ? !(f0 && f1) : !f0;
+    const int old = tl.steps[3 * tl.bank + g];
+    const double st = (double)(old + 1);
+    s_step_size[g] = (float)(tl.lr / (1.0 - pow(tl.b1, st)));
+    s_bc2_sqrt[g] = (float)sqrt(1.0 - pow(tl.b2, st));
+    if (tail_block) tl.steps[3 * (1 - tl.bank) + g] = old + (s_active[g] ? 1 : 0);
+  }
+  if (tail_block) {
+    // the objects' loss terms from the workgroups' partial sums, in workgroup order; status as loss_total_kernel
+    __shared__ int s_bad;
+    if (threadIdx.x == 0) s_bad = 0;
+    __syncthreads();
+    int bad = 0;
+    // a wave per (object, term): lane l adds partials l, l + 64, .. in order, then the lanes meet in a fixed butterfly --
+    // one association for every run (bit-reproducible), 64 loads in flight instead of a chain of `loss_blocks` latencies
+    // (1200 workgroups at the benchmark shape: 120 us as one thread per term)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int e = wv; e < 4 * tl.K; e += 4) {
+      const float* p = tl.loss_part + (long)(e >> 2) * tl.loss_blocks * 4 + (e & 3);
+      float v = 0.f;
+      for (int b = lane; b < tl.loss_blocks; b += 64) v += p[4 * b];
+      for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+      if (lane == 0) {
+        tl.loss_terms[e] = v;
+        if (v > 100000.f) bad |= 1;                 // render_rays.py:109-111
+        if (!(fabsf(v) <= 3.0e38f)) bad |= 2;       // NaN / Inf
+      }
+    }
+    if (bad) atomicOr(&s_bad, bad);
+    __syncthreads();
+    if (threadIdx.x == 0 && tl.status) *tl.status = s_bad;
+    return;
+  }
   int i = 0;
   while (i + 1 < gr.count && (int)blockIdx.x >= gr.beg[i + 1]) ++i;
   const RedItem& r = gr.it[i];
@@ -801,11 +856,31 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(const RedGroup gr) {
   __syncthreads();
   if (w == 0 && live) {
     const float sum = ((quarter[0][lane] + quarter[1][lane]) + quarter[2][lane]) + quarter[3][lane];
+    float* dst;
     if (is_c) {
       const long m = q / r.N, n = q - m * r.N;
-      r.C[z * r.bsc + m * r.scm + n] = sum;
+      dst = r.C + z * r.bsc + m * r.scm + n;
     } else {
-      r.rowsum[z * r.bsrs + (q - per)] = sum;
+      dst = r.rowsum + z * r.bsrs + (q - per);
+    }
+    *dst = sum;
+    if (tl.params) {
+      const long idx = dst - tl.grads;                       // position in the gradient arena = in params / moments
+      const long pi = idx % tl.p_stride;
+      const int g = (pi >= tl.lo1 && pi < tl.lo2) ? 1 : ((pi >= tl.lo2 && pi < tl.hi2) ? 2 : 0);
+      if (s_active[g]) {
+        const float decay = (float)(1.0 - tl.lr * tl.wd), w1 = (float)(1.0 - tl.b1), w2 = (float)(1.0 - tl.b2);
+        const float beta2 = (float)tl.b2;
+        float p = tl.params[idx] * decay;
+        const float mo = tl.m[idx];
+        const float mn = mo + w1 * (sum - mo);
+        const float vn = tl.v[idx] * beta2 + (w2 * sum) * sum;
+        const float denom = sqrtf(vn) / s_bc2_sqrt[g] + tl.eps;
+        p = p + (-s_step_size[g]) * (mn / denom);
+        tl.params[idx] = p;
+        tl.m[idx] = mn;
+        tl.v[idx] = vn;
+      }
     }
   }
 }
@@ -819,7 +894,8 @@ static void red_append(RedGroup& rg, const RedItem& r) {
   ++rg.count;
 }
 static void launch_reductions(hipStream_t st, RedGroup& rg) {
-  if (rg.count) hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)rg.beg[rg.count]), dim3(256), 0, st, rg);
+  const int tail = rg.tail.loss_part ? 1 : 0;
+  if (rg.count) hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)(rg.beg[rg.count] + tail)), dim3(256), 0, st, rg);
   rg.count = 0;
 }
 // the layer GEMMs the resident-panel kernel takes (16-bit modes, rows k-contiguous, contraction <= 352, N <= 256)
@@ -930,7 +1006,8 @@ static void gemm(GemmEnv& E, hipStream_t st, int batch, int M, int N, int Kd, co
 static void wgrad(GemmEnv& E, hipStream_t st, int batch, int M, int N, long n, const float* A, long sam, long sak, long bsa,
                   const float* B, long sbk, long sbn, long bsb, float* C, long scm, long bsc,
                   float* bias_grad = nullptr) {
-  const int sk = wgrad_slices(batch, M, N, n);
+  int sk = wgrad_slices(batch, M, N, n);
+  if (E.max_slices > 0 && sk > E.max_slices) sk = E.max_slices;
 #ifndef OBJ_WGRAD_ATOMICS
   // deterministic form: every slice stores its partial tile; an ordered reduction follows
   const int skd = sk;
@@ -953,6 +1030,7 @@ static void wgrad(GemmEnv& E, hipStream_t st, int batch, int M, int N, long n, c
     return;
   }
 #endif
+  if (E.need_parts) { E.parts_failed = true; return; }
   gemm(E, st, batch, M, N, (int)n, A, sam, sak, bsa, B, sbk, sbn, bsb, C, scm, 1, bsc, false, nullptr, 0, false, nullptr, 0,
        0, 0, sk, bias_grad, bsc);
 }
@@ -1469,6 +1547,8 @@ static void launch_fwd_small(hipStream_t st, const FwdSmall& f, int K, bool bf) 
   else hipLaunchKernelGGL((mlp_fwd_small_kernel<RT, false>), grid, dim3(512), fs_lds_bytes<RT>(), st, f);
 }
 
+#include "objnerf_small_body.h"
+
 // row tiles per workgroup: the smallest RT for which K * ceil(n / (16 RT)) workgroups fit the chip in one round;
 // 0 = not a small batch
 static int small_batch_rt(const GemmEnv& E, int H, long n, int K) {
@@ -1963,7 +2043,11 @@ __global__ void form_points_kernel(long total, int S, const float* origins, cons
   for (int x = 0; x < 3; ++x) pts[i * 3 + x] = (origins[ray * 3 + x] + dirs[ray * 3 + x] * zz) - centre;
 }
 
-int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* stream) {
+// forward declaration: the one-launch iteration (after the workspace carve below)
+static int train_step_small(const objnerf_net* net, const objnerf_train_args* a, hipStream_t st, GemmEnv& E, const WS& w,
+                            const int64_t* off, bool bf, int* done);
+
+int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* stream, int* done) {
   objnerf_train_args a_local = *a_in;
   const objnerf_train_args* a = &a_local;
   GemmEnv E;                                   // this call's GEMM environment (nothing outlives the call)
@@ -1981,6 +2065,23 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
   if (a->workspace_bytes < w.bytes) return OBJNERF_EINVAL;
   E.parts = w.parts; E.parts_cap = w.parts_floats; E.parts_off = 0;
   E.packb = w.packb; E.packb_entries = w.packb ? K : 0;
+  // ---- small batches of the hidden-128 network without the feature loss: ONE forward + loss + backward launch, the
+  // grouped weight gradients, one reduction launch (objnerf_small_body.h)
+  {
+    const int S = a->S;
+    const int rpw = S > 0 && S <= 64 ? 80 / S : 0;
+    const long nwg = rpw ? ((long)a->R + rpw - 1) / rpw : 0;
+#ifndef OBJ_NO_SMALL_FUSED
+    if (H == FS_H && !feat && S >= 4 && S <= 64 && (long)K * nwg <= 1536 && !half_acts && K <= 65535 &&
+        !(a->mode & OBJNERF_TRAIN_LAYERWISE && K > 8))
+      return train_step_small(net, a, st, E, w, off, E.operands == 1, done);
+#endif
+  }
+  if (a->mode & OBJNERF_TRAIN_SELF_COUNTS) {
+    const int rc0 = objnerf_label_counts(K, a->R, a->labels, const_cast<int32_t*>(a->counts), const_cast<int32_t*>(a->flags),
+                                         stream);
+    if (rc0) return rc0;
+  }
   RedGroup step_red;                 // small-batch path: every ordered reduction of the step in ONE launch, after the join
   step_red.count = 0;
   if (!a->pts) {
@@ -2301,6 +2402,117 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
     (void)hipStreamWaitEvent(st, sd.done_all[i], 0);
   }
   launch_reductions(st, step_red);
+  if (hipGetLastError() != hipSuccess) return OBJNERF_ELAUNCH;
+  return OBJNERF_OK;
+}
+
+// The one-launch small-batch iteration: train_small_kernel -> the seven weight-gradient GEMMs as ONE grouped launch ->
+// ONE reduction launch (weight-gradient slices, head / d B / loss partials, status, optionally AdamW).  Everything on
+// the caller's stream: three dependent launches need no helper stream and no events.
+static int train_step_small(const objnerf_net* net, const objnerf_train_args* a, hipStream_t st, GemmEnv& E, const WS& w,
+                            const int64_t* off, bool bf, int* done) {
+  const int H = net->hidden, K = a->K, S = a->S;
+  const long n = (long)a->R * S, nH = n * H, ps = a->p_stride;
+  const int rpw = 80 / S;
+  const int nwg = (int)(((long)a->R + rpw - 1) / rpw);
+  const int E1 = OBJ_E1, E2 = OBJ_E2, EM = OBJ_EMB;
+  const float* P = a->params;
+  float* G = a->grads;
+  const bool self_counts = (a->mode & OBJNERF_TRAIN_SELF_COUNTS) != 0;
+  if (self_counts && K > 1) {        // several objects: the cross-object flags need every object's labels (one small launch)
+    const int rc0 = objnerf_label_counts(K, a->R, a->labels, const_cast<int32_t*>(a->counts), const_cast<int32_t*>(a->flags),
+                                         (void*)st);
+    if (rc0) return rc0;
+  }
+  SmallFused f;
+  f.K = K; f.R = a->R; f.S = S; f.rpw = rpw;
+  f.params = P; f.ps = ps; f.scale = a->scale;
+  f.pts = a->pts; f.origins = a->origins; f.dirs = a->dirs; f.z = a->z; f.centre = a->obj_center;
+  f.gt_depth = a->gt_depth; f.gt_rgb = a->gt_rgb; f.labels = a->labels;
+  f.counts = const_cast<int*>(a->counts); f.flags = const_cast<int*>(a->flags); f.self_counts = (self_counts && K == 1) ? 1 : 0;
+  f.cs = a->color_scaling; f.os = a->opacity_scaling;
+  f.emb = w.emb; f.h1 = w.h1; f.h2 = w.h2; f.h3 = w.h3; f.h4 = w.h4; f.hc = w.hc;
+  f.d_hc = w.dA; f.d_h4 = w.dB_; f.d_h3 = w.dC; f.d_h2 = w.dD; f.d_h1 = w.dE;
+  // per-workgroup partials live in workspace regions this path does not use otherwise (d_emb: K n 129 floats, dhead:
+  // K n 4, loss_part: K R 4): nwg <= R and S >= 4 make them fit
+  float* hp = w.d_emb;
+  f.partA = hp; hp += (size_t)K * nwg * H;
+  f.partW = hp; hp += (size_t)K * nwg * 3 * H;
+  f.rsA = hp; hp += (size_t)K * nwg;
+  f.rsW = hp;
+  f.pe_part = w.dhead;
+  f.loss_part = w.loss_part;
+  f.o_in_w = (int)off[0]; f.o_in_b = (int)off[1]; f.o_m1_w = (int)off[2]; f.o_m1_b = (int)off[3];
+  f.o_cat_w = (int)off[4]; f.o_cat_b = (int)off[5]; f.o_m2_w = (int)off[6]; f.o_m2_b = (int)off[7];
+  f.o_a_w = (int)off[8]; f.o_a_b = (int)off[9]; f.o_cl_w = (int)off[10]; f.o_cl_b = (int)off[11];
+  f.o_oc_w = (int)off[12]; f.o_oc_b = (int)off[13]; f.o_B = (int)off[18];
+  if (rpw * S <= 64) launch_train_small<4>(st, f, nwg, bf);
+  else launch_train_small<5>(st, f, nwg, bf);
+  if (hipGetLastError() != hipSuccess) return OBJNERF_ELAUNCH;
+  if (a->relu_masks) {       // test hook: the ReLU branch bits of this iteration, from the stored activations
+    const float* acts[5] = {w.h1, w.h2, w.h3, w.h4, w.hc};
+    const long nb = (long)K * n * (H / 8);
+    for (int l = 0; l < 5; ++l)
+      hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, nb, H, acts[l], a->relu_masks, l, 0);
+  }
+  // ---- the step's reductions, collected: head partials, d B partials, the weight gradients' split-K slices
+  RedGroup red;
+  red.count = 0;
+  {
+    RedItem a0;
+    a0.part = f.partA; a0.rs_part = f.rsA; a0.C = G + off[8]; a0.rowsum = G + off[9];
+    a0.M = 1; a0.N = H; a0.sk = nwg; a0.batch = K; a0.scm = H; a0.bsc = ps; a0.bsrs = ps;
+    RedItem a1;
+    a1.part = f.partW; a1.rs_part = f.rsW; a1.C = G + off[12]; a1.rowsum = G + off[13];
+    a1.M = 3; a1.N = H; a1.sk = nwg; a1.batch = K; a1.scm = H; a1.bsc = ps; a1.bsrs = ps;
+    RedItem r;
+    r.part = f.pe_part; r.rs_part = nullptr; r.C = G + off[18]; r.rowsum = nullptr;
+    r.M = 1; r.N = 63; r.sk = nwg; r.batch = K; r.scm = 63; r.bsc = ps; r.bsrs = 0;
+    red_append(red, a0); red_append(red, a1); red_append(red, r);
+  }
+  E.operands = 0;                   // (the grouped launch picks its operand type through group16)
+  E.a_scale = 1.0f;
+  GemmGroup group;
+  group.count = 0;
+  E.group = &group;
+  E.group16 = bf;
+  E.red_group = &red;
+  E.need_parts = true;              // no zero-filled gradient arena here: the deterministic slab form or an error
+  // Split-K slices of the grouped launch: its seven GEMMs are ONE 128 x 128 tile each, so `slices` is also the number of
+  // workgroups per GEMM.  ~2 rounds of the chip (7 x 37 = 259 workgroups at least), at most ~1024 samples per slice
+  // beyond that: every slice writes its partial tile to HBM and the reduction reads it back -- 128 slices at the
+  // benchmark's 76 800 background samples were 48 MB each way for 0.4 MB of gradient (reduction 131 us).
+  {
+    long want = (n + 1023) / 1024;
+    if (want < 36) want = 36;
+    // whole rounds of the chip: 7 GEMMs x slices workgroups on num_cu compute units (75 slices = 525 workgroups left a
+    // third round for 13 of them: 260 us against 227)
+    const int cu = 256, ng = 7;
+    long rounds = (want * ng + cu / 2) / cu;
+    if (rounds < 1) rounds = 1;
+    E.max_slices = (int)(rounds * cu / ng);
+  }
+  wgrad(E, st, K, H, H, n, f.d_hc, 1, H, nH, w.h4, H, 1, nH, G + off[10], H + E2, ps, G + off[11]);
+  wgrad(E, st, K, H, E2, n, f.d_hc, 1, H, nH, w.emb + E1, EM, 1, n * EM, G + off[10] + H, H + E2, ps);
+  wgrad(E, st, K, H, H, n, f.d_h4, 1, H, nH, w.h3, H, 1, nH, G + off[6], H, ps, G + off[7]);
+  wgrad(E, st, K, H, H, n, f.d_h3, 1, H, nH, w.h2, H, 1, nH, G + off[4], H + E1, ps, G + off[5]);
+  wgrad(E, st, K, H, E1, n, f.d_h3, 1, H, nH, w.emb, EM, 1, n * EM, G + off[4] + H, H + E1, ps);
+  wgrad(E, st, K, H, H, n, f.d_h2, 1, H, nH, w.h1, H, 1, nH, G + off[2], H, ps, G + off[3]);
+  wgrad(E, st, K, H, E1, n, f.d_h1, 1, H, nH, w.emb, EM, 1, n * EM, G + off[0], E1, ps, G + off[1]);
+  if (E.parts_failed) return OBJNERF_EINVAL;
+  flush_group(E, st, group);
+  red.tail.loss_part = f.loss_part; red.tail.loss_blocks = nwg; red.tail.K = K; red.tail.loss_terms = a->loss_terms;
+  red.tail.status = a->status;
+  if (a->optim) {
+    const objnerf_adamw_args* o = a->optim;
+    RedTail& t = red.tail;
+    t.params = const_cast<float*>(a->params); t.grads = G; t.m = o->exp_avg; t.v = o->exp_avg_sq; t.flags = a->flags;
+    t.steps = o->group_steps; t.bank = o->bank; t.p_stride = ps;
+    t.lo1 = off[10]; t.lo2 = off[14]; t.hi2 = off[18];
+    t.lr = (double)o->lr; t.b1 = (double)o->beta1; t.b2 = (double)o->beta2; t.wd = (double)o->weight_decay; t.eps = o->eps;
+    if (done) *done |= 2;
+  }
+  launch_reductions(st, red);
   if (hipGetLastError() != hipSuccess) return OBJNERF_ELAUNCH;
   return OBJNERF_OK;
 }

@@ -129,6 +129,7 @@ __global__ void label_counts_kernel(int K, int R, const uint8_t* labels, int* co
     const int a = s1[0] + s1[1] + s1[2] + s1[3], b = s2[0] + s2[1] + s2[2] + s2[3];
     counts[2 * k] = a;
     counts[2 * k + 1] = b;
+    if (!flags) return;                 // (counts only: the consumer derives the flags, objnerf_train_common.h)
     if (K == 1) {                       // a single object owns the flags: no zero fill, no atomics
       flags[0] = a == 0;
       flags[1] = b == 0;
@@ -418,7 +419,7 @@ __global__ void adamw_kernel(long P, long p_stride, float* params, const float* 
 // [lo1, lo2), 2 = feature branch [lo2, hi2).
 __global__ void adamw_dyn_kernel(long P, long p_stride, float* params, const float* grads, float* m, float* v,
                                  const uint8_t* has_grad, const int* flags, int* steps, int bank, long lo1, long lo2,
-                                 long hi2, double lr, double b1, double b2, float eps, double wd) {
+                                 long hi2, double lr, double b1, double b2, float eps, double wd, long ng_lo, long ng_hi) {
   // step counters: two banks of three; this call READS bank `bank` and its first block WRITES the advanced counters to
   // the other one -- no second launch, and no block can see a counter of its own call already advanced
   __shared__ float s_step_size[3], s_bc2_sqrt[3];
@@ -435,7 +436,7 @@ __global__ void adamw_dyn_kernel(long P, long p_stride, float* params, const flo
   }
   __syncthreads();
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= P || (has_grad && !has_grad[i])) return;
+  if (i >= P || (has_grad && !has_grad[i]) || (i >= ng_lo && i < ng_hi)) return;
   const int g = (i >= lo1 && i < lo2) ? 1 : ((i >= lo2 && i < hi2) ? 2 : 0);
   if (!s_active[g]) return;
   const float decay = (float)(1.0 - lr * wd), w1 = (float)(1.0 - b1), w2 = (float)(1.0 - b2), beta2 = (float)b2;
@@ -710,6 +711,29 @@ __global__ void sample_place_kernel(const objnerf_sample_args a_, const objnerf_
   }
 }
 
+// sceneObject.sample_3d_points alone (vmap.py:456-554): the pixels are already gathered.  This pass puts them where
+// sample_place_kernel expects the gather pass's outputs: rgb / state split (:552-554), the batch depth maximum (:489),
+// the per-frame origin broadcast over the frame's rays (:548).
+__global__ void sample_prepare_kernel(const objnerf_sample_args a, const uint8_t* __restrict__ rgbs4,
+                                      const float* __restrict__ depth, const float* __restrict__ origins,
+                                      const float* __restrict__ dirs_w, float* origins_ws, float* dirs_ws) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = a.n_frames * a.n_px;
+  if (i >= n) return;
+  const uint8_t* px = rgbs4 + (long)i * 4;
+  a.out_rgb[i * 3] = px[0]; a.out_rgb[i * 3 + 1] = px[1]; a.out_rgb[i * 3 + 2] = px[2];
+  a.out_labels[i] = px[3];
+  const float d = depth[i];
+  a.out_depth[i] = d;
+  atomicMax((int*)a.max_depth_ws, __float_as_int(fmaxf(d, 0.0f)));
+  const int f = i / a.n_px;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    origins_ws[i * 3 + r] = origins[f * 3 + r];
+    dirs_ws[i * 3 + r] = dirs_w[i * 3 + r];
+  }
+}
+
 }  // namespace
 
 #define CHECK_LAUNCH() do { if (hipGetLastError() != hipSuccess) return OBJNERF_ELAUNCH; } while (0)
@@ -756,6 +780,30 @@ int step_batch_loss_impl(const objnerf_loss_args* a, const LossHoisted* hz, void
   hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(256), 0, st, a->K, a->loss_terms, a->color_scaling,
                      a->opacity_scaling, (a->pred_feat || hz) ? a->feat_scaling : 0.0f, a->total, a->status,
                      (const float*)loss_part, a->R / rb);
+  CHECK_LAUNCH();
+  return OBJNERF_OK;
+}
+int label_counts_only(int32_t K, int32_t R, const uint8_t* labels, int32_t* counts, void* stream) {
+  CLEAR_STALE();
+  if (K <= 0 || R <= 0 || !labels || !counts) return OBJNERF_EINVAL;
+  hipLaunchKernelGGL(label_counts_kernel, dim3(K), dim3(256), 0, (hipStream_t)stream, K, R, labels, counts, (int*)nullptr);
+  CHECK_LAUNCH();
+  return OBJNERF_OK;
+}
+int adamw_flags_range(int32_t K, int64_t P, int64_t p_stride, float* params, const float* grads, float* exp_avg,
+                      float* exp_avg_sq, const uint8_t* has_grad, const int32_t* flags, int32_t* group_steps, int32_t bank,
+                      int64_t colour_lo, int64_t feature_lo, int64_t feature_hi, int64_t ng_lo, int64_t ng_hi, float lr,
+                      float beta1, float beta2, float eps, float weight_decay, void* stream) {
+  CLEAR_STALE();
+  if (K <= 0 || P <= 0 || p_stride < P || !params || !grads || !exp_avg || !exp_avg_sq || !flags || !group_steps ||
+      (bank != 0 && bank != 1) ||
+      colour_lo > feature_lo || feature_lo > feature_hi || feature_hi > P)
+    return OBJNERF_EINVAL;
+  dim3 grid((unsigned)((P + 255) / 256), (unsigned)K);
+  hipLaunchKernelGGL(adamw_dyn_kernel, grid, dim3(256), 0, (hipStream_t)stream, (long)P, (long)p_stride, params, grads,
+                     exp_avg, exp_avg_sq, has_grad, flags, group_steps, (int)bank, (long)colour_lo, (long)feature_lo,
+                     (long)feature_hi, (double)lr, (double)beta1, (double)beta2, eps, (double)weight_decay, (long)ng_lo,
+                     (long)ng_hi);
   CHECK_LAUNCH();
   return OBJNERF_OK;
 }
@@ -895,17 +943,8 @@ int objnerf_adamw_step_flags(int32_t K, int64_t P, int64_t p_stride, float* para
                              float* exp_avg_sq, const uint8_t* has_grad, const int32_t* flags, int32_t* group_steps,
                              int32_t bank, int64_t colour_lo, int64_t feature_lo, int64_t feature_hi, float lr, float beta1,
                              float beta2, float eps, float weight_decay, void* stream) {
-  CLEAR_STALE();
-  if (K <= 0 || P <= 0 || p_stride < P || !params || !grads || !exp_avg || !exp_avg_sq || !flags || !group_steps ||
-      (bank != 0 && bank != 1) ||
-      colour_lo > feature_lo || feature_lo > feature_hi || feature_hi > P)
-    return OBJNERF_EINVAL;
-  dim3 grid((unsigned)((P + 255) / 256), (unsigned)K);
-  hipLaunchKernelGGL(adamw_dyn_kernel, grid, dim3(256), 0, (hipStream_t)stream, (long)P, (long)p_stride, params, grads,
-                     exp_avg, exp_avg_sq, has_grad, flags, group_steps, (int)bank, (long)colour_lo, (long)feature_lo,
-                     (long)feature_hi, (double)lr, (double)beta1, (double)beta2, eps, (double)weight_decay);
-  CHECK_LAUNCH();
-  return OBJNERF_OK;
+  return objmisc::adamw_flags_range(K, P, p_stride, params, grads, exp_avg, exp_avg_sq, has_grad, flags, group_steps, bank,
+                                    colour_lo, feature_lo, feature_hi, P, P, lr, beta1, beta2, eps, weight_decay, stream);
 }
 
 int objnerf_rays_dirs(int32_t W, int32_t H, float fx, float fy, float cx, float cy, float* out, void* stream) {
@@ -964,6 +1003,31 @@ int objnerf_sample_rays(const objnerf_sample_args* a, void* stream) {
   hipLaunchKernelGGL(sample_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, st, *a, (const objnerf_kf_store*)nullptr);
   CHECK_LAUNCH();
   hipLaunchKernelGGL(sample_place_kernel, dim3((n + 255) / 256), dim3(256), 0, st, *a, (const objnerf_kf_store*)nullptr);
+  CHECK_LAUNCH();
+  return OBJNERF_OK;
+}
+
+int objnerf_sample_points(const objnerf_sample_args* a, const uint8_t* sampled_rgbs, const float* sampled_depth,
+                          const float* origins, const float* dirs_w, void* stream) {
+  CLEAR_STALE();
+  if (!a || !sampled_rgbs || !sampled_depth || !origins || !dirs_w) return OBJNERF_EINVAL;
+  if ((a->u != nullptr) != (a->g != nullptr)) return OBJNERF_EINVAL;
+  if (!a->out_pts && (!a->out_origins || !a->out_dirs)) return OBJNERF_EINVAL;
+  if ((a->out_origins != nullptr) != (a->out_dirs != nullptr)) return OBJNERF_EINVAL;
+  if (!(a->out_rgb && a->out_depth && a->out_valid && a->out_labels && a->out_z && a->max_depth_ws && a->n_frames > 0 &&
+        a->n_px > 0 && a->n_cam2surf > 0 && a->n_bins > 0))
+    return OBJNERF_EINVAL;
+  const int n = a->n_frames * a->n_px;
+  hipStream_t st = (hipStream_t)stream;
+  objnerf_sample_args b = *a;
+  b.kf_meta = nullptr;                    // (the random stream is a->obj_index; there is no keyframe draw here)
+  float* origins_ws = b.out_origins ? b.out_origins : b.max_depth_ws + 1;
+  float* dirs_ws = b.out_origins ? b.out_dirs : b.max_depth_ws + 1 + (size_t)n * 3;
+  (void)hipMemsetAsync(b.max_depth_ws, 0, sizeof(float), st);
+  hipLaunchKernelGGL(sample_prepare_kernel, dim3((n + 255) / 256), dim3(256), 0, st, b, sampled_rgbs, sampled_depth, origins,
+                     dirs_w, origins_ws, dirs_ws);
+  CHECK_LAUNCH();
+  hipLaunchKernelGGL(sample_place_kernel, dim3((n + 255) / 256), dim3(256), 0, st, b, (const objnerf_kf_store*)nullptr);
   CHECK_LAUNCH();
   return OBJNERF_OK;
 }

@@ -121,8 +121,10 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
   const float scale = a.scale[k];
   const int S = a.S, R = a.R, TR = a.TR;
   const float n1 = (float)a.counts[2 * k], n2 = (float)a.counts[2 * k + 1];
-  const float inv1 = a.flags[0] ? 0.0f : 1.0f / (n1 + 1e-10f);
-  const float inv2 = a.flags[1] ? 0.0f : 1.0f / (n2 + 1e-10f);
+  int bflag0, bflag1;
+  batch_flags(a, bflag0, bflag1);
+  const float inv1 = bflag0 ? 0.0f : 1.0f / (n1 + 1e-10f);
+  const float inv2 = bflag1 ? 0.0f : 1.0f / (n2 + 1e-10f);
 
   // persistent gradient accumulators
   f32x4 accA0 = zero4(), accA1 = zero4(), accB0 = zero4(), accB1 = zero4(), accC0 = zero4(), accC1 = zero4();
@@ -802,29 +804,108 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// grads[k][i] = sum_g slab[k][g][i] for entries with has_grad; loss_terms[k][:] = sum_g loss_part.
+// The step's last launch: grads[k][i] = sum_g slab[k][g][i] for every entry this configuration differentiates,
+// loss_terms[k][:] = sum_g loss_part, the status word -- and, with an optimiser attached (objnerf_train_args.optim),
+// torch.optim.AdamW on the element just summed (adamw_dyn_kernel's arithmetic; objnerf_misc.hip).
+// No byte mask and no zero fill: [ng_lo, ng_hi) are the entries WITHOUT a gradient (the feature branch when gt_feat is
+// NULL: .grad stays None, train.py:435-438), [ext_lo, ext_hi) the entries whose gradient another kernel has already
+// written to `grads` (the 512-d head: feat_finish_kernel).  Block (0, 0) also sums the loss terms of ALL objects and
+// WRITES the status word (bit 0: a term above 1e5, render_rays.py:109-111; bit 1: a term that is not finite).
 // flat_nwg > 0 (objnerf_train_common.h): object k's partial slabs are those of the workgroups whose share touches it,
 // slot 0 .. cnt - 1 of its Gs
-__global__ void finalize_kernel(const float* slab, const float* loss_part, int K, int G, long P, long slab_stride,
-                                long p_stride, const uint8_t* has_grad, float* grads, float* loss_terms, int* status,
-                                int flat_nwg, int NT, int Gs) {
+struct FinalizeArgs {
+  const float* slab; const float* loss_part;
+  int K, G; long P, slab_stride, p_stride;
+  long ng_lo, ng_hi, ext_lo, ext_hi;
+  float* grads; float* loss_terms; int* status;
+  int flat_nwg, NT, Gs;
+  // AdamW (params == NULL: gradients only)
+  float* params; float* m; float* v; const int* flags; int* steps; int bank;
+  long lo1, lo2, hi2;
+  double lr, b1, b2, wd; float eps;
+  const int* counts_in; int* flags_out;      // OBJNERF_TRAIN_SELF_COUNTS: derive the flags from counts [K][2], publish them
+};
+__global__ __launch_bounds__(256) void finalize_kernel(const FinalizeArgs a) {
   const int k = blockIdx.y;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (flat_nwg) {
-    const long T = (long)K * NT;
-    G = flat_wg_of(T, flat_nwg, (long)(k + 1) * NT - 1) - flat_wg_of(T, flat_nwg, (long)k * NT) + 1;
+  __shared__ float s_step_size[3], s_bc2_sqrt[3];
+  __shared__ int s_active[3];
+  __shared__ int s_bad;
+  const bool first = blockIdx.x == 0 && blockIdx.y == 0;
+  if (a.counts_in && first && threadIdx.x == 64) {     // derived flags: published for the host / later launches
+    int e0 = 0, e1 = 0;
+    for (int kk = 0; kk < a.K; ++kk) { e0 |= a.counts_in[2 * kk] == 0; e1 |= a.counts_in[2 * kk + 1] == 0; }
+    a.flags_out[0] = e0; a.flags_out[1] = e1;
   }
-  const int stride = flat_nwg ? Gs : G;
-  if (i < P && has_grad[i]) {
-    float s = 0.f;
-    for (int g = 0; g < G; ++g) s += slab[((long)k * stride + g) * slab_stride + i];
-    grads[(long)k * p_stride + i] = s;
+  if (a.params && threadIdx.x < 3) {          // (as adamw_dyn_kernel: read bank `bank`, the first block writes the other)
+    const int g = threadIdx.x;
+    bool f0, f1;
+    if (a.counts_in) {
+      int e0 = 0, e1 = 0;
+      for (int kk = 0; kk < a.K; ++kk) { e0 |= a.counts_in[2 * kk] == 0; e1 |= a.counts_in[2 * kk + 1] == 0; }
+      f0 = e0 != 0; f1 = e1 != 0;
+    } else {
+      f0 = a.flags[0] != 0; f1 = a.flags[1] != 0;
+    }
+    s_active[g] = g == 0 ? !(f0 && f1) : !f0;
+    const int old = a.steps[3 * a.bank + g];
+    const double st = (double)(old + 1);
+    s_step_size[g] = (float)(a.lr / (1.0 - pow(a.b1, st)));
+    s_bc2_sqrt[g] = (float)sqrt(1.0 - pow(a.b2, st));
+    if (first) a.steps[3 * (1 - a.bank) + g] = old + (s_active[g] ? 1 : 0);
   }
-  if (blockIdx.x == 0 && threadIdx.x < 4) {
-    float s = 0.f;
-    for (int g = 0; g < G; ++g) s += loss_part[((long)k * stride + g) * 4 + threadIdx.x];
-    loss_terms[k * 4 + threadIdx.x] = s;
-    if (s > 100000.0f) atomicOr(status, 1);       // render_rays.py:109-111
+  if (first && threadIdx.x == 0) s_bad = 0;
+  if (a.params || first) __syncthreads();
+  int G = a.G;
+  if (a.flat_nwg) {
+    const long T = (long)a.K * a.NT;
+    G = flat_wg_of(T, a.flat_nwg, (long)(k + 1) * a.NT - 1) - flat_wg_of(T, a.flat_nwg, (long)k * a.NT) + 1;
+  }
+  const int stride = a.flat_nwg ? a.Gs : a.G;
+  if (i < a.P && !(i >= a.ng_lo && i < a.ng_hi)) {
+    const long idx = (long)k * a.p_stride + i;
+    float s;
+    if (i >= a.ext_lo && i < a.ext_hi) {
+      s = a.grads[idx];
+    } else {
+      s = 0.f;
+      for (int g = 0; g < G; ++g) s += a.slab[((long)k * stride + g) * a.slab_stride + i];
+      a.grads[idx] = s;
+    }
+    if (a.params) {
+      const int g = (i >= a.lo1 && i < a.lo2) ? 1 : ((i >= a.lo2 && i < a.hi2) ? 2 : 0);
+      if (s_active[g]) {
+        const float decay = (float)(1.0 - a.lr * a.wd), w1 = (float)(1.0 - a.b1), w2 = (float)(1.0 - a.b2), beta2 = (float)a.b2;
+        float p = a.params[idx] * decay;
+        const float mo = a.m[idx];
+        const float mn = mo + w1 * (s - mo);
+        const float vn = a.v[idx] * beta2 + (w2 * s) * s;
+        const float denom = sqrtf(vn) / s_bc2_sqrt[g] + a.eps;
+        p = p + (-s_step_size[g]) * (mn / denom);
+        a.params[idx] = p;
+        a.m[idx] = mn;
+        a.v[idx] = vn;
+      }
+    }
+  }
+  if (first) {
+    int bad = 0;
+    for (int e = threadIdx.x; e < 4 * a.K; e += blockDim.x) {
+      const int kk = e >> 2;
+      int Gk = a.G;
+      if (a.flat_nwg) {
+        const long T = (long)a.K * a.NT;
+        Gk = flat_wg_of(T, a.flat_nwg, (long)(kk + 1) * a.NT - 1) - flat_wg_of(T, a.flat_nwg, (long)kk * a.NT) + 1;
+      }
+      float sl = 0.f;
+      for (int g = 0; g < Gk; ++g) sl += a.loss_part[((long)kk * stride + g) * 4 + (e & 3)];
+      a.loss_terms[e] = sl;
+      if (sl > 100000.0f) bad |= 1;          // render_rays.py:109-111
+      if (!(fabsf(sl) <= 3.0e38f)) bad |= 2;   // NaN / Inf (the reference carries on with NaN parameters)
+    }
+    if (bad) atomicOr(&s_bad, bad);
+    __syncthreads();
+    if (threadIdx.x == 0) *a.status = s_bad;
   }
 }
 
@@ -1256,17 +1337,50 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
   if (a->K <= 0 || a->R <= 0 || a->S <= 0) return OBJNERF_EINVAL;
   if (net->n_freqs != 6) return OBJNERF_ENOTSUP;
   if ((a->mode & OBJNERF_TRAIN_FP16) && (a->mode & OBJNERF_TRAIN_BF16)) return OBJNERF_EINVAL;
+  if (a->optim && (!a->optim->exp_avg || !a->optim->exp_avg_sq || !a->optim->group_steps ||
+                   (a->optim->bank != 0 && a->optim->bank != 1)))
+    return OBJNERF_EINVAL;
   if (net->hidden != 32 || a->S > 64 || (a->mode & (OBJNERF_TRAIN_LAYERWISE | OBJNERF_TRAIN_FP16))) {
     // wider networks (background: hidden 128) and long rays: layer-wise path, activations in the workspace
     if (a->workspace_bytes < objgen::train_workspace_bytes(net, a->K, a->R, a->S, a->gt_feat != nullptr,
                                                            (a->mode & (OBJNERF_TRAIN_FP16 | OBJNERF_TRAIN_BF16)) != 0))
       return OBJNERF_EINVAL;
     if (a->emb_debug) return OBJNERF_ENOTSUP;
+    // (objgen::train_step takes OBJNERF_TRAIN_SELF_COUNTS and the optimiser itself where its one-launch kernels run
+    // -- it reports what it has done through `done` -- and leaves them to the launches below otherwise)
+    int done = 0;
+    int rc;
 #ifndef OBJ_NO_TRAIN256
-    if (!(a->mode & OBJNERF_TRAIN_LAYERWISE) && obj256::applicable(net, a)) return obj256::train_step(net, a, stream);
+    if (!(a->mode & OBJNERF_TRAIN_LAYERWISE) && obj256::applicable(net, a)) {
+      if (a->mode & OBJNERF_TRAIN_SELF_COUNTS) {
+        rc = objnerf_label_counts(a->K, a->R, a->labels, const_cast<int32_t*>(a->counts), const_cast<int32_t*>(a->flags), stream);
+        if (rc) return rc;
+      }
+      rc = obj256::train_step(net, a, stream);
+    } else
 #endif
-    (void)hipMemsetAsync(a->status, 0, sizeof(int), (hipStream_t)stream);
-    return objgen::train_step(net, a, stream);
+    rc = objgen::train_step(net, a, stream, &done);
+    if (rc) return rc;
+    if (a->optim && !(done & 2)) {
+      int64_t offs[OBJNERF_N_TENSORS + 1];
+      objnerf_param_layout(net, offs);
+      const bool feat_ = a->gt_feat != nullptr;
+      const objnerf_adamw_args* o = a->optim;
+      return objmisc::adamw_flags_range(a->K, offs[OBJNERF_N_TENSORS], a->p_stride, const_cast<float*>(a->params), a->grads,
+                                        o->exp_avg, o->exp_avg_sq, nullptr, a->flags, o->group_steps, o->bank,
+                                        offs[OBJNERF_T_CL_W], offs[OBJNERF_T_FL_W], offs[OBJNERF_T_PE_B],
+                                        feat_ ? offs[OBJNERF_N_TENSORS] : offs[OBJNERF_T_FL_W],
+                                        feat_ ? offs[OBJNERF_N_TENSORS] : offs[OBJNERF_T_PE_B], o->lr, o->beta1, o->beta2,
+                                        o->eps, o->weight_decay, stream);
+    }
+    return OBJNERF_OK;
+  }
+  const bool self_counts = (a->mode & OBJNERF_TRAIN_SELF_COUNTS) != 0;
+  if (self_counts) {
+    // per-object counts only (one workgroup per object, no zero fill, no atomics): the fused kernel's workgroups derive
+    // the cross-object flags from them and finalize_kernel publishes the pair
+    const int rc = objmisc::label_counts_only(a->K, a->R, a->labels, const_cast<int32_t*>(a->counts), stream);
+    if (rc) return rc;
   }
   const bool feat = a->gt_feat != nullptr;
   if (feat && (TS / a->S) > 16) return OBJNERF_ENOTSUP;
@@ -1289,7 +1403,7 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
   d.params = a->params; d.p_stride = a->p_stride; d.scale = a->scale;
   d.pts = a->pts; d.origins = a->origins; d.dirs = a->dirs; d.z = a->z;
   d.gt_depth = a->gt_depth; d.gt_rgb = a->gt_rgb; d.labels = a->labels; d.gt_feat = a->gt_feat;
-  d.counts = a->counts; d.flags = a->flags;
+  d.counts = a->counts; d.flags = a->flags; d.derive_flags = self_counts ? 1 : 0;
   d.L = make_layout(net->feat_dim);
   char* ws = (char*)a->workspace;
   const int Gmax = grid_cap(a->K);
@@ -1320,14 +1434,10 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
   d.emb_debug = a->emb_debug;
 
   hipStream_t st = (hipStream_t)stream;
-  // slab-reduced entries: everything except what this launch does not differentiate.  Without gt_feat the
-  // whole feature branch has no gradient (train.py:435-438 -> .grad stays None); with it, the 512-d head's
-  // gradient is produced by feat_finish_kernel instead of the slabs.
-  (void)hipMemsetAsync(has_grad, 1, (size_t)ps, st);
-  if (feat) (void)hipMemsetAsync(has_grad + d.L.of_w, 0, (size_t)(d.L.pe_b - d.L.of_w), st);
-  else (void)hipMemsetAsync(has_grad + d.L.fl_w, 0, (size_t)(d.L.pe_b - d.L.fl_w), st);
-  (void)hipMemsetAsync(a->status, 0, sizeof(int), st);
-
+  // (no byte mask and no zero fills: finalize_kernel takes the ranges without a gradient as arguments -- without
+  // gt_feat the whole feature branch has none (train.py:435-438 -> .grad stays None); with it, the 512-d head's
+  // gradient is produced by feat_finish_kernel instead of the slabs -- and writes the status word itself)
+  (void)has_grad;
   const size_t lds_bytes = (size_t)((feat ? W_FLOATS_FEAT : W_FLOATS_NOFEAT) + SM_FLOATS + STG_ROWS * STG_LD) * 4;
   objnerf_once_per_device([] {
     (void)hipFuncSetAttribute((const void*)train_fused_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1399,8 +1509,24 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
   if (hipGetLastError() != hipSuccess) return OBJNERF_ELAUNCH;
   const long P = offs[OBJNERF_N_TENSORS];
   dim3 fg((unsigned)((P + 255) / 256), (unsigned)a->K);
-  hipLaunchKernelGGL(finalize_kernel, fg, dim3(256), 0, st, d.slab, d.loss_part, a->K, d.G, P, (long)ps,
-                     (long)a->p_stride, has_grad, a->grads, a->loss_terms, a->status, d.flat_nwg, d.NT, d.Gs);
+  FinalizeArgs fa;
+  fa.slab = d.slab; fa.loss_part = d.loss_part; fa.K = a->K; fa.G = d.G; fa.P = P; fa.slab_stride = (long)ps;
+  fa.p_stride = (long)a->p_stride;
+  fa.ng_lo = feat ? P : d.L.fl_w; fa.ng_hi = feat ? P : d.L.pe_b;
+  fa.ext_lo = feat ? d.L.of_w : P; fa.ext_hi = feat ? d.L.pe_b : P;
+  fa.grads = a->grads; fa.loss_terms = a->loss_terms; fa.status = a->status;
+  fa.flat_nwg = d.flat_nwg; fa.NT = d.NT; fa.Gs = d.Gs;
+  fa.params = nullptr; fa.m = fa.v = nullptr; fa.flags = a->flags; fa.steps = nullptr; fa.bank = 0;
+  fa.lo1 = offs[OBJNERF_T_CL_W]; fa.lo2 = offs[OBJNERF_T_FL_W]; fa.hi2 = offs[OBJNERF_T_PE_B];
+  fa.lr = fa.b1 = fa.b2 = fa.wd = 0.0; fa.eps = 0.f;
+  fa.counts_in = self_counts ? a->counts : nullptr; fa.flags_out = const_cast<int*>(a->flags);
+  if (a->optim) {
+    const objnerf_adamw_args* o = a->optim;
+    fa.params = const_cast<float*>(a->params); fa.m = o->exp_avg; fa.v = o->exp_avg_sq; fa.steps = o->group_steps;
+    fa.bank = o->bank; fa.lr = (double)o->lr; fa.b1 = (double)o->beta1; fa.b2 = (double)o->beta2;
+    fa.wd = (double)o->weight_decay; fa.eps = o->eps;
+  }
+  hipLaunchKernelGGL(finalize_kernel, fg, dim3(256), 0, st, fa);
   if (hipGetLastError() != hipSuccess) return OBJNERF_ELAUNCH;
   return OBJNERF_OK;
 }

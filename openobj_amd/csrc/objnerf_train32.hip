@@ -193,8 +193,10 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
   const float scale = a.scale[k];
   const int S = SS ? SS : a.S, R = a.R, TR = SS ? TS / SS : a.TR;
   const float n1 = (float)a.counts[2 * k], n2 = (float)a.counts[2 * k + 1];
-  const float inv1 = a.flags[0] ? 0.0f : 1.0f / (n1 + 1e-10f);
-  const float inv2 = a.flags[1] ? 0.0f : 1.0f / (n2 + 1e-10f);
+  int bflag0, bflag1;
+  batch_flags(a, bflag0, bflag1);
+  const float inv1 = bflag0 ? 0.0f : 1.0f / (n1 + 1e-10f);
+  const float inv2 = bflag1 ? 0.0f : 1.0f / (n2 + 1e-10f);
 
   // per-lane LDS bases (objnerf_mlp32.h)
   const float* wf = (const float*)__builtin_assume_aligned(lds + 4 * g * WROW + out_pos(c), 8);

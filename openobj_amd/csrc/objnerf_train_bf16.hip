@@ -156,8 +156,10 @@ __global__ __launch_bounds__(NTHR) void train_fused_bf16_kernel(const TrainDev a
   const float inv_scale = 1.0f / a.scale[k];
   const int S = SS ? SS : a.S, R = a.R, TR = SS ? TS / SS : a.TR;
   const float n1 = (float)a.counts[2 * k], n2 = (float)a.counts[2 * k + 1];
-  const float inv1 = a.flags[0] ? 0.0f : 1.0f / (n1 + 1e-10f);
-  const float inv2 = a.flags[1] ? 0.0f : 1.0f / (n2 + 1e-10f);
+  int bflag0, bflag1;
+  batch_flags(a, bflag0, bflag1);
+  const float inv1 = bflag0 ? 0.0f : 1.0f / (n1 + 1e-10f);
+  const float inv2 = bflag1 ? 0.0f : 1.0f / (n2 + 1e-10f);
 
   f32x4 accA0 = zero4(), accA1 = zero4(), accB0 = zero4(), accB1 = zero4(), accC0 = zero4(), accC1 = zero4();
   // Row sums over the samples (head weights, mid1 / mid2 biases): transposing DPP butterflies into slot registers per

@@ -20,6 +20,8 @@ struct TrainDev {
   const float* pts; const float* origins; const float* dirs; const float* z;
   const float* gt_depth; const float* gt_rgb; const uint8_t* labels; const float* gt_feat;
   const int* counts; const int* flags;
+  int derive_flags;   // OBJNERF_TRAIN_SELF_COUNTS: `flags` is not an input -- every workgroup derives the early-return pair
+                      // from counts [K][2] (batch_flags below) and finalize_kernel publishes it
   float* slab;        // [K][G][slab_stride]  (flat mode: [K][Gs][slab_stride])
   long slab_stride;
   float* loss_part;   // [K][G][4]
@@ -37,6 +39,14 @@ struct TrainDev {
   Layout L;
 };
 constexpr int RAYIN = 34, GRAM = 1088, RAYFEAT = 36;
+// The early-return pair of render_rays.py:89-94 ("some object of the batch has an empty mask"): the caller's (possibly
+// reduced over GPUs), or derived from the K objects' counts by the calling wave (all 64 lanes active).
+__device__ __forceinline__ void batch_flags(const TrainDev& a, int& f0, int& f1) {
+  if (!a.derive_flags) { f0 = a.flags[0]; f1 = a.flags[1]; return; }
+  int e0 = 0, e1 = 0;
+  for (int k = threadIdx.x & 63; k < a.K; k += 64) { e0 |= a.counts[2 * k] == 0; e1 |= a.counts[2 * k + 1] == 0; }
+  f0 = __ballot(e0) != 0; f1 = __ballot(e1) != 0;
+}
 // flat mode: the workgroup whose share [T b / nwg, T (b + 1) / nwg) holds flat tile x
 __host__ __device__ inline int flat_wg_of(const long T, const int nwg, const long x) { return (int)(((x + 1) * nwg - 1) / T); }
 // LDS aliases inside the staging area, valid from the forward pass until phase B of the backward pass

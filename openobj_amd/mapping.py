@@ -231,6 +231,24 @@ class IncrementalMapper:
                                                  device=cfg.training_device, resident=True)
             pre = sharded_it.frame_pre(pool["labels"] if pool is not None else None,
                                        bg_pool["labels"] if bg_pool is not None else None, cfg.n_iter_per_frame)
+        # un-sharded: the label statistics of ALL iterations in one launch per pool (the pools are complete before the
+        # first iteration, train.py:394-404) and the loss terms of the frame in one tensor per chain -- an iteration is
+        # then two launches on the object stream (fused kernel; slab reduction + AdamW) and three on the background
+        # stream (forward + loss + backward; grouped weight gradients; reduction + AdamW), with no copies in between
+        stats = {}
+        if not sharded and getattr(self.loop, "strategy", "hip") != "forloop":
+            n_it = cfg.n_iter_per_frame
+            dev_t = cfg.training_device
+            if pool is not None:
+                K_ = pool["labels"].shape[1]
+                oc = ops.label_counts(pool["labels"].reshape(n_it * K_, -1))[0].reshape(n_it, K_, 2)
+                stats["oc"], stats["of"] = oc, (oc == 0).any(dim=1).to(torch.int32).contiguous()
+                stats["ot"] = torch.zeros(n_it, K_, 4, device=dev_t)
+            if bg_pool is not None:
+                with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                    bc = ops.label_counts(bg_pool["labels"].reshape(n_it, -1))[0].reshape(n_it, 1, 2)
+                    stats["bc"], stats["bf"] = bc, (bc == 0).any(dim=1).to(torch.int32).contiguous()
+                    stats["bt"] = torch.zeros(n_it, 1, 4, device=dev_t)
         for it in range(cfg.n_iter_per_frame):
             batch = {k: v[it] for k, v in pool.items()} if pool is not None else None
             bg_slice = (lambda: {k: v[it] for k, v in bg_pool.items()}) if bg_pool is not None else None
@@ -242,10 +260,26 @@ class IncrementalMapper:
                     out["bg"].append(bt.clone())
                 continue
             if batch is not None:
-                out["obj"].append(self.loop.step(batch).clone())
+                if "oc" in stats:
+                    self.loop.step(batch, global_flags=stats["of"][it], global_counts=stats["oc"][it],
+                                   loss_out=stats["ot"][it])
+                else:
+                    out["obj"].append(self.loop.step(batch).clone())
             if bg_slice is not None:
                 with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
-                    out["bg"].append(self.bg_loop.step(bg_slice()).clone())       # (the slice copies run on `side` too)
+                    if "bc" in stats:
+                        self.bg_loop.step(bg_slice(), counts=stats["bc"][it], flags=stats["bf"][it],
+                                          loss_out=stats["bt"][it])
+                    else:
+                        out["bg"].append(self.bg_loop.step(bg_slice()).clone())   # (the slice copies run on `side` too)
+        if "ot" in stats:
+            out["obj"] = list(stats["ot"].unbind(0))
+        if "bt" in stats:
+            if side is not None:        # (allocated and written on the second stream, handed to the caller's)
+                main_s = torch.cuda.current_stream(cfg.training_device)
+                main_s.wait_stream(side)
+                stats["bt"].record_stream(main_s)
+            out["bg"] = list(stats["bt"].unbind(0))
         if side is not None:
             torch.cuda.current_stream(cfg.training_device).wait_stream(side)
         # render_rays.py:109-111 ("loss explode" -> exit): every rank must leave together, so the status is MAX-reduced

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import LossArgs, Net, ObjnerfError, SampleArgs, TrainArgs, check, lib
+from ._lib import AdamWArgs, LossArgs, Net, ObjnerfError, SampleArgs, TRAIN_SELF_COUNTS, TrainArgs, check, lib
 
 EMB1, EMB2, N_DIRS = 87, 42, 21
 TENSOR_NAMES = [
@@ -455,8 +455,16 @@ def train_step(arena: ParamArena, ws: TrainWorkspace, batch: Dict[str, torch.Ten
                opacity_scaling=10.0, feat_scaling=5.0, with_feat=False, obj_center=0.0,
                global_flags: Optional[torch.Tensor] = None, global_counts: Optional[torch.Tensor] = None,
                bf16: bool = False, layerwise: bool = False, relu_masks: Optional[torch.Tensor] = None,
-               emb_debug: Optional[torch.Tensor] = None) -> None:
+               emb_debug: Optional[torch.Tensor] = None, optim=None) -> None:
     """One fused iteration (train.py:424-472): fills ws.grads, ws.loss_terms, ws.status.
+
+    optim: an optim.ArenaAdamW over `arena` -- the iteration's optimiser.step() (train.py:472-473) runs INSIDE the call
+    (objnerf_train_args.optim: the launch that reduces the partial gradients applies AdamW to each element it has just
+    summed, with the iteration's early-return flags deciding which tensor groups are stepped); ws.grads is still
+    written.  None: gradients only.
+
+    Without global_flags AND global_counts the step derives the label statistics itself (OBJNERF_TRAIN_SELF_COUNTS;
+    ws.counts / ws.flags receive them) -- no separate objnerf_label_counts call.
 
     layerwise: OBJNERF_TRAIN_LAYERWISE -- run the layer-wise (any width) implementation even where the fused
     kernel applies (cross-check of two independent implementations; ws must be built with layerwise=True).
@@ -483,7 +491,8 @@ def train_step(arena: ParamArena, ws: TrainWorkspace, batch: Dict[str, torch.Ten
     gt_rgb = _req(batch["gt_rgb"], torch.float32, "gt_rgb")
     gt_feat = _req(batch["gt_feat"], torch.float32, "gt_feat") if with_feat else None
     st = _stream()
-    if global_flags is None or global_counts is None:
+    self_counts = global_flags is None and global_counts is None
+    if not self_counts and (global_flags is None or global_counts is None):
         check(lib().objnerf_label_counts(K, R, _ptr(labels), _ptr(ws.counts), _ptr(ws.flags), st),
               "objnerf_label_counts")
     flags = ws.flags
@@ -505,12 +514,26 @@ def train_step(arena: ParamArena, ws: TrainWorkspace, batch: Dict[str, torch.Ten
     kc = getattr(ws, "k_chunk", K)
     ctx = ws.context.handle if getattr(ws, "context", None) is not None else None
     if kc >= K:
-        a = TrainArgs(K, R, S, mode, color_scaling, opacity_scaling, feat_scaling, obj_center, _ptr(arena.params),
+        oa = None
+        if optim is not None:
+            if optim.arena is not arena:
+                raise ObjnerfError("train_step: optim must be the optimiser of `arena`")
+            oa = AdamWArgs(_ptr(optim.exp_avg), _ptr(optim.exp_avg_sq), _ptr(optim._banks), int(optim._bank), 0,
+                           optim.lr, optim.betas[0], optim.betas[1], optim.eps, optim.weight_decay, 0.0)
+        a = TrainArgs(K, R, S, mode | (TRAIN_SELF_COUNTS if self_counts else 0), color_scaling, opacity_scaling,
+                      feat_scaling, obj_center, _ptr(arena.params),
                       arena.p_stride, _ptr(arena.scale), _ptr(pts), _ptr(origins), _ptr(dirs), _ptr(z), _ptr(gt_depth),
                       _ptr(gt_rgb), _ptr(labels), _ptr(gt_feat), _ptr(counts), _ptr(flags), _ptr(ws.grads),
-                      _ptr(ws.loss_terms), _ptr(ws.status), _ptr(ws.buf), ws.nbytes, _ptr(relu_masks), ctx, _ptr(emb_debug))
+                      _ptr(ws.loss_terms), _ptr(ws.status), _ptr(ws.buf), ws.nbytes, _ptr(relu_masks), ctx, _ptr(emb_debug),
+                      C.addressof(oa) if oa is not None else None)
         check(lib().objnerf_train_step(C.byref(net), C.byref(a), st), "objnerf_train_step")
+        if optim is not None:
+            optim._bank ^= 1
+            arena.version += 1          # (the call wrote the arena through raw pointers: torch's counter misses it)
         return
+    if self_counts:                     # (the flags span the whole batch, not a chunk of it)
+        check(lib().objnerf_label_counts(K, R, _ptr(labels), _ptr(ws.counts), _ptr(ws.flags), st),
+              "objnerf_label_counts")
     # layer-wise path, chunk of objects at a time (leading-dimension slices are contiguous views)
     sl = lambda t, k0, k1: None if t is None else t[k0:k1]           # noqa: E731
     for ci, k0 in enumerate(range(0, K, kc)):
@@ -520,15 +543,19 @@ def train_step(arena: ParamArena, ws: TrainWorkspace, batch: Dict[str, torch.Ten
                       _ptr(sl(origins, k0, k1)), _ptr(sl(dirs, k0, k1)), _ptr(z[k0:k1]), _ptr(gt_depth[k0:k1]),
                       _ptr(gt_rgb[k0:k1]), _ptr(labels[k0:k1]), _ptr(sl(gt_feat, k0, k1)), _ptr(counts[k0:k1]),
                       _ptr(flags), _ptr(ws.grads[k0:k1]), _ptr(ws.loss_terms[k0:k1]), _ptr(ws.status_chunks[ci:ci + 1]),
-                      _ptr(ws.buf), ws.nbytes, _ptr(sl(relu_masks, k0, k1)), ctx, _ptr(sl(emb_debug, k0, k1)))
+                      _ptr(ws.buf), ws.nbytes, _ptr(sl(relu_masks, k0, k1)), ctx, _ptr(sl(emb_debug, k0, k1)), None)
         check(lib().objnerf_train_step(C.byref(net), C.byref(a), st), "objnerf_train_step")
     torch.amax(ws.status_chunks, dim=0, keepdim=True, out=ws.status)
+    if optim is not None:               # (chunked: one optimiser launch over the whole arena after the last chunk)
+        optim.step(ws.grads, arena.has_grad_mask(with_feat), flags=flags)
 
 
 def adamw_step(arena: ParamArena, grads: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor,
                has_grad: Optional[torch.Tensor], step: int, lr: float, weight_decay: float, beta1=0.9, beta2=0.999,
                eps=1e-8, params: Optional[torch.Tensor] = None) -> None:
     p = arena.params if params is None else params
+    if params is None:
+        arena.version += 1              # (raw-pointer write: torch's version counter misses it; autograd.py checks this one)
     check(lib().objnerf_adamw_step(arena.K, arena.P, arena.p_stride, _ptr(p), _ptr(grads), _ptr(exp_avg),
                                    _ptr(exp_avg_sq), _ptr(has_grad), step, lr, beta1, beta2, eps, weight_decay,
                                    _stream()), "objnerf_adamw_step")
@@ -542,6 +569,8 @@ def adamw_step_flags(arena: ParamArena, grads: torch.Tensor, exp_avg: torch.Tens
     (objnerf_adamw_step_flags); group_steps: int32[2, 3] device counters owned by the caller, `bank` the bank to read
     (the other one receives the advanced counters: alternate it from call to call)."""
     p = arena.params if params is None else params
+    if params is None:
+        arena.version += 1
     flags = _req(flags, torch.int32, "flags")
     group_steps = _req(group_steps, torch.int32, "group_steps")
     if group_steps.numel() != 6 or bank not in (0, 1):
@@ -755,6 +784,47 @@ def sample_rays(rgbs_batch, depth_batch, t_wc_batch, bbox, rays_dir_cache, kf_id
     check(lib().objnerf_sample_rays(C.byref(a), _stream()), "objnerf_sample_rays")
     r = (out_rgb, out_depth, out_valid.bool(), out_labels, out_pts, out_z)
     return r if partfeat is None else r + (pf.reshape(n_frames, n_px, -1),)
+
+
+def sample_points(sampled_rgbs, sampled_depth, origins, dirs_w, n_cam2surf: int, n_bins: int, surface_eps: float,
+                  stop_eps: float, min_bound: float = 0.0, obj_center: float = 0.0, u=None, g=None, seed=None,
+                  obj_index: int = 0):
+    """sceneObject.sample_3d_points alone (vmap.py:456-554, objnerf_sample_points): the pixels are already gathered.
+    sampled_rgbs u8 [n_frames, n_px, 4] (rgb + state), sampled_depth [n_frames, n_px], origins [n_frames, 3], dirs_w
+    [n_frames, n_px, 3].  u [n, N + M] / g [n, M]: the reference's draws injected (both or neither; neither = Philox
+    draws under `seed` and a per-call counter).  -> (rgb u8, depth, valid bool [n], labels u8 [n], pts, z)."""
+    sampled_rgbs = _req(sampled_rgbs, torch.uint8, "sampled_rgbs")
+    sampled_depth = _req(sampled_depth, torch.float32, "sampled_depth")
+    origins = _req(origins, torch.float32, "origins")
+    dirs_w = _req(dirs_w, torch.float32, "dirs_w")
+    n_frames, n_px = sampled_depth.shape
+    if tuple(sampled_rgbs.shape) != (n_frames, n_px, 4) or tuple(origins.shape) != (n_frames, 3) or \
+            tuple(dirs_w.shape) != (n_frames, n_px, 3):
+        raise ObjnerfError("sample_points: sampled_rgbs [F,P,4], sampled_depth [F,P], origins [F,3], dirs_w [F,P,3]")
+    if (u is None) != (g is None):
+        raise ObjnerfError("sample_points: inject both u and g or neither")
+    n, S = n_frames * n_px, n_cam2surf + n_bins
+    dev = sampled_rgbs.device
+    if u is not None:
+        u = _req(u, torch.float32, "u")
+        g = _req(g, torch.float32, "g")
+        draw = 0
+    else:
+        draw = _next_offset() & 0x1FFFFFFF
+    out_rgb = torch.empty(n_frames, n_px, 3, dtype=torch.uint8, device=dev)
+    out_depth = torch.empty(n_frames, n_px, device=dev)
+    out_valid = torch.empty(n, dtype=torch.uint8, device=dev)
+    out_labels = torch.empty(n, dtype=torch.uint8, device=dev)
+    out_z = torch.empty(n_frames, n_px, S, device=dev)
+    out_pts = torch.empty(n_frames, n_px, S, 3, device=dev)
+    ws = torch.empty(1 + 6 * n, device=dev)
+    a = SampleArgs(0, 0, 0, n_frames, n_px, n_cam2surf, n_bins, int(obj_index), surface_eps, stop_eps, min_bound,
+                   obj_center, None, None, None, None, None, None, None, None, _ptr(u), _ptr(g), _ptr(out_rgb),
+                   _ptr(out_depth), _ptr(out_valid), _ptr(out_labels), _ptr(out_z), _ptr(out_pts), _ptr(ws),
+                   _seed_of(seed), draw, 0, None, None, None, None, None)
+    check(lib().objnerf_sample_points(C.byref(a), _ptr(sampled_rgbs), _ptr(sampled_depth), _ptr(origins), _ptr(dirs_w),
+                                      _stream()), "objnerf_sample_points")
+    return out_rgb, out_depth, out_valid.bool(), out_labels, out_pts, out_z
 
 
 # ------------------------------------------------------------------------------------------------

@@ -28,7 +28,8 @@ class ArenaAdamW:
         constants this iteration are skipped like parameters with .grad = None in torch.optim.AdamW (no decay, no moment
         update, their own step count) -- decided on the device, no host sync.  Without it every tensor of `has_grad`
         is stepped with one global step count."""
-        self.arena.version += 1         # (the kernel writes the arena through raw pointers: torch's counter misses it)
+        # (arena.version -- the "parameters were written through raw pointers" counter autograd.py checks -- is advanced by
+        # the ops-level writers themselves)
         if flags is not None:
             ops.adamw_step_flags(self.arena, grads, self.exp_avg, self.exp_avg_sq, has_grad, flags, self._banks, self._bank,
                                  self.lr, self.weight_decay, self.betas[0], self.betas[1], self.eps)

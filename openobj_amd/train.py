@@ -50,26 +50,40 @@ class BackgroundLoop:
         """(counts, early-return flags) of the rays at hand (objnerf_label_counts: both from one launch)."""
         return ops.label_counts(batch["labels"])
 
-    def begin(self, batch: Dict[str, torch.Tensor], counts: torch.Tensor, flags: torch.Tensor):
-        """Launch the step with the GLOBAL mask counts / flags and start the gradient all-reduce; returns its handle."""
+    def begin(self, batch: Dict[str, torch.Tensor], counts: Optional[torch.Tensor], flags: Optional[torch.Tensor],
+              loss_out: Optional[torch.Tensor] = None):
+        """Launch the step with the GLOBAL mask counts / flags and start the gradient all-reduce; returns its handle.
+        counts = flags = None (one rank holds all of the iteration's background rays): the step counts the labels
+        itself and, with no collective between the gradient and the optimiser, applies AdamW in its last launch
+        (ops.train_step(optim=)) -- finish() then has nothing left to do."""
         ws = self._workspace(batch)
-        self._flags = flags
+        sharded = odist._active(self.group)
+        # loss_out (float32 [1, 4], un-sharded callers): this iteration's loss terms go there instead of the tail of the
+        # collective's buffer -- a frame's terms land in one [n_iter, 1, 4] tensor without a copy per iteration
+        ws.loss_terms = loss_out if (loss_out is not None and not sharded) else self.flat[self.arena.p_stride:].view(1, 4)
+        self._fused_opt = not sharded
+        self._flags = flags if flags is not None else ws.flags
         ops.train_step(self.arena, ws, batch, with_feat=self.with_feat, global_flags=flags, global_counts=counts,
-                       bf16=self.bf16)
+                       bf16=self.bf16, optim=self.opt if self._fused_opt else None)
         return odist.allreduce_sum_async(self.flat, self.group)    # the one data-path collective
 
     def finish(self, work) -> torch.Tensor:
         if work is not None:
             work.wait()
-        self.opt.step(self.ws.grads, self.mask, flags=self._flags)
+        if not self._fused_opt:
+            self.opt.step(self.ws.grads, self.mask, flags=self._flags)
         return self.ws.loss_terms
 
-    def step(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
-        """batch: THIS rank's slice of the background rays, tensors shaped [1, R_local, ...]."""
+    def step(self, batch: Dict[str, torch.Tensor], counts: Optional[torch.Tensor] = None,
+             flags: Optional[torch.Tensor] = None, loss_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """batch: THIS rank's slice of the background rays, tensors shaped [1, R_local, ...].
+        counts / flags (un-sharded): label statistics the caller already has (one launch per frame, mapping.train_frame);
+        None = the step counts the labels itself."""
+        if not odist._active(self.group):
+            return self.finish(self.begin(batch, counts, flags, loss_out=loss_out))
         counts, flags = self.local_counts_flags(batch)
-        if odist._active(self.group):
-            odist.allreduce_sum_(counts, self.group)              # global n(label==1), n(label!=2)
-            flags = ((counts.reshape(-1, 2) == 0).any(dim=0)).to(torch.int32)
+        odist.allreduce_sum_(counts, self.group)              # global n(label==1), n(label!=2)
+        flags = ((counts.reshape(-1, 2) == 0).any(dim=0)).to(torch.int32)
         return self.finish(self.begin(batch, counts, flags))
 
 
@@ -85,7 +99,7 @@ class ShardedIteration:
     obj_loop / bg_loop may be None (a rank without foreground objects, do_bg = 0)."""
 
     def __init__(self, obj_loop=None, bg_loop=None, group=None, overlap: bool = True, resident: bool = False,
-                 device=None):
+                 device=None, pipelined: bool = False):
         """device: where this rank's collectives' buffers live (cfg.training_device).  Needed by a rank that is handed
         NO batch in some iteration (no foreground object yet, do_bg = 0): it still has to join both exchanges, or the
         other ranks block in them.  Defaults to the device of the first batch seen.
@@ -96,9 +110,16 @@ class ShardedIteration:
         resident: the caller guarantees that the batches handed to step() are complete before the call (resident
         pools, as in bench.py / mapping.IncrementalMapper); the second stream then never waits for the object
         stream, so the background chain of iteration i + 1 fills the tail of object kernel i.  Otherwise it waits
-        for the work queued on the caller's stream at every step()."""
+        for the work queued on the caller's stream at every step().
+        pipelined (with resident): step() does not make the caller's stream wait for the background stream before it
+        returns.  The two chains only share the iteration's label statistics, so with resident batches the background
+        chain of iteration i may still be running under the object kernel of iteration i + 1 (each chain stays in order
+        on its own stream; both need whole compute units -- 160 KB of LDS per workgroup -- so what one leaves idle at
+        its ragged end the other fills).  The caller calls join() before it reads the returned loss terms or the
+        background parameters on its own stream."""
         self.obj_loop, self.bg_loop, self.group = obj_loop, bg_loop, group
         self.overlap, self.resident = overlap, resident
+        self.pipelined = bool(pipelined and resident)
         self.device = torch.device(device) if device is not None else None
         self._side = None
 
@@ -177,11 +198,9 @@ class ShardedIteration:
                 gflags, bg_counts, bg_flags = pre
             elif do_obj and sharded:
                 obj_flags = ops.label_counts(obj_batch["labels"])[1]
-            if do_bg and pre is None:
-                if sharded:
-                    bg_counts = self.bg_loop.local_counts(bg_batch)
-                else:                               # one object, one rank: the kernel's own flag pair is the batch's
-                    bg_counts, bg_flags = self.bg_loop.local_counts_flags(bg_batch)
+            if do_bg and pre is None and sharded:
+                bg_counts = self.bg_loop.local_counts(bg_batch)
+            # (un-sharded: bg_counts = bg_flags = None -- the background step counts its labels itself)
             if sharded and pre is None:
                 pre1 = odist.pack_pre(obj_flags, bg_counts, dev)
                 odist.allreduce_sum_(pre1, self.group)             # collective 1
@@ -197,9 +216,14 @@ class ShardedIteration:
         if do_bg:
             with on_side():
                 bg_terms = self.bg_loop.finish(work)
-        if side is not None:
+        if side is not None and not self.pipelined:
             main.wait_stream(side)
         return obj_terms, bg_terms
+
+    def join(self):
+        """The caller's stream waits for everything queued on the background stream (pipelined mode)."""
+        if self._side is not None and self.device is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self._side)
 
 
 class HipTrainLoop:
@@ -277,17 +301,23 @@ class HipTrainLoop:
             torch.maximum(self.status, self.wss[k].status, out=self.status)
         return self.loss_terms
 
-    def step(self, batch: Dict[str, torch.Tensor], global_flags: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """One iteration (train.py:424-474).  Returns the per-object loss terms [K,4] (device tensor)."""
+    def step(self, batch: Dict[str, torch.Tensor], global_flags: Optional[torch.Tensor] = None,
+             global_counts: Optional[torch.Tensor] = None, loss_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """One iteration (train.py:424-474).  Returns the per-object loss terms [K,4] (device tensor).
+        global_counts (with global_flags): the batch's label counts [K, 2] when the caller already has them (one launch
+        for all iterations of a frame, mapping.train_frame) -- the step then launches no label pass of its own.
+        loss_out: float32 [K, 4] that receives this iteration's loss terms (default: the workspace's own tensor)."""
         if self.strategy == "forloop":
             return self._step_forloop(batch, global_flags)
         K, R, S = batch["z"].shape
         if self.ws is None or self.ws.key != ops.TrainWorkspace.make_key(K, R, S, self.with_feat, self.bf16):
             self.ws = ops.TrainWorkspace(self.arena, K, R, S, self.with_feat, precision=self.bf16)
+            self._own_terms = self.ws.loss_terms
+        self.ws.loss_terms = loss_out if loss_out is not None else self._own_terms
+        # (optim=: the iteration's optimiser.step() runs in the step's last launch; the flags it skips tensor groups by are
+        # the global pair, or the batch's own -- ws.flags -- when none was supplied)
         ops.train_step(self.arena, self.ws, batch, with_feat=self.with_feat, global_flags=global_flags,
-                       bf16=self.bf16)
-        # (ws.flags holds the batch's own flags when no global pair was supplied)
-        self.opt.step(self.ws.grads, self.mask, flags=global_flags if global_flags is not None else self.ws.flags)
+                       global_counts=global_counts, bf16=self.bf16, optim=self.opt)
         return self.ws.loss_terms
 
     def train_frame(self, pool: Dict[str, torch.Tensor], n_iter: Optional[int] = None,

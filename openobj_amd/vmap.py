@@ -215,6 +215,21 @@ class sceneObject:
             float(self.min_bound), float(self.obj_center), partfeat=pf)
         return r if pf is not None else r + (None,)
 
+    def sample_3d_points(self, sampled_rgbs, sampled_depth, origins, dirs_w, sampled_partfeat=None, draws=None,
+                         seed=None):
+        """vmap.py:456-554 as a callable of its own (get_training_samples above runs gather + placement as one launch
+        chain): sampled_rgbs u8 [n_frames, n_px, 4] (rgb + state), sampled_depth [n_frames, n_px], origins
+        [n_frames, 3], dirs_w [n_frames, n_px, 3] -> the reference's 7-tuple (rgb u8, depth, valid_depth_mask[flat],
+        obj_labels[flat] u8, input_pcs, sampled_z, sampled_partfeat); sampled_partfeat is returned as given (:554).
+        draws = dict(u [n, N + M], g [n, M]) injects the reference's torch.rand / normal_ numbers in ray order (exact
+        parity); otherwise the placement kernel draws them itself (Philox under `seed`)."""
+        u = draws["u"] if draws is not None else None
+        g = draws["g"] if draws is not None else None
+        r = ops.sample_points(sampled_rgbs, sampled_depth, origins, dirs_w, self.n_bins_cam2surface, self.n_bins,
+                              self.surface_eps, self.stop_eps, float(self.min_bound), float(self.obj_center), u=u, g=g,
+                              seed=seed, obj_index=int(self.obj_id) & 0x7FFFFFFF)
+        return r + (sampled_partfeat,)
+
     def keyframe_store(self):
         """The four device tensors the sampler reads (fixed addresses for the life of the object)."""
         return self.rgbs_batch, self.depth_batch, self.t_wc_batch, self.bbox

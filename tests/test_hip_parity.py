@@ -288,6 +288,38 @@ def test_sampler_g7(golden, dev, tag):
     assert bool((zz[..., 1:N] >= zz[..., :N - 1]).all())     # stratified bins are ordered
 
 
+@pytest.mark.parametrize("tag", ["obj", "bg", "metric"])
+def test_sample_3d_points_method_g7(golden, dev, tag):
+    """sceneObject.sample_3d_points(sampled_rgbs, sampled_depth, origins, dirs_w, sampled_partfeat) as a callable of its
+    own (vmap.py:456-554, objnerf_sample_points) against fixture G7 -- the reference's method run unbound on the same
+    pixels with its torch.rand / normal_ draws recorded: the whole 7-tuple, points included."""
+    import types
+    from openobj_amd import vmap as hvmap
+    g = golden("g7_sample")
+    N, M = [int(x) for x in g[f"{tag}_NM"]]
+    ns = types.SimpleNamespace(n_bins_cam2surface=N, n_bins=M, surface_eps=0.1, stop_eps=0.05, min_bound=0.0,
+                               obj_center=0.0, obj_id=1)
+    rgbs = T(g[f"{tag}_rgbs"]).to(dev)
+    pf = torch.arange(6.0)
+    out = hvmap.sceneObject.sample_3d_points(ns, rgbs, T(g[f"{tag}_depth"]).to(dev), T(g[f"{tag}_origins"]).to(dev),
+                                             T(g[f"{tag}_dirs"]).to(dev), sampled_partfeat=pf,
+                                             draws={"u": T(g[f"{tag}_u"]).to(dev), "g": T(g[f"{tag}_g"]).to(dev)})
+    rgb, d, valid, labels, pts, z, pf_out = out
+    assert pf_out is pf and len(out) == 7
+    assert torch.equal(rgb.cpu(), T(g[f"{tag}_rgbs"])[..., :3]) and torch.equal(d.cpu(), T(g[f"{tag}_depth"]))
+    assert torch.equal(labels.cpu(), T(g[f"{tag}_labels"])) and labels.dtype == torch.uint8
+    assert torch.equal(valid.cpu(), T(g[f"{tag}_valid"])) and valid.dtype == torch.bool
+    assert tuple(z.shape) == tuple(g[f"{tag}_z"].shape) and tuple(pts.shape) == tuple(g[f"{tag}_pts"].shape)
+    assert maxerr(z, g[f"{tag}_z"]) < 1e-6              # (torch.linspace's CPU / GPU forms differ by 1 ulp: test_sampler_g7)
+    assert maxerr(pts, g[f"{tag}_pts"]) < 4e-6
+    # the seeded form (no draws): same labels / validity, ordered bins inside the reference's intervals
+    out2 = hvmap.sceneObject.sample_3d_points(ns, rgbs, T(g[f"{tag}_depth"]).to(dev), T(g[f"{tag}_origins"]).to(dev),
+                                              T(g[f"{tag}_dirs"]).to(dev), seed=5)
+    assert torch.equal(out2[3], labels) and torch.equal(out2[2], valid) and out2[6] is None
+    z2 = out2[5].cpu()
+    assert bool((z2[..., 1:N] >= z2[..., :N - 1]).all()) and bool(torch.isfinite(z2).all())
+
+
 def test_get_training_samples_g7(golden, dev):
     g = golden("g7_sample")
     out = ops.sample_rays(T(g["gts_rgbs_batch"]).to(dev), T(g["gts_depth_batch"]).to(dev), T(g["gts_t_wc"]).to(dev),
