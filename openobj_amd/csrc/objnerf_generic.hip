@@ -722,6 +722,8 @@ struct GemmEnv {
   float* next_rs_part = nullptr;
   RedGroup* red_group = nullptr;    // non-null: reductions are collected (grouped launch)
   int max_slices = 0;               // > 0: wgrad(E, ) cuts the sample axis into at most this many split-K slices
+  bool error = false;               // a GEMM of the step was handed operands its kernel does not take: train_step returns
+                                    // OBJNERF_EINVAL (a library call never ends the host process)
   bool need_parts = false;          // wgrad(E, ): the slab form is required (the gradient arena is not zero-filled)
   bool parts_failed = false;        // ... and the scratch did not hold it
   bool in_act16(const void* p) const {
@@ -928,7 +930,7 @@ static void gemm(GemmEnv& E, hipStream_t st, int batch, int M, int N, int Kd, co
     GemmGroup& gr = *E.group;               // collected; launched by flush_group(E, )
     if (E.group16) {
       // gemm_group16_kernel stages both operands k-major: rows contiguous in memory (weight gradients are)
-      if (!(sak != 1 && sam == 1 && sbk != 1 && sbn == 1)) { fprintf(stderr, "objnerf: grouped bf16 GEMM needs k-major operands\n"); abort(); }
+      if (!(sak != 1 && sam == 1 && sbk != 1 && sbn == 1)) { E.error = true; return; }      // (needs k-major operands)
       g.vec4 = (sak % 4 == 0 && bsa % 4 == 0 && M % 4 == 0 && ((uintptr_t)A & 15) == 0) ? 1 : 0;
     }
     if (gr.count == 0) gr.zbeg[0] = 0;
@@ -951,8 +953,7 @@ static void gemm(GemmEnv& E, hipStream_t st, int batch, int M, int N, int Kd, co
       g.A2 = E.a2.A2 ? E.a2.A2 : A; g.sam2 = E.a2.sam2; g.bsa2 = E.a2.bsa2; g.k2 = ka;
       E.a2.A2 = nullptr;
       g.vec4 = (ka % 8 == 0 && sam % 8 == 0 && bsa % 8 == 0 && ((uintptr_t)A & 15) == 0) ? 1 : 0;
-      if (g.a16 && !g.vec4) { fprintf(stderr, "objnerf: 16-bit activation panel needs aligned rows\n"); abort(); }
-      if (g.c16 && g.b16) { fprintf(stderr, "objnerf: unsupported 16-bit GEMM operands\n"); abort(); }
+      if ((g.a16 && !g.vec4) || (g.c16 && g.b16)) { E.error = true; return; }   // (16-bit panel: aligned rows, one 16-bit side)
       g.Bp = E.packb;
       const dim3 pgrid(1, (M + 63) / 64, nz);
 #define OBJ_G16_PANEL(OT_, KM_)                                                                                         \
@@ -968,8 +969,8 @@ static void gemm(GemmEnv& E, hipStream_t st, int batch, int M, int N, int Kd, co
     E.a2.A2 = nullptr;
     g.vec4 = (akm && sak % 4 == 0 && bsa % 4 == 0 && M % 4 == 0 && ((uintptr_t)A & 15) == 0) ? 1 : 0;
     if ((g.a16 && !(akm && g.vec4)) || g.c16 || (g.b16 && !(bkm && sbk % 4 == 0 && N % 4 == 0 && bsb % 4 == 0))) {
-      fprintf(stderr, "objnerf: 16-bit activations in a GEMM shape that does not take them\n");
-      abort();
+      E.error = true;                 // (16-bit activations in a GEMM shape that does not take them)
+      return;
     }
 #define OBJ_G16_LAUNCH(OT_, AK_, BK_)                                                                                   \
     do {                                                                                                                \
@@ -2403,6 +2404,7 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
   }
   launch_reductions(st, step_red);
   if (hipGetLastError() != hipSuccess) return OBJNERF_ELAUNCH;
+  if (E.error) return OBJNERF_EINVAL;
   return OBJNERF_OK;
 }
 
@@ -2499,7 +2501,7 @@ static int train_step_small(const objnerf_net* net, const objnerf_train_args* a,
   wgrad(E, st, K, H, E1, n, f.d_h3, 1, H, nH, w.emb, EM, 1, n * EM, G + off[4] + H, H + E1, ps);
   wgrad(E, st, K, H, H, n, f.d_h2, 1, H, nH, w.h1, H, 1, nH, G + off[2], H, ps, G + off[3]);
   wgrad(E, st, K, H, E1, n, f.d_h1, 1, H, nH, w.emb, EM, 1, n * EM, G + off[0], E1, ps, G + off[1]);
-  if (E.parts_failed) return OBJNERF_EINVAL;
+  if (E.parts_failed || E.error) return OBJNERF_EINVAL;
   flush_group(E, st, group);
   red.tail.loss_part = f.loss_part; red.tail.loss_blocks = nwg; red.tail.K = K; red.tail.loss_terms = a->loss_terms;
   red.tail.status = a->status;

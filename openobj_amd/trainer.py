@@ -73,6 +73,9 @@ class Trainer:
         dirs_W, near, far, hit = ops.box_rays(T_WC, T_OC, half, dirs_C)
         n_rays = int(hit.sum())
         if n_rays <= 1:
+            # (nothing of an earlier call may be served by the lazy z_vals / input_pcs properties after this)
+            self._bbox_samples = None
+            self._z_vals = self._input_pcs = None
             return None, None, None
         self.dirs_W = dirs_W[hit]
         self.origins = T_WC[:3, 3].to(dev).expand(n_rays, 3)
@@ -80,13 +83,18 @@ class Trainer:
         u = None if draws is None else torch.as_tensor(draws).to(dev)     # None: drawn inside the kernel (seeded)
         # z_vals / input_pcs are formed on first access (properties below): the fused renderer (vmap.render_2D_syn ->
         # ops.render_fwd) never needs the [n, 149, 3] point tensor; the same (seed, draw) reproduces the same numbers
+        # (the process-wide Philox call counter advances only when this call DRAWS: injected draws leave every later
+        # seeded launch on the stream it would have had without this call)
+        draw = (ops._next_offset() & 0x1FFFFFFF) if u is None else 0
         self._bbox_samples = dict(origin=T_WC[:3, 3], dirs_W=self.dirs_W.contiguous(), near=near_h, far=far_h, u=u,
-                                  n_bins=n_bins, seed=ops._seed_of(None), draw=ops._next_offset() & 0x1FFFFFFF)
+                                  n_bins=n_bins, seed=ops._seed_of(None), draw=draw)
         self._z_vals = self._input_pcs = None
         return hit, near_h, far_h
 
     def _materialise_bbox_samples(self):
         b = self._bbox_samples
+        if b is None:
+            raise RuntimeError("z_vals / input_pcs: the last sample_points_bbox call found no ray inside the box")
         self._z_vals, self._input_pcs = ops.box_points(b["origin"], b["dirs_W"], b["near"], b["far"], b["u"], b["n_bins"],
                                                        seed=b["seed"], draw=b["draw"])
 

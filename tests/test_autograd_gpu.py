@@ -125,6 +125,19 @@ def test_backward_after_the_arena_changed_raises(dev):
     opt.step(torch.zeros_like(t.arena.params))             # the kernel writes the arena behind torch's back
     with pytest.raises(RuntimeError, match="modified by an inplace operation"):
         l2.backward()
+    # the ops-level writers themselves advance the arena's version (not only optim.ArenaAdamW): a direct
+    # ops.adamw_step / adamw_step_flags / train_step(optim=) between forward and backward is caught too
+    l2b = fwd()
+    ops_mod = __import__("openobj_amd.ops", fromlist=["ops"])
+    z = torch.zeros_like(t.arena.params)
+    ops_mod.adamw_step(t.arena, z, z.clone(), z.clone(), None, 1, 1e-3, 0.0)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        l2b.backward()
+    l2c = fwd()
+    ops_mod.adamw_step_flags(t.arena, z, z.clone(), z.clone(), None, torch.zeros(2, dtype=torch.int32, device=dev),
+                             torch.zeros(2, 3, dtype=torch.int32, device=dev), 0, 1e-3, 0.0)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        l2c.backward()
     l3 = fwd()
     with torch.no_grad():
         list(t.fc_occ_map.parameters())[0].mul_(1.0)       # torch-side in-place write into an arena view

@@ -452,7 +452,11 @@ def test_stress_shape_step_vs_oracle(dev):
 
 
 @pytest.mark.parametrize("shape,feat_on", [((1, 1200, 5, 9), False), ((1, 700, 5, 9), True), ((3, 260, 5, 9), False),
-                                           ((2, 333, 4, 7), True), ((1, 2500, 5, 9), False)])
+                                           ((2, 333, 4, 7), True), ((1, 2500, 5, 9), False),
+                                           # round 5, the one-launch iteration (train_small_kernel): one 64-sample ray per
+                                           # workgroup (4 row tiles: the benchmark's / configs[3]'s background shape), two
+                                           # 32-sample rays with a ragged last workgroup, 4-sample rays (20 per workgroup)
+                                           ((1, 150, 16, 48), False), ((2, 37, 8, 24), False), ((1, 101, 1, 3), False)])
 def test_small_batch_one_launch_kernels_vs_oracle(dev, shape, feat_on):
     """Hidden 128 at the reference's native background batch (1200 rays x 14 samples) and around it: the forward and
     the input-gradient chain are ONE launch each (mlp_fwd_small_kernel / mlp_bwd_small_kernel with 5, 3, 4, 3 row
