@@ -451,7 +451,16 @@ __global__ __launch_bounds__(NTHR) void V2_KERNEL(const TrainDev a) {
 #define g (lane_l >> 4)
 #define q4 ((lane_l >> 2) & 3)
 #define p4 (lane_l & 3)
-#define tr_stg (stg + (4 * g + q4) * PITCH + 8 * p4)               /* staging, weight gradients (k = samples) */
+  // Staging rows are SWIZZLED (round 5): the 16-byte chunk at byte offset o of sample row R sits at o ^ 16 when bit 2
+  // of R is set.  A ds_write_b128 is serviced in groups of 8 consecutive lanes = 8 consecutive samples at one column
+  // offset, bank = (a / 4) mod 32 (MI355X_MICROARCH.md, LDS): with the 992- / 928-byte pitches (24 / 8 dwords mod 32,
+  // which the transposing reads need: 8 x odd mod 64) rows R and R + 4 started on the same bank -- every staging store
+  // was a 2-way conflict (SQ_LDS_BANK_CONFLICT 29 % of SQ_LDS_IDX_ACTIVE, profiles/r04_pmc_bf16_v4.txt).  Moving rows
+  // 4..7 of a group by one chunk puts the eight stores on eight disjoint bank quads; a transposing read's 32-lane
+  // group reads the same two chunks of rows 4..7 in swapped order, so its banks are unchanged.  (Reader: row 32 st +
+  // 4 g + q (+ 16) -> bit 2 of the row = g & 1; writer: row 16 w + c -> (c >> 2) & 1.)
+#define tr_stg (stg + (4 * g + q4) * PITCH + ((8 * p4) ^ ((g & 1) << 4)))   /* staging, weight gradients (k = samples) */
+#define stg_swz (((lane_l >> 2) & 1) << 4)                          /* writer's swizzle: bit 2 of its sample row */
 #define f_in (ldsb + B_IN + c * RS_IN + 16 * g)                    /* forward A operands (rows = outputs) */
 #define f_m1 (ldsb + B_M1 + c * RS_M + 16 * g)
 #define f_cat (ldsb + B_CAT + c * RS_CAT + 16 * g)
@@ -468,7 +477,7 @@ __global__ __launch_bounds__(NTHR) void V2_KERNEL(const TrainDev a) {
 #define t_fl (ldsb + B_FL + (4 * g + q4) * RS_CL + 16 * p4)
 #endif
 #define slot (16 * w + c)
-#define row_st (stg + slot * PITCH + 16 * g)                        /* this lane's 16 bytes of every block of its sample */
+#define row_st (stg + slot * PITCH + ((16 * g) ^ stg_swz))           /* this lane's 16 bytes of every block of its sample */
   // W^T d for the 16 input features (block blk, half tt) of an image: chunk p of feature 16 tt + 4 p + j sits at
   // position 8 p + 4 tt + j of the block
 #define BWD_TILE(accv, timg, RS_, blk, tt, db) \
@@ -897,7 +906,7 @@ __global__ __launch_bounds__(NTHR) void V2_KERNEL(const TrainDev a) {
       bf16x4 hv;
       hv[0] = (__bf16)(g == 0 ? da : 0.0f); hv[1] = (__bf16)(g == 0 ? dc0 : 0.0f);
       hv[2] = (__bf16)(g == 0 ? dc1 : 0.0f); hv[3] = (__bf16)(g == 0 ? dc2 : 0.0f);
-      *reinterpret_cast<bf16x4*>(stg + slot * PITCH + F_HEAD + 8 * g) = hv;
+      *reinterpret_cast<bf16x4*>(stg + slot * PITCH + F_HEAD + ((8 * g) ^ stg_swz)) = hv;
     }
 #else
     {                                             // head-weight gradients as per-lane sums (no room for their operands)
@@ -984,7 +993,7 @@ __global__ __launch_bounds__(NTHR) void V2_KERNEL(const TrainDev a) {
       for (int T = 0; T < 3; ++T) {
         bf16x4 xv4;
         xv4[0] = (__bf16)x2v[T][0]; xv4[1] = (__bf16)x2v[T][1]; xv4[2] = (__bf16)x2v[T][2]; xv4[3] = (__bf16)x2v[T][3];
-        *reinterpret_cast<bf16x4*>(stg + slot * PITCH + F_X2 + 32 * T + 8 * g) = xv4;
+        *reinterpret_cast<bf16x4*>(stg + slot * PITCH + F_X2 + ((32 * T + 8 * g) ^ stg_swz)) = xv4;
       }
 #elif defined(V2_RECOMPUTE_PE)
       *reinterpret_cast<bf16x8*>(row_st + F_X2) = pack8(x2v[0], x2v[1]);
@@ -1078,6 +1087,7 @@ __global__ __launch_bounds__(NTHR) void V2_KERNEL(const TrainDev a) {
 #undef q4
 #undef p4
 #undef tr_stg
+#undef stg_swz
 #undef f_in
 #undef f_m1
 #undef f_cat

@@ -106,6 +106,16 @@ def reference_ensemble_c() -> Optional[Dict[str, np.ndarray]]:
         return None
 
 
+def reference_early_d() -> Optional[Dict[str, np.ndarray]]:
+    """Fixture G9D: the reference's PSNR after 10 and 20 iterations on scene G9C, per weight seed
+    (tests/golden/make_g9d_early.py); None when absent."""
+    try:
+        d = np.load(os.path.join(GOLDEN, "g9d_early_h256.npz"))
+        return {k: d[k] for k in d.files}
+    except OSError:
+        return None
+
+
 def delta_report(hip: np.ndarray, ref: np.ndarray) -> Dict[str, float]:
     """Difference of ensemble means with its 95 % confidence half-width (Welch, normal quantile)."""
     se = math.sqrt(hip.var(ddof=1) / len(hip) + ref.var(ddof=1) / len(ref))

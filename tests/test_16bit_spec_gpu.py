@@ -98,6 +98,32 @@ def test_layerwise_16bit_feature_step_matches_its_specification(dev, mode, shape
         assert rel < (4 if i in ops.FEAT_TENSORS else 2) * BOUND[mode], (i, ops.TENSOR_NAMES[i], rel)
 
 
+# Second-generation kernels (64 samples per ray), per tensor: what tools/bf16v2_diag.py / bf16v2f_diag.py print, ASSERTED
+# (round 5).  Measured relative Frobenius distance to the operand-rounded specification at 3 x 300 x 64 = 57 600 samples
+# and 2 x 333 x 64 (the larger of the two; profiles/r05_bf16_spec_rel.txt), in units of 1e-3, without / with the feature
+# loss; the bound of a tensor is 1.6 x its measured distance (at least 0.5 %, at most V2_CAP).  Round 4's hipcc miscompile of the packed ReLU (gradients off
+# by 10 - 170 %) passes none of them; neither does a 4 % error in one tensor that the former flat 6 - 8 % bounds let by.
+V2_MEASURED = {"in_layer.0.weight": (17.7, 17.5), "in_layer.0.bias": (8.1, 7.1), "mid1.0.0.weight": (9.1, 8.7),
+               "mid1.0.0.bias": (6.9, 6.6), "cat_layer.0.weight": (7.2, 7.2), "cat_layer.0.bias": (2.8, 2.6),
+               "mid2.0.0.weight": (3.0, 2.8), "mid2.0.0.bias": (1.8, 1.6), "out_alpha.weight": (1.3, 1.3),
+               "out_alpha.bias": (0.7, 0.7), "color_linear.0.weight": (15.9, 15.7), "color_linear.0.bias": (9.4, 9.2),
+               "out_color.weight": (1.3, 1.1), "out_color.bias": (0.5, 0.2), "clip_linear.0.weight": (None, 25.4),
+               "clip_linear.0.bias": (None, 22.4), "out_clip.weight": (None, 2.2), "out_clip.bias": (None, 0.6),
+               "B_layer.weight": (22.0, 21.9)}
+V2_CAP = {False: 0.03, True: 0.04}      # trunk tensors <= 3 %, feature-branch tensors (and d B) <= 4 %: the review's figures
+
+
+def v2_bound(name, i, feat, samples_per_object):
+    """Bound of tensor `name` for a second-generation launch: the table above at >= 6400 samples per object (the sums
+    behind a gradient are then long enough for the rounding noise to average as in the measured shape); below that --
+    (60, 40, ..): 2560 per object, (300, 9, ..): 576 -- a flat 6 % (measured <= 3.4 %; 10 - 12 % until round 5)."""
+    if samples_per_object < 6400:
+        return 0.06
+    cap = V2_CAP[i in ops.FEAT_TENSORS or name == "B_layer.weight"]
+    m = V2_MEASURED[name][1 if feat else 0]
+    return min(cap, max(0.005, 1.6e-3 * m))
+
+
 @pytest.mark.parametrize("shape", [(3, 300, 16, 48), (2, 211, 5, 9), (4, 128, 8, 24), (2, 333, 16, 48), (300, 9, 16, 48)])
 def test_fused_bf16_kernel_matches_its_specification(dev, shape):
     """The fused hidden-32 kernel in bf16 mode (objnerf_train_bf16.hip, the kernel behind BASELINE configs[1] / [2]'s
@@ -120,7 +146,11 @@ def test_fused_bf16_kernel_matches_its_specification(dev, shape):
     for i in list(range(14)) + [18]:
         rel = rel_norm(gv[i], o["grads"][i])
         print(f"fused bf16 R={R} {ops.TENSOR_NAMES[i]:24s} rel {rel:.2e}")
-        assert rel < (0.06 if K * R * (n1 + n2) >= 20000 else 0.10), (i, ops.TENSOR_NAMES[i], rel)
+        if n1 + n2 == 64:           # second generation: per-tensor bounds
+            bound = v2_bound(ops.TENSOR_NAMES[i], i, False, R * 64)
+        else:                       # first generation (S != 64): measured 3.0 % (S = 14) / 5.5 % (S = 32, 16 384 samples)
+            bound = 0.06 if K * R * (n1 + n2) >= 20000 else 0.10
+        assert rel < bound, (i, ops.TENSOR_NAMES[i], rel, bound)
 
 
 @pytest.mark.parametrize("shape", [(3, 300, 16, 48), (2, 333, 16, 48), (60, 40, 16, 48), (300, 9, 16, 48)])
@@ -137,12 +167,11 @@ def test_fused_bf16_feature_kernel_matches_its_specification(dev, shape):
     np.testing.assert_allclose(ws.loss_terms.double().cpu()[:, 1:], o["terms"][:, 1:], rtol=5e-3, atol=1e-4)
     np.testing.assert_allclose(ws.loss_terms.double().cpu()[:, 0], o["terms"][:, 0], rtol=5e-2, atol=1e-3)
     gv = arena.views(ws.grads)
-    big = K * R * (n1 + n2) >= 20000
     for i in range(19):
         rel = rel_norm(gv[i], o["grads"][i])
         print(f"fused bf16 feat R={R} {ops.TENSOR_NAMES[i]:24s} rel {rel:.2e}")
-        bound = (0.08 if i in ops.FEAT_TENSORS else 0.06) if big else 0.12
-        assert rel < bound, (i, ops.TENSOR_NAMES[i], rel)
+        bound = v2_bound(ops.TENSOR_NAMES[i], i, True, R * 64)
+        assert rel < bound, (i, ops.TENSOR_NAMES[i], rel, bound)
 
 
 @pytest.mark.parametrize("feat", [False, True])
@@ -164,7 +193,9 @@ def test_fused_bf16_kernels_at_the_full_baseline_size(dev, feat):
         rel = rel_norm(gv[i], o["grads"][i])
         worst = max(worst, rel)
         print(f"full size feat={feat} {ops.TENSOR_NAMES[i]:24s} rel {rel:.2e}")
-        assert rel < (0.08 if i in ops.FEAT_TENSORS else 0.06), (i, ops.TENSOR_NAMES[i], rel)
+        # (round 5: the review's <= 3 % trunk / <= 4 % feature-branch and d B; measured worst 1.2 % / 1.7 % / 2.9 %)
+        name = ops.TENSOR_NAMES[i]
+        assert rel < V2_CAP[i in ops.FEAT_TENSORS or name == "B_layer.weight"], (i, name, rel)
     print(f"worst {worst:.2e}")
 
 
