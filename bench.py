@@ -103,6 +103,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-other-configs", action="store_true",
                     help="default line only: do not also time c3, configs[3]'s share and configs[4]'s share")
     ap.add_argument("--other-steps", type=int, default=10, help="timed steps of each `other_configs` entry")
+    ap.add_argument("--share-curve-out", default=None,
+                    help="also time the emulated 1 / 2 / 4 / 8-rank shares of c4 and c2 (fp32 and bf16, --steps each) and "
+                         "write the table to this file (profiles/r05_share_curve.json)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="CPU form of the N-rank launch: gloo instead of RCCL, the iteration's two collectives on host "
                          "buffers, no kernels; the line carries \"dry_launch\": true and value 0")
@@ -198,9 +201,16 @@ def flop_per_ray(S: int, H: int = 32, feat: bool = False) -> float:
     return 3.0 * 2.0 * (S * ms + (512 * H if feat else 0))
 
 
-def algorithmic_bytes(K, R, S, feat):
-    """SURVEY.md 8(d), points / z supplied: 16 B per sample + 17 B per ray (+ the fp32 target feature read once)."""
-    return K * R * (S * 16 + 17 + (2048 if feat else 0))
+def algorithmic_bytes(K, R, S, feat, scope="step"):
+    """SURVEY.md 8(d), points / z supplied: 16 B per sample + 17 B per ray.  With the feature loss the STEP also reads the
+    fp32 target feature once (2 KB per ray) -- but not the fused kernel: feat_pre_kernel / feat_post_kernel do, the fused
+    kernel reads their 34-float record per ray and writes its own 36-float one.  scope = "kernel" is
+    what the fused kernel's recorded FETCH / WRITE counters have to be compared with (round 4 compared them with the
+    step figure: traffic ratios below 1)."""
+    per_ray = S * 16 + 17
+    if feat:
+        per_ray += 2048 if scope == "step" else (34 + 36) * 4
+    return K * R * per_ray
 
 
 def recorded_counters(kernel: str, K, R, S):
@@ -324,7 +334,7 @@ class Workload:
         arena.load_stacked(obj_init.init_stacked(K, Hd, 512, seed=1000 + rank))
         keys = ["pts", "z", "gt_depth", "gt_rgb", "labels"] + (["gt_feat"] if feat else [])
         self.nb = 2 if Hd == 32 else 1  # resident batches, alternated so no step re-reads its own outputs
-        self.distinct = K if Hd == 32 else min(K, 8)     # (the stress shape re-uses 8 objects' rays for its 64 networks)
+        self.distinct = K                                    # every network trains on its own rays (round 5: configs[4] too)
         self.batches = []
         for i in range(self.nb):
             b = synthetic.random_batch(self.distinct, R, n1, n2, seed=4242 + 17 * rank + i, feat_dim=512 if feat else 0)
@@ -434,12 +444,16 @@ class Workload:
         achieved = K * R * fpr / (kern_ms * 1e-3) / 1e12
         peak = PEAK_BF16_MFMA_TFLOPS if mode else PEAK_F32_MFMA_TFLOPS
         rec = recorded_counters(kname, K, R, S)
-        alg = algorithmic_bytes(K, R, S, self.feat)
+        fused32 = self.Hd == 32 and S <= 64 and mode != "fp16"
+        alg = algorithmic_bytes(K, R, S, self.feat, scope="kernel" if fused32 else "step")
         roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                 "traffic": rec.get("hbm_bytes_per_launch") if rec else None,
                 "traffic_note": ("RECORDED, not measured by this run: " + rec["source"]) if rec else
                                 "no recorded PMC pass for this workload",
-                "kernel": kname, "kernel_ms": kern_ms, "flop_per_ray": fpr, "algorithmic_bytes_per_launch": alg}
+                "kernel": kname, "kernel_ms": kern_ms, "flop_per_ray": fpr, "algorithmic_bytes_per_launch": alg,
+                "algorithmic_bytes_scope": "the fused kernel (what `traffic` was recorded for)" if fused32 else "the step"}
+        if self.feat and fused32:
+            roof["step_algorithmic_bytes"] = algorithmic_bytes(K, R, S, True, scope="step")
         if rec:
             if rec.get("hbm_bytes_per_launch"):
                 roof["traffic_ratio"] = rec["hbm_bytes_per_launch"] / alg
@@ -507,6 +521,85 @@ def other_configs(args, dev):
             out[key] = entry
         except Exception as e:      # a failing extra must not cost the headline line; it is reported, not hidden
             out[key] = {"error": f"{type(e).__name__}: {e}"}
+    return out
+
+
+def share_curve(args, dev, steps):
+    """Emulated per-rank shares on ONE GPU (hardware-free; NO scaling curve is claimed): this process stands for one of
+    N = 1, 2, 4, 8 ranks -- configs[3] (strong scaling: 120 objects with the feature loss dealt to the ranks, 120 / N
+    here) and configs[1] (weak: 50 objects per rank) -- and takes that rank's 1200 / N of the iteration's background
+    rays as dist.shard_rays deals them.  NOT in it: the latency of the iteration's collectives (the background
+    gradient's 729 KB all-reduce, the pre-step int32[4]) and any xGMI effect.  efficiency = per-rank throughput at N
+    over the N = 1 figure (weak), or the speed-up of the step over N (strong)."""
+    names = {False: "f32", True: "bf16"}
+    out = {"note": "one GPU standing for one of N ranks; collective latency NOT included; no measured multi-GPU curve",
+           "steps": steps, "rows": []}
+    for cfgname, base in (("c4", "c4"), ("c2", "c2")):
+        t1 = {}
+        for n in (1, 2, 4, 8):
+            wl = dict(CONFIGS[base])
+            if wl["scaling"] == "strong":
+                wl.update(objects=wl["objects"] // n, scaling="weak")
+            wl["bg_ranks"] = n
+            try:
+                w = Workload(f"{cfgname}_share_of_{n}", wl, args, dev, 1, 0, False)
+                for mode in (False, True):
+                    dt, kms = w.timed(mode, steps, 3)
+                    ms = dt / steps * 1e3
+                    if n == 1:
+                        t1[mode] = ms
+                    strong = CONFIGS[base]["scaling"] == "strong"
+                    eff = (t1[mode] / ms / n) if strong else (t1[mode] / ms)
+                    out["rows"].append({"config": cfgname, "ranks": n, "dtype": names[mode], "objects_on_this_rank": w.K,
+                                        "background_rays_on_this_rank": int(w.bg_batches[0]["labels"].shape[1]),
+                                        "ms_per_step": ms, "kernel_ms": kms, "rays_per_s_per_rank": w.K * w.R / (ms * 1e-3),
+                                        "scaling": CONFIGS[base]["scaling"], "efficiency_vs_1": eff})
+                w.free()
+            except Exception as e:
+                out["rows"].append({"config": cfgname, "ranks": n, "error": f"{type(e).__name__}: {e}"})
+    return out
+
+
+def native_frame(dev, bf16=False, n_objects=50, frames=4):
+    """The mapping loop at the reference's NATIVE shape on the driver's clock (north_star's "stratified ray sampling"
+    included): synthetic 1200 x 680 frames, 50 objects + background, room_0 hyper-parameters (100 iterations of 120 rays x
+    10 samples per object, background 1200 rays x 14 samples; mapping.IncrementalMapper): per frame the ingestion, the
+    sample pools (objnerf_sample_rays_stacked, seeded draws), the 100 iterations with the copy-back.  Medians over the
+    frames after the first (which pays the allocations)."""
+    import numpy as np
+    import torch
+    from openobj_amd import cfg as ocfg, mapping, synthetic
+    c = ocfg.Config(ocfg.replica_room0_config(train_device=str(dev), **{"trainer.part_mode": 0}))
+    m = mapping.IncrementalMapper(c, bf16=bf16)
+    sync = torch.cuda.synchronize
+    rows = []
+    for i in range(frames):
+        s = synthetic.grid_frame(i, n_objects)
+        sync(); t0 = time.perf_counter()
+        m.ingest(s, i)
+        sync(); t1 = time.perf_counter()
+        m._ensure_stack()
+        pool, bg_pool = m.sample_pools()
+        sync(); t2 = time.perf_counter()
+        real = m.sample_pools
+        m.sample_pools = lambda: (pool, bg_pool)
+        m.train_frame()
+        m.sample_pools = real
+        sync(); t3 = time.perf_counter()
+        rows.append((1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (t3 - t2)))
+    r = np.median(np.array(rows[1:]), axis=0)
+    n_it = c.n_iter_per_frame
+    rays = n_objects * c.n_per_optim * n_it
+    out = {"workload": f"{n_objects} objects + background, 1200 x 680 frames, {n_it} iterations x {c.n_per_optim} rays x "
+                       f"{c.n_bins_cam2surface + c.n_bins} samples per object, background {c.n_per_optim_bg} rays x "
+                       f"{c.n_bins_cam2surface_bg + c.n_bins} samples, hidden 32 / 128, {'bf16' if bf16 else 'fp32'}",
+           "ingest_ms": float(r[0]), "sample_pools_ms": float(r[1]), "iterations_ms": float(r[2]),
+           "ms_per_iteration": float(r[2] / n_it), "frame_ms": float(r.sum()),
+           "object_rays_per_s": rays / (float(r.sum()) * 1e-3), "frames_timed": frames - 1,
+           "hbm_gb": torch.cuda.memory_allocated() / 2 ** 30}
+    del m
+    sync()
+    torch.cuda.empty_cache()
     return out
 
 
@@ -647,6 +740,17 @@ def main():
     if rank == 0:
         if world == 1 and default_line and not args.no_other_configs:
             out["other_configs"] = other_configs(args, dev)
+            for key, fn in (("native_frame", lambda: native_frame(dev)), ("native_frame_bf16", lambda: native_frame(dev, True)),
+                            ("share_curve", lambda: share_curve(args, dev, max(10, args.other_steps)))):
+                try:
+                    out["other_configs"][key] = fn()
+                except Exception as e:
+                    out["other_configs"][key] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and args.share_curve_out:
+            sc = share_curve(args, dev, args.steps)
+            with open(args.share_curve_out, "w") as f:
+                json.dump(sc, f, indent=1)
+            out["share_curve_file"] = args.share_curve_out
         if world == 1 and not args.no_psnr and Hd == 32:
             ps = psnr_block(dev, args.psnr_seeds, with_bf16=args.bf16_line or mode is True, with_fp16=mode == "fp16")
             if ps is not None:
@@ -660,6 +764,41 @@ def main():
                 out["psnr_delta_iter50_ci95_db"] = ps["iter50"][key]["ci95_db"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(feat)
+        # what the line's figures mean has changed before (round 4: psnr_delta_db became the 300-iteration ensemble figure,
+        # kernel_ms moved inside the timed steps); versioned since round 5, whose changes are listed here
+        out["metric_version"] = 5
+        out["metric_changes"] = ("v5: objnerf_train_step applies AdamW in its last launch, so roofline.kernel_ms (HIP events "
+                                 "around objnerf_train_step, inside the timed steps) now includes the optimiser; the "
+                                 "background chain of step i may run under the object kernel of step i + 1 (--no-pipeline "
+                                 "restores the per-step join); algorithmic_bytes_per_launch of the feature configs is the "
+                                 "fused kernel's scope; c5 trains 64 distinct ray sets; other_configs.c4_share stands "
+                                 "for one of 8 ranks WITHOUT the gradient all-reduce it would take part in")
+        # LAST in the line (the driver records its tail): the figures a reader looks for first
+        summ = {"f32_rays_per_s": out["value"] if args.dtype == "f32" else None, "f32_ms_per_step": out["ms_per_step"]
+                if args.dtype == "f32" else None, "f32_roofline_frac": out["roofline"]["frac"] if args.dtype == "f32" else None}
+        if "bf16_mode" in out:
+            summ.update({"bf16_rays_per_s": out["bf16_mode"]["value"], "bf16_ms_per_step": out["bf16_mode"]["ms_per_step"],
+                         "bf16_roofline_frac": out["bf16_mode"]["roofline"]["frac"],
+                         "bf16_kernel_ms": out["bf16_mode"]["roofline"]["kernel_ms"]})
+        oc = out.get("other_configs", {})
+        for key in ("c3", "c4_share", "c5_share_fp16"):
+            for m_ in ("f32", "bf16", "fp16"):
+                if isinstance(oc.get(key), dict) and m_ in oc[key]:
+                    summ[f"{key}_{m_}_rays_per_s"] = oc[key][m_]["value"]
+                    summ[f"{key}_{m_}_ms_per_step"] = oc[key][m_]["ms_per_step"]
+        for key in ("native_frame", "native_frame_bf16"):
+            if isinstance(oc.get(key), dict) and "frame_ms" in oc[key]:
+                summ[f"{key}_ms"] = oc[key]["frame_ms"]
+                summ[f"{key}_ms_per_iteration"] = oc[key]["ms_per_iteration"]
+        if isinstance(oc.get("share_curve"), dict):
+            summ["share_curve_efficiency_at_8"] = {f"{r['config']}_{r['dtype']}": round(r["efficiency_vs_1"], 3)
+                                                   for r in oc["share_curve"]["rows"] if r.get("ranks") == 8 and "dtype" in r}
+        for k_ in ("psnr_delta_db", "psnr_delta_ci95_db"):
+            if k_ in out:
+                summ[k_] = out[k_]
+        if "cpu_baseline" in out:
+            summ["cpu_baseline_rays_per_s"] = out["cpu_baseline"]["value"]
+        out["summary"] = summ
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(512, 8) void gemm_kernel8(const Gemm g) {
 // Several independent GEMMs in ONE launch (the weight-gradient GEMMs of a small-batch step: each alone is ~260
 // workgroups of latency-bound work): blockIdx.z runs over the concatenated (batch x split-K) slices of all of them.
 struct GemmGroup {
-  static constexpr int MAXG = 10;
+  static constexpr int MAXG = 11;
   int count;
   int zbeg[MAXG + 1];
   Gemm g[MAXG];
@@ -774,7 +774,7 @@ struct RedItem {
 struct RedTail {
   const float* loss_part = nullptr; int loss_blocks, K; float* loss_terms; int* status;      // loss_part == NULL: no tail
   float* params = nullptr; const float* grads; float* m; float* v; const int* flags; int* steps; int bank;   // params == NULL: no AdamW
-  long p_stride, lo1, lo2, hi2;
+  long p_stride, lo1, lo2, hi2, arena_floats;      // (sums that land outside [grads, grads + arena_floats) are not parameters' gradients)
   double lr, b1, b2, wd; float eps;
 };
 struct RedGroup {
@@ -866,8 +866,8 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(const RedGroup gr) {
       dst = r.rowsum + z * r.bsrs + (q - per);
     }
     *dst = sum;
-    if (tl.params) {
-      const long idx = dst - tl.grads;                       // position in the gradient arena = in params / moments
+    const long idx = dst - tl.grads;                         // position in the gradient arena = in params / moments
+    if (tl.params && idx >= 0 && idx < tl.arena_floats) {    // (the 512-d head's moment sums go to the workspace)
       const long pi = idx % tl.p_stride;
       const int g = (pi >= tl.lo1 && pi < tl.lo2) ? 1 : ((pi >= tl.lo2 && pi < tl.hi2) ? 2 : 0);
       if (s_active[g]) {
@@ -2070,11 +2070,11 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
   // grouped weight gradients, one reduction launch (objnerf_small_body.h)
   {
     const int S = a->S;
-    const int rpw = S > 0 && S <= 64 ? 80 / S : 0;
+    const int rpw = S > 0 && S <= 64 ? sf_rays_per_wg(S, feat) : 0;
     const long nwg = rpw ? ((long)a->R + rpw - 1) / rpw : 0;
 #ifndef OBJ_NO_SMALL_FUSED
-    if (H == FS_H && !feat && S >= 4 && S <= 64 && (long)K * nwg <= 1536 && !half_acts && K <= 65535 &&
-        !(a->mode & OBJNERF_TRAIN_LAYERWISE && K > 8))
+    if (H == FS_H && S >= 4 && S <= 64 && (long)K * nwg <= 1536 && !half_acts && K <= 65535 &&
+        !(a->mode & OBJNERF_TRAIN_LAYERWISE && K > 8) && (!feat || (C % 4 == 0 && a->R >= 1)))
       return train_step_small(net, a, st, E, w, off, E.operands == 1, done);
 #endif
   }
@@ -2413,9 +2413,10 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
 // the caller's stream: three dependent launches need no helper stream and no events.
 static int train_step_small(const objnerf_net* net, const objnerf_train_args* a, hipStream_t st, GemmEnv& E, const WS& w,
                             const int64_t* off, bool bf, int* done) {
-  const int H = net->hidden, K = a->K, S = a->S;
+  const int H = net->hidden, K = a->K, S = a->S, C = net->feat_dim;
   const long n = (long)a->R * S, nH = n * H, ps = a->p_stride;
-  const int rpw = 80 / S;
+  const bool feat = a->gt_feat != nullptr;
+  const int rpw = sf_rays_per_wg(S, feat);
   const int nwg = (int)(((long)a->R + rpw - 1) / rpw);
   const int E1 = OBJ_E1, E2 = OBJ_E2, EM = OBJ_EMB;
   const float* P = a->params;
@@ -2426,8 +2427,23 @@ static int train_step_small(const objnerf_net* net, const objnerf_train_args* a,
                                          (void*)st);
     if (rc0) return rc0;
   }
+  const long R = a->R;
+  const int XC = H + 1;
+  if (feat) {
+    // the 512-d head is NOT applied per sample: per object G = W_of^T W_of (+ wb, bb), per ray
+    // u = W_of^T g, beta, |g| -- none of it depends on the forward pass; four small launches ahead of the fused one
+    const long gst = (long)H * H + H + 1;
+    E.operands = 0;
+    gemm(E, st, K, H, H, C, P + off[16], 1, H, ps, P + off[16], H, 1, ps, w.gram, H, 1, gst);
+    hipLaunchKernelGGL(featg_wb_kernel, dim3(H + 1, K), dim3(64), 0, st, P, ps, (int)off[16], (int)off[17], C, H, w.gram, gst);
+    gemm(E, st, K, (int)R, H, C, a->gt_feat, C, 1, R * C, P + off[16], H, 1, ps, w.rayin, H + 2, 1, R * (H + 2));
+    hipLaunchKernelGGL(featg_rowstats_kernel, dim3((unsigned)((R + 15) / 16), K), dim3(256), 0, st, P, ps, (int)off[17], C,
+                       (int)R, H + 2, a->gt_feat, w.rayin);
+  }
   SmallFused f;
   f.K = K; f.R = a->R; f.S = S; f.rpw = rpw;
+  f.fs = a->feat_scaling; f.o_fl_w = (int)off[14]; f.o_fl_b = (int)off[15];
+  f.rayin = w.rayin; f.gram = w.gram; f.hf = w.hf; f.d_hf = w.d_hf; f.rayfeat = w.rayfeat; f.X1 = w.X1; f.X2 = w.X2;
   f.params = P; f.ps = ps; f.scale = a->scale;
   f.pts = a->pts; f.origins = a->origins; f.dirs = a->dirs; f.z = a->z; f.centre = a->obj_center;
   f.gt_depth = a->gt_depth; f.gt_rgb = a->gt_rgb; f.labels = a->labels;
@@ -2448,14 +2464,20 @@ static int train_step_small(const objnerf_net* net, const objnerf_train_args* a,
   f.o_cat_w = (int)off[4]; f.o_cat_b = (int)off[5]; f.o_m2_w = (int)off[6]; f.o_m2_b = (int)off[7];
   f.o_a_w = (int)off[8]; f.o_a_b = (int)off[9]; f.o_cl_w = (int)off[10]; f.o_cl_b = (int)off[11];
   f.o_oc_w = (int)off[12]; f.o_oc_b = (int)off[13]; f.o_B = (int)off[18];
-  if (rpw * S <= 64) launch_train_small<4>(st, f, nwg, bf);
-  else launch_train_small<5>(st, f, nwg, bf);
+  if (feat) {
+    if (rpw * S <= 64) launch_train_small<4, true>(st, f, nwg, bf);
+    else launch_train_small<5, true>(st, f, nwg, bf);
+  } else {
+    if (rpw * S <= 64) launch_train_small<4, false>(st, f, nwg, bf);
+    else launch_train_small<5, false>(st, f, nwg, bf);
+  }
   if (hipGetLastError() != hipSuccess) return OBJNERF_ELAUNCH;
   if (a->relu_masks) {       // test hook: the ReLU branch bits of this iteration, from the stored activations
-    const float* acts[5] = {w.h1, w.h2, w.h3, w.h4, w.hc};
+    const float* acts[6] = {w.h1, w.h2, w.h3, w.h4, w.hc, feat ? w.hf : nullptr};
     const long nb = (long)K * n * (H / 8);
-    for (int l = 0; l < 5; ++l)
-      hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, nb, H, acts[l], a->relu_masks, l, 0);
+    for (int l = 0; l < 6; ++l)
+      if (acts[l])
+        hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, nb, H, acts[l], a->relu_masks, l, 0);
   }
   // ---- the step's reductions, collected: head partials, d B partials, the weight gradients' split-K slices
   RedGroup red;
@@ -2489,7 +2511,7 @@ static int train_step_small(const objnerf_net* net, const objnerf_train_args* a,
     if (want < 36) want = 36;
     // whole rounds of the chip: 7 GEMMs x slices workgroups on num_cu compute units (75 slices = 525 workgroups left a
     // third round for 13 of them: 260 us against 227)
-    const int cu = 256, ng = 7;
+    const int cu = 256, ng = feat ? 9 : 7;
     long rounds = (want * ng + cu / 2) / cu;
     if (rounds < 1) rounds = 1;
     E.max_slices = (int)(rounds * cu / ng);
@@ -2501,20 +2523,49 @@ static int train_step_small(const objnerf_net* net, const objnerf_train_args* a,
   wgrad(E, st, K, H, E1, n, f.d_h3, 1, H, nH, w.emb, EM, 1, n * EM, G + off[4] + H, H + E1, ps);
   wgrad(E, st, K, H, H, n, f.d_h2, 1, H, nH, w.h1, H, 1, nH, G + off[2], H, ps, G + off[3]);
   wgrad(E, st, K, H, E1, n, f.d_h1, 1, H, nH, w.emb, EM, 1, n * EM, G + off[0], E1, ps, G + off[1]);
+  if (feat) {
+    // feature layer
+    wgrad(E, st, K, H, H, n, f.d_hf, 1, H, nH, w.h4, H, 1, nH, G + off[14], H + E2, ps, G + off[15]);
+    wgrad(E, st, K, H, E2, n, f.d_hf, 1, H, nH, w.emb + E1, EM, 1, n * EM, G + off[14] + H, H + E2, ps);
+  }
   if (E.parts_failed || E.error) return OBJNERF_EINVAL;
   flush_group(E, st, group);
+  if (feat) {
+    // the 512-d head's moments over the RAYS: T = gt_feat^T [a fh | a O], M = [c fh | c O]^T [fh | O] (featg_finish_kernel
+    // turns them into d W_of, d b_of after the reduction).  Two launches of their own: inside the grouped launch their
+    // 512-row output made it 5x slower (1.82 against 0.35 ms at the benchmark's background batch -- every GEMM of the
+    // group is then launched over four row tiles)
+    E.group = nullptr; E.group16 = false; E.operands = 0; E.red_group = &red; E.max_slices = 0;
+    wgrad(E, st, K, C, XC, R, a->gt_feat, 1, C, R * C, w.X1, XC, 1, R * XC, w.Tm, XC, (long)C * XC);
+    wgrad(E, st, K, XC, XC, R, w.X2, 1, XC, R * XC, w.rayfeat, H + 3, 1, R * (H + 3), w.mom, XC, (long)XC * XC);
+    if (E.parts_failed || E.error) return OBJNERF_EINVAL;
+  }
   red.tail.loss_part = f.loss_part; red.tail.loss_blocks = nwg; red.tail.K = K; red.tail.loss_terms = a->loss_terms;
   red.tail.status = a->status;
   if (a->optim) {
     const objnerf_adamw_args* o = a->optim;
     RedTail& t = red.tail;
     t.params = const_cast<float*>(a->params); t.grads = G; t.m = o->exp_avg; t.v = o->exp_avg_sq; t.flags = a->flags;
-    t.steps = o->group_steps; t.bank = o->bank; t.p_stride = ps;
+    t.steps = o->group_steps; t.bank = o->bank; t.p_stride = ps; t.arena_floats = (long)K * ps;
     t.lo1 = off[10]; t.lo2 = off[14]; t.hi2 = off[18];
     t.lr = (double)o->lr; t.b1 = (double)o->beta1; t.b2 = (double)o->beta2; t.wd = (double)o->weight_decay; t.eps = o->eps;
     if (done) *done |= 2;
   }
   launch_reductions(st, red);
+  if (feat) {
+    hipLaunchKernelGGL(featg_finish_kernel, dim3((unsigned)(((long)C * XC + 255) / 256), K), dim3(256), 0, st, P, ps,
+                       (int)off[16], (int)off[17], C, H, w.Tm, w.mom, G);
+    if (a->optim) {               // the head's own entries [of_w, pe_b): their gradient exists only now
+      const objnerf_adamw_args* o = a->optim;
+      // (entries [off[16], off[18]) only: "P" = off[18] with [0, off[16]) skipped -- B's gradient behind them was stepped
+      // by the reduction launch)
+      const int rc = objmisc::adamw_flags_range(K, off[18], ps, const_cast<float*>(a->params), G, o->exp_avg,
+                                                o->exp_avg_sq, nullptr, a->flags, o->group_steps, o->bank, off[10], off[14],
+                                                off[18], 0, off[16], o->lr, o->beta1, o->beta2, o->eps, o->weight_decay,
+                                                (void*)st);
+      if (rc) return rc;
+    }
+  }
   if (hipGetLastError() != hipSuccess) return OBJNERF_ELAUNCH;
   return OBJNERF_OK;
 }

@@ -41,15 +41,35 @@ struct SmallFused {
   float* pe_part;                         // [K][nwg][63]
   float* loss_part;                       // [K][nwg][4]
   int o_in_w, o_in_b, o_m1_w, o_m1_b, o_cat_w, o_cat_b, o_m2_w, o_m2_b, o_a_w, o_a_b, o_cl_w, o_cl_b, o_oc_w, o_oc_b, o_B;
+  // feature-distillation branch (FEAT; the 512-d head hoisted past the compositing): inputs from the
+  // preparation launches, outputs for the weight-gradient launches
+  float fs; int o_fl_w, o_fl_b;
+  const float* rayin;                     // [K][R][H + 2]  u = W_of^T g, beta = b_of . g, |g|
+  const float* gram;                      // [K][H H + H + 1]  G = W_of^T W_of (symmetric), wb = W_of^T b_of, bb
+  float *hf, *d_hf;                       // [K][n][128]  feature hidden / its pre-activation gradient
+  float* rayfeat;                         // [K][R][H + 3]  fh, O, a, c
+  float *X1, *X2;                         // [K][R][H + 1]  [a fh | a O], [c fh | c O]  (featg_scale_kernel's outputs)
 };
 constexpr int SF_SMALL = 1536;            // floats of small LDS arrays (below)
-template <int RT> constexpr size_t sf_lds_bytes() { return (size_t)((FS_H + 2 * 16 * RT) * FS_P + SF_SMALL) * sizeof(float); }
+constexpr int SF_FEAT_RT4 = 5632, SF_FEAT_RT5 = 1408;      // extra small arrays of the feature branch (floats): RT 4 / RT 5
+template <int RT, bool FEAT = false> constexpr size_t sf_lds_bytes() {
+  return (size_t)((FS_H + 2 * 16 * RT) * FS_P + SF_SMALL + (FEAT ? (RT == 5 ? SF_FEAT_RT5 : SF_FEAT_RT4) : 0)) * sizeof(float);
+}
+// rays per workgroup: as many whole rays as 80 rows hold (16 RT <= 80); with the feature branch the composited hidden and
+// its gradient (2 x 128 floats per ray) live in LDS too -- at most 5 rays beside an 80-row tile, 20 beside a 64-row one
+__host__ __device__ inline int sf_rays_per_wg(int S, bool feat) {
+  int rpw = 80 / S;
+  if (feat && rpw > 5) rpw = 64 / S;
+  return rpw;
+}
 
 __device__ __forceinline__ float sf_sgn(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
 
-template <int RT, bool BF>
+template <int RT, bool BF, bool FEAT>
 __global__ __launch_bounds__(512) void train_small_kernel(const SmallFused a) {
   constexpr int BM = 16 * RT, H = FS_H, PT = FS_P, PW = BS_PW;
+  constexpr int MAXRAY = RT == 5 ? 5 : 20;         // rays per workgroup with the feature branch (sf_rays_per_wg)
+  static_assert(!FEAT || (BM + 2 * MAXRAY * FS_H + 4 * MAXRAY <= (RT == 5 ? SF_FEAT_RT5 : SF_FEAT_RT4)), "feature LDS arrays");
   static_assert(BM * 12 + 32 + 128 * 3 + 48 * 3 + 16 <= SF_SMALL, "small LDS arrays");
   extern __shared__ __attribute__((aligned(16))) float fs_lds[];
   float* Wb = fs_lds;                   // forward: [out][in] pitch 132; backward: [k = out][n = in] pitch 130
@@ -63,6 +83,11 @@ __global__ __launch_bounds__(512) void train_small_kernel(const SmallFused a) {
   float* s_pe1 = s_red + 32;            // [128][3] d B contributions per x1 column
   float* s_pe2 = s_pe1 + 128 * 3;       // [48][3]  ... per x2 column
   int* s_cnt = reinterpret_cast<int*>(s_pe2 + 48 * 3);      // [16]
+  // feature branch
+  float* s_wt = reinterpret_cast<float*>(s_cnt + 16);       // [BM]           ray weight of every sample; later d loss / d weight (feature part)
+  float* s_fh = s_wt + BM;                                   // [MAXRAY][128]  composited feature hidden
+  float* s_dfh = s_fh + MAXRAY * H;                          // [MAXRAY][128]  d loss / d fh
+  float* s_rayf = s_dfh + MAXRAY * H;                        // [MAXRAY][4]    O, m1, gof of the ray
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int c = lane & 15, gg = lane >> 4;
   const long z = blockIdx.y;
@@ -364,11 +389,14 @@ __global__ __launch_bounds__(512) void train_small_kernel(const SmallFused a) {
   const float woc0_f = P[a.o_oc_w + fb], woc1_f = P[a.o_oc_w + H + fb], woc2_f = P[a.o_oc_w + 2 * H + fb];
   __syncthreads();
   // ---- a wave per ray: occupancy_activation / occupancy_to_termination / render (render_rays.py:6-63), the loss terms
-  // of loss.py:27-79 and their gradients -- loss_kernel's arithmetic (objnerf_misc.hip) on one 64-lane chunk (S <= 64)
-  {
-    const float inv1 = fl0 ? 0.0f : 1.0f / ((float)n1i + 1e-10f);
-    const float inv2 = fl1 ? 0.0f : 1.0f / ((float)n2i + 1e-10f);
-    float lt0 = 0.f, lt1 = 0.f, lt2 = 0.f;
+  // of loss.py:27-79 and their gradients -- loss_kernel's arithmetic (objnerf_misc.hip) on one 64-lane chunk (S <= 64).
+  // With the feature branch the pass runs twice: FIRST without the feature term's d loss / d weight (it yields the ray
+  // weights, the loss terms, the rays' opacity and the colour head's gradients, none of which depend on it), and again
+  // once that term is known (s_wt then holds it), for d alpha alone.
+  const float inv1 = fl0 ? 0.0f : 1.0f / ((float)n1i + 1e-10f);
+  const float inv2 = fl1 ? 0.0f : 1.0f / ((float)n2i + 1e-10f);
+  float lt0 = 0.f, lt1 = 0.f, lt2 = 0.f, lt3 = 0.f;
+  auto composite = [&](const bool first, const bool with_dwv) {
     const bool on = lane < S;
     for (int lr = w; lr < ((SM_ABL & 8) ? 0 : nr); lr += 8) {
       const long rr = z * a.R + ray0 + lr;
@@ -397,10 +425,13 @@ __global__ __launch_bounds__(512) void train_small_kernel(const SmallFused a) {
       const float gD = m1 * sf_sgn(rd) * info * inv1;
       const float gC0 = a.cs * m1 * sf_sgn(r0) * inv1, gC1 = a.cs * m1 * sf_sgn(r1) * inv1, gC2 = a.cs * m1 * sf_sgn(r2) * inv1;
       const float gO = a.os * m2 * sf_sgn(ro) * inv2;
-      lt0 += m1 * fabsf(rd) * info * inv1;
-      lt1 += m1 * (fabsf(r0) + fabsf(r1) + fabsf(r2)) * inv1;
-      lt2 += m2 * fabsf(ro) * inv2;
-      const float dw = on ? gD * zz + gO + gC0 * c0 + gC1 * c1 + gC2 * c2 : 0.f;
+      if (first) {
+        lt0 += m1 * fabsf(rd) * info * inv1;
+        lt1 += m1 * (fabsf(r0) + fabsf(r1) + fabsf(r2)) * inv1;
+        lt2 += m2 * fabsf(ro) * inv2;
+      }
+      const float dwf = (with_dwv && on) ? s_wt[m] : 0.0f;        // (second pass: the feature term's d loss / d weight)
+      const float dw = on ? gD * zz + gO + gC0 * c0 + gC1 * c1 + gC2 * c2 + dwf : 0.f;
       const float qv = dw * wt;
       const float inc = SegRows::make(64, lane).rscan_add(qv, lane);
       const float suf = inc - qv;
@@ -409,38 +440,158 @@ __global__ __launch_bounds__(512) void train_small_kernel(const SmallFused a) {
         const float da = docc * occ * (1.0f - occ);
         float* dh = s_dh + 4 * m;                 // heads_bwd_kernel: dhead = (10 d_alpha, d_colour * c (1 - c))
         dh[0] = 10.0f * da;
-        dh[1] = (gC0 * wt) * c0 * (1.0f - c0);
-        dh[2] = (gC1 * wt) * c1 * (1.0f - c1);
-        dh[3] = (gC2 * wt) * c2 * (1.0f - c2);
+        if (first) {
+          dh[1] = (gC0 * wt) * c0 * (1.0f - c0);
+          dh[2] = (gC1 * wt) * c1 * (1.0f - c1);
+          dh[3] = (gC2 * wt) * c2 * (1.0f - c2);
+        }
+      }
+      if (FEAT && first) {
+        if (on) s_wt[m] = wt;
+        if (lane == 0) { s_rayf[4 * lr] = O; s_rayf[4 * lr + 1] = m1; }
       }
     }
-    if (lane == 0) { s_red[4 * w] = lt0; s_red[4 * w + 1] = lt1; s_red[4 * w + 2] = lt2; s_red[4 * w + 3] = 0.f; }
+  };
+  // head weight-gradient partials of this workgroup (head_wgrad_kernel's sums over the rows in LDS): d wa[f] = sum_m
+  // dhead[m][0] h4[m][f] (q = 0), d Woc[x][f] = sum_m dhead[m][1 + x] hc[m][f] (q = 1..3); biases = column sums of dhead
+  auto head_partials = [&](const int q_lo, const int q_hi) {
+    const int q = tid >> 7;                    // 0: alpha head (h4 = Xb), 1..3: colour head rows (hc = Xc)
+    if (q >= q_lo && q <= q_hi) {
+      const float* X = q == 0 ? Xb : Xc;
+      float sacc = 0.f;
+      for (int m = 0; m < rows; ++m) sacc = fmaf(s_dh[4 * m + q], X[m * PT + kk], sacc);
+      if (q == 0) a.partA[zb * H + kk] = sacc;
+      else a.partW[(zb * 3 + (q - 1)) * H + kk] = sacc;
+    }
+    if (tid < 4 && tid >= q_lo && tid <= q_hi) {
+      float b = 0.f;
+      for (int m = 0; m < rows; ++m) b += s_dh[4 * m + tid];
+      if (tid == 0) a.rsA[zb] = b; else a.rsW[zb * 3 + tid - 1] = b;
+    }
+  };
+  composite(true, false);
+  unsigned mkf = 0;
+  if constexpr (!FEAT) {
+    __syncthreads();
+    head_partials(0, 3);
+  } else {
+    // ================= feature branch: hf = relu([h4 | x2] W_fl^T + b) (model.py:98-101), fh = sum_s w_s hf_s per ray, the
+    // cosine term in Gram form (loss.py:81-99 through DESIGN.md 4.3: loss_kernel's hoisted arithmetic), d loss / d fh ->
+    // d hf and the feature part of d loss / d weight
+    __syncthreads();                             // dhead's colour columns, s_wt, s_rayf
+    head_partials(1, 3);                         // (the colour head's weights need hc, which the next staging overwrites)
+    fetch_w(P + a.o_fl_w, H + OBJ_E2, H);
+    __syncthreads();
+    put_wf();
+    __syncthreads();
+    fetch_w(P + a.o_fl_w + H, H + OBJ_E2, OBJ_E2);
+    bv = P[a.o_fl_b + fb];
+    zero(acc);
+    mma_f(Xb, H);
+    __syncthreads();
+    put_wf();
+    __syncthreads();
+    // (the object's Gram matrix G = W_of^T W_of, 64 KB, takes the weight buffer next: the feature layer's weights are
+    // dead after this contraction and the backward's first block is staged after the loss)
+    const float* Gk = a.gram + z * ((long)H * H + H + 1);
+    fetch_w(Gk, H, H);
+    mma_f(Xa, E2P);
+    __syncthreads();
+    mkf = store(Xa, a.hf, bv);                   // hf replaces x2 in LDS (its ReLU mask is the sign of these values)
+    (void)mkf;
+    put_wf();                                    // Wb <- G
+    __syncthreads();
+    fetch_w(P + a.o_fl_w, H + OBJ_E2, H);       // (the backward's first weight block)
+    // fh[ray][f] = sum_s w_s hf[s][f]      (thread (f, q) takes rays q, q + 4, ..; s ascending as loss_kernel)
+    for (int lr = rg; lr < nr; lr += 4) {
+      float f = 0.f;
+      for (int si = 0; si < S; ++si) f = fmaf(s_wt[lr * S + si], Xa[(lr * S + si) * PT + kk], f);
+      s_fh[lr * H + kk] = f;
+    }
+    __syncthreads();
+    {
+      const float* wbv = Gk + (long)H * H;
+      const float bb = wbv[H];
+      for (int lr = w; lr < nr; lr += 8) {       // a wave per ray; lane owns entries lane, lane + 64
+        const long rr = z * a.R + ray0 + lr;
+        const float* rin = a.rayin + rr * (H + 2);
+        const float* fhr = s_fh + lr * H;
+        // G fh from the LDS copy of G (rows lane, lane + 64; 16-byte reads, conflict-free at the 132-float pitch; the
+        // first build read G's columns from L2 inside this loop: 128 load latencies per ray, +1.2 ms on configs[2])
+        float gf0 = 0.f, gf1 = 0.f;
+        const float* g0p = Wb + lane * PT;
+        const float* g1p = Wb + (lane + 64) * PT;
+#pragma unroll 8
+        for (int h2 = 0; h2 < H; h2 += 4) {
+          const f32x4 fv = *reinterpret_cast<const f32x4*>(fhr + h2);
+          const f32x4 ga = *reinterpret_cast<const f32x4*>(g0p + h2), gb = *reinterpret_cast<const f32x4*>(g1p + h2);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { gf0 = fmaf(ga[e], fv[e], gf0); gf1 = fmaf(gb[e], fv[e], gf1); }
+        }
+        const float f0 = fhr[lane], f1 = fhr[lane + 64];
+        const float u0 = rin[lane], u1 = rin[lane + 64], wb0 = wbv[lane], wb1 = wbv[lane + 64];
+        const float fu = wave_sum64(fmaf(f1, u1, f0 * u0));
+        const float fGf = wave_sum64(fmaf(f1, gf1, f0 * gf0));
+        const float fwb = wave_sum64(fmaf(f1, wb1, f0 * wb0));
+        const float O = s_rayf[4 * lr], m1 = s_rayf[4 * lr + 1];
+        const float beta = rin[H], ngv = rin[H + 1];
+        const float dotFg = fu + O * beta;
+        const float nF2 = fmaxf(fGf + 2.0f * O * fwb + O * O * bb, 0.0f);
+        const float nF = fmaxf(sqrtf(nF2), 1e-8f), ngc = fmaxf(ngv, 1e-8f);
+        const float cosv = dotFg / (nF * ngc);
+        lt3 += m1 * (1.0f - cosv) * inv1;
+        const float gam = -a.fs * m1 * inv1;                 // d total / d cos
+        const float ar = gam / (nF * ngc), cr = -gam * cosv / (nF * nF);
+        const float gof = ar * beta + cr * (fwb + O * bb);   // d total / d opacity (feature part)
+        float* rf = a.rayfeat + rr * (H + 3);
+        float* x1o = a.X1 + rr * (H + 1);
+        float* x2o = a.X2 + rr * (H + 1);
+        rf[lane] = f0; rf[lane + 64] = f1;
+        x1o[lane] = ar * f0; x1o[lane + 64] = ar * f1;
+        x2o[lane] = cr * f0; x2o[lane + 64] = cr * f1;
+        if (lane == 0) {
+          rf[H] = O; rf[H + 1] = ar; rf[H + 2] = cr;
+          x1o[H] = ar * O; x2o[H] = cr * O;
+          s_rayf[4 * lr + 2] = gof;
+        }
+        s_dfh[lr * H + lane] = ar * u0 + cr * (gf0 + O * wb0);   // d total / d fh
+        s_dfh[lr * H + lane + 64] = ar * u1 + cr * (gf1 + O * wb1);
+      }
+    }
+    __syncthreads();
+    // per sample (a wave per row): the feature part of d loss / d weight = gof + d fh . hf, and hf -> d hf in place
+    // (pre-activation gradient of the feature layer: relu'(hf) w_s d fh)
+    {
+      float* out = a.d_hf + (z * n + m0) * H;
+      for (int m = w; m < rows; m += 8) {
+        const int lr = m / S;
+        const float h0 = Xa[m * PT + lane], h1 = Xa[m * PT + lane + 64];
+        const float d0 = s_dfh[lr * H + lane], d1 = s_dfh[lr * H + lane + 64];
+        const float pp = wave_sum64(fmaf(d1, h1, d0 * h0));
+        const float wt = s_wt[m];
+        const float g0 = h0 > 0.0f ? wt * d0 : 0.0f, g1 = h1 > 0.0f ? wt * d1 : 0.0f;
+        Xa[m * PT + lane] = g0; Xa[m * PT + lane + 64] = g1;
+        out[(long)m * H + lane] = g0; out[(long)m * H + lane + 64] = g1;
+        if (lane == 0) s_wt[m] = s_rayf[4 * lr + 2] + pp;
+      }
+      for (int m = rows + w; m < BM; m += 8) { Xa[m * PT + lane] = 0.f; Xa[m * PT + lane + 64] = 0.f; }
+    }
+    __syncthreads();
+    composite(false, true);                      // d alpha with the feature term
+    __syncthreads();
+    head_partials(0, 0);
   }
+  if (lane == 0) { s_red[4 * w] = lt0; s_red[4 * w + 1] = lt1; s_red[4 * w + 2] = lt2; s_red[4 * w + 3] = lt3; }
   __syncthreads();
   if (tid < 4) {
     float v = 0.f;
     for (int q = 0; q < 8; ++q) v += s_red[4 * q + tid];
     a.loss_part[zb * 4 + tid] = v;
   }
-  // ---- head weight-gradient partials of this workgroup (head_wgrad_kernel's sums over the rows in LDS):
-  // d wa[f] = sum_m dhead[m][0] h4[m][f], d Woc[x][f] = sum_m dhead[m][1 + x] hc[m][f]; biases = column sums of dhead
-  {
-    const int q = tid >> 7;                    // 0: alpha head (h4 = Xb), 1..3: colour head rows (hc = Xc)
-    const float* X = q == 0 ? Xb : Xc;
-    float s = 0.f;
-    for (int m = 0; m < rows; ++m) s = fmaf(s_dh[4 * m + q], X[m * PT + kk], s);
-    if (q == 0) a.partA[zb * H + kk] = s;
-    else a.partW[(zb * 3 + (q - 1)) * H + kk] = s;
-    if (tid < 4) {
-      float b = 0.f;
-      for (int m = 0; m < rows; ++m) b += s_dh[4 * m + tid];
-      if (tid == 0) a.rsA[zb] = b; else a.rsW[zb * 3 + tid - 1] = b;
-    }
-  }
-  // ---- d_hc = relu'(hc) Woc^T d_craw -> Da (the backward's first operand) and HBM
+  // ---- d_hc = relu'(hc) Woc^T d_craw -> Da (the colour layer's backward operand) and HBM
   float* Da = Xa;
   float* Db = Xb;
-  {
+  auto form_dhc = [&]() {
     float* out = a.d_hc + (z * n + m0) * H;
 #pragma unroll
     for (int i = 0; i < RT; ++i)
@@ -453,7 +604,8 @@ __global__ __launch_bounds__(512) void train_small_kernel(const SmallFused a) {
         Da[m * PT + fb] = v;
         if (m < rows) out[(long)m * H + fb] = v;
       }
-  }
+  };
+  if constexpr (!FEAT) form_dhc();
   __syncthreads();                             // Xb (h4) / Xc (hc) have been read; Da is complete
   // ================= backward (mlp_bwd_small_kernel's chain; masks from the branch bits, no d_emb round trip)
   auto mma_b = [&](const float* D, f32x4 (&v)[RT]) {
@@ -559,18 +711,34 @@ __global__ __launch_bounds__(512) void train_small_kernel(const SmallFused a) {
     if (gg == 0 && fb < ncol) { s_pe[3 * fb] = a0; s_pe[3 * fb + 1] = a1; s_pe[3 * fb + 2] = a2; }
   };
   const bool e1_wave = 16 * w < OBJ_E1, e2_wave = 16 * w < OBJ_E2;      // waves that own embedding columns
-  // ---- colour layer: d_h4 = relu'(h4) (wa d_araw + d_hc W_cl[:, :H]), d_x2 = d_hc W_cl[:, H:]
+  zero(acc);
+  zero(accE);
+  if constexpr (FEAT) {
+    // ---- feature layer first (Da = d_hf): d_h4 += d_hf W_fl[:, :H], d_x2 = d_hf W_fl[:, H:]; the colour layer
+    // accumulates onto both
+    put_wb();
+    __syncthreads();
+    fetch_w(P + a.o_fl_w + H, H + OBJ_E2, OBJ_E2);
+    mma_b(Da, acc);
+    __syncthreads();
+    put_wb();
+    __syncthreads();
+    fetch_w(P + a.o_cl_w, H + OBJ_E2, H);
+    if (e2_wave) mma_b(Da, accE);
+    __syncthreads();                             // every wave has read d_hf
+    form_dhc();                                  // Da <- d_hc
+    __syncthreads();
+  }
+  // ---- colour layer: d_h4 = relu'(h4) (wa d_araw + [d_hf W_fl1] + d_hc W_cl[:, :H]), d_x2 (+)= d_hc W_cl[:, H:]
   put_wb();
   __syncthreads();
   fetch_w(P + a.o_cl_w + H, H + OBJ_E2, OBJ_E2);
-  zero(acc);
   mma_b(Da, acc);
   __syncthreads();
   store_dh(Db, a.d_h4, mk4, true);               // Db = d_h4
   put_wb();
   __syncthreads();
   fetch_w(P + a.o_m2_w, H, H);
-  zero(accE);
   if (e2_wave) { mma_b(Da, accE); pe_bwd(s_pe2, OBJ_E2, OBJ_E1 - 3); }
   __syncthreads();
   // ---- mid2: d_h3 = relu'(h3) (d_h4 W_m2)
@@ -616,15 +784,16 @@ __global__ __launch_bounds__(512) void train_small_kernel(const SmallFused a) {
   }
 }
 
-template <int RT>
+template <int RT, bool FEAT>
 static void launch_train_small(hipStream_t st, const SmallFused& f, int nwg, bool bf) {
   objnerf_once_per_device([] {
-    (void)hipFuncSetAttribute((const void*)train_small_kernel<RT, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)sf_lds_bytes<RT>());
-    (void)hipFuncSetAttribute((const void*)train_small_kernel<RT, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)sf_lds_bytes<RT>());
+    (void)hipFuncSetAttribute((const void*)train_small_kernel<RT, false, FEAT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)sf_lds_bytes<RT, FEAT>());
+    (void)hipFuncSetAttribute((const void*)train_small_kernel<RT, true, FEAT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)sf_lds_bytes<RT, FEAT>());
   });
   dim3 grid((unsigned)nwg, (unsigned)f.K);
-  if (bf) hipLaunchKernelGGL((train_small_kernel<RT, true>), grid, dim3(512), sf_lds_bytes<RT>(), st, f);
-  else hipLaunchKernelGGL((train_small_kernel<RT, false>), grid, dim3(512), sf_lds_bytes<RT>(), st, f);
+  constexpr size_t lds_bytes = sf_lds_bytes<RT, FEAT>();
+  if (bf) hipLaunchKernelGGL((train_small_kernel<RT, true, FEAT>), grid, dim3(512), lds_bytes, st, f);
+  else hipLaunchKernelGGL((train_small_kernel<RT, false, FEAT>), grid, dim3(512), lds_bytes, st, f);
 }

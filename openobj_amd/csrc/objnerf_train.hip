@@ -1479,9 +1479,13 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
     const long nr = (long)a->K * a->R;
     int gpo = num_cu() / a->K;                    // ray chunks per object: one round of the chip
     if (gpo < 1) gpo = 1;
-    if (gpo > 8) gpo = 8;
-    while (gpo > 1 && (size_t)gpo * ((size_t)C * XCOLS + XCOLS * XCOLS) > (size_t)a->R * XCOLS) --gpo;   // partials live in X1's room
-    const bool one_pass = C == 512 && (size_t)gpo * ((size_t)C * XCOLS + XCOLS * XCOLS) <= (size_t)a->R * XCOLS;
+    if (gpo > 16) gpo = 16;
+    // the partials live in the room of X1 AND X2 (adjacent in the workspace, both unused on this route): 2 K R XCOLS floats.
+    // (Round 4 used X1's room only and at most 8 chunks: a rank's share of configs[3] -- 15 objects -- then ran 105
+    // workgroups over 126 MB of target features, 1.1 TB/s.)
+    const size_t part_room = ((size_t)((char*)X2 - (char*)X1) / 4 + (size_t)a->K * a->R * XCOLS) / (size_t)a->K;
+    while (gpo > 1 && (size_t)gpo * ((size_t)C * XCOLS + XCOLS * XCOLS) > part_room) --gpo;
+    const bool one_pass = C == 512 && (size_t)gpo * ((size_t)C * XCOLS + XCOLS * XCOLS) <= part_room;
     int Gfin = 1;
     const float *Tsrc = Tm, *Msrc = mom;
     if (one_pass) {

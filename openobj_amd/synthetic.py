@@ -201,3 +201,38 @@ class EllipsoidScene:
         pts = (oo[:, :, None, :] + (dd[:, :, None, :] * z[..., None]).astype(np.float32)).astype(np.float32)
         rgb = np.broadcast_to(self.color[:, None, :], (K, R, 3)).astype(np.float32).copy()
         return dict(origins=oo, dirs=dd, z=z, pts=pts, gt_depth=tt, gt_rgb=rgb)
+
+
+def grid_frame(i: int, n_objects: int, W: int = 1200, H: int = 680, part: bool = False) -> Dict[str, object]:
+    """Frame i of a synthetic stream for the mapping loop (openobj_amd/mapping.py) at the reference's camera size:
+    n_objects rectangles on a grid in front of a wall, instance image / depth / colour / 2-D boxes laid out as the
+    dataset adapters hand them over ([W, H] arrays, dataset.py).  tools/mapping_bench.py and bench.py's `native_frame`."""
+    import torch
+    nx = int(np.ceil(np.sqrt(n_objects * W / H)))
+    ny = int(np.ceil(n_objects / nx))
+    cw, ch = W // nx, H // ny
+    inst = np.zeros((W, H), np.int32)               # 0 = background
+    depth = np.full((W, H), 3.0, np.float32)
+    rgb = np.full((W, H, 3), 90, np.uint8)
+    bbox = {0: torch.tensor([0, W, 0, H])}
+    k = 0
+    for iy in range(ny):
+        for ix in range(nx):
+            if k >= n_objects:
+                break
+            x0, y0 = ix * cw + cw // 6 + i, iy * ch + ch // 6
+            x1, y1 = x0 + 2 * cw // 3, y0 + 2 * ch // 3
+            oid = k + 4
+            inst[x0:x1, y0:y1] = oid
+            depth[x0:x1, y0:y1] = 1.2 + 0.02 * k
+            rgb[x0:x1, y0:y1] = ((37 * k) % 255, (91 * k) % 255, (53 * k) % 255)
+            bbox[oid] = torch.tensor([max(x0 - 8, 0), min(x1 + 8, W - 1), max(y0 - 8, 0), min(y1 + 8, H - 1)])
+            k += 1
+    T = np.eye(4)
+    T[0, 3] = 0.002 * i
+    feats = {oid: np.ones((1, 8), np.float32) for oid in bbox}
+    s = {"image": rgb, "depth": depth, "T": T, "obj": inst, "bbox_dict": bbox, "frame_id": 10 * i,
+         "obj_clip": feats, "obj_cap": {o: np.ones(8, np.float32) for o in bbox}}
+    if part:
+        s["part_feat"] = torch.randn(W // 5, H // 5, 512)
+    return s

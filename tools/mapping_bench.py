@@ -23,37 +23,11 @@ a = ap.parse_args()
 dev = "cuda:0"
 W, H = 1200, 680
 c = ocfg.Config(ocfg.replica_room0_config(train_device=dev, **{"trainer.part_mode": int(a.part)}))
-nx = int(np.ceil(np.sqrt(a.objects * W / H)))
-ny = int(np.ceil(a.objects / nx))
-cw, ch = W // nx, H // ny
+from openobj_amd import synthetic
 
 
 def sample(i):
-    inst = np.zeros((W, H), np.int32)               # [W, H] like the loader's arrays; 0 = background
-    depth = np.full((W, H), 3.0, np.float32)
-    rgb = np.full((W, H, 3), 90, np.uint8)
-    bbox = {0: torch.tensor([0, W, 0, H])}
-    k = 0
-    for iy in range(ny):
-        for ix in range(nx):
-            if k >= a.objects:
-                break
-            x0, y0 = ix * cw + cw // 6 + i, iy * ch + ch // 6
-            x1, y1 = x0 + 2 * cw // 3, y0 + 2 * ch // 3
-            oid = k + 4
-            inst[x0:x1, y0:y1] = oid
-            depth[x0:x1, y0:y1] = 1.2 + 0.02 * k
-            rgb[x0:x1, y0:y1] = ((37 * k) % 255, (91 * k) % 255, (53 * k) % 255)
-            bbox[oid] = torch.tensor([max(x0 - 8, 0), min(x1 + 8, W - 1), max(y0 - 8, 0), min(y1 + 8, H - 1)])
-            k += 1
-    T = np.eye(4)
-    T[0, 3] = 0.002 * i
-    feats = {oid: np.ones((1, 8), np.float32) for oid in bbox}
-    s = {"image": rgb, "depth": depth, "T": T, "obj": inst, "bbox_dict": bbox, "frame_id": 10 * i,
-         "obj_clip": feats, "obj_cap": {o: np.ones(8, np.float32) for o in bbox}}
-    if a.part:
-        s["part_feat"] = torch.randn(W // 5, H // 5, 512)
-    return s
+    return synthetic.grid_frame(i, a.objects, W, H, a.part)
 
 
 m = mapping.IncrementalMapper(c, bf16=a.bf16)
