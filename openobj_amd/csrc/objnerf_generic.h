@@ -39,6 +39,18 @@ void gemm_f32(void* stream, int batch, int M, int N, int Kd, const float* A, lon
 size_t wgrad_parts_floats(int batch, int M, int N, long n);
 void wgrad_f32(void* stream, int batch, int M, int N, long n, const float* A, long sam, long sak, long bsa, const float* B,
                long sbk, long sbn, long bsb, float* C, long scm, long bsc, float* parts, size_t parts_floats);
+// The hoisted 512-d feature head around a fused kernel of ANOTHER width (the hidden-256 path, objnerf_train256.hip):
+// buffers, the preparation ahead of the kernel (G = W_of^T W_of, wb, bb per object; u = W_of^T g, beta, |g| per ray) and
+// the head's gradient behind it (the rays' moment GEMMs + featg_finish_kernel).  operands: 0 fp32, 1 bf16, 2 fp16 GEMMs.
+struct FeatHead {
+  float *gram, *rayin, *rayfeat, *X1, *X2, *Tm, *mom, *parts; size_t parts_floats;
+};
+size_t feat_head_workspace_bytes(int K, int R, int Hh, int C);
+FeatHead feat_head_carve(char* base, int K, int R, int Hh, int C);
+int feat_head_prep(void* stream, int K, int R, int Hh, int C, const float* params, long p_stride, long off_w, long off_b,
+                   const float* gt_feat, const FeatHead& f, int operands);
+int feat_head_grads(void* stream, int K, int R, int Hh, int C, const float* params, long p_stride, long off_w, long off_b,
+                    const float* gt_feat, const FeatHead& f, float* grads, int operands);
 size_t eval_workspace_bytes(const objnerf_net* net, int K, long N);
 // pts == NULL: emb_in [K][N][129] is the embedding (OccupancyMap.forward on a caller-supplied tensor)
 int eval_points(const objnerf_net* net, int K, long N, const float* params, long p_stride, const float* scale,
@@ -56,6 +68,6 @@ int embed_backward(const objnerf_net* net, int K, long N, const float* params, l
 // hidden 256 in the 16-bit operand modes without the feature loss (BASELINE configs[4]): objnerf_train256.hip
 namespace obj256 {
 bool applicable(const objnerf_net* net, const objnerf_train_args* a);
-size_t workspace_bytes(int K, int R, int S);
+size_t workspace_bytes(int K, int R, int S, int feat = 0, int C = 0);
 int train_step(const objnerf_net* net, const objnerf_train_args* a, void* stream);
 }

@@ -1967,7 +1967,7 @@ size_t train_workspace_bytes(const objnerf_net* net, int K, int R, int S, int fe
                sixteen && acts16_shape(net->hidden, (long)R * S));
   size_t need = w.bytes + 256;
   if (net->hidden == 256 && (S == 32 || S == 64 || S == 128)) {      // the fused hidden-256 path (16-bit modes)
-    const size_t n256 = obj256::workspace_bytes(K, R, S);
+    const size_t n256 = obj256::workspace_bytes(K, R, S, feat, net->feat_dim);
     if (n256 > need) need = n256;
   }
   return need;
@@ -2732,6 +2732,63 @@ int embed_backward(const objnerf_net* net, int K, long N, const float* params, l
 }
 
 // G = W_of^T W_of, wb = W_of^T b_of, bb = b_of . b_of of K objects: gram[k][Hh * Hh | Hh | 1], batch stride gstride
+// ---- the hoisted 512-d feature head around a fused kernel of another width (objnerf_generic.h)
+size_t feat_head_workspace_bytes(int K, int R, int Hh, int C) {
+  const size_t XC = (size_t)Hh + 1;
+  size_t fl = (size_t)K * ((size_t)Hh * Hh + Hh + 1) + (size_t)K * R * (Hh + 2) + (size_t)K * R * (Hh + 3) + 2 * (size_t)K * R * XC +
+              (size_t)K * C * XC + (size_t)K * XC * XC;
+  const size_t parts = wgrad_parts_floats(K, C, (int)XC, R) + wgrad_parts_floats(K, (int)XC, (int)XC, R) + 256;
+  return (fl + parts) * 4 + 10 * 256;
+}
+FeatHead feat_head_carve(char* base, int K, int R, int Hh, int C) {
+  FeatHead f;
+  char* p = base;
+  auto take = [&](size_t floats) { float* r = (float*)p; p += al(floats * 4); return r; };
+  const size_t XC = (size_t)Hh + 1;
+  f.gram = take((size_t)K * ((size_t)Hh * Hh + Hh + 1));
+  f.rayin = take((size_t)K * R * (Hh + 2));
+  f.rayfeat = take((size_t)K * R * (Hh + 3));
+  f.X1 = take((size_t)K * R * XC);
+  f.X2 = take((size_t)K * R * XC);
+  f.Tm = take((size_t)K * C * XC);
+  f.mom = take((size_t)K * XC * XC);
+  f.parts_floats = wgrad_parts_floats(K, C, (int)XC, R) + wgrad_parts_floats(K, (int)XC, (int)XC, R) + 256;
+  f.parts = take(f.parts_floats);
+  return f;
+}
+int feat_head_prep(void* stream, int K, int R, int Hh, int C, const float* params, long p_stride, long off_w, long off_b,
+                   const float* gt_feat, const FeatHead& f, int operands) {
+  GemmEnv E;
+  E.operands = operands;
+  hipStream_t st = (hipStream_t)stream;
+  const long gst = (long)Hh * Hh + Hh + 1;
+  const float* P = params;
+  gemm(E, st, K, Hh, Hh, C, P + off_w, 1, Hh, p_stride, P + off_w, Hh, 1, p_stride, f.gram, Hh, 1, gst);
+  hipLaunchKernelGGL(featg_wb_kernel, dim3(Hh + 1, K), dim3(64), 0, st, P, p_stride, (int)off_w, (int)off_b, C, Hh, f.gram, gst);
+  gemm(E, st, K, R, Hh, C, gt_feat, C, 1, (long)R * C, P + off_w, Hh, 1, p_stride, f.rayin, Hh + 2, 1, (long)R * (Hh + 2));
+  hipLaunchKernelGGL(featg_rowstats_kernel, dim3((unsigned)((R + 15) / 16), K), dim3(256), 0, st, P, p_stride, (int)off_b, C, R,
+                     Hh + 2, gt_feat, f.rayin);
+  if (E.error) return OBJNERF_EINVAL;
+  return hipGetLastError() == hipSuccess ? OBJNERF_OK : OBJNERF_ELAUNCH;
+}
+int feat_head_grads(void* stream, int K, int R, int Hh, int C, const float* params, long p_stride, long off_w, long off_b,
+                    const float* gt_feat, const FeatHead& f, float* grads, int operands) {
+  GemmEnv E;
+  E.operands = operands;
+  E.parts = f.parts; E.parts_cap = f.parts_floats; E.parts_off = 0;
+  E.need_parts = true;
+  hipStream_t st = (hipStream_t)stream;
+  const int XC = Hh + 1;
+  // T = gt_feat^T [a fh | a O], M = [c fh | c O]^T [fh | O] over the rays (X1 / X2 written by the fused kernel), then
+  // d W_of = T + W_of M + b_of m^T, d b_of likewise (featg_finish_kernel)
+  wgrad(E, st, K, C, XC, R, gt_feat, 1, C, (long)R * C, f.X1, XC, 1, (long)R * XC, f.Tm, XC, (long)C * XC);
+  wgrad(E, st, K, XC, XC, R, f.X2, 1, XC, (long)R * XC, f.rayfeat, Hh + 3, 1, (long)R * (Hh + 3), f.mom, XC, (long)XC * XC);
+  if (E.parts_failed || E.error) return OBJNERF_EINVAL;
+  hipLaunchKernelGGL(featg_finish_kernel, dim3((unsigned)(((long)C * XC + 255) / 256), K), dim3(256), 0, st, params, p_stride,
+                     (int)off_w, (int)off_b, C, Hh, f.Tm, f.mom, grads);
+  return hipGetLastError() == hipSuccess ? OBJNERF_OK : OBJNERF_ELAUNCH;
+}
+
 void feat_gram(void* stream, int K, const float* params, long p_stride, int off_w, int off_b, int C, int Hh, float* gram,
                long gstride) {
   GemmEnv E;

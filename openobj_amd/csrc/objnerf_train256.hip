@@ -103,21 +103,17 @@ __host__ __device__ constexpr int x2_slot_col(int h, int u) {      // column ins
 // sequences: row rho of block b belongs to lane half h = (rho >> 2) & 1 and is its register n = 4 (rho >> 3) + (rho & 3),
 // slot u = 16 b + n -- every lane receives the gradients of ITS OWN slots.
 // ---------------------------------------------------------------------------------------------------------------
-enum Seq { F1, F2, F3, F4, F5, F6, B6, B5H, B5X, B4, B3H, B3X, B2, B1, NSEQ };
+// With the feature-distillation loss (gt_feat != NULL; SQ<true>) three sequences join, in consumption order between F6 and B6:
+//  F7  hf       W_fl ; x2 slot (h = 0, u = 22) = b_fl      h4 | x2 slots (slot 22 holds 1.0)      8      19
+//  B7H d h4 (partial, unmasked)  W_fl[:, :H]^T             d hf                                   8      16
+//  B7X d x2     rows = x2 slots: W_fl[:, H:]^T             d hf                                   2      16
+enum Seq { F1, F2, F3, F4, F5, F6, B6, B5H, B5X, B4, B3H, B3X, B2, B1, F7, B7H, B7X, NSEQ_ALL };
 __host__ __device__ constexpr int seq_nb(int q) {
-  return q == F5 ? 9 : q == F6 ? 1 : q == B5X ? 2 : (q == B3X || q == B1) ? 3 : 8;
+  return q == F5 ? 9 : q == F6 ? 1 : (q == B5X || q == B7X) ? 2 : (q == B3X || q == B1) ? 3 : 8;
 }
 __host__ __device__ constexpr int seq_nk(int q) {
-  return q == F1 ? 6 : q == F3 ? 22 : q == F5 ? 19 : q == B6 ? 1 : q == B5H ? 17 : 16;
+  return q == F1 ? 6 : q == F3 ? 22 : (q == F5 || q == F7) ? 19 : q == B6 ? 1 : q == B5H ? 17 : 16;
 }
-__host__ __device__ constexpr int seq_off(int q) {       // first piece of the sequence
-  int o = 0;
-  for (int i = 0; i < q; ++i) o += seq_nb(i) * seq_nk(i);
-  return o;
-}
-constexpr int N_PIECES = seq_off(NSEQ);
-static_assert(N_PIECES == 1323, "image size");
-constexpr long IMG_BYTES = (long)N_PIECES * PIECE;
 constexpr int MAX_NK = 22;
 constexpr int RING_SLOT = MAX_NK * PIECE;            // 22 KB
 // Ring stages: one per block of a sequence -- except B6, whose eight one-piece blocks form ONE stage.  A tile's stage
@@ -125,21 +121,55 @@ constexpr int RING_SLOT = MAX_NK * PIECE;            // 22 KB
 // transfer set-up is a handful of scalar additions (no table look-ups, no division, no selects).
 __host__ __device__ constexpr int stg_nb(int q) { return q == B6 ? 1 : seq_nb(q); }
 __host__ __device__ constexpr int stg_np(int q) { return q == B6 ? 8 : seq_nk(q); }      // pieces per stage
-__host__ __device__ constexpr int stg_base(int q) {
-  int g = 0;
-  for (int i = 0; i < q; ++i) g += stg_nb(i);
-  return g;
-}
-constexpr int N_STAGES = stg_base(NSEQ);
-static_assert(N_STAGES == 83, "stage schedule");
-__host__ __device__ constexpr int stage_pieces(int g) {        // pieces of stage g (mod N_STAGES)
-  g %= N_STAGES;
-  for (int q = 0; q < NSEQ; ++q) {
-    if (g < stg_nb(q)) return stg_np(q);
-    g -= stg_nb(q);
+template <bool FEAT>
+struct SQ {
+  static constexpr int NSEQ = FEAT ? 17 : 14;
+  // the sequences in CONSUMPTION order (the image is read front to back, the stages follow each other in this order)
+  __host__ __device__ static constexpr int at(int i) {
+    if (!FEAT) return i;                                 // F1 .. F6, B6 .. B1: the enum's own order
+    return i < 6 ? i : i == 6 ? F7 : i == 7 ? B7H : i == 8 ? B7X : i - 3;      // .. F6, F7, B7H, B7X, B6, B5H ..
   }
-  return 0;
-}
+  __host__ __device__ static constexpr int pos(int q) {
+    for (int i = 0; i < NSEQ; ++i) if (at(i) == q) return i;
+    return NSEQ;
+  }
+  __host__ __device__ static constexpr int seq_off(int q) {       // first piece of sequence q (q == NSEQ_ALL: the image's end)
+    int o = 0;
+    const int n = q == NSEQ_ALL ? NSEQ : pos(q);
+    for (int i = 0; i < n; ++i) o += seq_nb(at(i)) * seq_nk(at(i));
+    return o;
+  }
+  __host__ __device__ static constexpr int stg_base(int q) {
+    int g = 0;
+    const int n = q == NSEQ_ALL ? NSEQ : pos(q);
+    for (int i = 0; i < n; ++i) g += stg_nb(at(i));
+    return g;
+  }
+  static constexpr int N_PIECES = seq_off(NSEQ_ALL);
+  static constexpr long IMG_BYTES = (long)N_PIECES * PIECE;
+  static constexpr int N_STAGES = stg_base(NSEQ_ALL);
+  __host__ __device__ static constexpr int stage_pieces(int g) {        // pieces of stage g (mod N_STAGES)
+    g %= N_STAGES;
+    for (int i = 0; i < NSEQ; ++i) {
+      if (g < stg_nb(at(i))) return stg_np(at(i));
+      g -= stg_nb(at(i));
+    }
+    return 0;
+  }
+  // the sequence of piece `piece` of the image and its first piece
+  __host__ __device__ static constexpr int seq_of_piece(int piece, int& first) {
+    int o = 0;
+    for (int i = 0; i < NSEQ; ++i) {
+      const int n = seq_nb(at(i)) * seq_nk(at(i));
+      if (piece < o + n) { first = o; return at(i); }
+      o += n;
+    }
+    first = o;
+    return NSEQ_ALL;
+  }
+};
+static_assert(SQ<false>::N_PIECES == 1323 && SQ<false>::N_STAGES == 83, "image / stage schedule without the feature loss");
+static_assert(SQ<true>::N_PIECES == 1323 + 8 * 19 + 8 * 16 + 2 * 16 && SQ<true>::N_STAGES == 83 + 18, "... with it");
 // piece-count classes of a stage; a wave moves a CONTIGUOUS share of a stage: quota pieces (the last wave what is left)
 constexpr int NCLS = 6;
 __host__ __device__ constexpr int cls_of(int np) { return np == 6 ? 0 : np == 8 ? 1 : np == 16 ? 2 : np == 17 ? 3 : np == 19 ? 4 : 5; }
@@ -150,20 +180,23 @@ __host__ __device__ constexpr int wave_cnt(int np, int nw, int w) {
   return r < 0 ? 0 : (r > q ? q : r);
 }
 
-struct Lay256 { int in_w, in_b, m1_w, m1_b, cat_w, cat_b, m2_w, m2_b, a_w, a_b, cl_w, cl_b, oc_w, oc_b, pe_b; };
+struct Lay256 { int in_w, in_b, m1_w, m1_b, cat_w, cat_b, m2_w, m2_b, a_w, a_b, cl_w, cl_b, oc_w, oc_b, pe_b, fl_w, fl_b; };
 
-template <typename OT>
+constexpr int X2_BIAS_SLOT = 22;        // x2 slot (h = 0, u = 22) is unused by the embedding: with the feature loss it carries the
+                                        // constant 1 and the feature layer's image its bias there (no bias table for F7)
+template <typename OT, bool FEAT>
 __global__ __launch_bounds__(256) void pack256_kernel(int K, const float* __restrict__ params, long p_stride, Lay256 L,
                                                       OT* __restrict__ img) {
+  constexpr int N_PIECES = SQ<FEAT>::N_PIECES;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;        // (object, piece, lane)
   if (idx >= (long)K * N_PIECES * 64) return;
   const int lane = (int)(idx & 63);
   const int piece = (int)((idx >> 6) % N_PIECES);
   const int k = (int)((idx >> 6) / N_PIECES);
   const float* P = params + (long)k * p_stride;
-  int q = 0;
-  while (q + 1 < NSEQ && piece >= seq_off(q + 1)) ++q;
-  const int rel = piece - seq_off(q), nk = seq_nk(q);
+  int first = 0;
+  const int q = SQ<FEAT>::seq_of_piece(piece, first);
+  const int rel = piece - first, nk = seq_nk(q);
   const int blk = rel / nk, ks = rel - blk * nk;
   const int r = lane & 31, h = lane >> 5;
   const int E1 = OBJ_E1, E2 = OBJ_E2;
@@ -200,6 +233,22 @@ __global__ __launch_bounds__(256) void pack256_kernel(int K, const float* __rest
                if (c >= 0) v = (q == B3X) ? P[L.cat_w + kf * (HID + E1) + HID + c] : P[L.in_w + kf * E1 + c]; }
         break;
       }
+      case F7:
+        if (ks < KS_H) v = P[L.fl_w + o * (HID + E2) + hid_feat(ks, h, j)];
+        else {
+          const int u = 8 * (ks - KS_H) + j;
+          const int c = x2_slot_col(h, u);
+          if (c >= 0) v = P[L.fl_w + o * (HID + E2) + HID + c];
+          else if (h == 0 && u == X2_BIAS_SLOT) v = P[L.fl_b + o];
+        }
+        break;
+      case B7H: v = P[L.fl_w + hid_feat(ks, h, j) * (HID + E2) + o]; break;
+      case B7X: {
+        const int hr = (r >> 2) & 1, n = 4 * (r >> 3) + (r & 3), u = 16 * blk + n;
+        const int c = u < 24 ? x2_slot_col(hr, u) : COL_ZERO;
+        if (c >= 0) v = P[L.fl_w + hid_feat(ks, h, j) * (HID + E2) + HID + c];
+        break;
+      }
       case B4: v = P[L.m2_w + hid_feat(ks, h, j) * HID + o]; break;
       case B3H: v = P[L.cat_w + hid_feat(ks, h, j) * (HID + E1) + o]; break;
       case B2: v = P[L.m1_w + hid_feat(ks, h, j) * HID + o]; break;
@@ -220,13 +269,14 @@ struct WsLay {
   long act_stride;          // bytes of one activation tensor of one object
   long obj_bytes;           // everything of one object
   long off_dpre, off_x1, off_x2, off_dhead;
-  __host__ __device__ static WsLay make(long n, int tsamp) {
+  // feat: two more tensors behind the ten -- 10 = hf (the feature hidden), 11 = d pre-activation of the feature layer
+  __host__ __device__ static WsLay make(long n, int tsamp, bool feat = false) {
     WsLay w;
     const long ntile = (n + tsamp - 1) / tsamp;         // whole tiles of kernel A (tsamp samples each)
     w.nsg = ntile * (tsamp / 32);
     w.act_stride = w.nsg * KS_H * PIECE;
     w.off_dpre = 5 * w.act_stride;
-    w.off_x1 = 10 * w.act_stride;
+    w.off_x1 = (feat ? 12 : 10) * w.act_stride;
     w.off_x2 = w.off_x1 + w.nsg * KS_X1 * PIECE;
     w.off_dhead = w.off_x2 + w.nsg * KS_X2 * PIECE;
     w.obj_bytes = w.off_dhead + w.nsg * PIECE;
@@ -234,7 +284,7 @@ struct WsLay {
   }
 };
 
-constexpr int PART_FLOATS = 72;         // per (object, workgroup): d B (63), loss terms (3), padding
+constexpr int PART_FLOATS = 72;         // per (object, workgroup): d B (63), loss terms (3; 4 with the feature term), padding
 constexpr int NWG_A = 256;
 
 struct FwdArgs {
@@ -251,6 +301,12 @@ struct FwdArgs {
   float* part;                          // [K][NWG_A][PART_FLOATS]
   Lay256 L;
   WsLay wl;
+  // feature-distillation loss (FEAT kernels; DESIGN.md 4.3: the 512-d head hoisted past the compositing)
+  float feat_scaling;
+  const float* rayin;                   // [K][R][HID + 2]  u = W_of^T g, beta = b_of . g, |g|
+  const float* gram;                    // [K][HID HID + HID + 1]  G = W_of^T W_of (symmetric), wb, bb
+  float* rayfeat;                       // [K][R][HID + 3]  fh, O, a, c   (-> the head's moment GEMMs)
+  float *X1, *X2;                       // [K][R][HID + 1]  [a fh | a O], [c fh | c O]
 };
 
 // LDS of kernel A (NW waves, NW * 64 threads, tile of NW * 32 samples)
@@ -532,8 +588,25 @@ struct KA {
 // ---------------------------------------------------------------------------------------------------------------
 // kernel A
 // ---------------------------------------------------------------------------------------------------------------
-template <typename OT, int S, int NW>
+template <typename OT> struct Unpack;
+template <> struct Unpack<__bf16> {          // the two 16-bit halves of a packed word as floats
+  static __device__ __forceinline__ void get(uint32_t w, float& lo, float& hi) {
+    lo = __builtin_bit_cast(float, w << 16); hi = __builtin_bit_cast(float, w & 0xffff0000u);
+  }
+};
+template <> struct Unpack<_Float16> {
+  static __device__ __forceinline__ void get(uint32_t w, float& lo, float& hi) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 v = __builtin_bit_cast(h2, w);
+    lo = (float)v[0]; hi = (float)v[1];
+  }
+};
+
+template <typename OT, int S, int NW, bool FEAT>
 __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
+  typedef SQ<FEAT> SQT;
+  constexpr int N_STAGES = SQT::N_STAGES;
+  constexpr long IMG_BYTES = SQT::IMG_BYTES;
   constexpr int NTHR = NW * 64, TSAMP = NW * 32, NWAVE = NW;
   constexpr int L_MASK = l_mask(NW), L_BIAS = l_bias(NW), L_STRIP = l_strip(NW), L_SMALL = l_small(NW), L_DB = l_db(NW);
   static_assert(TSAMP % S == 0, "whole rays per tile");
@@ -572,7 +645,7 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
     k_i = (int)obj0; tile_i = tau0 - obj0 * a.ntile;
     strm.set_source((const char*)a.img + obj0 * IMG_BYTES);
     // prologue: stages 0 and 1 (F1 blocks 0 and 1) into slots 0 and 1; the stream then points at stage 2 / slot 2
-    constexpr int NP0 = stage_pieces(0), NP1 = stage_pieces(1);
+    constexpr int NP0 = SQT::stage_pieces(0), NP1 = SQT::stage_pieces(1);
     strm.template issue<NP0, 0, true>(strm.cw[cls_of(NP0)]); strm.template issue<NP0, 1, true>(strm.cw[cls_of(NP0)]);
     strm.srcp += (unsigned long long)NP0 * PIECE; strm.dst2 += RING_SLOT;
     strm.template issue<NP1, 0, true>(strm.cw[cls_of(NP1)]); strm.template issue<NP1, 1, true>(strm.cw[cls_of(NP1)]);
@@ -586,7 +659,7 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
   const float gs = a.grad_scale, inv_gs = 1.0f / a.grad_scale;
   T256_DECL;
   int cur_obj = -1;
-  float l_d = 0.f, l_c = 0.f, l_o = 0.f;
+  float l_d = 0.f, l_c = 0.f, l_o = 0.f, l_f = 0.f;
   float dbacc[11][3];               // d B of this lane's directions, summed over this lane's samples of the object
 #pragma unroll
   for (int dd = 0; dd < 11; ++dd) dbacc[dd][0] = dbacc[dd][1] = dbacc[dd][2] = 0.f;
@@ -606,10 +679,10 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
       }
       dbacc[dd][0] = dbacc[dd][1] = dbacc[dd][2] = 0.f;
     }
-    l_d = seg_sum<64>(l_d); l_c = seg_sum<64>(l_c); l_o = seg_sum<64>(l_o);
-    if (lane == 0) { pw[64] = l_d; pw[65] = l_c; pw[66] = l_o; }
+    l_d = seg_sum<64>(l_d); l_c = seg_sum<64>(l_c); l_o = seg_sum<64>(l_o); l_f = seg_sum<64>(l_f);
+    if (lane == 0) { pw[64] = l_d; pw[65] = l_c; pw[66] = l_o; pw[67] = l_f; }
     __syncthreads();
-    if (tid < 67) {
+    if (tid < 68) {
       float v = 0.f;
 #pragma unroll
       for (int ww = 0; ww < NWAVE; ++ww) v += s_db[ww * 68 + tid];
@@ -641,7 +714,17 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
   float npx, npy, npz, nzv;
   load_point(k_i, tile_i, npx, npy, npz, nzv);
 
+  const int tid_k = tid;
+  char* const hbuf_k = hbuf;
   for (long tau = tau0; tau < tau1; ++tau) {
+    // With the feature loss the lane-derived constants are re-derived per tile from an opaque copy of the thread index:
+    // left loop-invariant, the compiler hoists some 70 of them (LDS addresses of every fragment slot, vector bases,
+    // lane predicates) ahead of the tile loop and then spills them, and this compiler's AGPR rewrite pass crashes on
+    // the spilled form.  (Without the feature loss the kernel fits as it is, and its code is left alone.)
+    int tid = tid_k;
+    if constexpr (FEAT) asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, s = lane & 31, h = lane >> 5;
+    char* const hbuf = FEAT ? lds + L_HBUF + w * (KS_H * PIECE) + lane * 16 : hbuf_k;
     const int k = k_i;                        // (the stream is at stage 0 of this tile)
     const long tile = tile_i;
     const bool live = tau + 1 < tau1;         // another tile follows: the last two stages request its first two
@@ -659,7 +742,7 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
       if (tid == 64) s_small[64] = P[a.L.a_b];
       if (tid >= 65 && tid < 68) s_small[tid] = P[a.L.oc_b + tid - 65];
       for (int i = tid; i < NWAVE * 68; i += NTHR) s_db[i] = 0.0f;
-      l_d = l_c = l_o = 0.f;
+      l_d = l_c = l_o = l_f = 0.f;
       scale = a.scale[k];
       const float n1 = (float)a.counts[2 * k], n2 = (float)a.counts[2 * k + 1];
       inv1 = a.flags[0] ? 0.0f : 1.0f / (n1 + 1e-10f);         // render_rays.py:89-94 early return / :103 mean
@@ -673,8 +756,13 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
     // fragment (tensor, k-step ks) of this wave's sample group; tensor 0..4 h1..hc, 5..9 d_pre1..5: a wave-uniform base
     // (scalar arithmetic) + this lane's 32-bit offset
     const uint32_t lane_off = (uint32_t)lane * 16u;
+    // (the lane offset is made opaque at every use: left visible, the compiler hoists one 64-bit vector base per tensor
+    // out of the tile loop and then spills them -- with it hidden the base stays scalar and the lane offset rides in the
+    // access's own offset operand)
     auto act_base = [&](int tensor, int ks) __attribute__((always_inline)) -> GV* {
-      return (GV*)(ws_obj + (long)tensor * a.wl.act_stride + (sg * KS_H + ks) * (64 * 16) + lane_off);
+      uint32_t lo = lane_off;
+      asm volatile("" : "+v"(lo));
+      return (GV*)(ws_obj + (long)tensor * a.wl.act_stride + (sg * KS_H + ks) * (64 * 16) + lo);
     };
 
     // ------------------------------------------------------------------ sample point of this lane (vmap.py:548-551)
@@ -759,7 +847,7 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
       auto sd = [&](auto ks_tag) __attribute__((always_inline)) { dma_side(np2_tag, nk_tag, ks_tag, allc_tag, cnt); };
       KT::template block_mma<NK, !decltype(keep_tag)::value, true>(acc0, acc1, ring_addr(), bsel, sd);
     };
-#define NP2_OF(Q_, BLK_) stage_pieces(stg_base(Q_) + (BLK_) + 2)
+#define NP2_OF(Q_, BLK_) SQT::stage_pieces(SQT::stg_base(Q_) + (BLK_) + 2)
 
     // Hidden layers are SOFTWARE-PIPELINED over their eight blocks on two accumulators: with one wave per SIMD nothing
     // overlaps an MFMA but this wave's own independent instructions, so the epilogue of block b - 1 (convert, ReLU /
@@ -770,11 +858,16 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
     // forward hidden layer: NK k-steps from bsel(ks); blocks 0..7 -> fragments (LDS hand-off buffer + workspace tensor
     // `layer`), ReLU bits.  The block loop is rolled over block PAIRS (the accumulators swap roles) for blocks 0..5,
     // whose stage two ahead lies in the same sequence; blocks 6 and 7 are peeled (theirs is the next sequence's).
-    auto fwd_layer = [&](auto seq_tag, auto nk_tag, const int layer, auto&& bsel) __attribute__((always_inline)) {
+    auto fwd_layer = [&](auto seq_tag, auto nk_tag, const int layer, auto&& bsel, auto plain_tag, const int tensor)
+        __attribute__((always_inline)) {
+      // plain_tag: the feature layer -- its bias rides in the image (x2 slot 22), and its ReLU bits are not kept (d hf is
+      // formed from the values themselves): no bias table row, no mask words
+      constexpr bool PLAIN = decltype(plain_tag)::value;
       constexpr int NK = decltype(nk_tag)::value, Q = decltype(seq_tag)::value;
       constexpr int SK = NK - 1 < 8 ? NK - 1 : 8;          // the k-step whose shadow finishes the previous block's epilogue
       uint32_t mprev = 0;
       auto load_bias = [&](f32x16& acc, const int blk) __attribute__((always_inline)) {
+        if constexpr (PLAIN) { acc = zero16(); return; }
         const float* bp = s_bias + layer * 256 + blk * 32 + h * 16;
 #pragma unroll
         for (int n4 = 0; n4 < 4; ++n4) {
@@ -787,7 +880,7 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
         const V f0 = __builtin_bit_cast(V, u0), f1 = __builtin_bit_cast(V, u1);
         *reinterpret_cast<V*>(hbuf + (2 * pb) * PIECE) = f0;
         *reinterpret_cast<V*>(hbuf + (2 * pb + 1) * PIECE) = f1;
-        s_mask[(layer * 4 + (pb >> 1)) * NTHR + tid] = (pb & 1) ? (mprev | (bits << 8)) : bits;
+        if constexpr (!PLAIN) s_mask[(layer * 4 + (pb >> 1)) * NTHR + tid] = (pb & 1) ? (mprev | (bits << 8)) : bits;
         mprev = bits;
         // non-temporal: 5 KB per sample stream through the L2 that also has to keep serving the weight ring
         __builtin_nontemporal_store(f0, dst);
@@ -808,7 +901,7 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
           if constexpr (KS == SK) {
 #pragma unroll
             for (int i = SK; i < 8; ++i) piece(i);
-            finish(pb, wd, ~bits & 0x00ff00ffu, blk > 0 ? act_base(layer, 2 * pb) : (GV*)park);
+            finish(pb, wd, ~bits & 0x00ff00ffu, blk > 0 ? act_base(tensor, 2 * pb) : (GV*)park);
             load_bias(prv, (blk + 1) & 7);                 // prv becomes the next block's first chain (the second starts from 0)
           }
           dma_side(np2_tag, nk_tag, ks_tag, std::false_type{}, strm.cw[cls_of(NP2)]);
@@ -839,24 +932,24 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
           wd[i] = pk_relu(c);
           bits = ((c >> (15 - i)) & (0x00010001u << i)) | bits;
         }
-        finish(7, wd, ~bits & 0x00ff00ffu, act_base(layer, 14));
+        finish(7, wd, ~bits & 0x00ff00ffu, act_base(tensor, 14));
       }
     };
     // ------------------------------------------------------------------ forward
     T256(6);
-    fwd_layer(std::integral_constant<int, F1>{}, std::integral_constant<int, 6>{}, 0, [&](int ks) -> V { return x1f[ks]; });   // h1
+    fwd_layer(std::integral_constant<int, F1>{}, std::integral_constant<int, 6>{}, 0, [&](int ks) -> V { return x1f[ks]; }, std::false_type{}, 0);   // h1
     {   // the loads requested at the top of the tile have landed under the first layer: park them for the compositing
       s_z[st_idx] = z_own;
       if (si == 0) { float* rp = s_ray + 8 * q; rp[0] = rg0; rp[1] = rg1; rp[2] = rg2; rp[3] = rg3; rp[4] = __int_as_float(rlab); }
       if (live) load_point((int)next_obj, next_obj != k ? 0 : tile + 1, npx, npy, npz, nzv);      // the next tile's sample
     }
     reload();
-    fwd_layer(std::integral_constant<int, F2>{}, std::integral_constant<int, 16>{}, 1, [&](int ks) -> V { return hin[ks]; });  // h2
+    fwd_layer(std::integral_constant<int, F2>{}, std::integral_constant<int, 16>{}, 1, [&](int ks) -> V { return hin[ks]; }, std::false_type{}, 1);  // h2
     reload();
     fwd_layer(std::integral_constant<int, F3>{}, std::integral_constant<int, 22>{}, 2,
-              [&](int ks) -> V { return ks < KS_H ? hin[ks] : x1f[ks - KS_H]; });                                              // h3
+              [&](int ks) -> V { return ks < KS_H ? hin[ks] : x1f[ks - KS_H]; }, std::false_type{}, 2);                        // h3
     reload();
-    fwd_layer(std::integral_constant<int, F4>{}, std::integral_constant<int, 16>{}, 3, [&](int ks) -> V { return hin[ks]; });  // h4
+    fwd_layer(std::integral_constant<int, F4>{}, std::integral_constant<int, 16>{}, 3, [&](int ks) -> V { return hin[ks]; }, std::false_type{}, 3);  // h4
     reload();
     // x2 fragments (octaves 4, 5): slot u = 2 dd + (f - 4)
     V x2f[KS_X2];
@@ -871,6 +964,7 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
           float v = 0.0f;
           if (dd < 10) v = rev_sin(vh[dd], vl[dd], (float)(1 << f));
           else if (dd == 10) v = h == 0 ? rev_sin(vh[10], vl[10], (float)(1 << f)) : 0.0f;
+          if (FEAT && u == X2_BIAS_SLOT && h == 0) v = 1.0f;       // the feature layer's bias column (pack256_kernel, F7)
           x2f[t][j] = Op<OT>::cvt(v);
         }
       }
@@ -881,7 +975,7 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
       for (int t = 0; t < KS_X2; ++t) xp[t * 64] = x2f[t];
     }
     fwd_layer(std::integral_constant<int, F5>{}, std::integral_constant<int, 19>{}, 4,
-              [&](int ks) -> V { return ks < KS_H ? hin[ks] : x2f[ks - KS_H]; });                                              // hc
+              [&](int ks) -> V { return ks < KS_H ? hin[ks] : x2f[ks - KS_H]; }, std::false_type{}, 4);                        // hc
     T256(7);
     {   // F5 block 8: row 0 = w_alpha . h4  (raw density, model.py:81)
       constexpr int NP2 = NP2_OF(F5, 8);
@@ -892,12 +986,14 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
       KT::template stage_sync<NW, NP2, 0>(strm.last);
       strm.template advance<NP2>();
     }
-    reload();                                  // hin = hc
+    // (with the feature loss h4 stays in `hin` for the feature layer: the colour head then reads hc's fragments straight
+    // from the hand-off buffer, one LDS read per k-step)
+    if constexpr (!FEAT) reload();             // hin = hc
     {   // F6: colour head on hc (model.py:95)
       constexpr int NP2 = NP2_OF(F6, 0);
       f32x16 acc = zero16(), acc1 = zero16();
       plain_stage(std::integral_constant<int, NP2>{}, std::integral_constant<int, 16>{}, std::false_type{}, std::false_type{}, strm.cw[cls_of(NP2)], acc, acc1,
-                  [&](int ks) -> V { return hin[ks]; });
+                  [&](int ks) -> V { if constexpr (FEAT) return *reinterpret_cast<const V*>(hbuf + ks * PIECE); else return hin[ks]; });
       if (h == 0) {
         s_col[st_idx] = (acc[0] + acc1[0]) + boc0; s_col[TSAMP + st_idx] = (acc[1] + acc1[1]) + boc1;
         s_col[2 * TSAMP + st_idx] = (acc[2] + acc1[2]) + boc2;
@@ -906,8 +1002,25 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
       strm.template advance<NP2>();
     }
     T256(8);
+    // ------------------------------------------------------------------ feature layer (FEAT): hf = relu([h4 | x2] W_fl^T + b_fl)
+    // scratch of the feature step: the ring slot of the stage just computed is free until the NEXT stage starts its
+    // transfers (its barrier has passed; the two other slots hold / receive the two stages ahead)
+    float* fx = nullptr;
+    if constexpr (FEAT) {
+      static_assert(!FEAT || NTHR == HID, "the feature step maps a thread to a hidden feature");
+      fwd_layer(std::integral_constant<int, F7>{}, std::integral_constant<int, 19>{}, 0,
+                [&](int ks) -> V { return ks < KS_H ? hin[ks] : x2f[ks - KS_H]; }, std::true_type{}, 10);                        // hf
+      const uint32_t free_slot = strm.rd == strm.lo ? strm.lo + 2 * RING_SLOT : strm.rd - RING_SLOT;
+      fx = reinterpret_cast<float*>(lds + (free_slot - lds0));
+    }
+    constexpr int FX_X = 0, FX_FH = FX_X + NW * HID, FX_DFH = FX_FH + 4 * HID, FX_W = FX_DFH + 4 * HID, FX_DWV = FX_W + TSAMP,
+                  FX_RQ = FX_DWV + TSAMP, FX_RED = FX_RQ + 4 * 8, FX_END = FX_RED + NW * 4;
+    static_assert(FX_END * 4 <= RING_SLOT, "feature scratch");
     // ------------------------------------------------------------------ compositing + losses (loss.py:27-101)
-    {
+    // pass 0: the whole pass (no feature loss).  With it the pass runs twice: 1 = ray weights, loss terms, opacity (nothing
+    // of which depends on the feature term), 2 = the gradients, with the feature term's d loss / d weight added.
+    auto composite = [&](auto pass_tag) __attribute__((always_inline)) {
+      constexpr int PASS = decltype(pass_tag)::value;
       constexpr int LPR = S < 64 ? S : 64;               // lanes per ray
       constexpr int SPL = S / LPR;                       // samples per lane
       constexpr int RPP = 64 / LPR;                      // rays per wave pass
@@ -964,15 +1077,23 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
         const float gC1 = a.color_scaling * m1 * sgn(r1) * inv1;
         const float gC2 = a.color_scaling * m1 * sgn(r2) * inv1;
         const float gO = a.opacity_scaling * m2 * sgn(ro) * inv2;
-        if (on && li == 0) {
+        if (PASS != 2 && on && li == 0) {
           l_d += m1 * fabsf(rd) * info * inv1;
           l_c += m1 * (fabsf(r0) + fabsf(r1) + fabsf(r2)) * inv1;
           l_o += m2 * fabsf(ro) * inv2;
+        }
+        if constexpr (PASS == 1) {                                      // ray weights / opacity for the feature step
+#pragma unroll
+          for (int e = 0; e < SPL; ++e)
+            if (qq < TR) fx[FX_W + qq * S + li * SPL + e] = on ? wgt[e] : 0.0f;
+          if (qq < TR && li == 0) { fx[FX_RQ + 8 * qq] = on ? Oo : 0.0f; fx[FX_RQ + 8 * qq + 1] = on ? m1 : 0.0f; }
+          continue;
         }
         float dw[SPL], qv[SPL], ql_sum = 0.f;
 #pragma unroll
         for (int e = 0; e < SPL; ++e) {
           dw[e] = gD * zz[e] + gO + gC0 * c0[e] + gC1 * c1[e] + gC2 * c2[e];
+          if constexpr (PASS == 2) dw[e] += on ? fx[FX_DWV + qq * S + li * SPL + e] : 0.0f;      // the feature term's part
           qv[e] = dw[e] * wgt[e];
           ql_sum += qv[e];
         }
@@ -994,6 +1115,125 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
           }
         }
       }
+    };
+    if constexpr (!FEAT) {
+      composite(std::integral_constant<int, 0>{});
+    } else {
+      // ================================================================ feature-distillation term (loss.py:81-99 in the
+      // hoisted form of DESIGN.md 4.3: F = W_of fh + b_of O with fh = sum_s w_s hf_s per ray; the cosine needs fh . u,
+      // fh^T G fh, fh . wb only)
+      for (int i = tid; i < 4 * HID; i += NTHR) fx[FX_DFH + i] = 0.0f;
+      composite(std::integral_constant<int, 1>{});
+      reload();                                                           // hin = hf (this wave's 32 samples)
+      __syncthreads();
+      const int qw = (32 * w) / S;                                        // the tile's ray this wave's samples belong to
+      const float wsm = valid ? fx[FX_W + st_idx] : 0.0f;
+      {
+        // fh partial of this wave: sum over its 32 samples (the lanes of a half) of w_s hf -- a reduce-scatter: after the
+        // five exchange steps lane s holds the complete sums of entries 4 s .. 4 s + 3 (entry 8 ks + j <-> feature
+        // hid_feat(ks, h, j)), i.e. four consecutive features
+        // (in two halves of 64 entries -- k-steps 0..7 and 8..15: 128 live sums next to the 64 fragment registers spilled)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          float v[64];
+#pragma unroll
+          for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[8 * ks + j] = wsm * (float)hin[8 * half + ks][j];
+#pragma unroll
+          for (int nn = 32, d = 16; nn >= 2; nn >>= 1, d >>= 1) {
+            const bool up = (s & d) != 0;
+#pragma unroll
+            for (int i = 0; i < nn; ++i) {
+              const float keep = up ? v[i + nn] : v[i], send = up ? v[i] : v[i + nn];
+              v[i] = keep + __shfl_xor(send, d, 32);
+            }
+          }
+          // lane s holds entries 2 s, 2 s + 1 of the half: k-step 8 half + (s >> 2), elements j = 2 (s & 3) + {0, 1}
+          const int ks = 8 * half + (s >> 2), j = 2 * (s & 3);
+          const int f0 = 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * h + (j & 3);      // hid_feat(ks, h, j)
+          fx[FX_X + w * HID + f0] = v[0];
+          fx[FX_X + w * HID + f0 + 1] = v[1];
+        }
+      }
+      __syncthreads();
+      const float* Gk = a.gram + (long)k * ((long)HID * HID + HID + 1);
+      const float* wbv = Gk + (long)HID * HID;
+#pragma unroll 1
+      for (int q2 = 0; q2 < TR; ++q2) {
+        const long rayq = tile * TR + q2;
+        if (rayq >= a.R) break;                                            // (wave-uniform: padding rays of the last tile)
+        const long rr = (long)k * a.R + rayq;
+        float fhv = 0.0f;
+#pragma unroll
+        for (int ww = 0; ww < S / 32; ++ww) fhv += fx[FX_X + (q2 * (S / 32) + ww) * HID + tid];
+        fx[FX_FH + q2 * HID + tid] = fhv;
+        __syncthreads();
+        // (G fh)[f] for f = tid: G is symmetric, so its COLUMN f is read -- coalesced over the threads, L2-resident
+        float gf = 0.0f;
+#pragma unroll 8
+        for (int f2 = 0; f2 < HID; ++f2) gf = fmaf(Gk[(long)f2 * HID + tid], fx[FX_FH + q2 * HID + f2], gf);
+        const float* rin = a.rayin + rr * (HID + 2);
+        const float uu = rin[tid], wbf = wbv[tid];
+        const float su = seg_sum<64>(fhv * uu), sg_ = seg_sum<64>(fhv * gf), sw = seg_sum<64>(fhv * wbf);
+        if (lane == 0) { fx[FX_RED + 4 * w] = su; fx[FX_RED + 4 * w + 1] = sg_; fx[FX_RED + 4 * w + 2] = sw; }
+        __syncthreads();
+        float fu = 0.f, fGf = 0.f, fwb = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) { fu += fx[FX_RED + 4 * ww]; fGf += fx[FX_RED + 4 * ww + 1]; fwb += fx[FX_RED + 4 * ww + 2]; }
+        const float Oq = fx[FX_RQ + 8 * q2], m1 = fx[FX_RQ + 8 * q2 + 1];
+        const float bb = wbv[HID], beta = rin[HID], ngv = rin[HID + 1];
+        const float dotFg = fu + Oq * beta;
+        const float nF2 = fmaxf(fGf + 2.0f * Oq * fwb + Oq * Oq * bb, 0.0f);
+        const float nF = fmaxf(sqrtf(nF2), 1e-8f), ngc = fmaxf(ngv, 1e-8f);
+        const float cosv = dotFg / (nF * ngc);
+        const float gam = -a.feat_scaling * m1 * inv1;                    // d total / d cos
+        const float ar = gam / (nF * ngc), cr = -gam * cosv / (nF * nF);
+        fx[FX_DFH + q2 * HID + tid] = ar * uu + cr * (gf + Oq * wbf);      // d total / d fh
+        a.rayfeat[rr * (HID + 3) + tid] = fhv;
+        a.X1[rr * (HID + 1) + tid] = ar * fhv;
+        a.X2[rr * (HID + 1) + tid] = cr * fhv;
+        if (tid == 0) {
+          float* rf = a.rayfeat + rr * (HID + 3);
+          rf[HID] = Oq; rf[HID + 1] = ar; rf[HID + 2] = cr;
+          a.X1[rr * (HID + 1) + HID] = ar * Oq;
+          a.X2[rr * (HID + 1) + HID] = cr * Oq;
+          fx[FX_RQ + 8 * q2 + 2] = ar * beta + cr * (fwb + Oq * bb);       // d total / d opacity (feature part)
+          l_f += m1 * (1.0f - cosv) * inv1;
+        }
+        __syncthreads();
+      }
+      __syncthreads();
+      {
+        // per sample: the feature part of d loss / d weight = gof + d fh . hf, and hf -> the pre-activation gradient of the
+        // feature layer relu'(hf) w_s d fh (times the gradient scale) IN PLACE: `hin` becomes B7's operand
+        float pp = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < KS_H; ++ks) {
+          const float* dp = fx + FX_DFH + qw * HID + 32 * (ks >> 1) + 16 * (ks & 1) + 4 * h;
+          const f32x4v d0 = *reinterpret_cast<const f32x4v*>(dp), d1 = *reinterpret_cast<const f32x4v*>(dp + 8);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float hv = (float)hin[ks][j];
+            const float dv = j < 4 ? d0[j] : d1[j - 4];
+            pp = fmaf(dv, hv, pp);
+            hin[ks][j] = Op<OT>::cvt(hv > 0.0f ? (wsm * dv) * gs : 0.0f);
+          }
+        }
+        pp += __shfl_xor(pp, 32, 64);
+        if (h == 0 && valid) fx[FX_DWV + st_idx] = fx[FX_RQ + 8 * qw + 2] + pp;
+        else if (h == 0) fx[FX_DWV + st_idx] = 0.0f;
+        // d hf goes back to the hand-off buffer (hf is dead): B7H / B7X read their operand from there, one LDS read per
+        // k-step -- held in registers next to their accumulators it spilled (and this compiler's AGPR rewrite crashes
+        // on spills); B7H does not write the buffer, so it survives until B6 fills it with d hc
+#pragma unroll
+        for (int ks = 0; ks < KS_H; ++ks) {
+          *reinterpret_cast<V*>(hbuf + ks * PIECE) = hin[ks];
+          __builtin_nontemporal_store(hin[ks], act_base(11, ks));
+        }
+      }
+      __syncthreads();
+      composite(std::integral_constant<int, 2>{});
     }
     __syncthreads();
     T256(9);
@@ -1011,21 +1251,46 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
     // hidden input-gradient layer: d(input features) from NK k-steps of bsel, masked by the ReLU bits of the PRODUCING
     // layer `mlayer`, stored as the weight-gradient operand `5 + mlayer` and handed to the next GEMM through hbuf;
     // pipelined like the forward layers (the mask word of a block is fetched one stage before its epilogue)
-    auto bwd_layer = [&](auto seq_tag, auto nk_tag, const int mlayer, auto&& bsel) __attribute__((always_inline)) {
-      constexpr int NK = decltype(nk_tag)::value, Q = decltype(seq_tag)::value;
+    // mode_tag (feature loss): 0 = as described; 1 = B7H, the feature layer's share of d h4 -- NOT masked (the colour layer's
+    // share is still to come), not handed over (the hand-off buffer is B6's next), parked in the workspace slot of d_pre4
+    // with ordinary stores; 2 = B5H with that share added back in the epilogue (read one stage ahead, like the mask word,
+    // from the very addresses the block's result then overwrites).
+    auto bwd_layer = [&](auto seq_tag, auto nk_tag, const int mlayer, auto&& bsel, auto mode_tag) __attribute__((always_inline)) {
+      constexpr int NK = decltype(nk_tag)::value, Q = decltype(seq_tag)::value, MODE = decltype(mode_tag)::value;
       constexpr int SK = NK - 1 < 8 ? NK - 1 : 8;
       auto mask_bits = [&](const int b) __attribute__((always_inline)) -> uint32_t {
+        if constexpr (MODE == 1) return 0x00ff00ffu;
         return s_mask[(mlayer * 4 + (b >> 1)) * NTHR + tid] >> (8 * (b & 1));
       };
       auto finish = [&](const int pb, const uint32_t (&wd)[8], GV* dst) __attribute__((always_inline)) {
         const uint4 u0 = make_uint4(wd[0], wd[1], wd[2], wd[3]), u1 = make_uint4(wd[4], wd[5], wd[6], wd[7]);
         const V f0 = __builtin_bit_cast(V, u0), f1 = __builtin_bit_cast(V, u1);
-        *reinterpret_cast<V*>(hbuf + (2 * pb) * PIECE) = f0;
-        *reinterpret_cast<V*>(hbuf + (2 * pb + 1) * PIECE) = f1;
-        __builtin_nontemporal_store(f0, dst);
-        __builtin_nontemporal_store(f1, dst + 64);
+        if constexpr (MODE == 1) {
+          *dst = f0;
+          *(dst + 64) = f1;
+        } else {
+          *reinterpret_cast<V*>(hbuf + (2 * pb) * PIECE) = f0;
+          *reinterpret_cast<V*>(hbuf + (2 * pb + 1) * PIECE) = f1;
+          __builtin_nontemporal_store(f0, dst);
+          __builtin_nontemporal_store(f1, dst + 64);
+        }
       };
       uint32_t mb = 0;                                     // mask bits of the block whose epilogue comes next
+      // MODE 2: block b's first accumulator chain STARTS from the parked share of block b (unpacked to fp32 into the
+      // accumulator that has just been drained, as the forward layers start theirs from the bias rows): no register beyond
+      // the accumulator itself carries it (a prefetched copy next to the epilogue words spilled, and this compiler's AGPR
+      // rewrite crashes on spills)
+      auto load_part = [&](f32x16& acc, const int b) __attribute__((always_inline)) {
+        if constexpr (MODE == 2) {
+          const GV* src = act_base(5 + mlayer, 2 * b);
+          const uint4 g0 = __builtin_bit_cast(uint4, *src), g1 = __builtin_bit_cast(uint4, *(src + 64));
+          float x0, x1;
+          Unpack<OT>::get(g0.x, x0, x1); acc[0] = x0; acc[1] = x1;   Unpack<OT>::get(g0.y, x0, x1); acc[2] = x0; acc[3] = x1;
+          Unpack<OT>::get(g0.z, x0, x1); acc[4] = x0; acc[5] = x1;   Unpack<OT>::get(g0.w, x0, x1); acc[6] = x0; acc[7] = x1;
+          Unpack<OT>::get(g1.x, x0, x1); acc[8] = x0; acc[9] = x1;   Unpack<OT>::get(g1.y, x0, x1); acc[10] = x0; acc[11] = x1;
+          Unpack<OT>::get(g1.z, x0, x1); acc[12] = x0; acc[13] = x1; Unpack<OT>::get(g1.w, x0, x1); acc[14] = x0; acc[15] = x1;
+        }
+      };
       auto stage = [&](auto np2_tag, const int blk, f32x16& cur, f32x16& cur1, f32x16& prv, f32x16& prv1) __attribute__((always_inline)) {
         constexpr int NP2 = decltype(np2_tag)::value;
         uint32_t wd[8];
@@ -1042,12 +1307,13 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
             for (int i = SK; i < 8; ++i) piece(i);
             finish(pb, wd, blk > 0 ? act_base(5 + mlayer, 2 * pb) : (GV*)park);
             mb = mask_bits(blk);
+            if (blk < 7) load_part(prv, blk + 1);          // prv becomes the next block's first chain
           }
           dma_side(np2_tag, nk_tag, ks_tag, std::false_type{}, strm.cw[cls_of(NP2)]);
           OBJ256_SCHED_FENCE();
         };
         T256(0);
-        KT::template block_mma<NK, true, true>(cur, cur1, ring_addr(), bsel, sd);
+        KT::template block_mma<NK, MODE != 2, true>(cur, cur1, ring_addr(), bsel, sd);
         asm volatile("" : "+v"(mb));
         T256(3);
         KT::template stage_sync<NW, NP2, 2>(strm.last);
@@ -1055,6 +1321,7 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
         T256(4);
       };
       f32x16 accA, accA1, accB = zero16(), accB1 = zero16();
+      load_part(accA, 0);
 #pragma unroll 1
       for (int blk = 0; blk < 6; blk += 2) {
         stage(nk_tag, blk, accA, accA1, accB, accB1);
@@ -1071,18 +1338,21 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
       }
     };
     // slot-gradient blocks (d x1 / d x2): NB blocks accumulated into xacc[b]
-    auto bwd_slots = [&](auto seq_tag, auto nb_tag, auto keep_tag, f32x16* xacc) __attribute__((always_inline)) {
+    auto bwd_slots = [&](auto seq_tag, auto nb_tag, auto keep_tag, f32x16* xacc, auto from_hbuf_tag) __attribute__((always_inline)) {
       // keep_tag: the chains continue from xacc instead of starting at zero
       constexpr int NB = decltype(nb_tag)::value, Q = decltype(seq_tag)::value;
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         f32x16 odd = zero16();
-        auto bs = [&](int ks) -> V { return hin[ks]; };
+        auto bs = [&](int ks) -> V {
+          if constexpr (decltype(from_hbuf_tag)::value) return *reinterpret_cast<const V*>(hbuf + ks * PIECE);
+          else return hin[ks];
+        };
         // (b is a constant after unrolling; the switch only turns it into one the templates can take)
         auto run = [&](auto b_tag) __attribute__((always_inline)) {
           constexpr int B = decltype(b_tag)::value;
-          constexpr int G2 = stg_base(Q) + B + 2;           // the stage requested here
-          constexpr int NP2 = stage_pieces(G2);
+          constexpr int G2 = SQT::stg_base(Q) + B + 2;           // the stage requested here
+          constexpr int NP2 = SQT::stage_pieces(G2);
           if constexpr (G2 >= N_STAGES) {
             // the next tile's first stages: nothing after the workgroup's last tile; the image restarts (next object's
             // image after the object's last tile)
@@ -1105,10 +1375,33 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
         else run(std::integral_constant<int, 2>{});
       }
     };
-    float dproj[11];
-#pragma unroll
-    for (int dd = 0; dd < 11; ++dd) dproj[dd] = 0.f;
 
+    if constexpr (FEAT) {
+      // B7H: the feature layer's share of d h4 = W_fl[:, :H]^T d hf (hin = d hf), parked unmasked in d_pre4's slot;
+      // B7X: its share of d x2, whose chain rule (embedding.py:49-52, linear in d x2) is applied right away
+      bwd_layer(std::integral_constant<int, B7H>{}, std::integral_constant<int, 16>{}, 3,
+                [&](int ks) -> V { return *reinterpret_cast<const V*>(hbuf + ks * PIECE); }, std::integral_constant<int, 1>{});
+      f32x16 xa[2];
+      bwd_slots(std::integral_constant<int, B7X>{}, std::integral_constant<int, 2>{}, std::false_type{}, xa, std::true_type{});
+      float vh[11], vl[11];
+      project(vh, vl);
+#pragma unroll
+      for (int dd = 0; dd < 11; ++dd) {                     // slot u = 2 dd + (f - 4)
+        float sv[2], cv[2];
+        rev_ladder<4, 2>(vh[dd], vl[dd], sv, cv);
+        float dpf = 0.0f;
+#pragma unroll
+        for (int f = 4; f < 6; ++f) {
+          const int u = 2 * dd + (f - 4);
+          dpf = fmaf(xa[u >> 4][u & 15], cv[f - 4] * (OBJ_PI_F * (float)(1 << f)), dpf);
+        }
+        // straight into d B (linear): eleven more values alive across B6 and B5H spilled
+        const float dp = (valid && (dd < 10 || h == 0)) ? dpf * inv_gs : 0.0f;
+        dbacc[dd][0] = fmaf(dp, t0, dbacc[dd][0]);
+        dbacc[dd][1] = fmaf(dp, t1, dbacc[dd][1]);
+        dbacc[dd][2] = fmaf(dp, t2, dbacc[dd][2]);
+      }
+    }
     {   // B6 (ONE stage, eight one-piece blocks): d hc = W_oc^T d colour, masked by hc's ReLU bits -> hbuf, tensor 9
       constexpr int NP2 = NP2_OF(B6, 0);
       constexpr int CD = quota(NP2, NW);
@@ -1155,11 +1448,14 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
     reload();                                                                                                                  // hin = d hc
     T256(10);
     bwd_layer(std::integral_constant<int, B5H>{}, std::integral_constant<int, 17>{}, 3,
-              [&](int ks) -> V { return ks < KS_H ? hin[ks] : dh; });                                                          // d h4
+              [&](int ks) -> V { return ks < KS_H ? hin[ks] : dh; }, std::integral_constant<int, FEAT ? 2 : 0>{});             // d h4
     T256(7);
+    float dproj[11];
+#pragma unroll
+    for (int dd = 0; dd < 11; ++dd) dproj[dd] = 0.f;
     {                                                                                                                          // B5X: d x2
       f32x16 xa[2];
-      bwd_slots(std::integral_constant<int, B5X>{}, std::integral_constant<int, 2>{}, std::false_type{}, xa);
+      bwd_slots(std::integral_constant<int, B5X>{}, std::integral_constant<int, 2>{}, std::false_type{}, xa, std::false_type{});
       float vh[11], vl[11];
       project(vh, vl);
 #pragma unroll
@@ -1175,9 +1471,9 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
     }
     T256(11);
     reload();                                                                                                                  // hin = d h4
-    bwd_layer(std::integral_constant<int, B4>{}, std::integral_constant<int, 16>{}, 2, [&](int ks) -> V { return hin[ks]; });  // d h3
+    bwd_layer(std::integral_constant<int, B4>{}, std::integral_constant<int, 16>{}, 2, [&](int ks) -> V { return hin[ks]; }, std::integral_constant<int, 0>{});  // d h3
     reload();
-    bwd_layer(std::integral_constant<int, B3H>{}, std::integral_constant<int, 16>{}, 1, [&](int ks) -> V { return hin[ks]; }); // d h2
+    bwd_layer(std::integral_constant<int, B3H>{}, std::integral_constant<int, 16>{}, 1, [&](int ks) -> V { return hin[ks]; }, std::integral_constant<int, 0>{}); // d h2
     auto pe_bwd_x1 = [&](const f32x16* x1a) __attribute__((always_inline)) {
       float vh[11], vl[11];
       project(vh, vl);
@@ -1195,17 +1491,17 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
     T256(7);
     {                                                                                                                          // B3X: d x1
       f32x16 x1a[3];
-      bwd_slots(std::integral_constant<int, B3X>{}, std::integral_constant<int, 3>{}, std::false_type{}, x1a);
+      bwd_slots(std::integral_constant<int, B3X>{}, std::integral_constant<int, 3>{}, std::false_type{}, x1a, std::false_type{});
       pe_bwd_x1(x1a);          // (the chain rule is linear in d x1: applied per contribution)
     }
     T256(12);
     reload();                                                                                                                  // hin = d h2
-    bwd_layer(std::integral_constant<int, B2>{}, std::integral_constant<int, 16>{}, 0, [&](int ks) -> V { return hin[ks]; });  // d h1
+    bwd_layer(std::integral_constant<int, B2>{}, std::integral_constant<int, 16>{}, 0, [&](int ks) -> V { return hin[ks]; }, std::integral_constant<int, 0>{});  // d h1
     reload();
     T256(7);
     {                                                                                                                          // B1: d x1 +=
       f32x16 x1a[3];
-      bwd_slots(std::integral_constant<int, B1>{}, std::integral_constant<int, 3>{}, std::false_type{}, x1a);
+      bwd_slots(std::integral_constant<int, B1>{}, std::integral_constant<int, 3>{}, std::false_type{}, x1a, std::false_type{});
       pe_bwd_x1(x1a);
     }
     T256(13);
@@ -1241,12 +1537,13 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
 // Every task also yields the row sums of its A operand (bias gradients).  A workgroup takes one (object, type, part)
 // = a range of sample groups, and writes its partial tiles [.][32][32] + row sums into its slab.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int NTYPE = 6;
-__host__ __device__ constexpr int type_tiles(int t) { return t == 1 ? 88 : t == 3 ? 88 : t == 4 ? 24 : t == 5 ? 8 : 64; }
+//   6 Lf   d_pre_f x [h4 | x2]        (8 x 10; the feature layer, only with the feature loss: zero parts otherwise)
+constexpr int NTYPE = 7;
+__host__ __device__ constexpr int type_tiles(int t) { return t == 1 ? 88 : t == 3 ? 88 : t == 4 ? 24 : t == 5 ? 8 : t == 6 ? 80 : 64; }
 __host__ __device__ constexpr int type_rows(int t) { return t == 3 ? 9 * 32 : t == 5 ? 32 : 8 * 32; }      // row sums
 __host__ __device__ constexpr int type_slab(int t) { return type_tiles(t) * 1024 + type_rows(t); }
 __host__ __device__ constexpr int type_pieces(int t) {      // 1-KB pieces per sample group
-  return t == 1 ? 16 + 16 + KS_X1 : t == 3 ? 16 + 1 + 16 + KS_X2 : t == 4 ? 16 + KS_X1 : t == 5 ? 1 + 16 : 32;
+  return t == 1 ? 16 + 16 + KS_X1 : t == 3 ? 16 + 1 + 16 + KS_X2 : t == 4 ? 16 + KS_X1 : t == 5 ? 1 + 16 : t == 6 ? 16 + 16 + KS_X2 : 32;
 }
 struct WgArgs {
   int K;
@@ -1566,7 +1863,7 @@ __global__ __launch_bounds__(NTHR) void wgrad256_kernel(const WgArgs a) {
   const int per_obj = a.prefix[NTYPE];
   const int k = blockIdx.x / per_obj, r = blockIdx.x - k * per_obj;
   int t = 0;
-  while (t + 1 < NTYPE && r >= a.prefix[t + 1]) ++t;
+  while (t + 1 < NTYPE && r >= a.prefix[t + 1]) ++t;         // (a type without parts has an empty range: never selected)
   const int part = r - a.prefix[t], nparts = a.parts[t];
   const long sg0 = a.wl.nsg * part / nparts, sg1 = a.wl.nsg * (part + 1) / nparts;
   const char* ws = a.ws + (long)k * a.wl.obj_bytes;
@@ -1579,7 +1876,8 @@ __global__ __launch_bounds__(NTHR) void wgrad256_kernel(const WgArgs a) {
     case 2: wgrad_task<OT, 8, 8, 4, 2, 0, 0, 0>(a, act(8), act(2), sg0, sg1, slab, lds); break;
     case 3: wgrad_cat<OT, KS_X2, true>(act(9), dh, act(3), x2, sg0, sg1, slab, lds); break;
     case 4: wgrad_task<OT, 8, 3, 8, 1, 0, 2, KS_X1>(a, act(5), x1, sg0, sg1, slab, lds); break;
-    default: wgrad_task<OT, 1, 8, 1, 8, 1, 0, 0>(a, dh, act(4), sg0, sg1, slab, lds); break;
+    case 5: wgrad_task<OT, 1, 8, 1, 8, 1, 0, 0>(a, dh, act(4), sg0, sg1, slab, lds); break;
+    default: wgrad_cat<OT, KS_X2, false>(act(11), dh, act(3), x2, sg0, sg1, slab, lds); break;
   }
 }
 
@@ -1594,6 +1892,7 @@ struct FinArgs {
   float* grads; float* loss_terms; int* status;
   float inv_gs;
   Lay256 L;
+  int feat;
 };
 __device__ __forceinline__ float slab_sum(const FinArgs& a, int k, int t, long elem) {
   const float* base = a.slabs + (long)k * a.slab_prefix[NTYPE] + a.slab_prefix[t] + elem;
@@ -1649,12 +1948,17 @@ __global__ __launch_bounds__(256) void finalize256_kernel(const FinArgs a) {
       for (int g = 0; g < NWG_A; ++g) sdb += a.part[((long)k * NWG_A + g) * PART_FLOATS + (i - L.pe_b)];
       a.grads[(long)k * a.p_stride + i] = sdb;          // (kernel A already removed the gradient scale)
       has = false;
-    } else has = false;                                  // feature branch: no gradient without gt_feat
+    } else if (a.feat && i >= L.fl_w && i < L.fl_b) {    // feature layer (task 6: tiles (o >> 5) * 10 + column block)
+      const int e = (int)(i - L.fl_w), o = e / (HID + E2), c = e % (HID + E2);
+      if (c < HID) v = tile(6, (o >> 5) * 10 + (c >> 5), o & 31, c & 31);
+      else { const int pos = x2_col_pos(c - HID); v = tile(6, (o >> 5) * 10 + 8 + (pos >> 10), o & 31, pos & 1023); }
+    } else if (a.feat && i >= L.fl_b && i < L.fl_b + HID) v = rowsum(6, (int)(i - L.fl_b));
+    else has = false;                                    // (the 512-d head: featg_finish_kernel; without gt_feat: no gradient)
     if (has) a.grads[(long)k * a.p_stride + i] = v * a.inv_gs;
   }
   if (blockIdx.x == 0 && threadIdx.x < 4) {
     float sl = 0.f;
-    if (threadIdx.x < 3)
+    if (threadIdx.x < (a.feat ? 4 : 3))
       for (int g = 0; g < NWG_A; ++g) sl += a.part[((long)k * NWG_A + g) * PART_FLOATS + 64 + threadIdx.x];
     a.loss_terms[k * 4 + threadIdx.x] = sl;
     if (sl > 100000.0f) atomicOr(a.status, 1);           // render_rays.py:109-111
@@ -1669,15 +1973,15 @@ static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 struct Plan {
   WsLay wl;
   int parts[NTYPE]; int prefix[NTYPE + 1]; long slab_prefix[NTYPE + 1];
-  size_t off_img, off_part, off_slabs, off_ws, off_dummy, bytes;
+  size_t off_img, off_part, off_slabs, off_ws, off_dummy, off_feat, bytes;
 };
 #ifndef OBJ256_NW
 #define OBJ256_NW 4          // waves per workgroup of kernel A where the ray length allows (S <= 32 NW)
 #endif
 static int waves_for(int) { return OBJ256_NW; }
-static Plan make_plan(int K, long n, int S) {
+static Plan make_plan(int K, long n, int S, bool feat = false, int R = 0, int C = 0) {
   Plan p;
-  p.wl = WsLay::make(n, 32 * waves_for(S));
+  p.wl = WsLay::make(n, 32 * waves_for(S), feat);
   static const long target_mb = [] { const char* e = getenv("OBJ256_WG_TARGET_MB"); return e ? atol(e) : 48L; }();   // (diagnostic override)
   const long target = target_mb << 20;                // bytes one weight-gradient workgroup streams
   p.prefix[0] = 0; p.slab_prefix[0] = 0;
@@ -1686,16 +1990,19 @@ static Plan make_plan(int K, long n, int S) {
     long parts = (bytes + target - 1) / target;
     if (parts < 1) parts = 1;
     if (parts > p.wl.nsg / 2) parts = p.wl.nsg / 2 > 0 ? p.wl.nsg / 2 : 1;
+    if (t == 6 && !feat) parts = 0;                     // the feature layer's task
     p.parts[t] = (int)parts;
     p.prefix[t + 1] = p.prefix[t] + (int)parts;
     p.slab_prefix[t + 1] = p.slab_prefix[t] + parts * type_slab(t);
   }
   size_t o = 0;
-  p.off_img = o; o += al256((size_t)K * IMG_BYTES);
+  p.off_img = o; o += al256((size_t)K * (feat ? SQ<true>::IMG_BYTES : SQ<false>::IMG_BYTES));
   p.off_part = o; o += al256((size_t)K * NWG_A * PART_FLOATS * 4);
   p.off_slabs = o; o += al256((size_t)K * p.slab_prefix[NTYPE] * 4);
   p.off_ws = o; o += al256((size_t)K * p.wl.obj_bytes);
   p.off_dummy = o; o += al256((size_t)NWG_A * 8 * 2048);      // kernel A: parking area of the stale stores of a layer's first stage
+  p.off_feat = o;
+  if (feat) o += al256(objgen::feat_head_workspace_bytes(K, R, HID, C));      // the hoisted 512-d head's buffers (objnerf_generic.hip)
   p.bytes = o;
   return p;
 }
@@ -1703,24 +2010,28 @@ static Plan make_plan(int K, long n, int S) {
 bool applicable(const objnerf_net* net, const objnerf_train_args* a) {
   if (net->hidden != HID || net->n_freqs != 6) return false;
   if (!(a->mode & (OBJNERF_TRAIN_BF16 | OBJNERF_TRAIN_FP16))) return false;
-  if (a->gt_feat || a->relu_masks || a->emb_debug) return false;
+  if (a->relu_masks || a->emb_debug) return false;
+  if (a->gt_feat && (OBJ256_NW != 4 || net->feat_dim % 4 != 0)) return false;   // (the feature step maps 256 threads to the 256 features)
   const int S = a->S;
   return S == 32 || S == 64 || S == 128;
 }
-size_t workspace_bytes(int K, int R, int S) { return make_plan(K, (long)R * S, S).bytes + 256; }
+size_t workspace_bytes(int K, int R, int S, int feat, int C) {
+  return make_plan(K, (long)R * S, S, feat != 0, R, C).bytes + 256;
+}
 
-template <typename OT, int S, int NW>
+template <typename OT, int S, int NW, bool FEAT>
 static void launch_fwd(const FwdArgs& fa, hipStream_t st) {
   objnerf_once_per_device([] {
-    (void)hipFuncSetAttribute((const void*)fwd256_kernel<OT, S, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, l_total(NW));
+    (void)hipFuncSetAttribute((const void*)fwd256_kernel<OT, S, NW, FEAT>, hipFuncAttributeMaxDynamicSharedMemorySize, l_total(NW));
   });
-  hipLaunchKernelGGL((fwd256_kernel<OT, S, NW>), dim3(NWG_A), dim3(NW * 64), l_total(NW), st, fa);
+  hipLaunchKernelGGL((fwd256_kernel<OT, S, NW, FEAT>), dim3(NWG_A), dim3(NW * 64), l_total(NW), st, fa);
 }
-template <typename OT>
+template <typename OT, bool FEAT>
 static int run(const objnerf_net* net, const objnerf_train_args* a, hipStream_t st) {
   const int K = a->K;
   const long n = (long)a->R * a->S;
-  const Plan p = make_plan(K, n, a->S);
+  const int C = net->feat_dim;
+  const Plan p = make_plan(K, n, a->S, FEAT, a->R, C);
   if (a->workspace_bytes < p.bytes) return OBJNERF_EINVAL;
   char* base = (char*)a->workspace;
   int64_t off[OBJNERF_N_TENSORS + 1];
@@ -1729,6 +2040,7 @@ static int run(const objnerf_net* net, const objnerf_train_args* a, hipStream_t 
   L.in_w = (int)off[0]; L.in_b = (int)off[1]; L.m1_w = (int)off[2]; L.m1_b = (int)off[3]; L.cat_w = (int)off[4];
   L.cat_b = (int)off[5]; L.m2_w = (int)off[6]; L.m2_b = (int)off[7]; L.a_w = (int)off[8]; L.a_b = (int)off[9];
   L.cl_w = (int)off[10]; L.cl_b = (int)off[11]; L.oc_w = (int)off[12]; L.oc_b = (int)off[13]; L.pe_b = (int)off[18];
+  L.fl_w = (int)off[14]; L.fl_b = (int)off[15];
   OT* img = (OT*)(base + p.off_img);
   float* part = (float*)(base + p.off_part);
   float* slabs = (float*)(base + p.off_slabs);
@@ -1736,9 +2048,18 @@ static int run(const objnerf_net* net, const objnerf_train_args* a, hipStream_t 
   (void)hipMemsetAsync(a->status, 0, sizeof(int), st);
   (void)hipMemsetAsync(part, 0, (size_t)K * NWG_A * PART_FLOATS * 4, st);
   {
-    const long tot = (long)K * N_PIECES * 64;
-    hipLaunchKernelGGL((pack256_kernel<OT>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, K, a->params,
+    const long tot = (long)K * SQ<FEAT>::N_PIECES * 64;
+    hipLaunchKernelGGL((pack256_kernel<OT, FEAT>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, K, a->params,
                        (long)a->p_stride, L, img);
+  }
+  objgen::FeatHead fh;
+  if (FEAT) {
+    // the hoisted 512-d head: per object G = W_of^T W_of (+ wb, bb), per ray u = W_of^T g, beta, |g| -- ahead
+    // of kernel A, with the operand type of the mode (16-bit GEMM operands, like the layer-wise path)
+    fh = objgen::feat_head_carve(base + p.off_feat, K, a->R, HID, C);
+    const int rc = objgen::feat_head_prep(st, K, a->R, HID, C, a->params, (long)a->p_stride, off[16], off[17], a->gt_feat, fh,
+                                          (a->mode & OBJNERF_TRAIN_FP16) ? 2 : 1);
+    if (rc) return rc;
   }
   const float gs = (a->mode & OBJNERF_TRAIN_FP16) ? exp2f(floorf(log2f((float)a->R)) + 3.0f) : 1.0f;
   FwdArgs fa;
@@ -1754,13 +2075,15 @@ static int run(const objnerf_net* net, const objnerf_train_args* a, hipStream_t 
   fa.gt_depth = a->gt_depth; fa.gt_rgb = a->gt_rgb; fa.labels = a->labels;
   fa.counts = a->counts; fa.flags = a->flags;
   fa.img = img; fa.ws = ws; fa.dummy = base + p.off_dummy; fa.part = part; fa.L = L; fa.wl = p.wl;
+  fa.feat_scaling = a->feat_scaling;
+  fa.rayin = fh.rayin; fa.gram = fh.gram; fa.rayfeat = fh.rayfeat; fa.X1 = fh.X1; fa.X2 = fh.X2;
 #ifdef OBJ256_ONE          // diagnostic builds: one instantiation (compile time)
-  launch_fwd<OT, 128, OBJ256_NW>(fa, st);
+  launch_fwd<OT, 128, OBJ256_NW, FEAT>(fa, st);
 #else
   switch (a->S) {
-    case 32: launch_fwd<OT, 32, OBJ256_NW>(fa, st); break;
-    case 64: launch_fwd<OT, 64, OBJ256_NW>(fa, st); break;
-    default: launch_fwd<OT, 128, OBJ256_NW>(fa, st); break;
+    case 32: launch_fwd<OT, 32, OBJ256_NW, FEAT>(fa, st); break;
+    case 64: launch_fwd<OT, 64, OBJ256_NW, FEAT>(fa, st); break;
+    default: launch_fwd<OT, 128, OBJ256_NW, FEAT>(fa, st); break;
   }
 #endif
   WgArgs wa;
@@ -1778,17 +2101,24 @@ static int run(const objnerf_net* net, const objnerf_train_args* a, hipStream_t 
   for (int t = 0; t < NTYPE; ++t) fn.parts[t] = p.parts[t];
   for (int t = 0; t <= NTYPE; ++t) fn.slab_prefix[t] = p.slab_prefix[t];
   fn.slabs = slabs; fn.part = part; fn.grads = a->grads; fn.loss_terms = a->loss_terms; fn.status = a->status;
-  fn.inv_gs = 1.0f / gs; fn.L = L;
+  fn.inv_gs = 1.0f / gs; fn.L = L; fn.feat = FEAT ? 1 : 0;
   hipLaunchKernelGGL(finalize256_kernel, dim3((unsigned)((fn.P + 255) / 256), (unsigned)K), dim3(256), 0, st, fn);
+  if (FEAT) {
+    // d W_of, d b_of from the rays' moments (two GEMMs over the rays + featg_finish_kernel)
+    const int rc = objgen::feat_head_grads(st, K, a->R, HID, C, a->params, (long)a->p_stride, off[16], off[17], a->gt_feat, fh,
+                                           a->grads, (a->mode & OBJNERF_TRAIN_FP16) ? 2 : 1);
+    if (rc) return rc;
+  }
   if (hipGetLastError() != hipSuccess) return OBJNERF_ELAUNCH;
   return OBJNERF_OK;
 }
 
 int train_step(const objnerf_net* net, const objnerf_train_args* a, void* stream) {
+  const bool feat = a->gt_feat != nullptr;
 #ifndef OBJ256_ONE
-  if (a->mode & OBJNERF_TRAIN_FP16) return run<_Float16>(net, a, (hipStream_t)stream);
+  if (a->mode & OBJNERF_TRAIN_FP16) return feat ? run<_Float16, true>(net, a, (hipStream_t)stream) : run<_Float16, false>(net, a, (hipStream_t)stream);
 #endif
-  return run<__bf16>(net, a, (hipStream_t)stream);
+  return feat ? run<__bf16, true>(net, a, (hipStream_t)stream) : run<__bf16, false>(net, a, (hipStream_t)stream);
 }
 
 }  // namespace obj256
