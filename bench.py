@@ -496,13 +496,15 @@ OTHER_CONFIGS = [   # (key, base config, overrides, operand modes) -- timed afte
     ("c3", "c3", {}, [False, True]),
     ("c4_share", "c4", {"objects": 15, "scaling": "weak", "bg_ranks": 8}, [False, True]),
     ("c5_share_fp16", "c5", {"bg": False}, ["fp16"]),
+    ("c5_share_fp16_feat", "c5", {"bg": False, "feat": True}, ["fp16"]),     # the reference always has the clip branch (model.py:98-101)
 ]
 
 
 def other_configs(args, dev):
     """The BASELINE configurations the headline line is not quoted on, each timed by the same procedure (`--other-steps`
     timed steps): c3, configs[3]'s per-GPU share (15 objects with the feature loss) and configs[4]'s per-GPU share
-    (64 objects, hidden 256, 8192 x 128) in fp16."""
+    (64 objects, hidden 256, 8192 x 128) in fp16, without and with the 512-d feature loss (both on the fused hidden-256
+    kernels since round 5)."""
     out = {}
     names = {False: "f32", True: "bf16", "fp16": "fp16"}
     for key, base, over, modes in OTHER_CONFIGS:
@@ -771,7 +773,8 @@ def main():
                                  "around objnerf_train_step, inside the timed steps) now includes the optimiser; the "
                                  "background chain of step i may run under the object kernel of step i + 1 (--no-pipeline "
                                  "restores the per-step join); algorithmic_bytes_per_launch of the feature configs is the "
-                                 "fused kernel's scope; c5 trains 64 distinct ray sets; other_configs.c4_share stands "
+                                 "fused kernel's scope; c5 trains 64 distinct ray sets (c5_share_fp16_feat: the same with the 512-d "
+                                 "feature loss, on the fused hidden-256 kernels); other_configs.c4_share stands "
                                  "for one of 8 ranks WITHOUT the gradient all-reduce it would take part in")
         # LAST in the line (the driver records its tail): the figures a reader looks for first
         summ = {"f32_rays_per_s": out["value"] if args.dtype == "f32" else None, "f32_ms_per_step": out["ms_per_step"]
@@ -781,7 +784,7 @@ def main():
                          "bf16_roofline_frac": out["bf16_mode"]["roofline"]["frac"],
                          "bf16_kernel_ms": out["bf16_mode"]["roofline"]["kernel_ms"]})
         oc = out.get("other_configs", {})
-        for key in ("c3", "c4_share", "c5_share_fp16"):
+        for key in ("c3", "c4_share", "c5_share_fp16", "c5_share_fp16_feat"):
             for m_ in ("f32", "bf16", "fp16"):
                 if isinstance(oc.get(key), dict) and m_ in oc[key]:
                     summ[f"{key}_{m_}_rays_per_s"] = oc[key][m_]["value"]

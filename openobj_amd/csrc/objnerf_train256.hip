@@ -258,6 +258,25 @@ __global__ __launch_bounds__(256) void pack256_kernel(int K, const float* __rest
   reinterpret_cast<typename Op<OT>::V*>(img)[idx] = out;
 }
 
+// The Gram matrix G = W_of^T W_of of the hoisted feature head as an A-operand image [8 row blocks][16 k-steps][64 lanes][8]
+// in the operand type (128 KB per object): kernel A's feature step multiplies it by the rays' fh on the matrix cores.
+constexpr int GIMG_PIECES = 8 * KS_H;
+template <typename OT>
+__global__ __launch_bounds__(256) void packg256_kernel(int K, const float* __restrict__ gram, long gstride, OT* __restrict__ gimg) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;        // (object, piece, lane)
+  if (idx >= (long)K * GIMG_PIECES * 64) return;
+  const int lane = (int)(idx & 63);
+  const int piece = (int)((idx >> 6) % GIMG_PIECES);
+  const int k = (int)((idx >> 6) / GIMG_PIECES);
+  const int blk = piece / KS_H, ks = piece - blk * KS_H;
+  const int r = lane & 31, h = lane >> 5;
+  const float* G = gram + (long)k * gstride + (long)(32 * blk + r) * HID;
+  typename Op<OT>::V out;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) out[j] = Op<OT>::cvt(G[hid_feat(ks, h, j)]);
+  reinterpret_cast<typename Op<OT>::V*>(gimg)[idx] = out;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Workspace of one call (K objects, n = R S samples each, padded to whole tiles): per object
 //   acts  [5][NSG][16][64][8] 16 bit   h1 h2 h3 h4 hc as B fragments (k-step ks of sample group sg: 1 KB)
@@ -305,6 +324,7 @@ struct FwdArgs {
   float feat_scaling;
   const float* rayin;                   // [K][R][HID + 2]  u = W_of^T g, beta = b_of . g, |g|
   const float* gram;                    // [K][HID HID + HID + 1]  G = W_of^T W_of (symmetric), wb, bb
+  const void* gimg;                     // [K][GIMG_PIECES][64][8] operand type: G as an A-operand image (packg256_kernel)
   float* rayfeat;                       // [K][R][HID + 3]  fh, O, a, c   (-> the head's moment GEMMs)
   float *X1, *X2;                       // [K][R][HID + 1]  [a fh | a O], [c fh | c O]
 };
@@ -399,7 +419,7 @@ template <> __device__ __forceinline__ uint32_t pk_cvt<_Float16>(float a, float 
 #define OBJ256_SCHED_FENCE() do {} while (0)
 #endif
 #ifdef OBJ256_TIMING      // diagnostic build: cycles per part of a stage (s_memtime), printed by workgroup 0 / wave 0
-#define T256_DECL unsigned long long tm_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tm_t = __builtin_amdgcn_s_memtime()
+#define T256_DECL unsigned long long tm_[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tm_t = __builtin_amdgcn_s_memtime()
 #define T256(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tm_[i] += t_ - tm_t; tm_t = t_; } while (0)
 #else
 #define T256_DECL do {} while (0)
@@ -660,16 +680,22 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
   T256_DECL;
   int cur_obj = -1;
   float l_d = 0.f, l_c = 0.f, l_o = 0.f, l_f = 0.f;
-  float dbacc[11][3];               // d B of this lane's directions, summed over this lane's samples of the object
+  // d B of this lane's directions, summed over this lane's samples of the object.  With the feature loss there is no room
+  // for 33 registers that live through every layer loop (the compiler spilled them and more, and its AGPR rewrite pass
+  // crashes on some spilled forms): there each tile's contribution is reduced over the lanes at once and added to the
+  // wave's sums in LDS (db_add below)
+  constexpr int NDB = FEAT ? 1 : 11;
+  float dbacc[NDB][3];
 #pragma unroll
-  for (int dd = 0; dd < 11; ++dd) dbacc[dd][0] = dbacc[dd][1] = dbacc[dd][2] = 0.f;
+  for (int dd = 0; dd < NDB; ++dd) dbacc[dd][0] = dbacc[dd][1] = dbacc[dd][2] = 0.f;
   float scale = 1.0f, inv1 = 0.f, inv2 = 0.f, ba = 0.f, boc0 = 0.f, boc1 = 0.f, boc2 = 0.f;
 
   auto flush_object = [&]() {       // partial d B and loss terms of (cur_obj, this workgroup)
     __syncthreads();
     float* pw = s_db + w * 68;
 #pragma unroll
-    for (int dd = 0; dd < 11; ++dd) {        // each 32-lane half owns its directions: sum over its lanes (samples)
+    for (int dd = 0; dd < NDB; ++dd) {       // each 32-lane half owns its directions: sum over its lanes (samples)
+      if constexpr (FEAT) break;             // (already in pw: db_add)
       float g0 = dbacc[dd][0], g1 = dbacc[dd][1], g2 = dbacc[dd][2];
 #pragma unroll
       for (int d = 16; d >= 1; d >>= 1) { g0 += __shfl_xor(g0, d, 32); g1 += __shfl_xor(g1, d, 32); g2 += __shfl_xor(g2, d, 32); }
@@ -778,6 +804,36 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
       rg0 = a.gt_depth[rr]; rg1 = a.gt_rgb[rr * 3]; rg2 = a.gt_rgb[rr * 3 + 1]; rg3 = a.gt_rgb[rr * 3 + 2]; rlab = a.labels[rr];
     }
     const float t0 = px / scale, t1 = py / scale, t2 = pz / scale;       // embedding.py:47
+    // d B[j][c] += d proj_j * t_c of this lane's sample (dpv: d loss / d projection of this half's directions, unscaled).
+    // FEAT: the 33 products are reduced over the 32 lanes of the half together (33 independent shuffle chains) and lane 0
+    // adds them to the wave's sums
+    auto db_add = [&](const float (&dpv)[11]) __attribute__((always_inline)) {
+      if constexpr (!FEAT) {
+#pragma unroll
+        for (int dd = 0; dd < 11; ++dd) {
+          dbacc[dd][0] = fmaf(dpv[dd], t0, dbacc[dd][0]);
+          dbacc[dd][1] = fmaf(dpv[dd], t1, dbacc[dd][1]);
+          dbacc[dd][2] = fmaf(dpv[dd], t2, dbacc[dd][2]);
+        }
+      } else {
+        float g[33];
+#pragma unroll
+        for (int dd = 0; dd < 11; ++dd) { g[3 * dd] = dpv[dd] * t0; g[3 * dd + 1] = dpv[dd] * t1; g[3 * dd + 2] = dpv[dd] * t2; }
+#pragma unroll
+        for (int d = 16; d >= 1; d >>= 1)
+#pragma unroll
+          for (int i = 0; i < 33; ++i) g[i] += __shfl_xor(g[i], d, 32);
+        if (s == 0) {                       // (all reads, then all writes: 33 dependent read-add-write round trips otherwise)
+          float* pj = s_db + w * 68 + 33 * h;
+          float o[33];
+#pragma unroll
+          for (int i = 0; i < 33; ++i) o[i] = pj[i];
+#pragma unroll
+          for (int i = 0; i < 33; ++i)
+            if (i < 30 || h == 0) pj[i] = o[i] + g[i];
+        }
+      }
+    };
     // projections of this half's directions as revolutions (hi + lo); recomputed where needed (22 registers otherwise)
     auto project = [&](float (&vh)[11], float (&vl)[11]) __attribute__((always_inline)) {
 #pragma unroll
@@ -1010,6 +1066,7 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
       static_assert(!FEAT || NTHR == HID, "the feature step maps a thread to a hidden feature");
       fwd_layer(std::integral_constant<int, F7>{}, std::integral_constant<int, 19>{}, 0,
                 [&](int ks) -> V { return ks < KS_H ? hin[ks] : x2f[ks - KS_H]; }, std::true_type{}, 10);                        // hf
+      T256(15);
       const uint32_t free_slot = strm.rd == strm.lo ? strm.lo + 2 * RING_SLOT : strm.rd - RING_SLOT;
       fx = reinterpret_cast<float*>(lds + (free_slot - lds0));
     }
@@ -1126,8 +1183,18 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
       composite(std::integral_constant<int, 1>{});
       reload();                                                           // hin = hf (this wave's 32 samples)
       __syncthreads();
+      T256(18);
       const int qw = (32 * w) / S;                                        // the tile's ray this wave's samples belong to
       const float wsm = valid ? fx[FX_W + st_idx] : 0.0f;
+      // G's fragments for the product G fh below (wave w: row blocks 2 w, 2 w + 1) are requested NOW, from the image in
+      // global memory (L2-resident: every workgroup of the object reads the same 128 KB), 16 bytes per lane and fragment:
+      // their latency passes under the reduce-scatter
+      V GA0[KS_H], GA1[KS_H];
+      {
+        const GV* gp = (const GV*)((const char*)a.gimg + ((long)k * GIMG_PIECES + 2 * w * KS_H) * PIECE) + lane;
+#pragma unroll
+        for (int i = 0; i < KS_H; ++i) { GA0[i] = gp[i * 64]; GA1[i] = gp[(KS_H + i) * 64]; }
+      }
       {
         // fh partial of this wave: sum over its 32 samples (the lanes of a half) of w_s hf -- a reduce-scatter: after the
         // five exchange steps lane s holds the complete sums of entries 4 s .. 4 s + 3 (entry 8 ks + j <-> feature
@@ -1157,22 +1224,53 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
         }
       }
       __syncthreads();
+      T256(16);
       const float* Gk = a.gram + (long)k * ((long)HID * HID + HID + 1);
       const float* wbv = Gk + (long)HID * HID;
+      // fh of every ray of the tile (thread = feature)
+#pragma unroll
+      for (int q2 = 0; q2 < TR; ++q2) {
+        float fhv = 0.0f;
+#pragma unroll
+        for (int ww = 0; ww < S / 32; ++ww) fhv += fx[FX_X + (q2 * (S / 32) + ww) * HID + tid];
+        fx[FX_FH + q2 * HID + tid] = fhv;
+      }
+      __syncthreads();
+      {
+        // G fh on the matrix cores: wave w owns the rows 64 w .. 64 w + 63 (two 32-row blocks) of G, column c of the B
+        // operand is ray c of the tile (c < TR; the other columns are zero) -- the thread-per-row dot product this replaces
+        // read 256 dependent-latency words per thread and ray and took more than the rest of the tile together.  (G
+        // enters in the operand type, like W_of and the targets entered its GEMM.)
+        f32x16 g0 = zero16(), g1 = zero16();
+        const int c = s;
+        const float* fb = fx + FX_FH + (c < TR ? c : 0) * HID + 4 * h;
+#pragma unroll
+        for (int ks = 0; ks < KS_H; ++ks) {
+          const float* dp = fb + 32 * (ks >> 1) + 16 * (ks & 1);
+          const f32x4v d0 = *reinterpret_cast<const f32x4v*>(dp), d1 = *reinterpret_cast<const f32x4v*>(dp + 8);
+          V bf;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) bf[j] = Op<OT>::cvt(c < TR ? (j < 4 ? d0[j] : d1[j - 4]) : 0.0f);
+          g0 = Op<OT>::mfma(GA0[ks], bf, g0);
+          g1 = Op<OT>::mfma(GA1[ks], bf, g1);
+        }
+        if (c < TR) {            // (the partial sums in FX_X are consumed: G fh of ray c goes there)
+#pragma unroll
+          for (int n = 0; n < 16; ++n) {
+            fx[FX_X + c * HID + 64 * w + acc_row(n, h)] = g0[n];
+            fx[FX_X + c * HID + 64 * w + 32 + acc_row(n, h)] = g1[n];
+          }
+        }
+      }
+      __syncthreads();
+      T256(17);
 #pragma unroll 1
       for (int q2 = 0; q2 < TR; ++q2) {
         const long rayq = tile * TR + q2;
         if (rayq >= a.R) break;                                            // (wave-uniform: padding rays of the last tile)
         const long rr = (long)k * a.R + rayq;
-        float fhv = 0.0f;
-#pragma unroll
-        for (int ww = 0; ww < S / 32; ++ww) fhv += fx[FX_X + (q2 * (S / 32) + ww) * HID + tid];
-        fx[FX_FH + q2 * HID + tid] = fhv;
-        __syncthreads();
-        // (G fh)[f] for f = tid: G is symmetric, so its COLUMN f is read -- coalesced over the threads, L2-resident
-        float gf = 0.0f;
-#pragma unroll 8
-        for (int f2 = 0; f2 < HID; ++f2) gf = fmaf(Gk[(long)f2 * HID + tid], fx[FX_FH + q2 * HID + f2], gf);
+        const float fhv = fx[FX_FH + q2 * HID + tid];
+        const float gf = fx[FX_X + q2 * HID + tid];                        // (G fh)[tid]
         const float* rin = a.rayin + rr * (HID + 2);
         const float uu = rin[tid], wbf = wbv[tid];
         const float su = seg_sum<64>(fhv * uu), sg_ = seg_sum<64>(fhv * gf), sw = seg_sum<64>(fhv * wbf);
@@ -1204,6 +1302,7 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
         __syncthreads();
       }
       __syncthreads();
+      T256(19);
       {
         // per sample: the feature part of d loss / d weight = gof + d fh . hf, and hf -> the pre-activation gradient of the
         // feature layer relu'(hf) w_s d fh (times the gradient scale) IN PLACE: `hin` becomes B7's operand
@@ -1233,6 +1332,7 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
         }
       }
       __syncthreads();
+      T256(20);
       composite(std::integral_constant<int, 2>{});
     }
     __syncthreads();
@@ -1280,10 +1380,18 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
       // accumulator that has just been drained, as the forward layers start theirs from the bias rows): no register beyond
       // the accumulator itself carries it (a prefetched copy next to the epilogue words spilled, and this compiler's AGPR
       // rewrite crashes on spills)
-      auto load_part = [&](f32x16& acc, const int b) __attribute__((always_inline)) {
+      // (requested a stage and a half before its use -- eight registers of raw words -- : one stage ahead left ~1 K cycles
+      // of the L2 round trip exposed in every stage)
+      uint4 pf0 = make_uint4(0, 0, 0, 0), pf1 = make_uint4(0, 0, 0, 0);
+      auto request_part = [&](const int b) __attribute__((always_inline)) {
         if constexpr (MODE == 2) {
           const GV* src = act_base(5 + mlayer, 2 * b);
-          const uint4 g0 = __builtin_bit_cast(uint4, *src), g1 = __builtin_bit_cast(uint4, *(src + 64));
+          pf0 = __builtin_bit_cast(uint4, *src); pf1 = __builtin_bit_cast(uint4, *(src + 64));
+        }
+      };
+      auto load_part = [&](f32x16& acc) __attribute__((always_inline)) {
+        if constexpr (MODE == 2) {
+          const uint4 g0 = pf0, g1 = pf1;
           float x0, x1;
           Unpack<OT>::get(g0.x, x0, x1); acc[0] = x0; acc[1] = x1;   Unpack<OT>::get(g0.y, x0, x1); acc[2] = x0; acc[3] = x1;
           Unpack<OT>::get(g0.z, x0, x1); acc[4] = x0; acc[5] = x1;   Unpack<OT>::get(g0.w, x0, x1); acc[6] = x0; acc[7] = x1;
@@ -1307,7 +1415,8 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
             for (int i = SK; i < 8; ++i) piece(i);
             finish(pb, wd, blk > 0 ? act_base(5 + mlayer, 2 * pb) : (GV*)park);
             mb = mask_bits(blk);
-            if (blk < 7) load_part(prv, blk + 1);          // prv becomes the next block's first chain
+            if (blk < 7) load_part(prv);                   // prv becomes the next block's first chain
+            if (blk < 6) request_part(blk + 2);
           }
           dma_side(np2_tag, nk_tag, ks_tag, std::false_type{}, strm.cw[cls_of(NP2)]);
           OBJ256_SCHED_FENCE();
@@ -1321,7 +1430,9 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
         T256(4);
       };
       f32x16 accA, accA1, accB = zero16(), accB1 = zero16();
-      load_part(accA, 0);
+      request_part(0);
+      load_part(accA);
+      request_part(1);
 #pragma unroll 1
       for (int blk = 0; blk < 6; blk += 2) {
         stage(nk_tag, blk, accA, accA1, accB, accB1);
@@ -1381,9 +1492,10 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
       // B7X: its share of d x2, whose chain rule (embedding.py:49-52, linear in d x2) is applied right away
       bwd_layer(std::integral_constant<int, B7H>{}, std::integral_constant<int, 16>{}, 3,
                 [&](int ks) -> V { return *reinterpret_cast<const V*>(hbuf + ks * PIECE); }, std::integral_constant<int, 1>{});
+      T256(21);
       f32x16 xa[2];
       bwd_slots(std::integral_constant<int, B7X>{}, std::integral_constant<int, 2>{}, std::false_type{}, xa, std::true_type{});
-      float vh[11], vl[11];
+      float vh[11], vl[11], dpv[11];
       project(vh, vl);
 #pragma unroll
       for (int dd = 0; dd < 11; ++dd) {                     // slot u = 2 dd + (f - 4)
@@ -1395,12 +1507,12 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
           const int u = 2 * dd + (f - 4);
           dpf = fmaf(xa[u >> 4][u & 15], cv[f - 4] * (OBJ_PI_F * (float)(1 << f)), dpf);
         }
-        // straight into d B (linear): eleven more values alive across B6 and B5H spilled
-        const float dp = (valid && (dd < 10 || h == 0)) ? dpf * inv_gs : 0.0f;
-        dbacc[dd][0] = fmaf(dp, t0, dbacc[dd][0]);
-        dbacc[dd][1] = fmaf(dp, t1, dbacc[dd][1]);
-        dbacc[dd][2] = fmaf(dp, t2, dbacc[dd][2]);
+        dpv[dd] = (valid && (dd < 10 || h == 0)) ? dpf * inv_gs : 0.0f;
       }
+      // straight into d B (linear in d x2): eleven more values alive across B6 and B5H (where the colour layer's share
+      // of d x2 joins) spilled
+      db_add(dpv);
+      T256(22);
     }
     {   // B6 (ONE stage, eight one-piece blocks): d hc = W_oc^T d colour, masked by hc's ReLU bits -> hbuf, tensor 9
       constexpr int NP2 = NP2_OF(B6, 0);
@@ -1506,13 +1618,11 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
     }
     T256(13);
     // d B[j][c] += d proj_j * t_c: per-lane sums, reduced over the lanes once per object (flush_object)
+    {
+      float dpv[11];
 #pragma unroll
-    for (int dd = 0; dd < 11; ++dd) {
-      const bool has = valid && (dd < 10 || h == 0);
-      const float dp = has ? dproj[dd] * inv_gs : 0.0f;
-      dbacc[dd][0] = fmaf(dp, t0, dbacc[dd][0]);
-      dbacc[dd][1] = fmaf(dp, t1, dbacc[dd][1]);
-      dbacc[dd][2] = fmaf(dp, t2, dbacc[dd][2]);
+      for (int dd = 0; dd < 11; ++dd) dpv[dd] = (valid && (dd < 10 || h == 0)) ? dproj[dd] * inv_gs : 0.0f;
+      db_add(dpv);
     }
     if (++tile_i == a.ntile) { tile_i = 0; ++k_i; }
     T256(14);
@@ -1524,6 +1634,9 @@ __global__ __launch_bounds__(NW * 64) void fwd256_kernel(const FwdArgs a) {
     printf("t256 (ticks of workgroup 0, wave 0): tile head %llu | fwd-layer mma %llu sync %llu | bwd-layer mma %llu sync %llu | layer tails (last epilogue, reload) %llu | "
            "alpha + colour stages %llu | compositing %llu | dh + B6 %llu | B5X + pe %llu | B3X + pe %llu | B1 + pe %llu | tile tail %llu | rest %llu %llu\n",
            tm_[6], tm_[1], tm_[2], tm_[3], tm_[4], tm_[7], tm_[8], tm_[9], tm_[10], tm_[11], tm_[12], tm_[13], tm_[14], tm_[0], tm_[5]);
+  if (FEAT && blockIdx.x == 0 && tid == 0)
+    printf("t256 feat: F7 tail %llu | compositing 1 + reload %llu | reduce-scatter %llu | G fh %llu | ray loop %llu | d hf %llu | (compositing 2 = "
+           "`compositing` above) | B7H tail %llu | B7X + pe %llu\n", tm_[15], tm_[18], tm_[16], tm_[17], tm_[19], tm_[20], tm_[21], tm_[22]);
 #endif
 }
 
@@ -1973,7 +2086,7 @@ static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 struct Plan {
   WsLay wl;
   int parts[NTYPE]; int prefix[NTYPE + 1]; long slab_prefix[NTYPE + 1];
-  size_t off_img, off_part, off_slabs, off_ws, off_dummy, off_feat, bytes;
+  size_t off_img, off_part, off_slabs, off_ws, off_dummy, off_feat, off_gimg, bytes;
 };
 #ifndef OBJ256_NW
 #define OBJ256_NW 4          // waves per workgroup of kernel A where the ray length allows (S <= 32 NW)
@@ -2003,6 +2116,8 @@ static Plan make_plan(int K, long n, int S, bool feat = false, int R = 0, int C 
   p.off_dummy = o; o += al256((size_t)NWG_A * 8 * 2048);      // kernel A: parking area of the stale stores of a layer's first stage
   p.off_feat = o;
   if (feat) o += al256(objgen::feat_head_workspace_bytes(K, R, HID, C));      // the hoisted 512-d head's buffers (objnerf_generic.hip)
+  p.off_gimg = o;
+  if (feat) o += al256((size_t)K * GIMG_PIECES * PIECE);                      // G as an operand image
   p.bytes = o;
   return p;
 }
@@ -2060,6 +2175,9 @@ static int run(const objnerf_net* net, const objnerf_train_args* a, hipStream_t 
     const int rc = objgen::feat_head_prep(st, K, a->R, HID, C, a->params, (long)a->p_stride, off[16], off[17], a->gt_feat, fh,
                                           (a->mode & OBJNERF_TRAIN_FP16) ? 2 : 1);
     if (rc) return rc;
+    const long tot = (long)K * GIMG_PIECES * 64;
+    hipLaunchKernelGGL((packg256_kernel<OT>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, K, fh.gram,
+                       (long)HID * HID + HID + 1, (OT*)(base + p.off_gimg));
   }
   const float gs = (a->mode & OBJNERF_TRAIN_FP16) ? exp2f(floorf(log2f((float)a->R)) + 3.0f) : 1.0f;
   FwdArgs fa;
@@ -2076,6 +2194,7 @@ static int run(const objnerf_net* net, const objnerf_train_args* a, hipStream_t 
   fa.counts = a->counts; fa.flags = a->flags;
   fa.img = img; fa.ws = ws; fa.dummy = base + p.off_dummy; fa.part = part; fa.L = L; fa.wl = p.wl;
   fa.feat_scaling = a->feat_scaling;
+  fa.gimg = base + p.off_gimg;
   fa.rayin = fh.rayin; fa.gram = fh.gram; fa.rayfeat = fh.rayfeat; fa.X1 = fh.X1; fa.X2 = fh.X2;
 #ifdef OBJ256_ONE          // diagnostic builds: one instantiation (compile time)
   launch_fwd<OT, 128, OBJ256_NW, FEAT>(fa, st);

@@ -44,8 +44,9 @@ def test_fp16_step_close_to_fp32(dev, shape):
         assert rel < bound, (i, ops.TENSOR_NAMES[i], rel)
 
 
+@pytest.mark.parametrize("feat", [False, True])
 @pytest.mark.parametrize("mode", ["fp16", "bf16"])
-def test_config_c5_object_at_full_size_16bit(dev, mode):
+def test_config_c5_object_at_full_size_16bit(dev, mode, feat):
     """BASELINE configs[4] in the dtype it names: objects at their full size (hidden 256, 8192 rays x 128 samples =
     10^6 samples per object) through the two fused hidden-256 kernels (objnerf_train256.hip: fwd256_kernel +
     wgrad256_kernel) against the SPECIFICATION of the 16-bit modes evaluated at the same size -- parity_util.
@@ -54,18 +55,24 @@ def test_config_c5_object_at_full_size_16bit(dev, mode):
     2^(floor(log2 R) + 3)), fp32 accumulation, run through torch on the device: every gradient tensor within 1 % in
     norm (tests/test_16bit_spec_gpu.py holds the same kernels to the same bound at <= 4096 x 64), loss terms within
     2e-3 / 2e-4.  Also: two objects at once give the same gradients as one by one to 1e-5, and the step is
-    bit-reproducible."""
+    bit-reproducible.
+
+    feat: the same with the 512-d feature loss (model.py:98-101, loss.py:81-99) -- since round 5 inside the same two
+    kernels (FEAT instantiations: feature layer, hoisted head in its Gram form, second compositing pass, B7H / B7X, weight
+    -gradient task 6) + the head's GEMMs around them; all 19 tensors, the four feature tensors within 2 % (measured
+    1.0 % bf16 / 0.4 % fp16: W_of and the targets enter the Gram / u GEMMs rounded, the specification rounds W_of only),
+    the feature loss term like the others."""
     import math
     from parity_util import oracle_step_16, rel_norm
     K, R, n1, n2, H = 2, 8192, 32, 96, 256
     arena = ops.ParamArena(K, ops.NetShape(H, 512, 6), dev)
     st = obj_init.init_stacked(K, H, 512, seed=41)
     arena.load_stacked(st)
-    b = synthetic.random_batch(K, R, n1, n2, seed=17)
-    batch = {k: T(b[k]).to(dev) for k in ["pts", "z", "gt_depth", "gt_rgb", "labels"]}
-    ws16 = ops.TrainWorkspace(arena, K, R, n1 + n2, False, precision=mode)
-    assert ws16.nbytes < 0.75 * ops.TrainWorkspace(arena, K, R, n1 + n2, False).nbytes
-    ops.train_step(arena, ws16, batch, bf16=mode)
+    b = synthetic.random_batch(K, R, n1, n2, seed=17, feat_dim=512 if feat else 0)
+    batch = {k: T(b[k]).to(dev) for k in ["pts", "z", "gt_depth", "gt_rgb", "labels"] + (["gt_feat"] if feat else [])}
+    ws16 = ops.TrainWorkspace(arena, K, R, n1 + n2, feat, precision=mode)
+    assert ws16.nbytes < 0.75 * ops.TrainWorkspace(arena, K, R, n1 + n2, feat).nbytes
+    ops.train_step(arena, ws16, batch, with_feat=feat, bf16=mode)
     torch.cuda.synchronize()
     assert int(ws16.status.item()) == 0 and bool(torch.isfinite(ws16.grads).all())
     gs = 2.0 ** (math.floor(math.log2(R)) + 3) if mode == "fp16" else 1.0
@@ -73,26 +80,28 @@ def test_config_c5_object_at_full_size_16bit(dev, mode):
     g16 = arena.views(ws16.grads)
     for k in range(K):                          # one object at a time: the autograd graph of 10^6 samples is ~40 GB
         bk = {key: v[k:k + 1] for key, v in b.items()}
-        o = oracle_step_16([p[k:k + 1] for p in st[:18]], st[18][k:k + 1], 2.0, bk, False, dt, True, gs, device=dev,
+        o = oracle_step_16([p[k:k + 1] for p in st[:18]], st[18][k:k + 1], 2.0, bk, feat, dt, True, gs, device=dev,
                            round_head_weights=True, round_head_grads=True)
-        np.testing.assert_allclose(ws16.loss_terms.double().cpu()[k, :3], o["terms"][0, :3],
+        nt = 4 if feat else 3
+        np.testing.assert_allclose(ws16.loss_terms.double().cpu()[k, :nt], o["terms"][0, :nt],
                                    rtol=2e-4 if mode == "fp16" else 2e-3, atol=1e-5)
-        for i in list(range(14)) + [18]:
+        for i in (range(19) if feat else list(range(14)) + [18]):
             rel = rel_norm(g16[i][k], o["grads"][i][0])
-            print(f"{mode} c5 object {k} {ops.TENSOR_NAMES[i]:24s} rel {rel:.2e}")
-            assert rel < 0.01, (k, i, ops.TENSOR_NAMES[i], rel)
+            print(f"{mode} c5 feat={feat} object {k} {ops.TENSOR_NAMES[i]:24s} rel {rel:.2e}")
+            assert rel < (0.02 if i in ops.FEAT_TENSORS else 0.01), (k, i, ops.TENSOR_NAMES[i], rel)
         del o
         torch.cuda.empty_cache()
-    for i in ops.FEAT_TENSORS:
-        assert float(g16[i].abs().max()) == 0.0
+    if not feat:
+        for i in ops.FEAT_TENSORS:
+            assert float(g16[i].abs().max()) == 0.0
     first = ws16.grads.clone()
-    ops.train_step(arena, ws16, batch, bf16=mode)                       # bit-reproducible
+    ops.train_step(arena, ws16, batch, with_feat=feat, bf16=mode)       # bit-reproducible
     torch.cuda.synchronize()
     assert torch.equal(ws16.grads, first)
     arena1 = ops.ParamArena(1, ops.NetShape(H, 512, 6), dev)            # object 1 alone == object 1 in the batch
     arena1.params.copy_(arena.params[1:2]); arena1.scale.copy_(arena.scale[1:2])
-    ws1 = ops.TrainWorkspace(arena1, 1, R, n1 + n2, False, precision=mode)
-    ops.train_step(arena1, ws1, {k: v[1:2].contiguous() for k, v in batch.items()}, bf16=mode,
+    ws1 = ops.TrainWorkspace(arena1, 1, R, n1 + n2, feat, precision=mode)
+    ops.train_step(arena1, ws1, {k: v[1:2].contiguous() for k, v in batch.items()}, with_feat=feat, bf16=mode,
                    global_flags=ws16.flags, global_counts=ws16.counts[1:2].contiguous())
     torch.cuda.synchronize()
     # (not bit for bit: the split-K slice count of the weight gradients follows the number of objects in the launch)
