@@ -55,7 +55,7 @@ __host__ __device__ constexpr int rc_badd(int c) { return c == C_AL ? 8 : 0; }
 constexpr int R_NA = 32, R_NAX = 12;
 __host__ __device__ constexpr int rc_nk16(int c) { return rc_nk(c) < 16 ? rc_nk(c) : 16; }
 __host__ __device__ constexpr bool rc_reg_valid(int n, int r) {
-  return rc_slot(n) && rc_nb(n) == 1 ? r < rc_nk(n) : (r & 15) < rc_nk16(n);
+  return n >= C_END ? false : rc_slot(n) && rc_nb(n) == 1 ? r < rc_nk(n) : (r & 15) < rc_nk16(n);
 }
 __host__ __device__ constexpr int rc_reg_b(int n, int r) { return rc_slot(n) && rc_nb(n) == 1 ? 0 : r >> 4; }
 __host__ __device__ constexpr int rc_reg_ks(int n, int r) { return rc_slot(n) && rc_nb(n) == 1 ? r : r & 15; }
@@ -68,8 +68,10 @@ static_assert(2 * (rc_nk(C_F3) - 16) <= R_NAX && rc_nk(C_AL) <= R_NA, "A registe
 #ifdef OBJ256_TIMING      // diagnostic build: cycles per part of a tile (s_memtime), printed by workgroup 0 / wave 0
 #define RT(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); T256(i); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define RSYNC() do { RT(0); __syncthreads(); RT(1); } while (0)
+#define RTP(i) RT(i)
 #else
 #define RT(i) do {} while (0)
+#define RTP(i) do {} while (0)
 #define RSYNC() __syncthreads()
 #endif
 #ifndef R256_CUT
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(256) void fwdr256_kernel(const FwdArgs a) {
   float* s_raw = reinterpret_cast<float*>(lds + R_STRIP);
   float* s_col = s_raw + TSAMP;
   float* s_z = s_raw + 4 * TSAMP;
-  float* s_ray = s_z + TSAMP;
+  float* s_ray = reinterpret_cast<float*>(lds + R_SMALL) + 68;      // per ray of the tile: gt depth, gt rgb, label (stride 5: 20 of the 28 spare floats)
   float* s_small = reinterpret_cast<float*>(lds + R_SMALL);
   float* s_db = reinterpret_cast<float*>(lds + R_DB);
   const uint32_t lane_off_k = (uint32_t)lane * 16u;
@@ -122,6 +124,10 @@ __global__ __launch_bounds__(256) void fwdr256_kernel(const FwdArgs a) {
   // half-wave at once and added to the wave's sums in LDS)
   float scale = 1.0f, inv1 = 0.f, inv2 = 0.f, ba = 0.f, boc0 = 0.f, boc1 = 0.f, boc2 = 0.f;
 
+  // wave-uniform floats as scalars (a uniform value that arrives through a vector load stays in a vector register otherwise)
+  auto rfl = [](const float v) __attribute__((always_inline)) -> float {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+  };
   auto flush_object = [&]() {       // partial d B and loss terms of (cur_obj, this workgroup)
     __syncthreads();
     float* pw = s_db + w * 68;            // (d B is already there)
@@ -214,13 +220,13 @@ __global__ __launch_bounds__(256) void fwdr256_kernel(const FwdArgs a) {
       if (tid >= 65 && tid < 68) s_small[tid] = P[a.L.oc_b + tid - 65];
       for (int i = tid; i < NWAVE * 68; i += NTHR) s_db[i] = 0.0f;
       l_d = l_c = l_o = 0.f;
-      scale = a.scale[k];
+      scale = rfl(a.scale[k]);
       const float n1 = (float)a.counts[2 * k], n2 = (float)a.counts[2 * k + 1];
-      inv1 = a.flags[0] ? 0.0f : 1.0f / (n1 + 1e-10f);         // render_rays.py:89-94 early return / :103 mean
-      inv2 = a.flags[1] ? 0.0f : 1.0f / (n2 + 1e-10f);
+      inv1 = rfl(a.flags[0] ? 0.0f : 1.0f / (n1 + 1e-10f));    // render_rays.py:89-94 early return / :103 mean
+      inv2 = rfl(a.flags[1] ? 0.0f : 1.0f / (n2 + 1e-10f));
     }
     RSYNC();                                            // tables visible; previous tile done with every buffer
-    ba = s_small[64]; boc0 = s_small[65]; boc1 = s_small[66]; boc2 = s_small[67];
+    ba = rfl(s_small[64]); boc0 = rfl(s_small[65]); boc1 = rfl(s_small[66]); boc2 = rfl(s_small[67]);
 
     const char* img_k = (const char*)a.img + (long)k * IMG_BYTES;
     const char* img_n = (const char*)a.img + (live ? next_obj : (long)k) * IMG_BYTES;
@@ -288,16 +294,18 @@ __global__ __launch_bounds__(256) void fwdr256_kernel(const FwdArgs a) {
     RSYNC();
 
     // ------------------------------------------------------------------ the layer machinery
-    f32x16 acc[2][2][2];                 // [phase parity][chain][row block]
+    f32x16 acc[2][2][2];                 // [phase = pair of column groups][column group of the pair][row block]
     uint32_t msk[5][4];                  // ReLU bits of this wave's rows: [layer][column group], block b in bits 8 b .. (pair form)
-    uint32_t ewd[8], ebits = 0;
-    // piece j (block j >> 3, value pair j & 7) of the epilogue of column group cgp, whose sums sit in acc[par]
-    auto epi_piece = [&](const bool fwd, const int par, const int cgp, const int lay, const int tensor, const uint32_t hout_l, const int j)
+    uint32_t ewd2[2][8], ebits2[2] = {0, 0};
+    // piece j (block j >> 3, value pair j & 7) of the epilogue of column group cgp = 2 par + ci, whose sums sit in acc[par][ci]
+    auto epi_piece = [&](const bool fwd, const int par, const int ci, const int lay, const int tensor, const uint32_t hout_l, const int j)
         __attribute__((always_inline)) {
-      const int b = j >> 3, i = j & 7;
+      const int b = j >> 3, i = j & 7, cgp = 2 * par + ci;
+      uint32_t (&ewd)[8] = ewd2[ci];
+      uint32_t& ebits = ebits2[ci];
       if (R256_X & 4) return;
       if (i == 0) ebits = 0;
-      const uint32_t c = pk_cvt<OT>(acc[par][0][b][2 * i] + acc[par][1][b][2 * i], acc[par][0][b][2 * i + 1] + acc[par][1][b][2 * i + 1]);
+      const uint32_t c = pk_cvt<OT>(acc[par][ci][b][2 * i], acc[par][ci][b][2 * i + 1]);
       if (fwd) {
         ewd[i] = pk_relu(c);
         ebits = ((c >> (15 - i)) & (0x00010001u << i)) | ebits;      // SIGN bits: bit i value 2 i, bit 16 + i value 2 i + 1
@@ -359,53 +367,68 @@ __global__ __launch_bounds__(256) void fwdr256_kernel(const FwdArgs a) {
 #pragma unroll
           for (int x = 0; x < NKX; ++x) AX[b * NKX + x] = *(const GV*)(frag_base(c_tag, b, 16 + x, img_c) + lane_off);
       }
-      V bq[4];
+      // Two phases, each a PAIR of column groups: 2 row blocks x 2 column groups = four independent accumulator chains
+      // (an MFMA that depends on the previous one starts ~110 cycles after it, an independent one after ~34), every chain
+      // runs the whole contraction -- no second chain per block to add in the epilogue (2 of its 12 instructions per value
+      // pair, + 2 accumulator reads).  The epilogue of pair 0 (32 pieces) rides behind pair 1's k-steps, two pieces each.
+      V bq[2][4];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        if (i < 4 * NK) bq[i] = bfrag(hin_l, xin_l, nkh, nx, i / NK, i % NK);
-      r256_wait_a();
-#pragma unroll
-      for (int cg = 0; cg < 4; ++cg) {
-        const int par = cg & 1;
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          if (fwd) {
-            uint32_t bpo = R_BIAS + 4 * (lay * 256 + (2 * w + b) * 32 + h * 16);
-            asm volatile("" : "+v"(bpo));
-            const float* bp = reinterpret_cast<const float*>(lds + bpo);
-#pragma unroll
-            for (int n4 = 0; n4 < 4; ++n4) {
-              const f32x4v b4 = *reinterpret_cast<const f32x4v*>(bp + 4 * n4);
-              acc[par][0][b][4 * n4] = b4[0]; acc[par][0][b][4 * n4 + 1] = b4[1]; acc[par][0][b][4 * n4 + 2] = b4[2]; acc[par][0][b][4 * n4 + 3] = b4[3];
-            }
-          } else acc[par][0][b] = zero16();
-          acc[par][1][b] = zero16();
+        if (i < 2 * NK) {
+          bq[0][i] = bfrag(hin_l, xin_l, nkh, nx, 2 * (i / NK), i % NK);
+          bq[1][i] = bfrag(hin_l, xin_l, nkh, nx, 2 * (i / NK) + 1, i % NK);
         }
-        if (cg == 3) {                    // registers this layer never used
+#pragma unroll
+      for (int pair = 0; pair < 2; ++pair) {
+        const int par = pair;
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            if (fwd) {
+              uint32_t bpo = R_BIAS + 4 * (lay * 256 + (2 * w + b) * 32 + h * 16);
+              asm volatile("" : "+v"(bpo));
+              const float* bp = reinterpret_cast<const float*>(lds + bpo);
+#pragma unroll
+              for (int n4 = 0; n4 < 4; ++n4) {
+                const f32x4v b4 = *reinterpret_cast<const f32x4v*>(bp + 4 * n4);
+                acc[par][ci][b][4 * n4] = b4[0]; acc[par][ci][b][4 * n4 + 1] = b4[1]; acc[par][ci][b][4 * n4 + 2] = b4[2]; acc[par][ci][b][4 * n4 + 3] = b4[3];
+              }
+            }
+          }
+        if (pair == 1) {                  // registers this layer never used
 #pragma unroll
           for (int r = 0; r < R_NA; ++r)
             if ((r & 15) >= NK16) loadR(n_tag, r, img_x);
         }
 #pragma unroll
         for (int ks = 0; ks < NK; ++ks) {
-          const int L = cg * NK + ks;
-          const V bf = bq[L & 3];
-          if (L + 4 < 4 * NK) bq[L & 3] = bfrag(hin_l, xin_l, nkh, nx, (L + 4) / NK, (L + 4) % NK);
+          const int L = pair * NK + ks;
+          const V bf0 = bq[0][L & 3], bf1 = bq[1][L & 3];
+          if (L + 4 < 2 * NK) {
+            bq[0][L & 3] = bfrag(hin_l, xin_l, nkh, nx, 2 * ((L + 4) / NK), (L + 4) % NK);
+            bq[1][L & 3] = bfrag(hin_l, xin_l, nkh, nx, 2 * ((L + 4) / NK) + 1, (L + 4) % NK);
+          }
           const V a0 = ks < 16 ? A[ks] : AX[ks - 16], a1 = ks < 16 ? A[16 + ks] : AX[NKX + ks - 16];
-          acc[par][ks & 1][0] = Op<OT>::mfma(a0, bf, acc[par][ks & 1][0]);
-          acc[par][ks & 1][1] = Op<OT>::mfma(a1, bf, acc[par][ks & 1][1]);
-          if (cg > 0 && ks < 16) epi_piece(fwd, par ^ 1, cg - 1, lay, tensor, hout_l, ks);
-          if (cg == 3 && ks < 16) { loadR(n_tag, ks, img_x); loadR(n_tag, 16 + ks, img_x); }
+          const bool z = !fwd && ks == 0;          // (a backward chain starts from the literal 0: a zero VECTOR gets hoisted and spilled)
+          acc[par][0][0] = Op<OT>::mfma(a0, bf0, z ? zero16() : acc[par][0][0]);
+          acc[par][0][1] = Op<OT>::mfma(a1, bf0, z ? zero16() : acc[par][0][1]);
+          acc[par][1][0] = Op<OT>::mfma(a0, bf1, z ? zero16() : acc[par][1][0]);
+          acc[par][1][1] = Op<OT>::mfma(a1, bf1, z ? zero16() : acc[par][1][1]);
+          if (pair > 0 && ks < 16) { epi_piece(fwd, 0, 0, lay, tensor, hout_l, ks); epi_piece(fwd, 0, 1, lay, tensor, hout_l, ks); }
+          if (pair == 1 && ks < 16) { loadR(n_tag, ks, img_x); loadR(n_tag, 16 + ks, img_x); }
           R256_FENCE();
         }
-        if (cg > 0) {
+        if (pair > 0) {
 #pragma unroll
-          for (int j = NK; j < 16; ++j) epi_piece(fwd, par ^ 1, cg - 1, lay, tensor, hout_l, j);
+          for (int j = NK; j < 16; ++j) { epi_piece(fwd, 0, 0, lay, tensor, hout_l, j); epi_piece(fwd, 0, 1, lay, tensor, hout_l, j); }
         }
+        RTP(c == C_B5H ? 28 + pair : 22 + pair);
       }
       if (!defer) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) epi_piece(fwd, 1, 3, lay, tensor, hout_l, j);
+        for (int j = 0; j < 16; ++j) { epi_piece(fwd, 1, 0, lay, tensor, hout_l, j); epi_piece(fwd, 1, 1, lay, tensor, hout_l, j); }
+        RTP(26);
       }
     };
     // a slot pass (consumer c: nb row blocks, this wave's own column group): xacc[b] = sum over the k-steps; pend: the
@@ -427,8 +450,7 @@ __global__ __launch_bounds__(256) void fwdr256_kernel(const FwdArgs a) {
 #pragma unroll
       for (int b = 0; b < NB; ++b) {       // block by block, two chains each (the accumulator file holds the 32 fragments and
         f32x16 ch[2];                      // the pending epilogue's 64 sums as well: four chains spilled; the pass shares its
-#pragma unroll                             // issue slots with that epilogue anyway)
-        for (int i = 0; i < 2; ++i) ch[i] = zero16();
+                                           // issue slots with that epilogue anyway)
         V bq[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) bq[i] = bfrag(hin_l, xin_l, nkh, nx, w, i);
@@ -438,23 +460,26 @@ __global__ __launch_bounds__(256) void fwdr256_kernel(const FwdArgs a) {
           const V bf = bq[ks & 3];
           if (ks + 4 < NK) bq[ks & 3] = bfrag(hin_l, xin_l, nkh, nx, w, ks + 4);
           const int r = NB == 1 ? ks : (b & 1) * 16 + ks;
-          if (!(R256_X & 8)) ch[ks & 1] = Op<OT>::mfma(A[r], bf, ch[ks & 1]);
-          if (pend && b == 0 && ks < 16) epi_piece(pfwd, 1, 3, play, ptensor, phout_l, ks);
+          ch[ks & 1] = Op<OT>::mfma(A[r], bf, ks < 2 ? zero16() : ch[ks & 1]);
+          if (pend && b == 0 && ks < 16) { epi_piece(pfwd, 1, 0, play, ptensor, phout_l, ks); epi_piece(pfwd, 1, 1, play, ptensor, phout_l, ks); }
           if (b + 2 < NB) frag_load(A[r], frag_base(c_tag, b + 2, ks, img_c));
           else loadR(n_tag, r, img_x);
           R256_FENCE();
         }
+        RTP(27);
         sink(b, ch[0] + ch[1]);
       }
     };
 
     // ------------------------------------------------------------------ forward
     rlayer(std::integral_constant<int, C_F1>{}, std::integral_constant<int, C_F2>{}, std::true_type{}, 0, 0, hb0, xb, 0, KS_X1, hb0, img_k, std::false_type{});                               // h1 -> buffer 0
+    if (si == 0) { float* rp = s_ray + 5 * q; rp[0] = rg0; rp[1] = rg1; rp[2] = rg2; rp[3] = rg3; rp[4] = __int_as_float(rlab); }     // (landed under F1)
     if (live) load_point((int)next_obj, next_obj != k ? 0 : tile + 1, npx, npy, npz, nzv);               // the next tile's sample
     RT(2);
     RSYNC();
     if (R256_X & 32) { if (++tile_i == a.ntile) { tile_i = 0; ++k_i; } continue; }
     rlayer(std::integral_constant<int, C_F2>{}, std::integral_constant<int, C_F3>{}, std::true_type{}, 1, 1, hb0, xb, KS_H, 1, hb1, img_k, std::false_type{});                                // h2 -> 1
+    asm volatile("" : "+v"(npx), "+v"(npy), "+v"(npz), "+v"(nzv));      // (computed HERE, not at the next tile's top: 4 live values instead of 9)
     RT(3);
     RSYNC();
     rlayer(std::integral_constant<int, C_F3>{}, std::integral_constant<int, C_F4>{}, std::true_type{}, 2, 2, hb1, xb, KS_H, KS_X1, hb0, img_k, std::false_type{});                            // h3 = f([h2 | x1]) -> 0
@@ -479,7 +504,6 @@ __global__ __launch_bounds__(256) void fwdr256_kernel(const FwdArgs a) {
         xp[t * 64] = xf;
       }
       s_z[st_idx] = z_own;
-      if (si == 0) { float* rp = s_ray + 8 * q; rp[0] = rg0; rp[1] = rg1; rp[2] = rg2; rp[3] = rg3; rp[4] = __int_as_float(rlab); }
     }
     rlayer(std::integral_constant<int, C_F4>{}, std::integral_constant<int, C_F5>{}, std::true_type{}, 3, 3, hb0, xb, KS_H, 1, hb1, img_k, std::false_type{});                                // h4 -> 1
     RT(5);
@@ -516,7 +540,7 @@ __global__ __launch_bounds__(256) void fwdr256_kernel(const FwdArgs a) {
         const bool on = (qq < TR) && (rayq < a.R);
         float gtd = 0.f, gr = 0.f, gg = 0.f, gb = 0.f;
         int lab = 2;
-        if (on) { const float* rp = s_ray + 8 * qq; gtd = rp[0]; gr = rp[1]; gg = rp[2]; gb = rp[3]; lab = __float_as_int(rp[4]); }
+        if (on) { const float* rp = s_ray + 5 * qq; gtd = rp[0]; gr = rp[1]; gg = rp[2]; gb = rp[3]; lab = __float_as_int(rp[4]); }
         float occ[SPL], fr[SPL], zz[SPL], c0[SPL], c1[SPL], c2[SPL], Tn[SPL], wgt[SPL];
         float lp = 1.0f;
 #pragma unroll
@@ -641,6 +665,7 @@ __global__ __launch_bounds__(256) void fwdr256_kernel(const FwdArgs a) {
 #pragma unroll
           for (int f = 0; f < OCT; ++f)
             dproj[dd] = fmaf(r[OCT * d2 + f], cv[f] * (OBJ_PI_F * (float)(1 << (F0 + f))), dproj[dd]);
+          R256_FENCE();                      // (one direction at a time: batched, their table reads and angles spill)
         }
       }
     };
@@ -669,7 +694,7 @@ __global__ __launch_bounds__(256) void fwdr256_kernel(const FwdArgs a) {
     RSYNC();
     R256_CUTAT(8)
     // B1: d x1 += W_in^T d_pre1; its registers take the next tile's first layer as they fall free
-    rslot(std::integral_constant<int, C_B1>{}, std::integral_constant<int, C_F1>{}, hb1, xb, KS_H, 1,
+    rslot(std::integral_constant<int, C_B1>{}, std::integral_constant<int, C_END>{}, hb1, xb, KS_H, 1,
           [&](const int b, const f32x16& r) __attribute__((always_inline)) { pe_bwd_block(std::integral_constant<int, 4>{}, std::integral_constant<int, 0>{}, b, r); },
           img_n, std::false_type{}, std::false_type{}, 0, 0, hb0);
     RT(16);
@@ -695,6 +720,12 @@ __global__ __launch_bounds__(256) void fwdr256_kernel(const FwdArgs a) {
       }
     }
     RT(18);
+    {   // the next tile's first layer (requested HERE, behind the reduction: whatever the compiler reloads from scratch at the
+        // tile boundary would otherwise queue behind these loads -- vmcnt completes in order)
+      const char* cbn = cons_base(std::integral_constant<int, C_F1>{}, img_n);
+#pragma unroll
+      for (int r = 0; r < R_NA; ++r) loadR(std::integral_constant<int, C_F1>{}, r, cbn);
+    }
     if (++tile_i == a.ntile) { tile_i = 0; ++k_i; }
   }
   flush_object();
@@ -704,6 +735,7 @@ __global__ __launch_bounds__(256) void fwdr256_kernel(const FwdArgs a) {
            "B5X %llu B4 %llu B3H %llu B3X %llu B2 %llu B1 %llu | tile tail + head %llu\n", tm_[0], tm_[1], tm_[2], tm_[3], tm_[4], tm_[5], tm_[6], tm_[7], tm_[8],
            tm_[9], tm_[10], tm_[11], tm_[12], tm_[13], tm_[14], tm_[15], tm_[16], tm_[17]);
   if (blockIdx.x == 0 && threadIdx.x == 0)
-    printf("r256 more: d B reduce %llu | strips written -> compositing start %llu | compositing %llu | head gradients %llu\n", tm_[18], tm_[19], tm_[20], tm_[21]);
+    printf("r256 more: d B reduce %llu | layer phases 0..3 %llu %llu %llu %llu, exposed epilogue %llu | slot blocks %llu | B5H phases %llu %llu %llu %llu\n", tm_[18],
+           tm_[22], tm_[23], tm_[24], tm_[25], tm_[26], tm_[27], tm_[28], tm_[29], tm_[30], tm_[31]);
 #endif
 }

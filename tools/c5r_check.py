@@ -1,4 +1,4 @@
-"""Hidden-256 fused path WITHOUT the feature loss (fwd256_kernel; the row-split kernel A with OBJ256_ROW_SPLIT=1) against the specification
+"""Hidden-256 fused path WITHOUT the feature loss (row-split kernel A; OBJ256_FIRST_FORM=1: fwd256_kernel) against the specification
 of the 16-bit modes, a few shapes, and the time of one step of 8 full-size objects.
 
     python tools/c5r_check.py [--full] [--time]
