@@ -31,7 +31,8 @@ constexpr int R_DH = R_STRIP + 3072;                           // ... and the he
 constexpr int R_BIAS = R_XB + 4 * KS_X1 * PIECE;
 constexpr int R_SMALL = R_BIAS + 5 * 256 * 4;
 constexpr int R_DB = R_SMALL + 96 * 4;
-constexpr int R_TOTAL = (R_DB + 4 * 68 * 4 + 15) & ~15;
+constexpr int R_T = (R_DB + 4 * 68 * 4 + 15) & ~15;             // x / scale of the tile's 128 samples [3][128]: read back where the
+constexpr int R_TOTAL = R_T + 3 * 128 * 4;                     // embedding's chain rule needs it (three registers through every layer otherwise)
 static_assert(R_DH + 4 * PIECE <= R_BIAS && R_TOTAL <= 163840, "LDS budget of the row-split kernel");
 static_assert((5 * 128 + 8 * 8) * 4 <= 3072, "strips");
 
@@ -120,8 +121,10 @@ __global__ __launch_bounds__(256) void fwdr256_kernel(const FwdArgs a) {
   { const long obj0 = tau0 / a.ntile; k_i = (int)obj0; tile_i = tau0 - obj0 * a.ntile; }
   int cur_obj = -1;
   float l_d = 0.f, l_c = 0.f, l_o = 0.f;
-  // (no per-lane d B accumulators: 33 registers through every layer -- each tile's contribution is reduced over the
-  // half-wave at once and added to the wave's sums in LDS)
+  // d B of the object, one entry per LANE: lane s of half h keeps entry 33 h + s of the wave's [63] sums (direction
+  // 11 h + dd, coordinate c at 3 dd + c; half 0's 33rd entry in dbl32) -- every contribution is summed over the half-wave
+  // first (DPP row sums + one row swap), so two registers replace 33 per-lane accumulators
+  float dbl = 0.0f, dbl32 = 0.0f;
   float scale = 1.0f, inv1 = 0.f, inv2 = 0.f, ba = 0.f, boc0 = 0.f, boc1 = 0.f, boc2 = 0.f;
 
   // wave-uniform floats as scalars (a uniform value that arrives through a vector load stays in a vector register otherwise)
@@ -130,7 +133,13 @@ __global__ __launch_bounds__(256) void fwdr256_kernel(const FwdArgs a) {
   };
   auto flush_object = [&]() {       // partial d B and loss terms of (cur_obj, this workgroup)
     __syncthreads();
-    float* pw = s_db + w * 68;            // (d B is already there)
+    float* pw = s_db + w * 68;
+    {
+      const int s_ = lane & 31, h_ = lane >> 5;
+      if (s_ < 30 || h_ == 0) pw[33 * h_ + s_] = dbl;
+      if (lane == 0) pw[32] = dbl32;
+      dbl = 0.0f; dbl32 = 0.0f;
+    }
     l_d = seg_sum<64>(l_d); l_c = seg_sum<64>(l_c); l_o = seg_sum<64>(l_o);
     if (lane == 0) { pw[64] = l_d; pw[65] = l_c; pw[66] = l_o; pw[67] = 0.0f; }
     __syncthreads();
@@ -251,9 +260,16 @@ __global__ __launch_bounds__(256) void fwdr256_kernel(const FwdArgs a) {
       rg0 = a.gt_depth[rr]; rg1 = a.gt_rgb[rr * 3]; rg2 = a.gt_rgb[rr * 3 + 1]; rg3 = a.gt_rgb[rr * 3 + 2]; rlab = a.labels[rr];
     }
     const float t0 = px / scale, t1 = py / scale, t2 = pz / scale;       // embedding.py:47
+    // x / scale of this lane's sample back from LDS (opaque address: see below)
+    auto load_t = [&](float& u0, float& u1, float& u2) __attribute__((always_inline)) {
+      uint32_t to = R_T + 4 * st_idx;
+      asm volatile("" : "+v"(to));
+      const float* st = reinterpret_cast<const float*>(lds + to);
+      u0 = st[0]; u1 = st[128]; u2 = st[256];
+    };
     // (the table pointers are opaque at every use: visible, the compiler reads the 33 embedding rows and a layer's bias rows
     // ONCE per tile / layer and keeps them in registers from the first use to the last -- and spills them)
-    auto project = [&](float (&vh)[11], float (&vl)[11]) __attribute__((always_inline)) {
+    auto project = [&](float (&vh)[11], float (&vl)[11], const float t0, const float t1, const float t2) __attribute__((always_inline)) {
       uint32_t smo = R_SMALL + 132 * h;                     // rows of this half's directions (jd = min(11 h + dd, 20)), LDS bytes
       asm volatile("" : "+v"(smo));
 #pragma unroll
@@ -269,7 +285,8 @@ __global__ __launch_bounds__(256) void fwdr256_kernel(const FwdArgs a) {
     };
     {   // x1 pieces of this wave's samples: slot u = 4 dd + f -> LDS (every wave's F1 / F3 reads them) and workspace
       float vh[11], vl[11];
-      project(vh, vl);
+      project(vh, vl, t0, t1, t2);
+      if (h == 0) { float* st = reinterpret_cast<float*>(lds + R_T); st[st_idx] = t0; st[128 + st_idx] = t1; st[256 + st_idx] = t2; }
       GV* xp = (GV*)(ws_obj + a.wl.off_x1 + ((sg_own * KS_X1) << 10) + lane_off);
 #pragma unroll
       for (int t = 0; t < KS_X1; ++t) {
@@ -447,27 +464,56 @@ __global__ __launch_bounds__(256) void fwdr256_kernel(const FwdArgs a) {
 #pragma unroll
         for (int r = NK; r < R_NA; ++r) loadR(n_tag, r, img_x);
       }
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {       // block by block, two chains each (the accumulator file holds the 32 fragments and
-        f32x16 ch[2];                      // the pending epilogue's 64 sums as well: four chains spilled; the pass shares its
-                                           // issue slots with that epilogue anyway)
+      // Blocks 0 and 1 run TOGETHER (two chains each = four independent chains: a chain of two leaves the matrix core idle
+      // for most of its ~110-cycle dependent-issue latency), a third block afterwards on four chains (k-step mod 4), its
+      // fragments having replaced block 0's as those fell free; a single block (alpha, colour) runs on four chains too.
+      constexpr int NB2 = NB >= 2 ? 2 : 1;                   // blocks of the first round
+      constexpr int NCH = NB == 1 ? 4 : 2;                   // chains per block in it
+      {
+        f32x16 ch[NB2][NCH];
         V bq[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) bq[i] = bfrag(hin_l, xin_l, nkh, nx, w, i);
-        if (b != 1) r256_wait_a();
 #pragma unroll
         for (int ks = 0; ks < NK; ++ks) {
           const V bf = bq[ks & 3];
           if (ks + 4 < NK) bq[ks & 3] = bfrag(hin_l, xin_l, nkh, nx, w, ks + 4);
-          const int r = NB == 1 ? ks : (b & 1) * 16 + ks;
-          ch[ks & 1] = Op<OT>::mfma(A[r], bf, ks < 2 ? zero16() : ch[ks & 1]);
-          if (pend && b == 0 && ks < 16) { epi_piece(pfwd, 1, 0, play, ptensor, phout_l, ks); epi_piece(pfwd, 1, 1, play, ptensor, phout_l, ks); }
-          if (b + 2 < NB) frag_load(A[r], frag_base(c_tag, b + 2, ks, img_c));
-          else loadR(n_tag, r, img_x);
+#pragma unroll
+          for (int b = 0; b < NB2; ++b) {
+            const int r = NB == 1 ? ks : b * 16 + ks;
+            ch[b][ks % NCH] = Op<OT>::mfma(A[r], bf, ks < NCH ? zero16() : ch[b][ks % NCH]);
+          }
+          if (pend && ks < 16) { epi_piece(pfwd, 1, 0, play, ptensor, phout_l, ks); epi_piece(pfwd, 1, 1, play, ptensor, phout_l, ks); }
+#pragma unroll
+          for (int b = 0; b < NB2; ++b) {
+            const int r = NB == 1 ? ks : b * 16 + ks;
+            if (b + 2 < NB) frag_load(A[r], frag_base(c_tag, b + 2, ks, img_c));
+            else loadR(n_tag, r, img_x);
+          }
           R256_FENCE();
         }
         RTP(27);
-        sink(b, ch[0] + ch[1]);
+#pragma unroll
+        for (int b = 0; b < NB2; ++b) {
+          if constexpr (NCH == 4) sink(b, (ch[b][0] + ch[b][1]) + (ch[b][2] + ch[b][3]));
+          else sink(b, ch[b][0] + ch[b][1]);
+        }
+      }
+      if constexpr (NB == 3) {
+        f32x16 ch[4];
+        V bq[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bq[i] = bfrag(hin_l, xin_l, nkh, nx, w, i);
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+          const V bf = bq[ks & 3];
+          if (ks + 4 < NK) bq[ks & 3] = bfrag(hin_l, xin_l, nkh, nx, w, ks + 4);
+          ch[ks & 3] = Op<OT>::mfma(A[ks], bf, ks < 4 ? zero16() : ch[ks & 3]);
+          loadR(n_tag, ks, img_x);
+          R256_FENCE();
+        }
+        RTP(27);
+        sink(2, (ch[0] + ch[1]) + (ch[2] + ch[3]));
       }
     };
 
@@ -487,7 +533,9 @@ __global__ __launch_bounds__(256) void fwdr256_kernel(const FwdArgs a) {
     RSYNC();
     {   // x1 is dead: its bytes take x2 (octaves 4, 5: slot u = 2 dd + (f - 4)), the strips and later the head gradients
       float vh[11], vl[11];
-      project(vh, vl);
+      float u0, u1, u2;
+      load_t(u0, u1, u2);
+      project(vh, vl, u0, u1, u2);
       GV* xp = (GV*)(ws_obj + a.wl.off_x2 + ((sg_own * KS_X2) << 10) + lane_off);
 #pragma unroll
       for (int t = 0; t < KS_X2; ++t) {
@@ -640,34 +688,62 @@ __global__ __launch_bounds__(256) void fwdr256_kernel(const FwdArgs a) {
     RSYNC();
     rlayer(std::integral_constant<int, C_B5H>{}, std::integral_constant<int, C_B5X>{}, std::false_type{}, 3, 8, hb1, dhb, KS_H, 1, hb0, img_k, std::true_type{});                             // d_pre4 -> 0
     R256_CUTAT(3)
-    float dproj[11];
-#pragma unroll
-    for (int dd = 0; dd < 11; ++dd) dproj[dd] = 0.f;
     // the embedding's chain rule (embedding.py:49-52), applied to a 16-slot block of gradients as it completes: OCT octaves
-    // per direction starting at F0 (x1: 4 from 0, x2: 2 from 4), slot u = OCT dd + (f - F0)
+    // per direction starting at F0 (x1: 4 from 0, x2: 2 from 4), slot u = OCT dd + (f - F0).  The chain rule is linear in the
+    // slot gradients, so every contribution goes straight into d B: d B[j][c] += d proj_j * t_c, summed over the half-wave's
+    // samples (DPP row sums + one row swap) and added to the wave's LDS sums by lane 0 -- nothing is carried from pass to
+    // pass (eleven registers through three layers otherwise, reloaded one by one from scratch at the tile's end).
     auto pe_bwd_block = [&](auto oct_tag, auto f0_tag, const int b, const f32x16& r) __attribute__((always_inline)) {
       constexpr int OCT = decltype(oct_tag)::value, F0 = decltype(f0_tag)::value;
       constexpr int DPB = 16 / OCT;                          // directions per block
+      float u0, u1, u2;
+      load_t(u0, u1, u2);
+      // three batches over the block's directions -- projections (their table rows in flight together), angle ladders and
+      // products, half-wave sums (independent DPP chains interleave) -- with a fence between the batches only: fenced per
+      // direction every LDS round trip and every dependent DPP chain was exposed (~330 cycles x 33 directions per tile)
+      constexpr int ND = (DPB == 8) ? 8 : 4;
+      float vh[ND], vl[ND];
 #pragma unroll
-      for (int d2 = 0; d2 < DPB; ++d2) {
+      for (int d2 = 0; d2 < ND; ++d2) {
         const int dd = b * DPB + d2;
+        vh[d2] = vl[d2] = 0.0f;
         if (dd < 11) {
           uint32_t smo = R_SMALL + 132 * h + 4 * (dd < 10 ? 3 * dd : (h ? 27 : 30));
-    RT(10);
           asm volatile("" : "+v"(smo));
           const float* sr = reinterpret_cast<const float*>(lds + smo);
-          const float p = fmaf(t2, sr[2], fmaf(t1, sr[1], t0 * sr[0]));
+          const float p = fmaf(u2, sr[2], fmaf(u1, sr[1], u0 * sr[0]));
           const float a0 = p * OBJ_PI_F;
-          const float vh = a0 * OBJ_INV2PI_HI_;
-          const float vl = fmaf(a0, OBJ_INV2PI_LO_, fmaf(a0, OBJ_INV2PI_HI_, -vh));
-          float sv[OCT], cv[OCT];
-          rev_ladder<F0, OCT>(vh, vl, sv, cv);
-#pragma unroll
-          for (int f = 0; f < OCT; ++f)
-            dproj[dd] = fmaf(r[OCT * d2 + f], cv[f] * (OBJ_PI_F * (float)(1 << (F0 + f))), dproj[dd]);
-          R256_FENCE();                      // (one direction at a time: batched, their table reads and angles spill)
+          vh[d2] = a0 * OBJ_INV2PI_HI_;
+          vl[d2] = fmaf(a0, OBJ_INV2PI_LO_, fmaf(a0, OBJ_INV2PI_HI_, -vh[d2]));
         }
       }
+      R256_FENCE();
+      float g[ND][3];
+#pragma unroll
+      for (int d2 = 0; d2 < ND; ++d2) {
+        const int dd = b * DPB + d2;
+        g[d2][0] = g[d2][1] = g[d2][2] = 0.0f;
+        if (dd < 11) {
+          float sv[OCT], cv[OCT];
+          rev_ladder<F0, OCT>(vh[d2], vl[d2], sv, cv);
+          float dpf = 0.0f;
+#pragma unroll
+          for (int f = 0; f < OCT; ++f) dpf = fmaf(r[OCT * d2 + f], cv[f] * (OBJ_PI_F * (float)(1 << (F0 + f))), dpf);
+          const float dp = (valid && (dd < 10 || h == 0)) ? dpf * inv_gs : 0.0f;
+          g[d2][0] = dp * u0; g[d2][1] = dp * u1; g[d2][2] = dp * u2;
+        }
+      }
+      R256_FENCE();
+#pragma unroll
+      for (int d2 = 0; d2 < ND; ++d2) {
+        const int dd = b * DPB + d2;
+        if (dd < 11) {
+          const float g0 = wave_sum32(g[d2][0]), g1 = wave_sum32(g[d2][1]), g2 = wave_sum32(g[d2][2]);
+          dbl += s == 3 * dd ? g0 : (s == 3 * dd + 1 ? g1 : (s == 3 * dd + 2 && dd < 10 ? g2 : 0.0f));
+          if (dd == 10) dbl32 += g2;         // (half 1 has no eleventh direction: its dp is 0 there)
+        }
+      }
+      R256_FENCE();
     };
     // B5X: d x2 of this wave's samples
     rslot(std::integral_constant<int, C_B5X>{}, std::integral_constant<int, C_B4>{}, hb1, xb, KS_H, 1,
@@ -699,26 +775,6 @@ __global__ __launch_bounds__(256) void fwdr256_kernel(const FwdArgs a) {
           img_n, std::false_type{}, std::false_type{}, 0, 0, hb0);
     RT(16);
     RT(16);
-    // d B[j][c] += d proj_j * t_c, summed over the half-wave's samples (33 independent shuffle chains), into the wave's sums
-    {
-      float g[33];
-#pragma unroll
-      for (int dd = 0; dd < 11; ++dd) {
-        const float dp = (valid && (dd < 10 || h == 0)) ? dproj[dd] * inv_gs : 0.0f;
-        g[3 * dd] = dp * t0; g[3 * dd + 1] = dp * t1; g[3 * dd + 2] = dp * t2;
-      }
-#pragma unroll
-      for (int i = 0; i < 33; ++i) g[i] = wave_sum32(g[i]);
-      if (s == 0) {
-        float* pj = s_db + w * 68 + 33 * h;
-        float o[33];
-#pragma unroll
-        for (int i = 0; i < 33; ++i) o[i] = pj[i];
-#pragma unroll
-        for (int i = 0; i < 33; ++i)
-          if (i < 30 || h == 0) pj[i] = o[i] + g[i];
-      }
-    }
     RT(18);
     {   // the next tile's first layer (requested HERE, behind the reduction: whatever the compiler reloads from scratch at the
         // tile boundary would otherwise queue behind these loads -- vmcnt completes in order)
