@@ -179,36 +179,26 @@ __global__ __launch_bounds__(256) void fwdr256_kernel(const FwdArgs a) {
   // this wave's first fragment of consumer c in image img -- ONE opaque scalar base per consumer and use: its fragments
   // are compile-time offsets from it (as one expression per fragment the compiler hoists ~300 64-bit offsets out of the
   // tile loop, spills them to vector lanes and reads them back lane by lane)
-  // (buffer loads: descriptor of the object's image + this lane's 32-bit offset + a SCALAR byte offset -- one scalar add per
-  // fragment, against two scalar adds + a 64-bit vector add + an address register pair for a global load)
-  struct FB { __amdgpu_buffer_rsrc_t rs; int off; };
-  auto cons_base = [&](auto c_tag, const char* img) __attribute__((always_inline)) -> FB {
+  auto cons_base = [&](auto c_tag, const char* img) __attribute__((always_inline)) -> const char* {
     constexpr int c = decltype(c_tag)::value;
-    FB f;
-    f.rs = __builtin_amdgcn_make_buffer_rsrc((void*)img, 0, (int)IMG_BYTES, 0x00020000);
-    f.off = (SQT::seq_off(rc_q(c)) + (rc_bmul(c) * w + rc_badd(c)) * rc_nk(c)) << 10;
-    asm volatile("" : "+s"(f.off));
-    return f;
+    const char* p = img + ((long)(SQT::seq_off(rc_q(c)) + (rc_bmul(c) * w + rc_badd(c)) * rc_nk(c)) << 10);
+    asm volatile("" : "+s"(p));
+    return p;
   };
-  auto frag_base = [&](auto c_tag, const int b, const int ks, const FB& cbase) __attribute__((always_inline)) -> FB {
+  auto frag_base = [&](auto c_tag, const int b, const int ks, const char* cbase) __attribute__((always_inline)) -> const char* {
     constexpr int c = decltype(c_tag)::value;
-    FB f = cbase;
-    f.off = cbase.off + ((b * rc_nk(c) + ks) << 10);
-    return f;
+    return cbase + ((b * rc_nk(c) + ks) << 10);
   };
-  typedef int i32x4_t __attribute__((ext_vector_type(4)));
-  auto frag_load = [&](V& dst, const FB& f) __attribute__((always_inline)) {
-    const i32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(f.rs, (int)lane_off, f.off, 0);
-    dst = __builtin_bit_cast(V, v);
-  };
+  auto frag_load = [&](V& dst, const char* base) __attribute__((always_inline)) { dst = *(const GV*)(base + lane_off); };
+#define r256_wait_a() do {} while (0)
   // register r of the next consumer n (if n keeps a fragment there)
-  auto loadR = [&](auto n_tag, const int r, const FB& img) __attribute__((always_inline)) {
+  auto loadR = [&](auto n_tag, const int r, const char* img) __attribute__((always_inline)) {
     constexpr int n = decltype(n_tag)::value;
     if ((R256_X & 1) && n != C_F1) return;
     if (rc_reg_valid(n, r)) frag_load(A[r], frag_base(n_tag, rc_reg_b(n, r), rc_reg_ks(n, r), img));
   };
   {
-    const FB cb0 = cons_base(std::integral_constant<int, C_F1>{}, (const char*)a.img + (long)k_i * IMG_BYTES);
+    const char* cb0 = cons_base(std::integral_constant<int, C_F1>{}, (const char*)a.img + (long)k_i * IMG_BYTES);
 #pragma unroll
     for (int r = 0; r < R_NA; ++r) loadR(std::integral_constant<int, C_F1>{}, r, cb0);
   }
@@ -386,13 +376,13 @@ __global__ __launch_bounds__(256) void fwdr256_kernel(const FwdArgs a) {
       constexpr int NK = rc_nk(c), NK16 = rc_nk16(c), NKX = NK - NK16;
       constexpr bool fwd = decltype(fwd_tag)::value, defer = decltype(defer_tag)::value && !(R256_X & 2);
       const uint32_t hin_l = opaque_lds(hin), xin_l = opaque_lds(xin), hout_l = opaque_lds(hout);
-      const FB img_c = cons_base(c_tag, img_k);
-      const FB img_x = cons_base(n_tag, img_next);
+      const char* img_c = cons_base(c_tag, img_k);
+      const char* img_x = cons_base(n_tag, img_next);
       if constexpr (NK > 16) {            // the x-slot k-steps' fragments: needed at the END of phase 0's k loop
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-          for (int x = 0; x < NKX; ++x) frag_load(AX[b * NKX + x], frag_base(c_tag, b, 16 + x, img_c));
+          for (int x = 0; x < NKX; ++x) AX[b * NKX + x] = *(const GV*)(frag_base(c_tag, b, 16 + x, img_c) + lane_off);
       }
       // Two phases, each a PAIR of column groups: 2 row blocks x 2 column groups = four independent accumulator chains
       // (an MFMA that depends on the previous one starts ~110 cycles after it, an independent one after ~34), every chain
@@ -468,8 +458,8 @@ __global__ __launch_bounds__(256) void fwdr256_kernel(const FwdArgs a) {
       constexpr int NK = rc_nk(c), NB = rc_nb(c);
       constexpr bool pend = decltype(pend_tag)::value && !(R256_X & 2), pfwd = decltype(pfwd_tag)::value;
       const uint32_t hin_l = opaque_lds(hin), xin_l = opaque_lds(xin), phout_l = opaque_lds(phout);
-      const FB img_c = cons_base(c_tag, img_k);
-      const FB img_x = cons_base(n_tag, img_next);
+      const char* img_c = cons_base(c_tag, img_k);
+      const char* img_x = cons_base(n_tag, img_next);
       if constexpr (NB == 1) {
 #pragma unroll
         for (int r = NK; r < R_NA; ++r) loadR(n_tag, r, img_x);
@@ -788,7 +778,7 @@ __global__ __launch_bounds__(256) void fwdr256_kernel(const FwdArgs a) {
     RT(18);
     {   // the next tile's first layer (requested HERE, behind the reduction: whatever the compiler reloads from scratch at the
         // tile boundary would otherwise queue behind these loads -- vmcnt completes in order)
-      const FB cbn = cons_base(std::integral_constant<int, C_F1>{}, img_n);
+      const char* cbn = cons_base(std::integral_constant<int, C_F1>{}, img_n);
 #pragma unroll
       for (int r = 0; r < R_NA; ++r) loadR(std::integral_constant<int, C_F1>{}, r, cbn);
     }
