@@ -109,6 +109,39 @@ def test_config_c5_object_at_full_size_16bit(dev, mode, feat):
     assert float(d) < 1e-5, float(d)
 
 
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape", [(2, 700, 8, 24), (2, 90, 16, 48), (1, 300, 32, 96)])
+def test_hidden256_kernel_forms_agree(dev, mode, shape, tmp_path):
+    """The two forms of kernel A (objnerf_train256.hip: fwd256_kernel -- waves own samples, weights through the LDS ring;
+    objnerf_train256r_body.h: fwdr256_kernel, the default without the feature loss -- waves own output rows, weights from
+    L2 into registers, activations in LDS) compute the same arithmetic in a different summation order (a contraction runs as one
+    fp32 chain in one form, as two added chains in the other): an activation that sits on a rounding boundary of the operand
+    type lands on either side, so the two agree to a fraction of their common distance from the specification -- gradients
+    within 2e-3 of each other in norm (measured 5e-5 .. 8e-4; the same shapes sit 2e-3 .. 5e-3 from the specification),
+    loss terms to 1e-4.  The switch is an environment variable read once per process, hence two child processes."""
+    import os
+    import subprocess
+    import sys
+    K, R, n1, n2 = shape
+    tool = os.path.join(os.path.dirname(__file__), "..", "tools", "h256_forms.py")
+    outs = []
+    for first in (False, True):
+        env = dict(os.environ)
+        env.pop("OBJ256_FIRST_FORM", None)
+        if first:
+            env["OBJ256_FIRST_FORM"] = "1"
+        out = str(tmp_path / f"form{int(first)}.npz")
+        subprocess.run([sys.executable, tool, out, mode, str(K), str(R), str(n1), str(n2)], check=True, env=env, timeout=600)
+        outs.append(np.load(out))
+    assert int(outs[0]["status"]) == 0 and int(outs[1]["status"]) == 0
+    g0, g1 = outs[0]["grads"].astype(np.float64), outs[1]["grads"].astype(np.float64)
+    assert np.isfinite(g0).all() and np.isfinite(g1).all()
+    rel = np.linalg.norm(g0 - g1) / np.linalg.norm(g1)
+    print(f"{mode} {shape}: forms differ by {rel:.2e}")
+    assert rel < 2e-3, rel
+    np.testing.assert_allclose(outs[0]["terms"][:, :3], outs[1]["terms"][:, :3], rtol=1e-4, atol=1e-6)
+
+
 def test_fp16_and_bf16_together_are_refused(dev):
     arena = ops.ParamArena(1, ops.NetShape(64, 512, 6), dev)
     arena.load_stacked(obj_init.init_stacked(1, 64, 512, seed=1))
