@@ -75,13 +75,7 @@ static_assert(2 * (rc_nk(C_F3) - 16) <= R_NAX && rc_nk(C_AL) <= R_NA, "A registe
 #define RTP(i) do {} while (0)
 #define RSYNC() __syncthreads()
 #endif
-#ifndef R256_CUT
-#define R256_CUT 0
-#endif
-#define R256_CUTAT(n_) if (R256_CUT == n_) { if (++tile_i == a.ntile) { tile_i = 0; ++k_i; } continue; }
-#ifndef R256_X
-#define R256_X 0      // diagnostic bits: 1 no next-consumer prefetch, 2 no deferred epilogues, 4 no epilogue at all, 8 no slot passes' MFMAs
-#endif
+
 
 template <typename OT, int S>
 __global__ __launch_bounds__(256) void fwdr256_kernel(const FwdArgs a) {
@@ -190,11 +184,9 @@ __global__ __launch_bounds__(256) void fwdr256_kernel(const FwdArgs a) {
     return cbase + ((b * rc_nk(c) + ks) << 10);
   };
   auto frag_load = [&](V& dst, const char* base) __attribute__((always_inline)) { dst = *(const GV*)(base + lane_off); };
-#define r256_wait_a() do {} while (0)
   // register r of the next consumer n (if n keeps a fragment there)
   auto loadR = [&](auto n_tag, const int r, const char* img) __attribute__((always_inline)) {
     constexpr int n = decltype(n_tag)::value;
-    if ((R256_X & 1) && n != C_F1) return;
     if (rc_reg_valid(n, r)) frag_load(A[r], frag_base(n_tag, rc_reg_b(n, r), rc_reg_ks(n, r), img));
   };
   {
@@ -320,7 +312,6 @@ __global__ __launch_bounds__(256) void fwdr256_kernel(const FwdArgs a) {
       const int b = j >> 3, i = j & 7, cgp = 2 * par + ci;
       uint32_t (&ewd)[8] = ewd2[ci];
       uint32_t& ebits = ebits2[ci];
-      if (R256_X & 4) return;
       if (i == 0) ebits = 0;
       const uint32_t c = pk_cvt<OT>(acc[par][ci][b][2 * i], acc[par][ci][b][2 * i + 1]);
       if (fwd) {
@@ -374,7 +365,7 @@ __global__ __launch_bounds__(256) void fwdr256_kernel(const FwdArgs a) {
                       const int nkh, const int nx, char* hout, const char* img_next, auto defer_tag) __attribute__((always_inline)) {
       constexpr int c = decltype(c_tag)::value;
       constexpr int NK = rc_nk(c), NK16 = rc_nk16(c), NKX = NK - NK16;
-      constexpr bool fwd = decltype(fwd_tag)::value, defer = decltype(defer_tag)::value && !(R256_X & 2);
+      constexpr bool fwd = decltype(fwd_tag)::value, defer = decltype(defer_tag)::value;
       const uint32_t hin_l = opaque_lds(hin), xin_l = opaque_lds(xin), hout_l = opaque_lds(hout);
       const char* img_c = cons_base(c_tag, img_k);
       const char* img_x = cons_base(n_tag, img_next);
@@ -456,7 +447,7 @@ __global__ __launch_bounds__(256) void fwdr256_kernel(const FwdArgs a) {
         __attribute__((always_inline)) {
       constexpr int c = decltype(c_tag)::value;
       constexpr int NK = rc_nk(c), NB = rc_nb(c);
-      constexpr bool pend = decltype(pend_tag)::value && !(R256_X & 2), pfwd = decltype(pfwd_tag)::value;
+      constexpr bool pend = decltype(pend_tag)::value, pfwd = decltype(pfwd_tag)::value;
       const uint32_t hin_l = opaque_lds(hin), xin_l = opaque_lds(xin), phout_l = opaque_lds(phout);
       const char* img_c = cons_base(c_tag, img_k);
       const char* img_x = cons_base(n_tag, img_next);
@@ -523,7 +514,6 @@ __global__ __launch_bounds__(256) void fwdr256_kernel(const FwdArgs a) {
     if (live) load_point((int)next_obj, next_obj != k ? 0 : tile + 1, npx, npy, npz, nzv);               // the next tile's sample
     RT(2);
     RSYNC();
-    if (R256_X & 32) { if (++tile_i == a.ntile) { tile_i = 0; ++k_i; } continue; }
     rlayer(std::integral_constant<int, C_F2>{}, std::integral_constant<int, C_F3>{}, std::true_type{}, 1, 1, hb0, xb, KS_H, 1, hb1, img_k, std::false_type{});                                // h2 -> 1
     asm volatile("" : "+v"(npx), "+v"(npy), "+v"(npz), "+v"(nzv));      // (computed HERE, not at the next tile's top: 4 live values instead of 9)
     RT(3);
@@ -573,7 +563,6 @@ __global__ __launch_bounds__(256) void fwdr256_kernel(const FwdArgs a) {
     }
     RSYNC();
 
-    if (R256_X & 16) { if (++tile_i == a.ntile) { tile_i = 0; ++k_i; } continue; }
     RT(19);
     // ------------------------------------------------------------------ compositing + losses (loss.py:27-101)
     {
@@ -679,15 +668,12 @@ __global__ __launch_bounds__(256) void fwdr256_kernel(const FwdArgs a) {
     }
     RSYNC();
 
-    R256_CUTAT(1)
     RT(21);
     // ------------------------------------------------------------------ backward
     rlayer(std::integral_constant<int, C_B6>{}, std::integral_constant<int, C_B5H>{}, std::false_type{}, 4, 9, hb0, dhb, 0, 1, hb1, img_k, std::false_type{});                                // d_pre5 = mask(W_oc^T d colour) -> 1
-    R256_CUTAT(2)
     RT(9);
     RSYNC();
     rlayer(std::integral_constant<int, C_B5H>{}, std::integral_constant<int, C_B5X>{}, std::false_type{}, 3, 8, hb1, dhb, KS_H, 1, hb0, img_k, std::true_type{});                             // d_pre4 -> 0
-    R256_CUTAT(3)
     // the embedding's chain rule (embedding.py:49-52), applied to a 16-slot block of gradients as it completes: OCT octaves
     // per direction starting at F0 (x1: 4 from 0, x2: 2 from 4), slot u = OCT dd + (f - F0).  The chain rule is linear in the
     // slot gradients, so every contribution goes straight into d B: d B[j][c] += d proj_j * t_c, summed over the half-wave's
@@ -750,30 +736,24 @@ __global__ __launch_bounds__(256) void fwdr256_kernel(const FwdArgs a) {
           [&](const int b, const f32x16& r) __attribute__((always_inline)) { pe_bwd_block(std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{}, b, r); },
           img_k, std::true_type{}, std::false_type{}, 3, 8, hb0);
     RT(11);
-    R256_CUTAT(4)
     RSYNC();
     rlayer(std::integral_constant<int, C_B4>{}, std::integral_constant<int, C_B3H>{}, std::false_type{}, 2, 7, hb0, xb, KS_H, 1, hb1, img_k, std::false_type{});                              // d_pre3 -> 1
-    R256_CUTAT(5)
     RT(12);
     RSYNC();
     rlayer(std::integral_constant<int, C_B3H>{}, std::integral_constant<int, C_B3X>{}, std::false_type{}, 1, 6, hb1, xb, KS_H, 1, hb0, img_k, std::true_type{});                              // d_pre2 -> 0
-    R256_CUTAT(6)
     // B3X: d x1 (cat layer's share) from d_pre3
     rslot(std::integral_constant<int, C_B3X>{}, std::integral_constant<int, C_B2>{}, hb1, xb, KS_H, 1,
           [&](const int b, const f32x16& r) __attribute__((always_inline)) { pe_bwd_block(std::integral_constant<int, 4>{}, std::integral_constant<int, 0>{}, b, r); },
           img_k, std::true_type{}, std::false_type{}, 1, 6, hb0);
     RT(13);
-    R256_CUTAT(7)
     RSYNC();
     rlayer(std::integral_constant<int, C_B2>{}, std::integral_constant<int, C_B1>{}, std::false_type{}, 0, 5, hb0, xb, KS_H, 1, hb1, img_k, std::false_type{});                               // d_pre1 -> 1
     RT(15);
     RSYNC();
-    R256_CUTAT(8)
     // B1: d x1 += W_in^T d_pre1; its registers take the next tile's first layer as they fall free
     rslot(std::integral_constant<int, C_B1>{}, std::integral_constant<int, C_END>{}, hb1, xb, KS_H, 1,
           [&](const int b, const f32x16& r) __attribute__((always_inline)) { pe_bwd_block(std::integral_constant<int, 4>{}, std::integral_constant<int, 0>{}, b, r); },
           img_n, std::false_type{}, std::false_type{}, 0, 0, hb0);
-    RT(16);
     RT(16);
     RT(18);
     {   // the next tile's first layer (requested HERE, behind the reduction: whatever the compiler reloads from scratch at the
