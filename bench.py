@@ -430,7 +430,9 @@ class Workload:
             if mode:
                 return "train_fused_bf16_kernel<%s, %d>" % ("true" if feat else "false", 64 if S == 64 else 0)
             return "train_fused32_kernel<%s, false, %d>" % ("true" if feat else "false", 64 if S == 64 else 0)
-        if Hd == 256 and mode and not feat and S in (32, 64, 128):
+        if Hd == 256 and mode and S in (32, 64, 128):
+            if feat:                                       # (on the fused kernels since round 5; no PMC pass recorded for it)
+                return "objnerf_train_step, fused hidden-256 path with the feature loss (fwd256_kernel<.., true> + wgrad256_kernel + the head's GEMMs)"
             return "objnerf_train_step, fused hidden-256 path (fwd256_kernel + wgrad256_kernel)"
         return "objnerf_train_step, layer-wise path (batched MFMA GEMMs)"
 

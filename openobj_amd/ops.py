@@ -6,6 +6,7 @@ libobjnerf_hip.so.  Every function requires CUDA(HIP) tensors and raises on anyt
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -437,6 +438,21 @@ class TrainWorkspace:
         uses_context = (arena.net.hidden != 32 or S > 64 or layerwise) and dev.type == "cuda"
         self.context = (context if context is not None else StreamContext(dev)) if uses_context else None
         self.buf = torch.empty(self.nbytes, dtype=torch.uint8, device=dev)
+        # Chunked hidden-256 steps in a 16-bit mode (configs[4]: the two fused kernels of objnerf_train256.hip) run their
+        # chunks ALTERNATELY on two streams, each with its own buffer: a chunk's HBM-bound weight-gradient kernel then fills the
+        # CUs that the next chunk's kernel A leaves idle at its tail (both hold ~150 KB of LDS per workgroup, so they never
+        # share a CU; tools/c5_overlap.py: 3 - 5 % of the step).  Only where a second buffer fits beside the first.
+        self.lanes = 1
+        self.buf2 = None
+        if (self.k_chunk < K and dev.type == "cuda" and arena.net.hidden == 256 and precision_bits(precision) in (1, 4)
+                and not (layerwise and precision_bits(precision) != 4) and S in (32, 64, 128)
+                and os.environ.get("OBJNERF_ONE_LANE", "0") != "1"):
+            free, _total = torch.cuda.mem_get_info(dev)
+            if free > self.nbytes + (8 << 30):
+                self.buf2 = torch.empty(self.nbytes, dtype=torch.uint8, device=dev)
+                self.side = torch.cuda.Stream(device=dev)
+                self.ev_in, self.ev_out = torch.cuda.Event(), torch.cuda.Event()
+                self.lanes = 2
         self.grads = torch.zeros_like(arena.params)
         self.loss_terms = torch.zeros(K, 4, device=dev)
         self.status = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -536,15 +552,26 @@ def train_step(arena: ParamArena, ws: TrainWorkspace, batch: Dict[str, torch.Ten
               "objnerf_label_counts")
     # layer-wise path, chunk of objects at a time (leading-dimension slices are contiguous views)
     sl = lambda t, k0, k1: None if t is None else t[k0:k1]           # noqa: E731
+    two = getattr(ws, "lanes", 1) == 2 and relu_masks is None and emb_debug is None
+    if two:                             # (odd chunks on the side stream with the second buffer; it starts behind this stream)
+        main = torch.cuda.current_stream()
+        ws.ev_in.record(main)
+        ws.side.wait_event(ws.ev_in)
     for ci, k0 in enumerate(range(0, K, kc)):
         k1 = min(K, k0 + kc)
+        side = two and (ci & 1) == 1
+        buf = ws.buf2 if side else ws.buf
+        sth = ws.side.cuda_stream if side else st
         a = TrainArgs(k1 - k0, R, S, mode, color_scaling, opacity_scaling, feat_scaling, obj_center,
                       _ptr(arena.params[k0:k1]), arena.p_stride, _ptr(arena.scale[k0:k1]), _ptr(sl(pts, k0, k1)),
                       _ptr(sl(origins, k0, k1)), _ptr(sl(dirs, k0, k1)), _ptr(z[k0:k1]), _ptr(gt_depth[k0:k1]),
                       _ptr(gt_rgb[k0:k1]), _ptr(labels[k0:k1]), _ptr(sl(gt_feat, k0, k1)), _ptr(counts[k0:k1]),
                       _ptr(flags), _ptr(ws.grads[k0:k1]), _ptr(ws.loss_terms[k0:k1]), _ptr(ws.status_chunks[ci:ci + 1]),
-                      _ptr(ws.buf), ws.nbytes, _ptr(sl(relu_masks, k0, k1)), ctx, _ptr(sl(emb_debug, k0, k1)), None)
-        check(lib().objnerf_train_step(C.byref(net), C.byref(a), st), "objnerf_train_step")
+                      _ptr(buf), ws.nbytes, _ptr(sl(relu_masks, k0, k1)), ctx, _ptr(sl(emb_debug, k0, k1)), None)
+        check(lib().objnerf_train_step(C.byref(net), C.byref(a), sth), "objnerf_train_step")
+    if two:
+        ws.ev_out.record(ws.side)
+        main.wait_event(ws.ev_out)
     torch.amax(ws.status_chunks, dim=0, keepdim=True, out=ws.status)
     if optim is not None:               # (chunked: one optimiser launch over the whole arena after the last chunk)
         optim.step(ws.grads, arena.has_grad_mask(with_feat), flags=flags)

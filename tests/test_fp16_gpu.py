@@ -142,6 +142,35 @@ def test_hidden256_kernel_forms_agree(dev, mode, shape, tmp_path):
     np.testing.assert_allclose(outs[0]["terms"][:, :3], outs[1]["terms"][:, :3], rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+@pytest.mark.parametrize("feat", [False, True])
+def test_chunked_hidden256_step_on_two_streams_is_bit_equal(dev, mode, feat):
+    """A hidden-256 batch whose workspace does not fit the budget runs chunk by chunk (ops.TrainWorkspace.k_chunk); in the
+    16-bit modes the chunks alternate between the caller's stream and a side stream with a second buffer (the weight
+    -gradient kernel of chunk i beside kernel A of chunk i + 1: tools/c5_overlap.py).  Same launches on the same data:
+    gradients, loss terms and status are BIT-equal to the one-stream order, and repeatable."""
+    K, R, n1, n2, H = 5, 200, 16, 48, 256
+    arena = ops.ParamArena(K, ops.NetShape(H, 512, 6), dev)
+    arena.load_stacked(obj_init.init_stacked(K, H, 512, seed=43))
+    b = synthetic.random_batch(K, R, n1, n2, seed=19, feat_dim=512 if feat else 0)
+    batch = {k: T(b[k]).to(dev) for k in ["pts", "z", "gt_depth", "gt_rgb", "labels"] + (["gt_feat"] if feat else [])}
+    one = ops.TrainWorkspace(arena, 1, R, n1 + n2, feat, precision=mode).nbytes
+    ws2 = ops.TrainWorkspace(arena, K, R, n1 + n2, feat, precision=mode, budget=2 * one + one // 2)     # chunks of two objects
+    assert ws2.k_chunk == 2 and ws2.lanes == 2
+    ws1 = ops.TrainWorkspace(arena, K, R, n1 + n2, feat, precision=mode, budget=2 * one + one // 2)
+    ws1.lanes = 1
+    for ws in (ws2, ws1, ws2):
+        ws.grads.zero_()
+        ops.train_step(arena, ws, batch, with_feat=feat, bf16=mode)
+        torch.cuda.synchronize()
+        assert int(ws.status.item()) == 0
+        if ws is ws1:
+            assert torch.equal(ws1.grads, first) and torch.equal(ws1.loss_terms, terms)
+        elif ws is ws2 and "first" in dir():
+            assert torch.equal(ws2.grads, first)
+        first, terms = ws2.grads.clone(), ws2.loss_terms.clone()
+
+
 def test_fp16_and_bf16_together_are_refused(dev):
     arena = ops.ParamArena(1, ops.NetShape(64, 512, 6), dev)
     arena.load_stacked(obj_init.init_stacked(1, 64, 512, seed=1))
