@@ -485,6 +485,9 @@ class Workload:
                 "objects_per_gpu": self.K, "objects_total": self.K_total, "rays_per_object": self.R,
                 "samples_per_ray": self.S, "hidden": self.Hd, "feature_head": self.feat,
                 "background_mlp": self.bg_loop is not None, "distinct_ray_sets": self.distinct,
+                "object_chunks": ((self.K + self.obj_loop.ws.k_chunk - 1) // self.obj_loop.ws.k_chunk
+                                  if getattr(self.obj_loop, "ws", None) is not None else 1),
+                "chunk_streams": getattr(getattr(self.obj_loop, "ws", None), "lanes", 1),
                 "background_rays_on_this_gpu": (self.bg_batches[0]["labels"].shape[1] if self.bg_loop is not None else 0)}
 
     def free(self):

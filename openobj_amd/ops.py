@@ -450,7 +450,9 @@ class TrainWorkspace:
             free, _total = torch.cuda.mem_get_info(dev)
             if free > self.nbytes + (8 << 30):
                 self.buf2 = torch.empty(self.nbytes, dtype=torch.uint8, device=dev)
-                self.side = torch.cuda.Stream(device=dev)
+                # (a HIGH-priority stream: streams of one priority share a few hardware queues round-robin, and two streams on
+                # one queue run their kernels back to back -- measured in a process that had created a dozen streams before)
+                self.side = torch.cuda.Stream(device=dev, priority=-1)
                 self.ev_in, self.ev_out = torch.cuda.Event(), torch.cuda.Event()
                 self.lanes = 2
         self.grads = torch.zeros_like(arena.params)
