@@ -56,8 +56,8 @@ def run(dev, K, R, n1, n2, mode, seed=7):
     return worst
 
 
-def timed(dev, mode):
-    K, R, n1, n2, H = 8, 8192, 32, 96, 256
+def timed(dev, mode, n1=32, n2=96):
+    K, R, H = 8, 8192, 256
     arena = ops.ParamArena(K, ops.NetShape(H, 512, 6), dev)
     arena.load_stacked(obj_init.init_stacked(K, H, 512, seed=3))
     b = synthetic.random_batch(K, R, n1, n2, seed=11)
@@ -70,7 +70,7 @@ def timed(dev, mode):
     for _ in range(5):
         ops.train_step(arena, ws, batch, bf16=mode)
     torch.cuda.synchronize()
-    print(f"time {mode}: {(time.perf_counter() - t) / 5 * 1e3:.2f} ms per step of 8 objects x 8192 x 128", flush=True)
+    print(f"time {mode}: {(time.perf_counter() - t) / 5 * 1e3:.2f} ms per step of 8 objects x 8192 x {n1 + n2}", flush=True)
 
 
 def main():
@@ -84,6 +84,9 @@ def main():
             print(f"   worst {w:.2e}")
         if "--time" in sys.argv:
             timed(dev, mode)
+            if "--all-s" in sys.argv:
+                timed(dev, mode, 16, 48)
+                timed(dev, mode, 8, 24)
 
 
 if __name__ == "__main__":
