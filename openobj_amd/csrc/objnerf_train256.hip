@@ -2176,15 +2176,22 @@ static int run(const objnerf_net* net, const objnerf_train_args* a, hipStream_t 
   float* part = (float*)(base + p.off_part);
   float* slabs = (float*)(base + p.off_slabs);
   char* ws = base + p.off_ws;
+  // diagnostic (tools/c5_cumask.py): OBJ256_ONLY=A issues kernel A's half of the step (pack, head preparation, kernel A), =B
+  // the other half (kernel B, finalize, head gradients) on data an earlier full step left in the workspace
+  const char* only_e = getenv("OBJ256_ONLY");
+  const bool do_a = !(only_e && only_e[0] == 'B'), do_b = !(only_e && only_e[0] == 'A');
+  if (do_a) {
   (void)hipMemsetAsync(a->status, 0, sizeof(int), st);
   (void)hipMemsetAsync(part, 0, (size_t)K * NWG_A * PART_FLOATS * 4, st);
-  {
+  }
+  if (do_a) {
     const long tot = (long)K * SQ<FEAT>::N_PIECES * 64;
     hipLaunchKernelGGL((pack256_kernel<OT, FEAT>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, K, a->params,
                        (long)a->p_stride, L, img);
   }
   objgen::FeatHead fh;
-  if (FEAT) {
+  if (FEAT && !do_a) fh = objgen::feat_head_carve(base + p.off_feat, K, a->R, HID, C);
+  if (FEAT && do_a) {
     // the hoisted 512-d head: per object G = W_of^T W_of (+ wb, bb), per ray u = W_of^T g, beta, |g| -- ahead
     // of kernel A, with the operand type of the mode (16-bit GEMM operands, like the layer-wise path)
     fh = objgen::feat_head_carve(base + p.off_feat, K, a->R, HID, C);
@@ -2212,6 +2219,7 @@ static int run(const objnerf_net* net, const objnerf_train_args* a, hipStream_t 
   fa.feat_scaling = a->feat_scaling;
   fa.gimg = base + p.off_gimg;
   fa.rayin = fh.rayin; fa.gram = fh.gram; fa.rayfeat = fh.rayfeat; fa.X1 = fh.X1; fa.X2 = fh.X2;
+  if (do_a) {
 #ifdef OBJ256_ONE          // diagnostic builds: one instantiation (compile time)
   if (!FEAT && use_row_split()) launch_fwdr_any<OT>(fa, 128, st);
   else launch_fwd<OT, 128, OBJ256_NW, FEAT>(fa, st);
@@ -2224,6 +2232,8 @@ static int run(const objnerf_net* net, const objnerf_train_args* a, hipStream_t 
     default: launch_fwd<OT, 128, OBJ256_NW, FEAT>(fa, st); break;
   }
 #endif
+  }
+  if (!do_b) return hipGetLastError() != hipSuccess ? OBJNERF_ELAUNCH : OBJNERF_OK;
   WgArgs wa;
   wa.K = K;
   for (int t = 0; t < NTYPE; ++t) wa.parts[t] = p.parts[t];
@@ -2268,7 +2278,8 @@ static void launch_fwdr(const FwdArgs& fa, hipStream_t st) {
   objnerf_once_per_device([] {
     (void)hipFuncSetAttribute((const void*)fwdr256_kernel<OT, S>, hipFuncAttributeMaxDynamicSharedMemorySize, R_TOTAL);
   });
-  hipLaunchKernelGGL((fwdr256_kernel<OT, S>), dim3(NWG_A), dim3(256), R_TOTAL, st, fa);
+  static const int nwg = [] { const char* e = getenv("OBJ256_NWG"); const int v = e ? atoi(e) : NWG_A; return (v >= 8 && v <= NWG_A && v % 8 == 0) ? v : NWG_A; }();
+  hipLaunchKernelGGL((fwdr256_kernel<OT, S>), dim3(nwg), dim3(256), R_TOTAL, st, fa);       // (OBJ256_NWG: diagnostic, tools/c5_cumask.py)
 }
 template <typename OT> static void launch_fwdr_s(const FwdArgs& fa, int S, hipStream_t st) {
 #ifdef OBJ256_ONE
