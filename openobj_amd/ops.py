@@ -450,10 +450,12 @@ class TrainWorkspace:
             free, _total = torch.cuda.mem_get_info(dev)
             if free > self.nbytes + (8 << 30):
                 self.buf2 = torch.empty(self.nbytes, dtype=torch.uint8, device=dev)
-                # (a HIGH-priority stream: streams of one priority share a few hardware queues round-robin, and two streams on
-                # one queue run their kernels back to back -- measured in a process that had created a dozen streams before)
-                self.side = torch.cuda.Stream(device=dev, priority=-1)
-                self.ev_in, self.ev_out = torch.cuda.Event(), torch.cuda.Event()
+                # TWO side streams created back to back (the caller's stream only hands over and collects): streams are dealt
+                # to a few hardware queues round-robin in creation order, and two streams that share a queue run their kernels
+                # back to back -- a single side stream overlapped with the caller's stream in a fresh process and not in one
+                # that had created a dozen streams before; a high-priority side stream the other way round (tools/lanes_ab.sh)
+                self.sides = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+                self.ev_in, self.ev_out = torch.cuda.Event(), [torch.cuda.Event(), torch.cuda.Event()]
                 self.lanes = 2
         self.grads = torch.zeros_like(arena.params)
         self.loss_terms = torch.zeros(K, 4, device=dev)
@@ -555,15 +557,15 @@ def train_step(arena: ParamArena, ws: TrainWorkspace, batch: Dict[str, torch.Ten
     # layer-wise path, chunk of objects at a time (leading-dimension slices are contiguous views)
     sl = lambda t, k0, k1: None if t is None else t[k0:k1]           # noqa: E731
     two = getattr(ws, "lanes", 1) == 2 and relu_masks is None and emb_debug is None
-    if two:                             # (odd chunks on the side stream with the second buffer; it starts behind this stream)
+    if two:                             # (even / odd chunks on the two side streams, each with its buffer, behind this stream)
         main = torch.cuda.current_stream()
         ws.ev_in.record(main)
-        ws.side.wait_event(ws.ev_in)
+        for sd in ws.sides:
+            sd.wait_event(ws.ev_in)
     for ci, k0 in enumerate(range(0, K, kc)):
         k1 = min(K, k0 + kc)
-        side = two and (ci & 1) == 1
-        buf = ws.buf2 if side else ws.buf
-        sth = ws.side.cuda_stream if side else st
+        buf = ws.buf2 if (two and (ci & 1)) else ws.buf
+        sth = ws.sides[ci & 1].cuda_stream if two else st
         a = TrainArgs(k1 - k0, R, S, mode, color_scaling, opacity_scaling, feat_scaling, obj_center,
                       _ptr(arena.params[k0:k1]), arena.p_stride, _ptr(arena.scale[k0:k1]), _ptr(sl(pts, k0, k1)),
                       _ptr(sl(origins, k0, k1)), _ptr(sl(dirs, k0, k1)), _ptr(z[k0:k1]), _ptr(gt_depth[k0:k1]),
@@ -572,8 +574,9 @@ def train_step(arena: ParamArena, ws: TrainWorkspace, batch: Dict[str, torch.Ten
                       _ptr(buf), ws.nbytes, _ptr(sl(relu_masks, k0, k1)), ctx, _ptr(sl(emb_debug, k0, k1)), None)
         check(lib().objnerf_train_step(C.byref(net), C.byref(a), sth), "objnerf_train_step")
     if two:
-        ws.ev_out.record(ws.side)
-        main.wait_event(ws.ev_out)
+        for sd, ev in zip(ws.sides, ws.ev_out):
+            ev.record(sd)
+            main.wait_event(ev)
     torch.amax(ws.status_chunks, dim=0, keepdim=True, out=ws.status)
     if optim is not None:               # (chunked: one optimiser launch over the whole arena after the last chunk)
         optim.step(ws.grads, arena.has_grad_mask(with_feat), flags=flags)
