@@ -26,7 +26,7 @@
 
 constexpr int R_HBSZ = 4 * KS_H * PIECE;                       // one activation buffer: [column group][k-step] pieces
 constexpr int R_XB = 2 * R_HBSZ;                               // x1 [4][KS_X1] pieces; after F3: x2 [4][KS_X2] pieces ...
-constexpr int R_STRIP = R_XB + 4 * KS_X2 * PIECE;              // ... the strips (raw alpha | colour pre [3] | z | ray targets)
+constexpr int R_STRIP = R_XB + 4 * KS_X2 * PIECE;              // ... the strips (raw alpha | colour pre [3] | z; the ray targets sit beside the embedding rows)
 constexpr int R_DH = R_STRIP + 3072;                           // ... and the head-gradient pieces [4]
 constexpr int R_BIAS = R_XB + 4 * KS_X1 * PIECE;
 constexpr int R_SMALL = R_BIAS + 5 * 256 * 4;
