@@ -103,6 +103,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-other-configs", action="store_true",
                     help="default line only: do not also time c3, configs[3]'s share and configs[4]'s share")
     ap.add_argument("--other-steps", type=int, default=10, help="timed steps of each `other_configs` entry")
+    ap.add_argument("--detail-out", default=None,
+                    help="file the FULL report goes to (other_configs, psnr detail, native_frame, per-shape cpu rows, notes); "
+                         "default gpurun_out/bench_detail.json.  stdout carries ONE short line (< 4 KB) naming this file")
     ap.add_argument("--share-curve-out", default=None,
                     help="also time the emulated 1 / 2 / 4 / 8-rank shares of c4 and c2 (fp32 and bf16, --steps each) and "
                          "write the table to this file (profiles/r05_share_curve.json)")
@@ -610,6 +613,84 @@ def native_frame(dev, bf16=False, n_objects=50, frames=4):
     return out
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# What stdout carries.  Round 5's line had grown to 20.8 KB and the driver stopped parsing it (BENCH_r05.parsed = null):
+# the line is now a fixed, flat selection (< LINE_LIMIT bytes, asserted) and the full report goes to --detail-out.
+# ----------------------------------------------------------------------------------------------------------------------
+LINE_LIMIT = 4096
+LINE_TOP_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                 "vs_baseline", "dtype", "data", "dry_launch", "rays_per_sec_per_gpu", "psnr_delta_db", "psnr_delta_ci95_db",
+                 "metric_version")
+LINE_CONFIG_KEYS = ("workload", "objects_per_gpu", "objects_total", "rays_per_object", "samples_per_ray", "hidden",
+                    "feature_head", "background_mlp", "parallelism", "collectives_per_step", "rccl_ranks", "objects_per_rank",
+                    "launched_by", "loss_status", "backend", "collectives_ok")
+LINE_ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "flop_per_ray",
+                      "algorithmic_bytes_per_launch", "traffic_ratio", "traffic_source", "peak_measured", "frac_of_measured_peak")
+LINE_CPU_KEYS = ("value", "unit", "cores", "kind", "sample")
+
+
+def _r6(x):
+    """Numbers of the line to 6 significant digits (the detail file keeps full precision)."""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    return float("%.6g" % x)
+
+
+def _clip(sx, n):
+    return sx if len(sx) <= n else sx[:n - 3] + "..."
+
+
+def short_line(out: dict, detail_path=None) -> str:
+    """The ONE stdout line: the contract's keys, `roofline` and `cpu_baseline` as flat objects, the flat `summary`
+    numbers, and the path of the detail file -- nothing nested deeper, no per-config blocks, no prose beyond the workload
+    name.  Always < LINE_LIMIT bytes: an oversized line is an error here, not a surprise in the driver's parser."""
+    line = {k: _r6(out[k]) for k in LINE_TOP_KEYS if k in out}
+    cfg = out.get("config", {})
+    line["config"] = {k: (_clip(cfg[k], 200) if isinstance(cfg[k], str) else cfg[k]) for k in LINE_CONFIG_KEYS if k in cfg}
+    if len(line["config"].get("objects_per_rank", [])) > 16:
+        line["config"].pop("objects_per_rank")
+    if "roofline" in out:
+        rf = dict(out["roofline"])
+        if rf.get("traffic") is not None and "traffic_source" not in rf:
+            rf["traffic_source"] = "recorded rocprofv3 --pmc pass of the same launch (profiles/), not read by this run"
+        line["roofline"] = {k: (_r6(rf[k]) if not isinstance(rf[k], str) else _clip(rf[k], 120))
+                            for k in LINE_ROOFLINE_KEYS if k in rf}
+    if "cpu_baseline" in out:
+        line["cpu_baseline"] = {k: (_r6(out["cpu_baseline"][k]) if not isinstance(out["cpu_baseline"][k], str)
+                                    else _clip(out["cpu_baseline"][k], 200)) for k in LINE_CPU_KEYS if k in out["cpu_baseline"]}
+    if "dist_selftest" in out:
+        line["dist_selftest"] = {k: _r6(v) for k, v in out["dist_selftest"].items() if not isinstance(v, (dict, list, str))}
+    if detail_path:
+        line["detail"] = detail_path
+    if "summary" in out:                                    # LAST (the driver records the tail): flat numbers only
+        line["summary"] = {k: _r6(v) for k, v in out["summary"].items() if isinstance(v, (int, float)) or v is None}
+    text = json.dumps(line)
+    if len(text) >= LINE_LIMIT:                             # shed the optional parts before giving up
+        for k in ("summary", "dist_selftest"):
+            line.pop(k, None)
+            text = json.dumps(line)
+            if len(text) < LINE_LIMIT:
+                break
+    if len(text) >= LINE_LIMIT:
+        raise RuntimeError(f"bench.py: the stdout line is {len(text)} bytes (limit {LINE_LIMIT})")
+    return text
+
+
+def emit(out: dict, json_fd: int, detail_path=None):
+    """Full report -> the detail file (best effort: an unwritable path must not cost the line); short line -> stdout."""
+    written = None
+    if detail_path:
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(detail_path)), exist_ok=True)
+            with open(detail_path, "w") as f:
+                json.dump(out, f, indent=1)
+            written = detail_path
+        except OSError as e:
+            sys.stderr.write(f"bench.py: detail file {detail_path} not written: {e}\n")
+    os.write(json_fd, (short_line(out, written) + "\n").encode())
+
+
+
 def dry_launch(args, world, rank, json_fd):
     """The N-rank launch on CPU: gloo, the iteration's two collectives on host buffers of the real sizes, the bench's
     barrier / max-over-ranks timing; no kernels (value 0)."""
@@ -653,7 +734,7 @@ def dry_launch(args, world, rank, json_fd):
                           "rccl_ranks": dist.get_world_size(), "backend": "gloo",
                           "objects_per_rank": per_rank.tolist(), "collectives_per_step": 2,
                           "collectives_ok": bool(ok)}}
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        emit(out, json_fd, args.detail_out)        # (no detail file unless asked for: the dry launch has nothing more to say)
     dist.destroy_process_group()
     if os.environ.get("OBJNERF_BENCH_FAIL_RANK") == str(rank):     # test hook: a rank that fails after the run
         return 3
@@ -747,8 +828,8 @@ def main():
     if rank == 0:
         if world == 1 and default_line and not args.no_other_configs:
             out["other_configs"] = other_configs(args, dev)
-            for key, fn in (("native_frame", lambda: native_frame(dev)), ("native_frame_bf16", lambda: native_frame(dev, True)),
-                            ("share_curve", lambda: share_curve(args, dev, max(10, args.other_steps)))):
+            # (the emulated 1 / 2 / 4 / 8-rank share table is NOT part of the default run: --share-curve-out)
+            for key, fn in (("native_frame", lambda: native_frame(dev)), ("native_frame_bf16", lambda: native_frame(dev, True))):
                 try:
                     out["other_configs"][key] = fn()
                 except Exception as e:
@@ -773,8 +854,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(feat)
         # what the line's figures mean has changed before (round 4: psnr_delta_db became the 300-iteration ensemble figure,
         # kernel_ms moved inside the timed steps); versioned since round 5, whose changes are listed here
-        out["metric_version"] = 5
-        out["metric_changes"] = ("v5: objnerf_train_step applies AdamW in its last launch, so roofline.kernel_ms (HIP events "
+        out["metric_version"] = 6
+        out["metric_changes"] = ("v6: stdout carries a fixed short line (< 4 KB: contract keys, flat roofline / cpu_baseline / "
+                                 "summary); this full report is the --detail-out file; the emulated share table left the "
+                                 "default run (--share-curve-out).  v5: objnerf_train_step applies AdamW in its last launch, so roofline.kernel_ms (HIP events "
                                  "around objnerf_train_step, inside the timed steps) now includes the optimiser; the "
                                  "background chain of step i may run under the object kernel of step i + 1 (--no-pipeline "
                                  "restores the per-step join); algorithmic_bytes_per_launch of the feature configs is the "
@@ -808,7 +891,7 @@ def main():
             summ["cpu_baseline_rays_per_s"] = out["cpu_baseline"]["value"]
         out["summary"] = summ
         sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        emit(out, json_fd, args.detail_out or os.path.join(ROOT, "gpurun_out", "bench_detail.json"))
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

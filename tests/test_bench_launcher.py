@@ -63,3 +63,52 @@ def test_a_rank_that_dies_before_the_rendezvous_ends_the_launch_quickly():
     r = _run("--gpus", "2", "--dry-launch", "--steps", "1", env={"OBJNERF_BENCH_DIE_EARLY": "1"})
     assert r.returncode != 0 and r.stdout.strip() == "" and ", 4]" in r.stderr
     assert time.time() - t0 < 90
+
+
+def test_line_is_short():
+    """The driver parses ONE stdout line; round 5's had grown to 20.8 KB and was not parsed (BENCH_r05.parsed = null).
+    The line is a fixed flat selection: < 4096 bytes on the dry-launch path AND for a full default-run report (round 5's
+    recorded one, profiles/r05_bench_default_v2.json, fattened further), with `roofline` and `cpu_baseline` present."""
+    sys.path.insert(0, ROOT)
+    import bench
+    r = _run("--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-launch")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and len(lines[0]) < bench.LINE_LIMIT == 4096
+    with open(os.path.join(ROOT, "profiles", "r05_bench_default_v2.json")) as f:
+        full = json.load(f)
+    assert len(json.dumps(full)) > 4 * bench.LINE_LIMIT                  # the report that broke the parser
+    full["other_configs"]["more"] = [full["other_configs"]] * 3          # growth of the detail must not reach the line
+    full["config"]["workload"] = full["config"]["workload"] * 4
+    full["summary"]["a_nested_block"] = {"x": [1] * 1000}
+    line = bench.short_line(full, "gpurun_out/bench_detail.json")
+    assert len(line) < bench.LINE_LIMIT and "\n" not in line
+    out = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "detail"):
+        assert k in out, k
+    assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms",
+                                    "algorithmic_bytes_per_launch"}
+    assert set(out["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+    assert all(not isinstance(v, (dict, list)) for v in out["summary"].values())
+    assert abs(out["value"] / full["value"] - 1) < 1e-5 and out["steps"] == full["steps"]
+    # a summary that cannot fit is shed before the contract keys are
+    full["summary"] = {f"k{i}": float(i) for i in range(400)}
+    out = json.loads(bench.short_line(full, None))
+    assert "summary" not in out and "roofline" in out and "cpu_baseline" in out
+
+
+def test_detail_file_holds_the_full_report(tmp_path):
+    sys.path.insert(0, ROOT)
+    import bench
+    with open(os.path.join(ROOT, "profiles", "r05_bench_default_v2.json")) as f:
+        full = json.load(f)
+    rd, wr = os.pipe()
+    path = str(tmp_path / "sub" / "detail.json")
+    bench.emit(full, wr, path)
+    os.close(wr)
+    line = json.loads(os.read(rd, 1 << 16).decode())
+    os.close(rd)
+    assert line["detail"] == path
+    with open(path) as f:
+        assert json.load(f) == full
