@@ -2073,7 +2073,11 @@ int train_step(const objnerf_net* net, const objnerf_train_args* a_in, void* str
     const int rpw = S > 0 && S <= 64 ? sf_rays_per_wg(S, feat) : 0;
     const long nwg = rpw ? ((long)a->R + rpw - 1) / rpw : 0;
 #ifndef OBJ_NO_SMALL_FUSED
+    // (the per-workgroup partials are parked in workspace regions of n = R S rows per object: the d B partials, 63 floats
+    // per workgroup, in dhead (4 n floats) and the head partials, 4 H + 4 per workgroup, in d_emb (129 n) -- tiny batches
+    // such as R <= 3 with S = 4 do not fit and take the general path)
     if (H == FS_H && S >= 4 && S <= 64 && (long)K * nwg <= 1536 && !half_acts && K <= 65535 &&
+        nwg * 63 <= n * 4 && nwg * (4L * H + 4) <= n * 129 &&
         !(a->mode & OBJNERF_TRAIN_LAYERWISE && K > 8) && (!feat || (C % 4 == 0 && a->R >= 1)))
       return train_step_small(net, a, st, E, w, off, E.operands == 1, done);
 #endif
@@ -2452,7 +2456,7 @@ static int train_step_small(const objnerf_net* net, const objnerf_train_args* a,
   f.emb = w.emb; f.h1 = w.h1; f.h2 = w.h2; f.h3 = w.h3; f.h4 = w.h4; f.hc = w.hc;
   f.d_hc = w.dA; f.d_h4 = w.dB_; f.d_h3 = w.dC; f.d_h2 = w.dD; f.d_h1 = w.dE;
   // per-workgroup partials live in workspace regions this path does not use otherwise (d_emb: K n 129 floats, dhead:
-  // K n 4, loss_part: K R 4): nwg <= R and S >= 4 make them fit
+  // K n 4, loss_part: K R 4): objnerf_train_step's applicability test checked that they fit
   float* hp = w.d_emb;
   f.partA = hp; hp += (size_t)K * nwg * H;
   f.partW = hp; hp += (size_t)K * nwg * 3 * H;

@@ -67,6 +67,7 @@ __global__ __launch_bounds__(256) void reduce_loss_kernel(int R, const float* lo
     const float m = zero ? 0.0f : red[0] / ((float)counts[k] + 1e-10f);
     out[k] = m;
     if (m > 100000.0f) atomicOr(status, 1);
+    if (!(fabsf(m) <= 3.0e38f)) atomicOr(status, 2);   // NaN / Inf: reported, not fatal
   }
 }
 

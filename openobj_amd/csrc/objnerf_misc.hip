@@ -382,7 +382,9 @@ __global__ void loss_total_kernel(int K, float* terms, float cs, float os, float
     int bad = 0;
     for (int k = 0; k < K; ++k) {
       const float d = terms[4 * k], c = terms[4 * k + 1], o = terms[4 * k + 2], f = terms[4 * k + 3];
-      if (d > 100000.f || c > 100000.f || o > 100000.f || f > 100000.f) bad = 1;
+      if (d > 100000.f || c > 100000.f || o > 100000.f || f > 100000.f) bad |= 1;        // render_rays.py:109-111
+      if (!(fabsf(d) <= 3.0e38f && fabsf(c) <= 3.0e38f && fabsf(o) <= 3.0e38f && fabsf(f) <= 3.0e38f))
+        bad |= 2;   // NaN / Inf: reported, NOT fatal (the reference's `> 100000` is false for NaN and it carries on)
       t += d + c * cs + o * os + f * fs;
     }
     if (total) *total = t;

@@ -3,7 +3,7 @@ and pred_partfeat like the reference's autograd graph (var detached, early retur
 import torch
 
 from . import ops
-from .render_rays import LossExplode
+from .render_rays import LossExplode, check_status  # noqa: F401
 
 
 class _StepBatchLoss(torch.autograd.Function):
@@ -12,8 +12,7 @@ class _StepBatchLoss(torch.autograd.Function):
         out = ops.step_batch_loss(alpha.squeeze(-1).contiguous(), color, gt_depth, gt_color, sem_labels, z_vals,
                                   color_scaling=cs, opacity_scaling=os_, feat_scaling=fs, gt_feat=gt_partfeat,
                                   pred_feat=pred_partfeat, want_grads=True)
-        if int(out["status"].item()) != 0:
-            raise LossExplode("loss explode")       # render_rays.py:109-111 prints and exit(-1)s
+        check_status(out["status"])                 # render_rays.py:109-111 prints and exit(-1)s (bit 0 only)
         ctx.save_for_backward(out["d_alpha"], out["d_color"],
                               out["d_pred_feat"] if out["d_pred_feat"] is not None else torch.empty(0))
         ctx.alpha_shape = alpha.shape

@@ -291,9 +291,8 @@ class IncrementalMapper:
             status = torch.maximum(status, self.bg_loop.ws.status)
         if sharded:
             odist.allreduce_max_(status, self.group)
-        if int(status.item()) != 0:
-            from .render_rays import LossExplode
-            raise LossExplode("loss explode")
+        from .render_rays import check_status
+        check_status(status)                     # bit 0 raises LossExplode; a non-finite term only warns (as the reference)
         if self.loop is not None:
             self.loop.copy_back()
         return out

@@ -447,15 +447,19 @@ class TrainWorkspace:
         if (self.k_chunk < K and dev.type == "cuda" and arena.net.hidden == 256 and precision_bits(precision) in (1, 4)
                 and not (layerwise and precision_bits(precision) != 4) and S in (32, 64, 128)
                 and os.environ.get("OBJNERF_ONE_LANE", "0") != "1"):
-            free, _total = torch.cuda.mem_get_info(dev)
-            if free > self.nbytes + (8 << 30):
+            # k_chunk was sized for ONE buffer of up to `budget` bytes: the second one is taken only where it leaves a quarter
+            # of the device (and at least 16 GiB) free for what comes after this workspace -- sample pools, render buffers,
+            # keyframe stores -- instead of "8 GiB above the buffer" (round 5: ~128 GiB of workspace with 8 GiB of slack)
+            free, total = torch.cuda.mem_get_info(dev)
+            if free - self.nbytes > max(total // 4, 16 << 30):
                 self.buf2 = torch.empty(self.nbytes, dtype=torch.uint8, device=dev)
                 # TWO side streams created back to back (the caller's stream only hands over and collects): streams are dealt
                 # to a few hardware queues round-robin in creation order, and two streams that share a queue run their kernels
                 # back to back -- a single side stream overlapped with the caller's stream in a fresh process and not in one
                 # that had created a dozen streams before; a high-priority side stream the other way round (tools/lanes_ab.sh)
-                self.sides = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
-                self.ev_in, self.ev_out = torch.cuda.Event(), [torch.cuda.Event(), torch.cuda.Event()]
+                with torch.cuda.device(dev):        # (events belong to the device current at their creation)
+                    self.sides = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+                    self.ev_in, self.ev_out = torch.cuda.Event(), [torch.cuda.Event(), torch.cuda.Event()]
                 self.lanes = 2
         self.grads = torch.zeros_like(arena.params)
         self.loss_terms = torch.zeros(K, 4, device=dev)
@@ -558,7 +562,7 @@ def train_step(arena: ParamArena, ws: TrainWorkspace, batch: Dict[str, torch.Ten
     sl = lambda t, k0, k1: None if t is None else t[k0:k1]           # noqa: E731
     two = getattr(ws, "lanes", 1) == 2 and relu_masks is None and emb_debug is None
     if two:                             # (even / odd chunks on the two side streams, each with its buffer, behind this stream)
-        main = torch.cuda.current_stream()
+        main = torch.cuda.current_stream(z.device)
         ws.ev_in.record(main)
         for sd in ws.sides:
             sd.wait_event(ws.ev_in)

@@ -206,8 +206,8 @@ class EnsembleRun:
             opt.step(ws.grads, mask, flags=ws.flags)
             if it + 1 == s["early"]:
                 early = self._evaluate(arena, n)
-        if int(ws.status.item()) != 0:
-            raise RuntimeError("loss explode in the PSNR scene")
+        if int(ws.status.item()) != 0:              # (here a non-finite term is fatal too: a NaN model has no PSNR)
+            raise RuntimeError("loss explode / non-finite loss in the PSNR scene")
         final = self._evaluate(arena, n)
         out = {"psnr50": early["psnr"], "psnr300": final["psnr"]}
         if self.with_feat:

@@ -55,6 +55,24 @@ class LossExplode(RuntimeError):
     """The reference prints 'loss explode' and exit(-1)s (render_rays.py:109-111)."""
 
 
+STATUS_EXPLODE = 1       # a loss term above 1e5: the reference's test (render_rays.py:109-111) -> LossExplode
+STATUS_NONFINITE = 2     # a NaN / Inf loss term: `nan > 100000` is False, the reference carries on -> a warning, once
+
+
+def check_status(status) -> int:
+    """The ONE contract for the kernels' status word, whichever path wrote it (fused hidden-32, small-batch, layer-wise,
+    hidden-256, objnerf_reduce_batch_loss): bit 0 raises LossExplode where the reference exits; bit 1 (a non-finite
+    term) is surfaced as a RuntimeWarning and the run carries on, as the reference does.  Returns the word."""
+    s = int(status.item()) if hasattr(status, "item") else int(status)
+    if s & STATUS_EXPLODE:
+        raise LossExplode("loss explode")
+    if s & STATUS_NONFINITE:
+        import warnings
+        warnings.warn("objnerf: a loss term is NaN / Inf; carrying on as the reference does (render_rays.py:109-111 "
+                      "tests only `> 100000`)", RuntimeWarning, stacklevel=2)
+    return s
+
+
 def reduce_batch_loss(loss_mat, var=None, avg=True, mask=None, loss_type="L1"):
     """Masked, optionally information-weighted reduction of a [K, R] loss matrix to one value per object
     (reference render_rays.py:85-117) on objnerf_reduce_batch_loss: if ANY object's mask is empty the result is zero
@@ -62,8 +80,8 @@ def reduce_batch_loss(loss_mat, var=None, avg=True, mask=None, loss_type="L1"):
     if mask is None:
         raise ValueError("reduce_batch_loss needs a mask (the reference sums it unconditionally, render_rays.py:88)")
     out, status = ops.reduce_batch_loss(loss_mat, var, mask, l2=(loss_type == "L2"), avg=bool(avg))
-    if avg and int(status.item()) != 0:
-        raise LossExplode("loss explode")
+    if avg:
+        check_status(status)
     return out
 
 

@@ -9,7 +9,7 @@ import torch
 
 from . import dist as odist
 from . import ops, optim
-from .render_rays import LossExplode
+from .render_rays import LossExplode, check_status as _check_status  # noqa: F401
 
 
 class BackgroundLoop:
@@ -331,8 +331,8 @@ class HipTrainLoop:
             sl = slice(it * npo, (it + 1) * npo)
             batch = {k: v[:, sl].contiguous() for k, v in pool.items()}
             out.append(self.step(batch).clone())
-        if check_status and int(self.ws.status.item()) != 0:
-            raise LossExplode("loss explode")
+        if check_status:
+            _check_status(self.ws.status)
         return out
 
     def copy_back(self):

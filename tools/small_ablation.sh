@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/../openobj_amd/csrc"
 mkdir -p abl
 make -s
-OBJS="objnerf_train.o objnerf_train32.o objnerf_train_bf16.o objnerf_train_bf16v2.o objnerf_train_bf16v2f.o objnerf_misc.o objnerf_helpers.o objnerf_train256.o objnerf_render.o objnerf_render_bf16.o"
+OBJS=$(ls *.o | grep -v '^objnerf_generic\.o$' | tr '\n' ' ')      # every unit of the Makefile but the one rebuilt below
 for v in "$@"; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -Wno-unused-function -DSM_ABL=$v -c objnerf_generic.hip -o abl/generic_sm$v.o &
 done
