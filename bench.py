@@ -691,6 +691,36 @@ def emit(out: dict, json_fd: int, detail_path=None):
 
 
 
+def collective_times(dev, dist, n=50):
+    """The iteration's two collectives ALONE, on the device, every rank together (RCCL; a single rank under
+    OBJNERF_DIST_SELFTEST=1 measures the backend's fixed cost per call): collective 1 = the pre-step int32[4] SUM,
+    collective 2 = the replicated background network's gradient, fp32 SUM of 182 339 + 4 floats (729 KB).  ms per call,
+    HIP events around `n` back-to-back calls after 5 warm-up calls; max over ranks.  The step hides collective 2 under
+    the object kernel (openobj_amd.train.ShardedIteration): these are the numbers that claim is to be checked against."""
+    import torch
+    from openobj_amd import dist as odist
+    pre = torch.zeros(4, dtype=torch.int32, device=dev)
+    flat = torch.zeros(BG_GRAD_FLOATS, device=dev)
+    out = {}
+    for name, t in (("collective1_ms", pre), ("collective2_ms", flat)):
+        for _ in range(5):
+            odist.allreduce_sum_(t)
+        torch.cuda.synchronize()
+        dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            odist.allreduce_sum_(t)
+        e1.record()
+        torch.cuda.synchronize()
+        tt = torch.tensor([e0.elapsed_time(e1) / n], device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        out[name] = float(tt.item())
+    out["collective2_bytes"] = BG_GRAD_FLOATS * 4
+    out["ranks"] = dist.get_world_size()
+    return out
+
+
 def dry_launch(args, world, rank, json_fd):
     """The N-rank launch on CPU: gloo, the iteration's two collectives on host buffers of the real sizes, the bench's
     barrier / max-over-ranks timing; no kernels (value 0)."""
@@ -792,11 +822,13 @@ def main():
     if not mode and args.bf16_line:
         bf16_extra = w.timed(True, args.steps, args.warmup, dist if use_dist else None)
     per_rank = [w.K]
+    coll = None
     if use_dist:
         pr = torch.zeros(world, dtype=torch.int64, device=dev)
         pr[rank] = w.K
         dist.all_reduce(pr)
         per_rank = pr.tolist()
+        coll = collective_times(dev, dist)
 
     if rank == 0:
         rays_per_step = w.rays_per_step()
@@ -816,6 +848,8 @@ def main():
             "rays_per_sec_per_gpu": value / world,
             "roofline": w.roofline(mode, kern_ms, with_peak=not args.no_peak),
         }
+        if coll is not None:
+            out["dist_selftest"] = coll
         if bf16_extra is not None:
             bdt, bk = bf16_extra
             out["bf16_mode"] = {"value": rays_per_step * args.steps / bdt, "unit": "rays/s",

@@ -132,7 +132,11 @@ __device__ __forceinline__ void stage_weights32(float* lds, const float* __restr
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // acc(32 outputs) += W[:, features of tile (row0 .. row0 + 15)] * xt     (xt: one 16-feature tile in K-order)
+#ifndef OBJ32_ABL
+#define OBJ32_ABL 0          // objnerf_train32.hip: ceiling-measurement builds only
+#endif
 __device__ __forceinline__ void mma_f16(T32& acc, const float* wf, const int row0, const f32x4& xt) {
+  if ((OBJ32_ABL) & 64) { asm volatile("" :: "v"(xt)); return; }
   f32x2 a[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) a[r] = *reinterpret_cast<const f32x2*>(wf + (row0 + r) * WROW);
@@ -150,6 +154,7 @@ __device__ __forceinline__ void mma_f32(T32& acc, const float* wf, const int row
 // wt0 = lds + c * WROW + 8 g + 4 (g & 1), wt1 = lds + c * WROW + 8 g + 4 (1 - (g & 1)): after the rotation of out_pos
 // both lane-group parities find the pairs r = 0, 1 at wt0 and r = 2, 3 at wt1
 __device__ __forceinline__ void mma_t16(f32x4& acc, const float* wt0, const float* wt1, const int row0, const T32& d) {
+  if ((OBJ32_ABL) & 64) { asm volatile("" :: "v"(d.t[0]), "v"(d.t[1])); return; }
   const f32x4 lo = *reinterpret_cast<const f32x4*>(wt0 + row0 * WROW);    // (r0 t0, r0 t1, r1 t0, r1 t1)
   const f32x4 hi = *reinterpret_cast<const f32x4*>(wt1 + row0 * WROW);    // (r2 t0, r2 t1, r3 t0, r3 t1)
   f32x4 acc2 = zero4();
@@ -236,8 +241,11 @@ __device__ __forceinline__ void pe32_octaves(const float vh, const float vl, flo
 #else
       const float w = fmaf(vl, sc, r);
 #endif
+      if ((OBJ32_ABL) & 16) { sn = w; cn = w * 0.5f; }
+      else {
       sn = __builtin_amdgcn_sinf(w);
       if (need_cos) cn = __builtin_amdgcn_cosf(w);
+      }
     } else {
       const float t2 = sp + sp;
       sn = t2 * cp;
@@ -270,6 +278,7 @@ __device__ __forceinline__ void pe32_x2_pair(const int i, const int g, const flo
 // backward of the x1 tile of slot i that also re-creates its forward values: returns the values, adds
 // sum_f d_x[f] * d sin / d proj to dps  (d arg / d proj = pi 2^f, embedding.py:49-52)
 __device__ __forceinline__ f32x4 pe32_x1_tile_fb(const Pe32& pe, const int i, const int g, const f32x4& dx, float& dps) {
+  if ((OBJ32_ABL) & 32) { dps += dx[0]; asm volatile("" : "+v"(dps)); return f32x4{pe.vh[i], pe.vl[i], pe.vh[i], pe.vl[i]}; }
   float s[6], c[6];
   pe32_octaves<0, 3, true>(pe.vh[i], pe.vl[i], s, c);
   float v = 0.f;
@@ -283,6 +292,7 @@ __device__ __forceinline__ f32x4 pe32_x1_tile_fb(const Pe32& pe, const int i, co
 // the same for the x2 pair of slot i (d_x4, d_x5: gradients of its octave-4 and octave-5 entries)
 __device__ __forceinline__ void pe32_x2_pair_fb(const Pe32& pe, const int i, const int g, const float dx4, const float dx5,
                                                 float& dps, float& v4, float& v5) {
+  if ((OBJ32_ABL) & 32) { dps += dx4 + dx5; asm volatile("" : "+v"(dps)); v4 = pe.vh[i]; v5 = pe.vl[i]; return; }
   float s[6], c[6];
   pe32_octaves<4, 5, true>(pe.vh[i], pe.vl[i], s, c);
   float v = fmaf(dx5, (c[5] * OBJ_PI_F) * 32.0f, dx4 * ((c[4] * OBJ_PI_F) * 16.0f));
@@ -297,6 +307,11 @@ struct Emb32 {
   f32x4 x2[3];     // x2[T][r] = entry t = 4 T + r = 2 (slot) + (octave - 4)
 };
 __device__ __forceinline__ void embed32(Emb32& e, const Pe32& pe, const int g) {
+  if ((OBJ32_ABL) & 32) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { e.x1[i] = f32x4{pe.vh[i], pe.vl[i], pe.vh[i], pe.vl[i]}; e.x2[i >> 1][2 * (i & 1)] = pe.vh[i]; e.x2[i >> 1][2 * (i & 1) + 1] = pe.vl[i]; }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     float s[6], c[6];

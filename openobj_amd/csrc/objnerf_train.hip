@@ -813,6 +813,7 @@ __global__ __launch_bounds__(NTHR) void train_fused_kernel(const TrainDev a) {
 // WRITES the status word (bit 0: a term above 1e5, render_rays.py:109-111; bit 1: a term that is not finite).
 // flat_nwg > 0 (objnerf_train_common.h): object k's partial slabs are those of the workgroups whose share touches it,
 // slot 0 .. cnt - 1 of its Gs
+constexpr int XCOLS = 33;      // [fh (32) | O]: the columns of the 512-d head's per-ray records and moments
 struct FinalizeArgs {
   const float* slab; const float* loss_part;
   int K, G; long P, slab_stride, p_stride;
@@ -824,13 +825,24 @@ struct FinalizeArgs {
   long lo1, lo2, hi2;
   double lr, b1, b2, wd; float eps;
   const int* counts_in; int* flags_out;      // OBJNERF_TRAIN_SELF_COUNTS: derive the flags from counts [K][2], publish them
+  // the 512-d head's gradient, folded in (round 6; feat_finish_kernel's arithmetic, element for element): Tpart
+  // [K][Gfin][C][33], Mpart [K][Gfin][33][33] of feat_post_kernel; NULL: the entries [ext_lo, ext_hi) of `grads` were
+  // written by an earlier launch.  head_w [K][C 32 + C]: feat_pre_kernel's copy of [W_of | b_of] from BEFORE the step (the
+  // head gradient of an entry reads a whole row of W_of and b_of, which other threads of this launch are stepping)
+  const float* Tpart; const float* Mpart; const float* head_w; int Gfin, C; long of_w, of_b;
 };
+// Round 6: FIN_EPT elements per thread (their slab loads are independent: FIN_EPT x G requests in flight instead of a
+// chain of G latencies per thread), so an object is ~30 workgroups instead of 120 and the whole grid is resident at once
+// -- the double-precision pow() preamble of the optimiser (a few microseconds of one thread, ahead of the block's
+// barrier) is paid ONCE, in parallel, instead of once per round of the chip (118 -> ~35 us at 50 objects).
+constexpr int FIN_EPT = 4;
 __global__ __launch_bounds__(256) void finalize_kernel(const FinalizeArgs a) {
   const int k = blockIdx.y;
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long i0 = (long)blockIdx.x * (256 * FIN_EPT) + threadIdx.x;
   __shared__ float s_step_size[3], s_bc2_sqrt[3];
   __shared__ int s_active[3];
   __shared__ int s_bad;
+  __shared__ float s_M[XCOLS * XCOLS];
   const bool first = blockIdx.x == 0 && blockIdx.y == 0;
   if (a.counts_in && first && threadIdx.x == 64) {     // derived flags: published for the host / later launches
     int e0 = 0, e1 = 0;
@@ -855,31 +867,83 @@ __global__ __launch_bounds__(256) void finalize_kernel(const FinalizeArgs a) {
     if (first) a.steps[3 * (1 - a.bank) + g] = old + (s_active[g] ? 1 : 0);
   }
   if (first && threadIdx.x == 0) s_bad = 0;
-  if (a.params || first) __syncthreads();
+  // the head's moments (workgroups that hold entries of [ext_lo, ext_hi) only): M = sum of the chunks' partials, in chunk order
+  const long blk_lo = (long)blockIdx.x * (256 * FIN_EPT), blk_hi = blk_lo + 256 * FIN_EPT;
+  const bool head_blk = a.Tpart && blk_lo < a.ext_hi && blk_hi > a.ext_lo;
+  if (head_blk)
+    for (int e = threadIdx.x; e < XCOLS * XCOLS; e += 256) {
+      float v = 0.f;
+      for (int g = 0; g < a.Gfin; ++g) v += a.Mpart[((long)k * a.Gfin + g) * XCOLS * XCOLS + e];
+      s_M[e] = v;
+    }
+  if (a.params || first || head_blk) __syncthreads();
   int G = a.G;
   if (a.flat_nwg) {
     const long T = (long)a.K * a.NT;
     G = flat_wg_of(T, a.flat_nwg, (long)(k + 1) * a.NT - 1) - flat_wg_of(T, a.flat_nwg, (long)k * a.NT) + 1;
   }
   const int stride = a.flat_nwg ? a.Gs : a.G;
-  if (i < a.P && !(i >= a.ng_lo && i < a.ng_hi)) {
+  float s[FIN_EPT];
+  bool live[FIN_EPT], slabbed[FIN_EPT];
+#pragma unroll
+  for (int e = 0; e < FIN_EPT; ++e) {
+    const long i = i0 + 256 * e;
+    live[e] = i < a.P && !(i >= a.ng_lo && i < a.ng_hi);
+    slabbed[e] = live[e] && !(i >= a.ext_lo && i < a.ext_hi);
+    s[e] = 0.f;
+  }
+  const float* sl0 = a.slab + (long)k * stride * a.slab_stride + i0;
+  for (int g = 0; g < G; ++g) {               // (slab order: one association for every run)
+    float t[FIN_EPT];
+#pragma unroll
+    for (int e = 0; e < FIN_EPT; ++e) t[e] = slabbed[e] ? sl0[(long)g * a.slab_stride + 256 * e] : 0.f;
+#pragma unroll
+    for (int e = 0; e < FIN_EPT; ++e) s[e] += t[e];
+  }
+#pragma unroll
+  for (int e = 0; e < FIN_EPT; ++e) {
+    const long i = i0 + 256 * e;
+    if (!live[e]) continue;
     const long idx = (long)k * a.p_stride + i;
-    float s;
-    if (i >= a.ext_lo && i < a.ext_hi) {
-      s = a.grads[idx];
-    } else {
-      s = 0.f;
-      for (int g = 0; g < G; ++g) s += a.slab[((long)k * stride + g) * a.slab_stride + i];
-      a.grads[idx] = s;
+    float sv_ = s[e];
+    if (!slabbed[e]) {
+      if (a.Tpart) {
+        // d W_of[c][h] = T[c][h] + sum_j W_of[c][j] M2[j][h] + b_of[c] m1[h];  d b_of[c] = T[c][32] + W_of[c] . m1 + b_of[c] s2
+        const bool is_b = i >= a.of_b;
+        const int cc = is_b ? (int)(i - a.of_b) : (int)((i - a.of_w) >> 5), hh = is_b ? 32 : (int)((i - a.of_w) & 31);
+        const float* hw = a.head_w + (long)k * ((long)a.C * 33);
+        const float* W = hw + cc * 32;
+        const float bc = hw[a.C * 32 + cc];
+        float v = 0.f;
+        for (int g = 0; g < a.Gfin; ++g) v += a.Tpart[((long)k * a.Gfin + g) * a.C * XCOLS + cc * XCOLS + hh];
+        if (!is_b) {
+          for (int j = 0; j < 32; ++j) v = fmaf(W[j], s_M[j * XCOLS + hh], v);
+          sv_ = fmaf(bc, s_M[32 * XCOLS + hh], v);
+        } else {
+          for (int j = 0; j < 32; ++j) v = fmaf(W[j], s_M[32 * XCOLS + j], v);
+          sv_ = fmaf(bc, s_M[32 * XCOLS + 32], v);
+        }
+      } else {
+        sv_ = a.grads[idx];
+      }
     }
+    s[e] = sv_;
+  }
+#pragma unroll
+  for (int e = 0; e < FIN_EPT; ++e) {
+    const long i = i0 + 256 * e;
+    if (!live[e]) continue;
+    const long idx = (long)k * a.p_stride + i;
+    const float sv_ = s[e];
+    if (slabbed[e] || a.Tpart) a.grads[idx] = sv_;
     if (a.params) {
       const int g = (i >= a.lo1 && i < a.lo2) ? 1 : ((i >= a.lo2 && i < a.hi2) ? 2 : 0);
       if (s_active[g]) {
         const float decay = (float)(1.0 - a.lr * a.wd), w1 = (float)(1.0 - a.b1), w2 = (float)(1.0 - a.b2), beta2 = (float)a.b2;
         float p = a.params[idx] * decay;
         const float mo = a.m[idx];
-        const float mn = mo + w1 * (s - mo);
-        const float vn = a.v[idx] * beta2 + (w2 * s) * s;
+        const float mn = mo + w1 * (sv_ - mo);
+        const float vn = a.v[idx] * beta2 + (w2 * sv_) * sv_;
         const float denom = sqrtf(vn) / s_bc2_sqrt[g] + a.eps;
         p = p + (-s_step_size[g]) * (mn / denom);
         a.params[idx] = p;
@@ -983,31 +1047,70 @@ __global__ __launch_bounds__(256) void feat_rowstats_kernel(const float* params,
 }
 // The same three quantities in ONE pass over gt_feat (round 3): rayin[r] = [u (32) | beta | |g|] with u = W_of^T g[r],
 // beta = b_of . g[r].  A workgroup of 8 waves takes 128 rays; [W_of | b_of] sits in LDS as the B operand of
-// v_mfma_f32_16x16x4_f32 (three 16-column tiles: u, u, beta + padding); a lane streams ITS ray's features as float4 --
+// v_mfma_f32_16x16x4_f32 (two 16-column tiles of u; beta and |g|^2 on the VALU); a lane streams ITS ray's features as float4 --
 // k-step j of block s uses feature 16 s + 4 q + j, a permutation of the contraction both operands share -- and squares
 // them on the way for |g|.  gt_feat is read once instead of twice (GEMM + feat_rowstats_kernel: 240 + 101 us at
 // K = 50, R = 4096 -> ~100 us).  C <= 512, C % 16 == 0.
 constexpr int FEAT_PRE_MAXC = 512;
-__global__ __launch_bounds__(512) void feat_pre_kernel(const float* __restrict__ params, long p_stride, int off_w, int off_b,
+__global__ __launch_bounds__(512, 4) void feat_pre_kernel(const float* __restrict__ params, long p_stride, int off_w, int off_b,
                                                        int C, int R, const float* __restrict__ gt_feat,
-                                                       float* __restrict__ rayin) {
-  extern __shared__ __attribute__((aligned(16))) float fp_lds[];       // [C / 16][3][64][4]
+                                                       float* __restrict__ rayin, float* __restrict__ gram,
+                                                       float* __restrict__ head_snap) {
+  extern __shared__ __attribute__((aligned(16))) float fp_lds[];       // W image [C / 16][2][64][4] | b_of [C]
   const int k = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int n = lane & 15, q = lane >> 4;
   const float* W = params + (long)k * p_stride + off_w;
   const float* Bv = params + (long)k * p_stride + off_b;
   const int nblk = C / 16;
   // B image: W_of row-major [c][h] read coalesced, scattered into (block c >> 4, tile h >> 4, lane (h & 15) + 16 ((c >> 2) & 3),
-  // element c & 3); tile 2 = [b_of | 0 ...]
+  // element c & 3).  Round 6: beta = b_of . g runs on the VALU beside |g|^2 (4 FMAs per float4 instead of the four MFMAs
+  // of a third, 15/16 empty column tile: a third of the kernel's matrix-core time), b_of is a plain vector behind the
+  // image, and the 66 KB of LDS let TWO workgroups share a compute unit.
+  float* fp_b = fp_lds + nblk * 2 * 64 * 4;
   for (int i = tid; i < C * 32; i += 512) {
     const int c = i >> 5, hc = i & 31;
-    fp_lds[(((c >> 4) * 3 + (hc >> 4)) * 64 + (hc & 15) + 16 * ((c >> 2) & 3)) * 4 + (c & 3)] = W[i];
+    fp_lds[(((c >> 4) * 2 + (hc >> 4)) * 64 + (hc & 15) + 16 * ((c >> 2) & 3)) * 4 + (c & 3)] = W[i];
   }
-  for (int i = tid; i < C * 16; i += 512) {
-    const int c = i >> 4, nn = i & 15;
-    fp_lds[(((c >> 4) * 3 + 2) * 64 + nn + 16 * ((c >> 2) & 3)) * 4 + (c & 3)] = nn == 0 ? Bv[c] : 0.0f;
-  }
+  for (int i = tid; i < C; i += 512) fp_b[i] = Bv[i];
   __syncthreads();
+  if (blockIdx.x == 0) {
+    // Round 6: the object's first workgroup also forms what used to be two launches ahead of this one (a batched GEMM +
+    // featg_wb_kernel) -- G = W_of^T W_of, wb = W_of^T b_of, bb = b_of . b_of for the hoisted head, from
+    // the image just staged -- and a copy of [W_of | b_of] as they are BEFORE the step: finalize_kernel forms the head's
+    // gradient from it while the optimiser in the same launch is already writing the parameters.
+    auto lw = [&](const int c, const int h) {
+      return fp_lds[(((c >> 4) * 2 + (h >> 4)) * 64 + (h & 15) + 16 * ((c >> 2) & 3)) * 4 + (c & 3)];
+    };
+    auto lb = [&](const int c) { return fp_b[c]; };
+    if (gram)
+      for (int o = tid; o < 32 * 32 + 33; o += 512) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        if (o < 1024) {
+          const int h1 = o >> 5, h2 = o & 31;
+          for (int c = 0; c < C; c += 4) {
+            s0 = fmaf(lw(c, h1), lw(c, h2), s0); s1 = fmaf(lw(c + 1, h1), lw(c + 1, h2), s1);
+            s2 = fmaf(lw(c + 2, h1), lw(c + 2, h2), s2); s3 = fmaf(lw(c + 3, h1), lw(c + 3, h2), s3);
+          }
+        } else if (o < 1056) {
+          const int h = o - 1024;
+          for (int c = 0; c < C; c += 4) {
+            s0 = fmaf(lw(c, h), lb(c), s0); s1 = fmaf(lw(c + 1, h), lb(c + 1), s1);
+            s2 = fmaf(lw(c + 2, h), lb(c + 2), s2); s3 = fmaf(lw(c + 3, h), lb(c + 3), s3);
+          }
+        } else {
+          for (int c = 0; c < C; c += 4) {
+            s0 = fmaf(lb(c), lb(c), s0); s1 = fmaf(lb(c + 1), lb(c + 1), s1);
+            s2 = fmaf(lb(c + 2), lb(c + 2), s2); s3 = fmaf(lb(c + 3), lb(c + 3), s3);
+          }
+        }
+        gram[(long)k * GRAM + o] = (s0 + s1) + (s2 + s3);
+      }
+    if (head_snap) {
+      float* hs = head_snap + (long)k * ((long)C * 33);
+      for (int i = tid; i < C * 32; i += 512) hs[i] = W[i];
+      for (int i = tid; i < C; i += 512) hs[C * 32 + i] = Bv[i];
+    }
+  }
   const f32x4* bl = reinterpret_cast<const f32x4*>(fp_lds) + lane;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   constexpr int PF = 8;                                                 // float4 loads in flight per lane: 8 blocks ahead
@@ -1015,8 +1118,8 @@ __global__ __launch_bounds__(512) void feat_pre_kernel(const float* __restrict__
     const long r = t0 + 16 * w + n;                                     // this lane's ray (as A row)
     const bool on = r < R;
     const float* gp = gt_feat + ((long)k * R + (on ? r : 0)) * C + 4 * q;
-    f32x4 acc0 = zero, acc1 = zero, acc2 = zero;
-    float gs = 0.f;
+    f32x4 acc0 = zero, acc1 = zero;
+    float gs = 0.f, bs = 0.f;
     f32x4 buf[PF];
 #pragma unroll
     for (int i = 0; i < PF; ++i) buf[i] = (on && i < nblk) ? *reinterpret_cast<const f32x4*>(gp + 16 * i) : zero;
@@ -1027,21 +1130,27 @@ __global__ __launch_bounds__(512) void feat_pre_kernel(const float* __restrict__
         const f32x4 av = buf[i];
         buf[i] = (on && sblk + PF < nblk) ? *reinterpret_cast<const f32x4*>(gp + 16 * (sblk + PF)) : zero;
         if (sblk < nblk) {
-          const f32x4 b0 = bl[(sblk * 3 + 0) * 64], b1 = bl[(sblk * 3 + 1) * 64], b2 = bl[(sblk * 3 + 2) * 64];
+          const f32x4 b0 = bl[(sblk * 2 + 0) * 64], b1 = bl[(sblk * 2 + 1) * 64];
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(fp_b + 16 * sblk + 4 * q);      // b_of of this lane's four features
           gs = fmaf(av[3], av[3], fmaf(av[2], av[2], fmaf(av[1], av[1], fmaf(av[0], av[0], gs))));
+          bs = fmaf(av[3], bv[3], fmaf(av[2], bv[2], fmaf(av[1], bv[1], fmaf(av[0], bv[0], bs))));
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], b0[j], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], b1[j], acc1, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], b2[j], acc2, 0, 0, 0);
           }
         }
       }
     }
-    // |g|^2: the four lanes (q) of a ray
+    // |g|^2 and beta: the four lanes (q) of a ray
     gs += __shfl_xor(gs, 16, 64);
     gs += __shfl_xor(gs, 32, 64);
-    if (on && q == 0) rayin[((long)k * R + r) * RAYIN + 33] = sqrtf(gs);
+    bs += __shfl_xor(bs, 16, 64);
+    bs += __shfl_xor(bs, 32, 64);
+    if (on && q == 0) {
+      rayin[((long)k * R + r) * RAYIN + 32] = bs;
+      rayin[((long)k * R + r) * RAYIN + 33] = sqrtf(gs);
+    }
     // D: lane (n, q) register rr = row 4 q + rr (ray), column n
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
@@ -1050,7 +1159,6 @@ __global__ __launch_bounds__(512) void feat_pre_kernel(const float* __restrict__
         float* o = rayin + ((long)k * R + ro) * RAYIN;
         o[n] = acc0[rr];
         o[16 + n] = acc1[rr];
-        if (n == 0) o[32] = acc2[rr];
       }
     }
   }
@@ -1059,7 +1167,6 @@ __global__ __launch_bounds__(512) void feat_pre_kernel(const float* __restrict__
 // F_r = W_of fh_r + b_of O_r, so  d W_of = gt_feat^T [a fh] + W_of M2 + b_of m1^T  and
 // d b_of = gt_feat^T [a O] + W_of m1 + b_of s2  with the moments  [M2 m1; . s2] = [c fh | c O]^T [fh | O].
 // This kernel writes the two row-scaled copies X1 = [a fh | a O], X2 = [c fh | c O]; two GEMMs do the sums.
-constexpr int XCOLS = 33;
 __global__ void feat_scale_kernel(long n, const float* rayfeat, float* X1, float* X2) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n * XCOLS) return;
@@ -1078,68 +1185,86 @@ __global__ void feat_scale_kernel(long n, const float* rayfeat, float* X1, float
 // T = gt_feat^T [a fh | a O].  The moments M = [c fh | c O]^T [fh | O] ride along: the B values of a lane are also its A
 // values (same lane index), each wave takes every eighth ray quad, the partial tiles meet in LDS.  Partials
 // Tpart [K][G][C][33], Mpart [K][G][33][33] are summed by feat_finish_kernel.  C == 512.
-__global__ __launch_bounds__(512) void feat_post_kernel(int C, int R, const float* __restrict__ gt_feat,
-                                                        const float* __restrict__ rayfeat, float* __restrict__ Tpart,
-                                                        float* __restrict__ Mpart) {
-  __shared__ float s_m[8][9][64][4];                   // per wave: 3 x 3 moment tiles as D fragments
+#ifndef FEAT_POST_PF
+#define FEAT_POST_PF 4
+#endif
+#ifndef FEAT_POST_PFF
+#define FEAT_POST_PFF 1
+#endif
+#ifndef FEAT_POST_WPE
+#define FEAT_POST_WPE 4          // waves per SIMD the register budget is set for (4 = two 512-thread workgroups per compute unit)
+#endif
+__global__ __launch_bounds__(512, FEAT_POST_WPE) void feat_post_kernel(int C, int R, const float* __restrict__ gt_feat,
+                                                           const float* __restrict__ rayfeat, float* __restrict__ Tpart,
+                                                           float* __restrict__ Mpart) {
+  // Round 6: the column of O (T[:, 32] = gt_feat^T [a O], M[32][:] = M[:][32] = sum c O fh, M[32][32] = sum c O^2) is
+  // formed on the VALU -- it used to be a third 16-column MFMA tile with one live column (4 of 12 MFMAs per ray quad, 5 of the
+  // 9 moment MFMAs): a third less matrix-core time, 34 KB of LDS instead of 74 (two workgroups per compute unit).
+  __shared__ float s_m[8][4][64][4];                   // per wave: the 2 x 2 fh x fh moment tiles as D fragments
+  __shared__ float s_o[8][36];                         // per wave: sum c O fh[0..31], sum c O^2
   const int k = blockIdx.y, g = blockIdx.x, G = gridDim.x;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int i = lane & 15, q = lane >> 4;
   const long r_lo = (long)R * g / G, r_hi = (long)R * (g + 1) / G;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  f32x4 acc[4][3], macc[3][3];
+  f32x4 acc[4][2], macc[2][2];
+  float t32[4] = {0.f, 0.f, 0.f, 0.f};                 // sum_r a_r O_r g_r[64 w + 4 i + j] over this lane's rays (q)
+  float mo0 = 0.f, mo1 = 0.f, moo = 0.f;               // sum c O fh[i], sum c O fh[16 + i], sum c O^2 (this wave's quads)
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < 4; ++j) acc[j][0] = acc[j][1] = zero;
 #pragma unroll
-    for (int t = 0; t < 3; ++t) acc[j][t] = zero;
-#pragma unroll
-  for (int a_ = 0; a_ < 3; ++a_)
-#pragma unroll
-    for (int b_ = 0; b_ < 3; ++b_) macc[a_][b_] = zero;
+  for (int a_ = 0; a_ < 2; ++a_) macc[a_][0] = macc[a_][1] = zero;
   const float* gbase = gt_feat + (long)k * R * C + 64 * w + 4 * i;
   const float* fbase = rayfeat + (long)k * R * RAYFEAT;
   const long nq = (r_hi - r_lo + 3) / 4;               // ray quads of this chunk
-  constexpr int PF = 6;
+  // in flight per lane: FEAT_POST_PF target-feature float4s (HBM) and FEAT_POST_PFF ray records (L2: the fused kernel has
+  // just written them) -- 128 registers per wave at two workgroups per compute unit leave room for ~28 of prefetch
+  constexpr int PF = FEAT_POST_PF, PFF = FEAT_POST_PFF;
+  static_assert(PF % PFF == 0, "the record ring is indexed statically inside the unrolled loop");
   f32x4 abuf[PF];
-  float fb[PF][5];                                     // fh[i], fh[16 + i], O, a, c of this lane's ray
-  auto fetch = [&](const long sq, f32x4& av, float (&f)[5]) {
+  float fb[PFF][5];                                    // fh[i], fh[16 + i], O, a, c of this lane's ray
+  auto fetch_g = [&](const long sq, f32x4& av) {
+    const long r = r_lo + 4 * sq + q;
+    av = (sq < nq && r < r_hi) ? *reinterpret_cast<const f32x4*>(gbase + r * C) : zero;
+  };
+  auto fetch_f = [&](const long sq, float (&f)[5]) {
     const long r = r_lo + 4 * sq + q;
     if (sq < nq && r < r_hi) {
-      av = *reinterpret_cast<const f32x4*>(gbase + r * C);
       const float* rf = fbase + r * RAYFEAT;
       f[0] = rf[i]; f[1] = rf[16 + i]; f[2] = rf[32]; f[3] = rf[33]; f[4] = rf[34];
     } else {
-      av = zero; f[0] = f[1] = f[2] = f[3] = f[4] = 0.f;
+      f[0] = f[1] = f[2] = f[3] = f[4] = 0.f;
     }
   };
 #pragma unroll
-  for (int p = 0; p < PF; ++p) fetch(p, abuf[p], fb[p]);
+  for (int p = 0; p < PF; ++p) fetch_g(p, abuf[p]);
+#pragma unroll
+  for (int p = 0; p < PFF; ++p) fetch_f(p, fb[p]);
   for (long s0 = 0; s0 < nq; s0 += PF) {
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
       const long sq = s0 + p;
       const f32x4 av = abuf[p];
-      const float f0 = fb[p][0], f1 = fb[p][1], f2 = i == 0 ? fb[p][2] : 0.0f, ar = fb[p][3], cr = fb[p][4];
-      fetch(sq + PF, abuf[p], fb[p]);
+      const float f0 = fb[p % PFF][0], f1 = fb[p % PFF][1], fo = fb[p % PFF][2], ar = fb[p % PFF][3], cr = fb[p % PFF][4];
+      fetch_g(sq + PF, abuf[p]);
+      fetch_f(sq + PFF, fb[p % PFF]);
       if (sq < nq) {
-        const float x0 = ar * f0, x1 = ar * f1, x2 = ar * f2;
+        const float x0 = ar * f0, x1 = ar * f1, xo = ar * fo;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], x0, acc[j][0], 0, 0, 0);
           acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], x1, acc[j][1], 0, 0, 0);
-          acc[j][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], x2, acc[j][2], 0, 0, 0);
+          t32[j] = fmaf(av[j], xo, t32[j]);
         }
         if ((int)(sq & 7) == w) {                      // (wave-uniform) this wave's share of the moments
-          const float y0 = cr * f0, y1 = cr * f1, y2 = cr * f2;
+          const float y0 = cr * f0, y1 = cr * f1, yo = cr * fo;
           macc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(y0, f0, macc[0][0], 0, 0, 0);
           macc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(y0, f1, macc[0][1], 0, 0, 0);
-          macc[0][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(y0, f2, macc[0][2], 0, 0, 0);
           macc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(y1, f0, macc[1][0], 0, 0, 0);
           macc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(y1, f1, macc[1][1], 0, 0, 0);
-          macc[1][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(y1, f2, macc[1][2], 0, 0, 0);
-          macc[2][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(y2, f0, macc[2][0], 0, 0, 0);
-          macc[2][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(y2, f1, macc[2][1], 0, 0, 0);
-          macc[2][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(y2, f2, macc[2][2], 0, 0, 0);
+          mo0 = fmaf(yo, f0, mo0);
+          mo1 = fmaf(yo, f1, mo1);
+          moo = fmaf(yo, fo, moo);
         }
       }
     }
@@ -1153,24 +1278,42 @@ __global__ __launch_bounds__(512) void feat_post_kernel(int C, int R, const floa
       float* row = Tp + (long)(64 * w + 4 * (4 * q + rr) + j) * XCOLS;
       row[i] = acc[j][0][rr];
       row[16 + i] = acc[j][1][rr];
-      if (i == 0) row[32] = acc[j][2][rr];
     }
-  // moments: sum the eight waves' partial tiles
+  // column 32: the four lanes (q) of a feature group meet
 #pragma unroll
-  for (int a_ = 0; a_ < 3; ++a_)
+  for (int j = 0; j < 4; ++j) {
+    float v = t32[j];
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    if (q == 0) Tp[(long)(64 * w + 4 * i + j) * XCOLS + 32] = v;
+  }
+  // moments: the O row per wave (lanes q of an entry meet), then the eight waves' partial tiles / rows in LDS
+  mo0 += __shfl_xor(mo0, 16, 64); mo0 += __shfl_xor(mo0, 32, 64);
+  mo1 += __shfl_xor(mo1, 16, 64); mo1 += __shfl_xor(mo1, 32, 64);
+  moo += __shfl_xor(moo, 16, 64); moo += __shfl_xor(moo, 32, 64);
+  if (q == 0) { s_o[w][i] = mo0; s_o[w][16 + i] = mo1; if (i == 0) s_o[w][32] = moo; }
 #pragma unroll
-    for (int b_ = 0; b_ < 3; ++b_)
+  for (int a_ = 0; a_ < 2; ++a_)
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) s_m[w][3 * a_ + b_][lane][rr] = macc[a_][b_][rr];
+    for (int b_ = 0; b_ < 2; ++b_)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) s_m[w][2 * a_ + b_][lane][rr] = macc[a_][b_][rr];
   __syncthreads();
   float* Mp = Mpart + ((long)k * G + g) * XCOLS * XCOLS;
-  for (int e = tid; e < 9 * 64 * 4; e += 512) {
+  for (int e = tid; e < 4 * 64 * 4; e += 512) {
     const int rr = e & 3, ln = (e >> 2) & 63, tile = e >> 8;
     float v = 0.f;
 #pragma unroll
     for (int ww = 0; ww < 8; ++ww) v += s_m[ww][tile][ln][rr];
-    const int m = 16 * (tile / 3) + 4 * (ln >> 4) + rr, nn = 16 * (tile % 3) + (ln & 15);
-    if (m < XCOLS && nn < XCOLS) Mp[m * XCOLS + nn] = v;
+    const int m = 16 * (tile >> 1) + 4 * (ln >> 4) + rr, nn = 16 * (tile & 1) + (ln & 15);
+    Mp[m * XCOLS + nn] = v;
+  }
+  if (tid < 33) {                                      // M is symmetric in its O row / column: sum_r c_r O_r fh_r[h]
+    float v = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < 8; ++ww) v += s_o[ww][tid];
+    Mp[32 * XCOLS + tid] = v;
+    if (tid < 32) Mp[tid * XCOLS + 32] = v;
   }
 }
 // d W_of[c][h] = T[c][h] + sum_j W_of[c][j] M2[j][h] + b_of[c] m1[h];  d b_of[c] = T[c][32] + W_of[c] . m1 + b_of[c] s2
@@ -1414,7 +1557,7 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
   ws += align256((size_t)a->K * Gmax * 4 * 4);
   uint8_t* has_grad = (uint8_t*)ws;
   ws += align256((size_t)ps) + 256;
-  float* rayin = nullptr; float* gram = nullptr; float* rayfeat = nullptr;
+  float* rayin = nullptr; float* gram = nullptr; float* rayfeat = nullptr; float* head_snap = nullptr;
   float *X1 = nullptr, *X2 = nullptr, *Tm = nullptr, *mom = nullptr, *parts_t = nullptr, *parts_m = nullptr;
   const int C = net->feat_dim;
   if (feat) {
@@ -1428,6 +1571,9 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
     ws += align256(((size_t)a->K * C * XCOLS + (size_t)a->K * XCOLS * XCOLS) * 4);
     parts_t = (float*)ws; ws += align256(objgen::wgrad_parts_floats(a->K, C, XCOLS, a->R) * 4);
     parts_m = (float*)ws;
+    // (the one-pass route does not use the split-K parts: the copy of [W_of | b_of] for finalize_kernel lives in their room,
+    // K C 33 floats of the K ceil(R / ..) C 33 + 64 that wgrad_parts_floats reserves)
+    head_snap = parts_t;
   }
   d.rayin = rayin; d.gram = gram; d.rayfeat = rayfeat;
   d.relu_masks = a->relu_masks;
@@ -1445,21 +1591,24 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
     (void)hipFuncSetAttribute((const void*)train_fused_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)((W_FLOATS_FEAT + SM_FLOATS + STG_ROWS * STG_LD) * 4));
   });
+  const float *fin_T = nullptr, *fin_M = nullptr;
+  int fin_G = 0;
   if (feat) {
-    objgen::feat_gram(stream, a->K, a->params, (long)a->p_stride, d.L.of_w, d.L.of_b, C, 32, gram, GRAM);
+    const bool pre_one = C <= FEAT_PRE_MAXC && C % 16 == 0;
+    if (!pre_one) objgen::feat_gram(stream, a->K, a->params, (long)a->p_stride, d.L.of_w, d.L.of_b, C, 32, gram, GRAM);
     // u = gt_feat W_of  ([R x C] [C x 32] per object) on the batched MFMA GEMM; beta, |g| beside it
-    if (C <= FEAT_PRE_MAXC && C % 16 == 0) {
+    if (pre_one) {
       // u, beta, |g| in one pass over gt_feat (feat_pre_kernel)
-      const size_t pre_lds = (size_t)(C / 16) * 3 * 64 * 4 * sizeof(float);
+      const size_t pre_lds = ((size_t)(C / 16) * 2 * 64 * 4 + C) * sizeof(float);
       objnerf_once_per_device([] {
         (void)hipFuncSetAttribute((const void*)feat_pre_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)((FEAT_PRE_MAXC / 16) * 3 * 64 * 4 * sizeof(float)));
+                                  (int)(((FEAT_PRE_MAXC / 16) * 2 * 64 * 4 + FEAT_PRE_MAXC) * sizeof(float)));
       });
-      int gpo = num_cu() / a->K;                  // workgroups per object: one round of the chip, each sweeping ray tiles
+      int gpo = 2 * num_cu() / a->K;              // workgroups per object: one round of the chip at two per compute unit
       if (gpo < 1) gpo = 1;
       if (gpo > (a->R + 127) / 128) gpo = (a->R + 127) / 128;
       hipLaunchKernelGGL(feat_pre_kernel, dim3(gpo, a->K), dim3(512), pre_lds, st, a->params, (long)a->p_stride,
-                         d.L.of_w, d.L.of_b, C, a->R, a->gt_feat, rayin);
+                         d.L.of_w, d.L.of_b, C, a->R, a->gt_feat, rayin, gram, head_snap);
     } else {
       objgen::gemm_f32(stream, a->K, a->R, 32, C, a->gt_feat, C, 1, (long)a->R * C, a->params + d.L.of_w, 32, 1,
                        (long)a->p_stride, rayin, RAYIN, 1, (long)a->R * RAYIN, false);
@@ -1477,7 +1626,7 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
     if (hipGetLastError() != hipSuccess) return OBJNERF_ELAUNCH;
     // 512-d head gradient from the per-ray (fh, O, a, c): two split-K GEMMs over the rays + a small finish
     const long nr = (long)a->K * a->R;
-    int gpo = num_cu() / a->K;                    // ray chunks per object: one round of the chip
+    int gpo = 2 * num_cu() / a->K;                // ray chunks per object: one round of the chip at two workgroups per compute unit
     if (gpo < 1) gpo = 1;
     if (gpo > 16) gpo = 16;
     // the partials live in the room of X1 AND X2 (adjacent in the workspace, both unused on this route): 2 K R XCOLS floats.
@@ -1502,8 +1651,12 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
                         (long)a->R * RAYFEAT, mom, XCOLS, (long)XCOLS * XCOLS, parts_m,
                         objgen::wgrad_parts_floats(a->K, XCOLS, XCOLS, a->R));
     }
-    hipLaunchKernelGGL(feat_finish_kernel, dim3((C * XCOLS + 255) / 256, a->K), dim3(256), 0, st, a->params,
-                       (long)a->p_stride, d.L.of_w, d.L.of_b, C, Tsrc, Msrc, a->grads, Gfin);
+    if (one_pass && pre_one) {      // finalize_kernel forms the head's gradient itself (round 6: one launch fewer)
+      fin_T = Tsrc; fin_M = Msrc; fin_G = Gfin;
+    } else {
+      hipLaunchKernelGGL(feat_finish_kernel, dim3((C * XCOLS + 255) / 256, a->K), dim3(256), 0, st, a->params,
+                         (long)a->p_stride, d.L.of_w, d.L.of_b, C, Tsrc, Msrc, a->grads, Gfin);
+    }
   } else if (bf16) {
     launch_train_bf16(d, stream, false);
   } else {
@@ -1512,7 +1665,7 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
   }
   if (hipGetLastError() != hipSuccess) return OBJNERF_ELAUNCH;
   const long P = offs[OBJNERF_N_TENSORS];
-  dim3 fg((unsigned)((P + 255) / 256), (unsigned)a->K);
+  dim3 fg((unsigned)((P + 256 * FIN_EPT - 1) / (256 * FIN_EPT)), (unsigned)a->K);
   FinalizeArgs fa;
   fa.slab = d.slab; fa.loss_part = d.loss_part; fa.K = a->K; fa.G = d.G; fa.P = P; fa.slab_stride = (long)ps;
   fa.p_stride = (long)a->p_stride;
@@ -1524,6 +1677,7 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
   fa.lo1 = offs[OBJNERF_T_CL_W]; fa.lo2 = offs[OBJNERF_T_FL_W]; fa.hi2 = offs[OBJNERF_T_PE_B];
   fa.lr = fa.b1 = fa.b2 = fa.wd = 0.0; fa.eps = 0.f;
   fa.counts_in = self_counts ? a->counts : nullptr; fa.flags_out = const_cast<int*>(a->flags);
+  fa.Tpart = fin_T; fa.Mpart = fin_M; fa.head_w = head_snap; fa.Gfin = fin_G; fa.C = C; fa.of_w = d.L.of_w; fa.of_b = d.L.of_b;
   if (a->optim) {
     const objnerf_adamw_args* o = a->optim;
     fa.params = const_cast<float*>(a->params); fa.m = o->exp_avg; fa.v = o->exp_avg_sq; fa.steps = o->group_steps;

@@ -19,15 +19,29 @@ using namespace objtrain;
 #define OBJ_LAZY_HEADS
 #endif
 
+// Ceiling measurements (tools/f32_ablation.sh -> profiles/r06_f32_ablation.txt): -DOBJ32_ABL=<bits> REMOVES parts of the
+// tile loop so that the kernel's time can be attributed.  Every such build computes wrong gradients by design and is
+// only ever built as a variant library (never by the Makefile, whose OBJ32_ABL is 0: all of this folds away).
+//   1  the compositing / loss pass (two of eight waves)      2  the tile loop's barriers
+//   4  the staging stores of the weight-gradient operands     8  the weight-gradient MFMA loops
+//  16  v_sin / v_cos of the encoding (identity instead)       32 the encoding's arithmetic altogether (fwd + chain rule)
+//  64  the forward / input-gradient MFMAs
+#ifndef OBJ32_ABL
+#define OBJ32_ABL 0
+#endif
+#define TILE_SYNC() do { if (!((OBJ32_ABL) & 2)) __syncthreads(); } while (0)
+
 namespace {
 
 __device__ __forceinline__ void st_T32(float* stg_lane, const int rowbase, const T32& v) {
+  if ((OBJ32_ABL) & 4) { asm volatile("" :: "v"(v.t[0]), "v"(v.t[1])); return; }
 #pragma unroll
   for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) stg_lane[(rowbase + 16 * tt + r) * STG_LD] = v.t[tt][r];
 }
 __device__ __forceinline__ void st_T16(float* stg_lane, const int rowbase, const f32x4& v) {
+  if ((OBJ32_ABL) & 4) { asm volatile("" :: "v"(v)); return; }
 #pragma unroll
   for (int r = 0; r < 4; ++r) stg_lane[(rowbase + r) * STG_LD] = v[r];
 }
@@ -36,6 +50,7 @@ __device__ __forceinline__ void st_T16(float* stg_lane, const int rowbase, const
 // group g) = sample 32 g + st: a lane walks consecutive samples, two steps per ds_read_b64, conflict-free with the
 // 130-float row pitch).  dT / aT point at &stg[(row0 + c) * LD + 32 g].
 __device__ __forceinline__ void wg_pair(f32x4& acc0, f32x4& acc1, const float* dT, const float* aT) {
+  if ((OBJ32_ABL) & 8) return;
   dT = (const float*)__builtin_assume_aligned(dT, 8);
   aT = (const float*)__builtin_assume_aligned(aT, 8);
 #pragma unroll 8
@@ -52,6 +67,7 @@ __device__ __forceinline__ void wg_pair(f32x4& acc0, f32x4& acc1, const float* d
 
 // one 16-output half of a tile pair (the feature variant balances its 28 tile pairs over the waves in halves)
 __device__ __forceinline__ void wg_half(f32x4& acc0, const float* dT, const float* aT) {
+  if ((OBJ32_ABL) & 8) return;
   dT = (const float*)__builtin_assume_aligned(dT, 8);
   aT = (const float*)__builtin_assume_aligned(aT, 8);
 #pragma unroll 8
@@ -65,6 +81,7 @@ __device__ __forceinline__ void wg_half(f32x4& acc0, const float* dT, const floa
 
 // a quarter: one 16-output half over half of the staged samples (steps st0 .. st0 + 15 of every lane group's 32)
 __device__ __forceinline__ void wg_quarter(f32x4& acc0, const float* dT, const float* aT, const int st0) {
+  if ((OBJ32_ABL) & 8) return;
   dT = (const float*)__builtin_assume_aligned(dT, 8);
   aT = (const float*)__builtin_assume_aligned(aT, 8);
 #pragma unroll 8
@@ -374,7 +391,7 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
         pf_lab2 = (int)a.labels[rr2_];
       }
     } else if (FEAT && w * (64 / S) < TR) feat_inputs(w, 0, pf_uh, pf_beta, pf_ngv, pf_lab2);
-    __syncthreads();
+    TILE_SYNC();
     PT(3);
     // ---------------------------------------------------------------- 2. composite + loss (loss.py:27-101)
     auto composite_passes = [&](const auto& sg) {
@@ -567,7 +584,7 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
         dw = gD * zz + gO + gC0 * c0 + gC1 * c1 + gC2 * c2;
         if (on) s_w[sl] = wgt;
       }
-      __syncthreads();
+      TILE_SYNC();
       {
         const float wv = valid ? s_w[slot] : 0.0f;
         float v8[8];
@@ -578,7 +595,7 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
         const float psum = slot_sums8(v8, c);
         if (c < 8) s_part[w * 32 + 16 * ((c & 7) >> 2) + 4 * g + (c & 3)] = psum;
       }
-      __syncthreads();
+      TILE_SYNC();
       {
         float* s_fhb = stg + OFF_FHB + 64 * w;
         const float* Gb = stg + OFF_GBUF;
@@ -629,7 +646,7 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
         const float dwf = xgroup_sum(dp) + gof;
         if (g == 0 && valid) s_dwf[slot] = dwf;
       }
-      __syncthreads();
+      TILE_SYNC();
       if (w < TR) {
         if (on) dw += s_dwf[sl];
         const float qv = dw * wgt;
@@ -642,9 +659,10 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
           s_col[2 * TS + sl] = gC2 * wgt * c2 * (1.0f - c2);
         }
       }
+    } else if ((OBJ32_ABL) & 1) { /* ablation: no compositing */
     } else if (SS || rows_mode) composite_passes(seg_rows); else composite_passes(SegGeneric{S});
     PT(4);
-    __syncthreads();
+    TILE_SYNC();
     PT(5);
     // ---------------------------------------------------------------- 3. backward
     const float da = valid ? s_alpha[slot] : 0.0f;
@@ -742,19 +760,19 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
     mma_t32(d_h3, wt0, wt1, R_M2, d_h4);
     d_h3 = relu_mask32(d_h3, act.h3);
     PT(6);
-    __syncthreads();
+    TILE_SYNC();
     PT(7);
     if (FEAT) {
       // round A: colour tiles 0..4 (waves 0..4), feature tiles 0..2 (waves 5..7)
       const int dTr = (w < 5) ? LY::A_DHC : LY::A_DHF;
       const int aTr = (w < 5) ? 16 * w : 16 * (w - 5);
       wg_pair(accA0, accA1, lane_rd + dTr * STG_LD, lane_rd + aTr * STG_LD);
-      __syncthreads();
+      TILE_SYNC();
       // round A2: h3 over the h4 rows, d_h4 over the d_hc rows; feature tiles 3, 4 (x2 rows 48..79, d_hf still in
       // place) and the two mid2 tiles, one 16-output half per wave
       st_T32(stg_lane, LY::A_H3, act.h3);
       st_T32(stg_lane, LY::A_DH4, d_h4);
-      __syncthreads();
+      TILE_SYNC();
       {
         const int half = w & 1, t2 = (w & 3) >> 1;
         const int dTr = ((w < 4) ? LY::A_DHF : LY::A_DH4) + 16 * half;
@@ -767,7 +785,7 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
       wg_pair(accA0, accA1, lane_rd + dTr * STG_LD, lane_rd + aTr * STG_LD);
     }
     PT(8);
-    __syncthreads();
+    TILE_SYNC();
     PT(9);
     // ---- phase B: cat layer.  [h2 | x1] rows 0..127, d_h3pre rows 128..
     st_T32(stg_lane, 0, act.h2);
@@ -812,31 +830,31 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
     }
     PT(10);
     PT(11);
-    __syncthreads();
+    TILE_SYNC();
     PT(12);
     wg_pair(accB0, accB1, lane_rd + 128 * STG_LD, lane_rd + (16 * w) * STG_LD);
     PT(13);
-    __syncthreads();
+    TILE_SYNC();
     // ---- phase C: in layer (x1 stays at rows 32..127) + mid1.  h1 rows 0.., d_h1pre 128.., d_h2pre 160..
     fetch_point(tile + tstep, slot, nx, ny, nz);
     st_T32(stg_lane, 0, act.h1);
     st_T32(stg_lane, 128, d_h1);
     if (!FEAT) st_T32(stg_lane, LY::C_DH2, d_h2);
     PT(14);
-    __syncthreads();
+    TILE_SYNC();
     PT(15);
     if (FEAT) {
       // round C: the six in-layer tiles; round C2: d_h2 over the d_h1 rows, the two mid1 tiles as eight quarters
       if (w < 6) wg_pair(accC0, accC1, lane_rd + 128 * STG_LD, lane_rd + (32 + 16 * w) * STG_LD);
-      __syncthreads();
+      TILE_SYNC();
       st_T32(stg_lane, LY::C_DH2, d_h2);
-      __syncthreads();
+      TILE_SYNC();
       // all eight waves: wave w takes half (w >> 1) & 1 of tile w >> 2 over the sample half w & 1; the two partial
       // sums of a half meet once, after the sweep
       wg_quarter(accC2, lane_rd + (LY::C_DH2 + 16 * ((w >> 1) & 1)) * STG_LD, lane_rd + (16 * (w >> 2)) * STG_LD,
                  16 * (w & 1));
       // the next tile's forward pass writes its hidden-feature buffer into rows this round is reading
-      __syncthreads();
+      TILE_SYNC();
     } else {
       const int dTr = (w < 6) ? 128 : 160;
       const int aTr = (w < 6) ? 32 + 16 * w : 16 * (w - 6);

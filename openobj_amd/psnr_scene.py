@@ -190,8 +190,10 @@ class EnsembleRun:
                 fcos.append(torch.nn.functional.cosine_similarity(F, self.feat_gt[:, None, :], dim=-1).mean().item())
         return {"psnr": np.array(psnr), "featcos": np.array(fcos) if self.with_feat else None}
 
-    def run(self, seeds: Sequence[int], mode=False) -> Dict[str, np.ndarray]:
-        """mode: ops.precision_bits (False / True = "bf16" / "fp16").  -> psnr50 [n], psnr300 [n] (+ featcos300)."""
+    def run(self, seeds: Sequence[int], mode=False, grad_hook=None) -> Dict[str, np.ndarray]:
+        """mode: ops.precision_bits (False / True = "bf16" / "fp16").  -> psnr50 [n], psnr300 [n] (+ featcos300).
+        grad_hook(iteration, ws.grads): diagnostic -- called between the step and the optimiser (tools/h256_handicap.py
+        degrades the gradients there to show what the paired gate detects); None in every gate and in bench.py."""
         s, n = self.spec, len(seeds)
         arena = self.initial_arena(seeds)
         nK = arena.K
@@ -203,6 +205,8 @@ class EnsembleRun:
         for it, b in enumerate(self.batches):
             batch = {k: v.repeat(n, *([1] * (v.dim() - 1))) for k, v in b.items()}
             ops.train_step(arena, ws, batch, with_feat=self.with_feat, bf16=mode)
+            if grad_hook is not None:
+                grad_hook(it, ws.grads)
             opt.step(ws.grads, mask, flags=ws.flags)
             if it + 1 == s["early"]:
                 early = self._evaluate(arena, n)
@@ -213,6 +217,27 @@ class EnsembleRun:
         if self.with_feat:
             out["featcos300"] = final["featcos"]
         return out
+
+
+# The paired hidden-256 gate (tests/test_psnr_gpu.py::test_hidden_256_network_psnr_paired_early): bounds on the per-seed
+# PSNR differences against the reference after 10 / 20 iterations.  One table for the test AND for tools/h256_handicap.py,
+# which shows the gate failing under a deliberately degraded gradient (profiles/r06_h256_handicap.txt).
+# (mean10, ci10, max10, mean20, max20) -- measured green values, profiles/r06_h256_paired_psnr.txt:
+#   f32  -0.004 / 0.005 / 0.065 / 0.000 / 0.21     fp16 -0.014 / 0.051 / 0.58 / +0.016 / 0.85
+#   bf16 -0.046 / 0.108 / 1.02 / +0.053 / 2.42
+PAIRED_GATE = {
+    "f32": dict(mean10=0.015, ci10=0.01, max10=0.1, mean20=0.06, max20=0.4),
+    "fp16": dict(mean10=0.1, ci10=0.08, max10=1.0, mean20=0.15, max20=1.5),
+    "bf16": dict(mean10=0.15, ci10=0.15, max10=1.5, mean20=0.3, max20=3.15),      # max20: 1.3 x the measured 2.42 (was 3.5)
+}
+
+
+def paired_gate_failures(mode: str, r10: dict, r20: dict) -> list:
+    """Names of the PAIRED_GATE bounds that (r10, r20) = paired_report after 10 / 20 iterations violate ([] = green)."""
+    g = PAIRED_GATE[mode]
+    checks = [("mean10", abs(r10["mean_delta_db"])), ("ci10", r10["ci95_db"]), ("max10", r10["max_abs_delta_db"]),
+              ("mean20", abs(r20["mean_delta_db"])), ("max20", r20["max_abs_delta_db"])]
+    return ["%s: %.3f >= %.3f" % (k, v, g[k]) for k, v in checks if not v < g[k]]
 
 
 def compare(run: Dict[str, np.ndarray], ref: Dict[str, np.ndarray], n: int) -> Dict[str, dict]:

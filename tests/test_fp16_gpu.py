@@ -109,6 +109,48 @@ def test_config_c5_object_at_full_size_16bit(dev, mode, feat):
     assert float(d) < 1e-5, float(d)
 
 
+@pytest.mark.parametrize("feat", [False, True])
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+def test_hidden256_step_is_bit_reproducible_at_full_size(dev, mode, feat):
+    """configs[4]'s object at its real size (1 x 8192 rays x 128 samples, hidden 256) through the DEFAULT kernels
+    (fwdr256_kernel, the row-split form of kernel A, without the feature loss; fwd256_kernel<.., true> with it; then
+    wgrad256_kernel): three runs in one workspace and a fourth in a FRESH workspace whose every byte was poisoned first
+    (0x7f7f7f7f = 3.4e38 as fp32, a NaN pattern as fp16 / bf16 pairs) give BIT-equal gradients and loss terms.  An
+    intermittent race between the waves of a tile, a read of a workspace region the step did not write, or an
+    order-dependent atomic would show here at the size where all 256 CUs carry several tiles -- the small repeat-run checks
+    (K = 5, R = 200) leave most of the chip idle.  (Round 5 reverted a buffer-load variant of the row-split kernel whose
+    fp16 results were NOT reproducible; tools/repro256.py runs any library build under this same check.)"""
+    K, R, n1, n2, H = 1, 8192, 32, 96, 256
+    arena = ops.ParamArena(K, ops.NetShape(H, 512, 6), dev)
+    arena.load_stacked(obj_init.init_stacked(K, H, 512, seed=47))
+    b = synthetic.random_batch(K, R, n1, n2, seed=23, feat_dim=512 if feat else 0)
+    batch = {k: T(b[k]).to(dev) for k in ["pts", "z", "gt_depth", "gt_rgb", "labels"] + (["gt_feat"] if feat else [])}
+    ws = ops.TrainWorkspace(arena, K, R, n1 + n2, feat, precision=mode)
+    # (without gt_feat the feature branch has NO gradient -- .grad stays None, train.py:435-438 -- and the step leaves those
+    # entries of the buffer alone: the comparison is over the tensors that have one)
+    has = [i for i in range(19) if feat or i not in ops.FEAT_TENSORS]
+
+    def snap(w):
+        return torch.cat([v.reshape(-1) for i, v in enumerate(arena.views(w.grads)) if i in has]).clone()
+    runs = []
+    for i in range(3):
+        ws.grads.fill_(float(i))                     # (the step writes every element that has a gradient: no dependence on what was there)
+        ops.train_step(arena, ws, batch, with_feat=feat, bf16=mode)
+        torch.cuda.synchronize()
+        assert int(ws.status.item()) == 0
+        runs.append((snap(ws), ws.loss_terms.clone()))
+    ws2 = ops.TrainWorkspace(arena, K, R, n1 + n2, feat, precision=mode)
+    ws2.buf.fill_(0x7f)
+    ws2.grads.fill_(float("nan"))
+    ops.train_step(arena, ws2, batch, with_feat=feat, bf16=mode)
+    torch.cuda.synchronize()
+    runs.append((snap(ws2), ws2.loss_terms.clone()))
+    assert bool(torch.isfinite(runs[0][0]).all()) and float(runs[0][0].abs().max()) > 0
+    for i in range(1, 4):
+        assert torch.equal(runs[i][0], runs[0][0]), (i, float((runs[i][0] - runs[0][0]).abs().max()))
+        assert torch.equal(runs[i][1], runs[0][1]), i
+
+
 @pytest.mark.parametrize("mode", ["bf16", "fp16"])
 @pytest.mark.parametrize("shape", [(2, 700, 8, 24), (2, 90, 16, 48), (1, 300, 32, 96)])
 def test_hidden256_kernel_forms_agree(dev, mode, shape, tmp_path):

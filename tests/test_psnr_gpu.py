@@ -112,10 +112,13 @@ def test_hidden_256_network_psnr_paired_early(dev, mode):
       fp32 (layer-wise chain, the reference's arithmetic): PER SEED within 0.1 dB after 10 iterations (measured max 0.065,
       mean -0.004 +- 0.005) and 0.4 dB after 20 (max 0.21, mean 0.000 +- 0.027);
       fp16 / bf16 (the two fused hidden-256 kernels): the MEAN of the 33 per-seed differences after 10 iterations within
-      0.1 / 0.15 dB (measured -0.014 +- 0.051 / -0.046 +- 0.108, 95 % intervals): a 0.3 dB handicap of fwd256_kernel /
-      wgrad256_kernel fails it; after 20 iterations within 0.15 / 0.3 dB (+0.016 +- 0.108 / +0.053 +- 0.22); no seed off by more than
-      1 / 1.5 dB after 10 iterations (measured 0.58 / 1.02).
-    (profiles/r05_h256_paired_psnr.txt.)"""
+      0.1 / 0.15 dB (measured -0.014 +- 0.051 / -0.046 +- 0.108, 95 % intervals); after 20 iterations within 0.15 / 0.3 dB
+      (+0.016 +- 0.108 / +0.053 +- 0.22); no seed off by more than 1 / 1.5 dB after 10 iterations (measured 0.58 / 1.02) and
+      1.5 / 3.15 dB after 20 (0.85 / 2.42; the bf16 bound is 1.3 x its measurement).
+    What it detects is DEMONSTRATED, not asserted: tools/h256_handicap.py degrades the gradients of the same runs (seeded
+    noise relative to each tensor's rms, between the step and AdamW) and profiles/r06_h256_handicap.txt records the
+    strength at which the trained PSNR drops by ~0.3 dB and that this gate fails there.
+    (profiles/r06_h256_paired_psnr.txt: the green run these bounds are read from.)"""
     ref = psnr_scene.reference_early_d()
     assert ref is not None, "tests/golden/g9d_early_h256.npz missing"
     seeds = [int(x) for x in ref["seeds"]]
@@ -127,12 +130,7 @@ def test_hidden_256_network_psnr_paired_early(dev, mode):
     print(mode, "hidden 256, paired, 10 iterations:", r10)
     print(mode, "hidden 256, paired, 20 iterations:", r20)
     assert r10["n"] >= 32 and 15.0 < r10["ref_mean_db"] < 25.0 and r20["ref_mean_db"] > r10["ref_mean_db"] + 3.0
-    if mode == "f32":
-        assert r10["max_abs_delta_db"] < 0.1 and r20["max_abs_delta_db"] < 0.4, (r10, r20)
-        assert abs(r10["mean_delta_db"]) < 0.015 and abs(r20["mean_delta_db"]) < 0.06, (r10, r20)
-    elif mode == "fp16":
-        assert abs(r10["mean_delta_db"]) < 0.1 and r10["ci95_db"] < 0.08 and r10["max_abs_delta_db"] < 1.0, r10
-        assert abs(r20["mean_delta_db"]) < 0.15 and r20["max_abs_delta_db"] < 1.5, r20
-    else:
-        assert abs(r10["mean_delta_db"]) < 0.15 and r10["ci95_db"] < 0.15 and r10["max_abs_delta_db"] < 1.5, r10
-        assert abs(r20["mean_delta_db"]) < 0.3 and r20["max_abs_delta_db"] < 3.5, r20
+    # the bounds: psnr_scene.PAIRED_GATE (one table for this test and for tools/h256_handicap.py, which records the gate
+    # FAILING under a degraded gradient: profiles/r06_h256_handicap.txt)
+    bad = psnr_scene.paired_gate_failures(mode, r10, r20)
+    assert not bad, (bad, r10, r20)

@@ -108,7 +108,10 @@ def test_status_reports_a_non_finite_loss(dev, path):
     ops.train_step(arena, ws, b, layerwise=lw, bf16=prec)
     assert int(ws.status.item()) == 0 and bool(torch.isfinite(ws.loss_terms).all())
     assert check_status(ws.status) == 0
-    arena.views()[8][K - 1, 0, 3] = float("nan")           # alpha_linear.weight of the last object
+    if H == 256:      # (the fused hidden-256 kernels clamp the density head's argument: v_max / v_min swallow a NaN weight like a ReLU)
+        b["gt_depth"][K - 1, 0] = float("nan")             # a NaN target of the last object: its depth term is NaN in the reference too
+    else:
+        arena.views()[8][K - 1, 0, 3] = float("nan")       # alpha_linear.weight of the last object
     ops.train_step(arena, ws, b, layerwise=lw, bf16=prec)
     torch.cuda.synchronize()
     assert int(ws.status.item()) & 2, int(ws.status.item())
