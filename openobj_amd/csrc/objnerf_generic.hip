@@ -2481,7 +2481,15 @@ static int train_step_small(const objnerf_net* net, const objnerf_train_args* a,
     const long nb = (long)K * n * (H / 8);
     for (int l = 0; l < 6; ++l)
       if (acts[l])
-        hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, nb, H, acts[l], a->relu_masks, l, 0);
+        hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, nb, H, acts[l], a->relu_masks, l,
+                           bf ? 1 : 0);
+  }
+  if (bf) {
+    // bf16 mode: the kernel above stored h1 .. hc (hf, d_hf) and d_hc .. d_h1 as bf16 (objnerf_small_body.h, `hst`); gemm(E, )
+    // recognises 16-bit operands by address and the grouped launch passes them through unconverted
+    E.act16_lo = (const char*)w.h1;
+    E.act16_hi = feat ? (const char*)(w.d_hf + (size_t)K * n * H) : (const char*)(w.hc + w.act_floats);
+    E.grad16_lo = (const char*)w.dA; E.grad16_hi = (const char*)(w.dE + w.act_floats);
   }
   // ---- the step's reductions, collected: head partials, d B partials, the weight gradients' split-K slices
   RedGroup red;

@@ -271,9 +271,16 @@ __global__ __launch_bounds__(512) void train_small_kernel(const SmallFused a) {
       for (int i = 0; i < RT; ++i) ac[i] = an[i];
     }
   };
+  // HBM copies of the activations / pre-activation gradients (operands of the grouped weight-gradient launch).  Round 6,
+  // bf16 mode: stored ALREADY ROUNDED, two bytes per element (the buffers keep their fp32 spacing; element e of object z's
+  // tensor sits at 16-bit index z n H + e) -- gemm_group16_kernel rounded every fp32 element it staged with the same
+  // conversion, so its results are bit-identical and both sides of the round trip move half the bytes.
+  auto hst = [&](float* base, const long e, const float v) {
+    if (BF) reinterpret_cast<__bf16*>(base)[e] = (__bf16)v; else base[e] = v;
+  };
   // relu(acc + bias) -> LDS buffer, the HBM activation (weight-gradient operand) and the branch bits (bit 4 i + r)
   auto store = [&](float* X, float* hbm, const float bv) -> unsigned {
-    float* out = hbm + (z * n + m0) * H + fb;
+    const long out = (z * n + m0) * H + fb;
     unsigned bits = 0;
 #pragma unroll
     for (int i = 0; i < RT; ++i)
@@ -291,14 +298,14 @@ __global__ __launch_bounds__(512) void train_small_kernel(const SmallFused a) {
 #pragma unroll
       for (int i = 0; i < RT; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) out[(long)(16 * i + 4 * gg + r) * H] = acc[i][r];
+        for (int r = 0; r < 4; ++r) hst(hbm, out + (long)(16 * i + 4 * gg + r) * H, acc[i][r]);
     } else {
 #pragma unroll
       for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int m = 16 * i + 4 * gg + r;
-          if (m < rows) out[(long)m * H] = acc[i][r];
+          if (m < rows) hst(hbm, out + (long)m * H, acc[i][r]);
         }
     }
     return bits;
@@ -562,7 +569,7 @@ __global__ __launch_bounds__(512) void train_small_kernel(const SmallFused a) {
     // per sample (a wave per row): the feature part of d loss / d weight = gof + d fh . hf, and hf -> d hf in place
     // (pre-activation gradient of the feature layer: relu'(hf) w_s d fh)
     {
-      float* out = a.d_hf + (z * n + m0) * H;
+      const long out = (z * n + m0) * H;
       for (int m = w; m < rows; m += 8) {
         const int lr = m / S;
         const float h0 = Xa[m * PT + lane], h1 = Xa[m * PT + lane + 64];
@@ -571,7 +578,7 @@ __global__ __launch_bounds__(512) void train_small_kernel(const SmallFused a) {
         const float wt = s_wt[m];
         const float g0 = h0 > 0.0f ? wt * d0 : 0.0f, g1 = h1 > 0.0f ? wt * d1 : 0.0f;
         Xa[m * PT + lane] = g0; Xa[m * PT + lane + 64] = g1;
-        out[(long)m * H + lane] = g0; out[(long)m * H + lane + 64] = g1;
+        hst(a.d_hf, out + (long)m * H + lane, g0); hst(a.d_hf, out + (long)m * H + lane + 64, g1);
         if (lane == 0) s_wt[m] = s_rayf[4 * lr + 2] + pp;
       }
       for (int m = rows + w; m < BM; m += 8) { Xa[m * PT + lane] = 0.f; Xa[m * PT + lane + 64] = 0.f; }
@@ -592,7 +599,7 @@ __global__ __launch_bounds__(512) void train_small_kernel(const SmallFused a) {
   float* Da = Xa;
   float* Db = Xb;
   auto form_dhc = [&]() {
-    float* out = a.d_hc + (z * n + m0) * H;
+    const long out = (z * n + m0) * H;
 #pragma unroll
     for (int i = 0; i < RT; ++i)
 #pragma unroll
@@ -602,7 +609,7 @@ __global__ __launch_bounds__(512) void train_small_kernel(const SmallFused a) {
         float v = fmaf(woc2_f, dh[3], fmaf(woc1_f, dh[2], woc0_f * dh[1]));
         v = ((mkc >> (4 * i + r)) & 1u) ? v : 0.f;
         Da[m * PT + fb] = v;
-        if (m < rows) out[(long)m * H + fb] = v;
+        if (m < rows) hst(a.d_hc, out + (long)m * H + fb, v);
       }
   };
   if constexpr (!FEAT) form_dhc();
@@ -654,7 +661,7 @@ __global__ __launch_bounds__(512) void train_small_kernel(const SmallFused a) {
   };
   // masked d_h: (acc [+ the alpha head's rank-1 part wa[f] dhead[m][0]]) where the forward's ReLU passed
   auto store_dh = [&](float* X, float* hbm, const unsigned bits, const bool add_alpha) {
-    float* out = hbm + (z * n + m0) * H + fb;
+    const long out = (z * n + m0) * H + fb;
 #pragma unroll
     for (int i = 0; i < RT; ++i)
 #pragma unroll
@@ -670,14 +677,14 @@ __global__ __launch_bounds__(512) void train_small_kernel(const SmallFused a) {
 #pragma unroll
       for (int i = 0; i < RT; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) out[(long)(16 * i + 4 * gg + r) * H] = acc[i][r];
+        for (int r = 0; r < 4; ++r) hst(hbm, out + (long)(16 * i + 4 * gg + r) * H, acc[i][r]);
     } else {
 #pragma unroll
       for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int m = 16 * i + 4 * gg + r;
-          if (m < rows) out[(long)m * H] = acc[i][r];
+          if (m < rows) hst(hbm, out + (long)m * H, acc[i][r]);
         }
     }
   };

@@ -1055,7 +1055,8 @@ constexpr int FEAT_PRE_MAXC = 512;
 __global__ __launch_bounds__(512, 4) void feat_pre_kernel(const float* __restrict__ params, long p_stride, int off_w, int off_b,
                                                        int C, int R, const float* __restrict__ gt_feat,
                                                        float* __restrict__ rayin, float* __restrict__ gram,
-                                                       float* __restrict__ head_snap) {
+                                                       float* __restrict__ head_snap, const uint8_t* __restrict__ labels,
+                                                       int* __restrict__ counts) {
   extern __shared__ __attribute__((aligned(16))) float fp_lds[];       // W image [C / 16][2][64][4] | b_of [C]
   const int k = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int n = lane & 15, q = lane >> 4;
@@ -1109,6 +1110,22 @@ __global__ __launch_bounds__(512, 4) void feat_pre_kernel(const float* __restric
       float* hs = head_snap + (long)k * ((long)C * 33);
       for (int i = tid; i < C * 32; i += 512) hs[i] = W[i];
       for (int i = tid; i < C; i += 512) hs[C * 32 + i] = Bv[i];
+    }
+    if (counts) {      // OBJNERF_TRAIN_SELF_COUNTS: this object's n(label == 1), n(label != 2) (label_counts_kernel's job: a launch less)
+      __shared__ int s_c[16];
+      int c1 = 0, c2 = 0;
+      for (int r = tid; r < R; r += 512) {
+        const int l = labels[(long)k * R + r];
+        c1 += (l == 1); c2 += (l != 2);
+      }
+      for (int d = 32; d >= 1; d >>= 1) { c1 += __shfl_xor(c1, d, 64); c2 += __shfl_xor(c2, d, 64); }
+      if (lane == 0) { s_c[2 * w] = c1; s_c[2 * w + 1] = c2; }
+      __syncthreads();
+      if (tid < 2) {
+        int t = 0;
+        for (int q_ = 0; q_ < 8; ++q_) t += s_c[2 * q_ + tid];
+        counts[2 * k + tid] = t;
+      }
     }
   }
   const f32x4* bl = reinterpret_cast<const f32x4*>(fp_lds) + lane;
@@ -1519,13 +1536,15 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
     return OBJNERF_OK;
   }
   const bool self_counts = (a->mode & OBJNERF_TRAIN_SELF_COUNTS) != 0;
-  if (self_counts) {
+  const bool feat = a->gt_feat != nullptr;
+  // (with the feature loss feat_pre_kernel's first workgroup of every object counts the labels: no launch of its own)
+  const bool counts_in_pre = self_counts && feat && net->feat_dim <= FEAT_PRE_MAXC && net->feat_dim % 16 == 0;
+  if (self_counts && !counts_in_pre) {
     // per-object counts only (one workgroup per object, no zero fill, no atomics): the fused kernel's workgroups derive
     // the cross-object flags from them and finalize_kernel publishes the pair
     const int rc = objmisc::label_counts_only(a->K, a->R, a->labels, const_cast<int32_t*>(a->counts), stream);
     if (rc) return rc;
   }
-  const bool feat = a->gt_feat != nullptr;
   if (feat && (TS / a->S) > 16) return OBJNERF_ENOTSUP;
   const bool bf16 = (a->mode & OBJNERF_TRAIN_BF16) != 0;
   if (bf16 && (a->relu_masks || a->emb_debug)) return OBJNERF_ENOTSUP;
@@ -1608,7 +1627,8 @@ int objnerf_train_step(const objnerf_net* net, const objnerf_train_args* a, void
       if (gpo < 1) gpo = 1;
       if (gpo > (a->R + 127) / 128) gpo = (a->R + 127) / 128;
       hipLaunchKernelGGL(feat_pre_kernel, dim3(gpo, a->K), dim3(512), pre_lds, st, a->params, (long)a->p_stride,
-                         d.L.of_w, d.L.of_b, C, a->R, a->gt_feat, rayin, gram, head_snap);
+                         d.L.of_w, d.L.of_b, C, a->R, a->gt_feat, rayin, gram, head_snap, a->labels,
+                         counts_in_pre ? const_cast<int32_t*>(a->counts) : nullptr);
     } else {
       objgen::gemm_f32(stream, a->K, a->R, 32, C, a->gt_feat, C, 1, (long)a->R * C, a->params + d.L.of_w, 32, 1,
                        (long)a->p_stride, rayin, RAYIN, 1, (long)a->R * RAYIN, false);

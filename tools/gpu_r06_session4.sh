@@ -5,16 +5,17 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r06_s4; mkdir -p $O
 cd $R
-python3 -m pytest tests/test_hip_parity.py tests/test_round5_gpu.py tests/test_16bit_spec_gpu.py -m gpu -x -q 2>&1 | tail -15 > $O/feat_tests.txt; tail -4 $O/feat_tests.txt
+python3 -m pytest tests/test_hip_parity.py tests/test_round5_gpu.py tests/test_16bit_spec_gpu.py tests/test_api_gpu.py -m gpu -x -q 2>&1 | tail -15 > $O/feat_tests.txt; tail -4 $O/feat_tests.txt
 Q="--no-cpu-baseline --no-psnr --no-peak --no-other-configs --no-bf16-line"
 chain() {  # label, lib
+  local label=$1 lib=$2
   for cfg in "c3 f32" "c3 bf16" "c4s f32" "c4s bf16" "c2 bf16"; do
-    set -- $cfg $1 $2
+    set -- $cfg
     case $1 in c3) A="--config c3";; c4s) A="--config c4 --objects 15 --bg-ranks 8";; c2) A="";; esac
-    if [ -n "$4" ]; then export OBJNERF_LIB=$4; else unset OBJNERF_LIB; fi
-    python3 bench.py $A --dtype $2 --no-bg --steps 30 --warmup 5 $Q --detail-out $O/d.json 2>/dev/null | python3 -c "
+    if [ -n "$lib" ]; then export OBJNERF_LIB=$lib; else unset OBJNERF_LIB; fi
+    python3 bench.py $A --dtype $2 --no-bg --steps 30 --warmup 5 $Q --detail-out $O/d.json 2>$O/chain_err.txt | python3 -c "
 import json,sys
-d=json.loads(sys.stdin.readline()); print('%-8s %-4s %-5s chain_ms %.3f step_ms %.3f' % ('$3', '$1', '$2', d['roofline']['kernel_ms'], d['ms_per_step']))"
+d=json.loads(sys.stdin.readline()); print('%-8s %-4s %-5s chain_ms %.3f step_ms %.3f' % ('$label', '$1', '$2', d['roofline']['kernel_ms'], d['ms_per_step']))"
   done
 }
 {
@@ -35,7 +36,8 @@ run c3_bf16 train_fused_bf16v2f --config c3 --steps 10 --warmup 3 --dtype bf16
 run c3_f32 "train_fused32_kernel<true" --config c3 --steps 10 --warmup 3
 run c4share_bf16 train_fused_bf16v2f --config c4 --objects 15 --bg-ranks 8 --steps 10 --warmup 3 --dtype bf16
 run default_bf16 train_fused_bf16v2_kernel --steps 10 --warmup 3 --dtype bf16
-cat $O/timeline_c3_bf16.txt
+cat $O/timeline_c3_bf16.txt | head -24
+for v in "" "--bf16" "--feat" "--feat --bf16"; do echo "bg chain alone (tools/bg_trace.py --metric $v): $(STEPS=100 python3 $R/tools/bg_trace.py --metric $v 2>/dev/null | tail -1)"; done | tee $O/bg_chain.txt
 python3 - <<'P'
 import csv,glob,os
 for f in sorted(glob.glob(os.environ.get('GRAFT_REPO_ROOT','/root/repo')+'/gpurun_out/r06_s4/kernel_stats_*.csv')):
