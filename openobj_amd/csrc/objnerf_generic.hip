@@ -212,15 +212,30 @@ __global__ __launch_bounds__(512, 8) void gemm_kernel8(const Gemm g) {
 
 // Several independent GEMMs in ONE launch (the weight-gradient GEMMs of a small-batch step: each alone is ~260
 // workgroups of latency-bound work): blockIdx.z runs over the concatenated (batch x split-K) slices of all of them.
+// Optional extra workgroups of a grouped launch (blockIdx.z >= zbeg[count], x = y = 0): the feature branch's small
+// preparation passes of the one-launch background iteration -- wb = W_of^T b_of, bb; beta = b_of . g, |g| per ray; a copy of
+// [W_of | b_of] for the head's finish -- ride on the launch of its two preparation GEMMs (round 6: three launches fewer).
+struct FeatPrepTask {
+  int blocks = 0;                         // 0: no task
+  const float* params; long ps; int off_w, off_b, C, Hh, R, rin_ld, K;
+  const float* gt_feat; float* rayin; float* gram; long gstride; float* snap;
+  int nb_wb, nb_rs, nb_snap;              // workgroups per object of the three passes
+};
 struct GemmGroup {
   static constexpr int MAXG = 11;
   int count;
   int zbeg[MAXG + 1];
   Gemm g[MAXG];
+  FeatPrepTask task;
 };
+__device__ void feat_prep_task(const FeatPrepTask& t, int b);
 // 8 waves per workgroup on a 128 x 128 output tile (4 x 2 waves of 32 x 64): every operand slice is read once
 // (64 x 64 tiles of 4 waves read it once per tile: 0.297 -> 0.287 ms for the background step)
 __global__ __launch_bounds__(512) void gemm_group_kernel(const GemmGroup gr) {
+  if ((int)blockIdx.z >= gr.zbeg[gr.count]) {            // (extra workgroups: FeatPrepTask)
+    if (blockIdx.x == 0 && blockIdx.y == 0) feat_prep_task(gr.task, (int)blockIdx.z - gr.zbeg[gr.count]);
+    return;
+  }
   int i = 0;
   while (i + 1 < gr.count && (int)blockIdx.z >= gr.zbeg[i + 1]) ++i;
   const Gemm& g = gr.g[i];
@@ -668,6 +683,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? ((AFULL && KMAX == 2
 // The weight-gradient GEMMs of a small-batch step in bf16 mode, in ONE launch (the fp32 twin: gemm_group_kernel): 64 x 64
 // tiles on 4 waves, both operands k-major (d_out^T and the activations as they lie in memory), split-K partial tiles.
 __global__ __launch_bounds__(256) void gemm_group16_kernel(const GemmGroup gr) {
+  if ((int)blockIdx.z >= gr.zbeg[gr.count]) return;      // (tasks ride on the fp32 grouped launch only)
   int i = 0;
   while (i + 1 < gr.count && (int)blockIdx.z >= gr.zbeg[i + 1]) ++i;
   const Gemm& g = gr.g[i];
@@ -1576,8 +1592,9 @@ static void flush_group(GemmEnv& E, hipStream_t st, GemmGroup& gr) {
     my = std::max(my, (gr.g[i].M + 63) / 64);
   }
   if (E.group16) hipLaunchKernelGGL(gemm_group16_kernel, dim3(mx, my, gr.zbeg[gr.count]), dim3(256), 0, st, gr);
-  else hipLaunchKernelGGL(gemm_group_kernel, dim3((mx + 1) / 2, (my + 1) / 2, gr.zbeg[gr.count]), dim3(512), 0, st, gr);
+  else hipLaunchKernelGGL(gemm_group_kernel, dim3((mx + 1) / 2, (my + 1) / 2, gr.zbeg[gr.count] + gr.task.blocks), dim3(512), 0, st, gr);
   gr.count = 0;
+  gr.task.blocks = 0;
   E.group16 = false;
   E.red_group = nullptr;                 // (the caller launches the collected reductions: launch_reductions)
 }
@@ -1884,6 +1901,124 @@ __global__ __launch_bounds__(256) void featg_finish_kernel(const float* params, 
     }
     v += (v0 + v1) + (v2 + v3);
     grads[(long)k * p_stride + off_b + cc] = fmaf(bc, M[(long)Hh * XC + Hh], v);
+  }
+}
+
+// FeatPrepTask (512 threads per workgroup): featg_wb_kernel's, featg_rowstats_kernel's arithmetic and the [W_of | b_of] copy.
+// b = (object, pass-local index)
+__device__ void feat_prep_task(const FeatPrepTask& t, int b) {
+  const int per = t.nb_wb + t.nb_rs + t.nb_snap;
+  const int k = b / per;
+  b -= k * per;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const float* W = t.params + (long)k * t.ps + t.off_w;
+  const float* B = t.params + (long)k * t.ps + t.off_b;
+  if (b < t.nb_wb) {                                       // wb[h] = W_of[:, h] . b_of (h < Hh), bb = b_of . b_of: a wave per entry
+    const int h = 8 * b + wv;
+    if (h <= t.Hh) {
+      float acc = 0.f;
+      for (int cc = lane; cc < t.C; cc += 64) acc = fmaf(h < t.Hh ? W[(long)cc * t.Hh + h] : B[cc], B[cc], acc);
+      acc = wave_sum64(acc);
+      if (lane == 0) t.gram[(long)k * t.gstride + (long)t.Hh * t.Hh + h] = acc;
+    }
+    return;
+  }
+  b -= t.nb_wb;
+  if (b < t.nb_rs) {                                       // beta, |g| of 32 rays: 16 lanes per ray
+    const int l16 = tid & 15;
+    const long r = (long)b * 32 + (tid >> 4);
+    float bs = 0.f, gs = 0.f;
+    if (r < t.R) {
+      const float* gp = t.gt_feat + ((long)k * t.R + r) * t.C;
+      for (int cc = l16; cc < t.C; cc += 16) {
+        const float gv = gp[cc];
+        bs = fmaf(B[cc], gv, bs);
+        gs = fmaf(gv, gv, gs);
+      }
+    }
+    bs = dpp_rowsum16(bs);
+    gs = dpp_rowsum16(gs);
+    if (r < t.R && l16 == 0) {
+      float* o = t.rayin + ((long)k * t.R + r) * t.rin_ld;
+      o[t.rin_ld - 2] = bs;
+      o[t.rin_ld - 1] = sqrtf(gs);
+    }
+    return;
+  }
+  b -= t.nb_rs;
+  if (t.snap) {                                            // [W_of (C x Hh) | b_of (C)] as they are BEFORE the step
+    float* o = t.snap + (long)k * ((long)t.C * (t.Hh + 1));
+    const long tot = (long)t.C * (t.Hh + 1);
+    for (long i = (long)b * 2048 + tid; i < tot && i < (long)(b + 1) * 2048; i += 512)
+      o[i] = i < (long)t.C * t.Hh ? W[i] : B[i - (long)t.C * t.Hh];
+  }
+}
+// featg_finish_kernel + the head's AdamW in one launch (the one-launch background iteration with an optimiser attached):
+// the entry's gradient is formed from the COPY of [W_of | b_of] (FeatPrepTask; a gradient needs a whole row of W_of that
+// other threads of this launch are stepping) and stepped at once -- adamw_dyn_kernel's arithmetic for the feature group
+// [lo2, hi2), whose counter the reduction launch has already advanced in the other bank.
+struct FeatFinishOpt {
+  float* params; float* m; float* v; const int* flags; const int* steps; int bank;
+  double lr, b1, b2, wd; float eps;
+};
+__global__ __launch_bounds__(256) void featg_finish_adamw_kernel(const float* snap, long p_stride, int off_w, int off_b, int C,
+                                                                 int Hh, const float* Tm, const float* mom, float* grads,
+                                                                 const FeatFinishOpt o) {
+  const int XC = Hh + 1;
+  const int k = blockIdx.y;
+  __shared__ float s_step, s_bc2;
+  __shared__ int s_act;
+  if (threadIdx.x == 0) {
+    const bool f0 = o.flags[0] != 0;
+    s_act = !f0;                                           // (group 2 of adamw_dyn_kernel: skipped when no ray has label 1)
+    const double st = (double)(o.steps[3 * o.bank + 2] + 1);
+    s_step = (float)(o.lr / (1.0 - pow(o.b1, st)));
+    s_bc2 = (float)sqrt(1.0 - pow(o.b2, st));
+  }
+  __syncthreads();
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)C * XC) return;
+  const int cc = (int)(i / XC), hh = (int)(i - (long)cc * XC);
+  const float* hs = snap + (long)k * ((long)C * XC);
+  const float* W = hs + (long)cc * Hh;
+  const float bc = hs[(long)C * Hh + cc];
+  const float* M = mom + (long)k * XC * XC;
+  float v = Tm[(long)k * C * XC + i];
+  float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, gr;
+  long idx;
+  if (hh < Hh) {
+    for (int j = 0; j < Hh; j += 4) {
+      v0 = fmaf(W[j], M[(long)j * XC + hh], v0);
+      v1 = fmaf(W[j + 1], M[(long)(j + 1) * XC + hh], v1);
+      v2 = fmaf(W[j + 2], M[(long)(j + 2) * XC + hh], v2);
+      v3 = fmaf(W[j + 3], M[(long)(j + 3) * XC + hh], v3);
+    }
+    v += (v0 + v1) + (v2 + v3);
+    gr = fmaf(bc, M[(long)Hh * XC + hh], v);
+    idx = (long)k * p_stride + off_w + (long)cc * Hh + hh;
+  } else {
+    for (int j = 0; j < Hh; j += 4) {
+      v0 = fmaf(W[j], M[(long)Hh * XC + j], v0);
+      v1 = fmaf(W[j + 1], M[(long)Hh * XC + j + 1], v1);
+      v2 = fmaf(W[j + 2], M[(long)Hh * XC + j + 2], v2);
+      v3 = fmaf(W[j + 3], M[(long)Hh * XC + j + 3], v3);
+    }
+    v += (v0 + v1) + (v2 + v3);
+    gr = fmaf(bc, M[(long)Hh * XC + Hh], v);
+    idx = (long)k * p_stride + off_b + cc;
+  }
+  grads[idx] = gr;
+  if (s_act) {
+    const float decay = (float)(1.0 - o.lr * o.wd), w1 = (float)(1.0 - o.b1), w2 = (float)(1.0 - o.b2), beta2 = (float)o.b2;
+    float p = o.params[idx] * decay;
+    const float mo = o.m[idx];
+    const float mn = mo + w1 * (gr - mo);
+    const float vn = o.v[idx] * beta2 + (w2 * gr) * gr;
+    const float denom = sqrtf(vn) / s_bc2 + o.eps;
+    p = p + (-s_step) * (mn / denom);
+    o.params[idx] = p;
+    o.m[idx] = mn;
+    o.v[idx] = vn;
   }
 }
 
@@ -2433,16 +2568,37 @@ static int train_step_small(const objnerf_net* net, const objnerf_train_args* a,
   }
   const long R = a->R;
   const int XC = H + 1;
+  float* head_snap = nullptr;          // [K][C (H + 1)]: [W_of | b_of] before the step (FeatPrepTask), for the fused finish + AdamW
   if (feat) {
     // the 512-d head is NOT applied per sample: per object G = W_of^T W_of (+ wb, bb), per ray
     // u = W_of^T g, beta, |g| -- none of it depends on the forward pass; four small launches ahead of the fused one
     const long gst = (long)H * H + H + 1;
     E.operands = 0;
+    // Round 6: ONE launch for the four (the two GEMMs as a group, wb / bb, the rays' beta and |g| and -- with an optimiser
+    // attached -- the copy of [W_of | b_of] the head's finish reads, as extra workgroups of the same launch: FeatPrepTask)
+    head_snap = a->optim ? E.parts_alloc((size_t)K * C * XC) : nullptr;
+    GemmGroup g0;
+    g0.count = 0;
+    E.group = &g0; E.group16 = false;
     gemm(E, st, K, H, H, C, P + off[16], 1, H, ps, P + off[16], H, 1, ps, w.gram, H, 1, gst);
-    hipLaunchKernelGGL(featg_wb_kernel, dim3(H + 1, K), dim3(64), 0, st, P, ps, (int)off[16], (int)off[17], C, H, w.gram, gst);
     gemm(E, st, K, (int)R, H, C, a->gt_feat, C, 1, R * C, P + off[16], H, 1, ps, w.rayin, H + 2, 1, R * (H + 2));
-    hipLaunchKernelGGL(featg_rowstats_kernel, dim3((unsigned)((R + 15) / 16), K), dim3(256), 0, st, P, ps, (int)off[17], C,
-                       (int)R, H + 2, a->gt_feat, w.rayin);
+    if (g0.count == 2 && !E.error) {
+      FeatPrepTask& t = g0.task;
+      t.params = P; t.ps = ps; t.off_w = (int)off[16]; t.off_b = (int)off[17]; t.C = C; t.Hh = H; t.R = (int)R; t.rin_ld = H + 2;
+      t.K = K; t.gt_feat = a->gt_feat; t.rayin = w.rayin; t.gram = w.gram; t.gstride = gst; t.snap = head_snap;
+      t.nb_wb = (H + 1 + 7) / 8; t.nb_rs = (int)((R + 31) / 32);
+      t.nb_snap = head_snap ? (int)(((long)C * XC + 2047) / 2048) : 0;
+      t.blocks = K * (t.nb_wb + t.nb_rs + t.nb_snap);
+      flush_group(E, st, g0);
+    } else {                          // (cannot happen for these shapes; the separate launches remain the fallback)
+      if (E.error) return OBJNERF_EINVAL;
+      flush_group(E, st, g0);
+      head_snap = nullptr;
+      hipLaunchKernelGGL(featg_wb_kernel, dim3(H + 1, K), dim3(64), 0, st, P, ps, (int)off[16], (int)off[17], C, H, w.gram, gst);
+      hipLaunchKernelGGL(featg_rowstats_kernel, dim3((unsigned)((R + 15) / 16), K), dim3(256), 0, st, P, ps, (int)off[17], C,
+                         (int)R, H + 2, a->gt_feat, w.rayin);
+    }
+    E.group = nullptr;
   }
   SmallFused f;
   f.K = K; f.R = a->R; f.S = S; f.rpw = rpw;
@@ -2547,10 +2703,16 @@ static int train_step_small(const objnerf_net* net, const objnerf_train_args* a,
     // turns them into d W_of, d b_of after the reduction).  Two launches of their own: inside the grouped launch their
     // 512-row output made it 5x slower (1.82 against 0.35 ms at the benchmark's background batch -- every GEMM of the
     // group is then launched over four row tiles)
-    E.group = nullptr; E.group16 = false; E.operands = 0; E.red_group = &red; E.max_slices = 0;
+    // (round 6: the two as ONE grouped launch of their own)
+    GemmGroup g2;
+    g2.count = 0;
+    E.group = &g2; E.group16 = false; E.operands = 0; E.red_group = &red; E.max_slices = 0;
     wgrad(E, st, K, C, XC, R, a->gt_feat, 1, C, R * C, w.X1, XC, 1, R * XC, w.Tm, XC, (long)C * XC);
     wgrad(E, st, K, XC, XC, R, w.X2, 1, XC, R * XC, w.rayfeat, H + 3, 1, R * (H + 3), w.mom, XC, (long)XC * XC);
     if (E.parts_failed || E.error) return OBJNERF_EINVAL;
+    RedGroup* keep = E.red_group;
+    flush_group(E, st, g2);              // (launches whatever was collected; GEMMs the group does not take were launched at once)
+    E.red_group = keep;
   }
   red.tail.loss_part = f.loss_part; red.tail.loss_blocks = nwg; red.tail.K = K; red.tail.loss_terms = a->loss_terms;
   red.tail.status = a->status;
@@ -2564,7 +2726,16 @@ static int train_step_small(const objnerf_net* net, const objnerf_train_args* a,
     if (done) *done |= 2;
   }
   launch_reductions(st, red);
-  if (feat) {
+  if (feat && a->optim && head_snap) {
+    // the head's gradient AND its AdamW step in one launch, from the copy of [W_of | b_of] (round 6)
+    const objnerf_adamw_args* o = a->optim;
+    FeatFinishOpt fo;
+    fo.params = const_cast<float*>(a->params); fo.m = o->exp_avg; fo.v = o->exp_avg_sq; fo.flags = a->flags;
+    fo.steps = o->group_steps; fo.bank = o->bank;
+    fo.lr = (double)o->lr; fo.b1 = (double)o->beta1; fo.b2 = (double)o->beta2; fo.wd = (double)o->weight_decay; fo.eps = o->eps;
+    hipLaunchKernelGGL(featg_finish_adamw_kernel, dim3((unsigned)(((long)C * XC + 255) / 256), K), dim3(256), 0, st, head_snap, ps,
+                       (int)off[16], (int)off[17], C, H, w.Tm, w.mom, G, fo);
+  } else if (feat) {
     hipLaunchKernelGGL(featg_finish_kernel, dim3((unsigned)(((long)C * XC + 255) / 256), K), dim3(256), 0, st, P, ps,
                        (int)off[16], (int)off[17], C, H, w.Tm, w.mom, G);
     if (a->optim) {               // the head's own entries [of_w, pe_b): their gradient exists only now
