@@ -682,6 +682,20 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? ((AFULL && KMAX == 2
 
 // The weight-gradient GEMMs of a small-batch step in bf16 mode, in ONE launch (the fp32 twin: gemm_group_kernel): 64 x 64
 // tiles on 4 waves, both operands k-major (d_out^T and the activations as they lie in memory), split-K partial tiles.
+// OBJ_GROUP16_WIDE: 128 x 128 tiles on 8 waves (every operand slice read once, as the fp32 twin) instead of 64 x 64 on 4
+#ifndef OBJ_GROUP16_WIDE
+#define OBJ_GROUP16_WIDE 1
+#endif
+#if OBJ_GROUP16_WIDE
+__global__ __launch_bounds__(512) void gemm_group16_kernel(const GemmGroup gr) {
+  if ((int)blockIdx.z >= gr.zbeg[gr.count]) return;      // (tasks ride on the fp32 grouped launch only)
+  int i = 0;
+  while (i + 1 < gr.count && (int)blockIdx.z >= gr.zbeg[i + 1]) ++i;
+  const Gemm& g = gr.g[i];
+  if ((int)blockIdx.x * 128 >= g.N || (int)blockIdx.y * 128 >= g.M) return;
+  gemm_bf16_body<2, 4, __bf16, OBJ_G16_BK_WIDE, 4, 2, true, true>(g, blockIdx.x, blockIdx.y, blockIdx.z - gr.zbeg[i]);
+}
+#else
 __global__ __launch_bounds__(256) void gemm_group16_kernel(const GemmGroup gr) {
   if ((int)blockIdx.z >= gr.zbeg[gr.count]) return;      // (tasks ride on the fp32 grouped launch only)
   int i = 0;
@@ -690,6 +704,7 @@ __global__ __launch_bounds__(256) void gemm_group16_kernel(const GemmGroup gr) {
   if ((int)blockIdx.x * 64 >= g.N || (int)blockIdx.y * 64 >= g.M) return;
   gemm_bf16_body<2, 2, __bf16, OBJ_G16_BK, 2, 2, true, true>(g, blockIdx.x, blockIdx.y, blockIdx.z - gr.zbeg[i]);
 }
+#endif
 
 // B (generic strides, fp32) -> the AFULL kernel's operand image: thread (ks, jt, lane) writes the 8 values
 // B[32 ks + 8 (lane >> 4) + e][16 jt + (lane & 15)], e = 0..7, rounded to OT; zero beyond Kd / N.
@@ -1591,7 +1606,9 @@ static void flush_group(GemmEnv& E, hipStream_t st, GemmGroup& gr) {
     mx = std::max(mx, (gr.g[i].N + 63) / 64);
     my = std::max(my, (gr.g[i].M + 63) / 64);
   }
-  if (E.group16) hipLaunchKernelGGL(gemm_group16_kernel, dim3(mx, my, gr.zbeg[gr.count]), dim3(256), 0, st, gr);
+  if (E.group16 && OBJ_GROUP16_WIDE)
+    hipLaunchKernelGGL(gemm_group16_kernel, dim3((mx + 1) / 2, (my + 1) / 2, gr.zbeg[gr.count]), dim3(OBJ_GROUP16_WIDE ? 512 : 256), 0, st, gr);
+  else if (E.group16) hipLaunchKernelGGL(gemm_group16_kernel, dim3(mx, my, gr.zbeg[gr.count]), dim3(256), 0, st, gr);
   else hipLaunchKernelGGL(gemm_group_kernel, dim3((mx + 1) / 2, (my + 1) / 2, gr.zbeg[gr.count] + gr.task.blocks), dim3(512), 0, st, gr);
   gr.count = 0;
   gr.task.blocks = 0;

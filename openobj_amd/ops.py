@@ -430,6 +430,9 @@ class TrainWorkspace:
         if (arena.net.hidden != 32 or S > 64 or layerwise) and nbytes > budget and K > 1:
             per_obj = lib().objnerf_train_workspace_bytes(C.byref(net), 1, R, S, wf)
             self.k_chunk = max(1, min(K, int(budget // max(1, per_obj))))
+            # (measured, round 6: EQUAL chunks -- 8 x 8 objects instead of 7 x 9 + 1 for configs[4]'s 64 -- are slower, 191.6
+            # against 187.4 ms per step: the fused hidden-256 kernels gain more from a ninth object per launch than the
+            # one-object tail costs)
             nbytes = lib().objnerf_train_workspace_bytes(C.byref(net), self.k_chunk, R, S, wf)
         if nbytes == 0:
             raise _lib.ObjnerfError("objnerf_train_workspace_bytes returned 0")
