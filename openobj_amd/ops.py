@@ -372,7 +372,8 @@ def step_batch_loss(alpha, color, gt_depth, gt_rgb, labels, z, color_scaling=5.0
                 counts=counts)
 
 
-LAYERWISE_WORKSPACE_BUDGET = 64 << 30      # bytes; the layer-wise path materialises activations per object chunk
+# bytes; the layer-wise / hidden-256 paths materialise activations per object chunk (OBJNERF_WORKSPACE_BUDGET_GIB: override)
+LAYERWISE_WORKSPACE_BUDGET = int(float(os.environ.get("OBJNERF_WORKSPACE_BUDGET_GIB", "64")) * (1 << 30))
 
 
 def precision_bits(p) -> int:
