@@ -29,7 +29,8 @@ def _batch(K, R, n1, n2, seed, dev, feat=False, empty_obj=None):
     return {k: T(b[k]).to(dev) for k in KEYS + (["gt_feat"] if feat else [])}
 
 
-@pytest.mark.parametrize("case", ["obj32", "obj32_bf16", "obj32_feat", "bg128", "bg128_bf16", "bg128_feat", "bg128_k3"])
+@pytest.mark.parametrize("case", ["obj32", "obj32_bf16", "obj32_feat", "obj32_bf16_feat", "bg128", "bg128_bf16", "bg128_feat",
+                                  "bg128_k3", "bg128_k3_feat", "bg128_bf16_feat"])
 def test_optimiser_inside_the_step_equals_the_separate_launch(dev, case):
     """objnerf_train_step(optim=) -- AdamW applied by the launch that reduces the partial gradients (finalize_kernel for
     the fused hidden-32 kernels, reduce_parts_kernel for the one-launch hidden-128 iteration, a trailing launch
@@ -37,9 +38,9 @@ def test_optimiser_inside_the_step_equals_the_separate_launch(dev, case):
     objnerf_train_step followed by objnerf_adamw_step_flags, over four iterations of which the second hits the
     cross-object early return (groups skipped like .grad = None)."""
     H = 32 if case.startswith("obj") else 128
-    K = 3 if case in ("obj32", "obj32_bf16", "obj32_feat", "bg128_k3") else 1
-    feat = case.endswith("feat")
-    bf16 = case.endswith("bf16")
+    K = 3 if (case.startswith("obj") or "k3" in case) else 1
+    feat = "feat" in case
+    bf16 = "bf16" in case
     R, n1, n2 = (96, 16, 48) if H == 32 else (150, 5, 9)
     runs = []
     for fused in (False, True):
@@ -160,3 +161,49 @@ def test_pipelined_iteration_equals_the_joined_one(dev):
     a, b = run(False), run(True)
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("C", [512, 64, 40])
+@pytest.mark.parametrize("with_opt", [False, True])
+def test_feature_step_at_other_feature_widths(dev, C, with_opt):
+    """The feature-loss step of the fused hidden-32 kernels at clip_point_feature_size = 512 (round 6's route: Gram matrix,
+    label counts and the [W_of | b_of] copy inside feat_pre_kernel, the head's finish inside finalize_kernel), 64 (feat_pre_kernel
+    + the two split-K GEMMs + feat_finish_kernel: the route for C != 512) and 40 (not a multiple of 16: batched GEMM +
+    feat_rowstats_kernel ahead of the fused kernel) against the oracle -- the reference's op sequence -- on the same batch: the
+    loss terms and all 19 gradients; with an optimiser attached, AdamW inside the step equals the separate launch bit for bit.
+    (No fixture has a feature width other than 512; cfg.clip_point_feature_size is a reference option, cfg.py.)"""
+    from oracle import objnerf_oracle as O
+    K, R, n1, n2 = 2, 40, 8, 24
+    st = obj_init.init_stacked(K, 32, C, seed=11)
+    b = synthetic.random_batch(K, R, n1, n2, seed=91, feat_dim=C)
+    batch = {k: T(b[k]).to(dev) for k in KEYS + ["gt_feat"]}
+    arena = ops.ParamArena(K, ops.NetShape(32, C, 6), dev)
+    arena.load_stacked([q.clone() for q in st])
+    ws = ops.TrainWorkspace(arena, K, R, n1 + n2, True)
+    opt = optim.ArenaAdamW(arena, lr=1e-3, weight_decay=0.013) if with_opt else None
+    ops.train_step(arena, ws, batch, with_feat=True, optim=opt)
+    torch.cuda.synchronize()
+    assert int(ws.status.item()) == 0
+    fcr = [p.clone().requires_grad_(True) for p in st[:18]]
+    Br = st[18].clone().requires_grad_(True)
+    loss, terms = O.train_forward_loss(fcr, Br, torch.full((K,), 2.0), *[T(b[k]) for k in ["pts", "gt_depth", "gt_rgb", "labels", "z"]],
+                                       gt_feat=T(b["gt_feat"]), return_terms=True)
+    grads = torch.autograd.grad(loss, fcr + [Br])
+    t = ws.loss_terms.cpu()
+    total = (t[:, 0] + 5 * t[:, 1] + 10 * t[:, 2] + 5 * t[:, 3]).sum().item()
+    assert abs(total - loss.item()) < 1e-4 * abs(loss.item()), (total, loss.item())
+    gv = arena.views(ws.grads)
+    for i, gr in enumerate(grads):
+        err = (gv[i].cpu() - gr).abs().max().item()
+        assert err < 2e-4 * max(1e-3, gr.abs().max().item()), (C, i, ops.TENSOR_NAMES[i], err)
+    if with_opt:            # the same step with the optimiser as a separate launch: parameters and moments bit-equal
+        arena2 = ops.ParamArena(K, ops.NetShape(32, C, 6), dev)
+        arena2.load_stacked([q.clone() for q in st])
+        ws2 = ops.TrainWorkspace(arena2, K, R, n1 + n2, True)
+        opt2 = optim.ArenaAdamW(arena2, lr=1e-3, weight_decay=0.013)
+        ops.train_step(arena2, ws2, batch, with_feat=True)
+        opt2.step(ws2.grads, arena2.has_grad_mask(True), flags=ws2.flags)
+        torch.cuda.synchronize()
+        assert torch.equal(ws.grads, ws2.grads)
+        assert torch.equal(arena.params, arena2.params) and torch.equal(opt.exp_avg, opt2.exp_avg)
+        assert torch.equal(opt.exp_avg_sq, opt2.exp_avg_sq)
