@@ -153,10 +153,27 @@ __device__ __forceinline__ void mma_f32(T32& acc, const float* wf, const int row
 // acc(16 inputs: image rows row0 .. row0 + 15) += W[:, those inputs]^T * d    (d: 32 outputs)
 // wt0 = lds + c * WROW + 8 g + 4 (g & 1), wt1 = lds + c * WROW + 8 g + 4 (1 - (g & 1)): after the rotation of out_pos
 // both lane-group parities find the pairs r = 0, 1 at wt0 and r = 2, 3 at wt1
+template <bool ONE_CHAIN = false>
 __device__ __forceinline__ void mma_t16(f32x4& acc, const float* wt0, const float* wt1, const int row0, const T32& d) {
   if ((OBJ32_ABL) & 64) { asm volatile("" :: "v"(d.t[0]), "v"(d.t[1])); return; }
   const f32x4 lo = *reinterpret_cast<const f32x4*>(wt0 + row0 * WROW);    // (r0 t0, r0 t1, r1 t0, r1 t1)
   const f32x4 hi = *reinterpret_cast<const f32x4*>(wt1 + row0 * WROW);    // (r2 t0, r2 t1, r3 t0, r3 t1)
+  // ONE_CHAIN (round 6; the headline instantiation of train_fused32_kernel): one dependent chain of eight MFMAs instead of
+  // two chains of four and a join (4 zero moves + 4 adds per call, 23 calls per tile).  A dependent
+  // v_mfma_f32_16x16x4_f32 issues every 34 cycles instead of 32, which the other wave of the SIMD absorbs, while the eight
+  // vector instructions of the join overlap with nothing (section 4.1).  With the weight-gradient loops fully unrolled:
+  // 8.90 -> 8.82 ms.  NOT for the feature instantiation: there the longer live ranges spill (12.0 -> 19.7 ms).
+  if (ONE_CHAIN) {
+  acc = OBJ_MFMA(lo[0], d.t[0][0], acc);
+  acc = OBJ_MFMA(lo[1], d.t[1][0], acc);
+  acc = OBJ_MFMA(lo[2], d.t[0][1], acc);
+  acc = OBJ_MFMA(lo[3], d.t[1][1], acc);
+  acc = OBJ_MFMA(hi[0], d.t[0][2], acc);
+  acc = OBJ_MFMA(hi[1], d.t[1][2], acc);
+  acc = OBJ_MFMA(hi[2], d.t[0][3], acc);
+  acc = OBJ_MFMA(hi[3], d.t[1][3], acc);
+  return;
+  }
   f32x4 acc2 = zero4();
   acc = OBJ_MFMA(lo[0], d.t[0][0], acc);
   acc2 = OBJ_MFMA(lo[1], d.t[1][0], acc2);
@@ -168,9 +185,10 @@ __device__ __forceinline__ void mma_t16(f32x4& acc, const float* wt0, const floa
   acc2 = OBJ_MFMA(hi[3], d.t[1][3], acc2);
   acc += acc2;
 }
+template <bool ONE_CHAIN = false>
 __device__ __forceinline__ void mma_t32(T32& acc, const float* wt0, const float* wt1, const int row0, const T32& d) {
-  mma_t16(acc.t[0], wt0, wt1, row0, d);
-  mma_t16(acc.t[1], wt0, wt1, row0 + 16, d);
+  mma_t16<ONE_CHAIN>(acc.t[0], wt0, wt1, row0, d);
+  mma_t16<ONE_CHAIN>(acc.t[1], wt0, wt1, row0 + 16, d);
 }
 
 // ----------------------------------------------------------------------------------------------------------------
