@@ -17,6 +17,37 @@ def load_matrix_from_txt(path, shape=(4, 4)):
     return np.array([float(v) for v in txt.split()]).reshape(shape)
 
 
+# The schema as DATA: attribute -> (section, key[, conversion]).  Attribute names and JSON keys are the reference's
+# (cfg.py:16-114: they are the interface the rest of objnerf/ reads); a missing key raises KeyError exactly as the
+# reference's chain of subscripts does.  Derived attributes follow in Config.__init__.
+_PLAIN = {
+    # trainer / dataset                                                        cfg.py:16-31
+    "start": ("trainer", "start"), "stride": ("trainer", "stride"), "do_bg": ("trainer", "do_bg", bool),
+    "training_device": ("trainer", "train_device"), "data_device": ("trainer", "data_device"),
+    "max_n_models": ("trainer", "n_models"), "imap_mode": ("trainer", "imap_mode"),
+    "training_strategy": ("trainer", "training_strategy"),          # "forloop" "vmap" "hip"
+    "live_mode": ("dataset", "live", bool), "keep_live_time": ("dataset", "keep_alive"),
+    "dataset_format": ("dataset", "format"), "dataset_dir": ("dataset", "path"),
+    # camera frame                                                             cfg.py:35-38
+    "mh": ("camera", "mh"), "mw": ("camera", "mw"), "height": ("camera", "h"), "width": ("camera", "w"),
+    # model / render                                                           cfg.py:75-95
+    "win_size": ("model", "window_size"), "win_size_bg": ("model", "window_size_bg"),
+    "keyframe_buffer_size": ("model", "keyframe_buffer_size"),
+    "obj_scale": ("model", "obj_scale"), "bg_scale": ("model", "bg_scale"),
+    "hidden_feature_size": ("model", "hidden_feature_size"), "hidden_feature_size_bg": ("model", "hidden_feature_size_bg"),
+    "clip_point_feature_size": ("model", "clip_point_feature_size"), "n_unidir_funcs": ("model", "n_unidir_funcs"),
+    "surface_eps": ("model", "surface_eps"), "stop_eps": ("model", "other_eps"),
+    "n_iter_per_frame": ("render", "iters_per_frame"), "n_per_optim": ("render", "n_per_optim"),
+    "n_per_optim_bg": ("render", "n_per_optim_bg"), "n_bins_cam2surface": ("render", "n_bins_cam2surface"),
+    "n_bins_cam2surface_bg": ("render", "n_bins_cam2surface_bg"), "n_bins": ("render", "n_bins"),
+    # visualisation                                                            cfg.py:102-114
+    **{name: ("vis", name, bool) for name in ("if_vis", "if_ckpt", "if_render", "if_obj", "save_pcd", "save_mesh")},
+    **{name: ("vis", name) for name in ("vis_device", "bg_id", "n_vis_iter", "eps_fine_vis", "n_bins_fine_vis",
+                                         "live_voxel_size", "grid_dim")},
+}
+_DISTORTION_KEYS = ("k1", "k2", "p1", "p2", "k3", "k4", "k5", "k6")
+
+
 class Config:
     def __init__(self, config_file):
         if isinstance(config_file, dict):
@@ -24,100 +55,42 @@ class Config:
         else:
             with open(config_file) as json_file:
                 config = json.load(json_file)
-
-        # training strategy                                                    cfg.py:16-26
-        self.start = config["trainer"]["start"]
-        self.stride = config["trainer"]["stride"]
-        self.do_bg = bool(config["trainer"]["do_bg"])
-        self.training_device = config["trainer"]["train_device"]
-        self.data_device = config["trainer"]["data_device"]
-        self.max_n_models = config["trainer"]["n_models"]
-        self.live_mode = bool(config["dataset"]["live"])
-        self.keep_live_time = config["dataset"]["keep_alive"]
-        self.imap_mode = config["trainer"]["imap_mode"]
-        self.training_strategy = config["trainer"]["training_strategy"]  # "forloop" "vmap" "hip"
+        for attr, (section, key, *conv) in _PLAIN.items():
+            value = config[section][key]
+            setattr(self, attr, conv[0](value) if conv else value)
         self.obj_id = -1
-
-        # dataset setting                                                      cfg.py:29-31
-        self.dataset_format = config["dataset"]["format"]
-        self.dataset_dir = config["dataset"]["path"]
         self.depth_scale = 1 / config["trainer"]["scale"]
-        # camera setting                                                       cfg.py:33-66
-        self.max_depth = config["render"]["depth_range"][1]
-        self.min_depth = config["render"]["depth_range"][0]
-        self.mh = config["camera"]["mh"]
-        self.mw = config["camera"]["mw"]
-        self.height = config["camera"]["h"]
-        self.width = config["camera"]["w"]
-        self.H = self.height - 2 * self.mh
-        self.W = self.width - 2 * self.mw
-        if "fx" in config["camera"]:
-            self.fx = config["camera"]["fx"]
-            self.fy = config["camera"]["fy"]
-            self.cx = config["camera"]["cx"] - self.mw
-            self.cy = config["camera"]["cy"] - self.mh
-        else:   # ScanNet: intrinsics from file (cfg.py:46-51)
-            intrinsic = load_matrix_from_txt(os.path.join(self.dataset_dir, "intrinsic/intrinsic_depth.txt"))
-            self.fx = intrinsic[0, 0]
-            self.fy = intrinsic[1, 1]
-            self.cx = intrinsic[0, 2] - self.mw
-            self.cy = intrinsic[1, 2] - self.mh
-        if "distortion" in config["camera"]:
-            self.distortion_array = np.array(config["camera"]["distortion"])
-        elif "k1" in config["camera"]:
-            c = config["camera"]
-            self.distortion_array = np.array([c["k1"], c["k2"], c["p1"], c["p2"], c["k3"], c["k4"], c["k5"], c["k6"]])
+        self.min_depth, self.max_depth = config["render"]["depth_range"][0], config["render"]["depth_range"][1]
+        opt = config["optimizer"]["args"]                                   # cfg.py:98-99
+        self.learning_rate, self.weight_decay = opt["lr"], opt["weight_decay"]
+
+        # camera (cfg.py:33-66): the image is cropped by the margins; intrinsics from the JSON or, ScanNet, from the dataset
+        cam = config["camera"]
+        self.H, self.W = self.height - 2 * self.mh, self.width - 2 * self.mw
+        if "fx" in cam:
+            fx, fy, cx, cy = cam["fx"], cam["fy"], cam["cx"], cam["cy"]
+        else:
+            K = load_matrix_from_txt(os.path.join(self.dataset_dir, "intrinsic/intrinsic_depth.txt"))
+            fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+        self.fx, self.fy, self.cx, self.cy = fx, fy, cx - self.mw, cy - self.mh
+        if "distortion" in cam:
+            self.distortion_array = np.array(cam["distortion"])
+        elif "k1" in cam:
+            self.distortion_array = np.array([cam[k] for k in _DISTORTION_KEYS])
         else:
             self.distortion_array = None
 
-        # part-level understanding                                             cfg.py:69-72
+        # part-level understanding (cfg.py:69-72): part_down exists only when the key is present
         self.part_mode = False
         if "part_mode" in config["trainer"]:
             self.part_mode = bool(config["trainer"]["part_mode"])
             self.part_down = config["trainer"]["part_down"]
 
-        # training setting                                                     cfg.py:75-95
-        self.win_size = config["model"]["window_size"]
-        self.n_iter_per_frame = config["render"]["iters_per_frame"]
-        self.n_per_optim = config["render"]["n_per_optim"]
+        # derived (cfg.py:78-86)
         self.n_samples_per_frame = self.n_per_optim // self.win_size
-        self.win_size_bg = config["model"]["window_size_bg"]
-        self.n_per_optim_bg = config["render"]["n_per_optim_bg"]
         self.n_samples_per_frame_bg = self.n_per_optim_bg // self.win_size_bg
-        self.keyframe_buffer_size = config["model"]["keyframe_buffer_size"]
         self.keyframe_step = config["model"]["keyframe_step"] / self.stride
         self.keyframe_step_bg = config["model"]["keyframe_step_bg"] / self.stride
-        self.obj_scale = config["model"]["obj_scale"]
-        self.bg_scale = config["model"]["bg_scale"]
-        self.hidden_feature_size = config["model"]["hidden_feature_size"]
-        self.hidden_feature_size_bg = config["model"]["hidden_feature_size_bg"]
-        self.clip_point_feature_size = config["model"]["clip_point_feature_size"]
-        self.n_bins_cam2surface = config["render"]["n_bins_cam2surface"]
-        self.n_bins_cam2surface_bg = config["render"]["n_bins_cam2surface_bg"]
-        self.n_bins = config["render"]["n_bins"]
-        self.n_unidir_funcs = config["model"]["n_unidir_funcs"]
-        self.surface_eps = config["model"]["surface_eps"]
-        self.stop_eps = config["model"]["other_eps"]
-
-        # optimizer setting                                                    cfg.py:98-99
-        self.learning_rate = config["optimizer"]["args"]["lr"]
-        self.weight_decay = config["optimizer"]["args"]["weight_decay"]
-
-        # vis setting                                                          cfg.py:102-114
-        v = config["vis"]
-        self.if_vis = bool(v["if_vis"])
-        self.if_ckpt = bool(v["if_ckpt"])
-        self.if_render = bool(v["if_render"])
-        self.if_obj = bool(v["if_obj"])
-        self.save_pcd = bool(v["save_pcd"])
-        self.save_mesh = bool(v["save_mesh"])
-        self.vis_device = v["vis_device"]
-        self.bg_id = v["bg_id"]
-        self.n_vis_iter = v["n_vis_iter"]
-        self.eps_fine_vis = v["eps_fine_vis"]
-        self.n_bins_fine_vis = v["n_bins_fine_vis"]
-        self.live_voxel_size = v["live_voxel_size"]
-        self.grid_dim = v["grid_dim"]
 
 
 def replica_room0_config(train_device="cuda:0", strategy="hip", **overrides):
