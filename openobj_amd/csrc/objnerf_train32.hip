@@ -181,7 +181,7 @@ __global__ __launch_bounds__(NTHR) void train_fused32_kernel(const TrainDev a) {
   // without the feature loss: one-chain input gradients (objnerf_mlp32.h, mma_t16) in EVERY instantiation -- the test-hook
   // and any-S builds must round like the headline one (test_headline_config_full_size_vs_anchor_and_additivity holds the
   // hook launch bit-equal to the production launch); the headline instantiation also unrolls its weight-gradient loops fully
-  constexpr bool FAST = !FEAT;
+  constexpr bool FAST = !FEAT;            // (measured in the feature instantiation too: 12.06 against 12.0 - 12.2 ms, no gain)
   constexpr int WGU = (!FEAT && !MASKS && SS == 64) ? OBJ32_WG_UNROLL_FAST : 8;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
