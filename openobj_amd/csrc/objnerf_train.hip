@@ -834,7 +834,7 @@ struct FinalizeArgs {
 // Round 6: FIN_EPT elements per thread (their slab loads are independent: FIN_EPT x G requests in flight instead of a
 // chain of G latencies per thread), so an object is ~30 workgroups instead of 120 and the whole grid is resident at once
 // -- the double-precision pow() preamble of the optimiser (a few microseconds of one thread, ahead of the block's
-// barrier) is paid ONCE, in parallel, instead of once per round of the chip (118 -> ~35 us at 50 objects).
+// barrier) is paid ONCE, in parallel, instead of once per round of the chip (118 -> 53 us at 50 objects, 79 beside the background chain).
 constexpr int FIN_EPT = 4;
 __global__ __launch_bounds__(256) void finalize_kernel(const FinalizeArgs a) {
   const int k = blockIdx.y;
