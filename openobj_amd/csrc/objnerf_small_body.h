@@ -26,7 +26,9 @@
 // background network -- counted by every workgroup from the R label bytes (1.2 KB) and published by workgroup 0.
 #ifndef SM_ABL
 #define SM_ABL 0      // diagnostic builds (tools/small_ablation.sh): bit 0 no HBM activation stores, 1 no sin / cos, 2 no
-#endif                // MFMAs, 3 no heads / compositing, 4 no weight staging, 5 no PE backward -- results are then wrong
+#endif                // MFMAs, 3 no heads / compositing, 4 no weight staging, 5 no PE backward, 6 no weight LOADS (the LDS
+                      // images are still written, from registers that were never filled), 7 no LDS image WRITES (the loads
+                      // are still issued and waited for) -- results are then wrong
 struct SmallFused {
   int K, R, S, rpw;                       // rpw: rays per workgroup (rpw * S <= 16 RT rows)
   const float* params; long ps; const float* scale;
@@ -134,8 +136,13 @@ __global__ __launch_bounds__(512) void train_small_kernel(const SmallFused a) {
   const float* Bp = P + a.o_B;
 
   float wr[32];
+  if (SM_ABL & 64) {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) wr[i] = 0.f;
+  }
   auto fetch_w = [&](const float* W, int ld, const int KC) {
     if (SM_ABL & 16) return;
+    if (SM_ABL & 64) return;
     // (the row offsets are re-formed per call from an OPAQUE stride: left visible, the compiler hoists the 32 offsets of
     // every distinct stride to the top of the kernel and keeps ~100 registers of addresses alive -- 80+ spills)
     asm volatile("" : "+s"(ld));
@@ -146,12 +153,22 @@ __global__ __launch_bounds__(512) void train_small_kernel(const SmallFused a) {
   };
   auto put_wf = [&]() {                   // forward image
     if (SM_ABL & 16) return;
+    if (SM_ABL & 128) {
+#pragma unroll
+      for (int i = 0; i < 32; ++i) asm volatile("" :: "v"(wr[i]));
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 32; ++i) Wb[(rg + 4 * i) * PT + kk] = wr[i];
   };
   constexpr int PW16 = 288;
   auto put_wb = [&]() {                   // backward image (bf16 mode: rounded rows, 288-byte pitch)
     if (SM_ABL & 16) return;
+    if (SM_ABL & 128) {
+#pragma unroll
+      for (int i = 0; i < 32; ++i) asm volatile("" :: "v"(wr[i]));
+      return;
+    }
     if (BF) {
       __bf16* W16 = reinterpret_cast<__bf16*>(Wb);
 #pragma unroll
