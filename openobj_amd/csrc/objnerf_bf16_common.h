@@ -15,7 +15,16 @@ namespace objtrain {
 namespace bf16k {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// V2_ABL (ceiling builds of the second-generation bf16 kernels only, tools/bf16_ablation.sh; the Makefile's value is 0):
+//   1 no compositing   2 no tile-loop barriers   8 no weight-gradient MFMAs   64 no MFMA at all   (+ -DOBJ32_ABL=16: no v_sin / v_cos)
+#ifndef V2_ABL
+#define V2_ABL 0
+#endif
+#if (V2_ABL) & 64
+#define MFMA_BF16(a, b, c) (c)
+#else
 #define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+#endif
 
 // forward images (byte offsets), 32 rows each
 constexpr int RS_IN = 224, RS_M = 96, RS_CAT = 288, RS_CL = 224;

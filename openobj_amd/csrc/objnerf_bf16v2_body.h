@@ -447,6 +447,7 @@ __global__ __launch_bounds__(NTHR) void V2_KERNEL(const TrainDev a) {
   // supplies row q, 8-byte chunk p of a transposing read)
   int lane_l = lane;
 #define RELAUNDER() asm volatile("" : "+v"(lane_l))
+#define V2_TILE_SYNC() do { if (!((V2_ABL) & 2)) __syncthreads(); } while (0)
 #define c (lane_l & 15)
 #define g (lane_l >> 4)
 #define q4 ((lane_l >> 2) & 3)
@@ -661,14 +662,14 @@ __global__ __launch_bounds__(NTHR) void V2_KERNEL(const TrainDev a) {
     }
 #endif
     PT(1);
-    __syncthreads();
+    V2_TILE_SYNC();
     RELAUNDER();
     PT(2);
     // ---------------------------------------------------------------- 2. waves 0-1: composite + loss of tile t's rays
     //                                                                     (render_rays.py:6-63, loss.py:5-103; fp32);
     //                                                                     waves 2-7: weight gradients of tile t - 1
 #if !V2_FEAT
-    if (w < TR) {
+    if (w < TR && !((V2_ABL) & 1)) {
       const int pos = lane;
       const int sl = w * S + pos;
       const bool on = ray0 + w < R;
@@ -715,7 +716,7 @@ __global__ __launch_bounds__(NTHR) void V2_KERNEL(const TrainDev a) {
         s_col[2 * TS + sl] = gC2 * wgt * c2 * (1.0f - c2);
       }
     }
-#ifdef V2_NO_WGRAD
+#if defined(V2_NO_WGRAD) || ((V2_ABL) & 8)
     if (have_prev && a.K < 0) {
 #else
     if (have_prev) {         // (the compositing waves take two of the 28 tile pairs each, the other six four)
@@ -801,7 +802,7 @@ __global__ __launch_bounds__(NTHR) void V2_KERNEL(const TrainDev a) {
       bbv = Gg[32 * 32 + 32];
     }
     PT(3);
-    __syncthreads();
+    V2_TILE_SYNC();
     RELAUNDER();
     PT(9);
     {
@@ -812,7 +813,7 @@ __global__ __launch_bounds__(NTHR) void V2_KERNEL(const TrainDev a) {
       const float psum = slot_sums8(v8, c);            // lane c & 7 <-> element e: the sum over the wave's 16 samples
       if (c < 8) s_part[w * 32 + 16 * ((c & 7) >> 2) + 4 * g + (c & 3)] = psum;
     }
-    __syncthreads();
+    V2_TILE_SYNC();
     RELAUNDER();
     PT(10);
     {
@@ -863,7 +864,7 @@ __global__ __launch_bounds__(NTHR) void V2_KERNEL(const TrainDev a) {
       const float dwf = xgroup_sum(dp) + gof;
       if (g == 0 && valid) s_dwf[slot] = dwf;
     }
-    __syncthreads();
+    V2_TILE_SYNC();
     RELAUNDER();
     PT(11);
     if (w < TR) {
@@ -892,7 +893,7 @@ __global__ __launch_bounds__(NTHR) void V2_KERNEL(const TrainDev a) {
     }
     PT(12);
 #endif
-    __syncthreads();
+    V2_TILE_SYNC();
     RELAUNDER();
     PT(4);
     // ---------------------------------------------------------------- 3. backward; writes tile t's staging image
