@@ -295,8 +295,10 @@ int objnerf_feature_head(const objnerf_net* net, int32_t K, int64_t n, const flo
  *   labels [K][R] u8 (0 other / 1 this / 2 unknown), optional pred_feat [K][R][S][C] + gt_feat
  *   [K][R][C].  Scalings as loss.py:6.
  * Outputs: loss_terms [K][4] = per-object (depth, colour, opacity, feature) means, total [1],
- *   optional d_alpha / d_color / d_pred_feat (gradients of `total`), status [1] int32 != 0 when a
- *   per-object term exceeds 1e5 (render_rays.py:109-111 "loss explode").
+ *   optional d_alpha / d_color / d_pred_feat (gradients of `total`), status [1] int32: bit 0 when a
+ *   per-object term exceeds 1e5 (render_rays.py:109-111 "loss explode": the reference exits), bit 1 when a term is
+ *   not finite (the reference's `> 100000` test is False for NaN and it carries on).  The same word, with the same
+ *   two bits, is written by every entry point that has a `status` argument.
  * The cross-object early return (render_rays.py:89-94) is applied: if ANY object has no label-1
  * ray the depth / colour / feature terms are zero for ALL objects, likewise label!=2 for opacity.
  * counts: int32 workspace of 2*K + 2 entries; receives [K][2] = (n_label1, n_label_not2) and the two
@@ -331,7 +333,9 @@ int objnerf_label_counts(int32_t K, int32_t R, const uint8_t* labels, int32_t* c
  * counts [K][2] + flags [2]: from objnerf_label_counts (flags may have been max-reduced across
  * GPUs first -- the early return spans every object of the batch).
  * Outputs: grads [K][P_stride] (same layout as params; entries of tensors without gradient are
- * left untouched), loss_terms [K][4], status [1].
+ * left untouched), loss_terms [K][4], status [1] (bits as objnerf_step_batch_loss: 0 = a term above 1e5, 1 = a term
+ * that is not finite; every path of this entry point -- fused hidden 32, one-launch hidden 128, layer-wise, fused
+ * hidden 256 -- writes both).
  * workspace: objnerf_train_workspace_bytes() bytes, 256-byte aligned (its with_feat argument: bit 0 = feature
  * loss, bit 1 = size for OBJNERF_TRAIN_LAYERWISE, bit 2 = size for the 16-bit modes only -- at hidden 256 they keep
  * the five activation and five gradient buffers in the operand type, a third less; a workspace sized without bit 2 serves every mode).
@@ -445,7 +449,8 @@ int objnerf_render_loss(int64_t n, int32_t C, int32_t mode, int32_t normalise, c
                         float* out, void* stream);
 /* render_rays.reduce_batch_loss (render_rays.py:85-117): loss_mat [K][R], var [K][R] or NULL (information weight
  * 1 / (sqrt(var) + 1e-4), or 1 / (var + 1e-4) with l2), mask [K][R] u8.  avg: out [K] = masked means, all zero when
- * ANY object's mask is empty (:89-94); status bit 0 set when a mean exceeds 1e5 (:109-111, the reference exits).
+ * ANY object's mask is empty (:89-94); status bit 0 set when a mean exceeds 1e5 (:109-111, the reference exits), bit 1
+ * when a mean is not finite.
  * avg == 0: out [K][R] = the weighted matrix.  counts_ws: K + 1 ints of scratch. */
 int objnerf_reduce_batch_loss(int32_t K, int32_t R, const float* loss_mat, const float* var, const uint8_t* mask,
                               int32_t l2, int32_t avg, int32_t* counts_ws, float* out, int32_t* status, void* stream);
