@@ -29,11 +29,14 @@ dtype: the headline line is fp32 -- the reference's arithmetic (train.py:74, AMP
 master weights, compositing and AdamW; PSNR-gated) is timed in the same run and reported as the `bf16_mode` object
 (or as the headline with --dtype bf16).
 
-Prints ONE JSON line (rank 0): `roofline` = the dominant kernel against the dense MFMA peak of its operand type (spec
-and measured), `cpu_baseline` = the oracle (the reference's op sequence in PyTorch on the host cores) at BASELINE.md
-section 3's shapes, `psnr` = the reconstruction quality of the same kernels on the G9 scene against the reference's
-ensemble, `other_configs` = the other BASELINE configurations (c3, configs[3]'s per-GPU share, configs[4]'s per-GPU
-share in fp16) timed by the same run.
+Prints ONE short JSON line (rank 0; < 4 KB, asserted: the driver parses it): the contract's keys, `roofline` = the dominant
+launch against the dense MFMA peak of its operand type (spec and measured; `traffic` = the RECORDED PMC bytes of the same
+launch, profiles/r06_counters.json), `cpu_baseline` = the oracle (the reference's op sequence in PyTorch on the host cores) at
+BASELINE.md section 3's metric shape, the PSNR delta of the trained model, a flat `summary` (the other BASELINE configurations'
+rays/s and ms per step, the native-shape frame) and `detail` = the path of the FULL report (--detail-out, default
+gpurun_out/bench_detail.json): `other_configs` (c3, configs[3]'s per-GPU share, configs[4]'s per-GPU share in fp16 without /
+with the feature loss, the mapping loop at the native shape), the `psnr` block, the per-shape CPU rows, `bf16_mode`.  A
+distributed run adds `dist_selftest` = the iteration's two collectives timed on their own.
 """
 import argparse
 import json
